@@ -1,0 +1,121 @@
+"""ctypes binding of the gfx950 C-ABI library (include/lvae.h).
+
+The product path is `load()`: it opens csrc/liblvae_hip.so (building it with hipcc when the file is
+missing) and raises if that is impossible -- there is NO CPU fallback.  `bind()` only attaches argtypes
+to an already opened CDLL; the GPU-less CI uses it on the emulator build under tests/emu/ to check the
+same kernel sources (tests only; nothing in this package opens that library).
+"""
+import ctypes
+import os
+import threading
+
+from . import build as _build
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+_u64 = ctypes.c_uint64
+
+# name -> argtypes (all functions return int status: 0 ok, >0 hipError_t, <0 argument check)
+SIGNATURES = {
+    "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp],
+    "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
+    "lv_lstm_bwd_ksplit": [_i],
+    "lv_lstm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
+    "lv_lstm_bwd_f32": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_embed_gather_f32": [_vp, _vp, _l, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "lv_token_sort": [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "lv_embed_scatter_f32": [_vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "lv_reparam_kl_fwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_reparam_kl_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_softmax_nll_fwd_f32": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp],
+    "lv_softmax_nll_bwd_f32": [_vp, _l, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp],
+    "lv_vae_loss_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lv_loss_bwd_scales_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "lv_tanh_f32": [_vp, _vp, _l, _vp],
+    "lv_colsum_f32": [_vp, _l, _i, _i, _vp, _vp, _vp],
+    "lv_add_f32": [_vp, _vp, _vp, _l, _vp],
+    "lv_sumsq_workspace_floats": [],
+    "lv_sumsq_f32": [_vp, _l, _vp, _vp, _i, _vp],
+    "lv_clip_coef_f32": [_vp, _f, _vp, _vp, _vp],
+    "lv_sgd_step_f32": [_vp, _vp, _l, _vp, _vp, _i, _vp],
+    "lv_scale_f32": [_vp, _l, _vp, _vp],
+    "lv_adam_step_f32": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _f, _i, _vp],
+    "lv_add_scalar_f32": [_vp, _f, _vp],
+    "lv_rng_normal_f32": [_vp, _l, _vp, _u64, _vp],
+    "lv_rng_keepmask_u8": [_vp, _l, _f, _vp, _u64, _vp],
+    "lv_rng_advance": [_vp, _u64, _vp],
+}
+
+
+class LvaeError(RuntimeError):
+    pass
+
+
+class Lib(object):
+    """Thin checked wrapper: lib.lv_xxx(*args) raises LvaeError on a non-zero status."""
+
+    def __init__(self, cdll, path):
+        self.cdll = cdll
+        self.path = path
+        missing = []
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(cdll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+            setattr(self, "_raw_" + name, fn)
+        if missing:
+            raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
+        # functions that return a value rather than a status
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats"}
+
+    def __getattr__(self, name):
+        if name.startswith("lv_"):
+            raw = object.__getattribute__(self, "_raw_" + name)
+            if name in object.__getattribute__(self, "_value_fns"):
+                return raw
+
+            def call(*args):
+                rc = raw(*args)
+                if rc != 0:
+                    raise LvaeError("%s failed with status %d (%s)" % (
+                        name, rc, "hipError_t" if rc > 0 else "argument check"))
+            call.__name__ = name
+            self.__dict__[name] = call
+            return call
+        raise AttributeError(name)
+
+
+def bind(cdll, path="<cdll>"):
+    return Lib(cdll, path)
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Open the gfx950 library; build it first if the .so is absent.  Never falls back to a CPU path."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            try:
+                _build.build_hip()
+            except Exception as e:  # noqa
+                raise LvaeError(
+                    "HIP extension %s is missing and could not be built (%s). The MI355X path has no CPU "
+                    "fallback: run `python -m vae_lagging_encoder_amd.build` where hipcc is available." % (path, e))
+        try:
+            cdll = ctypes.CDLL(path)
+        except OSError as e:
+            raise LvaeError("cannot load %s: %s" % (path, e))
+        _lib = Lib(cdll, path)
+        return _lib

@@ -1,0 +1,66 @@
+// lv_device.h -- device-side vocabulary shared by every kernel file (gfx950 / CDNA4, wave64).
+//
+// The product build is hipcc --offload-arch=gfx950.  The single LV_EMU switch below exists only so
+// that the GPU-less CI can compile the same kernel sources with g++ against tests/emu/hip_emu.h
+// (a thread-level emulator used by the `-m "not gpu"` tests); no kernel file contains an #ifdef.
+#pragma once
+
+#ifdef LV_EMU
+#include "hip_emu.h"
+#define LV_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    lv_emu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+#define LV_DYN_SHARED(name) char* name = lv_emu::dyn_smem()
+static inline f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) { return lv_emu_mfma_16x16x4(a, b, c); }
+static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu_mfma_32x32x2(a, b, c); }
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LV_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (shmem), (hipStream_t)(stream), __VA_ARGS__)
+#define LV_DYN_SHARED(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]
+__device__ __forceinline__ f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                          D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
+__device__ __forceinline__ f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+#include <stdint.h>
+
+#define LV_WAVE 64
+
+// ---- status codes returned through the C ABI (0 = ok, >0 = hipError_t, <0 = argument check) ----
+#define LV_OK 0
+#define LV_ERR_ARG (-1)
+#define LV_ERR_SHAPE (-2)
+#define LV_ERR_ALIGN (-3)
+#define LV_ERR_UNSUPPORTED (-4)
+
+#define LV_CHECK_LAUNCH()                        \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+__device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <class T>
+__device__ __forceinline__ T lv_wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float lv_wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ bool lv_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static inline int lv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,250 @@
+// lv_embed.hip -- embedding row gather (forward) and deterministic sorted-segment scatter-add (backward).
+//
+// Replaces nn.Embedding forward (modules/encoders/enc_lstm.py:58, modules/decoders/dec_lstm.py:80) fused with
+// the decoder's input dropout (dec_lstm.py:81), and aten::embedding_dense_backward reached from text.py:384
+// (decoder embedding has padding_idx = V-1, dec_lstm.py:28, SURVEY.md G3: that row's grad stays zero).
+//
+// ids stay in the reference's batch-first int64 layout [B][ids_stride]; activations are written time-major
+// ([T][B][ni], row r = t*B + b) so each LSTM timestep is one contiguous slab.  Dropout keep-masks are taken
+// in the reference's batch-first layout [B][T][ni] (that is what replaying torch's RNG produces).
+//
+// Backward is sort-based instead of atomic so the result is bit-reproducible: one 512-thread workgroup
+// radix-sorts (token, row) pairs (stable, 4 bits per pass, counts in LDS), then one workgroup per segment
+// head sums its rows in ascending row order.
+#include "lv_device.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ emb, const int64_t* __restrict__ ids,
+                                                           long ids_stride, const uint8_t* __restrict__ mask, float scale,
+                                                           float* __restrict__ X, int T, int B, int ni, int V, int vec) {
+    // 4 rows per workgroup, 64 threads (one wave) per row
+    const int r = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int l = (int)threadIdx.x & 63;
+    if (r >= T * B) return;
+    const int t = r / B, b = r % B;
+    long tok = ids[(long)b * ids_stride + t];
+    if (tok < 0) tok = 0;
+    if (tok >= V) tok = V - 1;
+    const float* src = emb + tok * (long)ni;
+    float* dst = X + (long)r * ni;
+    const uint8_t* m = mask ? mask + ((long)b * T + t) * ni : nullptr;
+    if (vec) {
+        for (int k = l * 4; k < ni; k += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + k);
+            if (m) {
+                v.x = m[k] ? v.x * scale : 0.f;
+                v.y = m[k + 1] ? v.y * scale : 0.f;
+                v.z = m[k + 2] ? v.z * scale : 0.f;
+                v.w = m[k + 3] ? v.w * scale : 0.f;
+            }
+            *reinterpret_cast<float4*>(dst + k) = v;
+        }
+    } else {
+        for (int k = l; k < ni; k += 64) {
+            float v = src[k];
+            if (m) v = m[k] ? v * scale : 0.f;
+            dst[k] = v;
+        }
+    }
+}
+
+// ---- stable LSD radix sort of (token, row) pairs by token; single 512-thread workgroup ----
+constexpr int SORT_THREADS = 512;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wave_tot /*[SORT_WAVES] LDS*/, int* total) {
+    // inclusive scan inside each wave with shuffles
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, (unsigned)d, 64);
+        if (l >= d) x += y;
+    }
+    if (l == 63) wave_tot[w] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < SORT_WAVES; ++i) {
+        const int wt = wave_tot[i];
+        if (i < w) base += wt;
+        tot += wt;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void token_sort_kernel(const int64_t* __restrict__ ids, long ids_stride, int T, int B,
+                                                                  int V, int* out_rows, int* out_tok, int* tmp) {
+    __shared__ int counts[16 * SORT_THREADS];
+    __shared__ int wave_tot[SORT_WAVES];
+    const int tid = (int)threadIdx.x;
+    const int N = T * B;
+    const int per = (N + SORT_THREADS - 1) / SORT_THREADS;
+    const int e0 = tid * per;
+    const int e1 = (e0 + per) < N ? (e0 + per) : N;
+    int bits = 1;
+    while ((1L << bits) < (long)V) ++bits;
+    const int npass = (bits + 3) / 4;
+    // ping-pong so that the LAST pass lands in (out_tok, out_rows)
+    int* kbuf[2] = {tmp, out_tok};
+    int* vbuf[2] = {tmp + N, out_rows};
+    int cur = (npass & 1) ? 0 : 1;   // buffer holding the input of pass 0 (only used for pass >= 1)
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 4 * pass;
+        const int* kin = kbuf[cur];
+        const int* vin = vbuf[cur];
+        int* kout = kbuf[cur ^ 1];
+        int* vout = vbuf[cur ^ 1];
+        int hist[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) hist[d] = 0;
+        for (int e = e0; e < e1; ++e) {
+            int key;
+            if (pass == 0) {
+                const int t = e / B, b = e % B;
+                long tok = ids[(long)b * ids_stride + t];
+                if (tok < 0) tok = 0;
+                if (tok >= V) tok = V - 1;
+                key = (int)tok;
+            } else {
+                key = kin[e];
+            }
+            const int dgt = (key >> shift) & 15;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) hist[d] += (d == dgt) ? 1 : 0;
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) counts[d * SORT_THREADS + tid] = hist[d];
+        __syncthreads();
+        // exclusive scan of counts in (digit-major, thread-minor) order: thread j owns [16j, 16j+16)
+        int loc[16];
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { loc[i] = counts[tid * 16 + i]; s += loc[i]; }
+        int total;
+        int base = block_exclusive_scan(s, wave_tot, &total);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { counts[tid * 16 + i] = base; base += loc[i]; }
+        __syncthreads();
+        int off[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) off[d] = counts[d * SORT_THREADS + tid];
+        for (int e = e0; e < e1; ++e) {
+            int key, val;
+            if (pass == 0) {
+                const int t = e / B, b = e % B;
+                long tok = ids[(long)b * ids_stride + t];
+                if (tok < 0) tok = 0;
+                if (tok >= V) tok = V - 1;
+                key = (int)tok;
+                val = e;
+            } else {
+                key = kin[e];
+                val = vin[e];
+            }
+            const int dgt = (key >> shift) & 15;
+            int pos = 0;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d == dgt) { pos = off[d]; off[d] = pos + 1; }
+            kout[pos] = key;
+            vout[pos] = val;
+        }
+        __syncthreads();   // single workgroup: global writes of this pass visible to the next via the barrier
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
+                                                            float scale, const int* __restrict__ rows,
+                                                            const int* __restrict__ toks, int N, int B, int T,
+                                                            float* __restrict__ dE, int ni, int pad_idx, int accumulate,
+                                                            int vec) {
+    const int p = (int)blockIdx.x;
+    const int tok = toks[p];
+    if (p > 0 && toks[p - 1] == tok) return;   // not a segment head
+    if (tok == pad_idx) return;
+    const int tid = (int)threadIdx.x;
+    float* dst = dE + (long)tok * ni;
+    if (vec) {
+        for (int k = tid * 4; k < ni; k += 512) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = p; q < N && toks[q] == tok; ++q) {
+                const int r = rows[q];
+                float4 v = *reinterpret_cast<const float4*>(dX + (long)r * ni + k);
+                if (mask) {
+                    const int t = r / B, b = r % B;
+                    const uint8_t* m = mask + ((long)b * T + t) * ni + k;
+                    v.x = m[0] ? v.x * scale : 0.f;
+                    v.y = m[1] ? v.y * scale : 0.f;
+                    v.z = m[2] ? v.z * scale : 0.f;
+                    v.w = m[3] ? v.w * scale : 0.f;
+                }
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float4* d4 = reinterpret_cast<float4*>(dst + k);
+            if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+            *d4 = acc;
+        }
+    } else {
+        for (int k = tid; k < ni; k += 128) {
+            float acc = 0.f;
+            for (int q = p; q < N && toks[q] == tok; ++q) {
+                const int r = rows[q];
+                float v = dX[(long)r * ni + k];
+                if (mask) {
+                    const int t = r / B, b = r % B;
+                    v = mask[((long)b * T + t) * ni + k] ? v * scale : 0.f;
+                }
+                acc += v;
+            }
+            if (accumulate) acc += dst[k];
+            dst[k] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+// X[t*B + b][:] = emb[ids[b*ids_stride + t]][:] * (mask ? mask[b][t][:] * scale : 1)
+extern "C" int lv_embed_gather_f32(const float* emb, const int64_t* ids, long ids_stride,
+                                   const uint8_t* mask, float scale, float* X,
+                                   int T, int B, int ni, int V, void* stream) {
+    if (!emb || !ids || !X) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    const int vec = (ni % 4 == 0) && (((uintptr_t)emb | (uintptr_t)X) & 15) == 0;
+    dim3 grid((unsigned)lv_cdiv((long)T * B, 4)), block(256);
+    LV_LAUNCH(embed_gather_kernel, grid, block, 0, stream, emb, ids, ids_stride, mask, scale, X, T, B, ni, V, vec);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// Stable sort of rows r = t*B + b by token id.  out_rows/out_tok: [T*B] ints; tmp: 2*T*B ints.
+extern "C" int lv_token_sort(const int64_t* ids, long ids_stride, int T, int B, int V,
+                             int* out_rows, int* out_tok, int* tmp, void* stream) {
+    if (!ids || !out_rows || !out_tok || !tmp) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || V <= 0) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(token_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, ids, ids_stride, T, B, V, out_rows, out_tok, tmp);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// dE[tok][:] (=|+=) sum over rows r with token tok of dX[r][:] * (mask ? mask[b][t][:]*scale : 1), in ascending r.
+// Rows of dE for tokens that do not occur are left untouched; pad_idx (or -1) is skipped entirely.
+extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale,
+                                    const int* sorted_rows, const int* sorted_tok, int T, int B,
+                                    float* dE, int ni, int pad_idx, int accumulate, void* stream) {
+    if (!dX || !sorted_rows || !sorted_tok || !dE) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || ni <= 0) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0;
+    const int N = T * B;
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+              N, B, T, dE, ni, pad_idx, accumulate, vec);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

@@ -1,0 +1,274 @@
+// lv_loss.hip -- the non-GEMM pieces of VAE.loss: reparameterise + analytic KL, token NLL, loss assembly.
+//
+// Replaces GaussianEncoderBase.encode / .reparameterize (modules/encoders/encoder.py:40-79: z = mu + eps*exp(0.5 lv),
+// KL = 0.5*sum(mu^2 + exp(lv) - lv - 1)), nn.CrossEntropyLoss(reduce=False) + .sum(-1) of
+// LSTMDecoder.reconstruct_error (modules/decoders/dec_lstm.py:143-148), the loss assembly of VAE.loss
+// (modules/vae.py:95-98), and their autograd backward.  eps is an INPUT (host torch RNG in parity mode,
+// lv_rng.hip Philox in throughput mode) -- SURVEY.md App. B.
+#include "lv_device.h"
+
+namespace {
+
+// one sub-wave group of G lanes per batch row; G = 32 when nz <= 32 (two rows per wave64), else 64
+template <int G>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
+                                                             float* __restrict__ z, float* __restrict__ kl,
+                                                             int B, int ns, int nz) {
+    const int tid = (int)threadIdx.x;
+    const int row = ((int)blockIdx.x * 256 + tid) / G;
+    const int j0 = tid % G;
+    const bool ok = row < B;
+    const float* mu = mulv + (long)(ok ? row : 0) * 2 * nz;
+    const float* lv = mu + nz;
+    float part = 0.f;
+    for (int j = j0; j < nz; j += G) {
+        if (!ok) break;
+        const float m = mu[j], l = lv[j];
+        const float sd = expf(0.5f * l);
+        part += (m * m + expf(l)) - l - 1.f;
+        for (int s = 0; s < ns; ++s) {
+            const long zi = ((long)row * ns + s) * nz + j;
+            z[zi] = m + eps[zi] * sd;
+        }
+    }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (ok && j0 == 0) kl[row] = 0.5f * part;
+}
+
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
+                                                             const float* __restrict__ dz, const float* __restrict__ dkl,
+                                                             float* __restrict__ dmulv, int B, int ns, int nz) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * nz) return;
+    const int b = (int)(idx / nz), j = (int)(idx % nz);
+    const float m = mulv[(long)b * 2 * nz + j], l = mulv[(long)b * 2 * nz + nz + j];
+    const float sd = expf(0.5f * l);
+    float gz = 0.f, gze = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const long zi = ((long)b * ns + s) * nz + j;
+        const float g = dz[zi];
+        gz += g;
+        gze += g * eps[zi];
+    }
+    const float gk = dkl[b];
+    dmulv[(long)b * 2 * nz + j] = gz + gk * m;
+    dmulv[(long)b * 2 * nz + nz + j] = gze * (0.5f * sd) + gk * (0.5f * (expf(l) - 1.f));
+}
+
+// online (max, sum-exp) merge
+__device__ __forceinline__ void ms_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { m = mn; s = 0.f; return; }
+    s = s * expf(m - mn) + s2 * expf(m2 - mn);
+    m = mn;
+}
+
+// one workgroup per logits row r = t*B + b
+__global__ __launch_bounds__(256) void softmax_nll_fwd_kernel(const float* __restrict__ logits, long ldl,
+                                                              const int64_t* __restrict__ ids, long ids_stride, int tgt_off,
+                                                              float* __restrict__ lse, float* __restrict__ nll,
+                                                              int T, int B, int V) {
+    __shared__ float sm[4], ss[4];
+    const int r = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const float* row = logits + (long)r * ldl;
+    float m = -INFINITY, s = 0.f;
+    const bool vec = (ldl % 4 == 0) && ((((uintptr_t)logits) & 15) == 0);
+    if (vec) {
+        const int V4 = V & ~3;
+        for (int k = tid * 4; k < V4; k += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            const float mn = fmaxf(m, mx);
+            s = s * expf(m - mn) + ((expf(v.x - mn) + expf(v.y - mn)) + (expf(v.z - mn) + expf(v.w - mn)));
+            m = mn;
+        }
+        for (int k = V4 + tid; k < V; k += 256) ms_merge(m, s, row[k], 1.f);
+    } else {
+        for (int k = tid; k < V; k += 256) ms_merge(m, s, row[k], 1.f);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float m2 = __shfl_xor(m, d, 64), s2 = __shfl_xor(s, d, 64);
+        ms_merge(m, s, m2, s2);
+    }
+    if (l == 0) { sm[w] = m; ss[w] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = sm[0], S = ss[0];
+        for (int i = 1; i < 4; ++i) ms_merge(M, S, sm[i], ss[i]);
+        const float L = M + logf(S);
+        const int t = r / B, b = r % B;
+        long tg = ids[(long)b * ids_stride + t + tgt_off];
+        if (tg < 0) tg = 0;
+        if (tg >= V) tg = V - 1;
+        lse[r] = L;
+        nll[r] = L - row[tg];
+    }
+}
+
+// in place: logits[r][c] <- (exp(logits[r][c] - lse[r]) - [c == target_r]) * rowscale[b]
+__global__ __launch_bounds__(256) void softmax_nll_bwd_kernel(float* __restrict__ logits, long ldl, const float* __restrict__ lse,
+                                                              const int64_t* __restrict__ ids, long ids_stride, int tgt_off,
+                                                              const float* __restrict__ rowscale, int T, int B, int V) {
+    const int r = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    float* row = logits + (long)r * ldl;
+    const int t = r / B, b = r % B;
+    long tg = ids[(long)b * ids_stride + t + tgt_off];
+    if (tg < 0) tg = 0;
+    if (tg >= V) tg = V - 1;
+    const float L = lse[r], sc = rowscale[b];
+    const bool vec = (ldl % 4 == 0) && ((((uintptr_t)logits) & 15) == 0);
+    const int itg = (int)tg;
+    if (vec) {
+        const int V4 = V & ~3;
+        for (int k = tid * 4; k < V4; k += 1024) {
+            float4 v = *reinterpret_cast<float4*>(row + k);
+            v.x = (expf(v.x - L) - (k == itg ? 1.f : 0.f)) * sc;
+            v.y = (expf(v.y - L) - (k + 1 == itg ? 1.f : 0.f)) * sc;
+            v.z = (expf(v.z - L) - (k + 2 == itg ? 1.f : 0.f)) * sc;
+            v.w = (expf(v.w - L) - (k + 3 == itg ? 1.f : 0.f)) * sc;
+            *reinterpret_cast<float4*>(row + k) = v;
+        }
+        for (int k = V4 + tid; k < V; k += 256) row[k] = (expf(row[k] - L) - (k == itg ? 1.f : 0.f)) * sc;
+    } else {
+        for (int k = tid; k < V; k += 256) row[k] = (expf(row[k] - L) - (k == itg ? 1.f : 0.f)) * sc;
+    }
+}
+
+// rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight * kl[b]
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
+                                                       const float* __restrict__ klw, float* __restrict__ loss,
+                                                       float* __restrict__ rec, int T, int B) {
+    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += nll[(long)t * B + b];
+    rec[b] = s;
+    loss[b] = s + klw[0] * kl[b];
+}
+
+// upstream grads (each may be null) -> per-row scales used by the backward kernels
+__global__ __launch_bounds__(256) void loss_bwd_scales_kernel(const float* g_loss, const float* g_rec, const float* g_kl,
+                                                              const float* klw, float* rowscale, float* dkl, int B) {
+    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (b >= B) return;
+    const float gl = g_loss ? g_loss[b] : 0.f;
+    rowscale[b] = gl + (g_rec ? g_rec[b] : 0.f);
+    dkl[b] = klw[0] * gl + (g_kl ? g_kl[b] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = tanhf(in[i]);
+}
+
+// out[c] = sum_r in[r][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, int R, int C,
+                                                     float* __restrict__ out, float* __restrict__ out2) {
+    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += in[(long)r * ld + c];
+    out[c] = s;
+    if (out2) out2[c] = s;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+}  // namespace
+
+extern "C" int lv_reparam_kl_fwd_f32(const float* mulv, const float* eps, float* z, float* kl,
+                                     int B, int ns, int nz, void* stream) {
+    if (!mulv || !eps || !z || !kl) return LV_ERR_ARG;
+    if (B <= 0 || ns <= 0 || nz <= 0) return LV_ERR_SHAPE;
+    if (nz <= 32) {
+        LV_LAUNCH((reparam_kl_fwd_kernel<32>), dim3((unsigned)lv_cdiv((long)B * 32, 256)), dim3(256), 0, stream,
+                  mulv, eps, z, kl, B, ns, nz);
+    } else {
+        LV_LAUNCH((reparam_kl_fwd_kernel<64>), dim3((unsigned)lv_cdiv((long)B * 64, 256)), dim3(256), 0, stream,
+                  mulv, eps, z, kl, B, ns, nz);
+    }
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_reparam_kl_bwd_f32(const float* mulv, const float* eps, const float* dz, const float* dkl,
+                                     float* dmulv, int B, int ns, int nz, void* stream) {
+    if (!mulv || !eps || !dz || !dkl || !dmulv) return LV_ERR_ARG;
+    if (B <= 0 || ns <= 0 || nz <= 0) return LV_ERR_SHAPE;
+    LV_LAUNCH(reparam_kl_bwd_kernel, dim3((unsigned)lv_cdiv((long)B * nz, 256)), dim3(256), 0, stream,
+              mulv, eps, dz, dkl, dmulv, B, ns, nz);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_softmax_nll_fwd_f32(const float* logits, long ldl, const int64_t* ids, long ids_stride, int tgt_off,
+                                      float* lse, float* nll, int T, int B, int V, void* stream) {
+    if (!logits || !ids || !lse || !nll) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || V <= 0 || ldl < V) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(softmax_nll_fwd_kernel, dim3((unsigned)(T * B)), dim3(256), 0, stream, logits, ldl, ids, ids_stride,
+              tgt_off, lse, nll, T, B, V);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_softmax_nll_bwd_f32(float* logits, long ldl, const float* lse, const int64_t* ids, long ids_stride,
+                                      int tgt_off, const float* rowscale, int T, int B, int V, void* stream) {
+    if (!logits || !ids || !lse || !rowscale) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || V <= 0 || ldl < V) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(softmax_nll_bwd_kernel, dim3((unsigned)(T * B)), dim3(256), 0, stream, logits, ldl, lse, ids, ids_stride,
+              tgt_off, rowscale, T, B, V);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_vae_loss_f32(const float* nll, const float* kl, const float* kl_weight_dev,
+                               float* loss, float* rec, int T, int B, void* stream) {
+    if (!nll || !kl || !kl_weight_dev || !loss || !rec) return LV_ERR_ARG;
+    if (T < 0 || B <= 0) return LV_ERR_SHAPE;
+    LV_LAUNCH(vae_loss_kernel, dim3((unsigned)lv_cdiv(B, 256)), dim3(256), 0, stream, nll, kl, kl_weight_dev, loss, rec, T, B);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_loss_bwd_scales_f32(const float* g_loss, const float* g_rec, const float* g_kl,
+                                      const float* kl_weight_dev, float* rowscale, float* dkl, int B, void* stream) {
+    if (!kl_weight_dev || !rowscale || !dkl) return LV_ERR_ARG;
+    if (B <= 0) return LV_ERR_SHAPE;
+    LV_LAUNCH(loss_bwd_scales_kernel, dim3((unsigned)lv_cdiv(B, 256)), dim3(256), 0, stream, g_loss, g_rec, g_kl,
+              kl_weight_dev, rowscale, dkl, B);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_tanh_f32(const float* in, float* out, long n, void* stream) {
+    if (!in || !out || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(tanh_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, in, out, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_colsum_f32(const float* in, long ld, int R, int C, float* out, float* out2, void* stream) {
+    if (!in || !out || R < 0 || C <= 0 || ld < C) return LV_ERR_ARG;
+    LV_LAUNCH(colsum_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, in, ld, R, C, out, out2);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
+    if (!a || !b || !out || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(add_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

@@ -1,0 +1,197 @@
+// lv_optim.hip -- global grad-norm, clip coefficient, fused clip+SGD / clip+Adam over flat parameter buffers.
+//
+// Replaces torch.nn.utils.clip_grad_norm_(vae.parameters(), 5.0) (text.py:385, image.py:312; the norm spans
+// encoder AND decoder grads -- SURVEY.md G1), optim.SGD(lr=1.0, momentum=0).step (text.py:325,387) and
+// optim.Adam(lr=1e-3).step (image.py:267,314).  Parameters and grads live in flat HBM buffers (one segment per
+// nn.Parameter, each 16-byte aligned) so the norm is one streaming reduction and the update one streaming pass.
+// Scalars that change between graph replays (lr, step count) are read from device memory.
+#include "lv_device.h"
+
+namespace {
+
+constexpr int NORM_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_stage1_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int tid = (int)threadIdx.x;
+    // contiguous chunk per block, 16-byte vector loads on the aligned interior
+    const long per = (((n + NORM_BLOCKS - 1) / NORM_BLOCKS) + 3) & ~3L;
+    const long beg = (long)blockIdx.x * per;
+    long end = beg + per;
+    if (end > n) end = n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (beg < end) {
+        const bool vec = ((((uintptr_t)x) & 15) == 0);
+        if (vec) {
+            const long nv = (end - beg) / 4;
+            const float4* x4 = reinterpret_cast<const float4*>(x + beg);
+            for (long i = tid; i < nv; i += 256) {
+                const float4 v = x4[i];
+                s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w;
+            }
+            for (long i = beg + nv * 4 + tid; i < end; i += 256) s0 += x[i] * x[i];
+        } else {
+            for (long i = beg + tid; i < end; i += 256) s0 += x[i] * x[i];
+        }
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] (=|+=) sum(partial[0..NORM_BLOCKS))
+__global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out, int accumulate) {
+    __shared__ double red[4];
+    const int tid = (int)threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < NORM_BLOCKS; i += 256) s += (double)partial[i];
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        out[0] = (float)(tot + (accumulate ? (double)out[0] : 0.0));
+    }
+}
+
+// norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float nrm = sqrtf(sumsq[0]);
+        float c = max_norm / (nrm + 1e-6f);
+        if (c > 1.f) c = 1.f;
+        coef[0] = c;
+        if (norm_out) norm_out[0] = nrm;
+    }
+}
+
+// g <- g*coef (optional write-back); p <- p - lr * g
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, long n,
+                                                  const float* __restrict__ lr, const float* __restrict__ coef,
+                                                  int write_back) {
+    const float c = coef ? coef[0] : 1.f;
+    const float a = lr[0];
+    const long stride = (long)gridDim.x * 256;
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0;
+    if (vec) {
+        const long n4 = n / 4;
+        float4* p4 = reinterpret_cast<float4*>(p);
+        float4* g4 = reinterpret_cast<float4*>(g);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 gv = g4[i], pv = p4[i];
+            gv.x *= c; gv.y *= c; gv.z *= c; gv.w *= c;
+            pv.x -= a * gv.x; pv.y -= a * gv.y; pv.z -= a * gv.z; pv.w -= a * gv.w;
+            p4[i] = pv;
+            if (write_back) g4[i] = gv;
+        }
+        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float gv = g[i] * c;
+            p[i] -= a * gv;
+            if (write_back) g[i] = gv;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float gv = g[i] * c;
+            p[i] -= a * gv;
+            if (write_back) g[i] = gv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef) {
+    const float c = coef[0];
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= c;
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay): state = {m, v}; step count t read from device (float)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, const float* __restrict__ lr,
+                                                   const float* __restrict__ coef, const float* __restrict__ step,
+                                                   float beta1, float beta2, float eps, int write_back) {
+    const float c = coef ? coef[0] : 1.f;
+    const float a = lr[0];
+    const float t = step[0];
+    const float bc1 = 1.f - powf(beta1, t);
+    const float bc2 = 1.f - powf(beta2, t);
+    const float step_size = a / bc1;
+    const float bc2s = sqrtf(bc2);
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gv = g[i] * c;
+        const float mi = m[i] + (gv - m[i]) * (1.f - beta1);        // lerp form, as torch's _single_tensor_adam
+        const float vi = v[i] * beta2 + (1.f - beta2) * gv * gv;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] -= step_size * (mi / denom);
+        m[i] = mi; v[i] = vi;
+        if (write_back) g[i] = gv;
+    }
+}
+
+__global__ void add_scalar_kernel(float* x, float v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) x[0] += v;
+}
+
+}  // namespace
+
+extern "C" int lv_sumsq_workspace_floats() { return NORM_BLOCKS; }
+
+// out[0] (=|+=) sum(x[i]^2); ws: lv_sumsq_workspace_floats() floats.  Deterministic two-stage reduction.
+extern "C" int lv_sumsq_f32(const float* x, long n, float* ws, float* out, int accumulate, void* stream) {
+    if (!x || !ws || !out || n < 0) return LV_ERR_ARG;
+    LV_LAUNCH(sumsq_stage1_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, x, n, ws);
+    LV_LAUNCH(sumsq_stage2_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, out, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_clip_coef_f32(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
+    if (!sumsq || !coef) return LV_ERR_ARG;
+    LV_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, stream, sumsq, max_norm, coef, norm_out);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+static inline unsigned lv_stream_grid(long n) {
+    long b = (n + 1023) / 1024;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (unsigned)b;
+}
+
+extern "C" int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev,
+                               int write_back_clipped, void* stream) {
+    if (!p || !g || !lr_dev || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream) {
+    if (!x || !coef_dev || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(scale_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, x, n, coef_dev);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float* lr_dev,
+                                const float* coef_dev, const float* step_dev, float beta1, float beta2, float eps,
+                                int write_back_clipped, void* stream) {
+    if (!p || !g || !m || !v || !lr_dev || !step_dev || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(adam_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, m, v, n, lr_dev, coef_dev, step_dev,
+              beta1, beta2, eps, write_back_clipped);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_add_scalar_f32(float* x_dev, float v, void* stream) {
+    if (!x_dev) return LV_ERR_ARG;
+    LV_LAUNCH(add_scalar_kernel, dim3(1), dim3(64), 0, stream, x_dev, v);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
