@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- aggressive-loop sequences/sec on the BASELINE.json metric configuration.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one body of the aggressive inner loop (reference text.py:373-387: zero_grad, VAE.loss, backward,
+clip_grad_norm_ over encoder+decoder grads, encoder SGD step) on one synthetic batch of the Yahoo LSTM-VAE
+configuration (B=32 sequences per GPU, T=200, V=20001, ni=512, H=1024, nz=32).  Inputs (a pool of 64
+batches) are resident in HBM before the timed region; noise (eps, dropout masks) is drawn on device.  Weak scaling:
+every rank runs its own B=32 batch and the flat gradient buffers are mean-all-reduced over RCCL each step.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel = the f32 MFMA
+GEMM, bracketed live by HIP events on its launch stream inside the timed region) and `cpu_baseline` (the CPU
+oracle's ATen path = the reference's CPU op sequence, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # BASELINE.json metric: "aggressive-loop seqs/sec (Yahoo LSTM-VAE, bsz=32, len=200)"
+    "yahoo": dict(V=20001, ni=512, H=1024, nz=32, B=32, T=200),
+    "yelp": dict(V=19997, ni=512, H=1024, nz=32, B=32, T=100),
+    "toy": dict(V=1004, ni=50, H=50, nz=1, B=16, T=12),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
+GFLOP_PER_SEQ = {"yahoo": 39.67, "yelp": 19.75}   # SURVEY.md 8(d) / BASELINE.md section 4
+
+
+def fwd_flops(V, ni, H, nz, B, T):
+    return 2 * B * (T * ni * 4 * H + T * H * 4 * H + H * 2 * nz) + 2 * B * nz * H + \
+        2 * B * (T - 1) * ((ni + nz) * 4 * H + H * 4 * H + H * V)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="yahoo", choices=sorted(WORKLOADS))
+    ap.add_argument("--graph", type=int, default=0, help="replay the step as captured hipGraphs (no per-kernel events)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", type=int, default=64)
+    args = ap.parse_args()
+
+    from vae_lagging_encoder_amd import dist as lvdist
+    from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    from helpers import build_vae
+    from oracle import text_vae_oracle as O
+
+    rank, local, world = lvdist.init_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg = WORKLOADS[args.workload]
+    V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
+
+    # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
+    vae = build_vae(V, ni, H, nz, dev, seed=783435)
+    sync = lvdist.GradSync(mode="strict") if world > 1 else None
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435 + rank, grad_sync=sync, use_graph=bool(args.graph))
+    pool = [O.synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
+    rs = np.random.RandomState(783435)
+    kl_weight = 0.1                                         # text.py default kl_start
+
+    def one_step():
+        tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    prof = None
+    if not args.graph:
+        prof = []
+        engine.GEMM_PROFILE = prof
+    tr.reset_stats()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    engine.GEMM_PROFILE = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stats = tr.read_stats()
+
+    if rank != 0:
+        return
+    seqs = world * B * args.steps
+    value = seqs / dt
+    out = {
+        "metric": "aggressive-loop seqs/sec", "value": round(value, 2), "unit": "seq/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s LSTM-VAE aggressive inner step (fwd+bwd+clip+encoder SGD), B=%d/GPU, T=%d, V=%d, "
+                               "ni=%d, H=%d, nz=%d" % (args.workload, B, T, V, ni, H, nz),
+                   "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
+                   "hipgraph": bool(args.graph)},
+        "mean_loss_per_seq": round(stats["loss_sum"] / (B * args.steps), 4),
+    }
+    step_flops = 3 * fwd_flops(V, ni, H, nz, B, T)
+    if prof:
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        fl = sum(f for _, _, f in prof)
+        achieved = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "lv_gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": len(prof) // args.steps, "gemm_ms_per_step": round(ms / args.steps, 4),
+            "gemm_gflop_per_step": round(fl / args.steps / 1e9, 1),
+            "whole_step_tflops": round(step_flops / (dt / args.steps) / 1e12, 2),
+        }
+    else:
+        out["roofline"] = {"bound": "mfma", "achieved": round(step_flops / (dt / args.steps) / 1e12, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": None, "note": "whole-step algorithmic flops (graph replay: no per-kernel events)"}
+
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's CPU op sequence (oracle 'aten' path), same shapes, bounded sample
+        torch.set_num_threads(os.cpu_count() or 1)
+        P = {k: v.detach().cpu() for k, v in vae.state_dict().items() if k in O.ALL_KEYS}
+        xb = pool[0].cpu()
+        eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=1)
+        tw = time.perf_counter()
+        r = O.inner_step(P, xb, kl_weight, eps, m_in, m_out, impl="aten")     # warm-up
+        warm = time.perf_counter() - tw
+        n_timed, t_cpu = 0, 0.0
+        while n_timed < 3 and t_cpu + warm < 30.0:
+            tc = time.perf_counter()
+            r = O.inner_step(P, xb, kl_weight, eps, m_in, m_out, impl="aten")
+            t_cpu += time.perf_counter() - tc
+            n_timed += 1
+        if n_timed == 0:
+            n_timed, t_cpu = 1, warm
+        out["cpu_baseline"] = {"value": round(B * n_timed / t_cpu, 3), "unit": "seq/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": "%d timed inner step(s) after 1 warm-up, same shapes (B=%d,T=%d), torch CPU ATen ops "
+                                         "(oneDNN LSTM) = the reference's CPU path restated in oracle/" % (n_timed, B, T)}
+        # ELBO delta of the HIP path vs that oracle on the identical batch/noise (north_star: <= 1e-4 relative)
+        vae2 = build_vae(V, ni, H, nz, dev, params=P)
+        tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0)
+        tr2.step(xb.to(dev), kl_weight, noise=(eps.to(dev), m_in.to(torch.uint8).to(dev), m_out.to(torch.uint8).to(dev)))
+        s2 = tr2.read_stats()
+        out["elbo_rel_delta_vs_cpu"] = float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum()))))
+        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

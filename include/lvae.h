@@ -1,0 +1,115 @@
+/* lvae.h -- C ABI of liblvae_hip.so: the MI355X (gfx950) kernels behind the aggressive-VAE training hot path.
+ *
+ * The reference (jxhe/vae-lagging-encoder) has no FFI layer: its hot path calls PyTorch/ATen ops from Python
+ * (SURVEY.md 2.2, 8b).  Each entry point below replaces one implicit ATen op (or a fused group of them) at the
+ * reference call site cited next to it.  Conventions for every function:
+ *   - plain device pointers + sizes + a hipStream_t passed as void*; no torch types, no C++ types, no exceptions;
+ *   - return int: 0 = ok, > 0 = hipError_t of the launch, < 0 = argument check (-1 arg, -2 shape, -3 alignment,
+ *     -4 unsupported);
+ *   - the caller owns every buffer including workspaces; functions never allocate, free or synchronise, and are
+ *     stream-ordered on `stream` (graph-capture safe); re-entrant, no global mutable state;
+ *   - scalars that change between hipGraph replays (kl weight, lr, clip coefficient, Adam step) are read from
+ *     device memory (`*_dev` arguments).
+ * Layouts: token ids int64 batch-first [B][ids_stride] (as data/text_data.py:219-255 builds them); activations
+ * time-major, row r = t*B + b; dropout keep-masks uint8 batch-first [B][T][C] (the reference's tensor layout).
+ */
+#ifndef LVAE_H
+#define LVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense contractions (exact f32 on v_mfma_f32_32x32x2_f32) ------------------------------------------------
+ * C[M,N](ldc) = alpha * op(A)[M,K] . op(B)[K,N] (+ add1[(row % mod1)*ld1 + col]) (+ add2[...]) (+ C if accumulate)
+ * transA = 0: A stored [M][K];  1: stored [K][M].   transB = 0: B stored [K][N];  1: stored [N][K].
+ * Replaces aten::mm/addmm under nn.LSTM's input projection (modules/encoders/enc_lstm.py:60,
+ * modules/decoders/dec_lstm.py:104), nn.Linear (enc_lstm.py:62; dec_lstm.py:99,109) and their backward
+ * (text.py:384).  The add1/add2 epilogue carries the two LSTM biases and the decoder's z-projection, so
+ * torch.cat((word_embed, z_), -1) (dec_lstm.py:97) is never materialised. */
+int lv_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                const float* A, long lda, const float* B, long ldb, float* C, long ldc, int accumulate,
+                const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2, void* stream);
+
+/* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
+int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ---- LSTM time recurrence: nn.LSTM forward (enc_lstm.py:60, dec_lstm.py:104) and its autograd backward --------
+ * gx [T][B][4H] input projection (+biases, + z term); whh [4H][H] (rows i|f|g|o); hs, cs [T+1][B][H] with index 0
+ * = initial state supplied by the caller; gates [T][B][4H] activated gates saved for BPTT.
+ * dmask (optional) uint8 [B][T][H] keep-mask of nn.Dropout on the outputs (dec_lstm.py:106): hdrop[t] =
+ * hs[t+1]*mask*dscale;  with dmask == NULL and hdrop != NULL, hdrop is a copy of the outputs. */
+int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                    const uint8_t* dmask, float dscale, float* hdrop, int T, int B, int H, void* stream);
+/* number of split-K slabs lv_lstm_bwd_f32 writes per step: dh_part must hold that many [B][H] slabs */
+int lv_lstm_bwd_ksplit(int H);
+/* BPTT.  dh_ext (optional) [T][B][H] grad wrt every output (times dmask*dscale when dmask given); dh_last
+ * (optional) [B][H] grad wrt the final output only (encoder: enc_lstm.py:60-62 uses last_state only).
+ * whhT [H][4H] = transpose of whh.  Outputs: dG [T][B][4H] grad wrt pre-activations; dGsum [B][4H] = sum_t dG[t];
+ * dc0/dh0 (optional) grads wrt the initial state; tanh_init = 1 when h0 = tanh(c0) (dec_lstm.py:99-101):
+ * then dc0 includes the path through h0.  Workspaces: dh_part [ksplit][B][H], dc_rec [B][H]. */
+int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                    const float* whhT, const float* gates, const float* hs, const float* cs,
+                    float* dG, float* dGsum, float* dh_part, float* dc_rec, float* dh0, float* dc0, int tanh_init,
+                    int T, int B, int H, void* stream);
+
+/* ---- embeddings: nn.Embedding forward (enc_lstm.py:58, dec_lstm.py:80) fused with dropout_in (dec_lstm.py:81);
+ * aten::embedding_dense_backward as a deterministic sorted-segment sum (padding_idx row skipped: dec_lstm.py:28) */
+int lv_embed_gather_f32(const float* emb, const int64_t* ids, long ids_stride, const uint8_t* mask, float scale,
+                        float* X, int T, int B, int ni, int V, void* stream);
+int lv_token_sort(const int64_t* ids, long ids_stride, int T, int B, int V,
+                  int* out_rows, int* out_tok, int* tmp /* 2*T*B ints */, void* stream);
+int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
+                         const int* sorted_tok, int T, int B, float* dE, int ni, int pad_idx, int accumulate,
+                         void* stream);
+
+/* ---- reparameterise + analytic KL: GaussianEncoderBase.encode / reparameterize (modules/encoders/encoder.py:40-79)
+ * mulv [B][2nz] = mu | logvar; eps [B][ns][nz] is an input (host RNG in parity mode, lv_rng_* otherwise). */
+int lv_reparam_kl_fwd_f32(const float* mulv, const float* eps, float* z, float* kl, int B, int ns, int nz, void* stream);
+int lv_reparam_kl_bwd_f32(const float* mulv, const float* eps, const float* dz, const float* dkl, float* dmulv,
+                          int B, int ns, int nz, void* stream);
+
+/* ---- token NLL: nn.CrossEntropyLoss(reduce=False) + view().sum(-1) (dec_lstm.py:45-47,143-148) ----------------
+ * logits [T*B][ldl]; target of row (t,b) = ids[b*ids_stride + t + tgt_off].  bwd rewrites logits in place with
+ * (softmax - onehot) * rowscale[b]. */
+int lv_softmax_nll_fwd_f32(const float* logits, long ldl, const int64_t* ids, long ids_stride, int tgt_off,
+                           float* lse, float* nll, int T, int B, int V, void* stream);
+int lv_softmax_nll_bwd_f32(float* logits, long ldl, const float* lse, const int64_t* ids, long ids_stride, int tgt_off,
+                           const float* rowscale, int T, int B, int V, void* stream);
+/* VAE.loss assembly (modules/vae.py:95-98): rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight*kl[b] */
+int lv_vae_loss_f32(const float* nll, const float* kl, const float* kl_weight_dev, float* loss, float* rec,
+                    int T, int B, void* stream);
+/* upstream grads (each may be NULL) -> rowscale[b] = g_loss+g_rec, dkl[b] = kl_weight*g_loss+g_kl */
+int lv_loss_bwd_scales_f32(const float* g_loss, const float* g_rec, const float* g_kl, const float* kl_weight_dev,
+                           float* rowscale, float* dkl, int B, void* stream);
+
+/* small elementwise / reductions used by the sequencing (h0 = tanh(c0) dec_lstm.py:100; bias grads) */
+int lv_tanh_f32(const float* in, float* out, long n, void* stream);
+int lv_colsum_f32(const float* in, long ld, int R, int C, float* out, float* out2, void* stream);
+int lv_add_f32(const float* a, const float* b, float* out, long n, void* stream);
+int lv_sum_accum_f32(const float* x, long n, float* out_dev, void* stream);   /* out_dev[0] += sum(x) (text.py:381) */
+int lv_add_scalar_f32(float* x_dev, float v, void* stream);
+
+/* ---- clip_grad_norm_ (text.py:385, image.py:312) + optim.SGD (text.py:325,387) / optim.Adam (image.py:267,314)
+ * over flat parameter/gradient buffers */
+int lv_sumsq_workspace_floats(void);
+int lv_sumsq_f32(const float* x, long n, float* ws, float* out_dev, int accumulate, void* stream);
+int lv_clip_coef_f32(const float* sumsq_dev, float max_norm, float* coef_dev, float* norm_out_dev, void* stream);
+int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
+                    void* stream);
+int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream);
+int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float* lr_dev, const float* coef_dev,
+                     const float* step_dev, float beta1, float beta2, float eps, int write_back_clipped, void* stream);
+
+/* ---- Philox4x32-10 draws for throughput mode (stand-in for torch's generator at encoder.py:77, dec_lstm.py:81,106)
+ * state_dev: uint64[2] = {seed, offset} in device memory */
+int lv_rng_normal_f32(float* out, long n, const uint64_t* state_dev, uint64_t substream, void* stream);
+int lv_rng_keepmask_u8(uint8_t* out, long n, float keep_prob, const uint64_t* state_dev, uint64_t substream, void* stream);
+int lv_rng_advance(uint64_t* state_dev, uint64_t inc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVAE_H */

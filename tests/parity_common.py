@@ -1,0 +1,79 @@
+"""Parity checks shared by the emulator (CPU, `not gpu`) and MI355X (`gpu`) test files: the drop-in modules are
+driven exactly as text.py:373-387 drives the reference's, and compared with the golden fixtures."""
+import numpy as np
+import torch
+
+from helpers import ALL_KEYS, DEC_KEYS, ENC_KEYS, build_vae, fixture_params, load, rel_err
+
+# north_star tolerance: ELBO / KL / rec within 1e-4 relative in fp32.  KL at the reference init is ~1e-5 and
+# cancellation-dominated, hence the absolute floor 1e-6*(1+|rec|) there.
+RTOL = 1e-4
+GRAD_RTOL = 2e-4
+
+
+def run_reference_style_step(name, device, clip=5.0, lr=1.0):
+    fx = load(name)
+    V, ni, H, nz = int(fx["V"]), int(fx["ni"]), int(fx["H"]), int(fx["nz"])
+    vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
+    x = torch.from_numpy(fx["x"]).to(device)
+    noise = (torch.from_numpy(fx["eps"]).to(device), torch.from_numpy(fx["mask_in"]).to(device),
+             torch.from_numpy(fx["mask_out"]).to(device))
+    enc_opt = torch.optim.SGD(vae.encoder.parameters(), lr=lr, momentum=0)
+    dec_opt = torch.optim.SGD(vae.decoder.parameters(), lr=lr, momentum=0)
+    enc_opt.zero_grad()
+    dec_opt.zero_grad()
+    loss, rec, kl = vae.loss(x, float(fx["kl_weight"]), nsamples=1, noise=noise)
+    loss.mean(dim=-1).backward()
+    grads = {k: p.grad.detach().clone() for k, p in vae.named_parameters()}
+    total = float(torch.nn.utils.clip_grad_norm_(vae.parameters(), clip))
+    enc_opt.step()
+    return fx, vae, loss.detach(), rec.detach(), kl.detach(), grads, total
+
+
+def check_step_against_fixture(name, device):
+    fx, vae, loss, rec, kl, grads, total = run_reference_style_step(name, device)
+    rec_scale = float(np.abs(fx["rec"]).max())
+    assert rel_err(loss, fx["loss"]) < RTOL, ("loss", rel_err(loss, fx["loss"]))
+    assert rel_err(rec, fx["rec"]) < RTOL
+    kl_err = float(np.abs(kl.cpu().numpy() - fx["kl"]).max())
+    assert kl_err < RTOL * float(np.abs(fx["kl"]).max()) + 1e-6 * (1 + rec_scale), ("kl", kl_err)
+    for k in ALL_KEYS:
+        g = fx["grad/" + k]
+        if np.abs(g).max() > 0:
+            e = rel_err(grads[k], g)
+            assert e < GRAD_RTOL, (k, e)
+        else:
+            assert float(grads[k].abs().max()) == 0.0, k
+    assert abs(total - float(fx["total_norm"])) / float(fx["total_norm"]) < RTOL
+    sd = vae.state_dict()
+    for k in ENC_KEYS:
+        assert rel_err(sd[k], fx["new/" + k]) < RTOL, k
+    for k in DEC_KEYS:   # encoder-only step leaves the decoder untouched
+        assert torch.equal(sd[k].cpu(), torch.from_numpy(fx["param/" + k])), k
+    return fx
+
+
+def check_trajectory_against_fixture(device, use_graph=False):
+    """K fused inner steps on a pool of batches + the joint decoder step (text.py:366-424 without the
+    data-dependent exit) through AggressiveTextTrainer, against the reference trajectory."""
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    fx = load("traj_small")
+    V, ni, H, nz = int(fx["V"]), int(fx["ni"]), int(fx["H"]), int(fx["nz"])
+    vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, use_graph=use_graph)
+    K = int(fx["K"])
+    klw = float(fx["kl_weight"])
+    pool = [torch.from_numpy(p).to(device) for p in fx["pool"]]
+    order = list(fx["order"])
+    for it in range(K + 1):
+        joint = it == K
+        bi = 0 if joint else int(order[it])
+        noise = tuple(torch.from_numpy(fx[k][it]).to(device) for k in ("eps", "mask_in", "mask_out"))
+        tr.reset_stats()
+        tr.step(pool[bi], klw, noise=noise, update="decoder" if joint else "encoder")
+        st = tr.read_stats()
+        assert abs(st["loss_sum"] - float(fx["loss"][it].sum())) / abs(float(fx["loss"][it].sum())) < RTOL
+        assert abs(st["norm"] - float(fx["total_norm"][it])) / float(fx["total_norm"][it]) < RTOL
+    sd = vae.state_dict()
+    for k in ALL_KEYS:
+        assert rel_err(sd[k], fx["final/" + k]) < RTOL, k

@@ -1,0 +1,28 @@
+"""Host sequencing + kernel index math on the GPU-less CI: the SAME kernel sources compiled with g++ against the
+thread-level emulator (tests/emu), driven through the drop-in modules, against the golden fixtures.
+This validates the code that will run on the MI355X, it is not a product path (the package refuses CPU tensors
+unless a test installs the emulator backend)."""
+import pytest
+import torch
+
+import parity_common as pc
+
+
+@pytest.mark.parametrize("name", ["text_small_refinit", "text_small_wide", "text_edge_T2"])
+def test_inner_step_matches_reference_fixture_emulated(emu_backend, name):
+    pc.check_step_against_fixture(name, "cpu")
+
+
+def test_cpu_tensors_refused_without_test_backend():
+    from vae_lagging_encoder_amd import _lib, engine
+    saved = engine._TEST_BACKEND
+    engine._install_test_backend(None)
+    try:
+        with pytest.raises(_lib.LvaeError):
+            engine.backend_for(torch.device("cpu"))
+    finally:
+        engine._install_test_backend(saved)
+
+
+def test_fused_trainer_trajectory_emulated(emu_backend):
+    pc.check_trajectory_against_fixture("cpu")

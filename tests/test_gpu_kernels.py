@@ -1,0 +1,286 @@
+"""MI355X kernel-level parity: every C-ABI entry point against a float64 torch restatement of the same op."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from vae_lagging_encoder_amd import _lib
+from vae_lagging_encoder_amd.engine import P, stream_ptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(hip_device):
+    return _lib.load()
+
+
+def _s(dev):
+    return stream_ptr(dev)
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [
+    (0, 1, 130, 140, 37), (0, 0, 130, 140, 37), (1, 0, 70, 260, 50), (1, 1, 33, 17, 20),
+    (0, 1, 512, 4096, 512), (0, 0, 640, 1024, 2001), (1, 0, 2001, 1024, 640), (0, 1, 32, 64, 1024),
+    (0, 1, 1, 1, 1), (0, 1, 257, 129, 16), (1, 0, 4096, 32, 32),
+])
+def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    lda = (M if tA else K) + 4
+    ldb = (K if tB else N) + 8
+    A = torch.randn(K if tA else M, lda, generator=g)
+    B = torch.randn(N if tB else K, ldb, generator=g)
+    C0 = torch.randn(M, N + 3, generator=g)
+    add1 = torch.randn(5, N, generator=g)
+    add2 = torch.randn(1, N, generator=g)
+    Aop = (A[:, :M].t() if tA else A[:, :K]).double()
+    Bop = (B[:, :K].t() if tB else B[:, :N]).double()
+    ref = 0.5 * (Aop @ Bop) + add1[torch.arange(M) % 5].double() + add2.double() + C0[:, :N].double()
+    Ad, Bd, Cd, a1, a2 = (t.to(hip_device) for t in (A, B, C0.clone(), add1, add2))
+    lib.lv_gemm_f32(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, P(a2), N, 1, _s(hip_device))
+    out = Cd.cpu()
+    assert torch.equal(out[:, N:], C0[:, N:])          # padding columns untouched
+    err = float((out[:, :N].double() - ref).abs().max())
+    assert err < 2e-6 * (K ** 0.5 + 1) * 8, err
+
+
+def test_gemm_unaligned_rows(lib, hip_device):
+    # ld % 4 != 0 and odd base offset: scalar load path (toy config has ni + nz = 51)
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 45, 200, 50
+    A = torch.randn(M, 51, generator=g)
+    B = torch.randn(N, 51, generator=g)
+    ref = A[:, 1:].double() @ B[:, 1:].double().t()
+    Ad, Bd = A.to(hip_device), B.to(hip_device)
+    C = torch.zeros(M, N, device=hip_device)
+    lib.lv_gemm_f32(0, 1, M, N, K, 1.0, P(Ad, 1), 51, P(Bd, 1), 51, P(C), N, 0, None, 0, 1, None, 0, 1, _s(hip_device))
+    assert float((C.cpu().double() - ref).abs().max()) < 1e-4
+
+
+def _lstm_ref(gx, whh, h0, c0, mask, scale):
+    T, B, _ = gx.shape
+    H = whh.shape[1]
+    h, c = h0, c0
+    hs, cs, outs = [h0], [c0], []
+    for t in range(T):
+        a = gx[t] + h @ whh.t()
+        i, f, g, o = a.chunk(4, -1)
+        i, f, o, g = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(g)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        hs.append(h)
+        cs.append(c)
+        outs.append(h * mask[:, t].to(h.dtype) * scale if mask is not None else h)
+    return torch.stack(hs), torch.stack(cs), torch.stack(outs)
+
+
+@pytest.mark.parametrize("T,B,H,use_mask,tanh_init,use_ext,use_last", [
+    (6, 32, 1024, True, True, True, False),      # decoder-shaped (Yahoo dims)
+    (6, 32, 1024, False, False, False, True),    # encoder-shaped
+    (3, 5, 50, True, True, True, True),          # toy dims, unaligned H
+    (4, 128, 256, False, True, True, False),     # stress batch
+    (2, 130, 64, True, False, True, True),       # batch > 128 -> two batch chunks
+])
+def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last):
+    dev = hip_device
+    g = torch.Generator().manual_seed(T * 100 + B + H)
+    gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(dev)
+    wext = torch.randn(T, B, H, generator=g).to(dev)
+    wlast = torch.randn(B, H, generator=g).to(dev)
+    gx64 = gx.double().requires_grad_(True)
+    whh64 = whh.double()
+    c064 = c0.double().requires_grad_(True)
+    h064 = torch.tanh(c064) if tanh_init else torch.zeros_like(c064)
+    hs_r, cs_r, out_r = _lstm_ref(gx64, whh64, h064, c064, mask if use_mask else None, 2.0)
+    loss = 0
+    if use_ext:
+        loss = loss + (out_r * wext.double()).sum()
+    if use_last:
+        loss = loss + (hs_r[-1] * wlast.double()).sum()
+    loss.backward()
+    hs = torch.zeros(T + 1, B, H, device=dev)
+    cs = torch.zeros(T + 1, B, H, device=dev)
+    hs[0] = h064.detach().float()
+    cs[0] = c0
+    gates = torch.empty(T, B, 4 * H, device=dev)
+    hdrop = torch.empty(T, B, H, device=dev)
+    m8 = mask.to(torch.uint8).contiguous()
+    lib.lv_lstm_fwd_f32(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), T, B, H, _s(dev))
+    assert float((hs.double() - hs_r.detach()).abs().max()) < 2e-5
+    assert float((cs.double() - cs_r.detach()).abs().max()) < 2e-5
+    assert float((hdrop.double() - out_r.detach()).abs().max()) < 4e-5
+    whhT = torch.empty(H, 4 * H, device=dev)
+    lib.lv_transpose_f32(P(whh), P(whhT), 4 * H, H, _s(dev))
+    assert torch.equal(whhT, whh.t().contiguous())
+    KS = lib.lv_lstm_bwd_ksplit(H)
+    dG = torch.empty(T, B, 4 * H, device=dev)
+    dGsum = torch.full((B, 4 * H), 7.0, device=dev)
+    part = torch.empty(KS, B, H, device=dev)
+    dcrec = torch.full((B, H), 3.0, device=dev)
+    dc0 = torch.empty(B, H, device=dev)
+    lib.lv_lstm_bwd_f32(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+                        P(whhT), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(part), P(dcrec), None, P(dc0),
+                        int(tanh_init), T, B, H, _s(dev))
+    sc = float(gx64.grad.abs().max())
+    assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc
+    assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T
+    assert float((dc0.double() - c064.grad).abs().max()) < 1e-4 * float(c064.grad.abs().max())
+
+
+@pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),
+                                              (200, 128, 64, 300, True)])
+def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):
+    dev = hip_device
+    g = torch.Generator().manual_seed(T + B + ni)
+    emb = torch.randn(V, ni, generator=g).to(dev)
+    ids = torch.randint(0, V, (B, T + 1), generator=g).to(dev)
+    ids[0, 0] = V - 1
+    mask = (torch.rand(B, T, ni, generator=g) < 0.5).to(torch.uint8).to(dev)
+    X = torch.empty(T * B, ni, device=dev)
+    lib.lv_embed_gather_f32(P(emb), P(ids), T + 1, P(mask) if masked else None, 2.0, P(X), T, B, ni, V, _s(dev))
+    ref = emb[ids[:, :T]]                                  # (B,T,ni)
+    if masked:
+        ref = ref * mask.float() * 2.0
+    ref = ref.transpose(0, 1).reshape(T * B, ni)
+    assert torch.equal(X, ref)
+    rows = torch.empty(T * B, dtype=torch.int32, device=dev)
+    toks = torch.empty(T * B, dtype=torch.int32, device=dev)
+    tmp = torch.empty(2 * T * B, dtype=torch.int32, device=dev)
+    lib.lv_token_sort(P(ids), T + 1, T, B, V, P(rows), P(toks), P(tmp), _s(dev))
+    flat_tok = ids[:, :T].t().reshape(-1)                  # row r = t*B + b
+    st, si = torch.sort(flat_tok, stable=True)
+    assert torch.equal(toks.long(), st)
+    assert torch.equal(rows.long(), si)
+    dX = torch.randn(T * B, ni, generator=g).to(dev)
+    dE = torch.zeros(V, ni, device=dev)
+    lib.lv_embed_scatter_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE), ni, V - 1, 0, _s(dev))
+    src = dX.double()
+    if masked:
+        src = src * (mask.double() * 2.0).transpose(0, 1).reshape(T * B, ni)
+    refE = torch.zeros(V, ni, dtype=torch.float64, device=dev).index_add_(0, flat_tok, src)
+    refE[V - 1] = 0
+    assert float((dE.double() - refE).abs().max()) < 1e-4
+    assert float(dE[V - 1].abs().max()) == 0.0
+    dE2 = torch.zeros(V, ni, device=dev)
+    lib.lv_embed_scatter_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE2), ni, V - 1, 0, _s(dev))
+    assert torch.equal(dE, dE2)                            # deterministic (sorted segments, no atomics)
+
+
+@pytest.mark.parametrize("B,ns,nz", [(32, 1, 32), (16, 1, 1), (5, 3, 40), (128, 2, 7)])
+def test_reparam_kl(lib, hip_device, B, ns, nz):
+    dev = hip_device
+    g = torch.Generator().manual_seed(B + nz)
+    mulv = torch.randn(B, 2 * nz, generator=g).to(dev)
+    eps = torch.randn(B, ns, nz, generator=g).to(dev)
+    z = torch.empty(B, ns, nz, device=dev)
+    kl = torch.empty(B, device=dev)
+    lib.lv_reparam_kl_fwd_f32(P(mulv), P(eps), P(z), P(kl), B, ns, nz, _s(dev))
+    m64 = mulv.double().requires_grad_(True)
+    mu, lv = m64[:, :nz], m64[:, nz:]
+    z_r = mu.unsqueeze(1) + eps.double() * (0.5 * lv).exp().unsqueeze(1)
+    kl_r = 0.5 * (mu.pow(2) + lv.exp() - lv - 1).sum(1)
+    assert float((z.double() - z_r.detach()).abs().max()) < 1e-5
+    assert float((kl.double() - kl_r.detach()).abs().max()) < 1e-5 * (1 + float(kl_r.detach().abs().max()))
+    dz = torch.randn(B, ns, nz, generator=g).to(dev)
+    dkl = torch.randn(B, generator=g).to(dev)
+    ((z_r * dz.double()).sum() + (kl_r * dkl.double()).sum()).backward()
+    dm = torch.empty(B, 2 * nz, device=dev)
+    lib.lv_reparam_kl_bwd_f32(P(mulv), P(eps), P(dz), P(dkl), P(dm), B, ns, nz, _s(dev))
+    assert float((dm.double() - m64.grad).abs().max()) < 1e-5 * (1 + float(m64.grad.abs().max()))
+
+
+@pytest.mark.parametrize("T,B,V", [(6, 4, 53), (20, 32, 20001), (3, 7, 1004)])
+def test_softmax_nll(lib, hip_device, T, B, V):
+    dev = hip_device
+    g = torch.Generator().manual_seed(V)
+    ldl = (V + 31) // 32 * 32
+    logits = torch.zeros(T * B, ldl)
+    logits[:, :V] = torch.randn(T * B, V, generator=g) * 3
+    logits = logits.to(dev)
+    ids = torch.randint(0, V, (B, T + 1), generator=g).to(dev)
+    lse = torch.empty(T * B, device=dev)
+    nll = torch.empty(T * B, device=dev)
+    lib.lv_softmax_nll_fwd_f32(P(logits), ldl, P(ids), T + 1, 1, P(lse), P(nll), T, B, V, _s(dev))
+    l64 = logits[:, :V].double()
+    tgt = ids[:, 1:].t().reshape(-1)
+    nll_r = torch.nn.functional.cross_entropy(l64, tgt, reduction="none")
+    assert float((nll.double() - nll_r).abs().max()) < 1e-5 * float(nll_r.abs().max())
+    rs = torch.rand(B, generator=g).to(dev)
+    p = torch.softmax(l64, -1)
+    p[torch.arange(T * B), tgt] -= 1
+    ref = p * rs.double()[torch.arange(T * B, device=dev) % B].unsqueeze(1)
+    lib.lv_softmax_nll_bwd_f32(P(logits), ldl, P(lse), P(ids), T + 1, 1, P(rs), T, B, V, _s(dev))
+    assert float((logits[:, :V].double() - ref).abs().max()) < 2e-6
+    kl2 = torch.full((B,), 2.0, device=dev)
+    w = torch.tensor([0.25], device=dev)
+    loss = torch.empty(B, device=dev)
+    rec = torch.empty(B, device=dev)
+    lib.lv_vae_loss_f32(P(nll), P(kl2), P(w), P(loss), P(rec), T, B, _s(dev))
+    rec_r = nll_r.view(T, B).sum(0)
+    assert float((rec.double() - rec_r).abs().max()) < 1e-5 * float(rec_r.abs().max())
+    assert float((loss.double() - (rec_r + 0.5)).abs().max()) < 1e-5 * float(rec_r.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 1000, 8193, 16_600_000])
+def test_norm_clip_sgd(lib, hip_device, n):
+    dev = hip_device
+    g = torch.Generator().manual_seed(n)
+    gr = torch.randn(n, generator=g).to(dev)
+    p = torch.randn(n, generator=g).to(dev)
+    ws = torch.empty(lib.lv_sumsq_workspace_floats(), device=dev)
+    sc = torch.zeros(4, device=dev)   # sumsq, coef, norm, lr
+    sc[3] = 0.5
+    lib.lv_sumsq_f32(P(gr), n, P(ws), P(sc, 0), 0, _s(dev))
+    lib.lv_sumsq_f32(P(gr), n, P(ws), P(sc, 0), 1, _s(dev))
+    ref = 2 * float(gr.double().pow(2).sum())
+    assert abs(float(sc[0]) - ref) / ref < 1e-6
+    lib.lv_clip_coef_f32(P(sc, 0), 5.0, P(sc, 1), P(sc, 2), _s(dev))
+    nrm = ref ** 0.5
+    coef = min(1.0, 5.0 / (nrm + 1e-6))
+    assert abs(float(sc[1]) - coef) < 1e-6 and abs(float(sc[2]) - nrm) / nrm < 1e-6
+    p_ref = p - 0.5 * (gr * float(sc[1]))
+    lib.lv_sgd_step_f32(P(p), P(gr), n, P(sc, 3), P(sc, 1), 1, _s(dev))
+    assert float((p - p_ref).abs().max()) < 1e-6
+
+
+def test_adam_matches_torch(lib, hip_device):
+    dev = hip_device
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(5000, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.clone().to(dev)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    sc = torch.tensor([1e-3, 0.0], device=dev)   # lr, step
+    for it in range(3):
+        gr = torch.randn(5000, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        gd = gr.to(dev)
+        lib.lv_add_scalar_f32(P(sc, 1), 1.0, _s(dev))
+        lib.lv_adam_step_f32(P(p), P(gd), P(m), P(v), 5000, P(sc, 0), None, P(sc, 1), 0.9, 0.999, 1e-8, 0, _s(dev))
+    assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+
+
+def test_philox_draws(lib, hip_device):
+    dev = hip_device
+    st = torch.tensor([783435, 0], dtype=torch.int64, device=dev)
+    n = 1 << 20
+    a = torch.empty(n, device=dev)
+    lib.lv_rng_normal_f32(P(a), n, P(st), 0, _s(dev))
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    m = torch.empty(n, dtype=torch.uint8, device=dev)
+    lib.lv_rng_keepmask_u8(P(m), n, 0.5, P(st), 1, _s(dev))
+    assert abs(float(m.float().mean()) - 0.5) < 3e-3 and int(m.max()) == 1
+    b = torch.empty(n, device=dev)
+    lib.lv_rng_normal_f32(P(b), n, P(st), 0, _s(dev))
+    assert torch.equal(a, b)                                 # counter-based: same state -> same draw
+    lib.lv_rng_advance(P(st), 1, _s(dev))
+    lib.lv_rng_normal_f32(P(b), n, P(st), 0, _s(dev))
+    assert not torch.equal(a, b)
+    assert abs(float((a * b).mean())) < 5e-3                 # successive draws uncorrelated

@@ -11,11 +11,11 @@ namespace {
 
 constexpr int NORM_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void sumsq_stage1_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void sumsq_stage1_kernel(const float* __restrict__ x, long n, float* __restrict__ partial, int nblk) {
     __shared__ float red[4];
     const int tid = (int)threadIdx.x;
     // contiguous chunk per block, 16-byte vector loads on the aligned interior
-    const long per = (((n + NORM_BLOCKS - 1) / NORM_BLOCKS) + 3) & ~3L;
+    const long per = (((n + nblk - 1) / nblk) + 3) & ~3L;
     const long beg = (long)blockIdx.x * per;
     long end = beg + per;
     if (end > n) end = n;
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void sumsq_stage1_kernel(const float* __restri
 }
 
 // out[0] (=|+=) sum(partial[0..NORM_BLOCKS))
-__global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out, int accumulate, int nblk) {
     __shared__ double red[4];
     const int tid = (int)threadIdx.x;
     double s = 0.0;
-    for (int i = tid; i < NORM_BLOCKS; i += 256) s += (double)partial[i];
+    for (int i = tid; i < nblk; i += 256) s += (double)partial[i];
     s = lv_wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
@@ -130,6 +130,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// out[0] += sum(x[0..n))  (single workgroup; n is a batch size)
+__global__ __launch_bounds__(256) void sum_accum_kernel(const float* __restrict__ x, long n, float* out) {
+    __shared__ float red[4];
+    const int tid = (int)threadIdx.x;
+    float s = 0.f;
+    for (long i = tid; i < n; i += 256) s += x[i];
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void add_scalar_kernel(float* x, float v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) x[0] += v;
 }
@@ -141,8 +153,12 @@ extern "C" int lv_sumsq_workspace_floats() { return NORM_BLOCKS; }
 // out[0] (=|+=) sum(x[i]^2); ws: lv_sumsq_workspace_floats() floats.  Deterministic two-stage reduction.
 extern "C" int lv_sumsq_f32(const float* x, long n, float* ws, float* out, int accumulate, void* stream) {
     if (!x || !ws || !out || n < 0) return LV_ERR_ARG;
-    LV_LAUNCH(sumsq_stage1_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, x, n, ws);
-    LV_LAUNCH(sumsq_stage2_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, out, accumulate);
+    long nb = (n + 8191) / 8192;
+    if (nb < 1) nb = 1;
+    if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
+    const int nblk = (int)nb;
+    LV_LAUNCH(sumsq_stage1_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, x, n, ws, nblk);
+    LV_LAUNCH(sumsq_stage2_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, out, accumulate, nblk);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -185,6 +201,13 @@ extern "C" int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, 
     if (n == 0) return LV_OK;
     LV_LAUNCH(adam_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, m, v, n, lr_dev, coef_dev, step_dev,
               beta1, beta2, eps, write_back_clipped);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_sum_accum_f32(const float* x, long n, float* out_dev, void* stream) {
+    if (!x || !out_dev || n < 0) return LV_ERR_ARG;
+    LV_LAUNCH(sum_accum_kernel, dim3(1), dim3(256), 0, stream, x, n, out_dev);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

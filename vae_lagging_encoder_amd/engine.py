@@ -1,0 +1,402 @@
+"""Host-side sequencing of the gfx950 kernels for the LSTM-VAE hot path.
+
+This is the layer between the reference's Python class surface (modules/*.py mirrors) and the C ABI in
+include/lvae.h.  PyTorch is used only for device memory (torch.empty), the current HIP stream and autograd
+plumbing; every arithmetic op on the hot path is a call into liblvae_hip.so.
+
+Layout contract: token ids stay batch-first int64 [B][T] exactly as the reference's
+create_data_batch hands them over (data/text_data.py:219-255); every activation is time-major ([T][B][*]) so one
+LSTM timestep is a contiguous slab; parameters of one module live in one flat fp32 buffer (FlatBuffer) whose
+segments back the module's nn.Parameters, gradients in a parallel flat buffer.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+# ---- backend selection -------------------------------------------------------------------------------
+_TEST_BACKEND = None   # set ONLY by tests (tests/emu) to run the host sequencing against the emulator build
+
+
+def _install_test_backend(lib):
+    """TEST HOOK (tests/emu only): route CPU tensors to an emulator build of the same kernel sources.
+
+    The product never calls this; without it, any non-CUDA tensor raises.  See tests/emu/README.md."""
+    global _TEST_BACKEND
+    _TEST_BACKEND = lib
+
+
+def backend_for(device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return _lib.load()
+    if _TEST_BACKEND is not None and device.type == "cpu":
+        return _TEST_BACKEND
+    raise _lib.LvaeError(
+        "vae_lagging_encoder_amd runs on MI355X (ROCm 'cuda' tensors) through its HIP extension; got a %s tensor. "
+        "There is no CPU fallback." % device.type)
+
+
+def stream_ptr(device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None
+
+
+def P(t, offset_elems=0):
+    """Raw device pointer of tensor t (+ element offset); None -> NULL."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class FlatBuffer(object):
+    """One flat fp32 buffer for a module's parameters and one for its gradients; each nn.Parameter's .data is
+    re-pointed to a 16-byte-aligned segment so the global grad-norm / clip+SGD are single streaming passes."""
+
+    def __init__(self, named_params, device):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.offsets = {}
+        off = 0
+        for n, p in named_params:
+            self.offsets[n] = off
+            off += _round_up(p.numel(), 4)
+        self.numel = off
+        self.device = torch.device(device)
+        self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.views, self.gviews = {}, {}
+        for n, p in named_params:
+            o = self.offsets[n]
+            v = self.data[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data.to(self.device, torch.float32))
+            p.data = v
+            self.views[n] = v
+            self.gviews[n] = self.grad[o:o + p.numel()].view(p.shape)
+
+    def bound(self):
+        return all(p.data_ptr() == self.views[n].data_ptr() for n, p in zip(self.names, self.params))
+
+    def attach_grads(self):
+        """Make param.grad alias the flat gradient segments (fused driver path)."""
+        for n, p in zip(self.names, self.params):
+            p.grad = self.gviews[n]
+
+
+class _WS(object):
+    """Shape-keyed cache of device workspaces."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cache = {}
+
+    def get(self, key, builder):
+        ws = self.cache.get(key)
+        if ws is None:
+            ws = builder()
+            self.cache[key] = ws
+        return ws
+
+    def f32(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def i32(self, *shape):
+        return torch.empty(*shape, dtype=torch.int32, device=self.device)
+
+
+class _NS(object):
+    pass
+
+
+# bench.py's roofline leg: when set to a list, every GEMM launch is bracketed by HIP events recorded on the launch
+# stream and (start, end, flops) is appended (measurement only; None in normal operation).
+GEMM_PROFILE = None
+
+
+def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add1=None, ld1=0, mod1=1,
+          add2=None, ld2=0, mod2=1):
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib.lv_gemm_f32(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, s)
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
+
+
+class LSTMEncoderEngine(object):
+    """Forward/backward of LSTMEncoder.forward (reference modules/encoders/enc_lstm.py:47-64)."""
+
+    def __init__(self, module):
+        self.m = module
+        self.flat = None
+        self.wsc = None
+        self.gen = 0
+
+    def ensure(self, device):
+        device = torch.device(device)
+        if self.flat is None or self.flat.device != device or not self.flat.bound():
+            named = [("embed.weight", self.m.embed.weight), ("lstm.weight_ih_l0", self.m.lstm.weight_ih_l0),
+                     ("lstm.weight_hh_l0", self.m.lstm.weight_hh_l0), ("lstm.bias_ih_l0", self.m.lstm.bias_ih_l0),
+                     ("lstm.bias_hh_l0", self.m.lstm.bias_hh_l0), ("linear.weight", self.m.linear.weight)]
+            self.flat = FlatBuffer(named, device)
+            self.wsc = _WS(device)
+        self.lib = backend_for(device)
+        return self.flat
+
+    def dims(self):
+        V, ni = self.m.embed.weight.shape
+        H = self.m.lstm.weight_hh_l0.shape[1]
+        nz2 = self.m.linear.weight.shape[0]
+        return V, ni, H, nz2
+
+    def _ws(self, B, T):
+        V, ni, H, nz2 = self.dims()
+        c = self.wsc
+
+        def build():
+            w = _NS()
+            w.X = c.f32(T * B, ni)
+            w.Gx = c.f32(T * B, 4 * H)
+            w.hs = c.f32(T + 1, B, H)
+            w.cs = c.f32(T + 1, B, H)
+            w.gates = c.f32(T * B, 4 * H)
+            w.mulv = c.f32(B, nz2)
+            w.dG = c.f32(T * B, 4 * H)
+            w.dGsum = c.f32(B, 4 * H)
+            w.part = c.f32(self.lib.lv_lstm_bwd_ksplit(H), B, H)
+            w.dc_rec = c.f32(B, H)
+            w.dhT = c.f32(B, H)
+            w.dX = c.f32(T * B, ni)
+            w.whhT = c.f32(H, 4 * H)
+            w.srows = c.i32(T * B)
+            w.stok = c.i32(T * B)
+            w.stmp = c.i32(2 * T * B)
+            return w
+        return c.get((B, T), build)
+
+    def forward(self, x):
+        """x int64 [B][T] on device -> mulv [B][2nz] (mu | logvar).  Keeps activations for backward()."""
+        assert x.dtype == torch.int64 and x.dim() == 2
+        x = x.contiguous()
+        B, T = x.shape
+        f = self.ensure(x.device)
+        lib, s = self.lib, stream_ptr(x.device)
+        V, ni, H, nz2 = self.dims()
+        w = self._ws(B, T)
+        v = f.views
+        lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
+        _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
+              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
+        w.hs[0].zero_()
+        w.cs[0].zero_()
+        lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None,
+                            T, B, H, s)
+        _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
+        self.gen += 1
+        self.last = (x, B, T, self.gen)
+        return w.mulv
+
+    def backward(self, dmulv, gen=None):
+        """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics)."""
+        x, B, T, g = self.last
+        if gen is not None and gen != g:
+            raise _lib.LvaeError("encoder activations were overwritten by a later forward(); the HIP engine keeps "
+                                 "one in-flight step per module")
+        f = self.flat
+        lib, s = self.lib, stream_ptr(x.device)
+        V, ni, H, nz2 = self.dims()
+        w = self._ws(B, T)
+        v, gv = f.views, f.gviews
+        dmulv = dmulv.contiguous()
+        # head: dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T
+        _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
+        _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
+        lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
+        lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG), P(w.dGsum),
+                            P(w.part), P(w.dc_rec), None, None, 0, T, B, H, s)
+        # input-side grads
+        _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni)
+        _gemm(lib, s, 1, 0, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni)
+        _gemm(lib, s, 1, 0, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H)
+        lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
+        gv["embed.weight"].zero_()
+        lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
+        lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(w.srows), P(w.stok), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
+
+
+class LSTMDecoderEngine(object):
+    """Forward/backward of LSTMDecoder.reconstruct_error (reference modules/decoders/dec_lstm.py:66-148)."""
+
+    def __init__(self, module):
+        self.m = module
+        self.flat = None
+        self.wsc = None
+        self.gen = 0
+
+    def ensure(self, device):
+        device = torch.device(device)
+        if self.flat is None or self.flat.device != device or not self.flat.bound():
+            m = self.m
+            named = [("embed.weight", m.embed.weight), ("trans_linear.weight", m.trans_linear.weight),
+                     ("lstm.weight_ih_l0", m.lstm.weight_ih_l0), ("lstm.weight_hh_l0", m.lstm.weight_hh_l0),
+                     ("lstm.bias_ih_l0", m.lstm.bias_ih_l0), ("lstm.bias_hh_l0", m.lstm.bias_hh_l0),
+                     ("pred_linear.weight", m.pred_linear.weight)]
+            self.flat = FlatBuffer(named, device)
+            self.wsc = _WS(device)
+        self.lib = backend_for(device)
+        return self.flat
+
+    def dims(self):
+        V, ni = self.m.embed.weight.shape
+        H = self.m.lstm.weight_hh_l0.shape[1]
+        nz = self.m.trans_linear.weight.shape[1]
+        return V, ni, H, nz
+
+    def _ws(self, Bd, Td):
+        V, ni, H, nz = self.dims()
+        c = self.wsc
+        ldl = _round_up(V, 32)
+
+        def build():
+            w = _NS()
+            w.ldl = ldl
+            w.X = c.f32(Td * Bd, ni)
+            w.Zp = c.f32(Bd, 4 * H)
+            w.Gx = c.f32(Td * Bd, 4 * H)
+            w.hs = c.f32(Td + 1, Bd, H)
+            w.cs = c.f32(Td + 1, Bd, H)
+            w.gates = c.f32(Td * Bd, 4 * H)
+            w.O = c.f32(Td * Bd, H)
+            w.logits = c.f32(Td * Bd, ldl)
+            w.lse = c.f32(Td * Bd)
+            w.nll = c.f32(Td * Bd)
+            w.rec = c.f32(Bd)
+            w.dO = c.f32(Td * Bd, H)
+            w.dG = c.f32(Td * Bd, 4 * H)
+            w.dGsum = c.f32(Bd, 4 * H)
+            w.part = c.f32(self.lib.lv_lstm_bwd_ksplit(H), Bd, H)
+            w.dc_rec = c.f32(Bd, H)
+            w.dc0 = c.f32(Bd, H)
+            w.dX = c.f32(Td * Bd, ni)
+            w.dz = c.f32(Bd, nz)
+            w.whhT = c.f32(H, 4 * H)
+            w.srows = c.i32(Td * Bd)
+            w.stok = c.i32(Td * Bd)
+            w.stmp = c.i32(2 * Td * Bd)
+            w.zero1 = torch.zeros(1, dtype=torch.float32, device=c.device)
+            w.klz = torch.zeros(Bd, dtype=torch.float32, device=c.device)
+            w.loss = c.f32(Bd)
+            return w
+        return c.get((Bd, Td), build)
+
+    def forward(self, x, z, mask_in, mask_out, p_in, p_out):
+        """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
+        batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B]."""
+        assert x.dtype == torch.int64 and x.dim() == 2
+        x = x.contiguous()
+        B, T = x.shape
+        Td = T - 1
+        if z.dim() != 3 or z.shape[1] != 1:
+            raise _lib.LvaeError("the HIP decoder path takes nsamples == 1 (z of shape [B,1,nz]); got %s" % (tuple(z.shape),))
+        z2 = z.reshape(B, -1).contiguous()
+        f = self.ensure(x.device)
+        lib, s = self.lib, stream_ptr(x.device)
+        V, ni, H, nz = self.dims()
+        w = self._ws(B, Td)
+        v = f.views
+        sc_in = 1.0 / (1.0 - p_in) if mask_in is not None else 1.0
+        sc_out = 1.0 / (1.0 - p_out) if mask_out is not None else 1.0
+        if mask_in is not None:
+            assert mask_in.dtype == torch.uint8 and tuple(mask_in.shape) == (B, Td, ni) and mask_in.is_contiguous()
+        if mask_out is not None:
+            assert mask_out.dtype == torch.uint8 and tuple(mask_out.shape) == (B, Td, H) and mask_out.is_contiguous()
+        lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
+        # c0 = z W_trans^T ; h0 = tanh(c0)   (dec_lstm.py:99-101)
+        _gemm(lib, s, 0, 1, B, H, nz, P(z2), nz, P(v["trans_linear.weight"]), nz, P(w.cs), H)
+        lib.lv_tanh_f32(P(w.cs), P(w.hs), B * H, s)
+        # Zp = z W_ih[:, ni:]^T + b_ih + b_hh ; Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised)
+        wih = v["lstm.weight_ih_l0"]
+        _gemm(lib, s, 0, 1, B, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
+              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
+        _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
+              add1=P(w.Zp), ld1=4 * H, mod1=B)
+        lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
+                            P(w.O), Td, B, H, s)
+        _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl)
+        lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
+        # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
+        lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
+        self.gen += 1
+        self.last = (x, z2, mask_in, mask_out, sc_in, sc_out, B, T, self.gen)
+        return w.rec
+
+    def backward(self, drec, gen=None):
+        """drec [B] = dL/d rec_b -> fills self.flat.grad; returns dz [B][nz]."""
+        x, z2, mask_in, mask_out, sc_in, sc_out, B, T, g = self.last
+        if gen is not None and gen != g:
+            raise _lib.LvaeError("decoder activations were overwritten by a later forward(); the HIP engine keeps "
+                                 "one in-flight step per module")
+        Td = T - 1
+        f = self.flat
+        lib, s = self.lib, stream_ptr(x.device)
+        V, ni, H, nz = self.dims()
+        w = self._ws(B, Td)
+        v, gv = f.views, f.gviews
+        drec = drec.contiguous()
+        wih = v["lstm.weight_ih_l0"]
+        gwih = gv["lstm.weight_ih_l0"]
+        lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
+        _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H)
+        _gemm(lib, s, 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H)
+        lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
+        lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG),
+                            P(w.dGsum), P(w.part), P(w.dc_rec), None, P(w.dc0), 1, Td, B, H, s)
+        _gemm(lib, s, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni)
+        _gemm(lib, s, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz)
+        _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
+        _gemm(lib, s, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H)
+        lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
+        # dz = dGsum . W_ih[:, ni:] + dc0 . W_trans ; dW_trans = dc0^T . z
+        _gemm(lib, s, 0, 0, B, nz, 4 * H, P(w.dGsum), 4 * H, P(wih, ni), ni + nz, P(w.dz), nz)
+        _gemm(lib, s, 0, 0, B, nz, H, P(w.dc0), H, P(v["trans_linear.weight"]), nz, P(w.dz), nz, acc=1)
+        _gemm(lib, s, 1, 0, H, nz, B, P(w.dc0), H, P(z2), nz, P(gv["trans_linear.weight"]), nz)
+        gv["embed.weight"].zero_()
+        lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
+        lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
+                                 V - 1, 0, s)
+        return w.dz
+
+
+def reparam_kl_forward(mulv, eps):
+    """mulv [B][2nz], eps [B][ns][nz] -> z [B][ns][nz], kl [B]   (encoder.py:53-55, 71-79)."""
+    lib, s = backend_for(mulv.device), stream_ptr(mulv.device)
+    B, nz2 = mulv.shape
+    nz = nz2 // 2
+    ns = eps.shape[1]
+    mulv = mulv.contiguous()
+    eps = eps.contiguous()
+    z = torch.empty(B, ns, nz, dtype=torch.float32, device=mulv.device)
+    kl = torch.empty(B, dtype=torch.float32, device=mulv.device)
+    lib.lv_reparam_kl_fwd_f32(P(mulv), P(eps), P(z), P(kl), B, ns, nz, s)
+    return z, kl
+
+
+def reparam_kl_backward(mulv, eps, dz, dkl):
+    lib, s = backend_for(mulv.device), stream_ptr(mulv.device)
+    B, nz2 = mulv.shape
+    nz = nz2 // 2
+    ns = eps.shape[1]
+    dmulv = torch.empty_like(mulv)
+    lib.lv_reparam_kl_bwd_f32(P(mulv.contiguous()), P(eps.contiguous()), P(dz.contiguous()), P(dkl.contiguous()),
+                              P(dmulv), B, ns, nz, s)
+    return dmulv

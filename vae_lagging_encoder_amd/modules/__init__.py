@@ -1,0 +1,7 @@
+"""Mirror of the reference's `modules` package surface (modules/__init__.py) for the hot path."""
+from .utils import log_sum_exp, generate_grid
+from .encoders import GaussianEncoderBase, LSTMEncoder
+from .decoders import DecoderBase, LSTMDecoder
+from .vae import VAE
+
+__all__ = ["VAE", "GaussianEncoderBase", "LSTMEncoder", "DecoderBase", "LSTMDecoder", "log_sum_exp", "generate_grid"]

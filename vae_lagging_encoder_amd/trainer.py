@@ -1,0 +1,227 @@
+"""Fused driver for the aggressive inference-network loop (reference text.py:366-424).
+
+`AggressiveTextTrainer.step()` is one body of the inner loop -- zero_grad, VAE.loss, loss.mean().backward(),
+clip_grad_norm_(all params, 5.0), encoder SGD step (text.py:373-387) -- as one stream-ordered sequence of C-ABI
+kernel calls with NO host synchronisation and no autograd: scalars (kl weight, lr, norm, clip coefficient, the
+running loss sum that text.py:381 pulls to the host every iteration) stay in device memory, so the sequence can be
+captured once per (B, T) bucket into a hipGraph and replayed (`use_graph=True`).
+`inner_loop()` reproduces the data-dependent exit of text.py:366-400 with one host read every 15 iterations
+instead of one per iteration.  Data parallelism (one process per GPU) plugs in through `dist.GradSync`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import engine as _eng
+from .engine import P
+
+
+class _Static(object):
+    pass
+
+
+class AggressiveTextTrainer(object):
+    def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None):
+        self.vae = vae
+        self.enc = vae.encoder._hip
+        self.dec = vae.decoder._hip
+        self.device = torch.device(device) if device is not None else next(vae.parameters()).device
+        self.enc.ensure(self.device)
+        self.dec.ensure(self.device)
+        self.enc.flat.attach_grads()
+        self.dec.flat.attach_grads()
+        self.lib = _eng.backend_for(self.device)
+        self.clip = float(clip)
+        self.grad_sync = grad_sync
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        d = self.device
+        # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum]
+        self.scal = torch.zeros(8, dtype=torch.float32, device=d)
+        self.scal[1] = lr
+        self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=d)   # Philox (seed, offset), uint64 bits
+        self.static = {}
+
+    # -- scalar views ------------------------------------------------------------------------------
+    def _s(self, i):
+        return P(self.scal, i)
+
+    def set_lr(self, lr):
+        self.scal[1] = lr
+
+    def read_stats(self):
+        """One host read: dict(loss_sum, rec_sum, kl_sum, norm, coef) accumulated since reset_stats()."""
+        v = self.scal.cpu().tolist()
+        return dict(loss_sum=v[5], rec_sum=v[6], kl_sum=v[7], norm=v[4], coef=v[3])
+
+    def reset_stats(self):
+        self.scal[5:8] = 0
+
+    # -- per-(B,T) static state ----------------------------------------------------------------------
+    def _static_for(self, B, T):
+        st = self.static.get((B, T))
+        if st is None:
+            d = self.device
+            V, ni, H, nz = self.dec.dims()
+            st = _Static()
+            st.x = torch.zeros(B, T, dtype=torch.int64, device=d)
+            st.eps = torch.zeros(B, 1, nz, dtype=torch.float32, device=d)
+            st.m_in = torch.ones(B, T - 1, ni, dtype=torch.uint8, device=d)
+            st.m_out = torch.ones(B, T - 1, H, dtype=torch.uint8, device=d)
+            st.z = torch.empty(B, 1, nz, dtype=torch.float32, device=d)
+            st.kl = torch.empty(B, dtype=torch.float32, device=d)
+            st.loss = torch.empty(B, dtype=torch.float32, device=d)
+            st.rec = torch.empty(B, dtype=torch.float32, device=d)
+            st.gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=d)   # d(mean_b loss_b)/d loss_b
+            st.rowscale = torch.empty(B, dtype=torch.float32, device=d)
+            st.dkl = torch.empty(B, dtype=torch.float32, device=d)
+            st.dmulv = torch.empty(B, 2 * nz, dtype=torch.float32, device=d)
+            st.graphs = {}
+            self.static[(B, T)] = st
+        return st
+
+    # -- the step ----------------------------------------------------------------------------------------
+    def _draw_noise(self, st, s):
+        """Throughput mode: eps and both dropout keep-masks from the on-device Philox stream."""
+        lib = self.lib
+        p_in, p_out = self.vae.decoder.dropout_in.p, self.vae.decoder.dropout_out.p
+        lib.lv_rng_normal_f32(P(st.eps), st.eps.numel(), P(self.rng_state), 0, s)
+        lib.lv_rng_keepmask_u8(P(st.m_in), st.m_in.numel(), 1.0 - p_in, P(self.rng_state), 1, s)
+        lib.lv_rng_keepmask_u8(P(st.m_out), st.m_out.numel(), 1.0 - p_out, P(self.rng_state), 2, s)
+        lib.lv_rng_advance(P(self.rng_state), 1, s)
+
+    def _fwd_bwd(self, st, draw):
+        lib, s = self.lib, _eng.stream_ptr(self.device)
+        B, T = st.x.shape
+        dec = self.vae.decoder
+        train = self.vae.training
+        if draw and train:
+            self._draw_noise(st, s)
+        elif draw:
+            lib.lv_rng_normal_f32(P(st.eps), st.eps.numel(), P(self.rng_state), 0, s)
+            lib.lv_rng_advance(P(self.rng_state), 1, s)
+        m_in = st.m_in if (train and dec.dropout_in.p > 0) else None
+        m_out = st.m_out if (train and dec.dropout_out.p > 0) else None
+        mulv = self.enc.forward(st.x)
+        nz = mulv.shape[1] // 2
+        lib.lv_reparam_kl_fwd_f32(P(mulv), P(st.eps), P(st.z), P(st.kl), B, 1, nz, s)
+        self.dec.forward(st.x, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p)
+        w = self.dec._ws(B, T - 1)
+        lib.lv_vae_loss_f32(P(w.nll), P(st.kl), self._s(0), P(st.loss), P(st.rec), T - 1, B, s)
+        lib.lv_sum_accum_f32(P(st.loss), B, self._s(5), s)
+        lib.lv_sum_accum_f32(P(st.rec), B, self._s(6), s)
+        lib.lv_sum_accum_f32(P(st.kl), B, self._s(7), s)
+        # backward of mean_b(loss_b)
+        lib.lv_loss_bwd_scales_f32(P(st.gl), None, None, self._s(0), P(st.rowscale), P(st.dkl), B, s)
+        dz = self.dec.backward(st.rowscale)
+        lib.lv_reparam_kl_bwd_f32(P(mulv), P(st.eps), P(dz), P(st.dkl), P(st.dmulv), B, 1, nz, s)
+        self.enc.backward(st.dmulv)
+
+    def _clip_and_step(self, update):
+        lib, s = self.lib, _eng.stream_ptr(self.device)
+        ef, df = self.enc.flat, self.dec.flat
+        lib.lv_sumsq_f32(P(ef.grad), ef.numel, P(self.norm_ws), self._s(2), 0, s)
+        lib.lv_sumsq_f32(P(df.grad), df.numel, P(self.norm_ws), self._s(2), 1, s)
+        lib.lv_clip_coef_f32(self._s(2), self.clip, self._s(3), self._s(4), s)
+        # clip_grad_norm_ scales every grad in place; the update only touches the stepped side
+        if update in ("encoder", "both"):
+            lib.lv_sgd_step_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, s)
+        else:
+            lib.lv_scale_f32(P(ef.grad), ef.numel, self._s(3), s)
+        if update in ("decoder", "both"):
+            lib.lv_sgd_step_f32(P(df.data), P(df.grad), df.numel, self._s(1), self._s(3), 1, s)
+        else:
+            lib.lv_scale_f32(P(df.grad), df.numel, self._s(3), s)
+
+    def _run(self, st, update, draw):
+        self._fwd_bwd(st, draw)
+        if self.grad_sync is not None:
+            self.grad_sync.sync(self.enc.flat, self.dec.flat)
+        self._clip_and_step(update)
+
+    def step(self, x, kl_weight, noise=None, update="encoder"):
+        """One body of the aggressive loop on batch x (int64 [B][T] on device).
+
+        noise=(eps, mask_in, mask_out) injects the random draws (parity mode); None draws them on device.
+        update: 'encoder' (inner loop, text.py:387), 'decoder' (joint step while aggressive, text.py:419-424)
+        or 'both' (joint step after aggressive mode ends)."""
+        B, T = x.shape
+        st = self._static_for(B, T)
+        st.x.copy_(x)
+        self.scal[0] = float(kl_weight)
+        draw = noise is None
+        if not draw:
+            eps, m_in, m_out = noise
+            st.eps.copy_(eps.reshape(st.eps.shape))
+            if m_in is not None:
+                st.m_in.copy_(m_in)
+            if m_out is not None:
+                st.m_out.copy_(m_out)
+        if not self.use_graph:
+            self._run(st, update, draw)
+            return
+        key = (update, draw, self.vae.training)
+        g = st.graphs.get(key)
+        if g is None:
+            # eager warm-up (allocates every workspace), then capture
+            self._run(st, update, draw)
+            torch.cuda.synchronize(self.device)
+            g = self._capture(st, update, draw)
+            st.graphs[key] = g
+            return
+        for part in g:
+            part()
+
+    def _capture(self, st, update, draw):
+        """Capture the step as hipGraph(s).  With a gradient all-reduce the step is split around it
+        (fwd+bwd graph | RCCL all-reduce | clip+SGD graph): collectives are not captured."""
+        parts = []
+        stream = torch.cuda.Stream(self.device)
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+
+        def cap(fn):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=stream):
+                fn()
+            return gr.replay
+        if self.grad_sync is None:
+            parts.append(cap(lambda: (self._fwd_bwd(st, draw), self._clip_and_step(update))))
+        else:
+            parts.append(cap(lambda: self._fwd_bwd(st, draw)))
+            parts.append(lambda: self.grad_sync.sync(self.enc.flat, self.dec.flat))
+            parts.append(cap(lambda: self._clip_and_step(update)))
+        return parts
+
+    # -- the loop of text.py:366-400 ------------------------------------------------------------------------
+    def inner_loop(self, batches, first, kl_weight, np_rng=None, max_iter=100, window=15, fixed_k=None, noise_fn=None):
+        """Run the aggressive inner loop starting on batch `first`; later batches are drawn with
+        np_rng.random_integers(0, len-1) semantics (text.py:389).  Returns the number of encoder steps taken.
+
+        fixed_k: run exactly that many steps with no data-dependent exit (BASELINE.json stress config)."""
+        rng = np_rng if np_rng is not None else np.random
+        sub_iter = 1
+        x = first
+        burn_num_words = 0
+        burn_pre_loss = 1e4
+        self.reset_stats()
+        steps = 0
+        while sub_iter < max_iter:
+            B, T = x.shape
+            burn_num_words += (T - 1) * B
+            self.step(x, kl_weight, noise=None if noise_fn is None else noise_fn(x), update="encoder")
+            steps += 1
+            idx = int(rng.randint(0, len(batches)))
+            x = batches[idx]
+            if fixed_k is not None:
+                if steps >= fixed_k:
+                    break
+            elif sub_iter % window == 0:
+                cur = self.read_stats()["loss_sum"] / burn_num_words     # the only host sync of the window
+                if burn_pre_loss - cur < 0:
+                    break
+                burn_pre_loss = cur
+                burn_num_words = 0
+                self.reset_stats()
+            sub_iter += 1
+        return steps
