@@ -77,7 +77,7 @@ def test_yelp_full_size_fixture(hip_device):
     loss.mean(dim=-1).backward()
     assert rel_err(loss, fx["loss"]) < 1e-4
     assert rel_err(rec, fx["rec"]) < 1e-4
-    assert float(np.abs(kl.cpu().numpy() - fx["kl"]).max()) < 1e-4 * float(np.abs(fx["kl"]).max()) + 1e-6 * (1 + float(np.abs(fx["rec"]).max()))
+    assert float(np.abs(kl.detach().cpu().numpy() - fx["kl"]).max()) < 1e-4 * float(np.abs(fx["kl"]).max()) + 1e-6 * (1 + float(np.abs(fx["rec"]).max()))
     named = dict(vae.named_parameters())
     for k in ALL_KEYS:
         gn = float(named[k].grad.double().norm())
@@ -117,7 +117,7 @@ def test_properties_at_bench_size(hip_device):
     vae = build_vae(V, ni, H, nz, hip_device, seed=783435)
     sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
     x = O.synthetic_batch(B, T, V, seed=5).to(hip_device)
-    x[0, 3] = V - 1
+    x[0, T - 2] = V - 1      # late position: the encoder gradient reaching an early token underflows to 0 at this init
     eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=6)
     noise = (eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device))
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0)
