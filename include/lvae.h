@@ -31,7 +31,8 @@ extern "C" {
  * torch.cat((word_embed, z_), -1) (dec_lstm.py:97) is never materialised. */
 int lv_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                 const float* A, long lda, const float* B, long ldb, float* C, long ldc, int accumulate,
-                const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2, void* stream);
+                const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
+                float* ws /* optional split-K scratch */, long ws_floats, void* stream);
 
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);

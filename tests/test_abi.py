@@ -37,8 +37,8 @@ def test_hip_library_builds_loads_and_exports_everything():
 def test_argument_checks_return_negative_status_without_touching_the_gpu():
     lib = _lib.bind(ctypes.CDLL(build.build_hip()))
     raw = lib.cdll.lv_gemm_f32
-    assert raw(0, 1, -1, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None) < 0
-    assert raw(0, 1, 4, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None) < 0   # NULL operands
+    assert raw(0, 1, -1, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None, 0, None) < 0
+    assert raw(0, 1, 4, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None, 0, None) < 0   # NULL operands
     assert lib.cdll.lv_lstm_fwd_f32(None, None, None, None, None, None, 1.0, None, 1, 1, 1, None) < 0
 
 

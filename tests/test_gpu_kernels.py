@@ -23,7 +23,8 @@ def _s(dev):
 @pytest.mark.parametrize("tA,tB,M,N,K", [
     (0, 1, 130, 140, 37), (0, 0, 130, 140, 37), (1, 0, 70, 260, 50), (1, 1, 33, 17, 20),
     (0, 1, 512, 4096, 512), (0, 0, 640, 1024, 2001), (1, 0, 2001, 1024, 640), (0, 1, 32, 64, 1024),
-    (0, 1, 1, 1, 1), (0, 1, 257, 129, 16), (1, 0, 4096, 32, 32),
+    (0, 1, 1, 1, 1), (0, 1, 257, 129, 16), (1, 0, 4096, 32, 32), (0, 0, 32, 32, 4096), (1, 0, 512, 256, 6368),
+    (0, 1, 4000, 4100, 64), (0, 0, 100, 70, 3000),
 ])
 def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -38,7 +39,8 @@ def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
     Bop = (B[:, :K].t() if tB else B[:, :N]).double()
     ref = 0.5 * (Aop @ Bop) + add1[torch.arange(M) % 5].double() + add2.double() + C0[:, :N].double()
     Ad, Bd, Cd, a1, a2 = (t.to(hip_device) for t in (A, B, C0.clone(), add1, add2))
-    lib.lv_gemm_f32(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, P(a2), N, 1, _s(hip_device))
+    ws = torch.empty(1 << 20, device=hip_device)
+    lib.lv_gemm_f32(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, P(a2), N, 1, P(ws), ws.numel(), _s(hip_device))
     out = Cd.cpu()
     assert torch.equal(out[:, N:], C0[:, N:])          # padding columns untouched
     err = float((out[:, :N].double() - ref).abs().max())
@@ -54,7 +56,7 @@ def test_gemm_unaligned_rows(lib, hip_device):
     ref = A[:, 1:].double() @ B[:, 1:].double().t()
     Ad, Bd = A.to(hip_device), B.to(hip_device)
     C = torch.zeros(M, N, device=hip_device)
-    lib.lv_gemm_f32(0, 1, M, N, K, 1.0, P(Ad, 1), 51, P(Bd, 1), 51, P(C), N, 0, None, 0, 1, None, 0, 1, _s(hip_device))
+    lib.lv_gemm_f32(0, 1, M, N, K, 1.0, P(Ad, 1), 51, P(Bd, 1), 51, P(C), N, 0, None, 0, 1, None, 0, 1, None, 0, _s(hip_device))
     assert float((C.cpu().double() - ref).abs().max()) < 1e-4
 
 

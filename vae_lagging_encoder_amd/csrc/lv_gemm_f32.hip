@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int BK = 16;
 
 struct GemmP {
     const float* A; const float* B; float* C;
@@ -27,6 +27,8 @@ struct GemmP {
     const float* add1; long ld1; int mod1;
     const float* add2; long ld2; int mod2;
     int tilesM, tilesN;
+    int splits, kt_per_split;      // split-K: blockIdx.y = slice, output slab ws[slice][M][N]
+    float* ws;
 };
 
 __device__ __forceinline__ float4 lv_load4(const float* __restrict__ base, long row, long col, long ld,
@@ -47,42 +49,44 @@ __device__ __forceinline__ float4 lv_load4(const float* __restrict__ base, long 
 }
 
 // KC = operand is contiguous along the contraction index (stored [rows][K]); otherwise stored [K][rows].
-template <bool KC>
+// WT = 32-wide MFMA tiles per wave per dimension: block tile = (64*WT) x (64*WT), WT float4 per thread per operand.
+template <bool KC, int WT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int rows, int K, int r0, int k0,
-                                          bool vec, int t, float4 (&reg)[2]) {
+                                          bool vec, int t, float4 (&reg)[WT]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = t + 256 * i;
+    for (int i = 0; i < WT; ++i) {
+        const int f = t + 256 * i;
         if (KC) {
-            int m = f >> 2, kq = f & 3;
+            const int m = f >> 2, kq = f & 3;
             reg[i] = lv_load4(P, r0 + m, k0 + 4 * kq, ld, rows, K, vec);
         } else {
-            int k = f >> 5, mq = f & 31;
+            const int k = f / (16 * WT), mq = f % (16 * WT);
             reg[i] = lv_load4(P, k0 + k, r0 + 4 * mq, ld, K, rows, vec);
         }
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[LDT], int t, const float4 (&reg)[2]) {
+template <bool KC, int WT>
+__device__ __forceinline__ void store_tile(float (*S)[64 * WT + 4], int t, const float4 (&reg)[WT]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = t + 256 * i;
+    for (int i = 0; i < WT; ++i) {
+        const int f = t + 256 * i;
         if (KC) {
-            int m = f >> 2, kq = f & 3;
+            const int m = f >> 2, kq = f & 3;
             S[4 * kq + 0][m] = reg[i].x;
             S[4 * kq + 1][m] = reg[i].y;
             S[4 * kq + 2][m] = reg[i].z;
             S[4 * kq + 3][m] = reg[i].w;
         } else {
-            int k = f >> 5, mq = f & 31;
+            const int k = f / (16 * WT), mq = f % (16 * WT);
             *reinterpret_cast<float4*>(&S[k][4 * mq]) = reg[i];
         }
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int WT>
 __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
+    constexpr int BT = 64 * WT, LDT = BT + 4;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
 
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
     const int gsz = (p.tilesM - first_m) < G ? (p.tilesM - first_m) : G;
     const int tm = first_m + (s % nig) % gsz;
     const int tn = (s % nig) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BT, n0 = tn * BT;
 
     const int t = (int)threadIdx.x;
     const int l = t & 63, w = t >> 6;
@@ -107,66 +111,99 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
     const bool vecA = (p.lda % 4 == 0) && ((((uintptr_t)p.A) & 15) == 0);
     const bool vecB = (p.ldb % 4 == 0) && ((((uintptr_t)p.B) & 15) == 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 ra[2], rb[2];
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile<A_KC>(p.A, p.lda, p.M, p.K, m0, 0, vecA, t, ra);
-    load_tile<B_KC>(p.B, p.ldb, p.N, p.K, n0, 0, vecB, t, rb);
-    store_tile<A_KC>(As[0], t, ra);
-    store_tile<B_KC>(Bs[0], t, rb);
+    float4 ra[WT], rb[WT];
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)blockIdx.y * p.kt_per_split;
+    int kt1 = kt0 + p.kt_per_split;
+    if (kt1 > nk_all) kt1 = nk_all;
+    load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, kt0 * BK, vecA, t, ra);
+    load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, vecB, t, rb);
+    store_tile<A_KC, WT>(As[0], t, ra);
+    store_tile<B_KC, WT>(Bs[0], t, rb);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile<A_KC>(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, vecA, t, ra);
-            load_tile<B_KC>(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, vecB, t, rb);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, vecA, t, ra);
+            load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, vecB, t, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (l >> 5);
-            const float a0 = As[buf][kr][wm * 64 + (l & 31)];
-            const float a1 = As[buf][kr][wm * 64 + 32 + (l & 31)];
-            const float b0 = Bs[buf][kr][wn * 64 + (l & 31)];
-            const float b1 = Bs[buf][kr][wn * 64 + 32 + (l & 31)];
-            acc[0][0] = lv_mfma_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = lv_mfma_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = lv_mfma_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = lv_mfma_32x32x2(a1, b1, acc[1][1]);
+            float a[WT], b[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) a[i] = As[buf][kr][wm * 32 * WT + i * 32 + (l & 31)];
+#pragma unroll
+            for (int j = 0; j < WT; ++j) b[j] = Bs[buf][kr][wn * 32 * WT + j * 32 + (l & 31)];
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) acc[i][j] = lv_mfma_32x32x2(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) {
-            store_tile<A_KC>(As[buf ^ 1], t, ra);
-            store_tile<B_KC>(Bs[buf ^ 1], t, rb);
+        if (kt + 1 < kt1) {
+            store_tile<A_KC, WT>(As[buf ^ 1], t, ra);
+            store_tile<B_KC, WT>(Bs[buf ^ 1], t, rb);
         }
         __syncthreads();
     }
 
     // Epilogue: D[row=(e&3)+8*(e>>2)+4*(l>>5)][col=l&31] per 32x32 accumulator.
+    const bool split = p.splits > 1;
+    float* const out = split ? p.ws + (long)blockIdx.y * p.M * p.N : p.C;
+    const long ldo = split ? p.N : p.ldc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (l & 31);
+        for (int j = 0; j < WT; ++j) {
+            const int col = n0 + wn * 32 * WT + j * 32 + (l & 31);
             if (col >= p.N) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                const int row = m0 + wm * 32 * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
                 if (row >= p.M) continue;
+                float* c = out + (long)row * ldo + col;
+                if (split) { *c = acc[i][j][e]; continue; }
                 float v = p.alpha * acc[i][j][e];
                 if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
                 if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
-                float* c = p.C + (long)row * p.ldc + col;
                 if (p.accumulate) v += *c;
                 *c = v;
             }
         }
+}
+
+// C = alpha * sum_s ws[s] (+ addends) (+ C): fixed summation order -> deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long MN = (long)p.M * p.N;
+    if (idx >= MN) return;
+    const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += p.ws[(long)k * MN + idx];
+    float v = p.alpha * s;
+    if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+    if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+    float* c = p.C + (long)row * p.ldc + col;
+    if (p.accumulate) v += *c;
+    *c = v;
+}
+
+template <int WT>
+void launch_gemm(const GemmP& p, bool akc, bool bkc, void* stream) {
+    dim3 grid((unsigned)(p.tilesM * p.tilesN), (unsigned)p.splits), block(256);
+    if (akc && bkc) LV_LAUNCH((lv_gemm_f32_kernel<true, true, WT>), grid, block, 0, stream, p);
+    else if (akc && !bkc) LV_LAUNCH((lv_gemm_f32_kernel<true, false, WT>), grid, block, 0, stream, p);
+    else if (!akc && bkc) LV_LAUNCH((lv_gemm_f32_kernel<false, true, WT>), grid, block, 0, stream, p);
+    else LV_LAUNCH((lv_gemm_f32_kernel<false, false, WT>), grid, block, 0, stream, p);
 }
 
 }  // namespace
@@ -174,11 +211,14 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
 // C[M,N] (ldc) = alpha * op(A)[M,K] * op(B)[K,N]  (+ add1[(row % mod1)*ld1 + col]) (+ add2[...]) (+ C if accumulate)
 // transA = 0: A stored [M][K] (lda >= K);  transA = 1: A stored [K][M] (lda >= M)
 // transB = 0: B stored [K][N] (ldb >= N);  transB = 1: B stored [N][K] (ldb >= K)
+// ws / ws_floats: optional caller-owned scratch for deterministic split-K (used when the output has too few tiles to
+// fill 256 CUs and K is long: wgrad GEMMs, the M = batch "skinny" GEMMs); NULL disables split-K.
 extern "C" int lv_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                            const float* A, long lda, const float* B, long ldb,
                            float* C, long ldc, int accumulate,
                            const float* add1, long ld1, int mod1,
-                           const float* add2, long ld2, int mod2, void* stream) {
+                           const float* add2, long ld2, int mod2,
+                           float* ws, long ws_floats, void* stream) {
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
@@ -189,13 +229,30 @@ extern "C" int lv_gemm_f32(int transA, int transB, int M, int N, int K, float al
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.accumulate = accumulate;
     p.add1 = add1; p.ld1 = ld1; p.mod1 = mod1 > 0 ? mod1 : 1;
     p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
-    p.tilesM = lv_cdiv(M, BM); p.tilesN = lv_cdiv(N, BN);
-    dim3 grid((unsigned)(p.tilesM * p.tilesN)), block(256);
+    p.ws = ws;
+    const int nk = lv_cdiv(K, BK);
+    const long t128 = (long)lv_cdiv(M, 128) * lv_cdiv(N, 128);
+    const bool big = t128 >= 1024;           // >= 4 workgroups per CU with 128x128 tiles; else 64x64 tiles
+    const int BT = big ? 128 : 64;
+    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
+    const long tiles = (long)p.tilesM * p.tilesN;
+    int splits = 1;
+    if (!big && ws && tiles < 256 && nk >= 16) {
+        long s = lv_cdiv(512, tiles);
+        if (s > nk / 8) s = nk / 8;
+        if (s > 64) s = 64;
+        const long cap = ws_floats / ((long)M * N);
+        if (s > cap) s = cap;
+        if (s > 1) splits = (int)s;
+    }
+    p.kt_per_split = lv_cdiv(nk > 0 ? nk : 1, splits);
+    splits = lv_cdiv(nk > 0 ? nk : 1, p.kt_per_split);
+    p.splits = splits;
     const bool akc = !transA, bkc = transB != 0;
-    if (akc && bkc) LV_LAUNCH((lv_gemm_f32_kernel<true, true>), grid, block, 0, stream, p);
-    else if (akc && !bkc) LV_LAUNCH((lv_gemm_f32_kernel<true, false>), grid, block, 0, stream, p);
-    else if (!akc && bkc) LV_LAUNCH((lv_gemm_f32_kernel<false, true>), grid, block, 0, stream, p);
-    else LV_LAUNCH((lv_gemm_f32_kernel<false, false>), grid, block, 0, stream, p);
+    if (big) launch_gemm<2>(p, akc, bkc, stream);
+    else launch_gemm<1>(p, akc, bkc, stream);
+    if (splits > 1)
+        LV_LAUNCH(splitk_reduce_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

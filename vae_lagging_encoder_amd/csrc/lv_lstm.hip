@@ -30,13 +30,15 @@ struct Ld4 { float v[4]; };
 template <bool ALIGNED>
 __device__ __forceinline__ Ld4 ld4(const float* __restrict__ row, bool rvalid, int k, int klim) {
     Ld4 o;
-    o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f;
-    if (rvalid && k < klim) {
-        if (ALIGNED) {
-            // klim % 4 == 0 and k % 4 == 0 in this instantiation, so the float4 is fully inside.
-            float4 t = *reinterpret_cast<const float4*>(row + k);
-            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-        } else {
+    const bool ok = rvalid && k < klim;
+    if (ALIGNED) {
+        // klim % 4 == 0 and k % 4 == 0 in this instantiation, so a float4 at k < klim is fully inside.  The load is
+        // unconditional (clamped to offset 0 of a valid row) and zeroed by select: no exec-mask branch per load.
+        const float4 t = *reinterpret_cast<const float4*>(row + (ok ? k : 0));
+        o.v[0] = ok ? t.x : 0.f; o.v[1] = ok ? t.y : 0.f; o.v[2] = ok ? t.z : 0.f; o.v[3] = ok ? t.w : 0.f;
+    } else {
+        o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f;
+        if (ok) {
             o.v[0] = row[k];
             if (k + 1 < klim) o.v[1] = row[k + 1];
             if (k + 2 < klim) o.v[2] = row[k + 2];
@@ -46,8 +48,11 @@ __device__ __forceinline__ Ld4 ld4(const float* __restrict__ row, bool rvalid, i
     return o;
 }
 
-// acc[mb] += A[rb + mb*16 + (l&15)][kbeg:kend] . W_lane_row[kbeg:kend]^T  (one 16x16 output tile per mb)
-template <int MB, bool ALIGNED>
+// acc[mb] += A[rb + mb*16 + (l&15)][kbeg:kend] . W_lane_row[kbeg:kend]^T  (one 16x16 output tile per mb).
+// The step kernels are latency-bound (one workgroup per CU, one wave per SIMD), so the loads of a whole
+// macro-chunk (NIT x 16 floats of K per operand row) are issued back-to-back into registers before the first
+// MFMA consumes them: at H=1024 a wave's entire K slice (16 iterations, 48 float4 at MB=2) is in flight at once.
+template <int MB, bool ALIGNED, int NIT>
 __device__ __forceinline__ void rec_mm_core(const float* __restrict__ A, long lda, int nrowsA, int rb,
                                             const float* __restrict__ wrow, bool wvalid,
                                             int kbeg, int kend, int l, f32x4 (&acc)[MB]) {
@@ -60,19 +65,43 @@ __device__ __forceinline__ void rec_mm_core(const float* __restrict__ A, long ld
         avalid[mb] = b < nrowsA;
         arow[mb] = A + (long)(avalid[mb] ? b : 0) * lda;
     }
-#pragma unroll 2
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const int kk = k0 + 4 * kq;
-        const Ld4 wv = ld4<ALIGNED>(wrow, wvalid, kk, kend);
-        Ld4 av[MB];
+    // Rows beyond the batch / beyond H read row 0 (a valid address) and their products land in output rows /
+    // columns the epilogue discards, so only the K range needs zero-fill -- and a full macro-chunk needs none.
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * NIT) {
+        Ld4 wv[NIT];
+        Ld4 av[NIT][MB];
+        if (ALIGNED && k0 + 16 * NIT <= kend) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[mb] = ld4<ALIGNED>(arow[mb], avalid[mb], kk, kend);
+            for (int it = 0; it < NIT; ++it) {
+                const int kk = k0 + 16 * it + 4 * kq;
+                const float4 t = *reinterpret_cast<const float4*>(wrow + kk);
+                wv[it].v[0] = t.x; wv[it].v[1] = t.y; wv[it].v[2] = t.z; wv[it].v[3] = t.w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                for (int mb = 0; mb < MB; ++mb) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow[mb] + kk);
+                    av[it][mb].v[0] = a.x; av[it][mb].v[1] = a.y; av[it][mb].v[2] = a.z; av[it][mb].v[3] = a.w;
+                }
+            }
+        } else {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[mb].v[j], wv.v[j], acc[mb]);
+            for (int it = 0; it < NIT; ++it) {
+                const int kk = k0 + 16 * it + 4 * kq;
+                wv[it] = ld4<ALIGNED>(wrow, wvalid, kk, kend);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[it][mb] = ld4<ALIGNED>(arow[mb], avalid[mb], kk, kend);
+            }
+        }
+        LV_SCHED_BARRIER();   // all loads of the macro-chunk are in flight before the first MFMA waits on one
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[it][mb].v[j], wv[it].v[j], acc[mb]);
     }
 }
+
+template <int MB> struct RecNit { static constexpr int value = MB <= 2 ? 16 : (MB == 4 ? 8 : 4); };
 
 __device__ __forceinline__ int round_up16(int x) { return (x + 15) & ~15; }
 
@@ -122,7 +151,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rec_mm_core<MB, ALIGNED>(h_prev, H, B, rb, wrow, wvalid, kbeg, kend, l, acc);
+    rec_mm_core<MB, ALIGNED, RecNit<MB>::value>(h_prev, H, B, rb, wrow, wvalid, kbeg, kend, l, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -169,7 +198,9 @@ struct LstmBwdP {
     int T, B, H, KS;
 };
 
-// elementwise part of BPTT step t
+// elementwise part of BPTT step t (KS = number of split-K slabs of the previous step's matmul, compile-time so
+// that all slab loads are issued together)
+template <int KS>
 __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int t) {
     const int B = p.B, H = p.H;
     const long BH = (long)B * H;
@@ -184,18 +215,26 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
         dh = p.dh_ext[(long)t * BH + idx] * m;
     }
     if (first && p.dh_last) dh += p.dh_last[idx];
+    float parts[KS];
+    float dcr = 0.f;
     if (!first) {
-        float s = 0.f;
-        for (int ks = 0; ks < p.KS; ++ks) s += p.dh_part[(long)ks * BH + idx];
-        dh += s;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) parts[ks] = p.dh_part[(long)ks * BH + idx];
+        dcr = p.dc_rec[idx];
     }
     const long gi = (long)t * B * 4 * H + (long)b * 4 * H + u;
     const float ig = p.gates[gi], fg = p.gates[gi + H], gg = p.gates[gi + 2L * H], og = p.gates[gi + 3L * H];
     const float c = p.cs[(long)(t + 1) * BH + idx];
     const float cprev = p.cs[(long)t * BH + idx];
+    if (!first) {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s += parts[ks];
+        dh += s;
+    }
     const float tc = tanhf(c);
     float dc = dh * og * (1.f - tc * tc);
-    if (!first) dc += p.dc_rec[idx];
+    if (!first) dc += dcr;
     const float d_o = dh * tc;
     const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
     const float da_i = d_i * ig * (1.f - ig);
@@ -233,7 +272,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_mm_kernel(LstmBwdP p, int t
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (kbeg < kend) rec_mm_core<MB, ALIGNED>(A, K, B, rb, wrow, wvalid, kbeg, kend, l, acc);
+    if (kbeg < kend) rec_mm_core<MB, ALIGNED, RecNit<MB>::value>(A, K, B, rb, wrow, wvalid, kbeg, kend, l, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -304,9 +343,9 @@ inline int pick_mb(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : (B <= 64 ? 4 : 8
 
 extern "C" int lv_lstm_bwd_ksplit(int H) {
     int nb = (H + 15) / 16;
-    int ks = 256 / (nb > 0 ? nb : 1);
-    if (ks < 1) ks = 1;
-    if (ks > 8) ks = 8;
+    int want = 256 / (nb > 0 ? nb : 1);
+    int ks = 1;                       // power of two in {1,2,4,8}: the elementwise kernel is templated on it
+    while (ks * 2 <= want && ks < 8) ks *= 2;
     return ks;
 }
 
@@ -353,7 +392,12 @@ extern "C" int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const 
     dim3 egrid((unsigned)lv_cdiv(BH, 256)), block(256);
     const int mb = pick_mb(B);
     for (int t = T - 1; t >= 0; --t) {
-        LV_LAUNCH(lstm_step_bwd_elem_kernel, egrid, block, 0, stream, p, t);
+        switch (p.KS) {
+            case 1: LV_LAUNCH((lstm_step_bwd_elem_kernel<1>), egrid, block, 0, stream, p, t); break;
+            case 2: LV_LAUNCH((lstm_step_bwd_elem_kernel<2>), egrid, block, 0, stream, p, t); break;
+            case 4: LV_LAUNCH((lstm_step_bwd_elem_kernel<4>), egrid, block, 0, stream, p, t); break;
+            default: LV_LAUNCH((lstm_step_bwd_elem_kernel<8>), egrid, block, 0, stream, p, t); break;
+        }
         if (t > 0 || need_h0) {
             switch (mb) {
                 case 1: launch_bwd_mm<1>(p, t, aligned, stream); break;

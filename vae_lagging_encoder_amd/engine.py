@@ -120,6 +120,19 @@ class _NS(object):
 GEMM_PROFILE = None
 
 
+_GEMM_WS = {}
+
+
+def _gemm_ws(lib, s):
+    """Per-device split-K scratch (16M floats) shared by every GEMM launch on that device's stream order."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if s is not None else torch.device("cpu")
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = torch.empty(1 << 24 if dev.type == "cuda" else 1 << 20, dtype=torch.float32, device=dev)
+        _GEMM_WS[dev] = ws
+    return ws
+
+
 def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add1=None, ld1=0, mod1=1,
           add2=None, ld2=0, mod2=1):
     prof = GEMM_PROFILE
@@ -127,7 +140,9 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib.lv_gemm_f32(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, s)
+    ws = _gemm_ws(lib, s)
+    lib.lv_gemm_f32(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2,
+                    P(ws), ws.numel(), s)
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K))
