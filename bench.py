@@ -36,6 +36,8 @@ WORKLOADS = {
     "toy": dict(V=1004, ni=50, H=50, nz=1, B=16, T=12),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (same table)
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured copy)
 GFLOP_PER_SEQ = {"yahoo": 39.67, "yelp": 19.75}   # SURVEY.md 8(d) / BASELINE.md section 4
 
 
@@ -51,6 +53,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="yahoo", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", type=int, default=0, help="replay the step as captured hipGraphs (no per-kernel events)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool", type=int, default=64)
     args = ap.parse_args()
@@ -74,7 +78,8 @@ def main():
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
     sync = lvdist.GradSync(mode="strict") if world > 1 else None
-    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435 + rank, grad_sync=sync, use_graph=bool(args.graph))
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435 + rank, grad_sync=sync, use_graph=bool(args.graph),
+                               precision=args.dtype)
     pool = [O.synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
     rs = np.random.RandomState(783435)
     kl_weight = 0.1                                         # text.py default kl_start
@@ -89,8 +94,8 @@ def main():
         torch.distributed.barrier()
     prof = None
     if not args.graph:
-        prof = []
-        engine.GEMM_PROFILE = prof
+        prof = {}
+        engine.PROFILE = prof
     tr.reset_stats()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -100,7 +105,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    engine.GEMM_PROFILE = None
+    engine.PROFILE = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -114,7 +119,7 @@ def main():
     out = {
         "metric": "aggressive-loop seqs/sec", "value": round(value, 2), "unit": "seq/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s LSTM-VAE aggressive inner step (fwd+bwd+clip+encoder SGD), B=%d/GPU, T=%d, V=%d, "
                                "ni=%d, H=%d, nz=%d" % (args.workload, B, T, V, ni, H, nz),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
@@ -123,21 +128,44 @@ def main():
     }
     step_flops = 3 * fwd_flops(V, ni, H, nz, B, T)
     if prof:
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-        fl = sum(f for _, _, f in prof)
-        achieved = fl / (ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "lv_gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "launches_per_step": len(prof) // args.steps, "gemm_ms_per_step": round(ms / args.steps, 4),
-            "gemm_gflop_per_step": round(fl / args.steps / 1e9, 1),
-            "whole_step_tflops": round(step_flops / (dt / args.steps) / 1e12, 2),
-        }
+        # live HIP-event timing of the two kernel groups that make up the step, on their launch stream
+        groups = {}
+        for name, recs in prof.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+            groups[name] = dict(ms=ms, work=sum(w for _, _, w, _ in recs), launches=sum(n for _, _, _, n in recs))
+        gname = "gemm_" + args.dtype
+        gemm = groups.get(gname, dict(ms=0.0, work=0.0, launches=0))
+        lstm_ms = sum(groups[k]["ms"] for k in ("lstm_fwd", "lstm_bwd") if k in groups)
+        lstm_launches = sum(groups[k]["launches"] for k in ("lstm_fwd", "lstm_bwd") if k in groups)
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
+        gemm_roof = {
+            "bound": "mfma", "kernel": "lv_gemm_%s_kernel" % args.dtype, "achieved": round(gemm_tf, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4), "traffic": None,
+            "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
+            "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
+        # LSTM recurrence: per launch the algorithmic HBM bytes are W_hh (4H*H) + one timestep of state/gates
+        per_fwd = 4.0 * (4 * H * H + B * H * 3 + B * 4 * H * 2)
+        per_bwd = 4.0 * (4 * H * H + B * 4 * H * 4 + B * H * 10) / 2.0        # two launches (elementwise + matmul) per step
+        steps_fwd = groups.get("lstm_fwd", dict(launches=0))["launches"]
+        steps_bwd = groups.get("lstm_bwd", dict(launches=0))["launches"]
+        lstm_bytes = per_fwd * steps_fwd + per_bwd * steps_bwd
+        lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
+        lstm_roof = {
+            "bound": "hbm", "kernel": "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep)",
+            "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
+            "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
+            "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3)}
+        if gemm["ms"] >= lstm_ms:
+            out["roofline"], out["roofline_secondary"] = gemm_roof, lstm_roof
+        else:
+            out["roofline"], out["roofline_secondary"] = lstm_roof, gemm_roof
+        out["whole_step_tflops"] = round(step_flops / (dt / args.steps) / 1e12, 2)
     else:
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "achieved": round(step_flops / (dt / args.steps) / 1e12, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(step_flops / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                           "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(step_flops / (dt / args.steps) / 1e12 / peak, 4),
                            "traffic": None, "note": "whole-step algorithmic flops (graph replay: no per-kernel events)"}
 
     if world == 1 and not args.no_cpu_baseline:
@@ -163,7 +191,7 @@ def main():
                                          "(oneDNN LSTM) = the reference's CPU path restated in oracle/" % (n_timed, B, T)}
         # ELBO delta of the HIP path vs that oracle on the identical batch/noise (north_star: <= 1e-4 relative)
         vae2 = build_vae(V, ni, H, nz, dev, params=P)
-        tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0)
+        tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0, precision=args.dtype)
         tr2.step(xb.to(dev), kl_weight, noise=(eps.to(dev), m_in.to(torch.uint8).to(dev), m_out.to(torch.uint8).to(dev)))
         s2 = tr2.read_stats()
         out["elbo_rel_delta_vs_cpu"] = float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum()))))

@@ -34,6 +34,13 @@ int lv_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                 const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
                 float* ws /* optional split-K scratch */, long ws_floats, void* stream);
 
+/* Same contract on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): f32 operands in HBM are rounded to bf16 while
+ * being staged, accumulation and outputs are f32.  The throughput configuration of BASELINE.json (bf16). */
+int lv_gemm_bf16(int transA, int transB, int M, int N, int K, float alpha,
+                 const float* A, long lda, const float* B, long ldb, float* C, long ldc, int accumulate,
+                 const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
+                 float* ws, long ws_floats, void* stream);
+
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 

@@ -70,6 +70,7 @@ struct WaveX {
     int count = 0;
     float fa[kWave], fb[kWave];
     uint64_t u[kWave];
+    uint4 qa[kWave], qb[kWave];
 };
 
 struct State {
@@ -253,6 +254,32 @@ static inline f32x16 lv_emu_mfma_32x32x2(float a, float b, f32x16 c) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         float acc = c[r];
         for (int k = 0; k < 2; ++k) acc = fmaf(w.fa[row + 32 * k], w.fb[col + 32 * k], acc);
+        d[r] = acc;
+    }
+    pthread_barrier_wait(&w.bar);
+    return d;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds 8 bf16 of A row (l&31) and of B column (l&31) for k = 8*(l>>5)+e
+// (any k assignment that is the same for A and B gives the same product); D layout as the f32 32x32 form.
+static inline float lv_emu_bf16_to_f32(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline f32x16 lv_emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+    static thread_local int dummy = 0; (void)dummy;
+    auto& w = lv_emu::my_wave();
+    int l = lv_emu::lane();
+    w.qa[l] = a; w.qb[l] = b;
+    pthread_barrier_wait(&w.bar);
+    f32x16 d = c;
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            unsigned short ea[8], eb[8];
+            memcpy(ea, &w.qa[row + 32 * h], 16);
+            memcpy(eb, &w.qb[col + 32 * h], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf(lv_emu_bf16_to_f32(ea[e]), lv_emu_bf16_to_f32(eb[e]), acc);
+        }
         d[r] = acc;
     }
     pthread_barrier_wait(&w.bar);

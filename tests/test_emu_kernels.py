@@ -14,6 +14,12 @@ def test_gemm(emu_backend, tA, tB, M, N, K_):
     K.test_gemm_f32(emu_backend, CPU, tA, tB, M, N, K_)
 
 
+@pytest.mark.parametrize("tA,tB,M,N,K_", [(0, 1, 130, 140, 37), (0, 0, 65, 140, 70), (1, 0, 70, 130, 50), (1, 1, 33, 17, 20),
+                                           (0, 1, 1, 1, 1), (0, 0, 32, 32, 1000), (1, 0, 70, 30, 600)])
+def test_gemm_bf16(emu_backend, tA, tB, M, N, K_):
+    K.test_gemm_bf16(emu_backend, CPU, tA, tB, M, N, K_)
+
+
 def test_gemm_unaligned(emu_backend):
     K.test_gemm_unaligned_rows(emu_backend, CPU)
 

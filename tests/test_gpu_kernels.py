@@ -47,6 +47,35 @@ def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
     assert err < 2e-6 * (K ** 0.5 + 1) * 8, err
 
 
+@pytest.mark.parametrize("tA,tB,M,N,K", [
+    (0, 1, 130, 140, 37), (0, 0, 130, 140, 70), (1, 0, 70, 260, 50), (1, 1, 33, 17, 20), (0, 1, 1, 1, 1),
+    (0, 1, 3000, 2100, 512), (0, 0, 640, 1024, 2001), (1, 0, 2001, 1024, 640), (0, 0, 32, 32, 4096), (1, 0, 512, 256, 6368),
+])
+def test_gemm_bf16(lib, hip_device, tA, tB, M, N, K):
+    """bf16 matrix pipe: exact against a float64 product of the bf16-ROUNDED operands (f32-accumulate class error),
+    and within bf16 input precision of the unrounded product."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 1)
+    lda = (M if tA else K) + 4
+    ldb = (K if tB else N) + 8
+    A = torch.randn(K if tA else M, lda, generator=g)
+    B = torch.randn(N if tB else K, ldb, generator=g)
+    C0 = torch.randn(M, N + 3, generator=g)
+    add1 = torch.randn(5, N, generator=g)
+    rb = lambda x: x.to(torch.bfloat16).double()
+    Aop = (A[:, :M].t() if tA else A[:, :K])
+    Bop = (B[:, :K].t() if tB else B[:, :N])
+    ref = 0.5 * (rb(Aop) @ rb(Bop)) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
+    ref_exact = 0.5 * (Aop.double() @ Bop.double()) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
+    Ad, Bd, Cd, a1 = (t.to(hip_device) for t in (A, B, C0.clone(), add1))
+    ws = torch.empty(1 << 20, device=hip_device)
+    lib.lv_gemm_bf16(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, None, 0, 1,
+                     P(ws), ws.numel(), _s(hip_device))
+    out = Cd.cpu()
+    assert torch.equal(out[:, N:], C0[:, N:])
+    assert float((out[:, :N].double() - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 8
+    assert float((out[:, :N].double() - ref_exact).abs().max()) < 2e-2 * (K ** 0.5 + 1)
+
+
 def test_gemm_unaligned_rows(lib, hip_device):
     # ld % 4 != 0 and odd base offset: scalar load path (toy config has ni + nz = 51)
     g = torch.Generator().manual_seed(5)

@@ -22,14 +22,14 @@ def test_fused_trainer_trajectory(hip_device, use_graph):
     pc.check_trajectory_against_fixture(hip_device, use_graph=use_graph)
 
 
-def _oracle_vs_hip(device, V, ni, H, nz, B, T, klw, seed, head_scale=0.2, scale=0.05, impl="explicit"):
+def _oracle_vs_hip(device, V, ni, H, nz, B, T, klw, seed, head_scale=0.2, scale=0.05, impl="explicit", precision="f32"):
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
     P = O.random_params(V, ni, H, nz, seed=seed, scale=scale, head_scale=head_scale)
     x = O.synthetic_batch(B, T, V, seed=seed + 1)
     eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=seed + 2)
     r = O.inner_step(P, x, klw, eps, m_in, m_out, impl=impl)
     vae = build_vae(V, ni, H, nz, device, params=P)
-    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision)
     tr.step(x.to(device), klw, noise=(eps.to(device), m_in.to(torch.uint8).to(device), m_out.to(torch.uint8).to(device)))
     st = tr.read_stats()
     out = {}
@@ -56,6 +56,14 @@ def test_fused_step_matches_oracle(hip_device, cfg):
     out, _ = _oracle_vs_hip(hip_device, **cfg)
     for k, v in out.items():
         assert v < (2e-4 if k in ("grads",) else 1e-4), (k, v, out)
+
+
+def test_bf16_throughput_path_tracks_oracle(hip_device):
+    """The bf16 matrix-pipe configuration (BASELINE.json configs: "bf16"): f32 master weights, bf16 operands into the
+    large GEMMs, f32 accumulate.  Not the parity path -- documents its ELBO delta (bf16 input rounding, ~2^-9)."""
+    out, _ = _oracle_vs_hip(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30, klw=0.5, seed=4, precision="bf16")
+    assert out["loss"] < 2e-3 and out["rec"] < 2e-3 and out["norm"] < 3e-2, out
+    assert out["grads"] < 5e-2, out
 
 
 def test_yelp_full_size_fixture(hip_device):

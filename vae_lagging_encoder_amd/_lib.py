@@ -20,6 +20,7 @@ _u64 = ctypes.c_uint64
 # name -> argtypes (all functions return int status: 0 ok, >0 hipError_t, <0 argument check)
 SIGNATURES = {
     "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],
     "lv_lstm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],

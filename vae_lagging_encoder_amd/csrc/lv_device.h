@@ -13,6 +13,7 @@
 static inline f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) { return lv_emu_mfma_16x16x4(a, b, c); }
 static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu_mfma_32x32x2(a, b, c); }
 #define LV_SCHED_BARRIER() do { } while (0)
+static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,9 +32,16 @@ __device__ __forceinline__ f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_bf16: a/b = 8 bf16 (raw bits in a uint4) of A row / B column (l&31), k = 8*(l>>5)+e
+typedef __bf16 lv_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
+                                                   c, 0, 0, 0);
+}
 #endif
 
 #include <stdint.h>
+#include <string.h>
 
 #define LV_WAVE 64
 
@@ -49,6 +57,17 @@ __device__ __forceinline__ f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) {
         hipError_t e__ = hipGetLastError();      \
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
+
+// f32 -> bf16 bits, round-to-nearest-even (finite inputs)
+__device__ __forceinline__ uint32_t lv_f32_to_bf16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint32_t lv_pack_bf16x2(float lo, float hi) {
+    return lv_f32_to_bf16_bits(lo) | (lv_f32_to_bf16_bits(hi) << 16);
+}
 
 __device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 

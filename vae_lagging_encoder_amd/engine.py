@@ -115,9 +115,25 @@ class _NS(object):
     pass
 
 
-# bench.py's roofline leg: when set to a list, every GEMM launch is bracketed by HIP events recorded on the launch
-# stream and (start, end, flops) is appended (measurement only; None in normal operation).
-GEMM_PROFILE = None
+# bench.py's roofline leg: when set to a dict, kernel-launch groups are bracketed by HIP events recorded on the launch
+# stream and (start, end, work, launches) is appended under the group name (measurement only; None normally).
+PROFILE = None
+
+
+class _prof(object):
+    def __init__(self, name, work, launches=1):
+        self.name, self.work, self.launches = name, work, launches
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.name, []).append((self.e0, self.e1, self.work, self.launches))
 
 
 _GEMM_WS = {}
@@ -134,18 +150,13 @@ def _gemm_ws(lib, s):
 
 
 def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add1=None, ld1=0, mod1=1,
-          add2=None, ld2=0, mod2=1):
-    prof = GEMM_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+          add2=None, ld2=0, mod2=1, prec="f32"):
+    """prec: 'f32' = exact-f32 MFMA (parity path); 'bf16' = bf16 matrix pipe with f32 accumulate (throughput path,
+    only requested for the large contractions)."""
     ws = _gemm_ws(lib, s)
-    lib.lv_gemm_f32(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2,
-                    P(ws), ws.numel(), s)
-    if prof is not None:
-        e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K))
+    fn = lib.lv_gemm_bf16 if prec == "bf16" else lib.lv_gemm_f32
+    with _prof("gemm_" + prec, 2.0 * M * N * K):
+        fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
 
 
 class LSTMEncoderEngine(object):
@@ -156,6 +167,7 @@ class LSTMEncoderEngine(object):
         self.flat = None
         self.wsc = None
         self.gen = 0
+        self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
 
     def ensure(self, device):
         device = torch.device(device)
@@ -211,11 +223,12 @@ class LSTMEncoderEngine(object):
         v = f.views
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
         _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
-              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
+              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1, prec=self.precision)
         w.hs[0].zero_()
         w.cs[0].zero_()
-        lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None,
-                            T, B, H, s)
+        with _prof("lstm_fwd", 0.0, T):
+            lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None,
+                                T, B, H, s)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
@@ -237,12 +250,13 @@ class LSTMEncoderEngine(object):
         _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
         lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
-        lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG), P(w.dGsum),
-                            P(w.part), P(w.dc_rec), None, None, 0, T, B, H, s)
+        with _prof("lstm_bwd", 0.0, 2 * T):
+            lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG), P(w.dGsum),
+                                P(w.part), P(w.dc_rec), None, None, 0, T, B, H, s)
         # input-side grads
-        _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni)
-        _gemm(lib, s, 1, 0, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni)
-        _gemm(lib, s, 1, 0, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H)
+        _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
+        _gemm(lib, s, 1, 0, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, prec=self.precision)
+        _gemm(lib, s, 1, 0, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, prec=self.precision)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         gv["embed.weight"].zero_()
         lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
@@ -257,6 +271,7 @@ class LSTMDecoderEngine(object):
         self.flat = None
         self.wsc = None
         self.gen = 0
+        self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
 
     def ensure(self, device):
         device = torch.device(device)
@@ -344,10 +359,11 @@ class LSTMDecoderEngine(object):
         _gemm(lib, s, 0, 1, B, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
               add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
-              add1=P(w.Zp), ld1=4 * H, mod1=B)
-        lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
-                            P(w.O), Td, B, H, s)
-        _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl)
+              add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
+        with _prof("lstm_fwd", 0.0, Td):
+            lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
+                                P(w.O), Td, B, H, s)
+        _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
         lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
         # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
         lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
@@ -371,15 +387,16 @@ class LSTMDecoderEngine(object):
         wih = v["lstm.weight_ih_l0"]
         gwih = gv["lstm.weight_ih_l0"]
         lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
-        _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H)
-        _gemm(lib, s, 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H)
+        _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
+        _gemm(lib, s, 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H, prec=self.precision)
         lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
-        lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG),
-                            P(w.dGsum), P(w.part), P(w.dc_rec), None, P(w.dc0), 1, Td, B, H, s)
-        _gemm(lib, s, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni)
-        _gemm(lib, s, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz)
+        with _prof("lstm_bwd", 0.0, 2 * Td):
+            lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG),
+                                P(w.dGsum), P(w.part), P(w.dc_rec), None, P(w.dc0), 1, Td, B, H, s)
+        _gemm(lib, s, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision)
+        _gemm(lib, s, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, prec=self.precision)
         _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
-        _gemm(lib, s, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H)
+        _gemm(lib, s, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, prec=self.precision)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         # dz = dGsum . W_ih[:, ni:] + dc0 . W_trans ; dW_trans = dc0^T . z
         _gemm(lib, s, 0, 0, B, nz, 4 * H, P(w.dGsum), 4 * H, P(wih, ni), ni + nz, P(w.dz), nz)

@@ -22,13 +22,16 @@ class _Static(object):
 
 
 class AggressiveTextTrainer(object):
-    def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None):
+    def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
+                 precision="f32"):
         self.vae = vae
         self.enc = vae.encoder._hip
         self.dec = vae.decoder._hip
         self.device = torch.device(device) if device is not None else next(vae.parameters()).device
         self.enc.ensure(self.device)
         self.dec.ensure(self.device)
+        assert precision in ("f32", "bf16")
+        self.enc.precision = self.dec.precision = precision   # large GEMMs: exact f32 (parity) or bf16 pipe (throughput)
         self.enc.flat.attach_grads()
         self.dec.flat.attach_grads()
         self.lib = _eng.backend_for(self.device)
