@@ -169,32 +169,42 @@ def main():
                            "traffic": None, "note": "whole-step algorithmic flops (graph replay: no per-kernel events)"}
 
     if world == 1 and not args.no_cpu_baseline:
-        # the reference's CPU op sequence (oracle 'aten' path), same shapes, bounded sample
-        torch.set_num_threads(os.cpu_count() or 1)
+        # The reference's CPU op sequence (oracle 'aten' path = torch CPU ATen ops, oneDNN LSTM) on this box's host
+        # cores, on a BOUNDED sample of the same workload: SB of the B sequences of one batch at full length T
+        # (per-sequence cost is what the metric counts), <= 64 threads (oneDNN's LSTM backward degrades badly with
+        # hundreds of threads: a full B=32 step took 278 s on the 256-core host), ~10-30 s of CPU work.
+        nthreads = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(nthreads)
+        SB = min(B, 8)
         P = {k: v.detach().cpu() for k, v in vae.state_dict().items() if k in O.ALL_KEYS}
         xb = pool[0].cpu()
         eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=1)
+        xs, es, mis, mos = xb[:SB].contiguous(), eps[:SB].contiguous(), m_in[:SB].contiguous(), m_out[:SB].contiguous()
         tw = time.perf_counter()
-        r = O.inner_step(P, xb, kl_weight, eps, m_in, m_out, impl="aten")     # warm-up
+        O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")              # warm-up
         warm = time.perf_counter() - tw
         n_timed, t_cpu = 0, 0.0
-        while n_timed < 3 and t_cpu + warm < 30.0:
+        while n_timed < 3 and (n_timed + 1) * warm + t_cpu < 25.0:
             tc = time.perf_counter()
-            r = O.inner_step(P, xb, kl_weight, eps, m_in, m_out, impl="aten")
+            O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")
             t_cpu += time.perf_counter() - tc
             n_timed += 1
         if n_timed == 0:
             n_timed, t_cpu = 1, warm
-        out["cpu_baseline"] = {"value": round(B * n_timed / t_cpu, 3), "unit": "seq/s", "cores": torch.get_num_threads(),
+        out["cpu_baseline"] = {"value": round(SB * n_timed / t_cpu, 3), "unit": "seq/s", "cores": nthreads,
                                "kind": "port",
-                               "sample": "%d timed inner step(s) after 1 warm-up, same shapes (B=%d,T=%d), torch CPU ATen ops "
-                                         "(oneDNN LSTM) = the reference's CPU path restated in oracle/" % (n_timed, B, T)}
-        # ELBO delta of the HIP path vs that oracle on the identical batch/noise (north_star: <= 1e-4 relative)
-        vae2 = build_vae(V, ni, H, nz, dev, params=P)
-        tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0, precision=args.dtype)
-        tr2.step(xb.to(dev), kl_weight, noise=(eps.to(dev), m_in.to(torch.uint8).to(dev), m_out.to(torch.uint8).to(dev)))
-        s2 = tr2.read_stats()
-        out["elbo_rel_delta_vs_cpu"] = float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum()))))
+                               "sample": "%d timed inner step(s) on %d of the %d sequences of one batch at full length T=%d "
+                                         "(after 1 warm-up), torch CPU ATen ops (oneDNN LSTM) = the reference's CPU path "
+                                         "restated in oracle/" % (n_timed, SB, B, T)}
+        # ELBO delta of the HIP path vs the oracle on the identical (sub)batch and noise (north_star: <= 1e-4 rel, f32)
+        r = O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten") if n_timed == 0 else None
+        r = r or O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten") if warm < 15 else None
+        if r is not None:
+            vae2 = build_vae(V, ni, H, nz, dev, params=P)
+            tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0, precision=args.dtype)
+            tr2.step(xs.to(dev), kl_weight, noise=(es.to(dev), mis.to(torch.uint8).to(dev), mos.to(torch.uint8).to(dev)))
+            s2 = tr2.read_stats()
+            out["elbo_rel_delta_vs_cpu"] = float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum()))))
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out))
 

@@ -50,17 +50,19 @@ int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stre
  * dmask (optional) uint8 [B][T][H] keep-mask of nn.Dropout on the outputs (dec_lstm.py:106): hdrop[t] =
  * hs[t+1]*mask*dscale;  with dmask == NULL and hdrop != NULL, hdrop is a copy of the outputs. */
 int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
-                    const uint8_t* dmask, float dscale, float* hdrop, int T, int B, int H, void* stream);
-/* number of split-K slabs lv_lstm_bwd_f32 writes per step: dh_part must hold that many [B][H] slabs */
+                    const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* floats of caller-owned scratch (16-byte aligned) both LSTM entry points need: MFMA-fragment-major packed copies of
+ * W_hh and of the recurrent state, split-K slabs */
+long lv_lstm_ws_floats(int B, int H);
+/* number of split-K slabs the BPTT matmul writes per step (informational) */
 int lv_lstm_bwd_ksplit(int H);
 /* BPTT.  dh_ext (optional) [T][B][H] grad wrt every output (times dmask*dscale when dmask given); dh_last
  * (optional) [B][H] grad wrt the final output only (encoder: enc_lstm.py:60-62 uses last_state only).
- * whhT [H][4H] = transpose of whh.  Outputs: dG [T][B][4H] grad wrt pre-activations; dGsum [B][4H] = sum_t dG[t];
- * dc0/dh0 (optional) grads wrt the initial state; tanh_init = 1 when h0 = tanh(c0) (dec_lstm.py:99-101):
- * then dc0 includes the path through h0.  Workspaces: dh_part [ksplit][B][H], dc_rec [B][H]. */
+ * Outputs: dG [T][B][4H] grad wrt pre-activations; dGsum [B][4H] = sum_t dG[t]; dc0/dh0 (optional) grads wrt the
+ * initial state; tanh_init = 1 when h0 = tanh(c0) (dec_lstm.py:99-101): then dc0 includes the path through h0. */
 int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                    const float* whhT, const float* gates, const float* hs, const float* cs,
-                    float* dG, float* dGsum, float* dh_part, float* dc_rec, float* dh0, float* dc0, int tanh_init,
+                    const float* whh, const float* gates, const float* hs, const float* cs,
+                    float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
                     int T, int B, int H, void* stream);
 
 /* ---- embeddings: nn.Embedding forward (enc_lstm.py:58, dec_lstm.py:80) fused with dropout_in (dec_lstm.py:81);

@@ -13,7 +13,7 @@ def header_symbols():
     with open(os.path.join(ROOT, "include", "lvae.h")) as fh:
         text = fh.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(lv_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(lv_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
@@ -39,7 +39,8 @@ def test_argument_checks_return_negative_status_without_touching_the_gpu():
     raw = lib.cdll.lv_gemm_f32
     assert raw(0, 1, -1, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None, 0, None) < 0
     assert raw(0, 1, 4, 4, 4, 1.0, None, 4, None, 4, None, 4, 0, None, 0, 1, None, 0, 1, None, 0, None) < 0   # NULL operands
-    assert lib.cdll.lv_lstm_fwd_f32(None, None, None, None, None, None, 1.0, None, 1, 1, 1, None) < 0
+    assert lib.cdll.lv_lstm_fwd_f32(None, None, None, None, None, None, 1.0, None, None, 1, 1, 1, None) < 0
+    assert lib.lv_lstm_ws_floats(32, 1024) > 4 * 1024 * 1024
 
 
 def test_package_has_no_cpu_fallback():

@@ -140,21 +140,20 @@ def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, us
     gates = torch.empty(T, B, 4 * H, device=dev)
     hdrop = torch.empty(T, B, H, device=dev)
     m8 = mask.to(torch.uint8).contiguous()
-    lib.lv_lstm_fwd_f32(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), T, B, H, _s(dev))
+    ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
+    lib.lv_lstm_fwd_f32(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
     assert float((hs.double() - hs_r.detach()).abs().max()) < 2e-5
     assert float((cs.double() - cs_r.detach()).abs().max()) < 2e-5
     assert float((hdrop.double() - out_r.detach()).abs().max()) < 4e-5
     whhT = torch.empty(H, 4 * H, device=dev)
     lib.lv_transpose_f32(P(whh), P(whhT), 4 * H, H, _s(dev))
     assert torch.equal(whhT, whh.t().contiguous())
-    KS = lib.lv_lstm_bwd_ksplit(H)
     dG = torch.empty(T, B, 4 * H, device=dev)
     dGsum = torch.full((B, 4 * H), 7.0, device=dev)
-    part = torch.empty(KS, B, H, device=dev)
-    dcrec = torch.full((B, H), 3.0, device=dev)
     dc0 = torch.empty(B, H, device=dev)
+    ws.fill_(float("nan"))            # scratch content must not matter
     lib.lv_lstm_bwd_f32(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
-                        P(whhT), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(part), P(dcrec), None, P(dc0),
+                        P(whh), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(ws), None, P(dc0),
                         int(tanh_init), T, B, H, _s(dev))
     sc = float(gx64.grad.abs().max())
     assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc

@@ -23,8 +23,9 @@ SIGNATURES = {
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],
-    "lv_lstm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp],
-    "lv_lstm_bwd_f32": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_lstm_ws_floats": [_i, _i],
+    "lv_lstm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "lv_lstm_bwd_f32": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_embed_gather_f32": [_vp, _vp, _l, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "lv_token_sort": [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
     "lv_embed_scatter_f32": [_vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -69,12 +70,12 @@ class Lib(object):
                 missing.append(name)
                 continue
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_long if name == "lv_lstm_ws_floats" else ctypes.c_int
             setattr(self, "_raw_" + name, fn)
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats"}
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

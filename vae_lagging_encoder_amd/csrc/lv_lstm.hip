@@ -5,122 +5,147 @@
 // oracle/text_vae_oracle.py (PyTorch gate order i|f|g|o).
 //
 // HBM layout: everything time-major so one timestep is one contiguous [B][*] slab:
-//   gx    [T][B][4H]  x_t W_ih^T + b_ih + b_hh (+ z W_z^T for the decoder)  -- produced by lv_gemm_f32
+//   gx    [T][B][4H]  x_t W_ih^T + b_ih + b_hh (+ z W_z^T for the decoder)  -- produced by lv_gemm_*
 //   hs,cs [T+1][B][H] hs[0]/cs[0] = initial state, step t writes index t+1
 //   gates [T][B][4H]  activated i,f,g,o saved for BPTT;  dG [T][B][4H] grads wrt pre-activations
 //
-// Forward step (one launch per timestep; the kernel boundary is the grid-wide h_t hand-off, ~1.5 us on
-// gfx950, cheaper than an in-kernel grid barrier -- MI355X_MICROARCH.md price list):
-//   grid.x = ceil(H/4) workgroups; each owns 4 hidden units = 16 gate columns (i,f,g,o x 4 units) for all
-//   batch rows, so the gate nonlinearity and the c/h update fuse into the epilogue.  The 4 waves split the
-//   K=H contraction; each wave streams float4s of h_{t-1} (A) and of its W_hh rows (B) straight from L2
-//   into v_mfma_f32_16x16x4_f32 (lane (i,kq) feeds element j of its float4 to MFMA j, the same
-//   permutation of K on both operands), partial 16x16 tiles are combined through LDS.
-//   block b lands on XCD b%8, so one XCD's 32 workgroups re-read the same 1/8 of W_hh every step and
-//   it stays resident in that XCD's 4 MiB L2 (2.1 MB of 16.8 MB at H=1024).
-// Backward step t = two launches: an elementwise kernel (gate grads, dc chain, dG[t]) and the recurrent
-//   matmul dh_{t-1} = dG[t] . W_hh as split-K partial slabs against a pre-transposed W_hh^T (same core as
-//   forward); the next step's elementwise kernel sums the slabs (deterministic, no atomics).
+// One launch per timestep: the kernel boundary is the grid-wide h_t hand-off (cheaper on gfx950 than an in-kernel
+// grid barrier -- MI355X_MICROARCH.md price list).  The step kernels are latency-bound: one workgroup per CU, 4
+// waves, each wave streams its slice of both operands of a 32 x 16 x K product straight into
+// v_mfma_f32_16x16x4_f32.  Measured on MI355X (profiles/r01_microbench_*): a wave64 float4 load that touches 16 rows
+// x 64 B costs twice one that touches whole 128 B lines, whatever the row pitch.  So both recurrent operands are kept
+// in an MFMA-fragment-major packed layout in which every wave-level load is 1 KB of consecutive bytes:
+//   activations  Ap[k/4][mb][16 rows][4 k]      (k-quad major; mb = 16-row batch block)
+//   weights      Wp[nb][k/4][16 cols][4 k]      (nb = 16-column block owned by one workgroup)
+// Lane (i = l&15, kq = l>>4) loads the float4 (k = 4*(4*it+kq) .. +3) of row/column i and feeds element j of it to
+// MFMA j -- the same permutation of K on both operands.  W_hh is re-packed once per call (16.8 MB, ~1% of a step);
+// h_t is written by the step epilogue both in the standard layout (for the GEMMs that consume hs) and packed (for
+// step t+1): a workgroup owns 4 hidden units = exactly one k-quad, so its packed store is 512 contiguous bytes.
+// K is zero-padded to a multiple of 16 and rows/columns beyond B / H are zero, so the inner loop has no predicates.
+//
+// Forward step: grid.x = ceil(H/4) workgroups, each owns 4 hidden units = 16 gate columns (i,f,g,o x 4 units) for
+//   all batch rows, so sigma/tanh, the c/h update and the decoder's output dropout fuse into the epilogue.
+// Backward step t = two launches: an elementwise kernel (gate grads, dc chain, dG[t], running sum of dG) and the
+//   recurrent matmul dh_{t-1} = dG[t] . W_hh as split-K partial slabs (same core, weights packed transposed); the
+//   next step's elementwise kernel sums the slabs in a fixed order (deterministic, no atomics).
 #include "lv_device.h"
 
 namespace {
 
-struct Ld4 { float v[4]; };
-
-template <bool ALIGNED>
-__device__ __forceinline__ Ld4 ld4(const float* __restrict__ row, bool rvalid, int k, int klim) {
-    Ld4 o;
-    const bool ok = rvalid && k < klim;
-    if (ALIGNED) {
-        // klim % 4 == 0 and k % 4 == 0 in this instantiation, so a float4 at k < klim is fully inside.  The load is
-        // unconditional (clamped to offset 0 of a valid row) and zeroed by select: no exec-mask branch per load.
-        const float4 t = *reinterpret_cast<const float4*>(row + (ok ? k : 0));
-        o.v[0] = ok ? t.x : 0.f; o.v[1] = ok ? t.y : 0.f; o.v[2] = ok ? t.z : 0.f; o.v[3] = ok ? t.w : 0.f;
-    } else {
-        o.v[0] = o.v[1] = o.v[2] = o.v[3] = 0.f;
-        if (ok) {
-            o.v[0] = row[k];
-            if (k + 1 < klim) o.v[1] = row[k + 1];
-            if (k + 2 < klim) o.v[2] = row[k + 2];
-            if (k + 3 < klim) o.v[3] = row[k + 3];
-        }
-    }
-    return o;
-}
-
-// acc[mb] += A[rb + mb*16 + (l&15)][kbeg:kend] . W_lane_row[kbeg:kend]^T  (one 16x16 output tile per mb).
-// The step kernels are latency-bound (one workgroup per CU, one wave per SIMD), so the loads of a whole
-// macro-chunk (NIT x 16 floats of K per operand row) are issued back-to-back into registers before the first
-// MFMA consumes them: at H=1024 a wave's entire K slice (16 iterations, 48 float4 at MB=2) is in flight at once.
-template <int MB, bool ALIGNED, int NIT>
-__device__ __forceinline__ void rec_mm_core(const float* __restrict__ A, long lda, int nrowsA, int rb,
-                                            const float* __restrict__ wrow, bool wvalid,
-                                            int kbeg, int kend, int l, f32x4 (&acc)[MB]) {
-    const int i = l & 15, kq = l >> 4;
-    const float* arow[MB];
-    bool avalid[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int b = rb + mb * 16 + i;
-        avalid[mb] = b < nrowsA;
-        arow[mb] = A + (long)(avalid[mb] ? b : 0) * lda;
-    }
-    // Rows beyond the batch / beyond H read row 0 (a valid address) and their products land in output rows /
-    // columns the epilogue discards, so only the K range needs zero-fill -- and a full macro-chunk needs none.
-    for (int k0 = kbeg; k0 < kend; k0 += 16 * NIT) {
-        Ld4 wv[NIT];
-        Ld4 av[NIT][MB];
-        if (ALIGNED && k0 + 16 * NIT <= kend) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int kk = k0 + 16 * it + 4 * kq;
-                const float4 t = *reinterpret_cast<const float4*>(wrow + kk);
-                wv[it].v[0] = t.x; wv[it].v[1] = t.y; wv[it].v[2] = t.z; wv[it].v[3] = t.w;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow[mb] + kk);
-                    av[it][mb].v[0] = a.x; av[it][mb].v[1] = a.y; av[it][mb].v[2] = a.z; av[it][mb].v[3] = a.w;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int kk = k0 + 16 * it + 4 * kq;
-                wv[it] = ld4<ALIGNED>(wrow, wvalid, kk, kend);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) av[it][mb] = ld4<ALIGNED>(arow[mb], avalid[mb], kk, kend);
-            }
-        }
-        LV_SCHED_BARRIER();   // all loads of the macro-chunk are in flight before the first MFMA waits on one
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[it][mb].v[j], wv[it].v[j], acc[mb]);
-    }
-}
+static inline int h_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 template <int MB> struct RecNit { static constexpr int value = MB <= 2 ? 16 : (MB == 4 ? 8 : 4); };
 
-__device__ __forceinline__ int round_up16(int x) { return (x + 15) & ~15; }
+// acc[mb] += sum over iterations [it0, it1) of (16 k each): A-block(mb) . W-block^T.
+// ap  -> Ap + mbase*64: packed activations, quad pitch = a_qpitch floats
+// wp  -> Wp + nb*Kq*64: this workgroup's packed weight block, quad pitch = 64 floats
+template <int MB, int NIT>
+__device__ __forceinline__ void rec_mm_core(const float* __restrict__ ap, long a_qpitch,
+                                            const float* __restrict__ wp, int it0, int it1, int l, f32x4 (&acc)[MB]) {
+    const int i = l & 15, kq = l >> 4;
+    const float* a_lane = ap + i * 4;
+    const float* w_lane = wp + i * 4;
+    for (int itb = it0; itb < it1; itb += NIT) {
+        float4 wv[NIT];
+        float4 av[NIT][MB];
+        if (itb + NIT <= it1) {
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const long q = 4 * (itb + u) + kq;
+                wv[u] = *reinterpret_cast<const float4*>(w_lane + q * 64);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[u][mb] = *reinterpret_cast<const float4*>(a_lane + q * a_qpitch + mb * 64);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const bool ok = itb + u < it1;
+                const long q = ok ? 4 * (itb + u) + kq : 4 * it0 + kq;     // clamped: load something valid, use zeros
+                const float4 t = *reinterpret_cast<const float4*>(w_lane + q * 64);
+                wv[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[u][mb] = *reinterpret_cast<const float4*>(a_lane + q * a_qpitch + mb * 64);
+            }
+        }
+        LV_SCHED_BARRIER();   // every load of the macro-chunk is in flight before the first MFMA waits on one
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[u][mb].x, wv[u].x, acc[mb]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[u][mb].y, wv[u].y, acc[mb]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[u][mb].z, wv[u].z, acc[mb]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x4(av[u][mb].w, wv[u].w, acc[mb]);
+        }
+    }
+}
+
+// ---- packing ---------------------------------------------------------------------------------------------------
+// forward weights: Wp[nb][kq][j][e] = whh[(j>>2)*H + 4*nb + (j&3)][4*kq + e]   (0 outside)
+__global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ whh, float* __restrict__ wp, int H, int Kq) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // one float4 of Wp
+    const long total = (long)((H + 3) / 4) * Kq * 16;
+    if (idx >= total) return;
+    const int j = (int)(idx % 16);
+    const int kq = (int)((idx / 16) % Kq);
+    const int nb = (int)(idx / (16L * Kq));
+    const int unit = 4 * nb + (j & 3);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (unit < H) {
+        const float* row = whh + ((long)(j >> 2) * H + unit) * H;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int k = 4 * kq + e; if (k < H) v[e] = row[k]; }
+    }
+    *reinterpret_cast<float4*>(wp + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// backward weights: WpT[nb][nq][j][e] = whh[4*nq + e][16*nb + j]   (contraction over the 4H gate rows)
+__global__ __launch_bounds__(256) void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wpT, int H, int Kq4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)((H + 15) / 16) * Kq4 * 16;
+    if (idx >= total) return;
+    const int j = (int)(idx % 16);
+    const int nq = (int)((idx / 16) % Kq4);
+    const int nb = (int)(idx / (16L * Kq4));
+    const int unit = 16 * nb + j;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (unit < H) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int n = 4 * nq + e; if (n < 4 * H) v[e] = whh[(long)n * H + unit]; }
+    }
+    *reinterpret_cast<float4*>(wpT + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// activations: Ap[k/4][b/16][b%16][k%4] = src[b][k]  (buffer pre-zeroed; only valid entries written)
+__global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__ src, float* __restrict__ ap, int B, int K, int MBTp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * K) return;
+    const int b = (int)(idx / K), k = (int)(idx % K);
+    ap[((long)(k >> 2) * MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (k & 3)] = src[idx];
+}
 
 struct LstmFwdP {
-    const float* gx; const float* whh; float* hs; float* cs; float* gates;
+    const float* gx; const float* wp; float* hs; float* cs; float* gates; float* hp;   // hp: 2 packed buffers
     const uint8_t* dmask; float dscale; float* hdrop;
-    int T, B, H;
+    int T, B, H, Kq, MBTp;
 };
 
-template <int MB, bool ALIGNED>
+template <int MB>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     __shared__ float red[4][MB][16][17];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int B = p.B, H = p.H;
     const long BH = (long)B * H;
-    const int u0 = (int)blockIdx.x * 4;
-    const int rb = (int)blockIdx.y * 16 * MB;
+    const int nb = (int)blockIdx.x;
+    const int u0 = nb * 4;
+    const int mbase = (int)blockIdx.y * MB;
+    const int rb = mbase * 16;
+    const long hp_sz = (long)p.Kq * p.MBTp * 64;
     const float* gx_t = p.gx + (long)t * B * 4 * H;
-    const float* h_prev = p.hs + (long)t * BH;
+    const float* hp_in = p.hp + (long)(t & 1) * hp_sz;
+    float* hp_out = p.hp + (long)((t + 1) & 1) * hp_sz;
     const float* c_prev = p.cs + (long)t * BH;
     float* h_out = p.hs + (long)(t + 1) * BH;
     float* c_out = p.cs + (long)(t + 1) * BH;
@@ -140,18 +165,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
         cp[q] = ok ? c_prev[(long)b * H + u] : 0.f;
     }
 
-    // recurrent matmul: this workgroup's 16 gate columns, K = H split over the 4 waves
-    const int n = l & 15;
-    const int unit = u0 + (n & 3);
-    const bool wvalid = unit < H;
-    const float* wrow = p.whh + ((long)(n >> 2) * H + (wvalid ? unit : 0)) * H;
-    const int chunk = round_up16((H + 3) / 4);
-    const int kbeg = w * chunk;
-    const int kend = (kbeg + chunk) < H ? (kbeg + chunk) : H;
+    // recurrent matmul: this workgroup's 16 gate columns, K split over the 4 waves in units of 16
+    const int nit = p.Kq / 4;
+    const int ipw = (nit + 3) / 4;
+    const int it0 = w * ipw;
+    const int it1 = (it0 + ipw) < nit ? (it0 + ipw) : nit;
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    rec_mm_core<MB, ALIGNED, RecNit<MB>::value>(h_prev, H, B, rb, wrow, wvalid, kbeg, kend, l, acc);
+    if (it0 < it1)
+        rec_mm_core<MB, RecNit<MB>::value>(hp_in + (long)mbase * 64, (long)p.MBTp * 64, p.wp + (long)nb * p.Kq * 64,
+                                           it0, it1, l, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -179,6 +203,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
             g_out[gi] = ig; g_out[gi + H] = fg; g_out[gi + 2L * H] = gg; g_out[gi + 3L * H] = og;
             c_out[(long)b * H + u] = c;
             h_out[(long)b * H + u] = h;
+            hp_out[((long)nb * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + uu] = h;    // packed copy for step t+1
             if (p.hdrop) {
                 float m = 1.f;
                 if (p.dmask) m = p.dmask[((long)b * p.T + t) * H + u] ? p.dscale : 0.f;
@@ -192,10 +217,10 @@ struct LstmBwdP {
     const float* dh_ext;   // [T][B][H] or null
     const float* dh_last;  // [B][H] or null (added at t = T-1)
     const uint8_t* dmask; float dscale;   // dropout on dh_ext (mask in reference [B][T][H] layout)
-    const float* whhT;     // [H][4H]
+    const float* wpT;      // packed transposed recurrent weights
     const float* gates; const float* cs;
-    float* dG; float* dGsum; float* dh_part; float* dc_rec;
-    int T, B, H, KS;
+    float* dG; float* dGsum; float* dGp; float* dh_part; float* dc_rec;
+    int T, B, H, KS, Kq4, MBTp;
 };
 
 // elementwise part of BPTT step t (KS = number of split-K slabs of the previous step's matmul, compile-time so
@@ -237,42 +262,45 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
     if (!first) dc += dcr;
     const float d_o = dh * tc;
     const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
-    const float da_i = d_i * ig * (1.f - ig);
-    const float da_f = d_f * fg * (1.f - fg);
-    const float da_g = d_g * (1.f - gg * gg);
-    const float da_o = d_o * og * (1.f - og);
+    float da[4];
+    da[0] = d_i * ig * (1.f - ig);
+    da[1] = d_f * fg * (1.f - fg);
+    da[2] = d_g * (1.f - gg * gg);
+    da[3] = d_o * og * (1.f - og);
     p.dc_rec[idx] = dc * fg;
-    p.dG[gi] = da_i; p.dG[gi + H] = da_f; p.dG[gi + 2L * H] = da_g; p.dG[gi + 3L * H] = da_o;
     const long si = (long)b * 4 * H + u;
-    if (first) {
-        p.dGsum[si] = da_i; p.dGsum[si + H] = da_f; p.dGsum[si + 2L * H] = da_g; p.dGsum[si + 3L * H] = da_o;
-    } else {
-        p.dGsum[si] += da_i; p.dGsum[si + H] += da_f; p.dGsum[si + 2L * H] += da_g; p.dGsum[si + 3L * H] += da_o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        p.dG[gi + (long)g * H] = da[g];
+        if (first) p.dGsum[si + (long)g * H] = da[g];
+        else p.dGsum[si + (long)g * H] += da[g];
+        const int n = g * H + u;                                   // packed copy: A operand of this step's matmul
+        p.dGp[((long)(n >> 2) * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (n & 3)] = da[g];
     }
 }
 
-// recurrent matmul of BPTT step t: dh_part[ks][b][j] = sum_{n in slice ks} dG[t][b][n] * whhT[j][n]
-template <int MB, bool ALIGNED>
+// recurrent matmul of BPTT step t: dh_part[ks][b][j] = sum_{n in slice ks} dG[t][b][n] * whh[n][j]
+template <int MB>
 __global__ __launch_bounds__(256) void lstm_step_bwd_mm_kernel(LstmBwdP p, int t) {
     __shared__ float red[4][MB][16][17];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int B = p.B, H = p.H, K = 4 * p.H;
+    const int B = p.B, H = p.H;
     const int nb = (int)blockIdx.x / p.KS, ks = (int)blockIdx.x % p.KS;
-    const int rb = (int)blockIdx.y * 16 * MB;
-    const float* A = p.dG + (long)t * B * K;
-    const int j = nb * 16 + (l & 15);
-    const bool wvalid = j < H;
-    const float* wrow = p.whhT + (long)(wvalid ? j : 0) * K;
-    const int kc = round_up16((K + p.KS - 1) / p.KS);
-    const int sbeg = ks * kc;
-    const int send = (sbeg + kc) < K ? (sbeg + kc) : K;
-    const int chunk = round_up16((kc + 3) / 4);
-    int kbeg = sbeg + w * chunk;
-    int kend = (kbeg + chunk) < send ? (kbeg + chunk) : send;
+    const int mbase = (int)blockIdx.y * MB;
+    const int rb = mbase * 16;
+    const int nit = p.Kq4 / 4;
+    const int ips = (nit + p.KS - 1) / p.KS;        // iterations per split-K slice
+    const int s0 = ks * ips;
+    const int s1 = (s0 + ips) < nit ? (s0 + ips) : nit;
+    const int ipw = (ips + 3) / 4;
+    const int it0 = s0 + w * ipw;
+    const int it1 = (it0 + ipw) < s1 ? (it0 + ipw) : s1;
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (kbeg < kend) rec_mm_core<MB, ALIGNED, RecNit<MB>::value>(A, K, B, rb, wrow, wvalid, kbeg, kend, l, acc);
+    if (it0 < it1)
+        rec_mm_core<MB, RecNit<MB>::value>(p.dGp + (long)mbase * 64, (long)p.MBTp * 64, p.wpT + (long)nb * p.Kq4 * 64,
+                                           it0, it1, l, acc);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -319,34 +347,62 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
-template <int MB>
-int launch_fwd_steps(const LstmFwdP& p, bool aligned, void* stream) {
-    dim3 grid((unsigned)lv_cdiv(p.H, 4), (unsigned)lv_cdiv(p.B, 16 * MB)), block(256);
-    for (int t = 0; t < p.T; ++t) {
-        if (aligned) LV_LAUNCH((lstm_step_fwd_kernel<MB, true>), grid, block, 0, stream, p, t);
-        else LV_LAUNCH((lstm_step_fwd_kernel<MB, false>), grid, block, 0, stream, p, t);
-    }
-    LV_CHECK_LAUNCH();
-    return LV_OK;
-}
-
-template <int MB>
-void launch_bwd_mm(const LstmBwdP& p, int t, bool aligned, void* stream) {
-    dim3 grid((unsigned)(lv_cdiv(p.H, 16) * p.KS), (unsigned)lv_cdiv(p.B, 16 * MB)), block(256);
-    if (aligned) LV_LAUNCH((lstm_step_bwd_mm_kernel<MB, true>), grid, block, 0, stream, p, t);
-    else LV_LAUNCH((lstm_step_bwd_mm_kernel<MB, false>), grid, block, 0, stream, p, t);
-}
-
 inline int pick_mb(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : (B <= 64 ? 4 : 8)); }
 
-}  // namespace
+struct Geo { int MB, MBT, MBTp, Kq, Kq4, NBf, NBb, KS; long wp, hp, wpT, dGp, part, dcrec; };
 
-extern "C" int lv_lstm_bwd_ksplit(int H) {
+inline int ksplit_for(int H) {
     int nb = (H + 15) / 16;
     int want = 256 / (nb > 0 ? nb : 1);
     int ks = 1;                       // power of two in {1,2,4,8}: the elementwise kernel is templated on it
     while (ks * 2 <= want && ks < 8) ks *= 2;
     return ks;
+}
+
+inline Geo geo(int B, int H) {
+    Geo g;
+    g.MB = pick_mb(B);
+    g.MBT = (B + 15) / 16;
+    g.MBTp = h_round_up(g.MBT, g.MB);
+    g.Kq = h_round_up(H, 16) / 4;
+    g.Kq4 = h_round_up(4 * H, 16) / 4;
+    g.NBf = (H + 3) / 4;
+    g.NBb = (H + 15) / 16;
+    g.KS = ksplit_for(H);
+    g.wp = (long)g.NBf * g.Kq * 64;
+    g.hp = 2L * g.Kq * g.MBTp * 64;
+    g.wpT = (long)g.NBb * g.Kq4 * 64;
+    g.dGp = (long)g.Kq4 * g.MBTp * 64;
+    g.part = ((long)g.KS * B * H + 3) / 4 * 4;
+    g.dcrec = ((long)B * H + 3) / 4 * 4;
+    return g;
+}
+
+template <int MB>
+int launch_fwd_steps(const LstmFwdP& p, void* stream) {
+    dim3 grid((unsigned)lv_cdiv(p.H, 4), (unsigned)(p.MBTp / MB)), block(256);
+    for (int t = 0; t < p.T; ++t) LV_LAUNCH((lstm_step_fwd_kernel<MB>), grid, block, 0, stream, p, t);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+template <int MB>
+void launch_bwd_mm(const LstmBwdP& p, int t, void* stream) {
+    dim3 grid((unsigned)(lv_cdiv(p.H, 16) * p.KS), (unsigned)(p.MBTp / MB)), block(256);
+    LV_LAUNCH((lstm_step_bwd_mm_kernel<MB>), grid, block, 0, stream, p, t);
+}
+
+}  // namespace
+
+extern "C" int lv_lstm_bwd_ksplit(int H) { return ksplit_for(H); }
+
+// floats of scratch lv_lstm_fwd_f32 / lv_lstm_bwd_f32 need (packed weights + packed state + split-K slabs)
+extern "C" long lv_lstm_ws_floats(int B, int H) {
+    if (B <= 0 || H <= 0) return 0;
+    const Geo g = geo(B, H);
+    const long fwd = g.wp + g.hp;
+    const long bwd = g.wpT + g.dGp + g.part + g.dcrec;
+    return (fwd > bwd ? fwd : bwd) + 64;
 }
 
 extern "C" int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
@@ -359,38 +415,47 @@ extern "C" int lv_transpose_f32(const float* in, float* out, int rows, int cols,
 }
 
 extern "C" int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
-                               const uint8_t* dmask, float dscale, float* hdrop,
+                               const uint8_t* dmask, float dscale, float* hdrop, float* ws,
                                int T, int B, int H, void* stream) {
-    if (!gx || !whh || !hs || !cs || !gates) return LV_ERR_ARG;
+    if (!gx || !whh || !hs || !cs || !gates || !ws) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (dmask && !hdrop) return LV_ERR_ARG;
-    LstmFwdP p{gx, whh, hs, cs, gates, dmask, dscale, hdrop, T, B, H};
-    const bool aligned = (H % 4 == 0) && ((((uintptr_t)whh) | ((uintptr_t)hs)) & 15) == 0;
-    switch (pick_mb(B)) {
-        case 1: return launch_fwd_steps<1>(p, aligned, stream);
-        case 2: return launch_fwd_steps<2>(p, aligned, stream);
-        case 4: return launch_fwd_steps<4>(p, aligned, stream);
-        default: return launch_fwd_steps<8>(p, aligned, stream);
+    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    const Geo g = geo(B, H);
+    float* wp = ws;
+    float* hp = ws + g.wp;
+    LV_LAUNCH(pack_w_fwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh, wp, H, g.Kq);
+    hipMemsetAsync(hp, 0, (size_t)g.hp * sizeof(float), (hipStream_t)stream);
+    LV_LAUNCH(pack_act_kernel, dim3((unsigned)lv_cdiv((long)B * H, 256)), dim3(256), 0, stream, (const float*)hs, hp, B, H, g.MBTp);
+    LstmFwdP p{gx, wp, hs, cs, gates, hp, dmask, dscale, hdrop, T, B, H, g.Kq, g.MBTp};
+    switch (g.MB) {
+        case 1: return launch_fwd_steps<1>(p, stream);
+        case 2: return launch_fwd_steps<2>(p, stream);
+        case 4: return launch_fwd_steps<4>(p, stream);
+        default: return launch_fwd_steps<8>(p, stream);
     }
 }
 
-// BPTT.  dh_part must hold lv_lstm_bwd_ksplit(H) * B * H floats; dc_rec B*H floats (returns dc wrt c_0's
-// successor chain, i.e. dL/dc_0 before the optional tanh-init term).  dh0/dc0 may be null.
+// BPTT.  ws: lv_lstm_ws_floats(B, H) floats of scratch.  dh0/dc0 may be null.
 extern "C" int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                               const float* whhT, const float* gates, const float* hs, const float* cs,
-                               float* dG, float* dGsum, float* dh_part, float* dc_rec,
-                               float* dh0, float* dc0, int tanh_init,
+                               const float* whh, const float* gates, const float* hs, const float* cs,
+                               float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
                                int T, int B, int H, void* stream) {
-    if (!whhT || !gates || !cs || !dG || !dGsum || !dh_part || !dc_rec) return LV_ERR_ARG;
+    if (!whh || !gates || !cs || !dG || !dGsum || !ws) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
-    LstmBwdP p{dh_ext, dh_last, dmask, dscale, whhT, gates, cs, dG, dGsum, dh_part, dc_rec, T, B, H,
-               lv_lstm_bwd_ksplit(H)};
-    const bool aligned = ((((uintptr_t)whhT) | ((uintptr_t)dG)) & 15) == 0;
+    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    const Geo g = geo(B, H);
+    float* wpT = ws;
+    float* dGp = wpT + g.wpT;
+    float* part = dGp + g.dGp;
+    float* dcrec = part + g.part;
+    LV_LAUNCH(pack_w_bwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh, wpT, H, g.Kq4);
+    hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
+    LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp};
     const long BH = (long)B * H;
     const bool need_h0 = (dh0 != nullptr) || tanh_init;
     dim3 egrid((unsigned)lv_cdiv(BH, 256)), block(256);
-    const int mb = pick_mb(B);
     for (int t = T - 1; t >= 0; --t) {
         switch (p.KS) {
             case 1: LV_LAUNCH((lstm_step_bwd_elem_kernel<1>), egrid, block, 0, stream, p, t); break;
@@ -399,22 +464,21 @@ extern "C" int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const 
             default: LV_LAUNCH((lstm_step_bwd_elem_kernel<8>), egrid, block, 0, stream, p, t); break;
         }
         if (t > 0 || need_h0) {
-            switch (mb) {
-                case 1: launch_bwd_mm<1>(p, t, aligned, stream); break;
-                case 2: launch_bwd_mm<2>(p, t, aligned, stream); break;
-                case 4: launch_bwd_mm<4>(p, t, aligned, stream); break;
-                default: launch_bwd_mm<8>(p, t, aligned, stream); break;
+            switch (g.MB) {
+                case 1: launch_bwd_mm<1>(p, t, stream); break;
+                case 2: launch_bwd_mm<2>(p, t, stream); break;
+                case 4: launch_bwd_mm<4>(p, t, stream); break;
+                default: launch_bwd_mm<8>(p, t, stream); break;
             }
         }
     }
     if (need_h0 || dc0) {
         if (!need_h0) {
-            // no recurrent term wanted: dc0 = dc_rec
-            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)dh_part, 0,
-                      (const float*)dc_rec, (const float*)nullptr, 0, (float*)nullptr, dc0, BH);
+            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, 0,
+                      (const float*)dcrec, (const float*)nullptr, 0, (float*)nullptr, dc0, BH);
         } else {
-            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)dh_part, p.KS,
-                      (const float*)dc_rec, hs, tanh_init, dh0, dc0, BH);
+            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, p.KS,
+                      (const float*)dcrec, hs, tanh_init, dh0, dc0, BH);
         }
     }
     LV_CHECK_LAUNCH();

@@ -200,11 +200,9 @@ class LSTMEncoderEngine(object):
             w.mulv = c.f32(B, nz2)
             w.dG = c.f32(T * B, 4 * H)
             w.dGsum = c.f32(B, 4 * H)
-            w.part = c.f32(self.lib.lv_lstm_bwd_ksplit(H), B, H)
-            w.dc_rec = c.f32(B, H)
+            w.lstm_ws = c.f32(self.lib.lv_lstm_ws_floats(B, H))
             w.dhT = c.f32(B, H)
             w.dX = c.f32(T * B, ni)
-            w.whhT = c.f32(H, 4 * H)
             w.srows = c.i32(T * B)
             w.stok = c.i32(T * B)
             w.stmp = c.i32(2 * T * B)
@@ -228,7 +226,7 @@ class LSTMEncoderEngine(object):
         w.cs[0].zero_()
         with _prof("lstm_fwd", 0.0, T):
             lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None,
-                                T, B, H, s)
+                                P(w.lstm_ws), T, B, H, s)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
@@ -249,10 +247,9 @@ class LSTMEncoderEngine(object):
         # head: dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T
         _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
-        lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
         with _prof("lstm_bwd", 0.0, 2 * T):
-            lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG), P(w.dGsum),
-                                P(w.part), P(w.dc_rec), None, None, 0, T, B, H, s)
+            lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
+                                P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
         # input-side grads
         _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
         _gemm(lib, s, 1, 0, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, prec=self.precision)
@@ -314,12 +311,10 @@ class LSTMDecoderEngine(object):
             w.dO = c.f32(Td * Bd, H)
             w.dG = c.f32(Td * Bd, 4 * H)
             w.dGsum = c.f32(Bd, 4 * H)
-            w.part = c.f32(self.lib.lv_lstm_bwd_ksplit(H), Bd, H)
-            w.dc_rec = c.f32(Bd, H)
+            w.lstm_ws = c.f32(self.lib.lv_lstm_ws_floats(Bd, H))
             w.dc0 = c.f32(Bd, H)
             w.dX = c.f32(Td * Bd, ni)
             w.dz = c.f32(Bd, nz)
-            w.whhT = c.f32(H, 4 * H)
             w.srows = c.i32(Td * Bd)
             w.stok = c.i32(Td * Bd)
             w.stmp = c.i32(2 * Td * Bd)
@@ -362,7 +357,7 @@ class LSTMDecoderEngine(object):
               add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
         with _prof("lstm_fwd", 0.0, Td):
             lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
-                                P(w.O), Td, B, H, s)
+                                P(w.O), P(w.lstm_ws), Td, B, H, s)
         _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
         lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
         # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
@@ -389,10 +384,9 @@ class LSTMDecoderEngine(object):
         lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
         _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         _gemm(lib, s, 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H, prec=self.precision)
-        lib.lv_transpose_f32(P(v["lstm.weight_hh_l0"]), P(w.whhT), 4 * H, H, s)
         with _prof("lstm_bwd", 0.0, 2 * Td):
-            lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(w.whhT), P(w.gates), P(w.hs), P(w.cs), P(w.dG),
-                                P(w.dGsum), P(w.part), P(w.dc_rec), None, P(w.dc0), 1, Td, B, H, s)
+            lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
+                                P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
         _gemm(lib, s, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision)
         _gemm(lib, s, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, prec=self.precision)
         _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
