@@ -34,6 +34,8 @@ WORKLOADS = {
     "yahoo": dict(V=20001, ni=512, H=1024, nz=32, B=32, T=200),
     "yelp": dict(V=19997, ni=512, H=1024, nz=32, B=32, T=100),
     "toy": dict(V=1004, ni=50, H=50, nz=1, B=16, T=12),
+    # BASELINE.json configs[3]: Omniglot ResNet-enc + PixelCNN-dec, 28x28 binary (parity-test case; bench line on request)
+    "omniglot": dict(B=50),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (same table)
@@ -44,6 +46,74 @@ GFLOP_PER_SEQ = {"yahoo": 39.67, "yelp": 19.75}   # SURVEY.md 8(d) / BASELINE.md
 def fwd_flops(V, ni, H, nz, B, T):
     return 2 * B * (T * ni * 4 * H + T * H * 4 * H + H * 2 * nz) + 2 * B * nz * H + \
         2 * B * (T - 1) * ((ni + nz) * 4 * H + H * 4 * H + H * V)
+
+
+def bench_omniglot(args, dev, rank, world):
+    """images/sec through the aggressive inner step of the Omniglot VAE (image.py:300-314), B=50 per GPU, replicas only
+    (BatchNorm batch statistics make naive data parallelism non-equivalent: SURVEY.md 8e)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_common as pc
+    from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    from oracle import image_vae_oracle as IO
+    B = WORKLOADS["omniglot"]["B"]
+    vae = pc.build_image_vae(dev, 783435)
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, seed=783435 + rank, precision=args.dtype)
+    g = torch.Generator().manual_seed(1 + rank)
+    probs = torch.rand(args.pool, B, 1, 28, 28, generator=g).to(dev)
+    rs = np.random.RandomState(783435)
+
+    def one_step():
+        tr.step(tr.binarize(probs[int(rs.randint(0, args.pool))]), 1.0)
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    prof = {}
+    engine.PROFILE = prof
+    tr.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    engine.PROFILE = None
+    stats = tr.read_stats()
+    value = world * B * args.steps / dt
+    out = {"metric": "aggressive-loop images/sec", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "omniglot ResNetEncoderV2 + PixelCNNDecoderV2 aggressive inner step (fwd+bwd+clip+encoder Adam), "
+                                  "B=%d/GPU, 28x28 binary, nz=32, fm=4" % B, "global_batch": world * B, "parallelism": "replicas%d" % world},
+           "mean_loss_per_image": round(stats["loss_sum"] / (B * args.steps), 4)}
+    gname = "gemm_" + args.dtype
+    recs = prof.get(gname, []) + (prof.get("gemm_f32", []) if args.dtype != "f32" else [])
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+    fl = sum(w for _, _, w, _ in recs)
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out["roofline"] = {"bound": "mfma", "kernel": "lv_gemm_%s_kernel (im2col convolutions)" % args.dtype, "achieved": round(tf, 2),
+                       "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                       "launches_per_step": len(recs) // args.steps, "ms_per_step": round(ms / args.steps, 4),
+                       "gflop_per_step": round(fl / args.steps / 1e9, 1)}
+    if rank == 0 and not args.no_cpu_baseline:
+        nthreads = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(nthreads)
+        Pd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+        xb = (probs[0].cpu() > 0.5).float()
+        eps = torch.randn(B, 1, 32)
+        IO.inner_step_adam(Pd, xb, 1.0, eps)
+        n, tcpu = 0, 0.0
+        while n < 5 and tcpu < 15.0:
+            tc = time.perf_counter()
+            IO.inner_step_adam(Pd, xb, 1.0, eps)
+            tcpu += time.perf_counter() - tc
+            n += 1
+        out["cpu_baseline"] = {"value": round(B * n / tcpu, 2), "unit": "img/s", "cores": nthreads, "kind": "port",
+                               "sample": "%d timed inner steps at B=%d after 1 warm-up, torch CPU ATen ops (the reference's CPU path "
+                                         "restated in oracle/image_vae_oracle.py)" % (n, B)}
+        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def main():
@@ -73,6 +143,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = WORKLOADS[args.workload]
+    if args.workload == "omniglot":
+        return bench_omniglot(args, dev, rank, world)
     V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
 
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank

@@ -118,6 +118,37 @@ int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float
 int lv_rng_normal_f32(float* out, long n, const uint64_t* state_dev, uint64_t substream, void* stream);
 int lv_rng_keepmask_u8(uint8_t* out, long n, float keep_prob, const uint64_t* state_dev, uint64_t substream, void* stream);
 int lv_rng_advance(uint64_t* state_dev, uint64_t inc, void* stream);
+int lv_rng_bernoulli_f32(const float* p, float* out, long n, const uint64_t* state_dev, uint64_t substream,
+                         void* stream);   /* torch.bernoulli(batch): dynamic binarisation, image.py:287,318 */
+
+/* ---- Omniglot path: ResNetEncoderV2 (modules/encoders/enc_resnet_v2.py:27-126) and PixelCNNDecoderV2
+ * (modules/decoders/dec_pixelcnn_v2.py:12-195).  Activations NHWC ([N*H*W][C]); a convolution = lv_im2col_f32 +
+ * lv_gemm_* against weights packed [Cout][taps][Cin]; 1x1 convolutions are plain GEMMs.  `ntaps` = length of the
+ * raster-order tap PREFIX that is materialised / used: kh*kw for an ordinary conv, (kh/2)*kw + kw/2 + 1 for a type-B
+ * masked conv (dec_pixelcnn_v2.py:17-20) -- the masked taps are skipped, not multiplied by zero. */
+int lv_im2col_f32(const float* x, float* col, long ldcol, int N, int H, int W, int C, int Ho, int Wo,
+                  int kh, int kw, int pad, int stride, int ntaps, void* stream);
+int lv_col2im_f32(const float* dcol, long ldcol, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                  int kh, int kw, int pad, int stride, int ntaps, int accumulate, void* stream);
+int lv_conv_pack_w_f32(const float* w /*[Cout][Cin][KK]*/, float* wg /*[Cout][KK][Cin]*/, int Cout, int Cin, int KK, void* stream);
+int lv_conv_unpack_dw_f32(const float* dwg, float* dw, int Cout, int Cin, int KK, int accumulate, void* stream);
+int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream);   /* MaskedConv2d.forward: weight.data.mul_(mask) */
+/* nn.BatchNorm2d in train mode (batch statistics, running stats momentum update with unbiased variance) fused with the
+ * residual add and nn.ELU that follow it in ResNetBlock / PixelCNNBlock; backward with ELU' from the saved output */
+int lv_bn_workspace_floats(int C);
+int lv_bn_fwd_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu,
+                  float* y, float* mean, float* invstd, float* run_mean, float* run_var,
+                  float eps, float momentum, float* ws, long P, int C, void* stream);
+int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
+                  const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
+                  int accumulate_param_grads, float* ws /* lv_bn_workspace_floats(C) + 2C */, long P, int C, void* stream);
+/* nn.Sigmoid + the BCE of PixelCNNDecoderV2.reconstruct_error (dec_pixelcnn_v2.py:190-195, eps = 1e-12) */
+int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream);
+int lv_sigmoid_bce_bwd_f32(const float* logit, const float* x, const float* drec, float* dlogit, int B, int npix,
+                           float eps, void* stream);
+/* torch.cat([img, z_transform(z).view(B, fm, 28, 28)], dim) as one NHWC tensor (dec_pixelcnn_v2.py:178-186) */
+int lv_dec_input_fwd_f32(const float* x, const float* zt, float* in5, int B, int npix, int fm, void* stream);
+int lv_dec_input_bwd_f32(const float* din5, float* dzt, int B, int npix, int fm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -72,3 +72,18 @@ def test_philox(emu_backend):
     assert torch.equal(a, b)
     emu_backend.lv_rng_advance(P(st), 1, None)
     assert int(st[1]) == 1
+
+
+@pytest.mark.parametrize("cfg", [(2, 5, 8, 9, 7, 1, 3, "A"), (2, 8, 8, 9, 5, 1, 2, "B"), (3, 4, 6, 7, 3, 2, 1, None),
+                                 (2, 8, 16, 4, 4, 1, 0, None), (3, 4, 6, 7, 1, 2, 0, None)])
+def test_conv(emu_backend, cfg):
+    K.test_conv_im2col_gemm_fwd_bwd(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(3, 8, 5, True, True), (2, 64, 6, False, False), (2, 300, 3, True, True)])
+def test_batchnorm(emu_backend, cfg):
+    K.test_batchnorm_train_fwd_bwd(emu_backend, CPU, *cfg)
+
+
+def test_bce_dec_input_bernoulli(emu_backend):
+    K.test_sigmoid_bce_and_dec_input(emu_backend, CPU)

@@ -314,3 +314,146 @@ def test_philox_draws(lib, hip_device):
     lib.lv_rng_normal_f32(P(b), n, P(st), 0, _s(dev))
     assert not torch.equal(a, b)
     assert abs(float((a * b).mean())) < 5e-3                 # successive draws uncorrelated
+
+
+# ---- Omniglot path kernels -----------------------------------------------------------------------------------------
+def _nhwc(x):   # (N,C,H,W) -> [N*H*W, C]
+    N, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(N * H * W, C).contiguous()
+
+
+def _nchw(t, N, H, W):
+    return t.reshape(N, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,stride,pad,masked", [
+    (2, 5, 8, 9, 7, 1, 3, "A"), (2, 8, 8, 9, 7, 1, 3, "B"), (2, 8, 8, 9, 5, 1, 2, "B"), (3, 4, 6, 7, 3, 2, 1, None),
+    (2, 1, 8, 28, 3, 2, 1, None), (2, 8, 16, 4, 4, 1, 0, None), (3, 4, 6, 7, 1, 2, 0, None), (2, 8, 4, 6, 3, 1, 1, "B"),
+])
+def test_conv_im2col_gemm_fwd_bwd(lib, hip_device, N, Cin, Cout, H, k, stride, pad, masked):
+    """conv = lv_im2col_f32 + lv_gemm_f32 (+ tap-prefix skipping for type-B masks); backward = GEMMs + lv_col2im_f32,
+    against F.conv2d autograd in float64."""
+    import torch.nn.functional as F
+    dev = hip_device
+    g = torch.Generator().manual_seed(N * 100 + Cin * 10 + k)
+    W = H
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.3
+    mask = torch.ones_like(w)
+    nt = k * k
+    if masked:
+        mc = 1 if masked == "A" else Cin
+        mask[:, :mc, k // 2, k // 2 + (masked == "B"):] = 0
+        mask[:, :mc, k // 2 + 1:] = 0
+        if masked == "B":
+            nt = (k // 2) * k + k // 2 + 1
+    wm = w * mask
+    x64 = x.double().requires_grad_(True)
+    w64 = wm.double().requires_grad_(True)
+    y_ref = F.conv2d(x64, w64, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * dy.double()).sum().backward()
+    Ho, Wo = y_ref.shape[2], y_ref.shape[3]
+    Pout, KK = N * Ho * Wo, k * k
+    xd = _nhwc(x).to(dev)
+    wd = wm.contiguous().to(dev)
+    col = torch.empty(Pout, KK * Cin, device=dev)
+    lib.lv_im2col_f32(P(xd), P(col), KK * Cin, N, H, W, Cin, Ho, Wo, k, k, pad, stride, KK, _s(dev))
+    wg = torch.empty(Cout, KK * Cin, device=dev)
+    lib.lv_conv_pack_w_f32(P(wd), P(wg), Cout, Cin, KK, _s(dev))
+    y = torch.empty(Pout, Cout, device=dev)
+    ws = torch.empty(1 << 20, device=dev)
+    K = nt * Cin
+    lib.lv_gemm_f32(0, 1, Pout, Cout, K, 1.0, P(col), KK * Cin, P(wg), KK * Cin, P(y), Cout, 0, None, 0, 1, None, 0, 1,
+                    P(ws), ws.numel(), _s(dev))
+    assert float((_nchw(y.cpu(), N, Ho, Wo).double() - y_ref.detach()).abs().max()) < 1e-4
+    dyd = _nhwc(dy).to(dev)
+    dwg = torch.empty(Cout, KK * Cin, device=dev)
+    lib.lv_gemm_f32(1, 0, Cout, KK * Cin, Pout, 1.0, P(dyd), Cout, P(col), KK * Cin, P(dwg), KK * Cin, 0, None, 0, 1, None, 0, 1,
+                    P(ws), ws.numel(), _s(dev))
+    dw = torch.empty(Cout, Cin, k, k, device=dev)
+    lib.lv_conv_unpack_dw_f32(P(dwg), P(dw), Cout, Cin, KK, 0, _s(dev))
+    assert float((dw.cpu().double() - w64.grad).abs().max()) < 1e-3      # ALL taps, masked ones included (G5)
+    dcol = torch.empty(Pout, K, device=dev)
+    lib.lv_gemm_f32(0, 0, Pout, K, Cout, 1.0, P(dyd), Cout, P(wg), KK * Cin, P(dcol), K, 0, None, 0, 1, None, 0, 1,
+                    P(ws), ws.numel(), _s(dev))
+    dx = torch.empty(N * H * W, Cin, device=dev)
+    lib.lv_col2im_f32(P(dcol), K, P(dx), N, H, W, Cin, Ho, Wo, k, k, pad, stride, nt, 0, _s(dev))
+    assert float((_nchw(dx.cpu(), N, H, W).double() - x64.grad).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("N,C,H,act,use_res", [(3, 8, 5, True, True), (4, 32, 7, True, False), (2, 64, 6, False, False),
+                                                (5, 512, 1, True, False), (2, 300, 3, True, True)])
+def test_batchnorm_train_fwd_bwd(lib, hip_device, N, C, H, act, use_res):
+    import torch.nn.functional as F
+    dev = hip_device
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, H, generator=g) * 2 + 0.5
+    res = torch.randn(N, C, H, H, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    x64, g64, b64, r64 = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True), res.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    y_ref = F.batch_norm(x64, rm, rv, g64, b64, True, 0.1, 1e-5)
+    if use_res:
+        y_ref = y_ref + r64
+    if act:
+        y_ref = F.elu(y_ref)
+    dy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * dy.double()).sum().backward()
+    Pn = N * H * H
+    xd, resd, gd, bd = _nhwc(x).to(dev), _nhwc(res).to(dev), gamma.to(dev), beta.to(dev)
+    rmd, rvd = rm0.clone().to(dev), rv0.clone().to(dev)
+    y = torch.empty(Pn, C, device=dev)
+    mean = torch.empty(C, device=dev)
+    invstd = torch.empty(C, device=dev)
+    ws = torch.empty(lib.lv_bn_workspace_floats(C) + 2 * C, device=dev)
+    lib.lv_bn_fwd_f32(P(xd), P(gd), P(bd), P(resd) if use_res else None, int(act), P(y), P(mean), P(invstd), P(rmd), P(rvd),
+                      1e-5, 0.1, P(ws), Pn, C, _s(dev))
+    assert float((_nchw(y.cpu(), N, H, H).double() - y_ref.detach()).abs().max()) < 2e-5
+    assert float((rmd.cpu().double() - rm).abs().max()) < 1e-5 and float((rvd.cpu().double() - rv).abs().max()) < 1e-4
+    dyd = _nhwc(dy).to(dev)
+    dv = torch.empty(Pn, C, device=dev)
+    dx = torch.empty(Pn, C, device=dev)
+    dg = torch.empty(C, device=dev)
+    db = torch.empty(C, device=dev)
+    lib.lv_bn_bwd_f32(P(xd), P(dyd), P(y), P(mean), P(invstd), P(gd), int(act), P(dv), P(dx), P(dg), P(db), 0, P(ws), Pn, C, _s(dev))
+    sc = float(x64.grad.abs().max())
+    assert float((_nchw(dx.cpu(), N, H, H).double() - x64.grad).abs().max()) < 2e-4 * sc
+    assert float((dg.cpu().double() - g64.grad).abs().max()) < 2e-4 * float(g64.grad.abs().max())
+    assert float((db.cpu().double() - b64.grad).abs().max()) < 2e-4 * float(b64.grad.abs().max())
+    if use_res:
+        assert float((_nchw(dv.cpu(), N, H, H).double() - r64.grad).abs().max()) < 2e-4 * float(r64.grad.abs().max())
+
+
+def test_sigmoid_bce_and_dec_input(lib, hip_device):
+    dev = hip_device
+    g = torch.Generator().manual_seed(4)
+    B, npix, fm = 5, 28 * 28, 4
+    logit = (torch.randn(B, npix, generator=g) * 3).to(dev)
+    x = (torch.rand(B, npix, generator=g) < 0.4).float().to(dev)
+    rec = torch.empty(B, device=dev)
+    lib.lv_sigmoid_bce_fwd_f32(P(logit), P(x), P(rec), B, npix, 1e-12, _s(dev))
+    l64 = logit.double().requires_grad_(True)
+    p = torch.sigmoid(l64)
+    ref = -((p + 1e-12).log() * x.double() + (1 - p + 1e-12).log() * (1 - x.double())).sum(1)
+    assert float((rec.double() - ref.detach()).abs().max()) < 1e-4 * float(ref.abs().max())
+    drec = torch.rand(B, generator=g).to(dev)
+    (ref * drec.double()).sum().backward()
+    dl = torch.empty(B, npix, device=dev)
+    lib.lv_sigmoid_bce_bwd_f32(P(logit), P(x), P(drec), P(dl), B, npix, 1e-12, _s(dev))
+    assert float((dl.double() - l64.grad).abs().max()) < 1e-5
+    zt = torch.randn(B, fm * npix, generator=g).to(dev)
+    in5 = torch.empty(B * npix, 1 + fm, device=dev)
+    lib.lv_dec_input_fwd_f32(P(x), P(zt), P(in5), B, npix, fm, _s(dev))
+    ref5 = torch.cat([x.view(B, 1, npix), zt.view(B, fm, npix)], 1).permute(0, 2, 1).reshape(B * npix, 1 + fm)
+    assert torch.equal(in5, ref5)
+    dzt = torch.empty(B, fm * npix, device=dev)
+    lib.lv_dec_input_bwd_f32(P(in5), P(dzt), B, npix, fm, _s(dev))
+    assert torch.equal(dzt, zt)
+    st = torch.tensor([5, 0], dtype=torch.int64, device=dev)
+    probs = torch.rand(20000, generator=g).to(dev)
+    out = torch.empty(20000, device=dev)
+    lib.lv_rng_bernoulli_f32(P(probs), P(out), 20000, P(st), 7, _s(dev))
+    assert set(out.unique().tolist()) <= {0.0, 1.0} and abs(float(out.mean()) - float(probs.mean())) < 0.02

@@ -183,3 +183,36 @@ def test_dropin_surface(hip_device):
     loss, rc, k = vae.loss(x, 0.5)            # default path: torch device RNG for eps and masks
     loss.mean().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in vae.parameters())
+
+
+# ---- Omniglot path (BASELINE.json configs[3]: ResNet encoder + PixelCNN decoder, 28x28 binary, B=50) -------------------
+@pytest.mark.parametrize("name", ["image_b6", "image_b50"])
+def test_image_step_dropin_matches_reference_fixture(hip_device, name):
+    pc.check_image_step_dropin(name, hip_device)
+
+
+@pytest.mark.parametrize("name", ["image_b6", "image_b50"])
+def test_image_step_fused_matches_reference_fixture(hip_device, name):
+    pc.check_image_step_fused(name, hip_device)
+
+
+def test_image_step_is_deterministic_and_masks_stay_applied(hip_device):
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    fx = load("image_b50")
+    x = torch.from_numpy(fx["x"]).float().to(hip_device)
+    eps = torch.from_numpy(fx["eps"]).to(hip_device)
+    outs = []
+    for _ in range(2):
+        vae = pc.build_image_vae(hip_device, int(fx["model_seed"]))
+        tr = AggressiveImageTrainer(vae)
+        tr.step(x, 1.0, eps=eps)
+        tr.step(tr.binarize(torch.full_like(x, 0.3)), 1.0, eps=eps)      # second step on a device-binarised batch
+        outs.append(({k: v.clone() for k, v in vae.state_dict().items()}, tr.read_stats()))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert outs[0][1] == outs[1][1]
+    sd = outs[0][0]
+    for k in sd:
+        if k.endswith(".mask"):
+            w = sd[k.replace(".mask", ".weight")]
+            assert float((w * (1 - sd[k])).abs().max()) == 0.0            # masked taps zeroed in place (G5)

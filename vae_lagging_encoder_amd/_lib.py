@@ -49,6 +49,19 @@ SIGNATURES = {
     "lv_rng_normal_f32": [_vp, _l, _vp, _u64, _vp],
     "lv_rng_keepmask_u8": [_vp, _l, _f, _vp, _u64, _vp],
     "lv_rng_advance": [_vp, _u64, _vp],
+    "lv_rng_bernoulli_f32": [_vp, _vp, _l, _vp, _u64, _vp],
+    "lv_im2col_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "lv_col2im_f32": [_vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "lv_conv_pack_w_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "lv_conv_unpack_dw_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],
+    "lv_bn_workspace_floats": [_i],
+    "lv_bn_fwd_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _vp],
+    "lv_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
+    "lv_sigmoid_bce_fwd_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "lv_sigmoid_bce_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "lv_dec_input_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_dec_input_bwd_f32": [_vp, _vp, _i, _i, _i, _vp],
 }
 
 
@@ -75,7 +88,7 @@ class Lib(object):
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats"}
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

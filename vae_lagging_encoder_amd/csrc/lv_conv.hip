@@ -20,7 +20,7 @@ namespace {
 
 // col[p][t*C + c] = x[n][ho*s + dh][wo*s + dw][c]  (0 outside); taps t = 0..nt-1 in raster order of the kh x kw window
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long ldcol,
-                                                     int N, int H, int W, int C, int Ho, int Wo, int kh, int kw, int pad,
+                                                     int N, int H, int W, int C, int Ho, int Wo, int kw, int pad,
                                                      int stride, int nt) {
     const long total = (long)N * Ho * Wo * nt * C;
     const long gs = (long)gridDim.x * 256;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 
 // dx[n][h][w][c] (=|+=) sum_t dcol[p(h,w,t)][t*C + c] over the taps/outputs that read (h,w)
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, long ldcol, float* __restrict__ dx,
-                                                     int N, int H, int W, int C, int Ho, int Wo, int kh, int kw, int pad,
+                                                     int N, int H, int W, int C, int Ho, int Wo, int kw, int pad,
                                                      int stride, int nt, int accumulate) {
     const long total = (long)N * H * W * C;
     const long gs = (long)gridDim.x * 256;
@@ -57,16 +57,13 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
     }
 }
 
-// wg[co][t][ci] = w[co][ci][t] * (mask ? mask[co][ci][t] : 1)   (reference weights are [Cout][Cin][kh][kw])
-__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, const float* __restrict__ mask,
-                                                          float* __restrict__ wg, int Cout, int Cin, int KK) {
+// wg[co][t][ci] = w[co][ci][t]   (reference weights are [Cout][Cin][kh][kw])
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const float* __restrict__ w, float* __restrict__ wg,
+                                                          int Cout, int Cin, int KK) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Cout * Cin * KK) return;
     const int ci = (int)(idx % Cin), t = (int)((idx / Cin) % KK), co = (int)(idx / ((long)Cin * KK));
-    const long src = ((long)co * Cin + ci) * KK + t;
-    float v = w[src];
-    if (mask) v *= mask[src];
-    wg[idx] = v;
+    wg[idx] = w[((long)co * Cin + ci) * KK + t];
 }
 
 // dw[co][ci][t] = dwg[co][t][ci]
@@ -85,17 +82,296 @@ __global__ __launch_bounds__(256) void mul_inplace_kernel(float* __restrict__ w,
     if (i < n) w[i] *= m[i];
 }
 
-constexpr int BN_BLOCKS = 256;
+constexpr int BN_BLOCKS = 128;
 
-// stage 1: partial[blk][0][c] = sum x, partial[blk][1][c] = sum x*x (optionally of dy and dy*xhat for backward)
-// MODE 0: stats of x.  MODE 1: (sum dv, sum dv*xhat) with dv = dy * elu'(y) (if act) -- also writes dv in place of dy.
+// Per-channel column reductions over a [P][C] matrix, stage 1: block blk reduces rows blk, blk+nblk, ... (in groups
+// of 256/CT rows, CT = channels handled per pass) and writes partial[blk][q][c], q = 0,1.
+// MODE 0 (forward stats):  q0 = sum x,            q1 = sum x*x
+// MODE 1 (backward):       dv = dy * elu'(y) (act) written to dv_out; q0 = sum dv, q1 = sum dv * xhat
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, float* __restrict__ dy,
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int act,
-                                                        float* __restrict__ partial, long P, int C, int nblk) {
-    extern __shared__ float sm[];   // not used in emulation path: see LV_DYN_SHARED below
-    (void)sm;
+                                                        float* __restrict__ dv_out, float* __restrict__ partial,
+                                                        long P, int C, int nblk) {
+    __shared__ float s0[256], s1[256];
+    const int tid = (int)threadIdx.x;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int CT = (C - c0) < 256 ? (C - c0) : 256;      // channels in this pass
+        const int RPB = 256 / CT;                             // rows per block iteration (>= 1)
+        const int c = c0 + tid % CT, rsub = tid / CT;
+        float a0 = 0.f, a1 = 0.f;
+        if (rsub < RPB) {
+            float mu = 0.f, is = 0.f;
+            if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+            for (long r = (long)blockIdx.x * RPB + rsub; r < P; r += (long)nblk * RPB) {
+                const long i = r * C + c;
+                if (MODE == 0) {
+                    const float v = x[i];
+                    a0 += v; a1 += v * v;
+                } else {
+                    float g = dy[i];
+                    if (act) { const float yy = y[i]; g = yy > 0.f ? g : g * (yy + 1.f); }
+                    dv_out[i] = g;
+                    a0 += g; a1 += g * ((x[i] - mu) * is);
+                }
+            }
+        }
+        s0[tid] = a0; s1[tid] = a1;
+        __syncthreads();
+        if (tid < CT) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int k = 0; k < RPB; ++k) { t0 += s0[tid + k * CT]; t1 += s1[tid + k * CT]; }
+            partial[((long)blockIdx.x * 2 + 0) * C + c0 + tid] = t0;
+            partial[((long)blockIdx.x * 2 + 1) * C + c0 + tid] = t1;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2 forward: mean, invstd = 1/sqrt(var_biased + eps); running stats with momentum (unbiased var), f64 combine
+__global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restrict__ partial, int nblk, long P, int C,
+                                                            float eps, float momentum, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ run_mean,
+                                                            float* __restrict__ run_var) {
+    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += (double)partial[((long)b * 2 + 0) * C + c]; q += (double)partial[((long)b * 2 + 1) * C + c]; }
+    const double m = s / (double)P;
+    double var = q / (double)P - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * (double)run_mean[c] + momentum * m);
+        run_var[c] = (float)((1.0 - momentum) * (double)run_var[c] + momentum * unb);
+    }
+}
+
+// stage 2 backward: dbeta, dgamma
+__global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += (double)partial[((long)b * 2 + 0) * C + c]; q += (double)partial[((long)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)(s + (accumulate ? (double)dbeta[c] : 0.0));
+    dgamma[c] = (float)(q + (accumulate ? (double)dgamma[c] : 0.0));
+}
+
+// y = act((x - mean) * invstd * gamma + beta (+ res))
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           int act, float* __restrict__ y, long n, int C) {
+    const long gs = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+        const int c = (int)(i % C);
+        float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (res) v += res[i];
+        if (act) v = v > 0.f ? v : expm1f(v);
+        y[i] = v;
+    }
+}
+
+// dx = gamma*invstd * (dv - dbeta/P - xhat * dgamma/P); dbeta/dgamma are THIS layer's sums (dbl, dgl), not accumulated
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dv,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgl,
+                                                           const float* __restrict__ dbl, float* __restrict__ dx,
+                                                           long n, int C, float invP) {
+    const long gs = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+        const int c = (int)(i % C);
+        const float is = invstd[c];
+        const float xh = (x[i] - mean[c]) * is;
+        dx[i] = gamma[c] * is * (dv[i] - dbl[c] * invP - xh * dgl[c] * invP);
+    }
+}
+
+// rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
+__global__ __launch_bounds__(256) void sigmoid_bce_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ x,
+                                                              float* __restrict__ rec, int npix, float eps) {
+    __shared__ float red[4];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < npix; i += 256) {
+        const float p = 1.f / (1.f + expf(-logit[(long)b * npix + i]));
+        const float xv = x[(long)b * npix + i];
+        s += logf(p + eps) * xv + logf(1.f - p + eps) * (1.f - xv);
+    }
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) rec[b] = -((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void sigmoid_bce_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ x,
+                                                              const float* __restrict__ drec, float* __restrict__ dlogit,
+                                                              int npix, long n, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = (int)(i / npix);
+    const float p = 1.f / (1.f + expf(-logit[i]));
+    const float xv = x[i];
+    const float dp = -(xv / (p + eps) - (1.f - xv) / (1.f - p + eps));
+    dlogit[i] = drec[b] * dp * p * (1.f - p);
+}
+
+// decoder input: in5[b][pix][0] = x[b][pix]; in5[b][pix][1+c] = zt[b][c*npix + pix]   (dec_pixelcnn_v2.py:178-186)
+__global__ __launch_bounds__(256) void dec_input_fwd_kernel(const float* __restrict__ x, const float* __restrict__ zt,
+                                                            float* __restrict__ in5, int npix, int fm, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*npix*(1+fm)
+    if (i >= n) return;
+    const int C = 1 + fm;
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int pix = (int)(p % npix);
+    const long b = p / npix;
+    in5[i] = c == 0 ? x[p] : zt[(b * fm + (c - 1)) * npix + pix];
+}
+
+__global__ __launch_bounds__(256) void dec_input_bwd_kernel(const float* __restrict__ din5, float* __restrict__ dzt,
+                                                            int npix, int fm, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // over B*fm*npix
+    if (i >= n) return;
+    const int pix = (int)(i % npix);
+    const int c = (int)((i / npix) % fm);
+    const long b = i / ((long)npix * fm);
+    dzt[i] = din5[(b * npix + pix) * (1 + fm) + 1 + c];
+}
+
+static inline unsigned conv_grid(long n) {
+    long b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;
+    return (unsigned)b;
 }
 
 }  // namespace
+
+// col[N*Ho*Wo][ldcol] <- the first `ntaps` raster-order taps of a kh x kw window (stride, pad) of NHWC x
+extern "C" int lv_im2col_f32(const float* x, float* col, long ldcol, int N, int H, int W, int C, int Ho, int Wo,
+                             int kh, int kw, int pad, int stride, int ntaps, void* stream) {
+    if (!x || !col) return LV_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return LV_ERR_SHAPE;
+    if (ntaps <= 0 || ntaps > kh * kw || ldcol < (long)ntaps * C) return LV_ERR_SHAPE;
+    LV_LAUNCH(im2col_kernel, dim3(conv_grid((long)N * Ho * Wo * ntaps * C)), dim3(256), 0, stream, x, col, ldcol, N, H, W, C, Ho, Wo,
+              kw, pad, stride, ntaps);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_col2im_f32(const float* dcol, long ldcol, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                             int kh, int kw, int pad, int stride, int ntaps, int accumulate, void* stream) {
+    if (!dcol || !dx) return LV_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return LV_ERR_SHAPE;
+    if (ntaps <= 0 || ntaps > kh * kw || ldcol < (long)ntaps * C) return LV_ERR_SHAPE;
+    LV_LAUNCH(col2im_kernel, dim3(conv_grid((long)N * H * W * C)), dim3(256), 0, stream, dcol, ldcol, dx, N, H, W, C, Ho, Wo,
+              kw, pad, stride, ntaps, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_conv_pack_w_f32(const float* w, float* wg, int Cout, int Cin, int KK, void* stream) {
+    if (!w || !wg || Cout <= 0 || Cin <= 0 || KK <= 0) return LV_ERR_ARG;
+    LV_LAUNCH(conv_pack_w_kernel, dim3((unsigned)lv_cdiv((long)Cout * Cin * KK, 256)), dim3(256), 0, stream, w, wg, Cout, Cin, KK);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_conv_unpack_dw_f32(const float* dwg, float* dw, int Cout, int Cin, int KK, int accumulate, void* stream) {
+    if (!dwg || !dw || Cout <= 0 || Cin <= 0 || KK <= 0) return LV_ERR_ARG;
+    LV_LAUNCH(conv_unpack_dw_kernel, dim3((unsigned)lv_cdiv((long)Cout * Cin * KK, 256)), dim3(256), 0, stream, dwg, dw, Cout, Cin, KK,
+              accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream) {
+    if (!w || !m || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(mul_inplace_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, w, m, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_bn_workspace_floats(int C) { return BN_BLOCKS * 2 * (C > 0 ? C : 1); }
+
+// BatchNorm2d (train) forward over x [P][C]: batch stats -> mean/invstd (saved), running stats (momentum, unbiased var),
+// y = act(xhat*gamma + beta (+ res)).  ws: lv_bn_workspace_floats(C).
+extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu,
+                             float* y, float* mean, float* invstd, float* run_mean, float* run_var,
+                             float eps, float momentum, float* ws, long P, int C, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !invstd || !ws) return LV_ERR_ARG;
+    if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
+    int nblk = (int)((P + 63) / 64);
+    if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
+    LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
+              (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
+    LV_LAUNCH(bn_finish_fwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, P, C, eps, momentum,
+              mean, invstd, run_mean, run_var);
+    LV_LAUNCH(bn_apply_fwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)mean, (const float*)invstd, gamma,
+              beta, res, act_elu, y, P * C, C);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// BatchNorm2d (train) backward.  dy = grad wrt y (post-activation); y = saved output (for ELU').  Writes
+// dv = dy*elu'(y) (also the gradient of the residual input), dgamma/dbeta (=|+=), dx.
+// ws: lv_bn_workspace_floats(C) + 2*C floats.
+extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
+                             const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
+                             int accumulate_param_grads, float* ws, long P, int C, void* stream) {
+    if (!x || !dy || !mean || !invstd || !gamma || !dv || !dx || !dgamma || !dbeta || !ws) return LV_ERR_ARG;
+    if (act_elu && !y) return LV_ERR_ARG;
+    if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
+    int nblk = (int)((P + 63) / 64);
+    if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
+    float* dgl = ws + (long)BN_BLOCKS * 2 * C;
+    float* dbl = dgl + C;
+    LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
+    LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgl, dbl, 0);
+    LV_LAUNCH(bn_apply_bwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)dv, mean, invstd, gamma,
+              (const float*)dgl, (const float*)dbl, dx, P * C, C, 1.0f / (float)P);
+    // parameter grads: (=|+=) this layer's sums
+    LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgamma, dbeta,
+              accumulate_param_grads);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream) {
+    if (!logit || !x || !rec || B <= 0 || npix <= 0) return LV_ERR_ARG;
+    LV_LAUNCH(sigmoid_bce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, stream, logit, x, rec, npix, eps);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_sigmoid_bce_bwd_f32(const float* logit, const float* x, const float* drec, float* dlogit, int B, int npix,
+                                      float eps, void* stream) {
+    if (!logit || !x || !drec || !dlogit || B <= 0 || npix <= 0) return LV_ERR_ARG;
+    const long n = (long)B * npix;
+    LV_LAUNCH(sigmoid_bce_bwd_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, logit, x, drec, dlogit, npix, n, eps);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_dec_input_fwd_f32(const float* x, const float* zt, float* in5, int B, int npix, int fm, void* stream) {
+    if (!x || !zt || !in5 || B <= 0 || npix <= 0 || fm < 0) return LV_ERR_ARG;
+    const long n = (long)B * npix * (1 + fm);
+    LV_LAUNCH(dec_input_fwd_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, x, zt, in5, npix, fm, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_dec_input_bwd_f32(const float* din5, float* dzt, int B, int npix, int fm, void* stream) {
+    if (!din5 || !dzt || B <= 0 || npix <= 0 || fm <= 0) return LV_ERR_ARG;
+    const long n = (long)B * npix * fm;
+    LV_LAUNCH(dec_input_bwd_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, din5, dzt, npix, fm, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

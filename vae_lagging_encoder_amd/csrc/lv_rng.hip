@@ -73,6 +73,17 @@ __global__ __launch_bounds__(256) void rng_keepmask_kernel(uint8_t* __restrict__
     }
 }
 
+// out[i] = 1 with probability p[i] (torch.bernoulli(batch) of image.py:287,318: dynamic binarisation)
+__global__ __launch_bounds__(256) void rng_bernoulli_kernel(const float* __restrict__ p, float* __restrict__ out, long n,
+                                                            const uint64_t* __restrict__ state, uint64_t substream) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // 4 outputs per thread
+    if (i * 4 >= n) return;
+    const U4 r = draw(state, substream, (uint64_t)i);
+    const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+    for (int j = 0; j < 4; ++j)
+        if (i * 4 + j < n) out[i * 4 + j] = (u[j] < p[i * 4 + j]) ? 1.f : 0.f;
+}
+
 __global__ void rng_advance_kernel(uint64_t* state, uint64_t inc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += inc;
 }
@@ -94,6 +105,15 @@ extern "C" int lv_rng_keepmask_u8(uint8_t* out, long n, float keep_prob, const u
     if (n == 0) return LV_OK;
     LV_LAUNCH(rng_keepmask_kernel, dim3((unsigned)lv_cdiv((n + 7) / 8, 256)), dim3(256), 0, stream, out, n, keep_prob, state,
               substream);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_rng_bernoulli_f32(const float* p, float* out, long n, const uint64_t* state, uint64_t substream,
+                                    void* stream) {
+    if (!p || !out || !state || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(rng_bernoulli_kernel, dim3((unsigned)lv_cdiv((n + 3) / 4, 256)), dim3(256), 0, stream, p, out, n, state, substream);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

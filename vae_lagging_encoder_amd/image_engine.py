@@ -1,0 +1,349 @@
+"""Host-side sequencing of the gfx950 kernels for the Omniglot VAE (ResNet encoder + PixelCNN decoder).
+
+Mirrors what autograd does for the reference's ResNetEncoderV2.forward (modules/encoders/enc_resnet_v2.py:120-126)
+and PixelCNNDecoderV2.reconstruct_error (modules/decoders/dec_pixelcnn_v2.py:172-195) with a small explicit tape:
+every op below launches hand-written HIP kernels through the C ABI (include/lvae.h) and records the closure that
+launches its backward kernels.  Activations are NHWC ([N*H*W][C]); convolutions are im2col + MFMA GEMM with tap
+skipping for the masked convolutions; BatchNorm (train) + residual + ELU are one fused pass.
+"""
+import torch
+
+from . import _lib
+from . import engine as _eng
+from .engine import P, FlatBuffer, _gemm, backend_for, stream_ptr
+
+
+class Act(object):
+    """An NHWC activation: t is a contiguous [N*H*W, C] fp32 tensor."""
+    __slots__ = ("t", "N", "H", "W", "C", "needs_grad")
+
+    def __init__(self, t, N, H, W, C, needs_grad=True):
+        self.t, self.N, self.H, self.W, self.C, self.needs_grad = t, N, H, W, C, needs_grad
+
+    @property
+    def P(self):
+        return self.N * self.H * self.W
+
+
+class Tape(object):
+    def __init__(self, device, precision="f32", train=True):
+        self.device = torch.device(device)
+        self.lib = backend_for(self.device)
+        self.precision = precision
+        self.train = train
+        self.back = []
+        self.grads = {}
+        self._bn_ws = {}
+
+    # -- helpers -------------------------------------------------------------------------------------------------
+    def s(self):
+        return stream_ptr(self.device)
+
+    def f32(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def bn_ws(self, C):
+        w = self._bn_ws.get(C)
+        if w is None:
+            w = self.f32(self.lib.lv_bn_workspace_floats(C) + 2 * C)
+            self._bn_ws[C] = w
+        return w
+
+    def add_grad(self, act, g):
+        """Accumulate g (a [P,C] tensor this tape owns) into the gradient of `act`."""
+        k = id(act)
+        cur = self.grads.get(k)
+        if cur is None:
+            self.grads[k] = g
+        else:
+            self.lib.lv_add_f32(P(cur), P(g), P(cur), cur.numel(), self.s())
+
+    def grad_of(self, act):
+        return self.grads.get(id(act))
+
+    def backward(self):
+        for fn in reversed(self.back):
+            fn()
+        self.back = []
+
+    # -- ops -----------------------------------------------------------------------------------------------------
+    def conv(self, x, weight, gview, stride=1, pad=0, ntaps=None, mask=None):
+        """nn.Conv2d(bias=False) / MaskedConv2d on NHWC x.  weight: [Cout][Cin][kh][kw] parameter view; gview: where
+        its gradient goes.  ntaps: raster-order tap prefix used by forward / data-gradient (None = all taps)."""
+        lib, s = self.lib, self.s()
+        Cout, Cin, kh, kw = weight.shape
+        assert Cin == x.C
+        KK = kh * kw
+        nt = KK if ntaps is None else ntaps
+        Ho = (x.H + 2 * pad - kh) // stride + 1
+        Wo = (x.W + 2 * pad - kw) // stride + 1
+        Pout = x.N * Ho * Wo
+        if mask is not None and self.train:
+            lib.lv_mul_inplace_f32(P(weight), P(mask), weight.numel(), s)     # weight.data.mul_(mask), G5
+        y = self.f32(Pout, Cout)
+        one_by_one = (KK == 1 and stride == 1 and pad == 0)
+        if one_by_one:
+            col, wg, ldk = x.t, weight, Cin
+        else:
+            ldk = KK * Cin
+            col = self.f32(Pout, ldk)
+            lib.lv_im2col_f32(P(x.t), P(col), ldk, x.N, x.H, x.W, Cin, Ho, Wo, kh, kw, pad, stride, KK, s)
+            wg = self.f32(Cout, ldk)
+            lib.lv_conv_pack_w_f32(P(weight), P(wg), Cout, Cin, KK, s)
+        K = nt * Cin
+        _gemm(lib, s, 0, 1, Pout, Cout, K, P(col), ldk, P(wg), ldk, P(y), Cout, prec=self.precision)
+        out = Act(y, x.N, Ho, Wo, Cout)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            # weight gradient over ALL taps (masked taps keep non-zero grads in the reference: they enter the clip norm)
+            if one_by_one:
+                _gemm(lib, s, 1, 0, Cout, Cin, Pout, P(dy), Cout, P(col), ldk, P(gview), Cin, prec=self.precision)
+            else:
+                dwg = self.f32(Cout, ldk)
+                _gemm(lib, s, 1, 0, Cout, ldk, Pout, P(dy), Cout, P(col), ldk, P(dwg), ldk, prec=self.precision)
+                lib.lv_conv_unpack_dw_f32(P(dwg), P(gview), Cout, Cin, KK, 0, s)
+            if x.needs_grad:
+                dx = self.f32(x.P, Cin)
+                if one_by_one:
+                    _gemm(lib, s, 0, 0, Pout, Cin, Cout, P(dy), Cout, P(wg), ldk, P(dx), Cin, prec=self.precision)
+                else:
+                    dcol = self.f32(Pout, K)
+                    _gemm(lib, s, 0, 0, Pout, K, Cout, P(dy), Cout, P(wg), ldk, P(dcol), K, prec=self.precision)
+                    lib.lv_col2im_f32(P(dcol), K, P(dx), x.N, x.H, x.W, Cin, Ho, Wo, kh, kw, pad, stride, nt, 0, s)
+                self.add_grad(x, dx)
+        self.back.append(bwd)
+        return out
+
+    def bn(self, x, bn, g_gamma, g_beta, res=None, act=True):
+        """nn.BatchNorm2d (+ residual add) (+ nn.ELU).  Train mode: batch statistics + running-stat update."""
+        lib, s = self.lib, self.s()
+        C, Pn = x.C, x.P
+        y = self.f32(Pn, C)
+        mean = self.f32(C)
+        invstd = self.f32(C)
+        if self.train:
+            lib.lv_bn_fwd_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
+                              P(mean), P(invstd), P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum,
+                              P(self.bn_ws(C)), Pn, C, s)
+            bn.num_batches_tracked += 1
+        else:
+            # eval mode (evaluation helpers only): normalise with the running statistics (tensor algebra)
+            mean.copy_(bn.running_mean)
+            invstd.copy_(torch.rsqrt(bn.running_var + bn.eps))
+            yy = (x.t - mean) * invstd * bn.weight + bn.bias
+            if res is not None:
+                yy = yy + res.t
+            y.copy_(torch.nn.functional.elu(yy) if act else yy)
+        out = Act(y, x.N, x.H, x.W, C)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            dv = self.f32(Pn, C)
+            dx = self.f32(Pn, C)
+            lib.lv_bn_bwd_f32(P(x.t), P(dy), P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx), P(g_gamma),
+                              P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
+            if res is not None and res.needs_grad:
+                self.add_grad(res, dv)
+            if x.needs_grad:
+                self.add_grad(x, dx)
+        self.back.append(bwd)
+        return out
+
+    def add(self, a, b):
+        lib, s = self.lib, self.s()
+        y = self.f32(a.P, a.C)
+        lib.lv_add_f32(P(a.t), P(b.t), P(y), y.numel(), s)
+        out = Act(y, a.N, a.H, a.W, a.C)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            if a.needs_grad:
+                self.add_grad(a, dy.clone())
+            if b.needs_grad:
+                self.add_grad(b, dy)
+        self.back.append(bwd)
+        return out
+
+    def linear(self, x2d, xact, weight, bias, g_w, g_b):
+        """y = x W^T + b on a [B, K] matrix.  xact: the Act providing x2d's gradient slot (or None for a leaf)."""
+        lib, s = self.lib, self.s()
+        B, K = x2d.shape
+        N = weight.shape[0]
+        y = self.f32(B, N)
+        _gemm(lib, s, 0, 1, B, N, K, P(x2d), K, P(weight), K, P(y), N, add1=P(bias), ld1=0, mod1=1)
+        out = Act(y, B, 1, 1, N)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            _gemm(lib, s, 1, 0, N, K, B, P(dy), N, P(x2d), K, P(g_w), K)
+            lib.lv_colsum_f32(P(dy), N, B, N, P(g_b), None, s)
+            if xact is not None and xact.needs_grad:
+                dx = self.f32(B, K)
+                _gemm(lib, s, 0, 0, B, K, N, P(dy), N, P(weight), K, P(dx), K)
+                self.add_grad(xact, dx)
+        self.back.append(bwd)
+        return out
+
+
+# ---- network walkers (structure of the reference modules; parameters read from the mirrored nn.Module tree) -----------
+def _gv(flat, param):
+    """Gradient view in the flat buffer for an nn.Parameter of this module."""
+    for n, p in zip(flat.names, flat.params):
+        if p is param:
+            return flat.gviews[n]
+    raise KeyError("parameter not in flat buffer")
+
+
+def resnet_block(tp, flat, blk, x):
+    if blk.downsample is not None:
+        r = tp.conv(x, blk.downsample[0].weight, _gv(flat, blk.downsample[0].weight), stride=blk.stride, pad=0)
+        residual = tp.bn(r, blk.downsample[1], _gv(flat, blk.downsample[1].weight), _gv(flat, blk.downsample[1].bias), act=False)
+    else:
+        residual = x
+    out = tp.conv(x, blk.conv1.weight, _gv(flat, blk.conv1.weight), stride=blk.stride, pad=1)
+    out = tp.bn(out, blk.bn1, _gv(flat, blk.bn1.weight), _gv(flat, blk.bn1.bias), act=True)
+    out = tp.conv(out, blk.conv2.weight, _gv(flat, blk.conv2.weight), stride=1, pad=1)
+    return tp.bn(out, blk.bn2, _gv(flat, blk.bn2.weight), _gv(flat, blk.bn2.bias), res=residual, act=True)
+
+
+def encoder_forward(tp, flat, enc, x_img):
+    """x_img [B,1,28,28] (any float layout with C=1) -> mulv Act [B, 2nz]."""
+    B = x_img.shape[0]
+    x = Act(x_img.reshape(B * 28 * 28, 1).contiguous().float(), B, 28, 28, 1, needs_grad=False)
+    resnet = enc.main[0]
+    for blk in resnet.main:
+        x = resnet_block(tp, flat, blk, x)
+    conv, bn = enc.main[1], enc.main[2]
+    x = tp.conv(x, conv.weight, _gv(flat, conv.weight), stride=1, pad=0)
+    x = tp.bn(x, bn, _gv(flat, bn.weight), _gv(flat, bn.bias), act=True)
+    return tp.linear(x.t, x, enc.linear.weight, enc.linear.bias, _gv(flat, enc.linear.weight), _gv(flat, enc.linear.bias))
+
+
+def pixelcnn_block(tp, flat, blk, x):
+    m = blk.main
+    k = m[3].kernel_size[0]
+    h = tp.conv(x, m[0].weight, _gv(flat, m[0].weight))
+    h = tp.bn(h, m[1], _gv(flat, m[1].weight), _gv(flat, m[1].bias), act=True)
+    # type-B mask: taps strictly before the centre in raster order plus the centre itself
+    h = tp.conv(h, m[3].weight, _gv(flat, m[3].weight), stride=1, pad=k // 2, ntaps=(k // 2) * k + k // 2 + 1, mask=m[3].mask)
+    h = tp.bn(h, m[4], _gv(flat, m[4].weight), _gv(flat, m[4].bias), act=True)
+    h = tp.conv(h, m[6].weight, _gv(flat, m[6].weight))
+    return tp.bn(h, m[7], _gv(flat, m[7].weight), _gv(flat, m[7].bias), res=x, act=True)
+
+
+def decoder_forward(tp, flat, dec, x_img, z2d, zact):
+    """x_img [B,1,28,28] binarised, z2d [B,nz] -> (logit Act [B*784,1], xflat [B*784])."""
+    lib, s = tp.lib, tp.s()
+    B = x_img.shape[0]
+    npix, fm = 28 * 28, dec.fm_latent
+    xflat = x_img.reshape(B * npix).contiguous().float()
+    lin = dec.z_transform[0]
+    zt = tp.linear(z2d, zact, lin.weight, lin.bias, _gv(flat, lin.weight), _gv(flat, lin.bias))      # [B, fm*784]
+    in5_t = tp.f32(B * npix, 1 + fm)
+    lib.lv_dec_input_fwd_f32(P(xflat), P(zt.t), P(in5_t), B, npix, fm, s)
+    in5 = Act(in5_t, B, 28, 28, 1 + fm)
+
+    def bwd_in():
+        d = tp.grad_of(in5)
+        if d is None:
+            return
+        dzt = tp.f32(B, fm * npix)
+        lib.lv_dec_input_bwd_f32(P(d), P(dzt), B, npix, fm, s)
+        tp.add_grad(zt, dzt)
+    tp.back.append(bwd_in)
+
+    pcnn = dec.main[0]
+    mA = pcnn.main[0].main
+    kA = mA[0].kernel_size[0]
+    # MaskABlock: only the image channel is masked (the latent maps see all taps): dense taps, pre-masked weights
+    h = tp.conv(in5, mA[0].weight, _gv(flat, mA[0].weight), stride=1, pad=kA // 2, mask=mA[0].mask)
+    inp = tp.bn(h, mA[1], _gv(flat, mA[1].weight), _gv(flat, mA[1].bias), act=True)
+    direct_inputs = [inp]
+    for i in range(1, len(pcnn.main)):
+        if i > 2:
+            di = direct_inputs.pop(0)
+            inp = tp.add(inp, pixelcnn_block(tp, flat, pcnn.direct_connects[i - 3], di))
+        inp = pixelcnn_block(tp, flat, pcnn.main[i], inp)
+        direct_inputs.append(inp)
+    assert len(direct_inputs) == 3
+    out = tp.add(inp, pixelcnn_block(tp, flat, pcnn.direct_connects[-1], direct_inputs.pop(0)))
+    c1, bn1, c2 = dec.main[1], dec.main[2], dec.main[4]
+    h = tp.conv(out, c1.weight, _gv(flat, c1.weight))
+    h = tp.bn(h, bn1, _gv(flat, bn1.weight), _gv(flat, bn1.bias), act=True)
+    logit = tp.conv(h, c2.weight, _gv(flat, c2.weight))
+    return logit, xflat
+
+
+class ImageEncoderEngine(object):
+    def __init__(self, module):
+        self.m = module
+        self.flat = None
+        self.precision = "f32"
+        self.gen = 0
+
+    def ensure(self, device):
+        device = torch.device(device)
+        if self.flat is None or self.flat.device != device or not self.flat.bound():
+            self.flat = FlatBuffer(list(self.m.named_parameters()), device)
+        return self.flat
+
+    def forward(self, x_img):
+        f = self.ensure(x_img.device)
+        self.tape = Tape(x_img.device, self.precision, train=self.m.training)
+        self.out = encoder_forward(self.tape, f, self.m, x_img)
+        self.gen += 1
+        return self.out.t
+
+    def backward(self, dmulv, gen=None):
+        if gen is not None and gen != self.gen:
+            raise _lib.LvaeError("encoder activations were overwritten by a later forward()")
+        self.tape.add_grad(self.out, dmulv.contiguous().clone())
+        self.tape.backward()
+
+
+class ImageDecoderEngine(object):
+    def __init__(self, module):
+        self.m = module
+        self.flat = None
+        self.precision = "f32"
+        self.gen = 0
+
+    def ensure(self, device):
+        device = torch.device(device)
+        if self.flat is None or self.flat.device != device or not self.flat.bound():
+            self.flat = FlatBuffer(list(self.m.named_parameters()), device)
+        return self.flat
+
+    def forward(self, x_img, z2d):
+        """-> rec [B] (BCE summed over pixels)."""
+        f = self.ensure(x_img.device)
+        tp = Tape(x_img.device, self.precision, train=self.m.training)
+        self.tape = tp
+        B = x_img.shape[0]
+        self.zact = Act(z2d.contiguous(), B, 1, 1, z2d.shape[1])
+        self.logit, self.xflat = decoder_forward(tp, f, self.m, x_img, self.zact.t, self.zact)
+        self.rec = tp.f32(B)
+        tp.lib.lv_sigmoid_bce_fwd_f32(P(self.logit.t), P(self.xflat), P(self.rec), B, 28 * 28, 1e-12, tp.s())
+        self.gen += 1
+        return self.rec
+
+    def backward(self, drec, gen=None):
+        """drec [B] -> parameter grads in self.flat.grad; returns dz [B, nz]."""
+        if gen is not None and gen != self.gen:
+            raise _lib.LvaeError("decoder activations were overwritten by a later forward()")
+        tp = self.tape
+        B = self.rec.shape[0]
+        dlogit = tp.f32(B * 28 * 28, 1)
+        tp.lib.lv_sigmoid_bce_bwd_f32(P(self.logit.t), P(self.xflat), P(drec.contiguous()), P(dlogit), B, 28 * 28, 1e-12, tp.s())
+        tp.add_grad(self.logit, dlogit)
+        tp.backward()
+        return tp.grad_of(self.zact)

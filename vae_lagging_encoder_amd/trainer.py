@@ -228,3 +228,93 @@ class AggressiveTextTrainer(object):
                 self.reset_stats()
             sub_iter += 1
         return steps
+
+
+class AggressiveImageTrainer(object):
+    """Fused driver for the Omniglot aggressive loop (reference image.py:295-348): one `step()` = zero_grad, VAE.loss,
+    loss.mean().backward(), clip_grad_norm_(all params, 5.0), Adam step on the encoder (image.py:302-314), as a
+    stream-ordered sequence of C-ABI kernel calls with device-resident scalars (kl weight, lr, Adam step, norm)."""
+
+    def __init__(self, vae, lr=1e-3, clip=5.0, seed=783435, device=None, precision="f32", betas=(0.9, 0.999), eps=1e-8):
+        self.vae = vae
+        self.enc = vae.encoder._hip
+        self.dec = vae.decoder._hip
+        self.device = torch.device(device) if device is not None else next(vae.parameters()).device
+        self.enc.ensure(self.device)
+        self.dec.ensure(self.device)
+        assert precision in ("f32", "bf16")
+        self.enc.precision = self.dec.precision = precision
+        self.enc.flat.attach_grads()
+        self.dec.flat.attach_grads()
+        self.lib = _eng.backend_for(self.device)
+        self.clip, self.betas, self.adam_eps = float(clip), betas, float(eps)
+        d = self.device
+        # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum, adam_step_enc, adam_step_dec, zero]
+        self.scal = torch.zeros(12, dtype=torch.float32, device=d)
+        self.scal[1] = lr
+        self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=d)
+        self.m = {"enc": torch.zeros_like(self.enc.flat.data), "dec": torch.zeros_like(self.dec.flat.data)}
+        self.v = {"enc": torch.zeros_like(self.enc.flat.data), "dec": torch.zeros_like(self.dec.flat.data)}
+
+    def _s(self, i):
+        return P(self.scal, i)
+
+    def read_stats(self):
+        v = self.scal.cpu().tolist()
+        return dict(loss_sum=v[5], rec_sum=v[6], kl_sum=v[7], norm=v[4], coef=v[3])
+
+    def reset_stats(self):
+        self.scal[5:8] = 0
+
+    def binarize(self, probs):
+        """torch.bernoulli(batch) (image.py:287,318) on device."""
+        probs = probs.contiguous().float()
+        out = torch.empty_like(probs)
+        s = _eng.stream_ptr(self.device)
+        self.lib.lv_rng_bernoulli_f32(P(probs), P(out), probs.numel(), P(self.rng_state), 7, s)
+        self.lib.lv_rng_advance(P(self.rng_state), 1, s)
+        return out
+
+    def step(self, x, kl_weight, eps=None, update="encoder"):
+        """x (B,1,28,28) binarised; eps (B,1,nz) injects the reparameterisation noise (parity mode)."""
+        lib, s, d = self.lib, _eng.stream_ptr(self.device), self.device
+        B = x.shape[0]
+        nz = self.vae.nz
+        self.scal[0] = float(kl_weight)
+        if eps is None:
+            eps = torch.empty(B, 1, nz, dtype=torch.float32, device=d)
+            lib.lv_rng_normal_f32(P(eps), eps.numel(), P(self.rng_state), 0, s)
+            lib.lv_rng_advance(P(self.rng_state), 1, s)
+        eps = eps.to(d).float().contiguous()
+        mulv = self.enc.forward(x)
+        z = torch.empty(B, 1, nz, dtype=torch.float32, device=d)
+        kl = torch.empty(B, dtype=torch.float32, device=d)
+        lib.lv_reparam_kl_fwd_f32(P(mulv), P(eps), P(z), P(kl), B, 1, nz, s)
+        rec = self.dec.forward(x, z.view(B, nz))
+        loss = torch.empty(B, dtype=torch.float32, device=d)
+        rec2 = torch.empty(B, dtype=torch.float32, device=d)
+        lib.lv_vae_loss_f32(P(rec), P(kl), self._s(0), P(loss), P(rec2), 1, B, s)
+        lib.lv_sum_accum_f32(P(loss), B, self._s(5), s)
+        lib.lv_sum_accum_f32(P(rec), B, self._s(6), s)
+        lib.lv_sum_accum_f32(P(kl), B, self._s(7), s)
+        gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=d)
+        drec = torch.empty(B, dtype=torch.float32, device=d)
+        dkl = torch.empty(B, dtype=torch.float32, device=d)
+        lib.lv_loss_bwd_scales_f32(P(gl), None, None, self._s(0), P(drec), P(dkl), B, s)
+        dz = self.dec.backward(drec)
+        dmulv = torch.empty(B, 2 * nz, dtype=torch.float32, device=d)
+        lib.lv_reparam_kl_bwd_f32(P(mulv), P(eps), P(dz), P(dkl), P(dmulv), B, 1, nz, s)
+        self.enc.backward(dmulv)
+        ef, df = self.enc.flat, self.dec.flat
+        lib.lv_sumsq_f32(P(ef.grad), ef.numel, P(self.norm_ws), self._s(2), 0, s)
+        lib.lv_sumsq_f32(P(df.grad), df.numel, P(self.norm_ws), self._s(2), 1, s)
+        lib.lv_clip_coef_f32(self._s(2), self.clip, self._s(3), self._s(4), s)
+        for name, flat, slot in (("enc", ef, 8), ("dec", df, 9)):
+            stepped = (update in ("encoder", "both")) if name == "enc" else (update in ("decoder", "both"))
+            if stepped:
+                lib.lv_add_scalar_f32(self._s(slot), 1.0, s)
+                lib.lv_adam_step_f32(P(flat.data), P(flat.grad), P(self.m[name]), P(self.v[name]), flat.numel, self._s(1),
+                                     self._s(3), self._s(slot), self.betas[0], self.betas[1], self.adam_eps, 1, s)
+            else:
+                lib.lv_scale_f32(P(flat.grad), flat.numel, self._s(3), s)
