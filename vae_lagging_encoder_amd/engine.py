@@ -150,10 +150,11 @@ def _gemm_ws(lib, s):
 
 
 def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add1=None, ld1=0, mod1=1,
-          add2=None, ld2=0, mod2=1, prec="f32"):
+          add2=None, ld2=0, mod2=1, prec="f32", ws=None):
     """prec: 'f32' = exact-f32 MFMA (parity path); 'bf16' = bf16 matrix pipe with f32 accumulate (throughput path,
     only requested for the large contractions)."""
-    ws = _gemm_ws(lib, s)
+    if ws is None:
+        ws = _gemm_ws(lib, s)
     fn = lib.lv_gemm_bf16 if prec == "bf16" else lib.lv_gemm_f32
     with _prof("gemm_" + prec, 2.0 * M * N * K):
         fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
@@ -269,6 +270,39 @@ class LSTMDecoderEngine(object):
         self.wsc = None
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
+        # The BPTT chains are latency-bound (one small launch per timestep) and leave most CUs idle: the decoder's
+        # weight-gradient GEMMs run on a side HIP stream underneath them (dW_pred under the decoder BPTT; dX / dW_ih /
+        # dW_hh / embedding scatter under the encoder's backward).  join() orders them before anything reads the grads.
+        self.overlap = True
+        self._side = None
+        self._side_ws = None
+        self._pending = None
+
+    def _fork(self, device):
+        """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
+        on the current stream (inline when overlap is off or on the test backend)."""
+        import contextlib
+        if not (self.overlap and torch.device(device).type == "cuda"):
+            return contextlib.nullcontext(), None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device)
+            self._side_ws = torch.empty(1 << 22, dtype=torch.float32, device=device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._side.wait_event(ev)
+        return torch.cuda.stream(self._side), self._side_ws
+
+    def _mark_pending(self, device):
+        if self._side is not None and self.overlap and torch.device(device).type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._pending = ev
+
+    def join(self):
+        """Order the current stream after the side-stream gradient work of the last backward()."""
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
 
     def ensure(self, device):
         device = torch.device(device)
@@ -381,25 +415,34 @@ class LSTMDecoderEngine(object):
         drec = drec.contiguous()
         wih = v["lstm.weight_ih_l0"]
         gwih = gv["lstm.weight_ih_l0"]
+        dev = x.device
         lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
+        ctx, sws = self._fork(dev)                    # side: dW_pred = dlogits^T . O (only needs dlogits and O)
+        with ctx:
+            _gemm(lib, stream_ptr(dev), 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
+                  prec=self.precision, ws=sws)
         _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
-        _gemm(lib, s, 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H, prec=self.precision)
         with _prof("lstm_bwd", 0.0, 2 * Td):
             lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
                                 P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
-        _gemm(lib, s, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision)
-        _gemm(lib, s, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, prec=self.precision)
-        _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
-        _gemm(lib, s, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, prec=self.precision)
-        lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
-        # dz = dGsum . W_ih[:, ni:] + dc0 . W_trans ; dW_trans = dc0^T . z
+        ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
+        with ctx:
+            s2 = stream_ptr(dev)
+            _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
+            _gemm(lib, s2, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, prec=self.precision, ws=sws)
+            _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
+            _gemm(lib, s2, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
+                  prec=self.precision, ws=sws)
+            lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
+            gv["embed.weight"].zero_()
+            lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s2)
+            lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
+                                     V - 1, 0, s2)
+        self._mark_pending(dev)
+        # dz = dGsum . W_ih[:, ni:] + dc0 . W_trans ; dW_trans = dc0^T . z   (critical path: feeds the encoder's backward)
         _gemm(lib, s, 0, 0, B, nz, 4 * H, P(w.dGsum), 4 * H, P(wih, ni), ni + nz, P(w.dz), nz)
         _gemm(lib, s, 0, 0, B, nz, H, P(w.dc0), H, P(v["trans_linear.weight"]), nz, P(w.dz), nz, acc=1)
         _gemm(lib, s, 1, 0, H, nz, B, P(w.dc0), H, P(z2), nz, P(gv["trans_linear.weight"]), nz)
-        gv["embed.weight"].zero_()
-        lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
-        lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
-                                 V - 1, 0, s)
         return w.dz
 
 

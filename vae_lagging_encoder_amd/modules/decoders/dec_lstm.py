@@ -27,6 +27,7 @@ class _DecoderFn(torch.autograd.Function):
     def backward(ctx, drec):
         eng = ctx.eng
         dz = eng.backward(drec, ctx.gen).clone().view(ctx.zshape)
+        eng.join()
         grads = tuple(eng.flat.gviews[n].clone() for n in eng.flat.names)
         return (None, None, dz, None, None, None, None) + grads
 

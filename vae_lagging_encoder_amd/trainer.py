@@ -120,6 +120,7 @@ class AggressiveTextTrainer(object):
         dz = self.dec.backward(st.rowscale)
         lib.lv_reparam_kl_bwd_f32(P(mulv), P(st.eps), P(dz), P(st.dkl), P(st.dmulv), B, 1, nz, s)
         self.enc.backward(st.dmulv)
+        self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
 
     def _clip_and_step(self, update):
         lib, s = self.lib, _eng.stream_ptr(self.device)
