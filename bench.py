@@ -64,7 +64,7 @@ def bench_omniglot(args, dev, rank, world):
     from oracle import image_vae_oracle as IO
     B = WORKLOADS["omniglot"]["B"]
     vae = pc.build_image_vae(dev, 783435)
-    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, seed=783435 + rank, precision=args.dtype)
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, seed=783435 + rank, precision=args.dtype, use_graph=bool(args.graph))
     g = torch.Generator().manual_seed(1 + rank)
     probs = torch.rand(args.pool, B, 1, 28, 28, generator=g).to(dev)
     rs = np.random.RandomState(783435)
@@ -75,7 +75,8 @@ def bench_omniglot(args, dev, rank, world):
         one_step()
     torch.cuda.synchronize(dev)
     prof = {}
-    engine.PROFILE = prof
+    if not args.graph:
+        engine.PROFILE = prof
     tr.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -89,7 +90,8 @@ def bench_omniglot(args, dev, rank, world):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "omniglot ResNetEncoderV2 + PixelCNNDecoderV2 aggressive inner step (fwd+bwd+clip+encoder Adam), "
-                                  "B=%d/GPU, 28x28 binary, nz=32, fm=4" % B, "global_batch": world * B, "parallelism": "replicas%d" % world},
+                                  "B=%d/GPU, 28x28 binary, nz=32, fm=4" % B, "global_batch": world * B, "parallelism": "replicas%d" % world,
+                      "hipgraph": bool(args.graph)},
            "mean_loss_per_image": round(stats["loss_sum"] / (B * args.steps), 4)}
     gname = "gemm_" + args.dtype
     recs = prof.get(gname, []) + (prof.get("gemm_f32", []) if args.dtype != "f32" else [])
@@ -146,7 +148,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     cfg = WORKLOADS[args.workload]
     if args.workload == "omniglot":

@@ -145,11 +145,11 @@ def check_image_step_dropin(name, device):
     return fx
 
 
-def check_image_step_fused(name, device):
+def check_image_step_fused(name, device, use_graph=False):
     from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
     fx = load(name)
     vae = build_image_vae(device, int(fx["model_seed"]))
-    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0)
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, use_graph=use_graph)
     x = torch.from_numpy(fx["x"]).float().to(device)
     tr.step(x, float(fx["kl_weight"]), eps=torch.from_numpy(fx["eps"]).to(device))
     st = tr.read_stats()

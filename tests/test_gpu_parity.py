@@ -196,6 +196,25 @@ def test_image_step_fused_matches_reference_fixture(hip_device, name):
     pc.check_image_step_fused(name, hip_device)
 
 
+def test_image_hipgraph_replay_equals_eager(hip_device):
+    """Two steps through captured-graph replay (first call = eager warm-up + capture, second = replay) land on the
+    same weights / statistics as two eager steps."""
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    fx = load("image_b6")
+    x = torch.from_numpy(fx["x"]).float().to(hip_device)
+    eps = torch.from_numpy(fx["eps"]).to(hip_device)
+    res = []
+    for use_graph in (False, True):
+        vae = pc.build_image_vae(hip_device, int(fx["model_seed"]))
+        tr = AggressiveImageTrainer(vae, use_graph=use_graph)
+        for _ in range(3):
+            tr.step(x, 0.5, eps=eps)
+        res.append(({k: v.clone() for k, v in vae.state_dict().items()}, tr.read_stats()))
+    for k in res[0][0]:
+        assert rel_err(res[1][0][k].float(), res[0][0][k].float(), floor=1e-12) < 1e-5, k
+    assert abs(res[0][1]["loss_sum"] - res[1][1]["loss_sum"]) / abs(res[0][1]["loss_sum"]) < 1e-6
+
+
 def test_image_step_is_deterministic_and_masks_stay_applied(hip_device):
     from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
     fx = load("image_b50")

@@ -273,7 +273,8 @@ class LSTMDecoderEngine(object):
         # The BPTT chains are latency-bound (one small launch per timestep) and leave most CUs idle: the decoder's
         # weight-gradient GEMMs run on a side HIP stream underneath them (dW_pred under the decoder BPTT; dX / dW_ih /
         # dW_hh / embedding scatter under the encoder's backward).  join() orders them before anything reads the grads.
-        self.overlap = True
+        self.overlap = None       # None = auto: on for the f32 path, off for bf16 (measured: with the short bf16 GEMMs the
+        #                           interference on the latency-critical step kernels costs more than the overlap saves)
         self._side = None
         self._side_ws = None
         self._pending = None
@@ -282,7 +283,7 @@ class LSTMDecoderEngine(object):
         """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
         on the current stream (inline when overlap is off or on the test backend)."""
         import contextlib
-        if not (self.overlap and torch.device(device).type == "cuda"):
+        if not (self._overlap_on() and torch.device(device).type == "cuda"):
             return contextlib.nullcontext(), None
         if self._side is None:
             self._side = torch.cuda.Stream(device)
@@ -292,8 +293,11 @@ class LSTMDecoderEngine(object):
         self._side.wait_event(ev)
         return torch.cuda.stream(self._side), self._side_ws
 
+    def _overlap_on(self):
+        return (self.precision == "f32") if self.overlap is None else bool(self.overlap)
+
     def _mark_pending(self, device):
-        if self._side is not None and self.overlap and torch.device(device).type == "cuda":
+        if self._side is not None and self._overlap_on() and torch.device(device).type == "cuda":
             ev = torch.cuda.Event()
             ev.record(self._side)
             self._pending = ev

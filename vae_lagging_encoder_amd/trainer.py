@@ -236,7 +236,8 @@ class AggressiveImageTrainer(object):
     loss.mean().backward(), clip_grad_norm_(all params, 5.0), Adam step on the encoder (image.py:302-314), as a
     stream-ordered sequence of C-ABI kernel calls with device-resident scalars (kl weight, lr, Adam step, norm)."""
 
-    def __init__(self, vae, lr=1e-3, clip=5.0, seed=783435, device=None, precision="f32", betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, vae, lr=1e-3, clip=5.0, seed=783435, device=None, precision="f32", betas=(0.9, 0.999), eps=1e-8,
+                 use_graph=False):
         self.vae = vae
         self.enc = vae.encoder._hip
         self.dec = vae.decoder._hip
@@ -249,6 +250,9 @@ class AggressiveImageTrainer(object):
         self.dec.flat.attach_grads()
         self.lib = _eng.backend_for(self.device)
         self.clip, self.betas, self.adam_eps = float(clip), betas, float(eps)
+        # ~1500 small launches per step: replaying the captured step as a hipGraph removes the host launch overhead
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._static = {}
         d = self.device
         # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum, adam_step_enc, adam_step_dec, zero]
         self.scal = torch.zeros(12, dtype=torch.float32, device=d)
@@ -279,15 +283,54 @@ class AggressiveImageTrainer(object):
 
     def step(self, x, kl_weight, eps=None, update="encoder"):
         """x (B,1,28,28) binarised; eps (B,1,nz) injects the reparameterisation noise (parity mode)."""
-        lib, s, d = self.lib, _eng.stream_ptr(self.device), self.device
+        d = self.device
         B = x.shape[0]
         nz = self.vae.nz
         self.scal[0] = float(kl_weight)
+        if not self.use_graph:
+            if eps is not None:
+                eps = eps.to(d).float().contiguous()
+            self._body(x, eps, update)
+            return
+        key = (B, update, eps is None, self.vae.training)
+        st = self._static.get(key)
+        if st is None:
+            st = dict(x=torch.zeros(B, 1, 28, 28, dtype=torch.float32, device=d),
+                      eps=torch.zeros(B, 1, nz, dtype=torch.float32, device=d), graph=None)
+            self._static[key] = st
+        st["x"].copy_(x.reshape(B, 1, 28, 28))
+        if eps is not None:
+            st["eps"].copy_(eps.reshape(B, 1, nz))
+        if st["graph"] is None:
+            self._body(st["x"], None if eps is None else st["eps"], update)      # eager warm-up performs this call's step
+            torch.cuda.synchronize(d)
+            g = torch.cuda.CUDAGraph()
+            stream = torch.cuda.Stream(d)
+            stream.wait_stream(torch.cuda.current_stream(d))
+            # capture must not advance state twice: snapshot the mutable state the body touches, capture, restore
+            snap = (self.enc.flat.data.clone(), self.dec.flat.data.clone(), self.scal.clone(), self.rng_state.clone(),
+                    {k: v.clone() for k, v in self.m.items()}, {k: v.clone() for k, v in self.v.items()},
+                    {k: b.clone() for k, b in self.vae.named_buffers()})
+            with torch.cuda.graph(g, stream=stream):
+                self._body(st["x"], None if eps is None else st["eps"], update)
+            self.enc.flat.data.copy_(snap[0]); self.dec.flat.data.copy_(snap[1]); self.scal.copy_(snap[2])
+            self.rng_state.copy_(snap[3])
+            for k in self.m:
+                self.m[k].copy_(snap[4][k]); self.v[k].copy_(snap[5][k])
+            for k, b in self.vae.named_buffers():
+                b.copy_(snap[6][k])
+            st["graph"] = g
+            return
+        st["graph"].replay()
+
+    def _body(self, x, eps, update):
+        lib, s, d = self.lib, _eng.stream_ptr(self.device), self.device
+        B = x.shape[0]
+        nz = self.vae.nz
         if eps is None:
             eps = torch.empty(B, 1, nz, dtype=torch.float32, device=d)
             lib.lv_rng_normal_f32(P(eps), eps.numel(), P(self.rng_state), 0, s)
             lib.lv_rng_advance(P(self.rng_state), 1, s)
-        eps = eps.to(d).float().contiguous()
         mulv = self.enc.forward(x)
         z = torch.empty(B, 1, nz, dtype=torch.float32, device=d)
         kl = torch.empty(B, dtype=torch.float32, device=d)
