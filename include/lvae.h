@@ -43,6 +43,7 @@ int lv_gemm_bf16(int transA, int transB, int M, int N, int K, float alpha,
 
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream);
 
 /* ---- LSTM time recurrence: nn.LSTM forward (enc_lstm.py:60, dec_lstm.py:104) and its autograd backward --------
  * gx [T][B][4H] input projection (+biases, + z term); whh [4H][H] (rows i|f|g|o); hs, cs [T+1][B][H] with index 0

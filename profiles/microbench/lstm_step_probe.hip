@@ -61,24 +61,26 @@ float time_us(F&& f, int iters, hipStream_t s) {
 int main() {
     const int H = 1024, B = 32, T = 64;
     hipStream_t s; CK(hipStreamCreate(&s));
-    float *gx, *whh, *whhT, *hs, *cs, *gates, *out, *dG, *dGsum, *part, *dcrec, *dhext;
-    CK(hipMalloc(&gx, (size_t)T * B * 4 * H * 4)); CK(hipMalloc(&whh, (size_t)4 * H * H * 4)); CK(hipMalloc(&whhT, (size_t)4 * H * H * 4));
+    float *gx, *whh, *hs, *cs, *gates, *out, *dG, *dGsum, *dhext, *ws;
+    CK(hipMalloc(&gx, (size_t)T * B * 4 * H * 4)); CK(hipMalloc(&whh, (size_t)4 * H * H * 4));
     CK(hipMalloc(&hs, (size_t)(T + 1) * B * H * 4)); CK(hipMalloc(&cs, (size_t)(T + 1) * B * H * 4));
     CK(hipMalloc(&gates, (size_t)T * B * 4 * H * 4)); CK(hipMalloc(&out, 1 << 20));
-    CK(hipMalloc(&dG, (size_t)T * B * 4 * H * 4)); CK(hipMalloc(&dGsum, (size_t)B * 4 * H * 4)); CK(hipMalloc(&part, (size_t)8 * B * H * 4));
-    CK(hipMalloc(&dcrec, (size_t)B * H * 4)); CK(hipMalloc(&dhext, (size_t)T * B * H * 4));
-    CK(hipMemset(gx, 0, (size_t)T * B * 4 * H * 4)); CK(hipMemset(whh, 0, (size_t)4 * H * H * 4)); CK(hipMemset(whhT, 0, (size_t)4 * H * H * 4));
+    CK(hipMalloc(&dG, (size_t)T * B * 4 * H * 4)); CK(hipMalloc(&dGsum, (size_t)B * 4 * H * 4));
+    CK(hipMalloc(&dhext, (size_t)T * B * H * 4)); CK(hipMalloc(&ws, (size_t)lv_lstm_ws_floats(B, H) * 4));
+    CK(hipMemset(gx, 0, (size_t)T * B * 4 * H * 4)); CK(hipMemset(whh, 0, (size_t)4 * H * H * 4));
     CK(hipMemset(hs, 0, (size_t)(T + 1) * B * H * 4)); CK(hipMemset(cs, 0, (size_t)(T + 1) * B * H * 4)); CK(hipMemset(dhext, 0, (size_t)T * B * H * 4));
     CK(hipMemset(gates, 0, (size_t)T * B * 4 * H * 4));
 
     printf("empty kernel 256x256, back-to-back          : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, out); }, 2000, s));
     printf("mfma only (128 x 16x16x4 per wave)           : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(mfma_only_kernel, dim3(256), dim3(256), 0, s, out, 1.0f); }, 2000, s));
-    printf("loads only (192 KB per WG, distinct W rows)  : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(loads_only_kernel<0>, dim3(256), dim3(256), 0, s, hs, whh, out, H, B); }, 2000, s));
-    printf("loads only (all WGs read the SAME 16 W rows) : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(loads_only_kernel<1>, dim3(256), dim3(256), 0, s, hs, whh, out, H, B); }, 2000, s));
-    printf("lv_lstm_fwd_f32, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_fwd_f32(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, T, B, H, s); }, 20, s) / T);
-    printf("lv_lstm_bwd_f32, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_bwd_f32(dhext, nullptr, nullptr, 1.f, whhT, gates, hs, cs, dG, dGsum, part, dcrec, nullptr, nullptr, 0, T, B, H, s); }, 20, s) / T);
-    // single-kernel durations via events around one launch each (includes launch latency)
-    LstmFwdP p{gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, T, B, H};
-    printf("fwd step kernel alone, back-to-back same t    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, true>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("loads only, 16 rows x 64 B per wave load     : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(loads_only_kernel<0>, dim3(256), dim3(256), 0, s, hs, whh, out, H, B); }, 2000, s));
+    printf("lv_lstm_fwd_f32 (packed operands), T=%d       : %7.2f us/step\n", T, time_us([&] { lv_lstm_fwd_f32(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, T, B, H, s); }, 20, s) / T);
+    printf("lv_lstm_bwd_f32 (packed operands), T=%d       : %7.2f us/step\n", T, time_us([&] { lv_lstm_bwd_f32(dhext, nullptr, nullptr, 1.f, whh, gates, hs, cs, dG, dGsum, ws, nullptr, nullptr, 0, T, B, H, s); }, 20, s) / T);
+    const Geo g = geo(B, H);
+    LstmFwdP p{gx, ws, hs, cs, gates, ws + g.wp, nullptr, 1.f, nullptr, T, B, H, g.Kq, g.MBTp};
+    printf("fwd step kernel alone, back-to-back same t    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    LstmBwdP q{dhext, nullptr, nullptr, 1.f, ws, gates, cs, dG, dGsum, ws + g.wpT, ws + g.wpT + g.dGp, ws + g.wpT + g.dGp + g.part, T, B, H, g.KS, g.Kq4, g.MBTp};
+    printf("bwd matmul kernel alone, back-to-back         : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_mm_kernel<2>), dim3(64 * g.KS, 1), dim3(256), 0, s, q, 3); }, 2000, s));
+    printf("bwd elementwise kernel alone, back-to-back    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_elem_kernel<4>), dim3(128), dim3(256), 0, s, q, 3); }, 2000, s));
     return 0;
 }

@@ -331,19 +331,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_finish_kernel(const float* dh_pa
     if (dc0) dc0[idx] = dc;
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long in_ld, float* __restrict__ out,
+                                                        long out_ld, int rows, int cols) {
     __shared__ float tile[32][33];
     const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;   // 32 x 8
     const int c0 = (int)blockIdx.x * 32, r0 = (int)blockIdx.y * 32;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+        tile[i][tx] = (r < rows && c < cols) ? in[(long)r * in_ld + c] : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (r < rows && c < cols) out[(long)c * rows + r] = tile[tx][i];
+        if (r < rows && c < cols) out[(long)c * out_ld + r] = tile[tx][i];
     }
 }
 
@@ -409,7 +409,17 @@ extern "C" int lv_transpose_f32(const float* in, float* out, int rows, int cols,
     if (!in || !out || rows < 0 || cols < 0) return LV_ERR_ARG;
     if (rows == 0 || cols == 0) return LV_OK;
     dim3 grid((unsigned)lv_cdiv(cols, 32), (unsigned)lv_cdiv(rows, 32)), block(256);
-    LV_LAUNCH(transpose_kernel, grid, block, 0, stream, in, out, rows, cols);
+    LV_LAUNCH(transpose_kernel, grid, block, 0, stream, in, (long)cols, out, (long)rows, rows, cols);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// out[c][r] (pitch out_ld) = in[r][c] (pitch in_ld): strided-view transpose (weight-gradient operands of the bf16 path)
+extern "C" int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream) {
+    if (!in || !out || rows < 0 || cols < 0 || in_ld < cols || out_ld < rows) return LV_ERR_ARG;
+    if (rows == 0 || cols == 0) return LV_OK;
+    dim3 grid((unsigned)lv_cdiv(cols, 32), (unsigned)lv_cdiv(rows, 32)), block(256);
+    LV_LAUNCH(transpose_kernel, grid, block, 0, stream, in, in_ld, out, out_ld, rows, cols);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -160,6 +160,37 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
         fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
 
 
+def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, scratch, ws=None):
+    """Weight gradient C[M,N] = A^T . B with A stored [K][M] (lda) and B stored [K][N] (ldb).
+
+    f32: the GEMM's TN form reads both operands as stored.  bf16: measured on MI355X the [K][rows]-stored staging path
+    of the bf16 kernel (scalar loads + transposing LDS writes) runs at the f32 kernel's speed, so both operands are
+    transposed once (streaming f32 pass) and the product runs on the fast NT form."""
+    if prec != "bf16":
+        _gemm(lib, s, 1, 0, M, N, K, A, lda, Bm, ldb, C, ldc, prec=prec, ws=ws)
+        return
+    Kp = _round_up(K, 4)
+    At, Bt = scratch(M * Kp, 0), scratch(N * Kp, 1)
+    lib.lv_transpose_ld_f32(A, lda, P(At), Kp, K, M, s)
+    lib.lv_transpose_ld_f32(Bm, ldb, P(Bt), Kp, K, N, s)
+    _gemm(lib, s, 0, 1, M, N, K, P(At), Kp, P(Bt), Kp, C, ldc, prec=prec, ws=ws)
+
+
+class _Scratch(object):
+    """Two growable device buffers for the transposed weight-gradient operands."""
+
+    def __init__(self):
+        self.buf = [None, None]
+
+    def __call__(self, n, slot, device=None):
+        b = self.buf[slot]
+        if b is None or b.numel() < n:
+            dev = device if device is not None else (b.device if b is not None else torch.device("cuda", torch.cuda.current_device()))
+            b = torch.empty(n, dtype=torch.float32, device=dev)
+            self.buf[slot] = b
+        return b
+
+
 class LSTMEncoderEngine(object):
     """Forward/backward of LSTMEncoder.forward (reference modules/encoders/enc_lstm.py:47-64)."""
 
@@ -169,6 +200,7 @@ class LSTMEncoderEngine(object):
         self.wsc = None
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
+        self._scratch = _Scratch()
 
     def ensure(self, device):
         device = torch.device(device)
@@ -253,8 +285,9 @@ class LSTMEncoderEngine(object):
                                 P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
         # input-side grads
         _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
-        _gemm(lib, s, 1, 0, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, prec=self.precision)
-        _gemm(lib, s, 1, 0, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, prec=self.precision)
+        sc = lambda n, slot: self._scratch(n, slot, x.device)
+        _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision, sc)
+        _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision, sc)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         gv["embed.weight"].zero_()
         lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
@@ -278,6 +311,7 @@ class LSTMDecoderEngine(object):
         self._side = None
         self._side_ws = None
         self._pending = None
+        self._scratch = _Scratch()
 
     def _fork(self, device):
         """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
@@ -423,8 +457,9 @@ class LSTMDecoderEngine(object):
         lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
         ctx, sws = self._fork(dev)                    # side: dW_pred = dlogits^T . O (only needs dlogits and O)
         with ctx:
-            _gemm(lib, stream_ptr(dev), 1, 0, V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
-                  prec=self.precision, ws=sws)
+            sc = lambda n, slot: self._scratch(n, slot, dev)
+            _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
+                   self.precision, sc, ws=sws)
         _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         with _prof("lstm_bwd", 0.0, 2 * Td):
             lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
@@ -433,10 +468,10 @@ class LSTMDecoderEngine(object):
         with ctx:
             s2 = stream_ptr(dev)
             _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
-            _gemm(lib, s2, 1, 0, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, prec=self.precision, ws=sws)
+            _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, sc, ws=sws)
             _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
-            _gemm(lib, s2, 1, 0, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
-                  prec=self.precision, ws=sws)
+            _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
+                   self.precision, sc, ws=sws)
             lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
             gv["embed.weight"].zero_()
             lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s2)
