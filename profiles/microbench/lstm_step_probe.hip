@@ -79,6 +79,11 @@ int main() {
     const Geo g = geo(B, H);
     LstmFwdP p{gx, ws, hs, cs, gates, ws + g.wp, nullptr, 1.f, nullptr, T, B, H, g.Kq, g.MBTp};
     printf("fwd step kernel alone, back-to-back same t    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("  fwd ablation: no matmul                      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 1>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("  fwd ablation: no gate math / gate stores     : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("  fwd ablation: no epilogue operand loads      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("  fwd ablation: matmul only (2+4)              : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 6>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    printf("  fwd ablation: nothing (1+2+4)                : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 7>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
     LstmBwdP q{dhext, nullptr, nullptr, 1.f, ws, gates, cs, dG, dGsum, ws + g.wpT, ws + g.wpT + g.dGp, ws + g.wpT + g.dGp + g.part, T, B, H, g.KS, g.Kq4, g.MBTp};
     printf("bwd matmul kernel alone, back-to-back         : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_mm_kernel<2>), dim3(64 * g.KS, 1), dim3(256), 0, s, q, 3); }, 2000, s));
     printf("bwd elementwise kernel alone, back-to-back    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_elem_kernel<4>), dim3(128), dim3(256), 0, s, q, 3); }, 2000, s));

@@ -24,7 +24,7 @@ def _s(dev):
     (0, 1, 130, 140, 37), (0, 0, 130, 140, 37), (1, 0, 70, 260, 50), (1, 1, 33, 17, 20),
     (0, 1, 512, 4096, 512), (0, 0, 640, 1024, 2001), (1, 0, 2001, 1024, 640), (0, 1, 32, 64, 1024),
     (0, 1, 1, 1, 1), (0, 1, 257, 129, 16), (1, 0, 4096, 32, 32), (0, 0, 32, 32, 4096), (1, 0, 512, 256, 6368),
-    (0, 1, 4000, 4100, 64), (0, 0, 100, 70, 3000),
+    (0, 1, 4000, 4100, 64), (0, 0, 100, 70, 3000), (0, 0, 1300, 1024, 4100), (1, 0, 1100, 1200, 2300),
 ])
 def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -39,7 +39,7 @@ def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
     Bop = (B[:, :K].t() if tB else B[:, :N]).double()
     ref = 0.5 * (Aop @ Bop) + add1[torch.arange(M) % 5].double() + add2.double() + C0[:, :N].double()
     Ad, Bd, Cd, a1, a2 = (t.to(hip_device) for t in (A, B, C0.clone(), add1, add2))
-    ws = torch.empty(1 << 20, device=hip_device)
+    ws = torch.empty(1 << 24, device=hip_device)
     lib.lv_gemm_f32(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, P(a2), N, 1, P(ws), ws.numel(), _s(hip_device))
     out = Cd.cpu()
     assert torch.equal(out[:, N:], C0[:, N:])          # padding columns untouched
@@ -50,6 +50,7 @@ def test_gemm_f32(lib, hip_device, tA, tB, M, N, K):
 @pytest.mark.parametrize("tA,tB,M,N,K", [
     (0, 1, 130, 140, 37), (0, 0, 130, 140, 70), (1, 0, 70, 260, 50), (1, 1, 33, 17, 20), (0, 1, 1, 1, 1),
     (0, 1, 3000, 2100, 512), (0, 0, 640, 1024, 2001), (1, 0, 2001, 1024, 640), (0, 0, 32, 32, 4096), (1, 0, 512, 256, 6368),
+    (0, 0, 1300, 1024, 4100), (1, 0, 1100, 1200, 2300),
 ])
 def test_gemm_bf16(lib, hip_device, tA, tB, M, N, K):
     """bf16 matrix pipe: exact against a float64 product of the bf16-ROUNDED operands (f32-accumulate class error),
@@ -67,7 +68,7 @@ def test_gemm_bf16(lib, hip_device, tA, tB, M, N, K):
     ref = 0.5 * (rb(Aop) @ rb(Bop)) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
     ref_exact = 0.5 * (Aop.double() @ Bop.double()) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
     Ad, Bd, Cd, a1 = (t.to(hip_device) for t in (A, B, C0.clone(), add1))
-    ws = torch.empty(1 << 20, device=hip_device)
+    ws = torch.empty(1 << 24, device=hip_device)
     lib.lv_gemm_bf16(tA, tB, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(Cd), N + 3, 1, P(a1), N, 5, None, 0, 1,
                      P(ws), ws.numel(), _s(hip_device))
     out = Cd.cpu()

@@ -229,11 +229,19 @@ extern "C" int lv_gemm_bf16(int transA, int transB, int M, int N, int K, float a
     p.ws = ws;
     const int nk = lv_cdiv(K, BK);
     const long t128 = (long)lv_cdiv(M, 128) * lv_cdiv(N, 128);
-    const bool big = t128 >= 512;
+    // same tile policy as lv_gemm_f32 (traffic-bound: prefer 128x128 tiles + split-K over smaller tiles)
+    int splits = 1;
+    bool big = t128 >= 512;
+    if (!big && ws && t128 >= 48 && nk >= 64) {
+        long s = lv_cdiv(1024, t128);
+        if (s > nk / 16) s = nk / 16;
+        const long cap = ws_floats / ((long)M * N);
+        if (s > cap) s = cap;
+        if (s >= 2) { big = true; splits = (int)s; }
+    }
     const int BT = big ? 128 : 64;
     p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     const long tiles = (long)p.tilesM * p.tilesN;
-    int splits = 1;
     if (!big && ws && tiles < 256 && nk >= 8) {
         long s = lv_cdiv(512, tiles);
         if (s > nk / 4) s = nk / 4;

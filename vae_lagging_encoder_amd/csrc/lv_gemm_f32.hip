@@ -232,11 +232,21 @@ extern "C" int lv_gemm_f32(int transA, int transB, int M, int N, int K, float al
     p.ws = ws;
     const int nk = lv_cdiv(K, BK);
     const long t128 = (long)lv_cdiv(M, 128) * lv_cdiv(N, 128);
-    const bool big = t128 >= 1024;           // >= 4 workgroups per CU with 128x128 tiles; else 64x64 tiles
+    // Tile choice.  Measured on MI355X these GEMMs are bound by L2-miss (Infinity Cache) traffic, which scales with
+    // 1/tile: prefer 128x128 tiles and, when they are too few to fill 256 CUs but K is long, split K across
+    // workgroups (deterministic slab reduce) instead of shrinking the tile; 64x64 tiles only for small outputs.
+    int splits = 1;
+    bool big = t128 >= 1024;
+    if (!big && ws && t128 >= 48 && nk >= 128) {
+        long s = lv_cdiv(1024, t128);
+        if (s > nk / 32) s = nk / 32;
+        const long cap = ws_floats / ((long)M * N);
+        if (s > cap) s = cap;
+        if (s >= 2) { big = true; splits = (int)s; }
+    }
     const int BT = big ? 128 : 64;
     p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     const long tiles = (long)p.tilesM * p.tilesN;
-    int splits = 1;
     if (!big && ws && tiles < 256 && nk >= 16) {
         long s = lv_cdiv(512, tiles);
         if (s > nk / 8) s = nk / 8;

@@ -55,6 +55,7 @@ __device__ __forceinline__ void rec_mm_core(const float* __restrict__ ap, long a
                 wv[u] = *reinterpret_cast<const float4*>(w_lane + q * 64);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) av[u][mb] = *reinterpret_cast<const float4*>(a_lane + q * a_qpitch + mb * 64);
+                LV_SCHED_BARRIER();   // keep the loads in consumption order: MFMA group u then waits only for loads <= u
             }
         } else {
 #pragma unroll
@@ -132,7 +133,9 @@ struct LstmFwdP {
     int T, B, H, Kq, MBTp;
 };
 
-template <int MB>
+// ABL: ablation switches for profiles/microbench/lstm_step_probe.hip only (product launches use ABL = 0):
+//      1 = skip the recurrent matmul, 2 = skip the gate math and all stores except h, 4 = skip the epilogue operand loads
+template <int MB, int ABL = 0>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     __shared__ float red[4][MB][16][17];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
         const int pi = tid + 256 * q;
         const int bb = pi >> 2, uu = pi & 3;
         const int b = rb + bb, u = u0 + uu;
-        const bool ok = (pi < 64 * MB) && b < B && u < H;
+        const bool ok = (pi < 64 * MB) && b < B && u < H && !(ABL & 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[q][g] = ok ? gx_t[(long)b * 4 * H + (long)g * H + u] : 0.f;
         cp[q] = ok ? c_prev[(long)b * H + u] : 0.f;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it0 < it1)
+    if (it0 < it1 && !(ABL & 1))
         rec_mm_core<MB, RecNit<MB>::value>(hp_in + (long)mbase * 64, (long)p.MBTp * 64, p.wp + (long)nb * p.Kq * 64,
                                            it0, it1, l, acc);
 #pragma unroll
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
                                 (red[2][bb >> 4][bb & 15][col] + red[3][bb >> 4][bb & 15][col]);
                 a[g] = pre[q][g] + s;
             }
+            if (ABL & 2) { h_out[(long)b * H + u] = a[0] + a[1] + a[2] + a[3]; continue; }
             const float ig = lv_sigmoid(a[0]), fg = lv_sigmoid(a[1]), gg = tanhf(a[2]), og = lv_sigmoid(a[3]);
             const float c = fg * cp[q] + ig * gg;
             const float h = og * tanhf(c);

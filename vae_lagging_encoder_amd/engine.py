@@ -140,11 +140,11 @@ _GEMM_WS = {}
 
 
 def _gemm_ws(lib, s):
-    """Per-device split-K scratch (16M floats) shared by every GEMM launch on that device's stream order."""
+    """Per-device split-K scratch (64M floats = 256 MB of the 288 GB) shared by every GEMM launch on that device's stream order."""
     dev = torch.device("cuda", torch.cuda.current_device()) if s is not None else torch.device("cpu")
     ws = _GEMM_WS.get(dev)
     if ws is None:
-        ws = torch.empty(1 << 24 if dev.type == "cuda" else 1 << 20, dtype=torch.float32, device=dev)
+        ws = torch.empty(1 << 26 if dev.type == "cuda" else 1 << 20, dtype=torch.float32, device=dev)
         _GEMM_WS[dev] = ws
     return ws
 
@@ -163,17 +163,10 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
 def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, scratch, ws=None):
     """Weight gradient C[M,N] = A^T . B with A stored [K][M] (lda) and B stored [K][N] (ldb).
 
-    f32: the GEMM's TN form reads both operands as stored.  bf16: measured on MI355X the [K][rows]-stored staging path
-    of the bf16 kernel (scalar loads + transposing LDS writes) runs at the f32 kernel's speed, so both operands are
-    transposed once (streaming f32 pass) and the product runs on the fast NT form."""
-    if prec != "bf16":
-        _gemm(lib, s, 1, 0, M, N, K, A, lda, Bm, ldb, C, ldc, prec=prec, ws=ws)
-        return
-    Kp = _round_up(K, 4)
-    At, Bt = scratch(M * Kp, 0), scratch(N * Kp, 1)
-    lib.lv_transpose_ld_f32(A, lda, P(At), Kp, K, M, s)
-    lib.lv_transpose_ld_f32(Bm, ldb, P(Bt), Kp, K, N, s)
-    _gemm(lib, s, 0, 1, M, N, K, P(At), Kp, P(Bt), Kp, C, ldc, prec=prec, ws=ws)
+    Both kernels read the operands as stored (TN form): each wave-level load is 256 contiguous bytes of one k-row.
+    (Measured on MI355X: transposing the operands first to use the NT form is SLOWER for the bf16 kernel -- dW_pred
+    1.63 ms + 0.27 ms of transposes vs ~0.9 ms as TN; profiles/r01f_*.)"""
+    _gemm(lib, s, 1, 0, M, N, K, A, lda, Bm, ldb, C, ldc, prec=prec, ws=ws)
 
 
 class _Scratch(object):
@@ -321,7 +314,7 @@ class LSTMDecoderEngine(object):
             return contextlib.nullcontext(), None
         if self._side is None:
             self._side = torch.cuda.Stream(device)
-            self._side_ws = torch.empty(1 << 22, dtype=torch.float32, device=device)
+            self._side_ws = torch.empty(1 << 26, dtype=torch.float32, device=device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         self._side.wait_event(ev)
