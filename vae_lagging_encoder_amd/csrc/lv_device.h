@@ -58,27 +58,18 @@ __device__ __forceinline__ f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
-// f32 -> bf16 bits, round-to-nearest-even
-#ifdef LV_EMU
-static inline uint32_t lv_f32_to_bf16_bits(float x) {
+// f32 -> bf16 bits, round-to-nearest-even on the integer pipe (finite inputs).  A/B on MI355X
+// (profiles/r01_microbench_gemm_shapes.txt): this is 1.6-1.7x faster in the bf16 GEMM's staging path than the
+// (__bf16) cast route hipcc lowers through v_cvt_pk_bf16_f32 (logits GEMM 813 us vs 1389 us).
+__device__ __forceinline__ uint32_t lv_f32_to_bf16_bits(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-static inline uint32_t lv_pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ uint32_t lv_pack_bf16x2(float lo, float hi) {
     return lv_f32_to_bf16_bits(lo) | (lv_f32_to_bf16_bits(hi) << 16);
 }
-#else
-// the __bf16 casts lower to one v_cvt_pk_bf16_f32 per pair on gfx950 (hardware RNE) instead of ~10 integer VALU ops
-typedef __bf16 lv_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lv_pack_bf16x2(float lo, float hi) {
-    lv_bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
-    return *reinterpret_cast<uint32_t*>(&v);
-}
-#endif
 
 __device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
