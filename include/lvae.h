@@ -52,6 +52,13 @@ int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, in
  * hs[t+1]*mask*dscale;  with dmask == NULL and hdrop != NULL, hdrop is a copy of the outputs. */
 int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                     const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* same recurrence with the h W_hh^T product on the bf16 matrix pipe (throughput configuration; f32 accumulate/state) */
+int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                     const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                     const float* whh, const float* gates, const float* hs, const float* cs,
+                     float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
+                     int T, int B, int H, void* stream);
 /* floats of caller-owned scratch (16-byte aligned) both LSTM entry points need: MFMA-fragment-major packed copies of
  * W_hh and of the recurrent state, split-K slabs */
 long lv_lstm_ws_floats(int B, int H);

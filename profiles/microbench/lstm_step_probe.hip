@@ -84,6 +84,15 @@ int main() {
     printf("  fwd ablation: no epilogue operand loads      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 4>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
     printf("  fwd ablation: matmul only (2+4)              : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 6>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
     printf("  fwd ablation: nothing (1+2+4)                : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 7>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
+    lv_lstm_fwd_bf16(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, 1, B, H, s);   // packs bf16 operands into ws
+    CK(hipStreamSynchronize(s));
+    const Geo g16 = geo(B, H, true);
+    LstmFwdP p16{gx, ws, hs, cs, gates, ws + g16.wp, nullptr, 1.f, nullptr, T, B, H, g16.Kq, g16.MBTp};
+    printf("fwd step kernel, bf16 recurrent operands      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 0, true>), dim3(256, 1), dim3(256), 0, s, p16, 3); }, 2000, s));
+    printf("lv_lstm_fwd_bf16, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_fwd_bf16(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, T, B, H, s); }, 20, s) / T);
+    printf("lv_lstm_bwd_bf16, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_bwd_bf16(dhext, nullptr, nullptr, 1.f, whh, gates, hs, cs, dG, dGsum, ws, nullptr, nullptr, 0, T, B, H, s); }, 20, s) / T);
+    lv_lstm_fwd_f32(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, 1, B, H, s);
+    CK(hipStreamSynchronize(s));
     LstmBwdP q{dhext, nullptr, nullptr, 1.f, ws, gates, cs, dG, dGsum, ws + g.wpT, ws + g.wpT + g.dGp, ws + g.wpT + g.dGp + g.part, T, B, H, g.KS, g.Kq4, g.MBTp};
     printf("bwd matmul kernel alone, back-to-back         : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_mm_kernel<2>), dim3(64 * g.KS, 1), dim3(256), 0, s, q, 3); }, 2000, s));
     printf("bwd elementwise kernel alone, back-to-back    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_bwd_elem_kernel<4>), dim3(128), dim3(256), 0, s, q, 3); }, 2000, s));

@@ -286,6 +286,29 @@ static inline f32x16 lv_emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_16x16x32_bf16: lane l holds 8 bf16 of A row (l&15) / B column (l&15) for k = 8*(l>>4)+e; D as 16x16x4
+static inline f32x4 lv_emu_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+    auto& w = lv_emu::my_wave();
+    int l = lv_emu::lane();
+    w.qa[l] = a; w.qb[l] = b;
+    pthread_barrier_wait(&w.bar);
+    f32x4 d = c;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            unsigned short ea[8], eb[8];
+            memcpy(ea, &w.qa[row + 16 * g], 16);
+            memcpy(eb, &w.qb[col + 16 * g], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf(lv_emu_bf16_to_f32(ea[e]), lv_emu_bf16_to_f32(eb[e]), acc);
+        }
+        d[r] = acc;
+    }
+    pthread_barrier_wait(&w.bar);
+    return d;
+}
+
 // ---- runtime API subset used by the host side of the C ABI -------------------------------
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }

@@ -114,8 +114,11 @@ def _lstm_ref(gx, whh, h0, c0, mask, scale):
     (4, 128, 256, False, True, True, False),     # stress batch
     (2, 130, 64, True, False, True, True),       # batch > 128 -> two batch chunks
 ])
-def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last):
+def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="f32"):
     dev = hip_device
+    fwd = lib.lv_lstm_fwd_bf16 if prec == "bf16" else lib.lv_lstm_fwd_f32
+    bwd = lib.lv_lstm_bwd_bf16 if prec == "bf16" else lib.lv_lstm_bwd_f32
+    tol = 300.0 if prec == "bf16" else 1.0      # bf16 recurrent operands: ~2^-9 relative per product
     g = torch.Generator().manual_seed(T * 100 + B + H)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
@@ -142,10 +145,10 @@ def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, us
     hdrop = torch.empty(T, B, H, device=dev)
     m8 = mask.to(torch.uint8).contiguous()
     ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
-    lib.lv_lstm_fwd_f32(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
-    assert float((hs.double() - hs_r.detach()).abs().max()) < 2e-5
-    assert float((cs.double() - cs_r.detach()).abs().max()) < 2e-5
-    assert float((hdrop.double() - out_r.detach()).abs().max()) < 4e-5
+    fwd(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
+    assert float((hs.double() - hs_r.detach()).abs().max()) < 2e-5 * tol
+    assert float((cs.double() - cs_r.detach()).abs().max()) < 2e-5 * tol
+    assert float((hdrop.double() - out_r.detach()).abs().max()) < 4e-5 * tol
     whhT = torch.empty(H, 4 * H, device=dev)
     lib.lv_transpose_f32(P(whh), P(whhT), 4 * H, H, _s(dev))
     assert torch.equal(whhT, whh.t().contiguous())
@@ -153,13 +156,21 @@ def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, us
     dGsum = torch.full((B, 4 * H), 7.0, device=dev)
     dc0 = torch.empty(B, H, device=dev)
     ws.fill_(float("nan"))            # scratch content must not matter
-    lib.lv_lstm_bwd_f32(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
-                        P(whh), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(ws), None, P(dc0),
-                        int(tanh_init), T, B, H, _s(dev))
+    bwd(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+        P(whh), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(ws), None, P(dc0),
+        int(tanh_init), T, B, H, _s(dev))
     sc = float(gx64.grad.abs().max())
-    assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc
-    assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T
-    assert float((dc0.double() - c064.grad).abs().max()) < 1e-4 * float(c064.grad.abs().max())
+    assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc * tol
+    assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T * tol
+    assert float((dc0.double() - c064.grad).abs().max()) < 1e-4 * float(c064.grad.abs().max()) * tol
+
+
+@pytest.mark.parametrize("T,B,H,use_mask,tanh_init,use_ext,use_last", [
+    (6, 32, 1024, True, True, True, False), (3, 5, 50, True, True, True, True), (4, 128, 256, False, True, True, False),
+    (2, 130, 64, True, False, True, True), (5, 32, 1024, False, False, False, True),
+])
+def test_lstm_fwd_bwd_bf16_recurrence(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last):
+    test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="bf16")
 
 
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),

@@ -14,6 +14,7 @@ static inline f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) { return lv_emu_m
 static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu_mfma_32x32x2(a, b, c); }
 #define LV_SCHED_BARRIER() do { } while (0)
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
+static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,11 @@ __device__ __forceinline__ f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) {
 typedef __bf16 lv_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
+                                                   c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_bf16: a/b = 8 bf16 of A row / B column (l&15), k = 8*(l>>4)+e; D[row=(l>>4)*4+r][col=l&15]
+__device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
                                                    c, 0, 0, 0);
 }
 #endif

@@ -83,6 +83,35 @@ __device__ __forceinline__ void rec_mm_core(const float* __restrict__ ap, long a
     }
 }
 
+// bf16 recurrent operands (throughput configuration): same structure on v_mfma_f32_16x16x32_bf16 -- one 16-byte load
+// per lane carries 8 consecutive k of its row/column, K is covered 32 at a time, operands packed
+//   Ap16[k/8][mb][16 rows][8 k],  Wp16[nb][k/8][16 cols][8 k]   (uint4 = one lane's 8 bf16)
+template <int MB, int NIT>
+__device__ __forceinline__ void rec_mm_core_bf16(const uint4* __restrict__ ap, long a_opitch,
+                                                 const uint4* __restrict__ wp, int it0, int it1, int l, f32x4 (&acc)[MB]) {
+    const int i = l & 15, kq = l >> 4;
+    for (int itb = it0; itb < it1; itb += NIT) {
+        uint4 wv[NIT];
+        uint4 av[NIT][MB];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const bool ok = itb + u < it1;
+            const long o = 4L * (ok ? itb + u : it0) + kq;
+            const uint4 t = wp[o * 16 + i];
+            wv[u] = ok ? t : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[u][mb] = ap[o * a_opitch + mb * 16 + i];
+        }
+        LV_SCHED_BARRIER();
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = lv_mfma_16x16x32_bf16(av[u][mb], wv[u], acc[mb]);
+    }
+}
+
+template <int MB> struct RecNit16 { static constexpr int value = MB <= 2 ? 8 : (MB == 4 ? 4 : 2); };
+
 // ---- packing ---------------------------------------------------------------------------------------------------
 // forward weights: Wp[nb][kq][j][e] = whh[(j>>2)*H + 4*nb + (j&3)][4*kq + e]   (0 outside)
 __global__ __launch_bounds__(256) void pack_w_fwd_kernel(const float* __restrict__ whh, float* __restrict__ wp, int H, int Kq) {
@@ -127,6 +156,51 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__
     ap[((long)(k >> 2) * MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (k & 3)] = src[idx];
 }
 
+// bf16 variants of the three packers (Kq8 = octs of K)
+__global__ __launch_bounds__(256) void pack_w_fwd_bf16_kernel(const float* __restrict__ whh, uint4* __restrict__ wp, int H, int Kq8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // one uint4 (8 bf16) of Wp16
+    const long total = (long)((H + 3) / 4) * Kq8 * 16;
+    if (idx >= total) return;
+    const int j = (int)(idx % 16);
+    const int oc = (int)((idx / 16) % Kq8);
+    const int nb = (int)(idx / (16L * Kq8));
+    const int unit = 4 * nb + (j & 3);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (unit < H) {
+        const float* row = whh + ((long)(j >> 2) * H + unit) * H;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int k = 8 * oc + e; if (k < H) v[e] = row[k]; }
+    }
+    wp[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+
+__global__ __launch_bounds__(256) void pack_w_bwd_bf16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpT, int H, int Kq8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)((H + 15) / 16) * Kq8 * 16;
+    if (idx >= total) return;
+    const int j = (int)(idx % 16);
+    const int oc = (int)((idx / 16) % Kq8);
+    const int nb = (int)(idx / (16L * Kq8));
+    const int unit = 16 * nb + j;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (unit < H) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int n = 8 * oc + e; if (n < 4 * H) v[e] = whh[(long)n * H + unit]; }
+    }
+    wpT[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+
+__global__ __launch_bounds__(256) void pack_act_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ ap, int B, int K, int MBTp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * K) return;
+    const int b = (int)(idx / K), k = (int)(idx % K);
+    ap[(((long)(k >> 3) * MBTp + (b >> 4)) * 16 + (b & 15)) * 8 + (k & 7)] = (unsigned short)lv_f32_to_bf16_bits(src[idx]);
+}
+
 struct LstmFwdP {
     const float* gx; const float* wp; float* hs; float* cs; float* gates; float* hp;   // hp: 2 packed buffers
     const uint8_t* dmask; float dscale; float* hdrop;
@@ -135,7 +209,7 @@ struct LstmFwdP {
 
 // ABL: ablation switches for profiles/microbench/lstm_step_probe.hip only (product launches use ABL = 0):
 //      1 = skip the recurrent matmul, 2 = skip the gate math and all stores except h, 4 = skip the epilogue operand loads
-template <int MB, int ABL = 0>
+template <int MB, int ABL = 0, bool BF = false>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     __shared__ float red[4][MB][16][17];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -145,7 +219,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     const int u0 = nb * 4;
     const int mbase = (int)blockIdx.y * MB;
     const int rb = mbase * 16;
-    const long hp_sz = (long)p.Kq * p.MBTp * 64;
+    const long hp_sz = (long)p.Kq * p.MBTp * 64;     // floats per packed buffer (f32: Kq quads x 64; bf16: Kq octs x 16 uint4)
     const float* gx_t = p.gx + (long)t * B * 4 * H;
     const float* hp_in = p.hp + (long)(t & 1) * hp_sz;
     float* hp_out = p.hp + (long)((t + 1) & 1) * hp_sz;
@@ -176,9 +250,14 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it0 < it1 && !(ABL & 1))
-        rec_mm_core<MB, RecNit<MB>::value>(hp_in + (long)mbase * 64, (long)p.MBTp * 64, p.wp + (long)nb * p.Kq * 64,
-                                           it0, it1, l, acc);
+    if (it0 < it1 && !(ABL & 1)) {
+        if (BF)
+            rec_mm_core_bf16<MB, RecNit16<MB>::value>(reinterpret_cast<const uint4*>(hp_in) + (long)mbase * 16, (long)p.MBTp * 16,
+                                                      reinterpret_cast<const uint4*>(p.wp) + (long)nb * p.Kq * 16, it0, it1, l, acc);
+        else
+            rec_mm_core<MB, RecNit<MB>::value>(hp_in + (long)mbase * 64, (long)p.MBTp * 64, p.wp + (long)nb * p.Kq * 64,
+                                               it0, it1, l, acc);
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -207,7 +286,11 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
             g_out[gi] = ig; g_out[gi + H] = fg; g_out[gi + 2L * H] = gg; g_out[gi + 3L * H] = og;
             c_out[(long)b * H + u] = c;
             h_out[(long)b * H + u] = h;
-            hp_out[((long)nb * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + uu] = h;    // packed copy for step t+1
+            if (BF)     // packed bf16 copy for step t+1: oct = u/8, element u%8
+                reinterpret_cast<unsigned short*>(hp_out)[((((long)(u >> 3)) * p.MBTp + (b >> 4)) * 16 + (b & 15)) * 8 + (u & 7)] =
+                    (unsigned short)lv_f32_to_bf16_bits(h);
+            else
+                hp_out[((long)nb * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + uu] = h;    // packed copy for step t+1
             if (p.hdrop) {
                 float m = 1.f;
                 if (p.dmask) m = p.dmask[((long)b * p.T + t) * H + u] ? p.dscale : 0.f;
@@ -229,7 +312,7 @@ struct LstmBwdP {
 
 // elementwise part of BPTT step t (KS = number of split-K slabs of the previous step's matmul, compile-time so
 // that all slab loads are issued together)
-template <int KS>
+template <int KS, bool BF = false>
 __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int t) {
     const int B = p.B, H = p.H;
     const long BH = (long)B * H;
@@ -279,12 +362,16 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
         if (first) p.dGsum[si + (long)g * H] = da[g];
         else p.dGsum[si + (long)g * H] += da[g];
         const int n = g * H + u;                                   // packed copy: A operand of this step's matmul
-        p.dGp[((long)(n >> 2) * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (n & 3)] = da[g];
+        if (BF)
+            reinterpret_cast<unsigned short*>(p.dGp)[(((long)(n >> 3) * p.MBTp + (b >> 4)) * 16 + (b & 15)) * 8 + (n & 7)] =
+                (unsigned short)lv_f32_to_bf16_bits(da[g]);
+        else
+            p.dGp[((long)(n >> 2) * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (n & 3)] = da[g];
     }
 }
 
 // recurrent matmul of BPTT step t: dh_part[ks][b][j] = sum_{n in slice ks} dG[t][b][n] * whh[n][j]
-template <int MB>
+template <int MB, bool BF = false>
 __global__ __launch_bounds__(256) void lstm_step_bwd_mm_kernel(LstmBwdP p, int t) {
     __shared__ float red[4][MB][16][17];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -302,9 +389,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_mm_kernel(LstmBwdP p, int t
     f32x4 acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it0 < it1)
-        rec_mm_core<MB, RecNit<MB>::value>(p.dGp + (long)mbase * 64, (long)p.MBTp * 64, p.wpT + (long)nb * p.Kq4 * 64,
-                                           it0, it1, l, acc);
+    if (it0 < it1) {
+        if (BF)
+            rec_mm_core_bf16<MB, RecNit16<MB>::value>(reinterpret_cast<const uint4*>(p.dGp) + (long)mbase * 16, (long)p.MBTp * 16,
+                                                      reinterpret_cast<const uint4*>(p.wpT) + (long)nb * p.Kq4 * 16, it0, it1, l, acc);
+        else
+            rec_mm_core<MB, RecNit<MB>::value>(p.dGp + (long)mbase * 64, (long)p.MBTp * 64, p.wpT + (long)nb * p.Kq4 * 64,
+                                               it0, it1, l, acc);
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -363,13 +455,14 @@ inline int ksplit_for(int H) {
     return ks;
 }
 
-inline Geo geo(int B, int H) {
+inline Geo geo(int B, int H, bool bf = false) {
     Geo g;
     g.MB = pick_mb(B);
     g.MBT = (B + 15) / 16;
     g.MBTp = h_round_up(g.MBT, g.MB);
-    g.Kq = h_round_up(H, 16) / 4;
-    g.Kq4 = h_round_up(4 * H, 16) / 4;
+    // f32: K in quads (16 k per MFMA group of 4);  bf16: K in octs (32 k per MFMA)
+    g.Kq = bf ? h_round_up(H, 32) / 8 : h_round_up(H, 16) / 4;
+    g.Kq4 = bf ? h_round_up(4 * H, 32) / 8 : h_round_up(4 * H, 16) / 4;
     g.NBf = (H + 3) / 4;
     g.NBb = (H + 15) / 16;
     g.KS = ksplit_for(H);
@@ -382,18 +475,106 @@ inline Geo geo(int B, int H) {
     return g;
 }
 
-template <int MB>
+template <int MB, bool BF>
 int launch_fwd_steps(const LstmFwdP& p, void* stream) {
     dim3 grid((unsigned)lv_cdiv(p.H, 4), (unsigned)(p.MBTp / MB)), block(256);
-    for (int t = 0; t < p.T; ++t) LV_LAUNCH((lstm_step_fwd_kernel<MB>), grid, block, 0, stream, p, t);
+    for (int t = 0; t < p.T; ++t) LV_LAUNCH((lstm_step_fwd_kernel<MB, 0, BF>), grid, block, 0, stream, p, t);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
-template <int MB>
+template <int MB, bool BF>
 void launch_bwd_mm(const LstmBwdP& p, int t, void* stream) {
     dim3 grid((unsigned)(lv_cdiv(p.H, 16) * p.KS), (unsigned)(p.MBTp / MB)), block(256);
-    LV_LAUNCH((lstm_step_bwd_mm_kernel<MB>), grid, block, 0, stream, p, t);
+    LV_LAUNCH((lstm_step_bwd_mm_kernel<MB, BF>), grid, block, 0, stream, p, t);
+}
+
+template <bool BF>
+void launch_bwd_elem(const LstmBwdP& p, int t, dim3 egrid, void* stream) {
+    dim3 block(256);
+    switch (p.KS) {
+        case 1: LV_LAUNCH((lstm_step_bwd_elem_kernel<1, BF>), egrid, block, 0, stream, p, t); break;
+        case 2: LV_LAUNCH((lstm_step_bwd_elem_kernel<2, BF>), egrid, block, 0, stream, p, t); break;
+        case 4: LV_LAUNCH((lstm_step_bwd_elem_kernel<4, BF>), egrid, block, 0, stream, p, t); break;
+        default: LV_LAUNCH((lstm_step_bwd_elem_kernel<8, BF>), egrid, block, 0, stream, p, t); break;
+    }
+}
+
+template <bool BF>
+int lstm_fwd_impl(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                  const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream) {
+    if (!gx || !whh || !hs || !cs || !gates || !ws) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (dmask && !hdrop) return LV_ERR_ARG;
+    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    const Geo g = geo(B, H, BF);
+    float* wp = ws;
+    float* hp = ws + g.wp;
+    hipMemsetAsync(hp, 0, (size_t)g.hp * sizeof(float), (hipStream_t)stream);
+    if (BF) {
+        LV_LAUNCH(pack_w_fwd_bf16_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh,
+                  reinterpret_cast<uint4*>(wp), H, g.Kq);
+        LV_LAUNCH(pack_act_bf16_kernel, dim3((unsigned)lv_cdiv((long)B * H, 256)), dim3(256), 0, stream, (const float*)hs,
+                  reinterpret_cast<unsigned short*>(hp), B, H, g.MBTp);
+    } else {
+        LV_LAUNCH(pack_w_fwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh, wp, H, g.Kq);
+        LV_LAUNCH(pack_act_kernel, dim3((unsigned)lv_cdiv((long)B * H, 256)), dim3(256), 0, stream, (const float*)hs, hp, B, H, g.MBTp);
+    }
+    LstmFwdP p{gx, wp, hs, cs, gates, hp, dmask, dscale, hdrop, T, B, H, g.Kq, g.MBTp};
+    switch (g.MB) {
+        case 1: return launch_fwd_steps<1, BF>(p, stream);
+        case 2: return launch_fwd_steps<2, BF>(p, stream);
+        case 4: return launch_fwd_steps<4, BF>(p, stream);
+        default: return launch_fwd_steps<8, BF>(p, stream);
+    }
+}
+
+template <bool BF>
+int lstm_bwd_impl(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                  const float* whh, const float* gates, const float* hs, const float* cs,
+                  float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
+                  int T, int B, int H, void* stream) {
+    if (!whh || !gates || !cs || !dG || !dGsum || !ws) return LV_ERR_ARG;
+    if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (tanh_init && !hs) return LV_ERR_ARG;
+    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    const Geo g = geo(B, H, BF);
+    float* wpT = ws;
+    float* dGp = wpT + g.wpT;
+    float* part = dGp + g.dGp;
+    float* dcrec = part + g.part;
+    if (BF)
+        LV_LAUNCH(pack_w_bwd_bf16_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh,
+                  reinterpret_cast<uint4*>(wpT), H, g.Kq4);
+    else
+        LV_LAUNCH(pack_w_bwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh, wpT, H, g.Kq4);
+    hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
+    LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp};
+    const long BH = (long)B * H;
+    const bool need_h0 = (dh0 != nullptr) || tanh_init;
+    dim3 egrid((unsigned)lv_cdiv(BH, 256)), block(256);
+    for (int t = T - 1; t >= 0; --t) {
+        launch_bwd_elem<BF>(p, t, egrid, stream);
+        if (t > 0 || need_h0) {
+            switch (g.MB) {
+                case 1: launch_bwd_mm<1, BF>(p, t, stream); break;
+                case 2: launch_bwd_mm<2, BF>(p, t, stream); break;
+                case 4: launch_bwd_mm<4, BF>(p, t, stream); break;
+                default: launch_bwd_mm<8, BF>(p, t, stream); break;
+            }
+        }
+    }
+    if (need_h0 || dc0) {
+        if (!need_h0) {
+            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, 0,
+                      (const float*)dcrec, (const float*)nullptr, 0, (float*)nullptr, dc0, BH);
+        } else {
+            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, p.KS,
+                      (const float*)dcrec, hs, tanh_init, dh0, dc0, BH);
+        }
+    }
+    LV_CHECK_LAUNCH();
+    return LV_OK;
 }
 
 }  // namespace
@@ -431,23 +612,15 @@ extern "C" int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long
 extern "C" int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                                const uint8_t* dmask, float dscale, float* hdrop, float* ws,
                                int T, int B, int H, void* stream) {
-    if (!gx || !whh || !hs || !cs || !gates || !ws) return LV_ERR_ARG;
-    if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
-    if (dmask && !hdrop) return LV_ERR_ARG;
-    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
-    const Geo g = geo(B, H);
-    float* wp = ws;
-    float* hp = ws + g.wp;
-    LV_LAUNCH(pack_w_fwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh, wp, H, g.Kq);
-    hipMemsetAsync(hp, 0, (size_t)g.hp * sizeof(float), (hipStream_t)stream);
-    LV_LAUNCH(pack_act_kernel, dim3((unsigned)lv_cdiv((long)B * H, 256)), dim3(256), 0, stream, (const float*)hs, hp, B, H, g.MBTp);
-    LstmFwdP p{gx, wp, hs, cs, gates, hp, dmask, dscale, hdrop, T, B, H, g.Kq, g.MBTp};
-    switch (g.MB) {
-        case 1: return launch_fwd_steps<1>(p, stream);
-        case 2: return launch_fwd_steps<2>(p, stream);
-        case 4: return launch_fwd_steps<4>(p, stream);
-        default: return launch_fwd_steps<8>(p, stream);
-    }
+    return lstm_fwd_impl<false>(gx, whh, hs, cs, gates, dmask, dscale, hdrop, ws, T, B, H, stream);
+}
+
+// Throughput configuration: the recurrent product h_{t-1} W_hh^T runs on the bf16 matrix pipe (operands rounded to bf16,
+// f32 accumulate); gates, cell state, outputs and everything stored stay f32.  Same arguments as lv_lstm_fwd_f32.
+extern "C" int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                                const uint8_t* dmask, float dscale, float* hdrop, float* ws,
+                                int T, int B, int H, void* stream) {
+    return lstm_fwd_impl<true>(gx, whh, hs, cs, gates, dmask, dscale, hdrop, ws, T, B, H, stream);
 }
 
 // BPTT.  ws: lv_lstm_ws_floats(B, H) floats of scratch.  dh0/dc0 may be null.
@@ -455,46 +628,14 @@ extern "C" int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const 
                                const float* whh, const float* gates, const float* hs, const float* cs,
                                float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
                                int T, int B, int H, void* stream) {
-    if (!whh || !gates || !cs || !dG || !dGsum || !ws) return LV_ERR_ARG;
-    if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
-    if (tanh_init && !hs) return LV_ERR_ARG;
-    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
-    const Geo g = geo(B, H);
-    float* wpT = ws;
-    float* dGp = wpT + g.wpT;
-    float* part = dGp + g.dGp;
-    float* dcrec = part + g.part;
-    LV_LAUNCH(pack_w_bwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh, wpT, H, g.Kq4);
-    hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
-    LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp};
-    const long BH = (long)B * H;
-    const bool need_h0 = (dh0 != nullptr) || tanh_init;
-    dim3 egrid((unsigned)lv_cdiv(BH, 256)), block(256);
-    for (int t = T - 1; t >= 0; --t) {
-        switch (p.KS) {
-            case 1: LV_LAUNCH((lstm_step_bwd_elem_kernel<1>), egrid, block, 0, stream, p, t); break;
-            case 2: LV_LAUNCH((lstm_step_bwd_elem_kernel<2>), egrid, block, 0, stream, p, t); break;
-            case 4: LV_LAUNCH((lstm_step_bwd_elem_kernel<4>), egrid, block, 0, stream, p, t); break;
-            default: LV_LAUNCH((lstm_step_bwd_elem_kernel<8>), egrid, block, 0, stream, p, t); break;
-        }
-        if (t > 0 || need_h0) {
-            switch (g.MB) {
-                case 1: launch_bwd_mm<1>(p, t, stream); break;
-                case 2: launch_bwd_mm<2>(p, t, stream); break;
-                case 4: launch_bwd_mm<4>(p, t, stream); break;
-                default: launch_bwd_mm<8>(p, t, stream); break;
-            }
-        }
-    }
-    if (need_h0 || dc0) {
-        if (!need_h0) {
-            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, 0,
-                      (const float*)dcrec, (const float*)nullptr, 0, (float*)nullptr, dc0, BH);
-        } else {
-            LV_LAUNCH(lstm_bwd_finish_kernel, egrid, block, 0, stream, (const float*)part, p.KS,
-                      (const float*)dcrec, hs, tanh_init, dh0, dc0, BH);
-        }
-    }
-    LV_CHECK_LAUNCH();
-    return LV_OK;
+    return lstm_bwd_impl<false>(dh_ext, dh_last, dmask, dscale, whh, gates, hs, cs, dG, dGsum, ws, dh0, dc0, tanh_init,
+                                T, B, H, stream);
+}
+
+extern "C" int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                                const float* whh, const float* gates, const float* hs, const float* cs,
+                                float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
+                                int T, int B, int H, void* stream) {
+    return lstm_bwd_impl<true>(dh_ext, dh_last, dmask, dscale, whh, gates, hs, cs, dG, dGsum, ws, dh0, dc0, tanh_init,
+                               T, B, H, stream);
 }

@@ -251,8 +251,8 @@ class LSTMEncoderEngine(object):
         w.hs[0].zero_()
         w.cs[0].zero_()
         with _prof("lstm_fwd", 0.0, T):
-            lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None,
-                                P(w.lstm_ws), T, B, H, s)
+            (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
+                P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
@@ -274,8 +274,9 @@ class LSTMEncoderEngine(object):
         _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
         with _prof("lstm_bwd", 0.0, 2 * T):
-            lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
-                                P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
+            (lib.lv_lstm_bwd_bf16 if self.precision == "bf16" else lib.lv_lstm_bwd_f32)(
+                None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
+                P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
         # input-side grads
         _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
         sc = lambda n, slot: self._scratch(n, slot, x.device)
@@ -421,8 +422,9 @@ class LSTMDecoderEngine(object):
         _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
               add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
         with _prof("lstm_fwd", 0.0, Td):
-            lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
-                                P(w.O), P(w.lstm_ws), Td, B, H, s)
+            (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
+                P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
+                P(w.O), P(w.lstm_ws), Td, B, H, s)
         _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
         lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
         # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
@@ -455,8 +457,9 @@ class LSTMDecoderEngine(object):
                    self.precision, sc, ws=sws)
         _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         with _prof("lstm_bwd", 0.0, 2 * Td):
-            lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
-                                P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
+            (lib.lv_lstm_bwd_bf16 if self.precision == "bf16" else lib.lv_lstm_bwd_f32)(
+                P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
+                P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
         with ctx:
             s2 = stream_ptr(dev)
