@@ -224,9 +224,11 @@ def main():
             "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4), "traffic": None,
             "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
             "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
-        # LSTM recurrence: per launch the algorithmic HBM bytes are W_hh (4H*H) + one timestep of state/gates
-        per_fwd = 4.0 * (4 * H * H + B * H * 3 + B * 4 * H * 2)
-        per_bwd = 4.0 * (4 * H * H + B * 4 * H * 4 + B * H * 10) / 2.0        # two launches (elementwise + matmul) per step
+        # LSTM recurrence: per launch the algorithmic HBM bytes are W_hh (4H*H, 2 B/element when the recurrent product
+        # runs on the bf16 pipe) + one timestep of f32 state/gates
+        wb = 2.0 if args.dtype == "bf16" else 4.0
+        per_fwd = wb * 4 * H * H + 4.0 * (B * H * 3 + B * 4 * H * 2)
+        per_bwd = (wb * 4 * H * H + 4.0 * (B * 4 * H * 4 + B * H * 10)) / 2.0  # two launches (elementwise + matmul) per step
         steps_fwd = groups.get("lstm_fwd", dict(launches=0))["launches"]
         steps_bwd = groups.get("lstm_bwd", dict(launches=0))["launches"]
         lstm_bytes = per_fwd * steps_fwd + per_bwd * steps_bwd
