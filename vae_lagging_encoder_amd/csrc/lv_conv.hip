@@ -36,6 +36,26 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     }
 }
 
+// same, four channels per thread (C % 4 == 0, 16-byte aligned rows): one index computation per float4
+__global__ __launch_bounds__(256) void im2col_vec4_kernel(const float* __restrict__ x, float* __restrict__ col, long ldcol,
+                                                          int N, int H, int W, int C, int Ho, int Wo, int kw, int pad,
+                                                          int stride, int nt) {
+    const int C4 = C >> 2;
+    const long total = (long)N * Ho * Wo * nt * C4;
+    const long gs = (long)gridDim.x * 256;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += gs) {
+        const int c4 = (int)(idx % C4);
+        const int t = (int)((idx / C4) % nt);
+        const long p = idx / ((long)C4 * nt);
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((long)Wo * Ho));
+        const int h = ho * stride + t / kw - pad, w = wo * stride + t % kw - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h >= 0 && h < H && w >= 0 && w < W)
+            v = *reinterpret_cast<const float4*>(x + (((long)n * H + h) * W + w) * C + 4 * c4);
+        *reinterpret_cast<float4*>(col + p * ldcol + (long)t * C + 4 * c4) = v;
+    }
+}
+
 // dx[n][h][w][c] (=|+=) sum_t dcol[p(h,w,t)][t*C + c] over the taps/outputs that read (h,w)
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, long ldcol, float* __restrict__ dx,
                                                      int N, int H, int W, int C, int Ho, int Wo, int kw, int pad,
@@ -82,7 +102,7 @@ __global__ __launch_bounds__(256) void mul_inplace_kernel(float* __restrict__ w,
     if (i < n) w[i] *= m[i];
 }
 
-constexpr int BN_BLOCKS = 128;
+constexpr int BN_BLOCKS = 512;
 
 // Per-channel column reductions over a [P][C] matrix, stage 1: block blk reduces rows blk, blk+nblk, ... (in groups
 // of 256/CT rows, CT = channels handled per pass) and writes partial[blk][q][c], q = 0,1.
@@ -129,15 +149,30 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-// stage 2 forward: mean, invstd = 1/sqrt(var_biased + eps); running stats with momentum (unbiased var), f64 combine
+// stage 2: one wave per channel sums the per-block partials (lanes stride over blocks, f64 shuffle reduction in a
+// fixed order -> deterministic); 4 channels per workgroup
+__device__ __forceinline__ void bn_partial_sums(const float* __restrict__ partial, int nblk, int C, int c, int lane,
+                                                double& s, double& q) {
+    s = 0.0; q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += (double)partial[((long)b * 2 + 0) * C + c];
+        q += (double)partial[((long)b * 2 + 1) * C + c];
+    }
+    s = lv_wave_sum(s);
+    q = lv_wave_sum(q);
+}
+
+// forward: mean, invstd = 1/sqrt(var_biased + eps); running stats with momentum (unbiased var)
 __global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restrict__ partial, int nblk, long P, int C,
                                                             float eps, float momentum, float* __restrict__ mean,
                                                             float* __restrict__ invstd, float* __restrict__ run_mean,
                                                             float* __restrict__ run_var) {
-    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += (double)partial[((long)b * 2 + 0) * C + c]; q += (double)partial[((long)b * 2 + 1) * C + c]; }
+    const int lane = (int)threadIdx.x & 63;
+    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int cc = c < C ? c : C - 1;          // keep every wave in the shuffles
+    double s, q;
+    bn_partial_sums(partial, nblk, C, cc, lane, s, q);
+    if (c >= C || lane != 0) return;
     const double m = s / (double)P;
     double var = q / (double)P - m * m;
     if (var < 0.0) var = 0.0;
@@ -150,14 +185,19 @@ __global__ __launch_bounds__(256) void bn_finish_fwd_kernel(const float* __restr
     }
 }
 
-// stage 2 backward: dbeta, dgamma
+// backward: this layer's sums into (dgl, dbl) and (=|+=) into the parameter gradients
 __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            float* __restrict__ dgl, float* __restrict__ dbl,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int accumulate) {
-    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += (double)partial[((long)b * 2 + 0) * C + c]; q += (double)partial[((long)b * 2 + 1) * C + c]; }
+    const int lane = (int)threadIdx.x & 63;
+    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int cc = c < C ? c : C - 1;
+    double s, q;
+    bn_partial_sums(partial, nblk, C, cc, lane, s, q);
+    if (c >= C || lane != 0) return;
+    dbl[c] = (float)s;
+    dgl[c] = (float)q;
     dbeta[c] = (float)(s + (accumulate ? (double)dbeta[c] : 0.0));
     dgamma[c] = (float)(q + (accumulate ? (double)dgamma[c] : 0.0));
 }
@@ -259,8 +299,12 @@ extern "C" int lv_im2col_f32(const float* x, float* col, long ldcol, int N, int 
     if (!x || !col) return LV_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return LV_ERR_SHAPE;
     if (ntaps <= 0 || ntaps > kh * kw || ldcol < (long)ntaps * C) return LV_ERR_SHAPE;
-    LV_LAUNCH(im2col_kernel, dim3(conv_grid((long)N * Ho * Wo * ntaps * C)), dim3(256), 0, stream, x, col, ldcol, N, H, W, C, Ho, Wo,
-              kw, pad, stride, ntaps);
+    if (C % 4 == 0 && ldcol % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)col)) & 15) == 0)
+        LV_LAUNCH(im2col_vec4_kernel, dim3(conv_grid((long)N * Ho * Wo * ntaps * (C / 4))), dim3(256), 0, stream, x, col, ldcol, N, H, W,
+                  C, Ho, Wo, kw, pad, stride, ntaps);
+    else
+        LV_LAUNCH(im2col_kernel, dim3(conv_grid((long)N * Ho * Wo * ntaps * C)), dim3(256), 0, stream, x, col, ldcol, N, H, W, C, Ho, Wo,
+                  kw, pad, stride, ntaps);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -312,7 +356,7 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
-    LV_LAUNCH(bn_finish_fwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, P, C, eps, momentum,
+    LV_LAUNCH(bn_finish_fwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, P, C, eps, momentum,
               mean, invstd, run_mean, run_var);
     LV_LAUNCH(bn_apply_fwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)mean, (const float*)invstd, gamma,
               beta, res, act_elu, y, P * C, C);
@@ -334,12 +378,10 @@ extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, co
     float* dgl = ws + (long)BN_BLOCKS * 2 * C;
     float* dbl = dgl + C;
     LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
-    LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgl, dbl, 0);
+    LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgl, dbl,
+              dgamma, dbeta, accumulate_param_grads);
     LV_LAUNCH(bn_apply_bwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)dv, mean, invstd, gamma,
               (const float*)dgl, (const float*)dbl, dx, P * C, C, 1.0f / (float)P);
-    // parameter grads: (=|+=) this layer's sums
-    LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 256)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgamma, dbeta,
-              accumulate_param_grads);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -52,13 +52,22 @@ class GradSync(object):
             self._inv = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.device)
         lib.lv_scale_f32(P(flat.grad), flat.numel, P(self._inv), _eng.stream_ptr(flat.device))
 
+    def start_decoder(self, dec_flat):
+        """Issue the decoder-gradient all-reduce as soon as the decoder's backward has been queued: RCCL runs it on
+        its own stream underneath the encoder's BPTT (strict mode only).  Completed by sync()."""
+        if self.world == 1 or self.mode != "strict":
+            return
+        self._h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def sync(self, enc_flat, dec_flat):
         if self.world == 1:
             return
-        if self.mode == "strict":
+        h_dec = getattr(self, "_h_dec", None)
+        self._h_dec = None
+        if self.mode == "strict" and h_dec is None:
             h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if self.mode == "strict":
+        if h_dec is not None:
             h_dec.wait()
             self._scale(dec_flat)
         h_enc.wait()

@@ -38,6 +38,7 @@ class AggressiveTextTrainer(object):
         self.clip = float(clip)
         self.grad_sync = grad_sync
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._capturing = False
         d = self.device
         # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum]
         self.scal = torch.zeros(8, dtype=torch.float32, device=d)
@@ -118,6 +119,10 @@ class AggressiveTextTrainer(object):
         # backward of mean_b(loss_b)
         lib.lv_loss_bwd_scales_f32(P(st.gl), None, None, self._s(0), P(st.rowscale), P(st.dkl), B, s)
         dz = self.dec.backward(st.rowscale)
+        if self.grad_sync is not None and not self._capturing:
+            # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward
+            self.dec.join()
+            self.grad_sync.start_decoder(self.dec.flat)
         lib.lv_reparam_kl_bwd_f32(P(mulv), P(st.eps), P(dz), P(st.dkl), P(st.dmulv), B, 1, nz, s)
         self.enc.backward(st.dmulv)
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
@@ -186,8 +191,12 @@ class AggressiveTextTrainer(object):
 
         def cap(fn):
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=stream):
-                fn()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(gr, stream=stream):
+                    fn()
+            finally:
+                self._capturing = False
             return gr.replay
         if self.grad_sync is None:
             parts.append(cap(lambda: (self._fwd_bwd(st, draw), self._clip_and_step(update))))
