@@ -168,3 +168,64 @@ def check_image_step_fused(name, device, use_graph=False):
             got = sd[k].reshape(-1)[idx].cpu()
             ref = torch.from_numpy(fx["sample_p0/" + k])
             assert bool(((got == ref) | (got == 0)).all()), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole aggressive inner loop with its data-dependent exit (text.py:366-400), oracle-driven replica vs trainer
+def check_inner_loop_exit_logic(device, window=3, max_iter=11):
+    """Replays text.py:366-400 literally (sub_iter counter, burn_* bookkeeping, np.random.random_integers batch pick,
+    windowed mean-loss-per-word comparison, break) with the CPU oracle doing the arithmetic, and checks that
+    AggressiveTextTrainer.inner_loop takes the same number of steps on the same batches and lands on the same encoder."""
+    import numpy as np
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    V, ni, H, nz, B = 97, 12, 20, 4, 6
+    P = O.random_params(V, ni, H, nz, seed=21, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    Ts = [5, 7, 6, 9]
+    batches = [O.synthetic_batch(B, T, V, seed=40 + i) for i, T in enumerate(Ts)]
+    klw = 0.8
+
+    def noise_for(step, x):
+        return O.draw_noise(x.shape[0], x.shape[1], ni, H, nz, seed=900 + step)
+
+    # ---- reference control flow, oracle arithmetic -------------------------------------------------------------------
+    rs = np.random.RandomState(5)
+    Pr = {k: v.clone() for k, v in P.items()}
+    sub_iter, x = 1, batches[0]
+    burn_num_words, burn_pre_loss, burn_cur_loss = 0, 1e4, 0.0
+    ref_steps = 0
+    while sub_iter < max_iter:
+        bsz, slen = x.shape
+        burn_num_words += (slen - 1) * bsz
+        eps, mi, mo = noise_for(ref_steps, x)
+        r = O.inner_step(Pr, x, klw, eps, mi, mo)
+        burn_cur_loss += float(r["loss"].sum())
+        Pr.update(r["new_params"])
+        ref_steps += 1
+        x = batches[int(rs.randint(0, len(batches)))]
+        if sub_iter % window == 0:
+            burn_cur_loss = burn_cur_loss / burn_num_words
+            if burn_pre_loss - burn_cur_loss < 0:
+                break
+            burn_pre_loss = burn_cur_loss
+            burn_cur_loss = burn_num_words = 0
+        sub_iter += 1
+
+    # ---- the fused driver -------------------------------------------------------------------------------------------------
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0)
+    counter = {"n": 0}
+
+    def noise_fn(xb):
+        eps, mi, mo = noise_for(counter["n"], xb)
+        counter["n"] += 1
+        return eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device)
+    steps = tr.inner_loop([b.to(device) for b in batches], batches[0].to(device), klw, np_rng=np.random.RandomState(5),
+                          max_iter=max_iter, window=window, noise_fn=noise_fn)
+    assert steps == ref_steps, (steps, ref_steps)
+    sd = vae.state_dict()
+    for k in ENC_KEYS:
+        assert rel_err(sd[k], Pr[k]) < 5e-4, (k, rel_err(sd[k], Pr[k]))
+    for k in DEC_KEYS:
+        assert torch.equal(sd[k].cpu(), P[k]), k
+    return steps

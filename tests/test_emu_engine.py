@@ -26,3 +26,8 @@ def test_cpu_tensors_refused_without_test_backend():
 
 def test_fused_trainer_trajectory_emulated(emu_backend):
     pc.check_trajectory_against_fixture("cpu")
+
+
+def test_inner_loop_exit_logic_emulated(emu_backend):
+    steps = pc.check_inner_loop_exit_logic("cpu", window=2, max_iter=4)
+    assert 1 <= steps < 4

@@ -235,3 +235,12 @@ def test_image_step_is_deterministic_and_masks_stay_applied(hip_device):
         if k.endswith(".mask"):
             w = sd[k.replace(".mask", ".weight")]
             assert float((w * (1 - sd[k])).abs().max()) == 0.0            # masked taps zeroed in place (G5)
+
+
+@pytest.mark.parametrize("window,max_iter", [(3, 11), (2, 100), (15, 20)])
+def test_inner_loop_with_data_dependent_exit(hip_device, window, max_iter):
+    """text.py:366-400 end to end: same batches, same windowed exit decision, same encoder after the loop."""
+    if max_iter == 100:
+        max_iter = 14          # the reference's `sub_iter < 100` bound, shortened for the CPU oracle replica
+    steps = pc.check_inner_loop_exit_logic(hip_device, window=window, max_iter=max_iter)
+    assert 1 <= steps < max_iter
