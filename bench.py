@@ -242,6 +242,18 @@ def main():
             "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
             "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
             "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3)}
+        # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            tr_ = pmc.get(args.workload, {}).get(args.dtype)
+            if tr_:
+                lstm_roof["traffic"] = round(tr_["lstm_MB_per_launch"] * 1e6)
+                gemm_roof["traffic"] = round(tr_["gemm_MB_per_launch"] * 1e6)
+                lstm_roof["algorithmic_bytes_per_launch"] = round(lstm_bytes / max(1, lstm_launches))
+                lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+        except (OSError, ValueError, KeyError):
+            pass
         if gemm["ms"] >= lstm_ms:
             out["roofline"], out["roofline_secondary"] = gemm_roof, lstm_roof
         else:

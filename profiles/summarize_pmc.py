@@ -1,0 +1,42 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
+
+    python profiles/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv>
+
+Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KB
+(bytes = value * 1024); on gfx950 FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced streaming read
+(128-B requests tallied at 64 B), so the read side is doubled; WRITE_SIZE is uncalibrated (reported as is).
+Infinity-Cache hits appear to be counted, not excluded.
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        name = r["Kernel_Name"]
+        a = acc[name]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return acc
+
+
+def main(fetch_csv, write_csv):
+    f = load(fetch_csv, "FETCH_SIZE")
+    w = load(write_csv, "WRITE_SIZE")
+    names = sorted(set(f) | set(w), key=lambda n: -(f.get(n, [0, 0])[1] * 2 + w.get(n, [0, 0])[1]))
+    print("%-100s %8s %16s %16s %16s" % ("kernel", "launches", "read_MB/launch", "write_MB/launch", "total_MB/launch"))
+    print("# read = FETCH_SIZE * 1024 * 2 (gfx950 half-count correction); write = WRITE_SIZE * 1024 (uncalibrated)")
+    for n in names[:30]:
+        nf, vf = f.get(n, [0, 0.0])
+        nw, vw = w.get(n, [0, 0.0])
+        rd = vf * 1024 * 2 / max(nf, 1) / 1e6
+        wr = vw * 1024 / max(nw, 1) / 1e6
+        print("%-100s %8d %16.3f %16.3f %16.3f" % (n[:100], max(nf, nw), rd, wr, rd + wr))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
