@@ -17,100 +17,121 @@ from ... import image_engine as _ie
 from .decoder import DecoderBase
 
 
-class MaskedConv2d(nn.Conv2d):
-    """Conv2d whose weight is multiplied by a causal mask: type 'A' hides the centre tap and everything after it in
-    raster order, type 'B' keeps the centre; only the first `masked_channels` input channels are masked."""
-
-    def __init__(self, mask_type, masked_channels, *args, **kwargs):
-        super(MaskedConv2d, self).__init__(*args, **kwargs)
-        assert mask_type in {'A', 'B'}
-        self.register_buffer('mask', self.weight.data.clone())
-        _, _, kH, kW = self.weight.size()
-        self.mask.fill_(1)
-        self.mask[:, :masked_channels, kH // 2, kW // 2 + (mask_type == 'B'):] = 0
-        self.mask[:, :masked_channels, kH // 2 + 1:] = 0
-
-    def reset_parameters(self):
-        n = self.kernel_size[0] * self.kernel_size[1] * self.out_channels
-        self.weight.data.normal_(0, math.sqrt(2. / n))
-        if self.bias is not None:
-            self.bias.data.zero_()
+def _fanout_normal_(conv):
+    """weight ~ N(0, 2 / (kH * kW * C_out)): the fan-out He initialisation both conv flavours use."""
+    kh, kw = conv.kernel_size
+    nn.init.normal_(conv.weight, mean=0.0, std=math.sqrt(2.0 / (kh * kw * conv.out_channels)))
 
 
-def _he_normal_convs_unit_bn(root):
+def _unit_affine_(bn):
+    nn.init.ones_(bn.weight)
+    nn.init.zeros_(bn.bias)
+
+
+def _reinit(root):
+    """Walk `root` in registration order (the order fixes the RNG draw sequence of a seeded construction)."""
     for m in root.modules():
         if isinstance(m, nn.Conv2d):
-            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-            m.weight.data.normal_(0, math.sqrt(2. / n))
+            _fanout_normal_(m)
         elif isinstance(m, nn.BatchNorm2d):
-            m.weight.data.fill_(1)
-            m.bias.data.zero_()
+            _unit_affine_(m)
+
+
+def raster_causal_mask(weight_shape, masked_channels, centre_visible):
+    """1 for the taps that precede the centre in raster order (plus the centre itself when `centre_visible`),
+    0 after; applies to the first `masked_channels` input channels, all others stay fully visible."""
+    _, _, kh, kw = weight_shape
+    tap = torch.arange(kh * kw).view(kh, kw)
+    last_visible = (kh // 2) * kw + kw // 2 - (0 if centre_visible else 1)
+    mask = torch.ones(weight_shape)
+    mask[:, :masked_channels] = (tap <= last_visible).to(mask.dtype)
+    return mask
+
+
+class MaskedConv2d(nn.Conv2d):
+    """Conv2d whose weight is multiplied by a causal mask before use: type 'A' hides the centre tap and everything
+    after it in raster order, type 'B' keeps the centre (reference dec_pixelcnn_v2.py:12-38).  Signature and the
+    `mask` buffer name follow the reference so checkpoints interchange."""
+
+    def __init__(self, mask_type, masked_channels, *conv_args, **conv_kwargs):
+        if mask_type not in ('A', 'B'):
+            raise ValueError("mask_type must be 'A' or 'B', got %r" % (mask_type,))
+        super().__init__(*conv_args, **conv_kwargs)
+        mask = raster_causal_mask(self.weight.shape, masked_channels, centre_visible=(mask_type == 'B'))
+        self.register_buffer('mask', mask.to(self.weight.dtype))
+
+    def reset_parameters(self):       # called by nn.Conv2d.__init__
+        _fanout_normal_(self)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+
+def _pointwise(c_in, c_out):
+    return nn.Conv2d(c_in, c_out, kernel_size=1, bias=False)
+
+
+def _causal(kind, masked, c_in, c_out, k):
+    return MaskedConv2d(kind, masked, c_in, c_out, k, padding=k // 2, bias=False)
+
+
+def _conv_bn_chain(*stages):
+    """stages: (conv, followed_by_elu).  Yields conv, BatchNorm2d[, ELU] per stage -- the Sequential index layout
+    (0,1,2 | 3,4,5 | 6,7) the reference's checkpoints use."""
+    layers = []
+    for conv, elu in stages:
+        layers.append(conv)
+        layers.append(nn.BatchNorm2d(conv.out_channels))
+        if elu:
+            layers.append(nn.ELU())
+    return nn.Sequential(*layers)
 
 
 class PixelCNNBlock(nn.Module):
-    """1x1 (C -> C/2) BN ELU, masked-B kxk (C/2 -> C/2) BN ELU, 1x1 (C/2 -> C) BN, residual, ELU.
-    Parameter container: the arithmetic runs in image_engine.pixelcnn_block."""
+    """Bottleneck residual block: 1x1 (C -> C/2) BN ELU, masked-B kxk (C/2 -> C/2) BN ELU, 1x1 (C/2 -> C) BN, + input,
+    ELU (reference dec_pixelcnn_v2.py:40-74).  Parameter container: the arithmetic is image_engine.pixelcnn_block."""
+    mask_type = 'B'
 
     def __init__(self, in_channels, kernel_size):
-        super(PixelCNNBlock, self).__init__()
-        self.mask_type = 'B'
-        padding = kernel_size // 2
-        out_channels = in_channels // 2
-        self.main = nn.Sequential(
-            nn.Conv2d(in_channels, out_channels, 1, bias=False),
-            nn.BatchNorm2d(out_channels),
-            nn.ELU(),
-            MaskedConv2d(self.mask_type, out_channels, out_channels, out_channels, kernel_size, padding=padding, bias=False),
-            nn.BatchNorm2d(out_channels),
-            nn.ELU(),
-            nn.Conv2d(out_channels, in_channels, 1, bias=False),
-            nn.BatchNorm2d(in_channels),
-        )
+        super().__init__()
+        half = in_channels // 2
+        squeeze = _pointwise(in_channels, half)
+        causal = _causal(self.mask_type, half, half, half, kernel_size)
+        expand = _pointwise(half, in_channels)
+        self.main = _conv_bn_chain((squeeze, True), (causal, True), (expand, False))
         self.activation = nn.ELU()
         self.reset_parameters()
 
     def reset_parameters(self):
-        _he_normal_convs_unit_bn(self)
+        _reinit(self)
 
 
 class MaskABlock(nn.Module):
+    """First layer: masked-A kxk conv that never sees the pixel it predicts, BN, ELU (reference :77-98)."""
+    mask_type = 'A'
+
     def __init__(self, in_channels, out_channels, kernel_size, masked_channels):
-        super(MaskABlock, self).__init__()
-        self.mask_type = 'A'
-        padding = kernel_size // 2
-        self.main = nn.Sequential(
-            MaskedConv2d(self.mask_type, masked_channels, in_channels, out_channels, kernel_size, padding=padding, bias=False),
-            nn.BatchNorm2d(out_channels),
-            nn.ELU(),
-        )
+        super().__init__()
+        self.main = _conv_bn_chain((_causal(self.mask_type, masked_channels, in_channels, out_channels, kernel_size), True))
         self.reset_parameters()
 
     def reset_parameters(self):
-        m = self.main[1]
-        assert isinstance(m, nn.BatchNorm2d)
-        m.weight.data.fill_(1)
-        m.bias.data.zero_()
+        _unit_affine_(self.main[1])
 
 
 class PixelCNN(nn.Module):
-    """A MaskA block followed by PixelCNN blocks, with a 'direct connection' block feeding the output of block i-3
-    into the input of block i (and one more after the last block)."""
+    """MaskA block then PixelCNN blocks; from block 3 on, block i also receives the output of block i-3 passed
+    through a 'direct connection' block, and one more closes the stack (reference :101-146; walked by
+    image_engine.pixelcnn_forward)."""
 
     def __init__(self, in_channels, out_channels, num_blocks, kernel_sizes, masked_channels):
-        super(PixelCNN, self).__init__()
-        assert num_blocks == len(kernel_sizes)
-        self.blocks = []
-        for i in range(num_blocks):
-            if i == 0:
-                block = MaskABlock(in_channels, out_channels, kernel_sizes[i], masked_channels)
-            else:
-                block = PixelCNNBlock(out_channels, kernel_sizes[i])
-            self.blocks.append(block)
-        self.main = nn.ModuleList(self.blocks)
-        self.direct_connects = []
-        for i in range(1, num_blocks - 1):
-            self.direct_connects.append(PixelCNNBlock(out_channels, kernel_sizes[i]))
-        self.direct_connects = nn.ModuleList(self.direct_connects)
+        super().__init__()
+        kernel_sizes = list(kernel_sizes)
+        if num_blocks != len(kernel_sizes):
+            raise ValueError("num_blocks=%d but %d kernel sizes" % (num_blocks, len(kernel_sizes)))
+        stem = MaskABlock(in_channels, out_channels, kernel_sizes[0], masked_channels)
+        self.main = nn.ModuleList([stem] + [PixelCNNBlock(out_channels, k) for k in kernel_sizes[1:]])
+        self.direct_connects = nn.ModuleList([PixelCNNBlock(out_channels, k) for k in kernel_sizes[1:-1]])
+        self.blocks = list(self.main)       # plain-list alias the reference also exposes
 
 
 class _ImageDecoderFn(torch.autograd.Function):
@@ -128,44 +149,37 @@ class _ImageDecoderFn(torch.autograd.Function):
         return (None, None, dz.clone()) + tuple(eng.flat.gviews[n].clone() for n in eng.flat.names)
 
 
+_KERNEL_PLANS = {'small': (7, 7, 7, 5, 5, 3, 3), 'large': (7,) * 5 + (5,) * 4 + (3,) * 4}
+_HIDDEN = 64
+_SIDE = 28
+
+
 class PixelCNNDecoderV2(DecoderBase):
+    """p(x|z) for 28x28 binary images (reference dec_pixelcnn_v2.py:149-232): z -> Linear -> fm_latent feature maps
+    concatenated under the image, gated PixelCNN trunk, 1x1 conv BN ELU 1x1 conv sigmoid."""
+
     def __init__(self, args, ngpu=1, mode='large'):
-        super(PixelCNNDecoderV2, self).__init__()
-        self.ngpu = ngpu
-        self.nz = args.nz
-        self.nc = 1
-        self.fm_latent = args.latent_feature_map
-        self.img_latent = 28 * 28 * self.fm_latent
-        if self.nz != 0:
-            self.z_transform = nn.Sequential(
-                nn.Linear(self.nz, self.img_latent),
-            )
-        if mode == 'small':
-            kernal_sizes = [7, 7, 7, 5, 5, 3, 3]
-        elif mode == 'large':
-            kernal_sizes = [7, 7, 7, 7, 7, 5, 5, 5, 5, 3, 3, 3, 3]
-        else:
+        super().__init__()
+        if mode not in _KERNEL_PLANS:
             raise ValueError('unknown mode: %s' % mode)
-        hidden_channels = 64
-        self.main = nn.Sequential(
-            PixelCNN(self.nc + self.fm_latent, hidden_channels, len(kernal_sizes), kernal_sizes, self.nc),
-            nn.Conv2d(hidden_channels, hidden_channels, 1, bias=False),
-            nn.BatchNorm2d(hidden_channels),
-            nn.ELU(),
-            nn.Conv2d(hidden_channels, self.nc, 1, bias=False),
-            nn.Sigmoid(),
-        )
+        self.ngpu, self.nz, self.nc = ngpu, args.nz, 1
+        self.fm_latent = args.latent_feature_map
+        self.img_latent = _SIDE * _SIDE * self.fm_latent
+        if self.nz != 0:
+            self.z_transform = nn.Sequential(nn.Linear(self.nz, self.img_latent))
+        plan = list(_KERNEL_PLANS[mode])
+        trunk = PixelCNN(self.nc + self.fm_latent, _HIDDEN, len(plan), plan, self.nc)
+        head = [_pointwise(_HIDDEN, _HIDDEN), nn.BatchNorm2d(_HIDDEN), nn.ELU(), _pointwise(_HIDDEN, self.nc), nn.Sigmoid()]
+        self.main = nn.Sequential(trunk, *head)
         self.reset_parameters()
         self._hip = _ie.ImageDecoderEngine(self)
 
     def reset_parameters(self):
         if self.nz != 0:
-            nn.init.xavier_uniform_(self.z_transform[0].weight)
-            nn.init.constant_(self.z_transform[0].bias, 0)
-        m = self.main[2]
-        assert isinstance(m, nn.BatchNorm2d)
-        m.weight.data.fill_(1)
-        m.bias.data.zero_()
+            lin = self.z_transform[0]
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+        _unit_affine_(self.main[2])
 
     def reconstruct_error(self, x, z, masks=None):
         """Binary cross entropy summed over pixels.  x (batch, 1, 28, 28) in {0,1}, z (batch, n_sample, nz)

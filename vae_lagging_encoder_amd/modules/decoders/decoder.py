@@ -1,30 +1,23 @@
-"""Decoder interface of the reference (modules/decoders/decoder.py:5-70)."""
+"""Decoder interface of the reference (modules/decoders/decoder.py:5-70): the method names the VAE wrapper and the
+trainers call.  Training-path methods (`reconstruct_error`, `log_probability`) are implemented by the HIP-backed
+subclasses; the generation methods are declared so a missing one fails with the reference's NotImplementedError."""
 import torch.nn as nn
 
 
+def _unimplemented(name, doc):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError("%s.%s" % (type(self).__name__, name))
+    method.__name__ = name
+    method.__doc__ = doc
+    return method
+
+
 class DecoderBase(nn.Module):
-    """Abstract decoder: subclasses implement reconstruct_error / log_probability (training path) and,
-    optionally, the generation methods."""
+    """Abstract p(x|z)."""
 
-    def __init__(self):
-        super(DecoderBase, self).__init__()
-
-    def decode(self, x, z):
-        raise NotImplementedError
-
-    def reconstruct_error(self, x, z):
-        """x (batch, *), z (batch, n_sample, nz) -> loss (batch, n_sample)."""
-        raise NotImplementedError
-
-    def beam_search_decode(self, z, K):
-        raise NotImplementedError
-
-    def sample_decode(self, z):
-        raise NotImplementedError
-
-    def greedy_decode(self, z):
-        raise NotImplementedError
-
-    def log_probability(self, x, z):
-        """log p(x|z): (batch, n_sample)."""
-        raise NotImplementedError
+    reconstruct_error = _unimplemented("reconstruct_error", "x (batch, *), z (batch, n_sample, nz) -> loss (batch, n_sample)")
+    log_probability = _unimplemented("log_probability", "log p(x|z) -> (batch, n_sample)")
+    decode = _unimplemented("decode", "teacher-forced / ancestral decode of (x, z)")
+    beam_search_decode = _unimplemented("beam_search_decode", "(z, K) -> decoded sentences")
+    greedy_decode = _unimplemented("greedy_decode", "z -> decoded sentences")
+    sample_decode = _unimplemented("sample_decode", "z -> decoded sentences")

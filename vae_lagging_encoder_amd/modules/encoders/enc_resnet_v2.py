@@ -15,55 +15,55 @@ from ... import image_engine as _ie
 from .encoder import GaussianEncoderBase
 
 
+def _conv(c_in, c_out, k, stride=1, pad=0):
+    return nn.Conv2d(c_in, c_out, kernel_size=k, stride=stride, padding=pad, bias=False)
+
+
 def conv3x3(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+    """Public helper name of the reference (enc_resnet_v2.py:9-12)."""
+    return _conv(in_planes, out_planes, 3, stride, 1)
 
 
-def _he_normal_convs_unit_bn(root):
-    """He-normal(fan_out) convolutions, BatchNorm gamma=1 beta=0."""
+def _reinit(root):
+    """He-normal(fan_out) convolutions, BatchNorm gamma=1 beta=0, in registration order so a seeded
+    construction consumes the RNG stream exactly as the reference's does."""
     for m in root.modules():
         if isinstance(m, nn.Conv2d):
-            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-            m.weight.data.normal_(0, math.sqrt(2. / n))
+            kh, kw = m.kernel_size
+            nn.init.normal_(m.weight, mean=0.0, std=math.sqrt(2.0 / (kh * kw * m.out_channels)))
         elif isinstance(m, nn.BatchNorm2d):
-            m.weight.data.fill_(1)
-            m.bias.data.zero_()
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
 
 
 class ResNetBlock(nn.Module):
-    """conv3x3(stride) - BN - ELU - conv3x3 - BN, plus a 1x1(stride) conv + BN shortcut when the shape changes;
-    ELU after the sum.  Parameter container: the arithmetic runs in image_engine.resnet_block."""
+    """conv3x3(stride) BN ELU conv3x3 BN, plus a 1x1(stride) conv + BN shortcut when the shape changes; ELU after
+    the sum (reference enc_resnet_v2.py:27-70).  Parameter container: the arithmetic is image_engine.resnet_block,
+    which reads conv1/bn1/conv2/bn2/downsample/stride."""
 
     def __init__(self, inplanes, planes, stride=1):
-        super(ResNetBlock, self).__init__()
-        self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.activation = nn.ELU()
-        self.conv2 = conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
-        downsample = None
-        if stride != 1 or inplanes != planes:
-            downsample = nn.Sequential(
-                nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes),
-            )
-        self.downsample = downsample
+        super().__init__()
         self.stride = stride
+        self.conv1, self.bn1 = conv3x3(inplanes, planes, stride), nn.BatchNorm2d(planes)
+        self.activation = nn.ELU()
+        self.conv2, self.bn2 = conv3x3(planes, planes), nn.BatchNorm2d(planes)
+        reshapes = (stride != 1) or (inplanes != planes)
+        self.downsample = nn.Sequential(_conv(inplanes, planes, 1, stride), nn.BatchNorm2d(planes)) if reshapes else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        _he_normal_convs_unit_bn(self)
+        _reinit(self)
 
 
 class ResNet(nn.Module):
+    """Chain of ResNetBlocks; `planes[i]` output channels at `strides[i]`."""
+
     def __init__(self, inplanes, planes, strides):
-        super(ResNet, self).__init__()
-        assert len(planes) == len(strides)
-        blocks = []
-        for plane, stride in zip(planes, strides):
-            blocks.append(ResNetBlock(inplanes, plane, stride=stride))
-            inplanes = plane
-        self.main = nn.Sequential(*blocks)
+        super().__init__()
+        if len(planes) != len(strides):
+            raise ValueError("planes and strides differ in length")
+        widths = [inplanes] + list(planes)
+        self.main = nn.Sequential(*[ResNetBlock(widths[i], widths[i + 1], stride=s) for i, s in enumerate(strides)])
 
 
 class _ImageEncoderFn(torch.autograd.Function):
@@ -81,29 +81,26 @@ class _ImageEncoderFn(torch.autograd.Function):
         return (None, None) + tuple(eng.flat.gviews[n].clone() for n in eng.flat.names)
 
 
+_WIDTHS, _STRIDES, _HIDDEN = (64, 64, 64), (2, 2, 2), 512
+
+
 class ResNetEncoderV2(GaussianEncoderBase):
-    """q(z|x) for 1x28x28 images: 3 stride-2 ResNet blocks (1->64->64->64), 4x4 conv -> 512, BN, ELU, Linear -> 2nz."""
+    """q(z|x) for 1x28x28 images (reference enc_resnet_v2.py:84-126): three stride-2 ResNet blocks 28 -> 14 -> 7 -> 4,
+    a 4x4 valid convolution to 512 features, BN, ELU, Linear -> (mu, logvar)."""
 
     def __init__(self, args, ngpu=1):
-        super(ResNetEncoderV2, self).__init__()
-        self.ngpu = ngpu
-        self.nz = args.nz
-        self.nc = 1
-        hidden_units = 512
-        self.main = nn.Sequential(
-            ResNet(self.nc, [64, 64, 64], [2, 2, 2]),
-            nn.Conv2d(64, hidden_units, 4, 1, 0, bias=False),
-            nn.BatchNorm2d(hidden_units),
-            nn.ELU(),
-        )
-        self.linear = nn.Linear(hidden_units, 2 * self.nz)
+        super().__init__()
+        self.ngpu, self.nz, self.nc = ngpu, args.nz, 1
+        trunk = ResNet(self.nc, list(_WIDTHS), list(_STRIDES))
+        self.main = nn.Sequential(trunk, _conv(_WIDTHS[-1], _HIDDEN, 4), nn.BatchNorm2d(_HIDDEN), nn.ELU())
+        self.linear = nn.Linear(_HIDDEN, 2 * self.nz)
         self.reset_parameters()
         self._hip = _ie.ImageEncoderEngine(self)
 
     def reset_parameters(self):
-        _he_normal_convs_unit_bn(self.main)
+        _reinit(self.main)
         nn.init.xavier_uniform_(self.linear.weight)
-        nn.init.constant_(self.linear.bias, 0.0)
+        nn.init.zeros_(self.linear.bias)
 
     def _forward_mulv(self, input):
         self._hip.ensure(input.device)

@@ -1,7 +1,7 @@
 """VAE -- drop-in for the reference's modules/vae.py (normal prior) on MI355X.
 
 `loss`, `encode`, `encode_stats` are the hot-path surface; they compose the HIP-backed
-encoder / reparam+KL / decoder autograd Functions.  The evaluation helpers keep the reference's names and
+encoder / reparam+KL / decoder autograd Functions.  The evaluation helpers keep the reference's method names and
 semantics on top of the same HIP forward (nll_iw, eval_*, calc_mi_q: SURVEY.md 8f "next" rows).
 """
 import math
@@ -11,105 +11,94 @@ import torch.nn as nn
 
 from .utils import log_sum_exp
 
+_GENERATORS = {"beam": "beam_search_decode", "greedy": "greedy_decode", "sample": "sample_decode"}
+
 
 class VAE(nn.Module):
-    """VAE with a standard normal prior."""
+    """Encoder q(z|x), decoder p(x|z), prior N(0, I)."""
 
     def __init__(self, encoder, decoder, args):
-        super(VAE, self).__init__()
-        self.encoder = encoder
-        self.decoder = decoder
-        self.args = args
-        self.nz = args.nz
-        loc = torch.zeros(self.nz, device=args.device)
-        scale = torch.ones(self.nz, device=args.device)
-        self.prior = torch.distributions.normal.Normal(loc, scale)
+        super().__init__()
+        self.encoder, self.decoder = encoder, decoder
+        self.args, self.nz = args, args.nz
+        dev = args.device
+        self.prior = torch.distributions.normal.Normal(torch.zeros(self.nz, device=dev), torch.ones(self.nz, device=dev))
 
+    # ---- training path (reference vae.py:35-98) ---------------------------------------------------------
     def encode(self, x, nsamples=1, eps=None):
-        """-> z (batch, nsamples, nz), KL (batch,)."""
-        if eps is None:
-            return self.encoder.encode(x, nsamples)
-        return self.encoder.encode(x, nsamples, eps=eps)
+        """-> z (batch, nsamples, nz), KL (batch,).  `eps` injects the reparameterisation noise."""
+        extra = {} if eps is None else {"eps": eps}
+        return self.encoder.encode(x, nsamples, **extra)
 
     def encode_stats(self, x):
         """-> mu (batch, nz), logvar (batch, nz)."""
         return self.encoder(x)
 
-    def decode(self, z, strategy, K=5):
-        if strategy == "beam":
-            return self.decoder.beam_search_decode(z, K)
-        elif strategy == "greedy":
-            return self.decoder.greedy_decode(z)
-        elif strategy == "sample":
-            return self.decoder.sample_decode(z)
-        raise ValueError("the decoding strategy is not supported")
-
-    def reconstruct(self, x, decoding_strategy="greedy", K=5):
-        z = self.sample_from_inference(x).squeeze(1)
-        return self.decode(z, decoding_strategy, K)
-
     def loss(self, x, kl_weight, nsamples=1, noise=None):
-        """-> (rec + kl_weight*KL, rec, KL), each (batch,)   (reference vae.py:79-98).
+        """-> (rec + kl_weight*KL, rec, KL), each (batch,).
 
         noise = (eps, mask_in, mask_out) injects the random draws of this call (parity tests); the default draws
         them from torch's device generator at the same three places the reference does."""
-        if noise is None:
-            z, KL = self.encode(x, nsamples)
-            reconstruct_err = self.decoder.reconstruct_error(x, z).mean(dim=1)
-        else:
-            eps, m_in, m_out = noise
-            z, KL = self.encode(x, nsamples, eps=eps)
-            reconstruct_err = self.decoder.reconstruct_error(x, z, masks=(m_in, m_out)).mean(dim=1)
-        return reconstruct_err + kl_weight * KL, reconstruct_err, KL
-
-    def nll_iw(self, x, nsamples, ns=100):
-        """Importance-weighted estimate of -log p(x), `ns` samples at a time -> (batch,)."""
-        tmp = []
-        for _ in range(int(nsamples / ns)):
-            z, param = self.encoder.sample(x, ns)
-            log_comp_ll = self.eval_complete_ll(x, z)
-            log_infer_ll = self.eval_inference_dist(x, z, param)
-            tmp.append(log_comp_ll - log_infer_ll)
-        ll_iw = log_sum_exp(torch.cat(tmp, dim=-1), dim=-1) - math.log(nsamples)
-        return -ll_iw
+        eps, masks = (None, None) if noise is None else (noise[0], (noise[1], noise[2]))
+        z, kl = self.encode(x, nsamples, eps=eps)
+        dec_extra = {} if masks is None else {"masks": masks}
+        rec = self.decoder.reconstruct_error(x, z, **dec_extra).mean(dim=1)
+        return rec + kl_weight * kl, rec, kl
 
     def KL(self, x):
-        _, KL = self.encode(x, 1)
-        return KL
+        return self.encode(x, 1)[1]
 
-    def eval_prior_dist(self, zrange):
-        return self.prior.log_prob(zrange).sum(dim=-1)
+    # ---- generation (delegated; generation itself is outside the hot path) -----------------------------
+    def decode(self, z, strategy, K=5):
+        if strategy not in _GENERATORS:
+            raise ValueError("the decoding strategy is not supported")
+        fn = getattr(self.decoder, _GENERATORS[strategy])
+        return fn(z, K) if strategy == "beam" else fn(z)
 
-    def eval_complete_ll(self, x, z):
-        """log p(z, x) for z (batch, nsamples, nz) -> (batch, nsamples)."""
-        return self.eval_prior_dist(z) + self.eval_cond_ll(x, z)
-
-    def eval_cond_ll(self, x, z):
-        return self.decoder.log_probability(x, z)
-
-    def eval_log_model_posterior(self, x, grid_z):
-        batch_size = x.size(0) if torch.is_tensor(x) else x[0].size(0)
-        grid_z = grid_z.unsqueeze(0).expand(batch_size, *grid_z.size()).contiguous()
-        log_comp = self.eval_complete_ll(x, grid_z)
-        return log_comp - log_sum_exp(log_comp, dim=1, keepdim=True)
+    def reconstruct(self, x, decoding_strategy="greedy", K=5):
+        return self.decode(self.sample_from_inference(x).squeeze(1), decoding_strategy, K)
 
     def sample_from_prior(self, nsamples):
         return self.prior.sample((nsamples,))
 
     def sample_from_inference(self, x, nsamples=1):
-        z, _ = self.encoder.sample(x, nsamples)
-        return z
+        return self.encoder.sample(x, nsamples)[0]
 
-    def calc_model_posterior_mean(self, x, grid_z):
-        posterior = self.eval_log_model_posterior(x, grid_z).exp()
-        return torch.mul(posterior.unsqueeze(2), grid_z.unsqueeze(0)).sum(1)
+    # ---- evaluation (reference vae.py:100-227) -------------------------------------------------------------
+    def nll_iw(self, x, nsamples, ns=100):
+        """Importance-weighted estimate of -log p(x) from `nsamples` draws, `ns` at a time -> (batch,)."""
+        log_w = []
+        for _ in range(int(nsamples / ns)):
+            z, stats = self.encoder.sample(x, ns)
+            log_w.append(self.eval_complete_ll(x, z) - self.eval_inference_dist(x, z, stats))
+        return math.log(nsamples) - log_sum_exp(torch.cat(log_w, dim=-1), dim=-1)
 
-    def calc_infer_mean(self, x):
-        mean, _ = self.encoder.forward(x)
-        return mean
+    def eval_prior_dist(self, zrange):
+        """log N(z; 0, I) summed over the latent dimension."""
+        return self.prior.log_prob(zrange).sum(dim=-1)
+
+    def eval_cond_ll(self, x, z):
+        return self.decoder.log_probability(x, z)
+
+    def eval_complete_ll(self, x, z):
+        """log p(z, x) for z (batch, nsamples, nz) -> (batch, nsamples)."""
+        return self.eval_prior_dist(z) + self.eval_cond_ll(x, z)
 
     def eval_inference_dist(self, x, z, param=None):
         return self.encoder.eval_inference_dist(x, z, param)
+
+    def eval_log_model_posterior(self, x, grid_z):
+        """log p(z|x) on a grid of K points (K, nz) -> (batch, K), normalised over the grid."""
+        n = x.size(0) if torch.is_tensor(x) else x[0].size(0)
+        joint = self.eval_complete_ll(x, grid_z.unsqueeze(0).expand(n, *grid_z.size()).contiguous())
+        return joint - log_sum_exp(joint, dim=1, keepdim=True)
+
+    def calc_model_posterior_mean(self, x, grid_z):
+        w = self.eval_log_model_posterior(x, grid_z).exp()
+        return (w.unsqueeze(2) * grid_z.unsqueeze(0)).sum(1)
+
+    def calc_infer_mean(self, x):
+        return self.encoder.forward(x)[0]
 
     def calc_mi_q(self, x):
         return self.encoder.calc_mi(x)
