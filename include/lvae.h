@@ -41,6 +41,19 @@ int lv_gemm_bf16(int transA, int transB, int M, int N, int K, float alpha,
                  const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
                  float* ws, long ws_floats, void* stream);
 
+/* bf16 matrix pipe over operands that are already bf16 in HBM (raw bits, uint16_t): the vocabulary-sized
+ * contractions of LSTMDecoder (pred_linear forward dec_lstm.py:117 and its two backward products).  B is stored
+ * [N][K]; A is stored [M][K] (transA = 0) or [K][M] (transA = 1); lda % 8 == 0, ldb % 8 == 0, both 16 B-aligned
+ * (else LV_ERR_ALIGN).  Same epilogue / split-K contract as lv_gemm_f32.  Operands
+ * rounded with lv_cvt_bf16_f32 / lv_softmax_nll_bwd_b16 give results bit-identical to lv_gemm_bf16 on the f32 data. */
+int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
+                const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C, long ldc, int accumulate,
+                const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
+                float* ws, long ws_floats, void* stream);
+/* src f32 [R][C](lds) -> dst bf16 [R][C](ldd) and/or dstT bf16 [C][R](ldt), round-to-nearest-even; either may be NULL */
+int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
+                    void* stream);
+
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream);
@@ -96,6 +109,9 @@ int lv_softmax_nll_fwd_f32(const float* logits, long ldl, const int64_t* ids, lo
                            float* lse, float* nll, int T, int B, int V, void* stream);
 int lv_softmax_nll_bwd_f32(float* logits, long ldl, const float* lse, const int64_t* ids, long ids_stride, int tgt_off,
                            const float* rowscale, int T, int B, int V, void* stream);
+/* same gradient written as bf16 into dlogits [T*B][ldo] (pad columns zeroed); logits are left untouched */
+int lv_softmax_nll_bwd_b16(const float* logits, long ldl, const float* lse, const int64_t* ids, long ids_stride, int tgt_off,
+                           const float* rowscale, uint16_t* dlogits, long ldo, int T, int B, int V, void* stream);
 /* VAE.loss assembly (modules/vae.py:95-98): rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight*kl[b] */
 int lv_vae_loss_f32(const float* nll, const float* kl, const float* kl_weight_dev, float* loss, float* rec,
                     int T, int B, void* stream);

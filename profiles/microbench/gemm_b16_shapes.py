@@ -1,0 +1,53 @@
+"""Microbenchmark (measurement tooling): the decoder's three vocabulary-sized GEMMs, lv_gemm_bf16 (f32 operands rounded
+on the fly) vs lv_gemm_b16 (operands pre-rounded to bf16), plus the producers (lv_cvt_bf16_f32, softmax bwd)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from vae_lagging_encoder_amd import _lib
+from vae_lagging_encoder_amd.engine import P, stream_ptr
+dev = torch.device("cuda:0")
+lib = _lib.load()
+B, T, V, H = 32, 200, 20001, 1024
+Td = T - 1
+R = Td * B
+ldl = (V + 31) // 32 * 32
+s = stream_ptr(dev)
+ws = torch.empty(1 << 26, device=dev)
+
+
+def timeit(fn, n=5):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+O = torch.randn(R, H, device=dev)
+W = torch.randn(V, H, device=dev) * 0.05
+dl = torch.randn(R, ldl, device=dev)
+O16 = torch.empty(R, H, dtype=torch.int16, device=dev)
+O16T = torch.empty(H, R, dtype=torch.int16, device=dev)
+W16 = torch.empty(V, H, dtype=torch.int16, device=dev)
+W16T = torch.empty(H, ldl, dtype=torch.int16, device=dev)
+dl16 = dl.to(torch.bfloat16).view(torch.int16).contiguous()
+logits = torch.empty(R, ldl, device=dev)
+dO = torch.empty(R, H, device=dev)
+dW = torch.empty(V, H, device=dev)
+GF = 2.0 * R * V * H
+print("cvt O  (+T): %7.1f us" % timeit(lambda: lib.lv_cvt_bf16_f32(P(O), H, R, H, P(O16), H, P(O16T), R, s)))
+print("cvt Wp (+T): %7.1f us" % timeit(lambda: lib.lv_cvt_bf16_f32(P(W), H, V, H, P(W16), H, P(W16T), ldl, s)))
+rows = [
+    ("logits", lambda: lib.lv_gemm_bf16(0, 1, R, V, H, 1.0, P(O), H, P(W), H, P(logits), ldl, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s),
+     lambda: lib.lv_gemm_b16(0, R, V, H, 1.0, P(O16), H, P(W16), H, P(logits), ldl, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)),
+    ("dO", lambda: lib.lv_gemm_bf16(0, 0, R, H, V, 1.0, P(dl), ldl, P(W), H, P(dO), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s),
+     lambda: lib.lv_gemm_b16(0, R, H, V, 1.0, P(dl16), ldl, P(W16T), ldl, P(dO), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)),
+    ("dW_pred", lambda: lib.lv_gemm_bf16(1, 0, V, H, R, 1.0, P(dl), ldl, P(O), H, P(dW), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s),
+     lambda: lib.lv_gemm_b16(1, V, H, R, 1.0, P(dl16), ldl, P(O16T), R, P(dW), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)),
+]
+for name, f_old, f_new in rows:
+    a, b = timeit(f_old), timeit(f_new)
+    print("%-8s on-the-fly %7.1f us %6.1f TF | pre-rounded %7.1f us %6.1f TF" % (name, a, GF / a / 1e6, b, GF / b / 1e6))

@@ -31,3 +31,7 @@ def test_fused_trainer_trajectory_emulated(emu_backend):
 def test_inner_loop_exit_logic_emulated(emu_backend):
     steps = pc.check_inner_loop_exit_logic("cpu", window=2, max_iter=4)
     assert 1 <= steps < 4
+
+
+def test_bf16_native_operands_equal_on_the_fly_emulated(emu_backend):
+    pc.check_bf16_native_operands_equal_on_the_fly("cpu", V=133, ni=16, H=24, nz=4, B=5, T=6)

@@ -20,6 +20,21 @@ def test_gemm_bf16(emu_backend, tA, tB, M, N, K_):
     K.test_gemm_bf16(emu_backend, CPU, tA, tB, M, N, K_)
 
 
+@pytest.mark.parametrize("cfg", [(0, 130, 140, 37, False), (1, 70, 130, 50, False), (0, 1, 1, 1, False), (1, 129, 64, 200, False),
+                                 (0, 65, 40, 1000, True), (1, 131, 30, 1100, True)])
+def test_gemm_b16(emu_backend, cfg):
+    K.test_gemm_b16(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("R,C", [(1, 1), (64, 64), (70, 130), (200, 33)])
+def test_cvt_bf16(emu_backend, R, C):
+    K.test_cvt_bf16(emu_backend, CPU, R, C)
+
+
+def test_gemm_b16_alignment(emu_backend):
+    K.test_gemm_b16_alignment_errors(emu_backend, CPU)
+
+
 def test_gemm_unaligned(emu_backend):
     K.test_gemm_unaligned_rows(emu_backend, CPU)
 

@@ -77,6 +77,75 @@ def test_gemm_bf16(lib, hip_device, tA, tB, M, N, K):
     assert float((out[:, :N].double() - ref_exact).abs().max()) < 2e-2 * (K ** 0.5 + 1)
 
 
+def _bf16_bits(x):
+    """f32 tensor -> int16 tensor holding the RNE bf16 bit patterns (what lv_cvt_bf16_f32 produces)."""
+    return x.to(torch.bfloat16).view(torch.int16)
+
+
+@pytest.mark.parametrize("R,C", [(1, 1), (64, 64), (70, 130), (200, 33), (641, 1024)])
+def test_cvt_bf16(lib, hip_device, R, C):
+    g = torch.Generator().manual_seed(R * 5 + C)
+    lds, ldd, ldt = C + 3, C + 5, R + 7
+    src = torch.randn(R, lds, generator=g)
+    src[0, 0] = 1.00390625            # exact tie between two bf16 values: RNE picks the even mantissa (1.0)
+    d = torch.full((R, ldd), 0x1234, dtype=torch.int16)
+    dT = torch.full((C, ldt), 0x1234, dtype=torch.int16)
+    sd, dd, dTd = src.to(hip_device), d.to(hip_device), dT.to(hip_device)
+    lib.lv_cvt_bf16_f32(P(sd), lds, R, C, P(dd), ldd, P(dTd), ldt, _s(hip_device))
+    want = _bf16_bits(src[:, :C])
+    assert torch.equal(dd.cpu()[:, :C], want)
+    assert torch.equal(dTd.cpu()[:, :R], want.t())
+    assert bool((dd.cpu()[:, C:] == 0x1234).all()) and bool((dTd.cpu()[:, R:] == 0x1234).all())   # padding untouched
+    only_t = torch.zeros(C, ldt, dtype=torch.int16, device=hip_device)
+    lib.lv_cvt_bf16_f32(P(sd), lds, R, C, None, 0, P(only_t), ldt, _s(hip_device))
+    assert torch.equal(only_t.cpu()[:, :R], want.t())
+
+
+@pytest.mark.parametrize("tA,M,N,K,split", [
+    (0, 130, 140, 37, False), (1, 70, 130, 50, False), (0, 1, 1, 1, False), (1, 33, 17, 20, False), (1, 129, 64, 200, False),
+    (0, 257, 129, 1000, True), (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False),
+    (0, 3000, 2100, 512, False), (1, 1100, 1200, 2300, True),
+])
+def test_gemm_b16(lib, hip_device, tA, M, N, K, split):
+    """Pre-rounded bf16 operands: bit-identical to lv_gemm_bf16 on the f32 data when neither splits K (same MFMA
+    chain), f32-accumulate-class agreement with a float64 product of the rounded operands always."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 2)
+    lda = ((M + 7) // 8) * 8 + 8 if tA else ((K + 7) // 8) * 8 + 8
+    ldb = ((K + 7) // 8) * 8
+    A = torch.randn(K if tA else M, lda, generator=g)
+    B = torch.randn(N, ldb, generator=g)
+    A[:, (M if tA else K):] = float("nan")          # row padding may be read but must never reach the result
+    B[:, K:] = float("nan")
+    C0 = torch.randn(M, N + 3, generator=g)
+    add1 = torch.randn(5, N, generator=g)
+    rb = lambda x: x.to(torch.bfloat16).double()
+    Aop = (A[:, :M].t() if tA else A[:, :K])
+    Bop = B[:, :K].t()
+    ref = 0.5 * (rb(Aop) @ rb(Bop)) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
+    A16, B16 = _bf16_bits(A).to(hip_device), _bf16_bits(B).to(hip_device)
+    Ad, Bd, a1 = A.to(hip_device), B.to(hip_device), add1.to(hip_device)
+    C1, C2 = C0.clone().to(hip_device), C0.clone().to(hip_device)
+    ws = torch.empty(1 << 24, device=hip_device) if split else None
+    wsp, wsn = (P(ws), ws.numel()) if split else (None, 0)
+    lib.lv_gemm_b16(tA, M, N, K, 0.5, P(A16), lda, P(B16), ldb, P(C1), N + 3, 1, P(a1), N, 5, None, 0, 1, wsp, wsn, _s(hip_device))
+    out = C1.cpu()
+    assert torch.equal(out[:, N:], C0[:, N:])
+    assert float((out[:, :N].double() - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 8
+    if not split:
+        lib.lv_gemm_bf16(tA, 1, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(C2), N + 3, 1, P(a1), N, 5, None, 0, 1, None, 0,
+                         _s(hip_device))
+        assert torch.equal(out, C2.cpu())
+
+
+def test_gemm_b16_alignment_errors(lib, hip_device):
+    z = torch.zeros(64, 64, dtype=torch.int16, device=hip_device)
+    c = torch.zeros(8, 8, device=hip_device)
+    with pytest.raises(_lib.LvaeError):
+        lib.lv_gemm_b16(0, 8, 8, 8, 1.0, P(z), 12, P(z), 8, P(c), 8, 0, None, 0, 1, None, 0, 1, None, 0, _s(hip_device))
+    with pytest.raises(_lib.LvaeError):
+        lib.lv_gemm_b16(1, 8, 8, 8, 1.0, P(z), 10, P(z), 8, P(c), 8, 0, None, 0, 1, None, 0, 1, None, 0, _s(hip_device))
+
+
 def test_gemm_unaligned_rows(lib, hip_device):
     # ld % 4 != 0 and odd base offset: scalar load path (toy config has ni + nz = 51)
     g = torch.Generator().manual_seed(5)
@@ -255,8 +324,16 @@ def test_softmax_nll(lib, hip_device, T, B, V):
     p = torch.softmax(l64, -1)
     p[torch.arange(T * B), tgt] -= 1
     ref = p * rs.double()[torch.arange(T * B, device=dev) % B].unsqueeze(1)
+    # bf16 image of the same gradient: must equal the RNE rounding of the f32 kernel's output, padding zeroed
+    ld16 = ldl + 8
+    d16 = torch.full((T * B, ld16), 0x7FC0, dtype=torch.int16, device=dev)
+    keep = logits.clone()
+    lib.lv_softmax_nll_bwd_b16(P(logits), ldl, P(lse), P(ids), T + 1, 1, P(rs), P(d16), ld16, T, B, V, _s(dev))
+    assert torch.equal(logits, keep)
     lib.lv_softmax_nll_bwd_f32(P(logits), ldl, P(lse), P(ids), T + 1, 1, P(rs), T, B, V, _s(dev))
     assert float((logits[:, :V].double() - ref).abs().max()) < 2e-6
+    assert torch.equal(d16[:, :V].cpu(), logits[:, :V].cpu().to(torch.bfloat16).view(torch.int16))
+    assert bool((d16[:, V:] == 0).all())
     kl2 = torch.full((B,), 2.0, device=dev)
     w = torch.tensor([0.25], device=dev)
     loss = torch.empty(B, device=dev)

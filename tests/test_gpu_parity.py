@@ -66,6 +66,11 @@ def test_bf16_throughput_path_tracks_oracle(hip_device):
     assert out["grads"] < 5e-2, out
 
 
+def test_bf16_native_operands_equal_on_the_fly(hip_device):
+    pc.check_bf16_native_operands_equal_on_the_fly(hip_device)
+    pc.check_bf16_native_operands_equal_on_the_fly(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30)
+
+
 def test_yelp_full_size_fixture(hip_device):
     """BASELINE.json configs[1] shape (B=32, T=100, V=19997, ni=512, H=1024, nz=32): weights regenerated from the
     reference seed through the same nn.Module construction order, outputs from the reference run."""

@@ -21,6 +21,8 @@ _u64 = ctypes.c_uint64
 SIGNATURES = {
     "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_cvt_bf16_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_transpose_ld_f32": [_vp, _l, _vp, _l, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],
@@ -36,6 +38,7 @@ SIGNATURES = {
     "lv_reparam_kl_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_softmax_nll_fwd_f32": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp],
     "lv_softmax_nll_bwd_f32": [_vp, _l, _vp, _vp, _l, _i, _vp, _i, _i, _i, _vp],
+    "lv_softmax_nll_bwd_b16": [_vp, _l, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_vae_loss_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "lv_loss_bwd_scales_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "lv_tanh_f32": [_vp, _vp, _l, _vp],

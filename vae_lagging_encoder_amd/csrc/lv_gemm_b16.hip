@@ -1,0 +1,322 @@
+// lv_gemm_b16.hip -- bf16-MFMA GEMM over operands that are ALREADY bf16 in HBM (f32 accumulate, f32 output).
+//
+// The three vocabulary-sized contractions of the decoder (logits = O.Wp^T, dO = dlogits.Wp, dWp = dlogits^T.O;
+// reference modules/decoders/dec_lstm.py:117,140-146 and their autograd) are L2->LDS-traffic- and latency-bound in
+// lv_gemm_bf16 (f32 sources: 32 KB of loads per 128x128x32 step, 5 integer ops per element to round).  Here the
+// producers hand over bf16 images -- lv_cvt_bf16_f32 for the small operands (O, Wp and their transposes),
+// lv_softmax_nll_bwd_b16 for dlogits -- with exactly the rounding lv_gemm_bf16 applies on the fly (RNE), so the
+// two routes give bit-identical results while this one moves half the bytes, converts nothing, and takes K in
+// steps of 64 (16 MFMAs per wave between a tile's loads and its LDS store).
+//
+// C[M,N] = alpha * A . B^T-form (+ epilogue), B stored [N][K] (K-contiguous) always;
+// A stored [M][K] (transA = 0) or [K][M] (transA = 1: the weight gradient reads dlogits as it lies).
+//
+// Tile 128x128x64, 4 waves 2x2, wave tile 64x64 = 2x2 v_mfma_f32_32x32x16_bf16.  LDS image S[c][row ^ 2c] = 8
+// consecutive-k bf16 of one row (16 B), chunk c of 8, pitch 128 rows: 2 operands x 2 buffers = 64 KB, 2 WG/CU.
+// The XOR keeps the K-contiguous staging write (16 lanes = 8 chunks x 2 rows -> 64 distinct banks) and the fragment
+// read (16 lanes = 16 consecutive rows of one chunk) conflict-free without padding.  For A stored [K][M] a thread
+// loads 16 B (eight adjacent rows at one k) for 4 consecutive k and transposes the 8x4 block in registers (16 integer
+// ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
+// consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
+#include "lv_device.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int BT = 128;
+constexpr int NCH = BK / 8;
+
+struct GemmQ {
+    const uint16_t* A; const uint16_t* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    float alpha;
+    int accumulate;
+    const float* add1; long ld1; int mod1;
+    const float* add2; long ld2; int mod2;
+    int tilesM, tilesN;
+    int splits, kt_per_split;
+    float* ws;
+};
+
+__device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int valid) {
+    if (valid >= 8) return *reinterpret_cast<const uint4*>(p);
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = e < valid ? (uint32_t)p[e] : 0u;
+    uint4 q;
+    q.x = h[0] | (h[1] << 16); q.y = h[2] | (h[3] << 16); q.z = h[4] | (h[5] << 16); q.w = h[6] | (h[7] << 16);
+    return q;
+}
+
+// K-contiguous operand ([rows][K]): unit = (row m = f>>3, chunk c = f&7), one 16 B load; 8 lanes cover a row's 128 B.
+__device__ __forceinline__ void load_kc(const uint16_t* __restrict__ P, long ld, int rows, int K, int r0, int k0, int t,
+                                        uint4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i;
+        const int m = f >> 3, c = f & 7;
+        const long row = r0 + m;
+        const int k = k0 + 8 * c;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (row < rows && k < K) q = load_chunk(P + row * ld + k, K - k);
+        reg[i] = q;
+    }
+}
+
+__device__ __forceinline__ void store_kc(uint4 (*S)[BT], int t, const uint4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i;
+        const int m = f >> 3, c = f & 7;
+        S[c][m ^ (2 * c)] = reg[i];
+    }
+}
+
+// rows-contiguous operand ([K][rows]): one unit per thread = (row octet m8 = t&15 -> rows 8*m8 .. 8*m8+7; k-quad
+// kq = t>>4), four 16 B loads (k .. k+3; a wave-level load = 4 k-rows x 256 contiguous bytes), transposed in registers
+// into the 8 rows' k-quads.  Rows past `rows` may hold anything: an A row only ever reaches the C row of the same index.
+__device__ __forceinline__ void load_mc(const uint16_t* __restrict__ P, long ld, int rows, int K, int r0, int k0, int t,
+                                        uint4 (&reg)[4]) {
+    const int m8 = t & 15, kq = t >> 4;
+    const long col = r0 + 8 * m8;
+    const int k = k0 + 4 * kq;
+    uint4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        d[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (col < rows && k + j < K) d[j] = *reinterpret_cast<const uint4*>(P + (long)(k + j) * ld + col);
+    }
+    const uint32_t w[4][4] = {{d[0].x, d[1].x, d[2].x, d[3].x}, {d[0].y, d[1].y, d[2].y, d[3].y},
+                              {d[0].z, d[1].z, d[2].z, d[3].z}, {d[0].w, d[1].w, d[2].w, d[3].w}};
+    uint32_t o[16];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {                                    // row pair (2*pr, 2*pr+1) of the octet
+        o[4 * pr + 0] = (w[pr][0] & 0xFFFFu) | (w[pr][1] << 16);        // even row: k, k+1
+        o[4 * pr + 1] = (w[pr][2] & 0xFFFFu) | (w[pr][3] << 16);        //           k+2, k+3
+        o[4 * pr + 2] = (w[pr][0] >> 16) | (w[pr][1] & 0xFFFF0000u);    // odd row : k, k+1
+        o[4 * pr + 3] = (w[pr][2] >> 16) | (w[pr][3] & 0xFFFF0000u);    //           k+2, k+3
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reg[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
+// Row e of octet m8 lives in LDS row e*16 + m8, so that for each e the 16 lanes of an octet group write 16 consecutive
+// LDS rows; the epilogue maps LDS row rho back to tile row 8*(rho & 15) + (rho >> 4).
+__device__ __forceinline__ void store_mc(uint4 (*S)[BT], int t, const uint4 (&reg)[4]) {
+    const int m8 = t & 15, kq = t >> 4;
+    const int c = kq >> 1, half = kq & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2* even = reinterpret_cast<uint2*>(&S[c][((2 * i) * 16 + m8) ^ (2 * c)]) + half;
+        uint2* odd = reinterpret_cast<uint2*>(&S[c][((2 * i + 1) * 16 + m8) ^ (2 * c)]) + half;
+        *even = make_uint2(reg[i].x, reg[i].y);
+        *odd = make_uint2(reg[i].z, reg[i].w);
+    }
+}
+
+template <bool A_KC>
+__global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
+    __shared__ __attribute__((aligned(16))) uint4 As[2][NCH][BT];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2][NCH][BT];
+
+    // XCD-aware bijective remap + grouped (8 tile-rows) ordering, as in lv_gemm_f32 / lv_gemm_bf16
+    const int nblk = p.tilesM * p.tilesN;
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid % 8, q = nblk / 8, r = nblk % 8;
+    const int s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const int G = 8;
+    const int nig = G * p.tilesN;
+    const int group = s / nig;
+    const int first_m = group * G;
+    const int gsz = (p.tilesM - first_m) < G ? (p.tilesM - first_m) : G;
+    const int tm = first_m + (s % nig) % gsz;
+    const int tn = (s % nig) / gsz;
+    const int m0 = tm * BT, n0 = tn * BT;
+
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = l & 31, lh = l >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[4], rb[4];
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)blockIdx.y * p.kt_per_split;
+    int kt1 = kt0 + p.kt_per_split;
+    if (kt1 > nk_all) kt1 = nk_all;
+
+    if (A_KC) load_kc(p.A, p.lda, p.M, p.K, m0, kt0 * BK, t, ra);
+    else load_mc(p.A, p.lda, p.M, p.K, m0, kt0 * BK, t, ra);
+    load_kc(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, t, rb);
+    if (A_KC) store_kc(As[0], t, ra);
+    else store_mc(As[0], t, ra);
+    store_kc(Bs[0], t, rb);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            if (A_KC) load_kc(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, t, ra);
+            else load_mc(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, t, ra);
+            load_kc(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, t, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = 2 * ks + lh;
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[buf][c][(wm * 64 + i * 32 + li) ^ (2 * c)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][c][(wn * 64 + j * 32 + li) ^ (2 * c)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < kt1) {
+            if (A_KC) store_kc(As[buf ^ 1], t, ra);
+            else store_mc(As[buf ^ 1], t, ra);
+            store_kc(Bs[buf ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+
+    const bool split = p.splits > 1;
+    float* const out = split ? p.ws + (long)blockIdx.y * p.M * p.N : p.C;
+    const long ldo = split ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (l & 31);
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);   // row within the wave's 64
+                const int rho = wm * 64 + rr;                                    // LDS row of this accumulator row
+                const int row = m0 + (A_KC ? rho : 8 * (rho & 15) + (rho >> 4));
+                if (row >= p.M) continue;
+                float* c = out + (long)row * ldo + col;
+                if (split) { *c = acc[i][j][e]; continue; }
+                float v = p.alpha * acc[i][j][e];
+                if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+                if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+                if (p.accumulate) v += *c;
+                *c = v;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long MN = (long)p.M * p.N;
+    if (idx >= MN) return;
+    const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += p.ws[(long)k * MN + idx];
+    float v = p.alpha * s;
+    if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+    if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+    float* c = p.C + (long)row * p.ldc + col;
+    if (p.accumulate) v += *c;
+    *c = v;
+}
+
+// f32 [R][C] -> bf16 [R][C] (dst) and/or bf16 [C][R] (dstT), RNE; 64x64 tiles, every global access a full row
+// segment (256 B reads, 128 B writes); the transposed copy goes through a pitch-66 LDS tile (bank stride 33).
+__global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ src, long lds_, int R, int C,
+                                                      uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt) {
+    __shared__ uint16_t tile[64][66];
+    const int t = (int)threadIdx.x;
+    const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
+    const int lane = t & 63, q = t >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = q + 4 * i;
+        const long gr = r0 + r, gc = c0 + lane;
+        uint16_t b = 0;
+        if (gr < R && gc < C) {
+            b = (uint16_t)lv_f32_to_bf16_bits(src[gr * lds_ + gc]);
+            if (dst) dst[gr * ldd + gc] = b;
+        }
+        tile[r][lane] = b;
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int c = q + 4 * i;
+        const long gc = c0 + c, gr = r0 + lane;
+        if (gc < C && gr < R) dstT[gc * ldt + gr] = tile[lane][c];
+    }
+}
+
+}  // namespace
+
+// C[M,N] = alpha * op(A) . B^T (+ add1 + add2 (+ C)), bf16 operands, f32 accumulate/output.
+// A: transA == 0 -> stored [M][K] (lda >= K); transA == 1 -> stored [K][M] (lda >= M).  B: stored [N][K] (ldb >= K).
+// All leading dimensions % 8 == 0 and bases 16 B-aligned (else LV_ERR_ALIGN).  Rows may be read up to the next
+// multiple of 8 elements past their logical end (never past ld); what lies there never reaches C.
+extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
+                           const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                           float* C, long ldc, int accumulate,
+                           const float* add1, long ld1, int mod1,
+                           const float* add2, long ld2, int mod2,
+                           float* ws, long ws_floats, void* stream) {
+    if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
+    if (M == 0 || N == 0) return LV_OK;
+    if (!A || !B || !C) return LV_ERR_ARG;
+    if ((add1 && mod1 <= 0) || (add2 && mod2 <= 0)) return LV_ERR_ARG;
+    if (lda < (transA ? M : K) || ldb < K || ldc < N) return LV_ERR_SHAPE;
+    if (ldb % 8 != 0 || (((uintptr_t)B) & 15) != 0) return LV_ERR_ALIGN;
+    if (lda % 8 != 0 || (((uintptr_t)A) & 15) != 0) return LV_ERR_ALIGN;
+    GemmQ p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.accumulate = accumulate;
+    p.add1 = add1; p.ld1 = ld1; p.mod1 = mod1 > 0 ? mod1 : 1;
+    p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
+    p.ws = ws;
+    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
+    const int nk = lv_cdiv(K > 0 ? K : 1, BK);
+    const long tiles = (long)p.tilesM * p.tilesN;
+    // split-K (deterministic: partial slabs + ordered reduce) when the tile count alone cannot fill 256 CUs x 2
+    int splits = 1;
+    if (ws && tiles < 512 && nk >= 8) {
+        long sp = lv_cdiv(1024, tiles);
+        if (sp > nk / 4) sp = nk / 4;
+        if (sp > 64) sp = 64;
+        const long cap = ws_floats / ((long)M * N);
+        if (sp > cap) sp = cap;
+        if (sp > 1) splits = (int)sp;
+    }
+    p.kt_per_split = lv_cdiv(nk, splits);
+    splits = lv_cdiv(nk, p.kt_per_split);
+    p.splits = splits;
+    dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+    if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
+    else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
+    if (splits > 1)
+        LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// src f32 [R][C] (lds) -> dst bf16 [R][C] (ldd) and/or dstT bf16 [C][R] (ldt); either destination may be null.
+extern "C" int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
+                               void* stream) {
+    if (!src || (!dst && !dstT)) return LV_ERR_ARG;
+    if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
+    if (R == 0 || C == 0) return LV_OK;
+    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+              dst, ldd, dstT, ldt);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

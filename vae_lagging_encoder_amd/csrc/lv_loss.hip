@@ -138,6 +138,41 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_kernel(float* __restrict_
     }
 }
 
+// Same gradient, written as bf16 (RNE) into a separate image for lv_gemm_b16; the f32 logits are left untouched.
+// Rounding here is the rounding lv_gemm_bf16 applies to the f32 dlogits on the fly, so both routes agree bit for bit.
+__global__ __launch_bounds__(256) void softmax_nll_bwd_b16_kernel(const float* __restrict__ logits, long ldl,
+                                                                  const float* __restrict__ lse, const int64_t* __restrict__ ids,
+                                                                  long ids_stride, int tgt_off, const float* __restrict__ rowscale,
+                                                                  uint16_t* __restrict__ out, long ldo, int T, int B, int V) {
+    const int r = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const float* row = logits + (long)r * ldl;
+    uint16_t* orow = out + (long)r * ldo;
+    const int t = r / B, b = r % B;
+    long tg = ids[(long)b * ids_stride + t + tgt_off];
+    if (tg < 0) tg = 0;
+    if (tg >= V) tg = V - 1;
+    const float L = lse[r], sc = rowscale[b];
+    const bool vec = (ldl % 4 == 0) && ((((uintptr_t)logits) & 15) == 0) && (ldo % 4 == 0) && ((((uintptr_t)out) & 7) == 0);
+    const int itg = (int)tg;
+    int done = 0;
+    if (vec) {
+        const int V4 = V & ~3;
+        for (int k = tid * 4; k < V4; k += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            const float g0 = (expf(v.x - L) - (k == itg ? 1.f : 0.f)) * sc;
+            const float g1 = (expf(v.y - L) - (k + 1 == itg ? 1.f : 0.f)) * sc;
+            const float g2 = (expf(v.z - L) - (k + 2 == itg ? 1.f : 0.f)) * sc;
+            const float g3 = (expf(v.w - L) - (k + 3 == itg ? 1.f : 0.f)) * sc;
+            *reinterpret_cast<uint2*>(orow + k) = make_uint2(lv_pack_bf16x2(g0, g1), lv_pack_bf16x2(g2, g3));
+        }
+        done = V4;
+    }
+    for (int k = done + tid; k < V; k += 256)
+        orow[k] = (uint16_t)lv_f32_to_bf16_bits((expf(row[k] - L) - (k == itg ? 1.f : 0.f)) * sc);
+    for (long k = V + tid; k < ldo; k += 256) orow[k] = 0;      // keep the row padding finite (zero)
+}
+
 // rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight * kl[b]
 __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
                                                        const float* __restrict__ klw, float* __restrict__ loss,
@@ -227,6 +262,18 @@ extern "C" int lv_softmax_nll_bwd_f32(float* logits, long ldl, const float* lse,
     if (T == 0) return LV_OK;
     LV_LAUNCH(softmax_nll_bwd_kernel, dim3((unsigned)(T * B)), dim3(256), 0, stream, logits, ldl, lse, ids, ids_stride,
               tgt_off, rowscale, T, B, V);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_softmax_nll_bwd_b16(const float* logits, long ldl, const float* lse, const int64_t* ids, long ids_stride,
+                                      int tgt_off, const float* rowscale, uint16_t* dlogits, long ldo, int T, int B, int V,
+                                      void* stream) {
+    if (!logits || !ids || !lse || !rowscale || !dlogits) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || V <= 0 || ldl < V || ldo < V) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(softmax_nll_bwd_b16_kernel, dim3((unsigned)(T * B)), dim3(256), 0, stream, logits, ldl, lse, ids, ids_stride,
+              tgt_off, rowscale, dlogits, ldo, T, B, V);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

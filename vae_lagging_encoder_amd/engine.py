@@ -107,6 +107,9 @@ class _WS(object):
     def f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
+    def i16(self, *shape):
+        return torch.empty(*shape, dtype=torch.int16, device=self.device)
+
     def i32(self, *shape):
         return torch.empty(*shape, dtype=torch.int32, device=self.device)
 
@@ -158,6 +161,15 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
     fn = lib.lv_gemm_bf16 if prec == "bf16" else lib.lv_gemm_f32
     with _prof("gemm_" + prec, 2.0 * M * N * K):
         fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
+
+
+def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, ws=None):
+    """C = op(A) . B^T with operands already rounded to bf16 in HBM (lv_gemm_b16): B stored [N][K]; A stored [M][K]
+    (tA = 0) or [K][M] (tA = 1).  Bit-identical to _gemm(prec='bf16') on the f32 data, at half the operand bytes."""
+    if ws is None:
+        ws = _gemm_ws(lib, s)
+    with _prof("gemm_bf16", 2.0 * M * N * K):
+        lib.lv_gemm_b16(tA, M, N, K, 1.0, A16, lda, B16, ldb, C, ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
 
 
 def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, scratch, ws=None):
@@ -302,6 +314,7 @@ class LSTMDecoderEngine(object):
         # dW_hh / embedding scatter under the encoder's backward).  join() orders them before anything reads the grads.
         self.overlap = None       # None = auto: on for the f32 path, off for bf16 (measured: with the short bf16 GEMMs the
         #                           interference on the latency-critical step kernels costs more than the overlap saves)
+        self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
         self._side = None
         self._side_ws = None
         self._pending = None
@@ -390,6 +403,26 @@ class LSTMDecoderEngine(object):
             return w
         return c.get((Bd, Td), build)
 
+    def _b16(self, Bd, Td):
+        """bf16 images of the vocabulary-sized GEMMs' operands (throughput path), or None when the shapes do not meet
+        lv_gemm_b16's 16-byte row alignment (then lv_gemm_bf16 rounds the f32 operands on the fly)."""
+        V, ni, H, nz = self.dims()
+        if self.precision != "bf16" or not self.native16 or H % 8 != 0:
+            return None
+        c = self.wsc
+
+        def build():
+            b = _NS()
+            b.ldr = _round_up(Td * Bd, 8)
+            b.ldv = _round_up(V, 32)
+            b.O = c.i16(Td * Bd, H)           # dropout(h_t) rows      [T*B][H]
+            b.OT = c.i16(H, b.ldr)            # ... transposed         [H][T*B]
+            b.W = c.i16(V, H)                 # pred_linear.weight     [V][H]
+            b.WT = c.i16(H, b.ldv)            # ... transposed         [H][V]
+            b.dl = c.i16(Td * Bd, b.ldv)      # dlogits                [T*B][V]
+            return b
+        return c.get(("b16", Bd, Td), build)
+
     def forward(self, x, z, mask_in, mask_out, p_in, p_out):
         """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
         batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B]."""
@@ -425,7 +458,13 @@ class LSTMDecoderEngine(object):
             (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
                 P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
                 P(w.O), P(w.lstm_ws), Td, B, H, s)
-        _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
+        b16 = self._b16(B, Td)
+        if b16 is not None:
+            lib.lv_cvt_bf16_f32(P(w.O), H, Td * B, H, P(b16.O), H, P(b16.OT), b16.ldr, s)
+            lib.lv_cvt_bf16_f32(P(v["pred_linear.weight"]), H, V, H, P(b16.W), H, P(b16.WT), b16.ldv, s)
+            _gemm16(lib, s, 0, Td * B, V, H, P(b16.O), H, P(b16.W), H, P(w.logits), w.ldl)
+        else:
+            _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
         lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
         # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
         lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
@@ -449,13 +488,24 @@ class LSTMDecoderEngine(object):
         wih = v["lstm.weight_ih_l0"]
         gwih = gv["lstm.weight_ih_l0"]
         dev = x.device
-        lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
+        b16 = self._b16(B, Td)
+        sc = lambda n, slot: self._scratch(n, slot, dev)
+        if b16 is not None:
+            lib.lv_softmax_nll_bwd_b16(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), P(b16.dl), b16.ldv, Td, B, V, s)
+        else:
+            lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
         ctx, sws = self._fork(dev)                    # side: dW_pred = dlogits^T . O (only needs dlogits and O)
         with ctx:
-            sc = lambda n, slot: self._scratch(n, slot, dev)
-            _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
-                   self.precision, sc, ws=sws)
-        _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
+            if b16 is not None:
+                _gemm16(lib, stream_ptr(dev), 1, V, H, Td * B, P(b16.dl), b16.ldv, P(b16.OT), b16.ldr,
+                        P(gv["pred_linear.weight"]), H, ws=sws)
+            else:
+                _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
+                       self.precision, sc, ws=sws)
+        if b16 is not None:
+            _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(b16.WT), b16.ldv, P(w.dO), H)
+        else:
+            _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         with _prof("lstm_bwd", 0.0, 2 * Td):
             (lib.lv_lstm_bwd_bf16 if self.precision == "bf16" else lib.lv_lstm_bwd_f32)(
                 P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
