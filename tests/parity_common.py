@@ -246,16 +246,17 @@ def check_bf16_native_operands_equal_on_the_fly(device, V=333, ni=24, H=64, nz=8
     for native in (True, False):
         vae = build_vae(V, ni, H, nz, device, params=P)
         tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
-        tr.dec.native16 = native
+        tr.dec.native16 = tr.enc.native16 = native
         tr.step(x.to(device), 0.6, noise=noise)
         st = tr.read_stats()
         grads = {k: p.grad.detach().cpu().clone() for k, p in vae.named_parameters()}
-        res.append((st, grads, (tr.dec._b16(B, T - 1) is not None)))
+        res.append((st, grads, (tr.dec._b16(B, T - 1) is not None and tr.dec._lstm_images(B, T - 1) is not None
+                                and tr.enc._b16(B, T) is not None)))
     (s1, g1, used1), (s0, g0, used0) = res
     assert used1 and not used0
-    # forward: identical MFMA chains (no split-K in the logits GEMM) -> identical statistics
+    # forward: the same rounded operands through the same MFMA chains, up to where split-K cuts the input projections
     for k in ("loss_sum", "rec_sum", "kl_sum"):
-        assert abs(s1[k] - s0[k]) <= 2e-6 * abs(s0[k]), (k, s1[k], s0[k])
+        assert abs(s1[k] - s0[k]) <= 2e-5 * abs(s0[k]), (k, s1[k], s0[k])
     # backward: the dO GEMM splits K at different boundaries in the two kernels (f32 summation order), and the bf16
     # BPTT re-rounds what it is fed, so last-bit differences can flip a few bf16 roundings downstream
     assert abs(s1["norm"] - s0["norm"]) <= 1e-4 * abs(s0["norm"]), (s1["norm"], s0["norm"])

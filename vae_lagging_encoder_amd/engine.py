@@ -163,13 +163,48 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
         fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
 
 
-def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, ws=None):
-    """C = op(A) . B^T with operands already rounded to bf16 in HBM (lv_gemm_b16): B stored [N][K]; A stored [M][K]
-    (tA = 0) or [K][M] (tA = 1).  Bit-identical to _gemm(prec='bf16') on the f32 data, at half the operand bytes."""
+def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, add1=None, ld1=0, mod1=1, add2=None, ld2=0, mod2=1, ws=None):
+    """C = op(A) . B^T (+ add1 + add2) with operands already rounded to bf16 in HBM (lv_gemm_b16): B stored [N][K];
+    A stored [M][K] (tA = 0) or [K][M] (tA = 1).  Bit-identical to _gemm(prec='bf16') on the f32 data (up to where
+    split-K cuts), at half the operand bytes and with no conversion work in the GEMM."""
     if ws is None:
         ws = _gemm_ws(lib, s)
     with _prof("gemm_bf16", 2.0 * M * N * K):
-        lib.lv_gemm_b16(tA, M, N, K, 1.0, A16, lda, B16, ldb, C, ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
+        lib.lv_gemm_b16(tA, M, N, K, 1.0, A16, lda, B16, ldb, C, ldc, 0, add1, ld1, mod1, add2, ld2, mod2,
+                        P(ws), ws.numel(), s)
+
+
+class _LstmImages(object):
+    """bf16 operand images of one LSTM layer's input-side GEMMs (Gx = X.W_ih^T forward; dX = dG.W_ih,
+    dW_ih = dG^T.X, dW_hh = dG^T.h_prev backward), built with lv_cvt_bf16_f32 next to the f32 originals."""
+
+    def __init__(self, c, TB, ni, H):
+        self.TB, self.ni, self.H = TB, ni, H
+        self.ldr = _round_up(TB, 8)
+        self.X = c.i16(TB, ni)              # layer input rows            [T*B][ni]
+        self.XT = c.i16(ni, self.ldr)       # ... transposed              [ni][T*B]
+        self.W = c.i16(4 * H, ni)           # W_ih (input columns)        [4H][ni]
+        self.WT = c.i16(ni, 4 * H)          # ... transposed              [ni][4H]
+        self.dG = c.i16(TB, 4 * H)          # gate pre-activation grads   [T*B][4H]
+        self.hT = c.i16(H, self.ldr)        # h_{t-1} rows, transposed    [H][T*B]
+
+    @staticmethod
+    def usable(precision, native16, ni, H):
+        return precision == "bf16" and native16 and ni % 8 == 0 and H % 8 == 0
+
+    def forward(self, lib, s, X, W_ih, ld_w, Gx, **epilogue):
+        TB, ni, H = self.TB, self.ni, self.H
+        lib.lv_cvt_bf16_f32(X, ni, TB, ni, P(self.X), ni, P(self.XT), self.ldr, s)
+        lib.lv_cvt_bf16_f32(W_ih, ld_w, 4 * H, ni, P(self.W), ni, P(self.WT), 4 * H, s)
+        _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, P(self.W), ni, Gx, 4 * H, **epilogue)
+
+    def backward(self, lib, s, dG, h_prev, dX, gW_ih, ld_gw, gW_hh, ws=None):
+        TB, ni, H = self.TB, self.ni, self.H
+        lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
+        lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
+        _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, P(self.WT), 4 * H, dX, ni, ws=ws)
+        _gemm16(lib, s, 1, 4 * H, ni, TB, P(self.dG), 4 * H, P(self.XT), self.ldr, gW_ih, ld_gw, ws=ws)
+        _gemm16(lib, s, 1, 4 * H, H, TB, P(self.dG), 4 * H, P(self.hT), self.ldr, gW_hh, H, ws=ws)
 
 
 def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, scratch, ws=None):
@@ -205,7 +240,14 @@ class LSTMEncoderEngine(object):
         self.wsc = None
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
+        self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self._scratch = _Scratch()
+
+    def _b16(self, B, T):
+        V, ni, H, nz2 = self.dims()
+        if not _LstmImages.usable(self.precision, self.native16, ni, H):
+            return None
+        return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H))
 
     def ensure(self, device):
         device = torch.device(device)
@@ -258,8 +300,13 @@ class LSTMEncoderEngine(object):
         w = self._ws(B, T)
         v = f.views
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
-        _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
-              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1, prec=self.precision)
+        img = self._b16(B, T)
+        biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
+        if img is not None:
+            img.forward(lib, s, P(w.X), P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), **biases)
+        else:
+            _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
+                  prec=self.precision, **biases)
         w.hs[0].zero_()
         w.cs[0].zero_()
         with _prof("lstm_fwd", 0.0, T):
@@ -290,10 +337,14 @@ class LSTMEncoderEngine(object):
                 None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
                 P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
         # input-side grads
-        _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
-        sc = lambda n, slot: self._scratch(n, slot, x.device)
-        _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision, sc)
-        _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision, sc)
+        img = self._b16(B, T)
+        if img is not None:
+            img.backward(lib, s, P(w.dG), P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
+        else:
+            _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
+            sc = lambda n, slot: self._scratch(n, slot, x.device)
+            _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision, sc)
+            _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision, sc)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         gv["embed.weight"].zero_()
         lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
@@ -423,6 +474,12 @@ class LSTMDecoderEngine(object):
             return b
         return c.get(("b16", Bd, Td), build)
 
+    def _lstm_images(self, Bd, Td):
+        V, ni, H, nz = self.dims()
+        if not _LstmImages.usable(self.precision, self.native16, ni, H):
+            return None
+        return self.wsc.get(("b16lstm", Bd, Td), lambda: _LstmImages(self.wsc, Td * Bd, ni, H))
+
     def forward(self, x, z, mask_in, mask_out, p_in, p_out):
         """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
         batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B]."""
@@ -452,8 +509,12 @@ class LSTMDecoderEngine(object):
         wih = v["lstm.weight_ih_l0"]
         _gemm(lib, s, 0, 1, B, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
               add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
-        _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
-              add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
+        img = self._lstm_images(B, Td)
+        if img is not None:
+            img.forward(lib, s, P(w.X), P(wih), ni + nz, P(w.Gx), add1=P(w.Zp), ld1=4 * H, mod1=B)
+        else:
+            _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
+                  add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
         with _prof("lstm_fwd", 0.0, Td):
             (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
                 P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
@@ -513,11 +574,15 @@ class LSTMDecoderEngine(object):
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
         with ctx:
             s2 = stream_ptr(dev)
-            _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
-            _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, sc, ws=sws)
+            img = self._lstm_images(B, Td)
+            if img is not None:
+                img.backward(lib, s2, P(w.dG), P(w.hs), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
+            else:
+                _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
+                _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, sc, ws=sws)
+                _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
+                       self.precision, sc, ws=sws)
             _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
-            _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
-                   self.precision, sc, ws=sws)
             lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
             gv["embed.weight"].zero_()
             lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s2)
