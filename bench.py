@@ -224,21 +224,21 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
         gemm_roof = {
-            "bound": "mfma", "kernel": "lv_gemm_%s_kernel" % args.dtype, "achieved": round(gemm_tf, 2), "peak": peak,
+            "bound": "mfma", "kernel": "lv_gemm_b16_kernel" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4), "traffic": None,
             "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
             "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
         # LSTM recurrence: per launch the algorithmic HBM bytes are W_hh (4H*H, 2 B/element when the recurrent product
         # runs on the bf16 pipe) + one timestep of f32 state/gates
         wb = 2.0 if args.dtype == "bf16" else 4.0
-        per_fwd = wb * 4 * H * H + 4.0 * (B * H * 3 + B * 4 * H * 2)
-        per_bwd = (wb * 4 * H * H + 4.0 * (B * 4 * H * 4 + B * H * 10)) / 2.0  # two launches (elementwise + matmul) per step
-        steps_fwd = groups.get("lstm_fwd", dict(launches=0))["launches"]
-        steps_bwd = groups.get("lstm_bwd", dict(launches=0))["launches"]
+        per_fwd = wb * 4 * H * H + 4.0 * (B * H * 3 + B * 4 * H * 2)             # per timestep
+        per_bwd = wb * 4 * H * H + 4.0 * (B * 4 * H * 4 + B * H * 10)            # per timestep (elementwise + matmul launches)
+        steps_fwd = groups.get("lstm_fwd", dict(work=0))["work"]                 # the LSTM groups record timesteps as work
+        steps_bwd = groups.get("lstm_bwd", dict(work=0))["work"]
         lstm_bytes = per_fwd * steps_fwd + per_bwd * steps_bwd
         lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
         lstm_roof = {
-            "bound": "hbm", "kernel": "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep)",
+            "bound": "hbm", "kernel": "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)",
             "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
             "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
             "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3)}

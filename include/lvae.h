@@ -72,6 +72,12 @@ int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* d
                      const float* whh, const float* gates, const float* hs, const float* cs,
                      float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
                      int T, int B, int H, void* stream);
+/* lv_lstm_bwd_bf16 that also (or only) writes dG16, the bf16 image of dG ([T][B][4H], bits identical to
+ * lv_cvt_bf16_f32 of dG) that lv_gemm_b16 consumes for dX / dW_ih / dW_hh; either of dG / dG16 may be NULL, not both. */
+int lv_lstm_bwd_bf16_img(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                           const float* whh, const float* gates, const float* hs, const float* cs,
+                           float* dG, uint16_t* dG16, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
+                           int T, int B, int H, void* stream);
 /* floats of caller-owned scratch (16-byte aligned) both LSTM entry points need: MFMA-fragment-major packed copies of
  * W_hh and of the recurrent state, split-K slabs */
 long lv_lstm_ws_floats(int B, int H);

@@ -51,6 +51,12 @@ def test_lstm_bf16(emu_backend, cfg):
     K.test_lstm_fwd_bwd(emu_backend, CPU, *cfg, prec="bf16")
 
 
+@pytest.mark.parametrize("cfg", [(3, 5, 50, True, True, True, True), (2, 33, 20, False, False, False, True),
+                                 (2, 130, 16, True, False, True, True), (1, 7, 33, True, False, True, True)])
+def test_lstm_bf16_img(emu_backend, cfg):
+    K.test_lstm_fwd_bwd(emu_backend, CPU, *cfg, prec="bf16_img")
+
+
 @pytest.mark.parametrize("cfg", [(7, 4, 8, 53, True), (12, 16, 50, 1004, False)])
 def test_embed(emu_backend, cfg):
     K.test_embed_gather_sort_scatter(emu_backend, CPU, *cfg)

@@ -185,9 +185,9 @@ def _lstm_ref(gx, whh, h0, c0, mask, scale):
 ])
 def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="f32"):
     dev = hip_device
-    fwd = lib.lv_lstm_fwd_bf16 if prec == "bf16" else lib.lv_lstm_fwd_f32
-    bwd = lib.lv_lstm_bwd_bf16 if prec == "bf16" else lib.lv_lstm_bwd_f32
-    tol = 300.0 if prec == "bf16" else 1.0      # bf16 recurrent operands: ~2^-9 relative per product
+    fwd = lib.lv_lstm_fwd_f32 if prec == "f32" else lib.lv_lstm_fwd_bf16
+    bwd = lib.lv_lstm_bwd_f32 if prec == "f32" else lib.lv_lstm_bwd_bf16
+    tol = 1.0 if prec == "f32" else 300.0       # bf16 recurrent operands: ~2^-9 relative per product
     g = torch.Generator().manual_seed(T * 100 + B + H)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
@@ -225,9 +225,26 @@ def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, us
     dGsum = torch.full((B, 4 * H), 7.0, device=dev)
     dc0 = torch.empty(B, H, device=dev)
     ws.fill_(float("nan"))            # scratch content must not matter
-    bwd(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
-        P(whh), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(ws), None, P(dc0),
-        int(tanh_init), T, B, H, _s(dev))
+    if prec == "bf16_img":          # one launch per step; also emits the bf16 image of dG and dh0
+        dG16 = torch.full((T, B, 4 * H), 0x7FC0, dtype=torch.int16, device=dev)
+        dh0 = torch.empty(B, H, device=dev)
+        lib.lv_lstm_bwd_bf16_img(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+                                   P(whh), P(gates), P(hs), P(cs), P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0),
+                                   int(tanh_init), T, B, H, _s(dev))
+        assert torch.equal(dG16.cpu(), dG.cpu().to(torch.bfloat16).view(torch.int16))
+        if not tanh_init:             # then h0 is a free input: dh0 = d loss / d h0 = dG[0] . W_hh
+            ref_dh0 = gx64.grad[0] @ whh64
+            assert float((dh0.double() - ref_dh0).abs().max()) < 1e-4 * float(ref_dh0.abs().max()) * tol
+        only16 = torch.empty_like(dG16)
+        dGsum2 = torch.empty_like(dGsum)
+        lib.lv_lstm_bwd_bf16_img(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+                                   P(whh), P(gates), P(hs), P(cs), None, P(only16), P(dGsum2), P(ws), None, None,
+                                   int(tanh_init), T, B, H, _s(dev))
+        assert torch.equal(only16, dG16) and torch.equal(dGsum2, dGsum)
+    else:
+        bwd(P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+            P(whh), P(gates), P(hs), P(cs), P(dG), P(dGsum), P(ws), None, P(dc0),
+            int(tanh_init), T, B, H, _s(dev))
     sc = float(gx64.grad.abs().max())
     assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc * tol
     assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T * tol
@@ -240,6 +257,14 @@ def test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, us
 ])
 def test_lstm_fwd_bwd_bf16_recurrence(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last):
     test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="bf16")
+
+
+@pytest.mark.parametrize("T,B,H,use_mask,tanh_init,use_ext,use_last", [
+    (6, 32, 1024, True, True, True, False), (3, 5, 50, True, True, True, True), (4, 128, 256, False, True, True, False),
+    (2, 130, 64, True, False, True, True), (5, 32, 1024, False, False, False, True), (1, 7, 33, True, False, True, True),
+])
+def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last):
+    test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="bf16_img")
 
 
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),

@@ -308,6 +308,7 @@ struct LstmBwdP {
     const float* gates; const float* cs;
     float* dG; float* dGsum; float* dGp; float* dh_part; float* dc_rec;
     int T, B, H, KS, Kq4, MBTp;
+    uint16_t* dG16;        // optional bf16 image of dG for lv_gemm_b16 (bf16 path; dG may then be null)
 };
 
 // elementwise part of BPTT step t (KS = number of split-K slabs of the previous step's matmul, compile-time so
@@ -358,14 +359,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
     const long si = (long)b * 4 * H + u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        p.dG[gi + (long)g * H] = da[g];
+        if (p.dG) p.dG[gi + (long)g * H] = da[g];
         if (first) p.dGsum[si + (long)g * H] = da[g];
         else p.dGsum[si + (long)g * H] += da[g];
         const int n = g * H + u;                                   // packed copy: A operand of this step's matmul
-        if (BF)
-            reinterpret_cast<unsigned short*>(p.dGp)[(((long)(n >> 3) * p.MBTp + (b >> 4)) * 16 + (b & 15)) * 8 + (n & 7)] =
-                (unsigned short)lv_f32_to_bf16_bits(da[g]);
-        else
+        if (BF) {
+            const unsigned short h16 = (unsigned short)lv_f32_to_bf16_bits(da[g]);
+            if (p.dG16) p.dG16[gi + (long)g * H] = h16;
+            reinterpret_cast<unsigned short*>(p.dGp)[(((long)(n >> 3) * p.MBTp + (b >> 4)) * 16 + (b & 15)) * 8 + (n & 7)] = h16;
+        } else
             p.dGp[((long)(n >> 2) * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + (n & 3)] = da[g];
     }
 }
@@ -533,8 +535,8 @@ template <bool BF>
 int lstm_bwd_impl(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
                   const float* whh, const float* gates, const float* hs, const float* cs,
                   float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,
-                  int T, int B, int H, void* stream) {
-    if (!whh || !gates || !cs || !dG || !dGsum || !ws) return LV_ERR_ARG;
+                  int T, int B, int H, void* stream, uint16_t* dG16 = nullptr) {
+    if (!whh || !gates || !cs || (!dG && !dG16) || !dGsum || !ws) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
     if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
@@ -549,7 +551,7 @@ int lstm_bwd_impl(const float* dh_ext, const float* dh_last, const uint8_t* dmas
     else
         LV_LAUNCH(pack_w_bwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh, wpT, H, g.Kq4);
     hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
-    LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp};
+    LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp, dG16};
     const long BH = (long)B * H;
     const bool need_h0 = (dh0 != nullptr) || tanh_init;
     dim3 egrid((unsigned)lv_cdiv(BH, 256)), block(256);
@@ -638,4 +640,14 @@ extern "C" int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const
                                 int T, int B, int H, void* stream) {
     return lstm_bwd_impl<true>(dh_ext, dh_last, dmask, dscale, whh, gates, hs, cs, dG, dGsum, ws, dh0, dc0, tanh_init,
                                T, B, H, stream);
+}
+
+// lv_lstm_bwd_bf16 that also (or only) emits the bf16 image of dG the input-side GEMMs consume (lv_gemm_b16): dG16
+// [T][B][4H] holds exactly what lv_cvt_bf16_f32 would make of dG; either of dG / dG16 may be null, not both.
+extern "C" int lv_lstm_bwd_bf16_img(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                                    const float* whh, const float* gates, const float* hs, const float* cs,
+                                    float* dG, uint16_t* dG16, float* dGsum, float* ws, float* dh0, float* dc0,
+                                    int tanh_init, int T, int B, int H, void* stream) {
+    return lstm_bwd_impl<true>(dh_ext, dh_last, dmask, dscale, whh, gates, hs, cs, dG, dGsum, ws, dh0, dc0, tanh_init,
+                               T, B, H, stream, dG16);
 }

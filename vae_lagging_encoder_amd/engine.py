@@ -120,6 +120,7 @@ class _NS(object):
 
 # bench.py's roofline leg: when set to a dict, kernel-launch groups are bracketed by HIP events recorded on the launch
 # stream and (start, end, work, launches) is appended under the group name (measurement only; None normally).
+# work = flops for the GEMM groups, timesteps for the LSTM groups.
 PROFILE = None
 
 
@@ -199,8 +200,10 @@ class _LstmImages(object):
         _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, P(self.W), ni, Gx, 4 * H, **epilogue)
 
     def backward(self, lib, s, dG, h_prev, dX, gW_ih, ld_gw, gW_hh, ws=None):
+        """dG: the f32 gate gradients, or None when the BPTT kernel already wrote their bf16 image into self.dG."""
         TB, ni, H = self.TB, self.ni, self.H
-        lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
+        if dG is not None:
+            lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
         lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
         _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, P(self.WT), 4 * H, dX, ni, ws=ws)
         _gemm16(lib, s, 1, 4 * H, ni, TB, P(self.dG), 4 * H, P(self.XT), self.ldr, gW_ih, ld_gw, ws=ws)
@@ -309,7 +312,7 @@ class LSTMEncoderEngine(object):
                   prec=self.precision, **biases)
         w.hs[0].zero_()
         w.cs[0].zero_()
-        with _prof("lstm_fwd", 0.0, T):
+        with _prof("lstm_fwd", float(T), T):
             (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
                 P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
@@ -332,14 +335,18 @@ class LSTMEncoderEngine(object):
         # head: dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T
         _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
-        with _prof("lstm_bwd", 0.0, 2 * T):
-            (lib.lv_lstm_bwd_bf16 if self.precision == "bf16" else lib.lv_lstm_bwd_f32)(
-                None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
-                P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
-        # input-side grads
         img = self._b16(B, T)
+        with _prof("lstm_bwd", float(T), 2 * T):
+            if self.precision == "bf16":     # BPTT writes the bf16 image of dG itself when the input-side GEMMs consume one
+                lib.lv_lstm_bwd_bf16_img(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
+                                         P(w.dG) if img is None else None, P(img.dG) if img is not None else None,
+                                         P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
+            else:
+                lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
+                                    P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
+        # input-side grads
         if img is not None:
-            img.backward(lib, s, P(w.dG), P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
+            img.backward(lib, s, None, P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
         else:
             _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
             sc = lambda n, slot: self._scratch(n, slot, x.device)
@@ -515,7 +522,7 @@ class LSTMDecoderEngine(object):
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
-        with _prof("lstm_fwd", 0.0, Td):
+        with _prof("lstm_fwd", float(Td), Td):
             (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
                 P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
                 P(w.O), P(w.lstm_ws), Td, B, H, s)
@@ -567,16 +574,20 @@ class LSTMDecoderEngine(object):
             _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(b16.WT), b16.ldv, P(w.dO), H)
         else:
             _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
-        with _prof("lstm_bwd", 0.0, 2 * Td):
-            (lib.lv_lstm_bwd_bf16 if self.precision == "bf16" else lib.lv_lstm_bwd_f32)(
-                P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
-                P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
+        img = self._lstm_images(B, Td)
+        with _prof("lstm_bwd", float(Td), 2 * Td):
+            if self.precision == "bf16":
+                lib.lv_lstm_bwd_bf16_img(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
+                                         P(w.cs), P(w.dG) if img is None else None, P(img.dG) if img is not None else None,
+                                         P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
+            else:
+                lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
+                                    P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
         with ctx:
             s2 = stream_ptr(dev)
-            img = self._lstm_images(B, Td)
             if img is not None:
-                img.backward(lib, s2, P(w.dG), P(w.hs), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
+                img.backward(lib, s2, None, P(w.hs), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
             else:
                 _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
                 _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, sc, ws=sws)
