@@ -48,6 +48,30 @@ rows = [
     ("dW_pred", lambda: lib.lv_gemm_bf16(1, 0, V, H, R, 1.0, P(dl), ldl, P(O), H, P(dW), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s),
      lambda: lib.lv_gemm_b16(1, V, H, R, 1.0, P(dl16), ldl, P(O16T), R, P(dW), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)),
 ]
+# LSTM input-side GEMMs (both networks): Gx = X.W_ih^T, dX = dG.W_ih, dW_ih = dG^T.X, dW_hh = dG^T.h
+ni, TB = 512, 6400
+X16 = torch.randn(TB, ni, device=dev).to(torch.bfloat16).view(torch.int16)
+XT16 = torch.randn(ni, TB, device=dev).to(torch.bfloat16).view(torch.int16)
+Wi16 = torch.randn(4 * H, ni, device=dev).to(torch.bfloat16).view(torch.int16)
+WiT16 = torch.randn(ni, 4 * H, device=dev).to(torch.bfloat16).view(torch.int16)
+dG16 = torch.randn(TB, 4 * H, device=dev).to(torch.bfloat16).view(torch.int16)
+hT16 = torch.randn(H, TB, device=dev).to(torch.bfloat16).view(torch.int16)
+Gx = torch.empty(TB, 4 * H, device=dev); dX = torch.empty(TB, ni, device=dev)
+dWi = torch.empty(4 * H, ni, device=dev); dWh = torch.empty(4 * H, H, device=dev)
+import ctypes
+libs = {"default": lib}
+alt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblvae_alt.so")
+if os.path.exists(alt):
+    libs["alt"] = _lib.bind(ctypes.CDLL(alt), alt)
+small = [("Gx", 0, TB, 4 * H, ni, X16, ni, Wi16, ni, Gx, 4 * H), ("dX", 0, TB, ni, 4 * H, dG16, 4 * H, WiT16, 4 * H, dX, ni),
+         ("dW_ih", 1, 4 * H, ni, TB, dG16, 4 * H, XT16, TB, dWi, ni), ("dW_hh", 1, 4 * H, H, TB, dG16, 4 * H, hT16, TB, dWh, H),
+         ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H)]
+for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc in small:
+    line = "%-6s M=%5d N=%5d K=%5d" % (name, M, N, K)
+    for ln, L in libs.items():
+        us = timeit(lambda: L.lv_gemm_b16(tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s))
+        line += " | %s %7.1f us %6.1f TF" % (ln, us, 2.0 * M * N * K / us / 1e6)
+    print(line)
 for name, f_old, f_new in rows:
     a, b = timeit(f_old), timeit(f_new)
     print("%-8s on-the-fly %7.1f us %6.1f TF | pre-rounded %7.1f us %6.1f TF" % (name, a, GF / a / 1e6, b, GF / b / 1e6))

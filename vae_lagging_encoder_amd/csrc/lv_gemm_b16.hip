@@ -22,6 +22,10 @@
 
 namespace {
 
+#ifndef LV_B16_SPLIT_TARGET
+#define LV_B16_SPLIT_TARGET 512     // workgroups a split-K launch aims for (2 per CU x 2 rounds); A/B knob of the microbench
+#endif
+
 constexpr int BK = 64;
 constexpr int BT = 128;
 constexpr int NCH = BK / 8;
@@ -290,7 +294,7 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     // split-K (deterministic: partial slabs + ordered reduce) when the tile count alone cannot fill 256 CUs x 2
     int splits = 1;
     if (ws && tiles < 512 && nk >= 8) {
-        long sp = lv_cdiv(1024, tiles);
+        long sp = lv_cdiv(LV_B16_SPLIT_TARGET, tiles);
         if (sp > nk / 4) sp = nk / 4;
         if (sp > 64) sp = 64;
         const long cap = ws_floats / ((long)M * N);

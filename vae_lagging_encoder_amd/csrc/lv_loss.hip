@@ -173,16 +173,21 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_b16_kernel(const float* _
     for (long k = V + tid; k < ldo; k += 256) orow[k] = 0;      // keep the row padding finite (zero)
 }
 
-// rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight * kl[b]
+// rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight * kl[b].  One wave per sequence: lanes stride over t (each
+// keeps a sequential partial), then a fixed-shape butterfly -- deterministic, and one memory round trip instead of T.
 __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
                                                        const float* __restrict__ klw, float* __restrict__ loss,
                                                        float* __restrict__ rec, int T, int B) {
-    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int b = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int l = (int)threadIdx.x & 63;
     if (b >= B) return;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += nll[(long)t * B + b];
-    rec[b] = s;
-    loss[b] = s + klw[0] * kl[b];
+    for (int t = l; t < T; t += 64) s += nll[(long)t * B + b];
+    s = lv_wave_sum(s);
+    if (l == 0) {
+        rec[b] = s;
+        loss[b] = s + klw[0] * kl[b];
+    }
 }
 
 // upstream grads (each may be null) -> per-row scales used by the backward kernels
@@ -282,7 +287,7 @@ extern "C" int lv_vae_loss_f32(const float* nll, const float* kl, const float* k
                                float* loss, float* rec, int T, int B, void* stream) {
     if (!nll || !kl || !kl_weight_dev || !loss || !rec) return LV_ERR_ARG;
     if (T < 0 || B <= 0) return LV_ERR_SHAPE;
-    LV_LAUNCH(vae_loss_kernel, dim3((unsigned)lv_cdiv(B, 256)), dim3(256), 0, stream, nll, kl, kl_weight_dev, loss, rec, T, B);
+    LV_LAUNCH(vae_loss_kernel, dim3((unsigned)lv_cdiv(B, 4)), dim3(256), 0, stream, nll, kl, kl_weight_dev, loss, rec, T, B);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
