@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
 
     // epilogue operands for this thread's (batch row, unit) pairs: issue the loads before the matmul
     constexpr int NP = (64 * MB + 255) / 256;
-    float pre[NP][4], cp[NP];
+    float pre[NP][4], cp[NP], keep[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int pi = tid + 256 * q;
@@ -240,6 +240,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[q][g] = ok ? gx_t[(long)b * 4 * H + (long)g * H + u] : 0.f;
         cp[q] = ok ? c_prev[(long)b * H + u] : 0.f;
+        keep[q] = 1.f;                               // dropout keep-mask x scale of the output copy, fetched up front
+        if (ok && p.hdrop && p.dmask) keep[q] = p.dmask[((long)b * p.T + t) * H + u] ? p.dscale : 0.f;
     }
 
     // recurrent matmul: this workgroup's 16 gate columns, K split over the 4 waves in units of 16
@@ -291,11 +293,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
                     (unsigned short)lv_f32_to_bf16_bits(h);
             else
                 hp_out[((long)nb * p.MBTp + (b >> 4)) * 64 + (b & 15) * 4 + uu] = h;    // packed copy for step t+1
-            if (p.hdrop) {
-                float m = 1.f;
-                if (p.dmask) m = p.dmask[((long)b * p.T + t) * H + u] ? p.dscale : 0.f;
-                p.hdrop[(long)t * BH + (long)b * H + u] = h * m;
-            }
+            if (p.hdrop) p.hdrop[(long)t * BH + (long)b * H + u] = h * keep[q];
         }
     }
 }
@@ -330,10 +328,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
     if (first && p.dh_last) dh += p.dh_last[idx];
     float parts[KS];
     float dcr = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};          // running sum of dG: read up front so the update below is not a second round trip
+    const long si = (long)b * 4 * H + u;
     if (!first) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) parts[ks] = p.dh_part[(long)ks * BH + idx];
         dcr = p.dc_rec[idx];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gsum[g] = p.dGsum[si + (long)g * H];
     }
     const long gi = (long)t * B * 4 * H + (long)b * 4 * H + u;
     const float ig = p.gates[gi], fg = p.gates[gi + H], gg = p.gates[gi + 2L * H], og = p.gates[gi + 3L * H];
@@ -356,12 +358,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
     da[2] = d_g * (1.f - gg * gg);
     da[3] = d_o * og * (1.f - og);
     p.dc_rec[idx] = dc * fg;
-    const long si = (long)b * 4 * H + u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (p.dG) p.dG[gi + (long)g * H] = da[g];
-        if (first) p.dGsum[si + (long)g * H] = da[g];
-        else p.dGsum[si + (long)g * H] += da[g];
+        p.dGsum[si + (long)g * H] = gsum[g] + da[g];
         const int n = g * H + u;                                   // packed copy: A operand of this step's matmul
         if (BF) {
             const unsigned short h16 = (unsigned short)lv_f32_to_bf16_bits(da[g]);
