@@ -38,5 +38,36 @@ def main(fetch_csv, write_csv):
         print("%-100s %8d %16.3f %16.3f %16.3f" % (n[:100], max(nf, nw), rd, wr, rd + wr))
 
 
+def groups(fetch_csv, write_csv):
+    """Launch-weighted HBM MB per launch of the two kernel groups bench.py reports, split by precision:
+    bf16 = lstm_step_*<..., true> + lv_gemm_b16_kernel; f32 = lstm_step_*<..., false> / <KS> + lv_gemm_f32_kernel<*, *, 2>."""
+    f = load(fetch_csv, "FETCH_SIZE")
+    w = load(write_csv, "WRITE_SIZE")
+
+    def mb(pred):
+        tot, n = 0.0, 0
+        for name in set(f) | set(w):
+            if not pred(name):
+                continue
+            nf, vf = f.get(name, [0, 0.0])
+            nw, vw = w.get(name, [0, 0.0])
+            tot += (vf * 1024 * 2 + vw * 1024) / 1e6
+            n += max(nf, nw)
+        return round(tot / max(n, 1), 3), n
+    is_lstm = lambda n: "lstm_step_" in n
+    bf = lambda n: "true>" in n
+    out = {
+        "bf16": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and bf(n))[0],
+                 "gemm_MB_per_launch": mb(lambda n: "lv_gemm_b16_kernel" in n)[0]},
+        "f32": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and not bf(n))[0],
+                "gemm_MB_per_launch": mb(lambda n: "lv_gemm_f32_kernel" in n and ", 2>" in n)[0]},
+    }
+    return out
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "--json":
+        import json
+        print(json.dumps(groups(sys.argv[1], sys.argv[2]), indent=1))
+    else:
+        main(sys.argv[1], sys.argv[2])
