@@ -33,7 +33,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
     # BASELINE.json metric: "aggressive-loop seqs/sec (Yahoo LSTM-VAE, bsz=32, len=200)"
@@ -57,13 +56,11 @@ def fwd_flops(V, ni, H, nz, B, T):
 def bench_omniglot(args, dev, rank, world):
     """images/sec through the aggressive inner step of the Omniglot VAE (image.py:300-314), B=50 per GPU, replicas only
     (BatchNorm batch statistics make naive data parallelism non-equivalent: SURVEY.md 8e)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import parity_common as pc
     from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.factory import build_image_vae
     from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
-    from oracle import image_vae_oracle as IO
     B = WORKLOADS["omniglot"]["B"]
-    vae = pc.build_image_vae(dev, 783435)
+    vae = build_image_vae(dev, 783435)
     tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, seed=783435 + rank, precision=args.dtype, use_graph=bool(args.graph))
     g = torch.Generator().manual_seed(1 + rank)
     probs = torch.rand(args.pool, B, 1, 28, 28, generator=g).to(dev)
@@ -108,6 +105,7 @@ def bench_omniglot(args, dev, rank, world):
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                            "note": "graph replay: no per-kernel events; see the eager run / profiles/ for the kernel breakdown"}
     if rank == 0 and not args.no_cpu_baseline:
+        from oracle import image_vae_oracle as IO          # the checker, used here only as the timed CPU baseline
         nthreads = min(64, os.cpu_count() or 1)
         torch.set_num_threads(nthreads)
         Pd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
@@ -138,14 +136,15 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="decoder weight-gradient GEMMs on a side stream under the BPTT chains (auto: on for f32, off for bf16)")
     ap.add_argument("--pool", type=int, default=64)
     args = ap.parse_args()
 
     from vae_lagging_encoder_amd import dist as lvdist
     from vae_lagging_encoder_amd import engine
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
-    from helpers import build_vae
-    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.factory import build_text_vae as build_vae, synthetic_batch
 
     rank, local, world = lvdist.init_from_env()
     if world != args.gpus:
@@ -164,7 +163,9 @@ def main():
     sync = lvdist.GradSync(mode="strict") if world > 1 else None
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435 + rank, grad_sync=sync, use_graph=bool(args.graph),
                                precision=args.dtype)
-    pool = [O.synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
+    if args.overlap != "auto":
+        tr.dec.overlap = (args.overlap == "on")
+    pool = [synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
     rs = np.random.RandomState(783435)
     kl_weight = 0.1                                         # text.py default kl_start
 
@@ -286,6 +287,7 @@ def main():
         # cores, on a BOUNDED sample of the same workload: SB of the B sequences of one batch at full length T
         # (per-sequence cost is what the metric counts), <= 64 threads (oneDNN's LSTM backward degrades badly with
         # hundreds of threads: a full B=32 step took 278 s on the 256-core host), ~10-30 s of CPU work.
+        from oracle import text_vae_oracle as O            # the checker, used here only as the timed CPU baseline
         nthreads = min(64, os.cpu_count() or 1)
         torch.set_num_threads(nthreads)
         SB = min(B, 8)

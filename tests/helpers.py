@@ -1,5 +1,4 @@
 """Shared helpers for the parity tests (fixture loading, model construction, comparisons)."""
-import argparse
 import os
 
 import numpy as np
@@ -15,29 +14,6 @@ DEC_KEYS = ["decoder.embed.weight", "decoder.trans_linear.weight", "decoder.lstm
 ALL_KEYS = ENC_KEYS + DEC_KEYS
 
 
-class Vocab(object):
-    def __init__(self, n):
-        self.n = n
-        self.w2i = {"<pad>": 0, "<s>": 1, "</s>": 2, "<unk>": 3}
-
-    def __len__(self):
-        return self.n
-
-    def __getitem__(self, w):
-        return self.w2i[w]
-
-    def id2word(self, i):
-        return "w%d" % i
-
-
-class uniform_initializer(object):
-    def __init__(self, stdv):
-        self.stdv = stdv
-
-    def __call__(self, tensor):
-        torch.nn.init.uniform_(tensor, -self.stdv, self.stdv)
-
-
 def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
@@ -48,19 +24,8 @@ def fixture_params(fx, prefix="param/"):
 
 def build_vae(V, ni, H, nz, device, seed=0, model_scale=0.01, emb_scale=0.1, params=None):
     """Our drop-in modules, constructed exactly as text.py:265-279 constructs the reference's."""
-    from vae_lagging_encoder_amd.modules import VAE, LSTMEncoder, LSTMDecoder
-    args = argparse.Namespace(ni=ni, enc_nh=H, dec_nh=H, nz=nz, dec_dropout_in=0.5, dec_dropout_out=0.5,
-                              device=torch.device(device))
-    torch.manual_seed(seed)
-    enc = LSTMEncoder(args, V, uniform_initializer(model_scale), uniform_initializer(emb_scale))
-    dec = LSTMDecoder(args, Vocab(V), uniform_initializer(model_scale), uniform_initializer(emb_scale))
-    vae = VAE(enc, dec, args)
-    if params is not None:
-        missing, unexpected = vae.load_state_dict(params, strict=False)
-        assert set(missing) <= {"decoder.loss.weight"} and not unexpected   # CrossEntropyLoss's ones() buffer
-    vae = vae.to(device)
-    vae.train()
-    return vae
+    from vae_lagging_encoder_amd.factory import build_text_vae
+    return build_text_vae(V, ni, H, nz, device, seed=seed, model_scale=model_scale, emb_scale=emb_scale, params=params)
 
 
 def rel_err(a, b, floor=0.0):

@@ -82,15 +82,8 @@ def check_trajectory_against_fixture(device, use_graph=False):
 # ---------------------------------------------------------------------------------------------------------------------
 # Omniglot path (ResNetEncoderV2 + PixelCNNDecoderV2), image.py:300-314
 def build_image_vae(device, seed):
-    import argparse
-    from vae_lagging_encoder_amd.modules import VAE, ResNetEncoderV2, PixelCNNDecoderV2
-    args = argparse.Namespace(nz=32, latent_feature_map=4, device=torch.device(device))
-    torch.manual_seed(seed)
-    enc = ResNetEncoderV2(args)
-    dec = PixelCNNDecoderV2(args)
-    vae = VAE(enc, dec, args).to(device)
-    vae.train()
-    return vae
+    from vae_lagging_encoder_amd.factory import build_image_vae as build
+    return build(device, seed)
 
 
 def _check_image_outputs(fx, vae, loss, rec, kl, grads, total):

@@ -370,8 +370,7 @@ class LSTMDecoderEngine(object):
         # The BPTT chains are latency-bound (one small launch per timestep) and leave most CUs idle: the decoder's
         # weight-gradient GEMMs run on a side HIP stream underneath them (dW_pred under the decoder BPTT; dX / dW_ih /
         # dW_hh / embedding scatter under the encoder's backward).  join() orders them before anything reads the grads.
-        self.overlap = None       # None = auto: on for the f32 path, off for bf16 (measured: with the short bf16 GEMMs the
-        #                           interference on the latency-critical step kernels costs more than the overlap saves)
+        self.overlap = None       # None = auto policy (_overlap_on); True / False force it
         self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
         self._side = None
         self._side_ws = None
@@ -382,7 +381,7 @@ class LSTMDecoderEngine(object):
         """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
         on the current stream (inline when overlap is off or on the test backend)."""
         import contextlib
-        if not (self._overlap_on() and torch.device(device).type == "cuda"):
+        if not (torch.device(device).type == "cuda" and self._overlap_on()):
             return contextlib.nullcontext(), None
         if self._side is None:
             self._side = torch.cuda.Stream(device)
@@ -393,10 +392,14 @@ class LSTMDecoderEngine(object):
         return torch.cuda.stream(self._side), self._side_ws
 
     def _overlap_on(self):
-        return (self.precision == "f32") if self.overlap is None else bool(self.overlap)
+        if self.overlap is not None:
+            return bool(self.overlap)
+        # auto (measured on MI355X): on for the f32 path; on the bf16 path it pays in eager launches
+        # (-0.13 ms/step) but not inside a captured hipGraph (+0.5 ms/step: the replayed side branch delays the step kernels)
+        return self.precision == "f32" or not torch.cuda.is_current_stream_capturing()
 
     def _mark_pending(self, device):
-        if self._side is not None and self._overlap_on() and torch.device(device).type == "cuda":
+        if self._side is not None and torch.device(device).type == "cuda" and self._overlap_on():
             ev = torch.cuda.Event()
             ev.record(self._side)
             self._pending = ev
