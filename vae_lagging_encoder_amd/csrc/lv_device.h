@@ -78,6 +78,14 @@ __device__ __forceinline__ uint32_t lv_pack_bf16x2(float lo, float hi) {
 }
 
 __device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Throughput-path activations (bf16 recurrent kernels only): hardware exp2 / reciprocal, ~1e-6 absolute error --
+// three orders below the bf16 rounding of the operands they sit next to.  The f32 parity path keeps expf / tanhf.
+#ifdef LV_EMU
+__device__ __forceinline__ float lv_sigmoid_fast(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
+__device__ __forceinline__ float lv_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+#endif
+__device__ __forceinline__ float lv_tanh_fast(float x) { return 2.0f * lv_sigmoid_fast(2.0f * x) - 1.0f; }
 
 template <class T>
 __device__ __forceinline__ T lv_wave_sum(T v) {

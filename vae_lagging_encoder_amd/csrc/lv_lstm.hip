@@ -281,9 +281,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
                 a[g] = pre[q][g] + s;
             }
             if (ABL & 2) { h_out[(long)b * H + u] = a[0] + a[1] + a[2] + a[3]; continue; }
-            const float ig = lv_sigmoid(a[0]), fg = lv_sigmoid(a[1]), gg = tanhf(a[2]), og = lv_sigmoid(a[3]);
-            const float c = fg * cp[q] + ig * gg;
-            const float h = og * tanhf(c);
+            float ig, fg, gg, og, h;
+            float c;
+            if (BF) {
+                ig = lv_sigmoid_fast(a[0]); fg = lv_sigmoid_fast(a[1]); gg = lv_tanh_fast(a[2]); og = lv_sigmoid_fast(a[3]);
+                c = fg * cp[q] + ig * gg;
+                h = og * lv_tanh_fast(c);
+            } else {
+                ig = lv_sigmoid(a[0]); fg = lv_sigmoid(a[1]); gg = tanhf(a[2]); og = lv_sigmoid(a[3]);
+                c = fg * cp[q] + ig * gg;
+                h = og * tanhf(c);
+            }
             const long gi = (long)b * 4 * H + u;
             g_out[gi] = ig; g_out[gi + H] = fg; g_out[gi + 2L * H] = gg; g_out[gi + 3L * H] = og;
             c_out[(long)b * H + u] = c;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
         for (int ks = 0; ks < KS; ++ks) s += parts[ks];
         dh += s;
     }
-    const float tc = tanhf(c);
+    const float tc = BF ? lv_tanh_fast(c) : tanhf(c);
     float dc = dh * og * (1.f - tc * tc);
     if (!first) dc += dcr;
     const float d_o = dh * tc;
