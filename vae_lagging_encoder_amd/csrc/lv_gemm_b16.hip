@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef LV_B16_ABL
+#define LV_B16_ABL 0      // ablation switches for profiles/microbench only: 1 = no MFMA, 2 = no global loads in the loop, 4 = no fragment reads
+#endif
 #ifndef LV_B16_SPLIT_TARGET
 #define LV_B16_SPLIT_TARGET 512     // workgroups a split-K launch aims for (2 per CU x 2 rounds); A/B knob of the microbench
 #endif
@@ -53,18 +56,37 @@ __device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int 
     return q;
 }
 
-// K-contiguous operand ([rows][K]): unit = (row m = f>>3, chunk c = f&7), one 16 B load; 8 lanes cover a row's 128 B.
-__device__ __forceinline__ void load_kc(const uint16_t* __restrict__ P, long ld, int rows, int K, int r0, int k0, int t,
-                                        uint4 (&reg)[4]) {
+// Staging is branch-free inside the K loop: every thread resolves its addresses once (rows beyond the operand are
+// CLAMPED to a valid row rather than predicated -- an A row only ever reaches the C row of the same index and a B row
+// the C column, and those are not written), full K tiles are loaded unconditionally (FULL), and only the single
+// ragged tile at the end of K takes the predicated path that zero-fills k >= K.
+
+// K-contiguous operand ([rows][K]): unit i of thread t = (row m = f>>3, chunk c = f&7), f = t + 256 i: one 16 B load,
+// 8 lanes cover a row's 128 B.
+struct KcPtr { const uint16_t* p[4]; };
+
+__device__ __forceinline__ KcPtr kc_setup(const uint16_t* __restrict__ P, long ld, int rows, int r0, int t) {
+    KcPtr q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i;
-        const int m = f >> 3, c = f & 7;
-        const long row = r0 + m;
-        const int k = k0 + 8 * c;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (row < rows && k < K) q = load_chunk(P + row * ld + k, K - k);
-        reg[i] = q;
+        int row = r0 + (f >> 3);
+        if (row > rows - 1) row = rows - 1;
+        q.p[i] = P + (long)row * ld + 8 * (f & 7);
+    }
+    return q;
+}
+
+template <bool FULL>
+__device__ __forceinline__ void kc_load(const KcPtr& q, int k0, int K, int t, uint4 (&reg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (FULL) {
+            reg[i] = *reinterpret_cast<const uint4*>(q.p[i] + k0);
+        } else {
+            const int k = k0 + 8 * ((t + 256 * i) & 7);
+            reg[i] = k < K ? load_chunk(q.p[i] + k0, K - k) : make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }
 
@@ -79,17 +101,27 @@ __device__ __forceinline__ void store_kc(uint4 (*S)[BT], int t, const uint4 (&re
 
 // rows-contiguous operand ([K][rows]): one unit per thread = (row octet m8 = t&15 -> rows 8*m8 .. 8*m8+7; k-quad
 // kq = t>>4), four 16 B loads (k .. k+3; a wave-level load = 4 k-rows x 256 contiguous bytes), transposed in registers
-// into the 8 rows' k-quads.  Rows past `rows` may hold anything: an A row only ever reaches the C row of the same index.
-__device__ __forceinline__ void load_mc(const uint16_t* __restrict__ P, long ld, int rows, int K, int r0, int k0, int t,
-                                        uint4 (&reg)[4]) {
-    const int m8 = t & 15, kq = t >> 4;
-    const long col = r0 + 8 * m8;
-    const int k = k0 + 4 * kq;
+// into the 8 rows' k-quads.
+struct McPtr { const uint16_t* p; long ld; };
+
+__device__ __forceinline__ McPtr mc_setup(const uint16_t* __restrict__ P, long ld, int r0, int t) {
+    long col = r0 + 8 * (t & 15);
+    if (col > ld - 8) col = ld - 8;                 // stay inside the row pitch (ld % 8 == 0)
+    McPtr q;
+    q.p = P + col + (long)(4 * (t >> 4)) * ld;
+    q.ld = ld;
+    return q;
+}
+
+template <bool FULL>
+__device__ __forceinline__ void mc_load(const McPtr& q, int k0, int K, int t, uint4 (&reg)[4]) {
+    const uint16_t* base = q.p + (long)k0 * q.ld;
+    const int k = k0 + 4 * (t >> 4);
     uint4 d[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        d[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (col < rows && k + j < K) d[j] = *reinterpret_cast<const uint4*>(P + (long)(k + j) * ld + col);
+        if (FULL || k + j < K) d[j] = *reinterpret_cast<const uint4*>(base + (long)j * q.ld);
+        else d[j] = make_uint4(0u, 0u, 0u, 0u);
     }
     const uint32_t w[4][4] = {{d[0].x, d[1].x, d[2].x, d[3].x}, {d[0].y, d[1].y, d[2].y, d[3].y},
                               {d[0].z, d[1].z, d[2].z, d[3].z}, {d[0].w, d[1].w, d[2].w, d[3].w}};
@@ -156,40 +188,74 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
     const int kt0 = (int)blockIdx.y * p.kt_per_split;
     int kt1 = kt0 + p.kt_per_split;
     if (kt1 > nk_all) kt1 = nk_all;
+    const int nfull = p.K / BK;                        // K tiles [0, nfull) are complete
 
-    if (A_KC) load_kc(p.A, p.lda, p.M, p.K, m0, kt0 * BK, t, ra);
-    else load_mc(p.A, p.lda, p.M, p.K, m0, kt0 * BK, t, ra);
-    load_kc(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, t, rb);
-    if (A_KC) store_kc(As[0], t, ra);
-    else store_mc(As[0], t, ra);
-    store_kc(Bs[0], t, rb);
+    const KcPtr qb = kc_setup(p.B, p.ldb, p.N, n0, t);
+    KcPtr qa;
+    McPtr qm;
+    if (A_KC) qa = kc_setup(p.A, p.lda, p.M, m0, t);
+    else qm = mc_setup(p.A, p.lda, m0, t);
+
+    auto stage = [&](int kt) {                         // global -> registers for K tile kt
+        const int k0 = kt * BK;
+        if (kt < nfull) {
+            if (A_KC) kc_load<true>(qa, k0, p.K, t, ra);
+            else mc_load<true>(qm, k0, p.K, t, ra);
+            kc_load<true>(qb, k0, p.K, t, rb);
+        } else {
+            if (A_KC) kc_load<false>(qa, k0, p.K, t, ra);
+            else mc_load<false>(qm, k0, p.K, t, ra);
+            kc_load<false>(qb, k0, p.K, t, rb);
+        }
+    };
+    auto commit = [&](int buf) {                       // registers -> LDS image
+        if (A_KC) store_kc(As[buf], t, ra);
+        else store_mc(As[buf], t, ra);
+        store_kc(Bs[buf], t, rb);
+    };
+
+    if (kt0 < kt1) stage(kt0);
+    commit(0);
     __syncthreads();
 
+    const int arow = wm * 64 + li, brow = wn * 64 + li;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            if (A_KC) load_kc(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, t, ra);
-            else load_mc(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, t, ra);
-            load_kc(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, t, rb);
+        if (kt + 1 < kt1 && !(LV_B16_ABL & 2)) stage(kt + 1);
+        // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+        uint4 fa[2][2], fb[2][2];
+        {
+            const int c = lh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[0][i] = As[buf][c][(arow + i * 32) ^ (2 * c)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][j] = Bs[buf][c][(brow + j * 32) ^ (2 * c)];
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const int c = 2 * ks + lh;
-            uint4 a[2], b[2];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 16 && !(LV_B16_ABL & 4)) {
+                const int c = 2 * (ks + 1) + lh;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[buf][c][(wm * 64 + i * 32 + li) ^ (2 * c)];
+                for (int i = 0; i < 2; ++i) fa[nxt][i] = As[buf][c][(arow + i * 32) ^ (2 * c)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[buf][c][(wn * 64 + j * 32 + li) ^ (2 * c)];
+                for (int j = 0; j < 2; ++j) fb[nxt][j] = Bs[buf][c][(brow + j * 32) ^ (2 * c)];
+            } else if (ks + 1 < BK / 16) {
+                fa[nxt][0] = fa[nxt][1] = ra[ks & 3]; fb[nxt][0] = fb[nxt][1] = rb[ks & 3];
+            }
+            if (LV_B16_ABL & 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)((fa[cur][i].x ^ fb[cur][j].y) & 0xFFu);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+            }
         }
-        if (kt + 1 < kt1) {
-            if (A_KC) store_kc(As[buf ^ 1], t, ra);
-            else store_mc(As[buf ^ 1], t, ra);
-            store_kc(Bs[buf ^ 1], t, rb);
-        }
+        if (kt + 1 < kt1) commit(buf ^ 1);
         __syncthreads();
     }
 
