@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
                                                   int write_back) {
     const float c = coef ? coef[0] : 1.f;
     const float a = lr[0];
+    const bool wb = write_back && c != 1.0f;      // g * 1 is g: the clipped-gradient write-back is skipped when the clip is inactive
     const long stride = (long)gridDim.x * 256;
     const bool vec = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0;
     if (vec) {
@@ -84,24 +85,25 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
             gv.x *= c; gv.y *= c; gv.z *= c; gv.w *= c;
             pv.x -= a * gv.x; pv.y -= a * gv.y; pv.z -= a * gv.z; pv.w -= a * gv.w;
             p4[i] = pv;
-            if (write_back) g4[i] = gv;
+            if (wb) g4[i] = gv;
         }
         for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
             const float gv = g[i] * c;
             p[i] -= a * gv;
-            if (write_back) g[i] = gv;
+            if (wb) g[i] = gv;
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
             const float gv = g[i] * c;
             p[i] -= a * gv;
-            if (write_back) g[i] = gv;
+            if (wb) g[i] = gv;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef) {
     const float c = coef[0];
+    if (c == 1.0f) return;            // clip inactive (coef is exactly 1): x * 1 is x bit for bit, skip the pass
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] *= c;
 }
