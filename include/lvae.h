@@ -54,13 +54,18 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
 int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
                     void* stream);
 
+/* LSTM gate weight W [4H][C] (rows g*H + u): dst = bf16 image with rows in unit-major order (4u + g), dstT = bf16 image
+ * of W^T [C][4H] in the standard order; either may be NULL */
+int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
+                          void* stream);
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream);
 
 /* ---- LSTM time recurrence: nn.LSTM forward (enc_lstm.py:60, dec_lstm.py:104) and its autograd backward --------
  * gx [T][B][4H] input projection (+biases, + z term); whh [4H][H] (rows i|f|g|o); hs, cs [T+1][B][H] with index 0
- * = initial state supplied by the caller; gates [T][B][4H] activated gates saved for BPTT.
+ * = initial state supplied by the caller; gates: T*B*4H floats of activated gates saved for BPTT (opaque: unit-major
+ * (i,f,g,o) records, written by the forward and read back only by lv_lstm_bwd_*).
  * dmask (optional) uint8 [B][T][H] keep-mask of nn.Dropout on the outputs (dec_lstm.py:106): hdrop[t] =
  * hs[t+1]*mask*dscale;  with dmask == NULL and hdrop != NULL, hdrop is a copy of the outputs. */
 int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, float* gates,
@@ -68,6 +73,13 @@ int lv_lstm_fwd_f32(const float* gx, const float* whh, float* hs, float* cs, flo
 /* same recurrence with the h W_hh^T product on the bf16 matrix pipe (throughput configuration; f32 accumulate/state) */
 int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                      const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* lv_lstm_fwd_bf16 for a gx whose 4H columns are UNIT-major (column 4u + g instead of g*H + u): each workgroup then
+ * fetches a unit's four gate pre-activations with one 16-byte load.  Such a gx is what lv_gemm_b16 produces from the
+ * lv_cvt_bf16_gates_f32 image of W_ih and lv_gate_interleave_f32-ed epilogue addends. */
+int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                        const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
+int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
                      const float* whh, const float* gates, const float* hs, const float* cs,
                      float* dG, float* dGsum, float* ws, float* dh0, float* dc0, int tanh_init,

@@ -77,7 +77,7 @@ int main() {
     printf("lv_lstm_fwd_f32 (packed operands), T=%d       : %7.2f us/step\n", T, time_us([&] { lv_lstm_fwd_f32(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, T, B, H, s); }, 20, s) / T);
     printf("lv_lstm_bwd_f32 (packed operands), T=%d       : %7.2f us/step\n", T, time_us([&] { lv_lstm_bwd_f32(dhext, nullptr, nullptr, 1.f, whh, gates, hs, cs, dG, dGsum, ws, nullptr, nullptr, 0, T, B, H, s); }, 20, s) / T);
     const Geo g = geo(B, H);
-    LstmFwdP p{gx, ws, hs, cs, gates, ws + g.wp, nullptr, 1.f, nullptr, T, B, H, g.Kq, g.MBTp};
+    LstmFwdP p{gx, ws, hs, cs, gates, ws + g.wp, nullptr, 1.f, nullptr, T, B, H, g.Kq, g.MBTp, 0};
     printf("fwd step kernel alone, back-to-back same t    : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
     printf("  fwd ablation: no matmul                      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 1>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
     printf("  fwd ablation: no gate math / gate stores     : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2>), dim3(256, 1), dim3(256), 0, s, p, 3); }, 2000, s));
@@ -87,10 +87,17 @@ int main() {
     lv_lstm_fwd_bf16(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, 1, B, H, s);   // packs bf16 operands into ws
     CK(hipStreamSynchronize(s));
     const Geo g16 = geo(B, H, true);
-    LstmFwdP p16{gx, ws, hs, cs, gates, ws + g16.wp, nullptr, 1.f, nullptr, T, B, H, g16.Kq, g16.MBTp};
+    LstmFwdP p16{gx, ws, hs, cs, gates, ws + g16.wp, nullptr, 1.f, nullptr, T, B, H, g16.Kq, g16.MBTp, 0};
     printf("fwd step kernel, bf16 recurrent operands      : %7.2f us/launch\n", time_us([&] { hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 0, true>), dim3(256, 1), dim3(256), 0, s, p16, 3); }, 2000, s));
     printf("lv_lstm_fwd_bf16, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_fwd_bf16(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, T, B, H, s); }, 20, s) / T);
     printf("lv_lstm_bwd_bf16, T=%d                         : %7.2f us/step\n", T, time_us([&] { lv_lstm_bwd_bf16(dhext, nullptr, nullptr, 1.f, whh, gates, hs, cs, dG, dGsum, ws, nullptr, nullptr, 0, T, B, H, s); }, 20, s) / T);
+    // the real dependent chain (t = 0..T-1, each step reads what the previous one wrote), with the ablation switches
+    auto chain = [&](auto kern) { for (int t = 0; t < T; ++t) hipLaunchKernelGGL(kern, dim3(256, 1), dim3(256), 0, s, p16, t); };
+    printf("bf16 fwd chain, T=%d (real dependencies)       : %7.2f us/step\n", T, time_us([&] { chain(lstm_step_fwd_kernel<2, 0, true>); }, 20, s) / T);
+    printf("  chain ablation: no gate math / gate stores   : %7.2f us/step\n", time_us([&] { chain(lstm_step_fwd_kernel<2, 2, true>); }, 20, s) / T);
+    printf("  chain ablation: no epilogue operand loads    : %7.2f us/step\n", time_us([&] { chain(lstm_step_fwd_kernel<2, 4, true>); }, 20, s) / T);
+    printf("  chain ablation: matmul only (2+4)            : %7.2f us/step\n", time_us([&] { chain(lstm_step_fwd_kernel<2, 6, true>); }, 20, s) / T);
+    printf("  chain ablation: no matmul                    : %7.2f us/step\n", time_us([&] { chain(lstm_step_fwd_kernel<2, 1, true>); }, 20, s) / T);
     lv_lstm_fwd_f32(gx, whh, hs, cs, gates, nullptr, 1.f, nullptr, ws, 1, B, H, s);
     CK(hipStreamSynchronize(s));
     LstmBwdP q{dhext, nullptr, nullptr, 1.f, ws, gates, cs, dG, dGsum, ws + g.wpT, ws + g.wpT + g.dGp, ws + g.wpT + g.dGp + g.part, T, B, H, g.KS, g.Kq4, g.MBTp};

@@ -31,6 +31,16 @@ def test_cvt_bf16(emu_backend, R, C):
     K.test_cvt_bf16(emu_backend, CPU, R, C)
 
 
+@pytest.mark.parametrize("cfg", [(8, 16, 3), (50, 33, 1)])
+def test_gate_interleave_and_gate_weight_image(emu_backend, cfg):
+    K.test_gate_interleave_and_gate_weight_image(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(3, 5, 50, True), (2, 33, 20, False)])
+def test_lstm_fwd_unit_major_gx(emu_backend, cfg):
+    K.test_lstm_fwd_unit_major_gx(emu_backend, CPU, *cfg)
+
+
 def test_gemm_b16_alignment(emu_backend):
     K.test_gemm_b16_alignment_errors(emu_backend, CPU)
 

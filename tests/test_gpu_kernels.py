@@ -101,6 +101,52 @@ def test_cvt_bf16(lib, hip_device, R, C):
     assert torch.equal(only_t.cpu()[:, :R], want.t())
 
 
+@pytest.mark.parametrize("H,C,R", [(8, 16, 3), (50, 33, 1), (256, 128, 5)])
+def test_gate_interleave_and_gate_weight_image(lib, hip_device, H, C, R):
+    g = torch.Generator().manual_seed(H + C)
+    W = torch.randn(4 * H, C + 3, generator=g)
+    a = torch.randn(R, 4 * H, generator=g)
+    b = torch.randn(R, 4 * H, generator=g)
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1)           # unit-major position 4u+g <- gate-major g*H+u
+    Wd, ad, bd = W.to(hip_device), a.to(hip_device), b.to(hip_device)
+    img = torch.zeros(4 * H, C + 5, dtype=torch.int16, device=hip_device)
+    imgT = torch.zeros(C, 4 * H + 8, dtype=torch.int16, device=hip_device)
+    lib.lv_cvt_bf16_gates_f32(P(Wd), C + 3, H, C, P(img), C + 5, P(imgT), 4 * H + 8, _s(hip_device))
+    want = _bf16_bits(W[:, :C])
+    assert torch.equal(img.cpu()[:, :C], want[perm])
+    assert torch.equal(imgT.cpu()[:, :4 * H], want.t())
+    out = torch.empty(R, 4 * H, device=hip_device)
+    lib.lv_gate_interleave_f32(P(ad), P(bd), R, H, P(out), _s(hip_device))
+    assert torch.equal(out.cpu(), (a + b)[:, perm])
+    lib.lv_gate_interleave_f32(P(ad), None, R, H, P(out), _s(hip_device))
+    assert torch.equal(out.cpu(), a[:, perm])
+
+
+@pytest.mark.parametrize("T,B,H,use_mask", [(3, 5, 50, True), (2, 33, 20, False), (4, 32, 256, True)])
+def test_lstm_fwd_unit_major_gx(lib, hip_device, T, B, H, use_mask):
+    """Same recurrence fed the gate pre-activations in unit-major column order: every output bit-identical."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(T + B + H)
+    gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(torch.uint8).to(dev)
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1).to(dev)
+    gxu = gx[:, :, perm].contiguous()
+    outs = []
+    for fn, x in ((lib.lv_lstm_fwd_bf16, gx), (lib.lv_lstm_fwd_bf16_ug, gxu)):
+        hs = torch.zeros(T + 1, B, H, device=dev)
+        cs = torch.zeros(T + 1, B, H, device=dev)
+        hs[0] = 0.1
+        cs[0] = -0.2
+        gates = torch.empty(T, B, 4 * H, device=dev)
+        hdrop = torch.empty(T, B, H, device=dev)
+        ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
+        fn(P(x), P(whh), P(hs), P(cs), P(gates), P(mask) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
+        outs.append((hs.cpu(), cs.cpu(), gates.cpu(), hdrop.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tA,M,N,K,split", [
     (0, 130, 140, 37, False), (1, 70, 130, 50, False), (0, 1, 1, 1, False), (1, 33, 17, 20, False), (1, 129, 64, 200, False),
     (0, 257, 129, 1000, True), (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False),

@@ -23,6 +23,9 @@ SIGNATURES = {
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_cvt_bf16_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
+    "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
+    "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
+    "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_transpose_ld_f32": [_vp, _l, _vp, _l, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],

@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
 
 // f32 [R][C] -> bf16 [R][C] (dst) and/or bf16 [C][R] (dstT), RNE; 64x64 tiles, every global access a full row
 // segment (256 B reads, 128 B writes); the transposed copy goes through a pitch-66 LDS tile (bank stride 33).
+// gate_H > 0: the rows of src are the 4H gate rows of an LSTM weight (g*H + u); dst gets them in unit-major order
+// (row u*4 + g) so that the GEMM it feeds emits each unit's four gate pre-activations side by side; dstT is unaffected.
 __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ src, long lds_, int R, int C,
-                                                      uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt) {
+                                                      uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt,
+                                                      int gate_H) {
     __shared__ uint16_t tile[64][66];
     const int t = (int)threadIdx.x;
     const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
@@ -315,7 +318,10 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
         uint16_t b = 0;
         if (gr < R && gc < C) {
             b = (uint16_t)lv_f32_to_bf16_bits(src[gr * lds_ + gc]);
-            if (dst) dst[gr * ldd + gc] = b;
+            if (dst) {
+                const long dr = gate_H > 0 ? (gr % gate_H) * 4 + gr / gate_H : gr;
+                dst[dr * ldd + gc] = b;
+            }
         }
         tile[r][lane] = b;
     }
@@ -386,7 +392,20 @@ extern "C" int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_
     if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
-              dst, ldd, dstT, ldt);
+              dst, ldd, dstT, ldt, 0);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// LSTM gate weight W [4H][C] (rows g*H + u, gate order i|f|g|o): dst = bf16 image with the rows in unit-major order
+// (u*4 + g), dstT = bf16 image of W^T [C][4H] in the standard order; either may be null.
+extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
+                                     void* stream) {
+    if (!src || (!dst && !dstT)) return LV_ERR_ARG;
+    if (H <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < 4 * H)) return LV_ERR_SHAPE;
+    if (C == 0) return LV_OK;
+    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(4 * H, 64)), dim3(256), 0, stream, src, lds, 4 * H, C,
+              dst, ldd, dstT, ldt, H);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

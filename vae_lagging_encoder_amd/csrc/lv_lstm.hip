@@ -7,7 +7,8 @@
 // HBM layout: everything time-major so one timestep is one contiguous [B][*] slab:
 //   gx    [T][B][4H]  x_t W_ih^T + b_ih + b_hh (+ z W_z^T for the decoder)  -- produced by lv_gemm_*
 //   hs,cs [T+1][B][H] hs[0]/cs[0] = initial state, step t writes index t+1
-//   gates [T][B][4H]  activated i,f,g,o saved for BPTT;  dG [T][B][4H] grads wrt pre-activations
+//   gates [T][B][H][4] activated (i,f,g,o) of one unit as one 16-byte record, saved for BPTT (private to these
+//                      kernels);  dG [T][B][4H] grads wrt pre-activations (gate-major, as the GEMMs consume them)
 //
 // One launch per timestep: the kernel boundary is the grid-wide h_t hand-off (cheaper on gfx950 than an in-kernel
 // grid barrier -- MI355X_MICROARCH.md price list).  The step kernels are latency-bound: one workgroup per CU, 4
@@ -205,6 +206,7 @@ struct LstmFwdP {
     const float* gx; const float* wp; float* hs; float* cs; float* gates; float* hp;   // hp: 2 packed buffers
     const uint8_t* dmask; float dscale; float* hdrop;
     int T, B, H, Kq, MBTp;
+    int gx_unit_major;     // gx rows hold (i,f,g,o) of unit u at columns 4u..4u+3 instead of g*H + u
 };
 
 // ABL: ablation switches for profiles/microbench/lstm_step_probe.hip only (product launches use ABL = 0):
@@ -237,8 +239,13 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
         const int bb = pi >> 2, uu = pi & 3;
         const int b = rb + bb, u = u0 + uu;
         const bool ok = (pi < 64 * MB) && b < B && u < H && !(ABL & 4);
+        if (p.gx_unit_major) {       // one 16-byte load: the producing GEMM ran on gate-interleaved weight rows
+            const float4 gq = ok ? *reinterpret_cast<const float4*>(gx_t + ((long)b * H + u) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[q][0] = gq.x; pre[q][1] = gq.y; pre[q][2] = gq.z; pre[q][3] = gq.w;
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[q][g] = ok ? gx_t[(long)b * 4 * H + (long)g * H + u] : 0.f;
+            for (int g = 0; g < 4; ++g) pre[q][g] = ok ? gx_t[(long)b * 4 * H + (long)g * H + u] : 0.f;
+        }
         cp[q] = ok ? c_prev[(long)b * H + u] : 0.f;
         keep[q] = 1.f;                               // dropout keep-mask x scale of the output copy, fetched up front
         if (ok && p.hdrop && p.dmask) keep[q] = p.dmask[((long)b * p.T + t) * H + u] ? p.dscale : 0.f;
@@ -292,8 +299,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdP p, int t) {
                 c = fg * cp[q] + ig * gg;
                 h = og * tanhf(c);
             }
-            const long gi = (long)b * 4 * H + u;
-            g_out[gi] = ig; g_out[gi + H] = fg; g_out[gi + 2L * H] = gg; g_out[gi + 3L * H] = og;
+            *reinterpret_cast<float4*>(g_out + ((long)b * H + u) * 4) = make_float4(ig, fg, gg, og);   // unit-major record
             c_out[(long)b * H + u] = c;
             h_out[(long)b * H + u] = h;
             if (BF)     // packed bf16 copy for step t+1: oct = u/8, element u%8
@@ -346,7 +352,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_elem_kernel(LstmBwdP p, int
         for (int g = 0; g < 4; ++g) gsum[g] = p.dGsum[si + (long)g * H];
     }
     const long gi = (long)t * B * 4 * H + (long)b * 4 * H + u;
-    const float ig = p.gates[gi], fg = p.gates[gi + H], gg = p.gates[gi + 2L * H], og = p.gates[gi + 3L * H];
+    const float4 gq = *reinterpret_cast<const float4*>(p.gates + ((long)t * BH + idx) * 4);
+    const float ig = gq.x, fg = gq.y, gg = gq.z, og = gq.w;
     const float c = p.cs[(long)(t + 1) * BH + idx];
     const float cprev = p.cs[(long)t * BH + idx];
     if (!first) {
@@ -512,11 +519,13 @@ void launch_bwd_elem(const LstmBwdP& p, int t, dim3 egrid, void* stream) {
 
 template <bool BF>
 int lstm_fwd_impl(const float* gx, const float* whh, float* hs, float* cs, float* gates,
-                  const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream) {
+                  const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream,
+                  int gx_unit_major = 0) {
     if (!gx || !whh || !hs || !cs || !gates || !ws) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (dmask && !hdrop) return LV_ERR_ARG;
-    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0) return LV_ERR_ALIGN;
+    if (gx_unit_major && (((uintptr_t)gx) & 15) != 0) return LV_ERR_ALIGN;
     const Geo g = geo(B, H, BF);
     float* wp = ws;
     float* hp = ws + g.wp;
@@ -530,7 +539,7 @@ int lstm_fwd_impl(const float* gx, const float* whh, float* hs, float* cs, float
         LV_LAUNCH(pack_w_fwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh, wp, H, g.Kq);
         LV_LAUNCH(pack_act_kernel, dim3((unsigned)lv_cdiv((long)B * H, 256)), dim3(256), 0, stream, (const float*)hs, hp, B, H, g.MBTp);
     }
-    LstmFwdP p{gx, wp, hs, cs, gates, hp, dmask, dscale, hdrop, T, B, H, g.Kq, g.MBTp};
+    LstmFwdP p{gx, wp, hs, cs, gates, hp, dmask, dscale, hdrop, T, B, H, g.Kq, g.MBTp, gx_unit_major};
     switch (g.MB) {
         case 1: return launch_fwd_steps<1, BF>(p, stream);
         case 2: return launch_fwd_steps<2, BF>(p, stream);
@@ -547,7 +556,7 @@ int lstm_bwd_impl(const float* dh_ext, const float* dh_last, const uint8_t* dmas
     if (!whh || !gates || !cs || (!dG && !dG16) || !dGsum || !ws) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
-    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0) return LV_ERR_ALIGN;
     const Geo g = geo(B, H, BF);
     float* wpT = ws;
     float* dGp = wpT + g.wpT;
@@ -658,4 +667,36 @@ extern "C" int lv_lstm_bwd_bf16_img(const float* dh_ext, const float* dh_last, c
                                     int tanh_init, int T, int B, int H, void* stream) {
     return lstm_bwd_impl<true>(dh_ext, dh_last, dmask, dscale, whh, gates, hs, cs, dG, dGsum, ws, dh0, dc0, tanh_init,
                                T, B, H, stream, dG16);
+}
+
+// lv_lstm_fwd_bf16 for a gx whose 4H columns are unit-major (column 4u + g): what lv_gemm_b16 produces from the
+// lv_cvt_bf16_gates_f32 image of W_ih with lv_gate_interleave_f32-ed addends.  Everything else as lv_lstm_fwd_bf16.
+extern "C" int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                                   const uint8_t* dmask, float dscale, float* hdrop, float* ws,
+                                   int T, int B, int H, void* stream) {
+    return lstm_fwd_impl<true>(gx, whh, hs, cs, gates, dmask, dscale, hdrop, ws, T, B, H, stream, 1);
+}
+
+namespace {
+// out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u])
+__global__ __launch_bounds__(256) void gate_interleave_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              long n, int H, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // index into out
+    if (idx >= n) return;
+    const long r = idx / (4L * H);
+    const int c = (int)(idx % (4L * H));
+    const long src = r * 4L * H + (long)(c & 3) * H + (c >> 2);
+    out[idx] = a[src] + (b ? b[src] : 0.f);
+}
+}  // namespace
+
+// Rows of 4H gate values (biases b_ih + b_hh, or the decoder's per-sequence z-projection) from gate-major to the
+// unit-major column order of lv_lstm_fwd_bf16_ug's gx.  b may be null.
+extern "C" int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream) {
+    if (!a || !out || R < 0 || H <= 0) return LV_ERR_ARG;
+    if (R == 0) return LV_OK;
+    const long n = (long)R * 4 * H;
+    LV_LAUNCH(gate_interleave_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, a, b, n, H, out);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
 }

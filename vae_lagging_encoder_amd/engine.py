@@ -184,8 +184,10 @@ class _LstmImages(object):
         self.ldr = _round_up(TB, 8)
         self.X = c.i16(TB, ni)              # layer input rows            [T*B][ni]
         self.XT = c.i16(ni, self.ldr)       # ... transposed              [ni][T*B]
-        self.W = c.i16(4 * H, ni)           # W_ih (input columns)        [4H][ni]
-        self.WT = c.i16(ni, 4 * H)          # ... transposed              [ni][4H]
+        self.W = c.i16(4 * H, ni)           # W_ih (input columns), rows in UNIT-major gate order (4u + g): Gx comes
+        #                                     out with each unit's (i,f,g,o) side by side (lv_lstm_fwd_bf16_ug)
+        self.WT = c.i16(ni, 4 * H)          # W_ih^T, standard gate-major order (contraction index of dX) [ni][4H]
+        self.addend = None                  # unit-major copy of the Gx epilogue addend (biases / z-projection)
         self.dG = c.i16(TB, 4 * H)          # gate pre-activation grads   [T*B][4H]
         self.hT = c.i16(H, self.ldr)        # h_{t-1} rows, transposed    [H][T*B]
 
@@ -193,11 +195,17 @@ class _LstmImages(object):
     def usable(precision, native16, ni, H):
         return precision == "bf16" and native16 and ni % 8 == 0 and H % 8 == 0
 
-    def forward(self, lib, s, X, W_ih, ld_w, Gx, **epilogue):
+    def forward(self, lib, s, X, W_ih, ld_w, Gx, add_a, add_b, rows, wsc):
+        """Gx[r][4u + g] = X[r] . W_ih[g*H + u] + (add_a + add_b)[r % rows][g*H + u]; add_a/add_b: gate-major [rows][4H]
+        (add_b may be None)."""
         TB, ni, H = self.TB, self.ni, self.H
+        if self.addend is None or self.addend.shape[0] != rows:
+            self.addend = wsc.f32(rows, 4 * H)
+        lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
         lib.lv_cvt_bf16_f32(X, ni, TB, ni, P(self.X), ni, P(self.XT), self.ldr, s)
-        lib.lv_cvt_bf16_f32(W_ih, ld_w, 4 * H, ni, P(self.W), ni, P(self.WT), 4 * H, s)
-        _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, P(self.W), ni, Gx, 4 * H, **epilogue)
+        lib.lv_cvt_bf16_gates_f32(W_ih, ld_w, H, ni, P(self.W), ni, P(self.WT), 4 * H, s)
+        _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, P(self.W), ni, Gx, 4 * H,
+                add1=P(self.addend), ld1=4 * H if rows > 1 else 0, mod1=rows)
 
     def backward(self, lib, s, dG, h_prev, dX, gW_ih, ld_gw, gW_hh, ws=None):
         """dG: the f32 gate gradients, or None when the BPTT kernel already wrote their bf16 image into self.dG."""
@@ -306,15 +314,16 @@ class LSTMEncoderEngine(object):
         img = self._b16(B, T)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
-            img.forward(lib, s, P(w.X), P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), **biases)
+            img.forward(lib, s, P(w.X), P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]),
+                        1, self.wsc)
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
         w.hs[0].zero_()
         w.cs[0].zero_()
+        fwd = lib.lv_lstm_fwd_f32 if self.precision != "bf16" else (lib.lv_lstm_fwd_bf16_ug if img is not None else lib.lv_lstm_fwd_bf16)
         with _prof("lstm_fwd", float(T), T):
-            (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
-                P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
+            fwd(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
@@ -522,13 +531,13 @@ class LSTMDecoderEngine(object):
               add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         img = self._lstm_images(B, Td)
         if img is not None:
-            img.forward(lib, s, P(w.X), P(wih), ni + nz, P(w.Gx), add1=P(w.Zp), ld1=4 * H, mod1=B)
+            img.forward(lib, s, P(w.X), P(wih), ni + nz, P(w.Gx), P(w.Zp), None, B, self.wsc)
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
+        fwd = lib.lv_lstm_fwd_f32 if self.precision != "bf16" else (lib.lv_lstm_fwd_bf16_ug if img is not None else lib.lv_lstm_fwd_bf16)
         with _prof("lstm_fwd", float(Td), Td):
-            (lib.lv_lstm_fwd_bf16 if self.precision == "bf16" else lib.lv_lstm_fwd_f32)(
-                P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
+            fwd(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
                 P(w.O), P(w.lstm_ws), Td, B, H, s)
         b16 = self._b16(B, Td)
         if b16 is not None:
