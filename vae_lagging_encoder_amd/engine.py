@@ -175,6 +175,39 @@ def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, add1=None, ld1=0, m
                         P(ws), ws.numel(), s)
 
 
+class _AuxStream(object):
+    """A per-engine auxiliary HIP stream for work that depends only on the token ids and must merely be finished by the
+    time the embedding gradient is scattered: the stable token sort (one workgroup, ~60 us at the bench shape) and the
+    zero fill of the embedding-gradient table.  Runs them beside the latency-bound LSTM chains, which leave almost every
+    CU idle; inline on the test backend."""
+
+    def __init__(self):
+        self.stream = None
+        self.done = None
+
+    def run(self, device, fn):
+        device = torch.device(device)
+        # inline on the test backend, and under hipGraph capture: a forked branch in a replayed graph was measured to
+        # cost ~0.5 ms per step (DESIGN.md section 5), far more than the 0.15 ms the side stream saves in eager mode
+        if device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            fn(None)
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn(self.stream.cuda_stream)
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+
+    def join(self, device):
+        if self.done is not None:
+            torch.cuda.current_stream(torch.device(device)).wait_event(self.done)
+            self.done = None
+
+
 class _LstmImages(object):
     """bf16 operand images of one LSTM layer's input-side GEMMs (Gx = X.W_ih^T forward; dX = dG.W_ih,
     dW_ih = dG^T.X, dW_hh = dG^T.h_prev backward), built with lv_cvt_bf16_f32 next to the f32 originals."""
@@ -253,6 +286,7 @@ class LSTMEncoderEngine(object):
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self._scratch = _Scratch()
+        self._aux = _AuxStream()
 
     def _b16(self, B, T):
         V, ni, H, nz2 = self.dims()
@@ -311,6 +345,8 @@ class LSTMEncoderEngine(object):
         w = self._ws(B, T)
         v = f.views
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
+        # the backward's token sort depends on x only: queue it now, beside the forward chain
+        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s))
         img = self._b16(B, T)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
@@ -363,7 +399,7 @@ class LSTMEncoderEngine(object):
             _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision, sc)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         gv["embed.weight"].zero_()
-        lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), s)
+        self._aux.join(x.device)                       # token sort queued by forward()
         lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(w.srows), P(w.stok), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
 
 
@@ -385,6 +421,7 @@ class LSTMDecoderEngine(object):
         self._side_ws = None
         self._pending = None
         self._scratch = _Scratch()
+        self._aux = _AuxStream()
 
     def _fork(self, device):
         """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
@@ -522,6 +559,7 @@ class LSTMDecoderEngine(object):
         if mask_out is not None:
             assert mask_out.dtype == torch.uint8 and tuple(mask_out.shape) == (B, Td, H) and mask_out.is_contiguous()
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
+        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s))
         # c0 = z W_trans^T ; h0 = tanh(c0)   (dec_lstm.py:99-101)
         _gemm(lib, s, 0, 1, B, H, nz, P(z2), nz, P(v["trans_linear.weight"]), nz, P(w.cs), H)
         lib.lv_tanh_f32(P(w.cs), P(w.hs), B * H, s)
@@ -609,7 +647,7 @@ class LSTMDecoderEngine(object):
             _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
             lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
             gv["embed.weight"].zero_()
-            lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), s2)
+            self._aux.join(dev)                        # token sort queued by forward()
             lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
                                      V - 1, 0, s2)
         self._mark_pending(dev)
