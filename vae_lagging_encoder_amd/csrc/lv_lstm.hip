@@ -529,7 +529,9 @@ int lstm_fwd_impl(const float* gx, const float* whh, float* hs, float* cs, float
     const Geo g = geo(B, H, BF);
     float* wp = ws;
     float* hp = ws + g.wp;
-    hipMemsetAsync(hp, 0, (size_t)g.hp * sizeof(float), (hipStream_t)stream);
+    // the packed state buffers carry zero padding for batch rows >= B and k >= H; with no padding every entry is written
+    // (pack_act for step 0, the step epilogues afterwards) before it is read, and the fill is skipped
+    if (g.MBTp * 16 != B || g.Kq * (BF ? 8 : 4) != H) hipMemsetAsync(hp, 0, (size_t)g.hp * sizeof(float), (hipStream_t)stream);
     if (BF) {
         LV_LAUNCH(pack_w_fwd_bf16_kernel, dim3((unsigned)lv_cdiv((long)g.NBf * g.Kq * 16, 256)), dim3(256), 0, stream, whh,
                   reinterpret_cast<uint4*>(wp), H, g.Kq);
@@ -567,7 +569,7 @@ int lstm_bwd_impl(const float* dh_ext, const float* dh_last, const uint8_t* dmas
                   reinterpret_cast<uint4*>(wpT), H, g.Kq4);
     else
         LV_LAUNCH(pack_w_bwd_kernel, dim3((unsigned)lv_cdiv((long)g.NBb * g.Kq4 * 16, 256)), dim3(256), 0, stream, whh, wpT, H, g.Kq4);
-    hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
+    if (g.MBTp * 16 != B || g.Kq4 * (BF ? 8 : 4) != 4 * H) hipMemsetAsync(dGp, 0, (size_t)g.dGp * sizeof(float), (hipStream_t)stream);
     LstmBwdP p{dh_ext, dh_last, dmask, dscale, wpT, gates, cs, dG, dGsum, dGp, part, dcrec, T, B, H, g.KS, g.Kq4, g.MBTp, dG16};
     const long BH = (long)B * H;
     const bool need_h0 = (dh0 != nullptr) || tanh_init;
