@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--persistent", type=int, default=1, help="forward LSTM recurrences as one persistent launch (bf16 path)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="decoder weight-gradient GEMMs on a side stream under the BPTT chains (auto: on for f32, off for bf16)")
     ap.add_argument("--pool", type=int, default=64)
@@ -165,6 +166,7 @@ def main():
                                precision=args.dtype)
     if args.overlap != "auto":
         tr.dec.overlap = (args.overlap == "on")
+    tr.enc.persistent = tr.dec.persistent = bool(args.persistent)
     pool = [synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
     rs = np.random.RandomState(783435)
     kl_weight = 0.1                                         # text.py default kl_start

@@ -78,6 +78,15 @@ int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, fl
  * lv_cvt_bf16_gates_f32 image of W_ih and lv_gate_interleave_f32-ed epilogue addends. */
 int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                         const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* The same forward recurrence as ONE persistent launch: 256 workgroups in 8 XCD-sized groups, each group carries a
+ * slice of the batch through all T steps with its slice of W_hh held in registers and hands h_t around inside the
+ * group through tagged 8-byte granules (lv_lstm_persist.hip).  gx unit-major as for lv_lstm_fwd_bf16_ug; ws of
+ * lv_lstm_persist_ws_floats() floats; *status (device int, zeroed by the caller) becomes non-zero if a hand-off timed
+ * out.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 64 and the device has >= 256 CUs: use lv_lstm_fwd_bf16_ug then. */
+long lv_lstm_persist_ws_floats(void);
+int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                             const uint8_t* dmask, float dscale, float* hdrop, float* ws, int* status,
+                             int T, int B, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,

@@ -1,0 +1,31 @@
+"""Microbenchmark (measurement tooling): forward LSTM recurrence, one persistent launch vs one launch per timestep."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from vae_lagging_encoder_amd import _lib
+from vae_lagging_encoder_amd.engine import P, stream_ptr
+dev = torch.device("cuda:0"); lib = _lib.load(); s = stream_ptr(dev)
+T, B, H = 200, 32, 1024
+gx = torch.randn(T, B, 4 * H, device=dev) * 0.5
+whh = torch.randn(4 * H, H, device=dev) / H ** 0.5
+hs = torch.zeros(T + 1, B, H, device=dev); cs = torch.zeros(T + 1, B, H, device=dev)
+gates = torch.empty(T, 4 * 64 * 64 * 8 * 8, device=dev)   # oversized: also holds the ABL=8 experiment's log records
+hdrop = torch.empty(T, B, H, device=dev)
+mask = (torch.rand(B, T, H, device=dev) < 0.5).to(torch.uint8)
+wsp = torch.empty(lib.lv_lstm_persist_ws_floats(), device=dev)
+ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
+st = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def t(f, n=10):
+    for _ in range(3): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+a = t(lambda: lib.lv_lstm_fwd_bf16_ug(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(ws), T, B, H, s))
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
+print("launch per step : %8.1f us  (%.2f us/step)" % (a, a / T))
+print("persistent      : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))

@@ -313,6 +313,61 @@ def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ex
     test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="bf16_img")
 
 
+@pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
+def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
+    """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
+    and against the launch-per-step kernel fed the same unit-major gx."""
+    if hip_device.type != "cuda":
+        pytest.skip("spin-synchronised persistent kernel: not runnable on the emulator")
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(T * 100 + B)
+    gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    h0 = torch.tanh(c0)
+    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(dev)
+    hs_r, cs_r, out_r = _lstm_ref(gx.double(), whh.double(), h0.double(), c0.double(), mask if use_mask else None, 2.0)
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1).to(dev)
+    gxu = gx[:, :, perm].contiguous()
+    m8 = mask.to(torch.uint8).contiguous()
+    res = []
+    for persistent in (True, False):
+        hs = torch.zeros(T + 1, B, H, device=dev)
+        cs = torch.zeros(T + 1, B, H, device=dev)
+        hs[0], cs[0] = h0, c0
+        gates = torch.empty(T, B, 4 * H, device=dev)
+        hdrop = torch.empty(T, B, H, device=dev)
+        if persistent:
+            ws = torch.full((lib.lv_lstm_persist_ws_floats(),), float("nan"), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.lv_lstm_fwd_bf16_persist(P(gxu), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
+                                         P(ws), P(status), T, B, H, _s(dev))
+            assert int(status.item()) == 0
+        else:
+            ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
+            lib.lv_lstm_fwd_bf16_ug(P(gxu), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
+                                    P(ws), T, B, H, _s(dev))
+        tol = 300.0
+        assert float((hs.double() - hs_r).abs().max()) < 2e-5 * tol
+        assert float((cs.double() - cs_r).abs().max()) < 2e-5 * tol
+        assert float((hdrop.double() - out_r).abs().max()) < 4e-5 * tol
+        res.append((hs.clone(), cs.clone(), gates.clone()))
+    # the two realisations differ only in f32 summation order of the recurrent product (and what that flips downstream)
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) < 6e-3
+
+
+def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):
+    if hip_device.type != "cuda":
+        pytest.skip("GPU only")
+    z = torch.zeros(1 << 16, device=hip_device)
+    st = torch.zeros(1, dtype=torch.int32, device=hip_device)
+    with pytest.raises(_lib.LvaeError):      # H != 1024
+        lib.lv_lstm_fwd_bf16_persist(P(z), P(z), P(z), P(z), P(z), None, 1.0, None, P(z), P(st), 1, 4, 64, _s(hip_device))
+    with pytest.raises(_lib.LvaeError):      # B > 64
+        lib.lv_lstm_fwd_bf16_persist(P(z), P(z), P(z), P(z), P(z), None, 1.0, None, P(z), P(st), 1, 65, 1024, _s(hip_device))
+
+
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),
                                               (200, 128, 64, 300, True)])
 def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):

@@ -26,6 +26,8 @@ SIGNATURES = {
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "lv_lstm_persist_ws_floats": [],
+    "lv_lstm_fwd_bf16_persist": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_transpose_ld_f32": [_vp, _l, _vp, _l, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],
@@ -93,12 +95,13 @@ class Lib(object):
                 missing.append(name)
                 continue
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_long if name == "lv_lstm_ws_floats" else ctypes.c_int
+            fn.restype = ctypes.c_long if name in ("lv_lstm_ws_floats", "lv_lstm_persist_ws_floats") else ctypes.c_int
             setattr(self, "_raw_" + name, fn)
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats"}
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+                           "lv_lstm_persist_ws_floats"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

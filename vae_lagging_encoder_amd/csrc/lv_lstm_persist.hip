@@ -1,0 +1,288 @@
+// lv_lstm_persist.hip -- the LSTM forward recurrence as ONE persistent launch (bf16 recurrent operands, H = 1024).
+//
+// lv_lstm.hip pays one kernel boundary per timestep and re-reads its slice of W_hh from L2 / Infinity Cache every step
+// (measured: ~4.1 us per forward step, of which ~1 us is useful work).  Here the chip is cut along its XCDs instead:
+//
+//   * 256 workgroups, one per CU, in 8 groups of 32 (group = blockIdx % 8: one XCD under the usual round-robin
+//     placement -- only speed depends on that, never correctness).  A group owns a slice of the BATCH (rows
+//     [g*R, g*R+R), R = ceil(B/8) <= 8) and carries it through all T steps on its own; groups never talk.
+//   * inside a group the 4H gate columns are split 128 ways: a wave owns 8 hidden units = 32 gate columns and keeps
+//     its 32 x 1024 slice of W_hh in REGISTERS for the whole call (64 KB = 256 VGPRs per lane; one wave per SIMD), so
+//     after the prologue no weight byte moves again.
+//   * per step the only traffic is the hand-off of h_t inside the group: R x 1024 bf16 published as 8-byte
+//     {2 x bf16, tag} granules with agent-scope relaxed 64-bit stores (write-through) and gathered by polling the
+//     tags -- each of a workgroup's 4 waves gathers a quarter into LDS.  profiles/microbench/xcd_gather_probe.hip
+//     measures this exchange at 1.7 us per step (8 KB per group), against 4.1 us for a launch-per-step.
+//   * a wave's MFMA output is exactly the gate pre-activations of its own units, so sigma/tanh, the cell update, the
+//     gate records for BPTT and the decoder's output dropout run in its epilogue as in lstm_step_fwd_kernel; the cell
+//     state never leaves the owning lane's registers.
+//
+// Every spin is bounded: a workgroup that waits longer than ~1 s raises *status and the whole launch drains.
+// Requirements (else LV_ERR_UNSUPPORTED and the caller uses the launch-per-step kernels): H == 1024, B <= 64,
+// a 256-CU device (all 256 workgroups must be resident at once), gx in unit-major column order.
+#include "lv_device.h"
+#include <stdlib.h>
+
+#ifndef LV_EMU   // the CI emulator runs workgroups one after another: spin-synchronised persistent kernels cannot run there
+
+namespace {
+
+constexpr int PH = 1024;            // hidden size this kernel is built for
+constexpr int PKS = PH / 32;        // MFMA k-steps per product
+constexpr int PGROUPS = 8;
+constexpr int PMEMBERS = 32;        // workgroups per group
+constexpr int PUW = 8;              // hidden units per wave
+constexpr int HPITCH = PH / 2 + 16; // LDS row pitch of the gathered h image in dwords: rows 16 banks apart, so the A-fragment
+                                    // reads of 4 rows x 4 k-quads hit 16 distinct bank groups
+constexpr int PRMAX = 8;            // batch rows per group this build supports (LDS: 2 x PRMAX x HPITCH dwords)
+constexpr int SPIN_LIMIT = 1 << 22;
+
+typedef unsigned long long gran_t;  // (tag << 32) | two bf16
+
+__device__ __forceinline__ gran_t gran_load(const gran_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_store(gran_t* p, gran_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wpk[wave_id (128)][ks (32)][nb (2)][lane (64)] : lane (c = l&15, kq = l>>4) holds W_hh[gate*H + unit][32ks + 8kq .. +7]
+// with unit = 8*wave_id + 4*nb + (c>>2), gate = c&3 -- the B operand of v_mfma_f32_16x16x32_bf16 for that column.
+__global__ __launch_bounds__(256) void pack_w_persist_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * PKS * 2 * 64) return;
+    const int l = (int)(idx & 63);
+    const int nb = (int)((idx >> 6) & 1);
+    const int ks = (int)((idx >> 7) % PKS);
+    const int wave_id = (int)(idx / (64L * 2 * PKS));
+    const int c = l & 15, kq = l >> 4;
+    const int unit = PUW * wave_id + 4 * nb + (c >> 2), gate = c & 3;
+    const float* row = whh + ((long)gate * PH + unit) * PH + 32 * ks + 8 * kq;
+    wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
+                          lv_pack_bf16x2(row[6], row[7]));
+}
+
+struct PersistFwdP {
+    const float* gx;            // [T][B][H][4] unit-major gate pre-activations (input projection + biases)
+    const uint4* wpk;
+    float* hs; float* cs;       // [T+1][B][H], index 0 = initial state
+    float* gates;               // [T][B][H][4] records for BPTT
+    const uint8_t* dmask; float dscale; float* hdrop;
+    gran_t* hx;                 // exchange: [2 parity][8 groups][16 rows][H/2] granules, zeroed before the launch
+    int* status;
+    int T, B, R;
+};
+
+constexpr int SB = 8;               // timesteps per I/O block (see below)
+
+// ABL (profiles/microbench only, product = 0): 1 = no MFMAs, 2 = no result stores, 4 = no gx / mask loads
+//
+// Global loads and stores of a wave retire in order on gfx9 (one vmcnt), so ANY load or store issued inside a step
+// ends up in front of the next hand-off poll and the poll waits for it (measured: +2.3 us per step for the result
+// stores alone).  The recurrence therefore does its bulk I/O in blocks of SB steps: the gate pre-activations of the
+// next block are fetched and the results of the previous block are written at block boundaries, and in between a
+// step touches global memory for the hand-off only.  Each lane owns ONE (batch row, unit) pair for the whole call.
+template <int ABL>
+__global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
+    __shared__ __attribute__((aligned(16))) uint32_t hl[2][PRMAX * HPITCH];   // gathered h_{t-1}, [parity][row][k/2]
+    __shared__ float pre[4][16][33];                                         // per wave: MFMA tile [row][col]
+    __shared__ int s_abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);          // valid batch rows of this group
+    if (rows == 0) return;                                                    // (uniform per group: nobody waits on it)
+    if (tid == 0) s_abort = 0;
+
+    // ---- weights: registers for the whole call --------------------------------------------------------------------------
+    uint4 wreg[PKS][2];
+    {
+        const uint4* wp = p.wpk + (long)wave_id * PKS * 2 * 64 + l;
+#pragma unroll
+        for (int ks = 0; ks < PKS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wreg[ks][nb] = wp[(ks * 2 + nb) * 64];
+    }
+
+    // ---- this lane's (row, unit) pair -------------------------------------------------------------------------------------
+    const int prow = l >> 3, ul = l & 7;
+    const int punit = PUW * wave_id + ul;
+    const bool own = prow < rows;
+    const long BH = (long)B * PH;
+    const long pidx = (long)(b0 + (own ? prow : 0)) * PH + punit;          // index into a [B][H] slab
+    float c_state = own ? p.cs[pidx] : 0.f;
+    gran_t* const hx_g = p.hx + (long)group * 16 * (PH / 2);
+    const long hx_par = (long)PGROUPS * 16 * (PH / 2);
+    gran_t* const my_gran = hx_g + (long)prow * (PH / 2) + (punit >> 1);
+    const bool publisher = own && !(ul & 1);
+
+    {   // publish the initial state hs[0] as state 0 (tag 1)
+        const uint32_t mine = lv_f32_to_bf16_bits(own ? p.hs[pidx] : 0.f);
+        const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+        if (publisher) gran_store(my_gran, ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
+    }
+
+    float4 gxb[SB];                  // gate pre-activations of the current block's steps
+    float keepb[SB];
+    float4 recb[SB];                 // results of the current block: gate record, c, h, dropped h
+    float cb[SB], hb[SB], hdb[SB];
+    auto load_block = [&](int tb) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            gxb[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            keepb[s2] = 1.f;
+            if (own && t < T && !(ABL & 4)) {
+                gxb[s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx) * 4);
+                if (p.hdrop && p.dmask) keepb[s2] = p.dmask[((long)(b0 + prow) * T + t) * PH + punit] ? p.dscale : 0.f;
+            }
+        }
+    };
+    auto store_block = [&](int tb) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            if (own && t < T && !(ABL & 2)) {
+                *reinterpret_cast<float4*>(p.gates + ((long)t * BH + pidx) * 4) = recb[s2];
+                p.cs[(long)(t + 1) * BH + pidx] = cb[s2];
+                p.hs[(long)(t + 1) * BH + pidx] = hb[s2];
+                if (p.hdrop) p.hdrop[(long)t * BH + pidx] = hdb[s2];
+            }
+        }
+    };
+    load_block(0);
+    __syncthreads();
+
+    // A-operand rows beyond the group's batch rows read a valid LDS row (row 0): their products land in MFMA output rows
+    // nobody owns, so no predicate sits between the LDS reads and the MFMAs
+    const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
+    const int ngran = rows * (PH / 2);                 // granules of one state of this group
+    const int gq = (ngran + 3) / 4;                    // this wave gathers granules [w*gq, w*gq + gq)
+
+    for (int tb = 0; tb < T; tb += SB) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            if (t >= T) break;
+            // ---- gather state t (tag t+1) of the whole group into LDS ---------------------------------------------------
+            const gran_t* src = hx_g + (long)(t & 1) * hx_par;
+            uint32_t* dst = hl[t & 1];
+            const uint32_t want = (uint32_t)(t + 1);
+            for (int base = w * gq; base < w * gq + gq; base += 64 * 8) {
+                gran_t v[8];
+                int spins = 0;
+                bool ok;
+                do {
+                    ok = true;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int idx = base + j * 64 + l;
+                        const bool in = idx < w * gq + gq && idx < ngran;
+                        v[j] = gran_load(src + (in ? idx : 0));          // out-of-range lanes re-read granule 0: no branch
+                        ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
+                    }
+                    ok = __all(ok);
+                    if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                } while (!ok);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = base + j * 64 + l;
+                    if (idx < w * gq + gq && idx < ngran) dst[(idx >> 9) * HPITCH + (idx & 511)] = (uint32_t)v[j];
+                }
+            }
+            __syncthreads();
+            if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
+
+            // ---- recurrent product: this wave's 32 gate columns, K from LDS x registers ---------------------------------
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const uint4* arowp = reinterpret_cast<const uint4*>(dst + arow * HPITCH) + kq;
+#pragma unroll
+            for (int ks = 0; ks < PKS; ++ks) {
+                const uint4 a = arowp[ks * 4];
+                if (ABL & 1) {
+                    acc[(ks & 1) * 2 + 0][0] += (float)((a.x ^ wreg[ks][0].x) & 0xFF);
+                    acc[(ks & 1) * 2 + 1][0] += (float)((a.y ^ wreg[ks][1].y) & 0xFF);
+                } else {
+                    acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
+                    acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): wave-private tile, the wave's own LDS accesses are ordered
+
+            // ---- epilogue: gates, cell update, hand-off of h_t ------------------------------------------------------------
+            float h = 0.f;
+            if (own) {
+                const float* pr = &pre[w][prow][4 * ul];
+                const float ig = lv_sigmoid_fast(gxb[s2].x + pr[0]), fg = lv_sigmoid_fast(gxb[s2].y + pr[1]);
+                const float gg = lv_tanh_fast(gxb[s2].z + pr[2]), og = lv_sigmoid_fast(gxb[s2].w + pr[3]);
+                const float c = fg * c_state + ig * gg;
+                h = og * lv_tanh_fast(c);
+                c_state = c;
+                recb[s2] = make_float4(ig, fg, gg, og);
+                cb[s2] = c; hb[s2] = h; hdb[s2] = h * keepb[s2];
+            }
+            const uint32_t mine = lv_f32_to_bf16_bits(h);
+            const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+            if (publisher)
+                gran_store(my_gran + (long)((t + 1) & 1) * hx_par, ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
+        }
+        // ---- block boundary: the only bulk global traffic of the recurrence ---------------------------------------------
+        store_block(tb);
+        load_block(tb + SB);
+    }
+}
+
+}  // namespace
+
+extern "C" long lv_lstm_persist_ws_floats(void) {
+    return (128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * 16 * (PH / 2) * 8) / 4 + 64;
+}
+
+// Forward recurrence in one persistent launch.  Arguments as lv_lstm_fwd_bf16_ug (gx unit-major) plus ws of
+// lv_lstm_persist_ws_floats() floats and a device status word (0 = ok; written non-zero if a hand-off timed out).
+extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                                        const uint8_t* dmask, float dscale, float* hdrop, float* ws, int* status,
+                                        int T, int B, int H, void* stream) {
+    if (!gx || !whh || !hs || !cs || !gates || !ws || !status) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (dmask && !hdrop) return LV_ERR_ARG;
+    if (H != PH || B > PRMAX * PGROUPS) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0) return LV_ERR_ALIGN;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return LV_ERR_UNSUPPORTED;
+    if (cus < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
+    if (T == 0) return LV_OK;
+    uint4* wpk = reinterpret_cast<uint4*>(ws);
+    gran_t* hx = reinterpret_cast<gran_t*>(ws + 128L * PKS * 2 * 64 * 4);
+    LV_LAUNCH(pack_w_persist_kernel, dim3((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), dim3(256), 0, stream, whh, wpk);
+    hipMemsetAsync(hx, 0, (size_t)2 * PGROUPS * 16 * (PH / 2) * sizeof(gran_t), (hipStream_t)stream);
+    const int R = (B + PGROUPS - 1) / PGROUPS;
+    PersistFwdP p{gx, wpk, hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
+    const char* abl = getenv("LVAE_PERSIST_ABL");          // measurement knob (profiles/microbench/lstm_persist_probe.py)
+    const int a = abl ? atoi(abl) : 0;
+    const dim3 grid(PGROUPS * PMEMBERS), block(256);
+    if (a == 1) LV_LAUNCH(lstm_fwd_persist_kernel<1>, grid, block, 0, stream, p);
+    else if (a == 2) LV_LAUNCH(lstm_fwd_persist_kernel<2>, grid, block, 0, stream, p);
+    else if (a == 4) LV_LAUNCH(lstm_fwd_persist_kernel<4>, grid, block, 0, stream, p);
+    else if (a == 7) LV_LAUNCH(lstm_fwd_persist_kernel<7>, grid, block, 0, stream, p);
+    else LV_LAUNCH(lstm_fwd_persist_kernel<0>, grid, block, 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+#else   // LV_EMU
+
+extern "C" long lv_lstm_persist_ws_floats(void) { return 64; }
+extern "C" int lv_lstm_fwd_bf16_persist(const float*, const float*, float*, float*, float*, const uint8_t*, float, float*,
+                                        float*, int*, int, int, int, void*) {
+    return LV_ERR_UNSUPPORTED;
+}
+
+#endif

@@ -141,6 +141,7 @@ class _prof(object):
 
 
 _GEMM_WS = {}
+_PERSISTENT_DEFAULT = True
 
 
 def _gemm_ws(lib, s):
@@ -206,6 +207,28 @@ class _AuxStream(object):
         if self.done is not None:
             torch.cuda.current_stream(torch.device(device)).wait_event(self.done)
             self.done = None
+
+
+_PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
+_PERSIST_MAX_B = 64
+
+
+def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, device):
+    """The forward recurrence of one LSTM layer: exact f32, bf16 launch-per-step, or (bf16 image path on a >= 256-CU
+    device, H = 1024, B <= 64) the single persistent launch of lv_lstm_persist.hip."""
+    args = (Gx, whh, P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop)
+    if eng.precision != "bf16":
+        lib.lv_lstm_fwd_f32(*args, P(w.lstm_ws), T, B, H, s)
+    elif img is None:
+        lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
+    elif eng.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and torch.device(device).type == "cuda" \
+            and torch.cuda.get_device_properties(device).multi_processor_count >= 256:
+        if getattr(w, "persist_ws", None) is None:
+            w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
+            w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
+        lib.lv_lstm_fwd_bf16_persist(*args, P(w.persist_ws), P(w.persist_status), T, B, H, s)
+    else:
+        lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
 
 class _LstmImages(object):
@@ -285,6 +308,7 @@ class LSTMEncoderEngine(object):
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
+        self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
         self._scratch = _Scratch()
         self._aux = _AuxStream()
 
@@ -357,9 +381,8 @@ class LSTMEncoderEngine(object):
                   prec=self.precision, **biases)
         w.hs[0].zero_()
         w.cs[0].zero_()
-        fwd = lib.lv_lstm_fwd_f32 if self.precision != "bf16" else (lib.lv_lstm_fwd_bf16_ug if img is not None else lib.lv_lstm_fwd_bf16)
         with _prof("lstm_fwd", float(T), T):
-            fwd(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
+            _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
@@ -417,6 +440,7 @@ class LSTMDecoderEngine(object):
         # dW_hh / embedding scatter under the encoder's backward).  join() orders them before anything reads the grads.
         self.overlap = None       # None = auto policy (_overlap_on); True / False force it
         self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
+        self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
         self._side = None
         self._side_ws = None
         self._pending = None
@@ -573,10 +597,8 @@ class LSTMDecoderEngine(object):
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
-        fwd = lib.lv_lstm_fwd_f32 if self.precision != "bf16" else (lib.lv_lstm_fwd_bf16_ug if img is not None else lib.lv_lstm_fwd_bf16)
         with _prof("lstm_fwd", float(Td), Td):
-            fwd(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), P(mask_out), sc_out,
-                P(w.O), P(w.lstm_ws), Td, B, H, s)
+            _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), P(mask_out), sc_out, P(w.O), Td, B, H, x.device)
         b16 = self._b16(B, Td)
         if b16 is not None:
             lib.lv_cvt_bf16_f32(P(w.O), H, Td * B, H, P(b16.O), H, P(b16.OT), b16.ldr, s)
