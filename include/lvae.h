@@ -87,6 +87,13 @@ long lv_lstm_persist_ws_floats(void);
 int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                              const uint8_t* dmask, float dscale, float* hdrop, float* ws, int* status,
                              int T, int B, int H, void* stream);
+/* BPTT as one persistent launch (same decomposition; dG[t] is what travels between steps and the gate-gradient math of
+ * a step runs where its dh is completed, so a timestep is one phase instead of two launches).  Arguments as
+ * lv_lstm_bwd_bf16_img plus ws / status as above.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 32, >= 256 CUs. */
+int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                             const float* whh, const float* gates, const float* hs, const float* cs,
+                             float* dG, uint16_t* dG16, float* dGsum, float* ws, int* status, float* dh0, float* dc0,
+                             int tanh_init, int T, int B, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,

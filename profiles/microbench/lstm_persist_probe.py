@@ -29,3 +29,14 @@ a = t(lambda: lib.lv_lstm_fwd_bf16_ug(P(gx), P(whh), P(hs), P(cs), P(gates), P(m
 b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
 print("launch per step : %8.1f us  (%.2f us/step)" % (a, a / T))
 print("persistent      : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+
+# ---- BPTT: one persistent launch vs elementwise + split-K matmul launches per step -------------------------------------
+gates_std = torch.empty(T, B, 4 * H, device=dev)
+lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates_std), P(mask), 2.0, P(hdrop), P(ws), T, B, H, s)
+dO = torch.randn(T, B, H, device=dev)
+dG16 = torch.empty(T, B, 4 * H, dtype=torch.int16, device=dev)
+dGsum = torch.empty(B, 4 * H, device=dev); dc0 = torch.empty(B, H, device=dev)
+a = t(lambda: lib.lv_lstm_bwd_bf16_img(P(dO), None, P(mask), 2.0, P(whh), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(ws), None, P(dc0), 1, T, B, H, s))
+b = t(lambda: lib.lv_lstm_bwd_bf16_persist(P(dO), None, P(mask), 2.0, P(whh), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
+print("BPTT two launches per step : %8.1f us  (%.2f us/step)" % (a, a / T))
+print("BPTT persistent            : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))

@@ -357,6 +357,72 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
         assert float((a - b).abs().max()) < 6e-3
 
 
+@pytest.mark.parametrize("T,B,use_mask,tanh_init,use_ext,use_last", [
+    (6, 32, True, True, True, False), (1, 5, False, False, True, True), (9, 32, True, False, True, True),
+    (40, 32, False, True, True, False), (3, 13, True, True, True, True), (17, 8, False, False, False, True),
+])
+def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last):
+    """The one-launch persistent BPTT (H = 1024) against the float64 autograd of the same recurrence (bf16-recurrence
+    tolerance) and against the two-launch-per-step kernels on the same saved activations."""
+    if hip_device.type != "cuda":
+        pytest.skip("spin-synchronised persistent kernel: not runnable on the emulator")
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(T * 100 + B + 7)
+    gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(dev)
+    wext = torch.randn(T, B, H, generator=g).to(dev)
+    wlast = torch.randn(B, H, generator=g).to(dev)
+    gx64 = gx.double().requires_grad_(True)
+    c064 = c0.double().requires_grad_(True)
+    h064 = torch.tanh(c064) if tanh_init else torch.zeros_like(c064)
+    hs_r, cs_r, out_r = _lstm_ref(gx64, whh.double(), h064, c064, mask if use_mask else None, 2.0)
+    loss = 0
+    if use_ext:
+        loss = loss + (out_r * wext.double()).sum()
+    if use_last:
+        loss = loss + (hs_r[-1] * wlast.double()).sum()
+    loss.backward()
+    hs = torch.zeros(T + 1, B, H, device=dev)
+    cs = torch.zeros(T + 1, B, H, device=dev)
+    hs[0], cs[0] = h064.detach().float(), c0
+    gates = torch.empty(T, B, 4 * H, device=dev)
+    hdrop = torch.empty(T, B, H, device=dev)
+    m8 = mask.to(torch.uint8).contiguous()
+    ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
+    lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
+    common = (P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+              P(whh), P(gates), P(hs), P(cs))
+    outs = []
+    for persistent in (True, False):
+        dG = torch.empty(T, B, 4 * H, device=dev)
+        dG16 = torch.full((T, B, 4 * H), 0x7FC0, dtype=torch.int16, device=dev)
+        dGsum = torch.full((B, 4 * H), 7.0, device=dev)
+        dh0 = torch.empty(B, H, device=dev)
+        dc0 = torch.empty(B, H, device=dev)
+        if persistent:
+            wsp = torch.full((lib.lv_lstm_persist_ws_floats(),), float("nan"), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.lv_lstm_bwd_bf16_persist(*common, P(dG), P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init),
+                                         T, B, H, _s(dev))
+            assert int(status.item()) == 0
+        else:
+            ws.fill_(float("nan"))
+            lib.lv_lstm_bwd_bf16_img(*common, P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
+        assert torch.equal(dG16.cpu(), dG.cpu().to(torch.bfloat16).view(torch.int16))
+        sc, tol = float(gx64.grad.abs().max()), 300.0
+        assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc * tol
+        assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T * tol
+        assert float((dc0.double() - c064.grad).abs().max()) < 1e-4 * float(c064.grad.abs().max()) * tol
+        if not tanh_init:
+            ref_dh0 = gx64.grad[0] @ whh.double()
+            assert float((dh0.double() - ref_dh0).abs().max()) < 1e-4 * float(ref_dh0.abs().max()) * tol
+        outs.append((dG.clone(), dGsum.clone(), dc0.clone()))
+    sc = float(outs[1][0].abs().max())
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
+
+
 def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):
     if hip_device.type != "cuda":
         pytest.skip("GPU only")

@@ -238,10 +238,268 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
     }
 }
 
+// =====================================================================================================================
+// BPTT as one persistent launch.  Same decomposition (8 groups x 32 workgroups, a group owns a batch slice), mirrored:
+// what travels between steps is dG[t] (4 gate gradients per unit), published by the lane that computed it as two 8-byte
+// granules and gathered by every workgroup of the group into an LDS image [row][4H] in UNIT-major K order (n' = 4u + g).
+// A workgroup owns 32 hidden units j; its 4 waves split the contraction over n' into quarters and each keeps its
+// 1024 x 32 slice of W_hh in registers (64 KB, as in the forward kernel).  The quarter products are summed through LDS,
+// and since the workgroup now holds dh_{t-1} for its units COMPLETELY, the gate-gradient math of step t-1 runs right
+// there: one phase per timestep instead of two launches (elementwise + split-K matmul).  Bulk I/O in SB-step blocks
+// as in the forward kernel.  H == 1024, at most 4 batch rows per group (B <= 32).
+constexpr int BR = 4;                            // batch rows per group (LDS image: BR x 4H bf16)
+constexpr int GPITCH = 2 * PH + 16;              // dwords per image row (4H bf16 = 2H dwords, + bank-spreading pad)
+
+// Wpb[wave_id (128)][ks (32)][nb (2)][lane (64)]: wave (m, w) = workgroup m's K-quarter w; lane (c, kq) holds, for column
+// unit j = 32m + 16nb + c, the 8 weights W_hh[gate*H + unit][j] of n' = 1024w + 32ks + 8kq + e (unit = n' >> 2, gate = n' & 3)
+__global__ __launch_bounds__(256) void pack_w_persist_bwd_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * PKS * 2 * 64) return;
+    const int l = (int)(idx & 63);
+    const int nb = (int)((idx >> 6) & 1);
+    const int ks = (int)((idx >> 7) % PKS);
+    const int wave_id = (int)(idx / (64L * 2 * PKS));
+    const int m = wave_id >> 2, w = wave_id & 3;
+    const int c = l & 15, kq = l >> 4;
+    const int j = 32 * m + 16 * nb + c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int np = 1024 * w + 32 * ks + 8 * kq + e;
+        v[e] = whh[((long)(np & 3) * PH + (np >> 2)) * PH + j];
+    }
+    wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+
+struct PersistBwdP {
+    const float* dh_ext; const float* dh_last; const uint8_t* dmask; float dscale;
+    const uint4* wpk;
+    const float* gates; const float* cs; const float* hs;
+    float* dG; uint16_t* dG16; float* dGsum;
+    float* dh0; float* dc0; int tanh_init;
+    gran_t* gxch;               // exchange: [2 parity][8 groups][BR rows][2H] granules, zeroed before the launch
+    int* status;
+    int T, B, R;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
+    __shared__ __attribute__((aligned(16))) uint32_t gl[BR * GPITCH];        // gathered dG[t+1], [row][n'/2]
+    __shared__ float red[4][16][33];                                         // per wave: quarter product [row][unit]
+    __shared__ int s_abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    if (rows == 0) return;
+    if (tid == 0) s_abort = 0;
+
+    uint4 wreg[PKS][2];
+    {
+        const uint4* wp = p.wpk + (long)wave_id * PKS * 2 * 64 + l;
+#pragma unroll
+        for (int ks = 0; ks < PKS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wreg[ks][nb] = wp[(ks * 2 + nb) * 64];
+    }
+
+    // this lane's (row, unit) pair: lanes 0..31 of each wave, unit = 32*member + 8*w + (l & 7)
+    const int prow = (l >> 3) & 3, ul = l & 7;
+    const int uw = 8 * w + ul;                                               // unit within the workgroup
+    const int punit = 32 * member + uw;
+    const bool own = l < 32 && prow < rows;
+    const long BH = (long)B * PH;
+    const long pidx = (long)(b0 + (own ? prow : 0)) * PH + punit;
+    gran_t* const gx_g = p.gxch + (long)group * BR * (2 * PH);
+    const long gx_par = (long)PGROUPS * BR * (2 * PH);
+    gran_t* const my_gran = gx_g + (long)prow * (2 * PH) + 2 * punit;       // granules (i,f) and (g,o) of this pair
+
+    float dc_rec = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float dhb[SB], keepb[SB], ctb[SB + 1];
+    float4 recb[SB];
+    uint32_t outb[SB][2];            // bf16 pairs (i,f), (g,o) of the block's steps, stored at the block boundary
+    float outf[SB][4];
+    auto load_block = [&](int t_hi) {            // steps t_hi, t_hi-1, ..., t_hi-SB+1
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = t_hi - s2;
+            dhb[s2] = 0.f; keepb[s2] = 1.f; recb[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (own && t >= 0) {
+                if (p.dh_ext) dhb[s2] = p.dh_ext[(long)t * BH + pidx];
+                if (p.dh_ext && p.dmask) keepb[s2] = p.dmask[((long)(b0 + prow) * T + t) * PH + punit] ? p.dscale : 0.f;
+                recb[s2] = *reinterpret_cast<const float4*>(p.gates + ((long)t * BH + pidx) * 4);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 <= SB; ++s2) {        // ctb[s2] = c of step t_hi - s2 (= cs[t+1]); ctb[s2+1] is that step's c_{t-1}
+            const int t = t_hi - s2;
+            ctb[s2] = (own && t + 1 >= 0) ? p.cs[(long)(t + 1) * BH + pidx] : 0.f;
+        }
+    };
+    auto store_block = [&](int t_hi) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = t_hi - s2;
+            if (own && t >= 0) {
+                const long gi = (long)t * B * 4 * PH + (long)(b0 + prow) * 4 * PH + punit;
+                if (p.dG16) {
+                    p.dG16[gi] = (uint16_t)(outb[s2][0] & 0xFFFFu);
+                    p.dG16[gi + PH] = (uint16_t)(outb[s2][0] >> 16);
+                    p.dG16[gi + 2L * PH] = (uint16_t)(outb[s2][1] & 0xFFFFu);
+                    p.dG16[gi + 3L * PH] = (uint16_t)(outb[s2][1] >> 16);
+                }
+                if (p.dG) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) p.dG[gi + (long)g * PH] = outf[s2][g];
+                }
+            }
+        }
+    };
+    load_block(T - 1);
+    __syncthreads();
+
+    const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
+    const int ngran = rows * 2 * PH;                   // granules of one dG image of this group (row pitch 2H granules)
+    const int gq = (ngran + 3) / 4;
+
+    // one recurrent phase: gather the image tagged `want`, contract it with this workgroup's columns, leave the summed
+    // dh for (row, unit) pairs in `dh_rec` of the owning lanes.  Returns false on a hand-off timeout.
+    auto recurrent = [&](uint32_t want, float& dh_rec) -> bool {
+        const gran_t* src = gx_g + (long)(want & 1) * gx_par;
+        for (int base = w * gq; base < w * gq + gq; base += 64 * 8) {
+            gran_t v[8];
+            int spins = 0;
+            bool ok;
+            do {
+                ok = true;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = base + j * 64 + l;
+                    const bool in = idx < w * gq + gq && idx < ngran;
+                    v[j] = gran_load(src + (in ? idx : 0));
+                    ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
+                }
+                ok = __all(ok);
+                if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+            } while (!ok);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = base + j * 64 + l;
+                if (idx < w * gq + gq && idx < ngran) gl[(idx >> 11) * GPITCH + (idx & 2047)] = (uint32_t)v[j];
+            }
+        }
+        __syncthreads();
+        if (s_abort) return false;
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const uint4* arowp = reinterpret_cast<const uint4*>(gl + arow * GPITCH + 512 * w) + kq;     // K-quarter w: 1024 n' = 512 dwords
+#pragma unroll
+        for (int ks = 0; ks < PKS; ++ks) {
+            const uint4 a = arowp[ks * 4];
+            acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
+            acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
+        __syncthreads();                               // quarter products of all 4 waves; also: everyone is done reading gl
+        dh_rec = (red[0][prow][uw] + red[1][prow][uw]) + (red[2][prow][uw] + red[3][prow][uw]);
+        return true;
+    };
+
+    for (int t_hi = T - 1; t_hi >= 0; t_hi -= SB) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = t_hi - s2;
+            if (t < 0) break;
+            float dh_rec = 0.f;
+            if (t < T - 1) {
+                if (!recurrent((uint32_t)(T - 1 - t), dh_rec)) { if (tid == 0) atomicExch(p.status, 200 + t); return; }
+            }
+            float da[4] = {0.f, 0.f, 0.f, 0.f};
+            if (own) {
+                float dh = dhb[s2] * keepb[s2] + dh_rec;
+                if (t == T - 1 && p.dh_last) dh += p.dh_last[pidx];
+                const float ig = recb[s2].x, fg = recb[s2].y, gg = recb[s2].z, og = recb[s2].w;
+                const float tc = lv_tanh_fast(ctb[s2]);
+                const float dc = dh * og * (1.f - tc * tc) + dc_rec;
+                const float d_o = dh * tc;
+                const float d_i = dc * gg, d_g = dc * ig, d_f = dc * ctb[s2 + 1];
+                da[0] = d_i * ig * (1.f - ig);
+                da[1] = d_f * fg * (1.f - fg);
+                da[2] = d_g * (1.f - gg * gg);
+                da[3] = d_o * og * (1.f - og);
+                dc_rec = dc * fg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { gsum[g] += da[g]; outf[s2][g] = da[g]; }
+            }
+            const uint32_t lo = lv_pack_bf16x2(da[0], da[1]), hi = lv_pack_bf16x2(da[2], da[3]);
+            outb[s2][0] = lo; outb[s2][1] = hi;
+            if (own) {      // hand dG[t] to the group: tag T - t, parity (T - t) & 1
+                gran_t* dst = my_gran + (long)((T - t) & 1) * gx_par;
+                const gran_t tag = (gran_t)(uint32_t)(T - t) << 32;
+                gran_store(dst, tag | (gran_t)lo);
+                gran_store(dst + 1, tag | (gran_t)hi);
+            }
+        }
+        store_block(t_hi);
+        load_block(t_hi - SB);
+    }
+
+    // closing phase: dh0 = dG[0] . W_hh, dc0 = dc_rec (+ dh0 * (1 - h0^2) when h0 = tanh(c0))
+    if (own) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.dGsum[(long)(b0 + prow) * 4 * PH + (long)g * PH + punit] = gsum[g];
+    }
+    if (p.dh0 || p.tanh_init) {
+        float s0 = 0.f;
+        if (!recurrent((uint32_t)T, s0)) { if (tid == 0) atomicExch(p.status, 300); return; }
+        if (own) {
+            if (p.dh0) p.dh0[pidx] = s0;
+            float dc = dc_rec;
+            if (p.tanh_init) { const float h0 = p.hs[pidx]; dc += s0 * (1.f - h0 * h0); }
+            if (p.dc0) p.dc0[pidx] = dc;
+        }
+    } else if (own && p.dc0) {
+        p.dc0[pidx] = dc_rec;
+    }
+}
+
 }  // namespace
 
 extern "C" long lv_lstm_persist_ws_floats(void) {
-    return (128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * 16 * (PH / 2) * 8) / 4 + 64;
+    const long fwd = 128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * 16 * (PH / 2) * 8;         // packed W_hh + h exchange
+    const long bwd = 128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * BR * (2 * PH) * 8;         // packed W_hh^T + dG exchange
+    return (fwd > bwd ? fwd : bwd) / 4 + 64;
+}
+
+// BPTT in one persistent launch.  Arguments as lv_lstm_bwd_bf16_img plus ws of lv_lstm_persist_ws_floats() floats and a
+// device status word.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 32 and the device has >= 256 CUs.
+extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                                        const float* whh, const float* gates, const float* hs, const float* cs,
+                                        float* dG, uint16_t* dG16, float* dGsum, float* ws, int* status, float* dh0, float* dc0,
+                                        int tanh_init, int T, int B, int H, void* stream) {
+    if (!whh || !gates || !cs || (!dG && !dG16) || !dGsum || !ws || !status) return LV_ERR_ARG;
+    if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (tanh_init && !hs) return LV_ERR_ARG;
+    if (H != PH || B > BR * PGROUPS) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0) return LV_ERR_ALIGN;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return LV_ERR_UNSUPPORTED;
+    if (cus < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
+    uint4* wpk = reinterpret_cast<uint4*>(ws);
+    gran_t* gxch = reinterpret_cast<gran_t*>(ws + 128L * PKS * 2 * 64 * 4);
+    LV_LAUNCH(pack_w_persist_bwd_kernel, dim3((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), dim3(256), 0, stream, whh, wpk);
+    hipMemsetAsync(gxch, 0, (size_t)2 * PGROUPS * BR * (2 * PH) * sizeof(gran_t), (hipStream_t)stream);
+    const int R = (B + PGROUPS - 1) / PGROUPS;
+    PersistBwdP p{dh_ext, dh_last, dmask, dscale, wpk, gates, cs, hs, dG, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    LV_LAUNCH(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
 }
 
 // Forward recurrence in one persistent launch.  Arguments as lv_lstm_fwd_bf16_ug (gx unit-major) plus ws of
@@ -282,6 +540,11 @@ extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float
 extern "C" long lv_lstm_persist_ws_floats(void) { return 64; }
 extern "C" int lv_lstm_fwd_bf16_persist(const float*, const float*, float*, float*, float*, const uint8_t*, float, float*,
                                         float*, int*, int, int, int, void*) {
+    return LV_ERR_UNSUPPORTED;
+}
+extern "C" int lv_lstm_bwd_bf16_persist(const float*, const float*, const uint8_t*, float, const float*, const float*, const float*,
+                                        const float*, float*, uint16_t*, float*, float*, int*, float*, float*, int, int, int, int,
+                                        void*) {
     return LV_ERR_UNSUPPORTED;
 }
 

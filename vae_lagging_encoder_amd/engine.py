@@ -231,6 +231,29 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
 
+_PERSIST_BWD_MAX_B = 32
+
+
+def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, dc0, tanh_init, T, B, H, device):
+    """BPTT of one LSTM layer: exact f32, bf16 two launches per step, or the single persistent launch where supported."""
+    if eng.precision != "bf16":
+        lib.lv_lstm_bwd_f32(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws),
+                            dh0, dc0, tanh_init, T, B, H, s)
+        return
+    dG = P(w.dG) if img is None else None
+    dG16 = P(img.dG) if img is not None else None
+    if img is not None and eng.persistent and H == _PERSIST_H and B <= _PERSIST_BWD_MAX_B and torch.device(device).type == "cuda" \
+            and torch.cuda.get_device_properties(device).multi_processor_count >= 256:
+        if getattr(w, "persist_ws", None) is None:
+            w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
+            w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
+        lib.lv_lstm_bwd_bf16_persist(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
+                                     P(w.persist_ws), P(w.persist_status), dh0, dc0, tanh_init, T, B, H, s)
+    else:
+        lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
+                                 P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
+
+
 class _LstmImages(object):
     """bf16 operand images of one LSTM layer's input-side GEMMs (Gx = X.W_ih^T forward; dX = dG.W_ih,
     dW_ih = dG^T.X, dW_hh = dG^T.h_prev backward), built with lv_cvt_bf16_f32 next to the f32 originals."""
@@ -405,13 +428,7 @@ class LSTMEncoderEngine(object):
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
         img = self._b16(B, T)
         with _prof("lstm_bwd", float(T), 2 * T):
-            if self.precision == "bf16":     # BPTT writes the bf16 image of dG itself when the input-side GEMMs consume one
-                lib.lv_lstm_bwd_bf16_img(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
-                                         P(w.dG) if img is None else None, P(img.dG) if img is not None else None,
-                                         P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
-            else:
-                lib.lv_lstm_bwd_f32(None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs), P(w.cs),
-                                    P(w.dG), P(w.dGsum), P(w.lstm_ws), None, None, 0, T, B, H, s)
+            _lstm_backward(self, lib, s, img, w, None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), None, None, 0, T, B, H, x.device)
         # input-side grads
         if img is not None:
             img.backward(lib, s, None, P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
@@ -649,13 +666,8 @@ class LSTMDecoderEngine(object):
             _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         img = self._lstm_images(B, Td)
         with _prof("lstm_bwd", float(Td), 2 * Td):
-            if self.precision == "bf16":
-                lib.lv_lstm_bwd_bf16_img(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
-                                         P(w.cs), P(w.dG) if img is None else None, P(img.dG) if img is not None else None,
-                                         P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
-            else:
-                lib.lv_lstm_bwd_f32(P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), P(w.gates), P(w.hs),
-                                    P(w.cs), P(w.dG), P(w.dGsum), P(w.lstm_ws), None, P(w.dc0), 1, Td, B, H, s)
+            _lstm_backward(self, lib, s, img, w, P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), None, P(w.dc0), 1,
+                           Td, B, H, dev)
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
         with ctx:
             s2 = stream_ptr(dev)
