@@ -234,6 +234,18 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
 _PERSIST_BWD_MAX_B = 32
 
 
+def check_persistent_status(eng):
+    """Raise if a persistent LSTM launch of this engine ever reported a hand-off timeout (device status words; one
+    host read per workspace -- call it where the host synchronises anyway)."""
+    if eng.wsc is None:
+        return
+    for w in eng.wsc.cache.values():
+        st = getattr(w, "persist_status", None)
+        if st is not None and int(st.item()) != 0:
+            raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups "
+                                 "were resident, e.g. another kernel held compute units for seconds" % int(st.item()))
+
+
 def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, dc0, tanh_init, T, B, H, device):
     """BPTT of one LSTM layer: exact f32, bf16 two launches per step, or the single persistent launch where supported."""
     if eng.precision != "bf16":

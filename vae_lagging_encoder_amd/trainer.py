@@ -57,6 +57,8 @@ class AggressiveTextTrainer(object):
     def read_stats(self):
         """One host read: dict(loss_sum, rec_sum, kl_sum, norm, coef) accumulated since reset_stats()."""
         v = self.scal.cpu().tolist()
+        _eng.check_persistent_status(self.enc)
+        _eng.check_persistent_status(self.dec)
         return dict(loss_sum=v[5], rec_sum=v[6], kl_sum=v[7], norm=v[4], coef=v[3])
 
     def reset_stats(self):
@@ -119,8 +121,10 @@ class AggressiveTextTrainer(object):
         # backward of mean_b(loss_b)
         lib.lv_loss_bwd_scales_f32(P(st.gl), None, None, self._s(0), P(st.rowscale), P(st.dkl), B, s)
         dz = self.dec.backward(st.rowscale)
-        if self.grad_sync is not None and not self._capturing:
-            # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward
+        if self.grad_sync is not None and not self._capturing and not (self.enc.persistent and self.enc.precision == "bf16"):
+            # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward.
+            # Not beside a PERSISTENT encoder BPTT: that launch needs every CU resident at once, and compute units held
+            # by the collective's kernels would leave part of its grid spinning -- both reductions then go out in sync().
             self.dec.join()
             self.grad_sync.start_decoder(self.dec.flat)
         lib.lv_reparam_kl_bwd_f32(P(mulv), P(st.eps), P(dz), P(st.dkl), P(st.dmulv), B, 1, nz, s)
