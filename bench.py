@@ -231,27 +231,36 @@ def main():
             "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4), "traffic": None,
             "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
             "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
-        # LSTM recurrence: per launch the algorithmic HBM bytes are W_hh (4H*H, 2 B/element when the recurrent product
-        # runs on the bf16 pipe) + one timestep of f32 state/gates
+        # LSTM recurrence.  Algorithmic HBM bytes: W_hh (4H*H, 2 B/element when the recurrent product runs on the bf16 pipe)
+        # once per LAUNCH + one timestep of f32 state / gates per timestep.  Launch-per-step kernels re-read W_hh every
+        # timestep; the persistent kernels (one launch per recurrence) read it once and keep it in registers.
         wb = 2.0 if args.dtype == "bf16" else 4.0
-        per_fwd = wb * 4 * H * H + 4.0 * (B * H * 3 + B * 4 * H * 2)             # per timestep
-        per_bwd = wb * 4 * H * H + 4.0 * (B * 4 * H * 4 + B * H * 10)            # per timestep (elementwise + matmul launches)
-        steps_fwd = groups.get("lstm_fwd", dict(work=0))["work"]                 # the LSTM groups record timesteps as work
-        steps_bwd = groups.get("lstm_bwd", dict(work=0))["work"]
-        lstm_bytes = per_fwd * steps_fwd + per_bwd * steps_bwd
+        fwd_g = groups.get("lstm_fwd", dict(work=0, launches=0, ms=0.0))      # work = timesteps
+        bwd_g = groups.get("lstm_bwd", dict(work=0, launches=0, ms=0.0))
+        persistent = lstm_launches > 0 and lstm_launches < fwd_g["work"] + bwd_g["work"]
+        state_fwd = 4.0 * (B * H * 3 + B * 4 * H * 2)
+        state_bwd = 4.0 * (B * 4 * H * 4 + B * H * 10)
+        w_reads = lstm_launches if persistent else (fwd_g["work"] + bwd_g["work"])
+        lstm_bytes = wb * 4 * H * H * w_reads + state_fwd * fwd_g["work"] + state_bwd * bwd_g["work"]
         lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
+        steps_total = fwd_g["work"] + bwd_g["work"]
         lstm_roof = {
-            "bound": "hbm", "kernel": "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)",
+            "bound": "hbm",
+            "kernel": ("lstm_{fwd,bwd}_persist_kernel (one launch per recurrence, W_hh register-resident, tagged-granule hand-off per timestep)"
+                       if persistent else "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)"),
             "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
             "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
-            "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3)}
+            "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3),
+            "timesteps_per_step": int(steps_total // args.steps),
+            "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
+            "note": "latency-bound chain of dependent timesteps: the HBM fraction is what a perfectly overlapped version would be bound by"}
         # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             tr_ = pmc.get(args.workload, {}).get(args.dtype)
             if tr_:
-                lstm_roof["traffic"] = round(tr_["lstm_MB_per_launch"] * 1e6)
+                lstm_roof["traffic"] = round(tr_["lstm_persist_MB_per_launch" if persistent else "lstm_MB_per_launch"] * 1e6)
                 gemm_roof["traffic"] = round(tr_["gemm_MB_per_launch"] * 1e6)
                 lstm_roof["algorithmic_bytes_per_launch"] = round(lstm_bytes / max(1, lstm_launches))
                 lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"

@@ -213,6 +213,11 @@ _PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
 _PERSIST_MAX_B = 64
 
 
+def _persistent_ok(eng, img, B, H, device, max_b):
+    return (eng.precision == "bf16" and img is not None and eng.persistent and H == _PERSIST_H and B <= max_b
+            and torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
+
+
 def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, device):
     """The forward recurrence of one LSTM layer: exact f32, bf16 launch-per-step, or (bf16 image path on a >= 256-CU
     device, H = 1024, B <= 64) the single persistent launch of lv_lstm_persist.hip."""
@@ -221,8 +226,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         lib.lv_lstm_fwd_f32(*args, P(w.lstm_ws), T, B, H, s)
     elif img is None:
         lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
-    elif eng.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and torch.device(device).type == "cuda" \
-            and torch.cuda.get_device_properties(device).multi_processor_count >= 256:
+    elif _persistent_ok(eng, img, B, H, device, _PERSIST_MAX_B):
         if getattr(w, "persist_ws", None) is None:
             w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
             w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
@@ -254,8 +258,7 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
         return
     dG = P(w.dG) if img is None else None
     dG16 = P(img.dG) if img is not None else None
-    if img is not None and eng.persistent and H == _PERSIST_H and B <= _PERSIST_BWD_MAX_B and torch.device(device).type == "cuda" \
-            and torch.cuda.get_device_properties(device).multi_processor_count >= 256:
+    if _persistent_ok(eng, img, B, H, device, _PERSIST_BWD_MAX_B):
         if getattr(w, "persist_ws", None) is None:
             w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
             w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
@@ -416,7 +419,7 @@ class LSTMEncoderEngine(object):
                   prec=self.precision, **biases)
         w.hs[0].zero_()
         w.cs[0].zero_()
-        with _prof("lstm_fwd", float(T), T):
+        with _prof("lstm_fwd", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
             _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
         _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
@@ -439,7 +442,7 @@ class LSTMEncoderEngine(object):
         _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
         _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
         img = self._b16(B, T)
-        with _prof("lstm_bwd", float(T), 2 * T):
+        with _prof("lstm_bwd", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_BWD_MAX_B) else 2 * T):
             _lstm_backward(self, lib, s, img, w, None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), None, None, 0, T, B, H, x.device)
         # input-side grads
         if img is not None:
@@ -626,7 +629,7 @@ class LSTMDecoderEngine(object):
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
-        with _prof("lstm_fwd", float(Td), Td):
+        with _prof("lstm_fwd", float(Td), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else Td):
             _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), P(mask_out), sc_out, P(w.O), Td, B, H, x.device)
         b16 = self._b16(B, Td)
         if b16 is not None:
@@ -677,7 +680,7 @@ class LSTMDecoderEngine(object):
         else:
             _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         img = self._lstm_images(B, Td)
-        with _prof("lstm_bwd", float(Td), 2 * Td):
+        with _prof("lstm_bwd", float(Td), 1 if _persistent_ok(self, img, B, H, dev, _PERSIST_BWD_MAX_B) else 2 * Td):
             _lstm_backward(self, lib, s, img, w, P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), None, P(w.dc0), 1,
                            Td, B, H, dev)
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
