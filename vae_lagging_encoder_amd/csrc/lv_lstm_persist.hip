@@ -275,7 +275,7 @@ struct PersistBwdP {
     const float* dh_ext; const float* dh_last; const uint8_t* dmask; float dscale;
     const uint4* wpk;
     const float* gates; const float* cs; const float* hs;
-    float* dG; uint16_t* dG16; float* dGsum;
+    uint16_t* dG16; float* dGsum;
     float* dh0; float* dc0; int tanh_init;
     gran_t* gxch;               // exchange: [2 parity][8 groups][BR rows][2H] granules, zeroed before the launch
     int* status;
@@ -284,7 +284,7 @@ struct PersistBwdP {
 
 __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     __shared__ __attribute__((aligned(16))) uint32_t gl[BR * GPITCH];        // gathered dG[t+1], [row][n'/2]
-    __shared__ float red[4][16][33];                                         // per wave: quarter product [row][unit]
+    __shared__ float red[2][4][16][33];                                      // [phase parity][wave]: quarter product [row][unit]
     __shared__ int s_abort;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
@@ -321,7 +321,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     float dhb[SB], keepb[SB], ctb[SB + 1];
     float4 recb[SB];
     uint32_t outb[SB][2];            // bf16 pairs (i,f), (g,o) of the block's steps, stored at the block boundary
-    float outf[SB][4];
     auto load_block = [&](int t_hi) {            // steps t_hi, t_hi-1, ..., t_hi-SB+1
 #pragma unroll
         for (int s2 = 0; s2 < SB; ++s2) {
@@ -345,15 +344,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
             const int t = t_hi - s2;
             if (own && t >= 0) {
                 const long gi = (long)t * B * 4 * PH + (long)(b0 + prow) * 4 * PH + punit;
-                if (p.dG16) {
+                {
                     p.dG16[gi] = (uint16_t)(outb[s2][0] & 0xFFFFu);
                     p.dG16[gi + PH] = (uint16_t)(outb[s2][0] >> 16);
                     p.dG16[gi + 2L * PH] = (uint16_t)(outb[s2][1] & 0xFFFFu);
                     p.dG16[gi + 3L * PH] = (uint16_t)(outb[s2][1] >> 16);
-                }
-                if (p.dG) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) p.dG[gi + (long)g * PH] = outf[s2][g];
                 }
             }
         }
@@ -362,37 +357,42 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     __syncthreads();
 
     const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
-    const int ngran = rows * 2 * PH;                   // granules of one dG image of this group (row pitch 2H granules)
-    const int gq = (ngran + 3) / 4;
 
     // one recurrent phase: gather the image tagged `want`, contract it with this workgroup's columns, leave the summed
     // dh for (row, unit) pairs in `dh_rec` of the owning lanes.  Returns false on a hand-off timeout.
+    // Wave w contracts over K-quarter w only, so it gathers exactly that quarter of every row (granules
+    // [row][512w, 512w+512)) into its own part of the LDS image and starts its MFMAs without waiting for the other
+    // waves; the one workgroup barrier of the phase is the exchange of the four quarter products.
+    const int nq = rows * 512;                         // granules this wave gathers per phase
+    int phase = 0;
     auto recurrent = [&](uint32_t want, float& dh_rec) -> bool {
         const gran_t* src = gx_g + (long)(want & 1) * gx_par;
-        for (int base = w * gq; base < w * gq + gq; base += 64 * 8) {
-            gran_t v[8];
+        constexpr int GJ = 16;                         // granules per lane per polling round (all in flight together)
+        bool fine = true;
+        for (int base = 0; base < nq && fine; base += 64 * GJ) {
+            gran_t v[GJ];
             int spins = 0;
             bool ok;
             do {
                 ok = true;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = base + j * 64 + l;
-                    const bool in = idx < w * gq + gq && idx < ngran;
-                    v[j] = gran_load(src + (in ? idx : 0));
+                for (int j = 0; j < GJ; ++j) {
+                    const int q = base + j * 64 + l;
+                    const bool in = q < nq;
+                    v[j] = gran_load(src + (in ? (q >> 9) * (2 * PH) + 512 * w + (q & 511) : 0));
                     ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
                 }
                 ok = __all(ok);
-                if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                if (!ok && ++spins > SPIN_LIMIT) { fine = false; break; }
             } while (!ok);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = base + j * 64 + l;
-                if (idx < w * gq + gq && idx < ngran) gl[(idx >> 11) * GPITCH + (idx & 2047)] = (uint32_t)v[j];
+            for (int j = 0; j < GJ; ++j) {
+                const int q = base + j * 64 + l;
+                if (q < nq) gl[(q >> 9) * GPITCH + 512 * w + (q & 511)] = (uint32_t)v[j];
             }
         }
-        __syncthreads();
-        if (s_abort) return false;
+        if (!fine) s_abort = 1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave reads back what its own lanes just wrote
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const uint4* arowp = reinterpret_cast<const uint4*>(gl + arow * GPITCH + 512 * w) + kq;     // K-quarter w: 1024 n' = 512 dwords
 #pragma unroll
@@ -401,12 +401,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
             acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
             acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
         }
+        float (*rd)[16][33] = red[phase & 1];
+        phase ^= 1;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
-        __syncthreads();                               // quarter products of all 4 waves; also: everyone is done reading gl
-        dh_rec = (red[0][prow][uw] + red[1][prow][uw]) + (red[2][prow][uw] + red[3][prow][uw]);
+            for (int r = 0; r < 4; ++r) rd[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
+        __syncthreads();                               // quarter products of all 4 waves (double-buffered by phase parity)
+        if (s_abort) return false;
+        dh_rec = (rd[0][prow][uw] + rd[1][prow][uw]) + (rd[2][prow][uw] + rd[3][prow][uw]);
         return true;
     };
 
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
                 da[3] = d_o * og * (1.f - og);
                 dc_rec = dc * fg;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) { gsum[g] += da[g]; outf[s2][g] = da[g]; }
+                for (int g = 0; g < 4; ++g) gsum[g] += da[g];
             }
             const uint32_t lo = lv_pack_bf16x2(da[0], da[1]), hi = lv_pack_bf16x2(da[2], da[3]);
             outb[s2][0] = lo; outb[s2][1] = hi;
@@ -485,7 +488,7 @@ extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_las
     if (!whh || !gates || !cs || (!dG && !dG16) || !dGsum || !ws || !status) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
-    if (H != PH || B > BR * PGROUPS) return LV_ERR_UNSUPPORTED;
+    if (H != PH || B > BR * PGROUPS || dG || !dG16) return LV_ERR_UNSUPPORTED;   // image-only: the f32 dG copy is not produced
     if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0) return LV_ERR_ALIGN;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -496,7 +499,7 @@ extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_las
     LV_LAUNCH(pack_w_persist_bwd_kernel, dim3((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), dim3(256), 0, stream, whh, wpk);
     hipMemsetAsync(gxch, 0, (size_t)2 * PGROUPS * BR * (2 * PH) * sizeof(gran_t), (hipStream_t)stream);
     const int R = (B + PGROUPS - 1) / PGROUPS;
-    PersistBwdP p{dh_ext, dh_last, dmask, dscale, wpk, gates, cs, hs, dG, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    PersistBwdP p{dh_ext, dh_last, dmask, dscale, wpk, gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
     LV_LAUNCH(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
