@@ -145,10 +145,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
         for (int s2 = 0; s2 < SB; ++s2) {
             const int t = tb + s2;
             if (own && t < T && !(ABL & 2)) {
-                *reinterpret_cast<float4*>(p.gates + ((long)t * BH + pidx) * 4) = recb[s2];
-                p.cs[(long)(t + 1) * BH + pidx] = cb[s2];
-                p.hs[(long)(t + 1) * BH + pidx] = hb[s2];
-                if (p.hdrop) p.hdrop[(long)t * BH + pidx] = hdb[s2];
+                // streaming stores: the results are consumed by later kernels only, and a write-allocating store of a
+                // partial line makes L2 fetch the line first -- measured 3.85 -> 3.46 us per step with the nt hint
+                __builtin_nontemporal_store(f32x4{recb[s2].x, recb[s2].y, recb[s2].z, recb[s2].w},
+                                            reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx) * 4));
+                __builtin_nontemporal_store(cb[s2], p.cs + (long)(t + 1) * BH + pidx);
+                __builtin_nontemporal_store(hb[s2], p.hs + (long)(t + 1) * BH + pidx);
+                if (p.hdrop) __builtin_nontemporal_store(hdb[s2], p.hdrop + (long)t * BH + pidx);
             }
         }
     };
