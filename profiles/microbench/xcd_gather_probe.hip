@@ -59,11 +59,16 @@ __global__ __launch_bounds__(256) void gather_probe(unsigned long long* buf, int
     if (acc == 12345.678f) sink[blockIdx.x * 256 + tid] = acc;
 }
 
+// where do consecutive blocks land?  (HW_REG_XCC_ID; on this machine block b runs on XCC (b + 7) % 8, so the
+// kernels' groups = blockIdx % 8 are XCD-local; agent-scope accesses keep them correct wherever they land)
+__global__ void xcc_probe(int* out) { if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(6164) & 0xF; }
+
 int main() {
     hipStream_t s; CK(hipStreamCreate(&s));
     int* err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
     float* sink; CK(hipMalloc(&sink, 256 * 256 * 4));
     const int steps = 400;
+    { int* xo; CK(hipMalloc(&xo, 256 * 4)); hipLaunchKernelGGL(xcc_probe, dim3(256), dim3(64), 0, s, xo); CK(hipStreamSynchronize(s)); int h[256]; CK(hipMemcpy(h, xo, 1024, hipMemcpyDeviceToHost)); int bad = 0; for (int i = 0; i < 256; ++i) if (h[i] != h[i % 8]) ++bad; printf("XCC_ID of blocks 0..15:"); for (int i = 0; i < 16; ++i) printf(" %d", h[i]); printf("  | blocks whose XCC differs from block (i %% 8): %d of 256\n", bad); }
     for (int variant = 0; variant < 9; ++variant) {
         // variant 0: 8 KB payload per group (4 rows x 1024 x bf16 = 2048 granules): forward-like
         // variant 1: 16 KB payload (4096 granules): reduce-scatter-like volume
