@@ -174,9 +174,30 @@ def main():
     def one_step():
         tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
 
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize(dev)
+    def warm_up():
+        for _ in range(args.warmup):
+            one_step()
+        torch.cuda.synchronize(dev)
+
+    warm_up()
+    # The persistent LSTM launches need the whole GPU resident at once; if one of them reported a hand-off timeout during
+    # warm-up (something else holds compute units on this box), every rank falls back to the launch-per-step kernels.
+    healthy = 1
+    try:
+        engine.check_persistent_status(tr.enc)
+        engine.check_persistent_status(tr.dec)
+    except Exception as e:      # noqa
+        healthy = 0
+        print("bench: persistent LSTM launch unhealthy (%s); using the launch-per-step kernels" % e, file=sys.stderr)
+    if world > 1:
+        flag = torch.tensor([healthy], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        healthy = int(flag.item())
+    if not healthy:
+        tr.enc.persistent = tr.dec.persistent = False
+        engine.reset_persistent_status(tr.enc)
+        engine.reset_persistent_status(tr.dec)
+        warm_up()
     if world > 1:
         torch.distributed.barrier()
     prof = None

@@ -209,6 +209,15 @@ class _AuxStream(object):
             self.done = None
 
 
+def reset_persistent_status(eng):
+    """Clear the status words (after the caller has handled a reported timeout, e.g. by turning `persistent` off)."""
+    if eng.wsc is not None:
+        for w in eng.wsc.cache.values():
+            st = getattr(w, "persist_status", None)
+            if st is not None:
+                st.zero_()
+
+
 _PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
 _PERSIST_MAX_B = 64
 
