@@ -321,28 +321,13 @@ class _LstmImages(object):
         _gemm16(lib, s, 1, 4 * H, H, TB, P(self.dG), 4 * H, P(self.hT), self.ldr, gW_hh, H, ws=ws)
 
 
-def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, scratch, ws=None):
+def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, ws=None):
     """Weight gradient C[M,N] = A^T . B with A stored [K][M] (lda) and B stored [K][N] (ldb).
 
     Both kernels read the operands as stored (TN form): each wave-level load is 256 contiguous bytes of one k-row.
     (Measured on MI355X: transposing the operands first to use the NT form is SLOWER for the bf16 kernel -- dW_pred
     1.63 ms + 0.27 ms of transposes vs ~0.9 ms as TN; profiles/r01f_*.)"""
     _gemm(lib, s, 1, 0, M, N, K, A, lda, Bm, ldb, C, ldc, prec=prec, ws=ws)
-
-
-class _Scratch(object):
-    """Two growable device buffers for the transposed weight-gradient operands."""
-
-    def __init__(self):
-        self.buf = [None, None]
-
-    def __call__(self, n, slot, device=None):
-        b = self.buf[slot]
-        if b is None or b.numel() < n:
-            dev = device if device is not None else (b.device if b is not None else torch.device("cuda", torch.cuda.current_device()))
-            b = torch.empty(n, dtype=torch.float32, device=dev)
-            self.buf[slot] = b
-        return b
 
 
 class LSTMEncoderEngine(object):
@@ -356,7 +341,6 @@ class LSTMEncoderEngine(object):
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
-        self._scratch = _Scratch()
         self._aux = _AuxStream()
 
     def _b16(self, B, T):
@@ -458,9 +442,8 @@ class LSTMEncoderEngine(object):
             img.backward(lib, s, None, P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
         else:
             _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
-            sc = lambda n, slot: self._scratch(n, slot, x.device)
-            _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision, sc)
-            _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision, sc)
+            _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision)
+            _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
         gv["embed.weight"].zero_()
         self._aux.join(x.device)                       # token sort queued by forward()
@@ -485,7 +468,6 @@ class LSTMDecoderEngine(object):
         self._side = None
         self._side_ws = None
         self._pending = None
-        self._scratch = _Scratch()
         self._aux = _AuxStream()
 
     def _fork(self, device):
@@ -671,7 +653,6 @@ class LSTMDecoderEngine(object):
         gwih = gv["lstm.weight_ih_l0"]
         dev = x.device
         b16 = self._b16(B, Td)
-        sc = lambda n, slot: self._scratch(n, slot, dev)
         if b16 is not None:
             lib.lv_softmax_nll_bwd_b16(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), P(b16.dl), b16.ldv, Td, B, V, s)
         else:
@@ -683,7 +664,7 @@ class LSTMDecoderEngine(object):
                         P(gv["pred_linear.weight"]), H, ws=sws)
             else:
                 _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
-                       self.precision, sc, ws=sws)
+                       self.precision, ws=sws)
         if b16 is not None:
             _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(b16.WT), b16.ldv, P(w.dO), H)
         else:
@@ -699,9 +680,9 @@ class LSTMDecoderEngine(object):
                 img.backward(lib, s2, None, P(w.hs), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
             else:
                 _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
-                _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, sc, ws=sws)
+                _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, ws=sws)
                 _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
-                       self.precision, sc, ws=sws)
+                       self.precision, ws=sws)
             _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
             lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
             gv["embed.weight"].zero_()
