@@ -66,6 +66,30 @@ def test_bf16_throughput_path_tracks_oracle(hip_device):
     assert out["grads"] < 5e-2, out
 
 
+@pytest.mark.parametrize("persistent", [True, False])
+def test_bf16_throughput_path_h1024(hip_device, persistent):
+    """H = 1024, B = 32: the shape class on which the bf16 path runs its LSTM recurrences as persistent XCD-group launches
+    (when the device has >= 256 CUs).  Both realisations must track the f32 oracle to the bf16 path's documented delta."""
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    V, ni, H, nz, B, T, klw = 3000, 64, 1024, 16, 32, 14, 0.5
+    P = O.random_params(V, ni, H, nz, seed=11, scale=0.03, head_scale=0.2)
+    x = O.synthetic_batch(B, T, V, seed=12)
+    eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=13)
+    r = O.inner_step(P, x, klw, eps, m_in, m_out)
+    vae = build_vae(V, ni, H, nz, hip_device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+    tr.enc.persistent = tr.dec.persistent = persistent
+    tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+    st = tr.read_stats()          # also checks the persistent launches' status words
+    assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
+    assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
+    named = dict(vae.named_parameters())
+    worst = max(rel_err(named[k].grad, r["grads"][k] * r["coef"]) for k in ALL_KEYS)
+    assert worst < 5e-2, worst
+    sd = vae.state_dict()
+    assert max(rel_err(sd[k], r["new_params"][k]) for k in ENC_KEYS) < 5e-2
+
+
 def test_bf16_native_operands_equal_on_the_fly(hip_device):
     pc.check_bf16_native_operands_equal_on_the_fly(hip_device)
     pc.check_bf16_native_operands_equal_on_the_fly(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30)
