@@ -29,6 +29,9 @@
 // Backward step t = two launches: an elementwise kernel (gate grads, dc chain, dG[t], running sum of dG) and the
 //   recurrent matmul dh_{t-1} = dG[t] . W_hh as split-K partial slabs (same core, weights packed transposed); the
 //   next step's elementwise kernel sums the slabs in a fixed order (deterministic, no atomics).
+//
+// lv_lstm_persist.hip holds the one-launch persistent forms of the bf16 recurrences (H = 1024 on a full MI355X); the step
+// kernels here are the general path (any H / B, f32 parity path, partitioned devices) and the reference they are tested against.
 #include "lv_device.h"
 
 namespace {
