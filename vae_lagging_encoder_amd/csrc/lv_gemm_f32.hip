@@ -66,6 +66,27 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
+// Branch-free staging for the common case (16-byte aligned operand, complete K tile; for [K][rows] operands also a tile
+// that lies completely inside the operand): addresses are resolved once per K tile and every load is an unconditional
+// float4.  Rows of a K-contiguous operand beyond its last row are CLAMPED to it instead of predicated: an A row only
+// reaches the C row of the same index (a B row the C column) and those are never written.
+template <bool KC, int WT>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, long ld, int rows, int r0, int k0, int t,
+                                               float4 (&reg)[WT]) {
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+        const int f = t + 256 * i;
+        if (KC) {
+            int row = r0 + (f >> 2);
+            if (row > rows - 1) row = rows - 1;
+            reg[i] = *reinterpret_cast<const float4*>(P + (long)row * ld + k0 + 4 * (f & 3));
+        } else {
+            const int k = f / (16 * WT), mq = f % (16 * WT);
+            reg[i] = *reinterpret_cast<const float4*>(P + (long)(k0 + k) * ld + r0 + 4 * mq);
+        }
+    }
+}
+
 template <bool KC, int WT>
 __device__ __forceinline__ void store_tile(float (*S)[64 * WT + 4], int t, const float4 (&reg)[WT]) {
 #pragma unroll
@@ -124,18 +145,23 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
     const int kt0 = (int)blockIdx.y * p.kt_per_split;
     int kt1 = kt0 + p.kt_per_split;
     if (kt1 > nk_all) kt1 = nk_all;
-    load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, kt0 * BK, vecA, t, ra);
-    load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, vecB, t, rb);
+    const int nfull = p.K / BK;                                       // K tiles [0, nfull) are complete
+    const bool fastA = vecA && (A_KC || m0 + BT <= p.M);
+    const bool fastB = vecB && (B_KC || n0 + BT <= p.N);
+    auto stage = [&](int kt) {
+        if (fastA && kt < nfull) load_tile_fast<A_KC, WT>(p.A, p.lda, p.M, m0, kt * BK, t, ra);
+        else load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, kt * BK, vecA, t, ra);
+        if (fastB && kt < nfull) load_tile_fast<B_KC, WT>(p.B, p.ldb, p.N, n0, kt * BK, t, rb);
+        else load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, kt * BK, vecB, t, rb);
+    };
+    stage(kt0);
     store_tile<A_KC, WT>(As[0], t, ra);
     store_tile<B_KC, WT>(Bs[0], t, rb);
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, vecA, t, ra);
-            load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, vecB, t, rb);
-        }
+        if (kt + 1 < kt1) stage(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + (l >> 5);
