@@ -74,6 +74,30 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, 
     }
 }
 
+// Branch-free staging for the common case (see lv_gemm_f32.hip: 16-byte aligned K-contiguous operand with clamped rows,
+// or a [K][rows] operand whose tile lies inside it; complete K tile): unconditional loads, conversion as above.
+template <bool KC, int WT>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, long ld, int rows, int r0, int k0, int t,
+                                               uint2 (&reg)[2 * WT]) {
+    constexpr int BT = 64 * WT;
+#pragma unroll
+    for (int i = 0; i < 2 * WT; ++i) {
+        const int f = t + 256 * i;
+        float v0, v1, v2, v3;
+        if (KC) {
+            int row = r0 + (f >> 3);
+            if (row > rows - 1) row = rows - 1;
+            const float4 q = *reinterpret_cast<const float4*>(P + (long)row * ld + k0 + 4 * (f & 7));
+            v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+        } else {
+            const float* p = P + (long)(k0 + 4 * (f / BT)) * ld + r0 + (f % BT);
+            v0 = p[0]; v1 = p[ld]; v2 = p[2 * ld]; v3 = p[3 * ld];
+        }
+        reg[i].x = lv_pack_bf16x2(v0, v1);
+        reg[i].y = lv_pack_bf16x2(v2, v3);
+    }
+}
+
 template <bool KC, int WT>
 __device__ __forceinline__ void store_tile(uint4 (*S)[64 * WT + 2], int t, const uint2 (&reg)[2 * WT]) {
     constexpr int BT = 64 * WT;
@@ -127,18 +151,23 @@ __global__ __launch_bounds__(256) void lv_gemm_bf16_kernel(GemmP p) {
     const int kt0 = (int)blockIdx.y * p.kt_per_split;
     int kt1 = kt0 + p.kt_per_split;
     if (kt1 > nk_all) kt1 = nk_all;
-    load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, kt0 * BK, vecA, t, ra);
-    load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, vecB, t, rb);
+    const int nfull = p.K / BK;                                       // K tiles [0, nfull) are complete
+    const bool fastA = A_KC ? vecA : (m0 + BT <= p.M);
+    const bool fastB = B_KC ? vecB : (n0 + BT <= p.N);
+    auto stage = [&](int kt) {
+        if (fastA && kt < nfull) load_tile_fast<A_KC, WT>(p.A, p.lda, p.M, m0, kt * BK, t, ra);
+        else load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, kt * BK, vecA, t, ra);
+        if (fastB && kt < nfull) load_tile_fast<B_KC, WT>(p.B, p.ldb, p.N, n0, kt * BK, t, rb);
+        else load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, kt * BK, vecB, t, rb);
+    };
+    stage(kt0);
     store_tile<A_KC, WT>(As[0], t, ra);
     store_tile<B_KC, WT>(Bs[0], t, rb);
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
-            load_tile<A_KC, WT>(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, vecA, t, ra);
-            load_tile<B_KC, WT>(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, vecB, t, rb);
-        }
+        if (kt + 1 < kt1) stage(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = 2 * ks + lh;
