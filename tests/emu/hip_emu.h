@@ -6,15 +6,19 @@
 // host-side launch sequencing.  Nothing in the package imports or loads the emulator build;
 // see tests/emu/README.md.
 //
-// Model: one workgroup at a time; every HIP thread of the workgroup is a pooled OS thread;
-// __syncthreads() is a pthread barrier over the workgroup; wave64 cross-lane ops (shuffles,
-// MFMA) rendezvous on a per-wave barrier and exchange operands through per-wave buffers.
+// Model: every HIP thread is a user-level FIBER (own stack, hand-rolled x86-64 context switch) scheduled round-robin on
+// the ONE OS thread that called the launch; a barrier is "yield until the generation changes", so a __syncthreads()
+// over 256 threads costs 256 context switches of a few ns instead of 256 futex round trips (the first version of this
+// emulator used pooled OS threads and spent 80 % of its time in the kernel).  A plain launch runs one workgroup at a
+// time; a CONCURRENT launch (lv_emu::launch_concurrent) keeps every workgroup of the grid live at once, which is what
+// the spin-synchronised persistent kernels need (their polls yield).  wave64 cross-lane ops (shuffles, MFMA)
+// rendezvous on a per-wave barrier and exchange operands through per-wave buffers.
 // MFMA lane->element maps follow /opt/skills/guides/cdna_hip_programming.md section 3:
 //   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]
 //   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
 // and the arithmetic is the k-ordered fmaf chain the hardware is documented to produce.
 #pragma once
-#include <pthread.h>
+#include <sys/mman.h>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -29,7 +33,6 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
 #define __launch_bounds__(...)
 #ifndef __restrict__
 #define __restrict__ __restrict
@@ -60,114 +63,176 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 
+// switch stacks: save the callee-saved registers on the current stack, park its pointer in *save_sp, adopt load_sp
+extern "C" void lv_emu_switch(void** save_sp, void* load_sp);
+
 namespace lv_emu {
 
 constexpr int kMaxThreads = 1024;
 constexpr int kWave = 64;
+constexpr size_t kStack = 256 << 10;      // per fiber; mmap'd, only touched pages are ever backed
+
+struct Bar {                               // generation barrier over `count` fibers
+    int count = 0, arrived = 0;
+    unsigned gen = 0;
+};
 
 struct WaveX {
-    pthread_barrier_t bar;
-    int count = 0;
+    Bar bar;
+    int base = 0;                          // first fiber of the wave (index into the live set)
+    int size = 0;                          // lanes of the wave (bar.count drops as lanes exit)
     float fa[kWave], fb[kWave];
     uint64_t u[kWave];
     uint4 qa[kWave], qb[kWave];
 };
 
-struct State {
-    std::mutex launch_mu;
-    pthread_barrier_t wg_bar;       // __syncthreads / end-of-block
-    pthread_barrier_t start_bar;    // pool start/finish (nthreads+1)
-    int nthreads = 0;               // threads in current config
-    std::vector<pthread_t> pool;
-    std::function<void()> job;
-    dim3 grid, block;
-    std::vector<WaveX*> waves;
-    std::vector<char> dyn;
-    bool shutdown = false;
+struct Block {                             // one live workgroup
+    lv_emu_idx idx{0, 0, 0};
+    Bar bar;
+    int base = 0;                          // first fiber of the block
+    std::vector<WaveX> waves;
+    std::vector<char> shared;              // `__shared__` storage of the block in a concurrent launch (see LV_SHARED)
 };
 
-inline State& st() { static State s; return s; }
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    lv_emu_idx tidx{0, 0, 0};
+    int lin = 0;                           // linear thread id in its block
+    Block* blk = nullptr;
+    bool done = true;
+};
 
-extern thread_local lv_emu_idx t_threadIdx;
-extern thread_local lv_emu_idx t_blockIdx;
-extern thread_local int t_lin;     // linear thread id in block
+struct State {
+    std::recursive_mutex launch_mu;
+    std::vector<Fiber> fibers;             // the live set (one block, or the whole grid in a concurrent launch)
+    std::vector<Block> blocks;
+    size_t nstacks = 0;
+    char* stacks = nullptr;
+    int cur = -1, nlive = 0, remaining = 0;
+    void* main_sp = nullptr;
+    std::function<void()> job;
+    dim3 grid, block;
+    std::vector<char> dyn;
+};
 
-#ifdef LV_EMU_IMPL
-thread_local lv_emu_idx t_threadIdx{0, 0, 0};
-thread_local lv_emu_idx t_blockIdx{0, 0, 0};
-thread_local int t_lin = 0;
-#endif
+extern State g_state;
+extern lv_emu_idx t_threadIdx;
+extern lv_emu_idx t_blockIdx;
+extern int t_lin;
+inline State& st() { return g_state; }
 
-inline void* worker(void* arg) {
-    State& s = st();
-    int tid = (int)(intptr_t)arg;
-    for (;;) {
-        pthread_barrier_wait(&s.start_bar);           // wait for a launch
-        if (s.shutdown) return nullptr;
-        unsigned bx = s.block.x, by = s.block.y;
-        t_lin = tid;
-        t_threadIdx.x = tid % bx;
-        t_threadIdx.y = (tid / bx) % by;
-        t_threadIdx.z = tid / (bx * by);
-        for (unsigned gz = 0; gz < s.grid.z; ++gz)
-            for (unsigned gy = 0; gy < s.grid.y; ++gy)
-                for (unsigned gx = 0; gx < s.grid.x; ++gx) {
-                    t_blockIdx.x = gx; t_blockIdx.y = gy; t_blockIdx.z = gz;
-                    s.job();
-                    pthread_barrier_wait(&s.wg_bar);  // block done before statics are reused
-                }
-        pthread_barrier_wait(&s.start_bar);           // signal completion
-    }
+void run_live(int nlive);                  // hip_emu_impl.cpp
+
+inline void enter(Fiber& f) {              // make `f` the running fiber's identity
+    t_threadIdx = f.tidx;
+    t_lin = f.lin;
+    t_blockIdx = f.blk->idx;
 }
 
-inline void configure(int nthreads) {
+// hand the OS thread to fiber `next` and come back when somebody hands it back
+inline void switch_to(int next) {
     State& s = st();
-    if (s.nthreads == nthreads) return;
-    // tear down the old pool
-    if (s.nthreads > 0) {
-        s.shutdown = true;
-        pthread_barrier_wait(&s.start_bar);
-        for (auto& p : s.pool) pthread_join(p, nullptr);
-        s.pool.clear();
-        pthread_barrier_destroy(&s.start_bar);
-        pthread_barrier_destroy(&s.wg_bar);
-        for (auto* w : s.waves) { pthread_barrier_destroy(&w->bar); delete w; }
-        s.waves.clear();
-        s.shutdown = false;
+    Fiber* me = &s.fibers[s.cur];
+    s.cur = next;
+    lv_emu_switch(&me->sp, s.fibers[next].sp);
+    enter(*me);
+}
+
+// next runnable fiber in [base, base+n) after the running one, cyclically; -1 when it is the only one
+inline int next_in(int base, int n) {
+    State& s = st();
+    int i = s.cur - base;
+    for (int k = 1; k < n; ++k) {
+        int j = base + (i + k) % n;
+        if (!s.fibers[j].done) return j;
     }
-    s.nthreads = nthreads;
-    pthread_barrier_init(&s.start_bar, nullptr, nthreads + 1);
-    pthread_barrier_init(&s.wg_bar, nullptr, nthreads);
-    int nw = (nthreads + kWave - 1) / kWave;
-    for (int w = 0; w < nw; ++w) {
-        WaveX* wx = new WaveX();
-        wx->count = std::min(kWave, nthreads - w * kWave);
-        pthread_barrier_init(&wx->bar, nullptr, wx->count);
-        s.waves.push_back(wx);
+    return -1;
+}
+
+inline void yield_in(int base, int n) {
+    int nx = next_in(base, n);
+    if (nx >= 0) switch_to(nx);
+}
+inline void yield_all() { yield_in(0, st().nlive); }
+
+inline void bar_wait(Bar& b, int base, int span) {
+    const unsigned g = b.gen;
+    if (++b.arrived >= b.count) { b.arrived = 0; ++b.gen; return; }
+    while (b.gen == g) {
+        int nx = next_in(base, span);
+        if (nx < 0) { fprintf(stderr, "lv_emu: barrier can never complete (divergent barrier?)\n"); abort(); }
+        switch_to(nx);
     }
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, 1 << 20);
-    s.pool.resize(nthreads);
-    for (int t = 0; t < nthreads; ++t)
-        pthread_create(&s.pool[t], &attr, worker, (void*)(intptr_t)t);
-    pthread_attr_destroy(&attr);
+}
+// a thread that exits stops counting towards its block's and wave's barriers (as exited waves do on the hardware)
+inline void bar_leave(Bar& b) {
+    --b.count;
+    if (b.count > 0 && b.arrived >= b.count) { b.arrived = 0; ++b.gen; }
 }
 
 template <class F>
-inline void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
+inline void launch_impl(dim3 grid, dim3 block, size_t shmem, F&& f, bool concurrent) {
     State& s = st();
-    std::lock_guard<std::mutex> lk(s.launch_mu);
-    int nthreads = (int)(block.x * block.y * block.z);
+    std::lock_guard<std::recursive_mutex> lk(s.launch_mu);
+    const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || nthreads > kMaxThreads) { fprintf(stderr, "lv_emu: bad block size %d\n", nthreads); abort(); }
-    if (grid.x * grid.y * grid.z == 0) return;
-    configure(nthreads);
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    if (nblocks == 0) return;
     s.grid = grid; s.block = block;
     s.dyn.assign(shmem + 64, 0);
     s.job = std::function<void()>(f);
-    pthread_barrier_wait(&s.start_bar);   // release workers
-    pthread_barrier_wait(&s.start_bar);   // wait for completion
+    const int live_blocks = concurrent ? (int)nblocks : 1;
+    const int nlive = live_blocks * nthreads;
+    if ((size_t)nlive > s.nstacks) {
+        if (s.stacks) munmap(s.stacks, s.nstacks * kStack);
+        s.stacks = (char*)mmap(nullptr, (size_t)nlive * kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (s.stacks == (char*)MAP_FAILED) { fprintf(stderr, "lv_emu: cannot map %d fiber stacks\n", nlive); abort(); }
+        s.nstacks = (size_t)nlive;
+    }
+    s.fibers.assign((size_t)nlive, Fiber());
+    s.blocks.assign((size_t)live_blocks, Block());
+    const int nw = (nthreads + kWave - 1) / kWave;
+    for (int b = 0; b < live_blocks; ++b) {
+        Block& B = s.blocks[b];
+        B.base = b * nthreads;
+        B.bar.count = nthreads;
+        B.waves.assign((size_t)nw, WaveX());
+        for (int w = 0; w < nw; ++w) {
+            B.waves[w].size = B.waves[w].bar.count = std::min(kWave, nthreads - w * kWave);
+            B.waves[w].base = B.base + w * kWave;
+        }
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& fb = s.fibers[B.base + t];
+            fb.stack = s.stacks + (size_t)(B.base + t) * kStack;
+            fb.lin = t;
+            fb.tidx.x = t % block.x;
+            fb.tidx.y = (t / block.x) % block.y;
+            fb.tidx.z = t / (block.x * block.y);
+            fb.blk = &B;
+        }
+    }
+    if (concurrent) {
+        long b = 0;
+        for (unsigned gz = 0; gz < grid.z; ++gz)
+            for (unsigned gy = 0; gy < grid.y; ++gy)
+                for (unsigned gx = 0; gx < grid.x; ++gx, ++b) s.blocks[b].idx = lv_emu_idx{gx, gy, gz};
+        run_live(nlive);
+    } else {
+        for (unsigned gz = 0; gz < grid.z; ++gz)
+            for (unsigned gy = 0; gy < grid.y; ++gy)
+                for (unsigned gx = 0; gx < grid.x; ++gx) {
+                    Block& B = s.blocks[0];
+                    B.idx = lv_emu_idx{gx, gy, gz};
+                    B.bar = Bar(); B.bar.count = nthreads;
+                    for (auto& w : B.waves) { w.bar = Bar(); w.bar.count = w.size; }
+                    run_live(nlive);
+                }
+    }
 }
+
+template <class F> inline void launch(dim3 grid, dim3 block, size_t shmem, F&& f) { launch_impl(grid, block, shmem, f, false); }
+template <class F> inline void launch_concurrent(dim3 grid, dim3 block, size_t shmem, F&& f) { launch_impl(grid, block, shmem, f, true); }
 
 inline char* dyn_smem() {
     State& s = st();
@@ -175,17 +240,34 @@ inline char* dyn_smem() {
     return (char*)((p + 15) & ~(uintptr_t)15);
 }
 
-inline WaveX& my_wave() { return *st().waves[t_lin / kWave]; }
+inline Fiber& me() { State& s = st(); return s.fibers[s.cur]; }
+inline WaveX& my_wave() { Fiber& f = me(); return f.blk->waves[f.lin / kWave]; }
 inline int lane() { return t_lin % kWave; }
+inline void wave_sync() { WaveX& w = my_wave(); bar_wait(w.bar, w.base, w.size); }
+
+// per-block storage for a kernel's shared arrays in a concurrent launch (a function-local `static` would be one copy
+// for the whole grid): the first caller of a block sizes it, every thread of the block gets the same pointer
+inline void* block_shared(size_t bytes) {
+    Block* b = me().blk;
+    if (b->shared.size() < bytes + 64) b->shared.assign(bytes + 64, 0);
+    uintptr_t p = (uintptr_t)b->shared.data();
+    return (void*)((p + 63) & ~(uintptr_t)63);
+}
 
 }  // namespace lv_emu
+
+// In a plain launch workgroups run one after another, so a function-local static IS the block's LDS.
+#define __shared__ static
 
 #define threadIdx (lv_emu::t_threadIdx)
 #define blockIdx (lv_emu::t_blockIdx)
 #define blockDim (lv_emu::st().block)
 #define gridDim (lv_emu::st().grid)
 
-static inline void __syncthreads() { pthread_barrier_wait(&lv_emu::st().wg_bar); }
+static inline void __syncthreads() {
+    lv_emu::Fiber& f = lv_emu::me();
+    lv_emu::bar_wait(f.blk->bar, f.blk->base, (int)(lv_emu::st().block.x * lv_emu::st().block.y * lv_emu::st().block.z));
+}
 
 // ---- wave64 cross-lane -------------------------------------------------------------------
 template <class T>
@@ -196,10 +278,10 @@ static inline T lv_emu_xchg(T v, int src_lane) {
     uint64_t bits = 0;
     memcpy(&bits, &v, sizeof(T));
     w.u[l] = bits;
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     T out = v;
-    if (src_lane >= 0 && src_lane < w.count) { uint64_t b = w.u[src_lane]; memcpy(&out, &b, sizeof(T)); }
-    pthread_barrier_wait(&w.bar);
+    if (src_lane >= 0 && src_lane < w.size) { uint64_t b = w.u[src_lane]; memcpy(&out, &b, sizeof(T)); }
+    lv_emu::wave_sync();
     return out;
 }
 template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
@@ -225,13 +307,24 @@ template <class T> static inline T __shfl(T v, int src, int width = 64) {
     int s = (l / width) * width + (src % width);
     return lv_emu_xchg(v, s);
 }
+// wave vote: true iff the predicate holds on every lane of the wave
+static inline bool __all(bool p) {
+    auto& w = lv_emu::my_wave();
+    int l = lv_emu::lane();
+    w.u[l] = p ? 1u : 0u;
+    lv_emu::wave_sync();
+    bool r = true;
+    for (int i = 0; i < w.size; ++i) r = r && (lv_emu::st().fibers[w.base + i].done || w.u[i] != 0);
+    lv_emu::wave_sync();
+    return r;
+}
 
 // ---- MFMA (f32 in / f32 accumulate), bit-for-bit the k-ordered fmaf chain -------------------
 static inline f32x4 lv_emu_mfma_16x16x4(float a, float b, f32x4 c) {
     auto& w = lv_emu::my_wave();
     int l = lv_emu::lane();
     w.fa[l] = a; w.fb[l] = b;
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     f32x4 d = c;
     int col = l & 15;
     for (int r = 0; r < 4; ++r) {
@@ -240,14 +333,14 @@ static inline f32x4 lv_emu_mfma_16x16x4(float a, float b, f32x4 c) {
         for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[row + 16 * k], w.fb[col + 16 * k], acc);
         d[r] = acc;
     }
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     return d;
 }
 static inline f32x16 lv_emu_mfma_32x32x2(float a, float b, f32x16 c) {
     auto& w = lv_emu::my_wave();
     int l = lv_emu::lane();
     w.fa[l] = a; w.fb[l] = b;
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     f32x16 d = c;
     int col = l & 31;
     for (int r = 0; r < 16; ++r) {
@@ -256,7 +349,7 @@ static inline f32x16 lv_emu_mfma_32x32x2(float a, float b, f32x16 c) {
         for (int k = 0; k < 2; ++k) acc = fmaf(w.fa[row + 32 * k], w.fb[col + 32 * k], acc);
         d[r] = acc;
     }
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     return d;
 }
 
@@ -264,11 +357,10 @@ static inline f32x16 lv_emu_mfma_32x32x2(float a, float b, f32x16 c) {
 // (any k assignment that is the same for A and B gives the same product); D layout as the f32 32x32 form.
 static inline float lv_emu_bf16_to_f32(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline f32x16 lv_emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
-    static thread_local int dummy = 0; (void)dummy;
     auto& w = lv_emu::my_wave();
     int l = lv_emu::lane();
     w.qa[l] = a; w.qb[l] = b;
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     f32x16 d = c;
     int col = l & 31;
     for (int r = 0; r < 16; ++r) {
@@ -282,7 +374,7 @@ static inline f32x16 lv_emu_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) {
         }
         d[r] = acc;
     }
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     return d;
 }
 
@@ -291,7 +383,7 @@ static inline f32x4 lv_emu_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
     auto& w = lv_emu::my_wave();
     int l = lv_emu::lane();
     w.qa[l] = a; w.qb[l] = b;
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     f32x4 d = c;
     int col = l & 15;
     for (int r = 0; r < 4; ++r) {
@@ -305,7 +397,7 @@ static inline f32x4 lv_emu_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
         }
         d[r] = acc;
     }
-    pthread_barrier_wait(&w.bar);
+    lv_emu::wave_sync();
     return d;
 }
 

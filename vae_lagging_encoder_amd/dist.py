@@ -44,6 +44,7 @@ class GradSync(object):
         self.group = group
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._inv = None
 
     def _scale(self, flat):
@@ -73,12 +74,14 @@ class GradSync(object):
         h_enc.wait()
         self._scale(enc_flat)
 
-    def all_equal_loss_window(self, value):
-        """Scalar mean over ranks so every rank takes the same data-dependent `break` (text.py:393-396)."""
+    def window_mean(self, loss_sum, num_words):
+        """Global mean loss per word of one exit window (text.py:393-396): sum of the ranks' loss sums over the sum of
+        their word counts, identical on every rank, so all ranks take the same data-dependent `break`."""
         if self.world == 1:
-            return value
-        t = torch.tensor([value], dtype=torch.float64)
+            return loss_sum / num_words
+        t = torch.tensor([loss_sum, float(num_words)], dtype=torch.float64)
         if dist.get_backend(self.group) == "nccl":
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return float(t.item()) / self.world
+        v = t.tolist()
+        return v[0] / v[1]

@@ -78,8 +78,10 @@ class Tape(object):
         Ho = (x.H + 2 * pad - kh) // stride + 1
         Wo = (x.W + 2 * pad - kw) // stride + 1
         Pout = x.N * Ho * Wo
-        if mask is not None and self.train:
-            lib.lv_mul_inplace_f32(P(weight), P(mask), weight.numel(), s)     # weight.data.mul_(mask), G5
+        if mask is not None:
+            # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
+            # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
+            lib.lv_mul_inplace_f32(P(weight), P(mask), weight.numel(), s)
         y = self.f32(Pout, Cout)
         one_by_one = (KK == 1 and stride == 1 and pad == 0)
         if one_by_one:

@@ -21,6 +21,12 @@ class _Static(object):
     pass
 
 
+def _rank_seed(seed, grad_sync):
+    """Philox key for this process: `seed` itself on a single GPU, a rank-specific key under data parallelism."""
+    rank = grad_sync.rank if grad_sync is not None else 0
+    return (int(seed) + 0x9E3779B1 * rank) & 0x7FFFFFFFFFFFFFFF
+
+
 class AggressiveTextTrainer(object):
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
                  precision="f32"):
@@ -44,7 +50,9 @@ class AggressiveTextTrainer(object):
         self.scal = torch.zeros(8, dtype=torch.float32, device=d)
         self.scal[1] = lr
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
-        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=d)   # Philox (seed, offset), uint64 bits
+        # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
+        # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
+        self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0], dtype=torch.int64, device=d)
         self.static = {}
 
     # -- scalar views ------------------------------------------------------------------------------
@@ -215,7 +223,13 @@ class AggressiveTextTrainer(object):
         """Run the aggressive inner loop starting on batch `first`; later batches are drawn with
         np_rng.random_integers(0, len-1) semantics (text.py:389).  Returns the number of encoder steps taken.
 
-        fixed_k: run exactly that many steps with no data-dependent exit (BASELINE.json stress config)."""
+        fixed_k: run exactly that many steps with no data-dependent exit (BASELINE.json stress config).
+
+        Data parallel (grad_sync set): the windowed exit test of text.py:393-396 is taken on the GLOBAL mean loss per word
+        (sum of the ranks' loss sums / sum of their word counts, one 2-element all-reduce per window), so every rank
+        leaves the loop at the same iteration -- a rank deciding on its local window would pair its joint-step all-reduce
+        with the other ranks' encoder-step all-reduces.  The device accumulators are cleared on exit, so a read_stats()
+        after the joint step reports that step alone (text.py:426-427)."""
         rng = np_rng if np_rng is not None else np.random
         sub_iter = 1
         x = first
@@ -234,13 +248,21 @@ class AggressiveTextTrainer(object):
                 if steps >= fixed_k:
                     break
             elif sub_iter % window == 0:
-                cur = self.read_stats()["loss_sum"] / burn_num_words     # the only host sync of the window
+                loss_sum = self.read_stats()["loss_sum"]                   # the only host sync of the window
+                if self.grad_sync is not None:
+                    cur = self.grad_sync.window_mean(loss_sum, burn_num_words)
+                else:
+                    cur = loss_sum / burn_num_words
                 if burn_pre_loss - cur < 0:
                     break
                 burn_pre_loss = cur
                 burn_num_words = 0
                 self.reset_stats()
             sub_iter += 1
+        # a persistent-launch hand-off timeout must not go unnoticed in the modes that never read the statistics
+        _eng.check_persistent_status(self.enc)
+        _eng.check_persistent_status(self.dec)
+        self.reset_stats()
         return steps
 
 
@@ -293,6 +315,44 @@ class AggressiveImageTrainer(object):
         self.lib.lv_rng_bernoulli_f32(P(probs), P(out), probs.numel(), P(self.rng_state), 7, s)
         self.lib.lv_rng_advance(P(self.rng_state), 1, s)
         return out
+
+    def inner_loop(self, x_train, first, kl_weight, batch_size=50, np_rng=None, max_iter=100, window=10, fixed_k=None,
+                   eps_fn=None, binarize_fn=None):
+        """The aggressive inner loop of image.py:295-327 starting on the binarised batch `first`: encoder-only steps,
+        each followed by the pick of the next batch -- np.random.choice(N, batch_size, replace=False) rows of `x_train`
+        (image.py:316), dynamically binarised on device (torch.bernoulli, image.py:318) -- and, every `window` (10)
+        iterations, the exit test on the mean loss per example (image.py:320-325).  One host read per window instead of
+        the reference's one per iteration.  Returns the number of encoder steps taken.
+
+        eps_fn(x) / binarize_fn(probs) inject the reparameterisation noise / the binarisation draw (parity tests)."""
+        rng = np_rng if np_rng is not None else np.random
+        N = int(x_train.shape[0])
+        sub_iter = 1
+        x = first
+        burn_num_examples = 0
+        burn_pre_loss = 1e4
+        self.reset_stats()
+        steps = 0
+        while sub_iter < max_iter:
+            burn_num_examples += int(x.shape[0])
+            self.step(x, kl_weight, eps=None if eps_fn is None else eps_fn(x), update="encoder")
+            steps += 1
+            id_ = rng.choice(N, batch_size, replace=False)
+            probs = x_train[torch.from_numpy(np.asarray(id_, dtype=np.int64)).to(x_train.device)].to(self.device)
+            x = binarize_fn(probs) if binarize_fn is not None else self.binarize(probs)
+            if fixed_k is not None:
+                if steps >= fixed_k:
+                    break
+            elif sub_iter % window == 0:
+                cur = self.read_stats()["loss_sum"] / burn_num_examples
+                if burn_pre_loss - cur < 0:
+                    break
+                burn_pre_loss = cur
+                burn_num_examples = 0
+                self.reset_stats()
+            sub_iter += 1
+        self.reset_stats()
+        return steps
 
     def step(self, x, kl_weight, eps=None, update="encoder"):
         """x (B,1,28,28) binarised; eps (B,1,nz) injects the reparameterisation noise (parity mode)."""
