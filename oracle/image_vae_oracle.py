@@ -134,6 +134,7 @@ def inner_step_adam(P, x, kl_weight, eps, adam=None, lr=1e-3, clip=5.0, betas=(0
         v2[k] = adam["v"][k] * betas[1] + (1 - betas[1]) * g * g
         denom = v2[k].sqrt() / math.sqrt(1 - betas[1] ** t) + adam_eps
         new[k] = P[k] - (lr / (1 - betas[0] ** t)) * (m2[k] / denom)
-    masked = {k: c.leaf[k].detach() for k in c.leaf if k + "" in P and (k.replace(".weight", ".mask") in P)}
+    # MaskedConv2d weights after this forward's in-place weight.data.mul_(mask) (G5)
+    masked = {k: c.leaf[k].detach() for k in c.leaf if k.endswith(".weight") and (k[:-len(".weight")] + ".mask") in P}
     return dict(loss=loss.detach(), rec=rec.detach(), kl=kl.detach(), grads=grads, total_norm=total, coef=coef,
                 new_params=new, new_stats=c.new_stats, masked_weights=masked, adam=dict(step=t, m=m2, v=v2))

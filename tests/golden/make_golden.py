@@ -146,19 +146,27 @@ def check_oracle(tag, P, x, klw, eps, m_in, m_out, loss, rec, kl, grads, total, 
         eg = max(rel(r["grads"][k], grads[k]) for k in O.ALL_KEYS if float(grads[k].abs().max()) > 0)
         en = abs(r["total_norm"] - total) / total
         ew = max(rel(r["new_params"][k], new_enc[k]) for k in O.ENC_KEYS)
+        if norm_tol > 1e-4:
+            # full-size case with the clip ACTIVE: the reference's coefficient inherits its fp32 norm's error, so compare
+            # the de-clipped updates (new - old) / coef, relative to the largest update
+            ref_coef = min(1.0, 5.0 / (total + 1e-6))
+            ew = max(rel((r["new_params"][k] - P[k]) / r["coef"], (new_enc[k] - P[k]) / ref_coef) for k in O.ENC_KEYS)
         print("  oracle[%s] vs reference %-14s loss %.1e rec %.1e kl %.1e grads %.1e norm %.1e w %.1e" % (
             impl, tag, e[0], e[1], ekl, eg, en, ew))
         assert max(e) < rtol and ekl < 1e-4 and eg < 1e-3 and en < norm_tol and ew < 1e-4, "oracle != reference"
 
 
 def make_case(name, V, ni, H, nz, B, T, klw, model_seed, noise_seed, data_seed, model_scale=0.01, emb_scale=0.1,
-              head_scale=None, force_last_token=False, store_params=True):
+              head_scale=None, force_last_token=False, store_params=True, pred_scale=None):
     from oracle import text_vae_oracle as O
     print("case", name)
     vae = build_ref_vae(V, ni, H, nz, model_seed, model_scale, emb_scale)
     if head_scale is not None:
         with torch.no_grad():
             vae.encoder.linear.weight.uniform_(-head_scale, head_scale)
+    if pred_scale is not None:        # drawn after the head, from the same generator stream
+        with torch.no_grad():
+            vae.decoder.pred_linear.weight.uniform_(-pred_scale, pred_scale)
     x = O.synthetic_batch(B, T, V, seed=data_seed)
     if force_last_token:
         x[0, 1 if T > 2 else 0] = V - 1      # decoder INPUT token V-1 -> zero embedding grad row (G3)
@@ -176,6 +184,8 @@ def make_case(name, V, ni, H, nz, B, T, klw, model_seed, noise_seed, data_seed, 
     total64 = math.sqrt(sum(float(g.double().pow(2).sum()) for g in grads.values()))
     out = dict(V=V, ni=ni, H=H, nz=nz, B=B, T=T, kl_weight=np.float32(klw), model_seed=model_seed, total_norm64=np.float64(total64),
                noise_seed=noise_seed, model_scale=model_scale, emb_scale=emb_scale,
+               head_scale=np.float64(head_scale if head_scale is not None else 0.0),
+               pred_scale=np.float64(pred_scale if pred_scale is not None else 0.0),
                x=x.numpy(), eps=eps.numpy(), mask_in=m_in.numpy().astype(np.uint8),
                mask_out=m_out.numpy().astype(np.uint8),
                loss=loss.numpy(), rec=rec.numpy(), kl=kl.numpy(), total_norm=np.float64(total), coef=np.float64(coef))
@@ -253,6 +263,9 @@ def make_trajectory(name, V, ni, H, nz, B, T, K, klw, model_seed, data_seed, hea
 
 def main():
     full = "--full" in sys.argv
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only == "text_yahoo_seeded":
+        return make_yahoo()
     # small fully materialised case, reference init (KL ~ 1e-5: conditioning case)
     make_case("text_small_refinit", V=53, ni=8, H=16, nz=4, B=4, T=7, klw=0.37, model_seed=11, noise_seed=21, data_seed=31)
     # same dims, wide weights: KL O(1), grad norm > 5 so the clip is ACTIVE
@@ -273,6 +286,15 @@ def main():
         # Yelp/Yahoo-shaped full-size cases: weights regenerated from the seed, outputs + samples stored
         make_case("text_yelp_seeded", V=19997, ni=512, H=1024, nz=32, B=32, T=100, klw=0.1, model_seed=783435,
                   noise_seed=26, data_seed=37, store_params=False)
+        make_yahoo()
+
+
+def make_yahoo():
+    # BASELINE.json's metric configuration (Yahoo: B=32, T=200, V=20001), weights 5x the reference init, a wide encoder
+    # head and a wide vocabulary projection so that the logits matter: loss 2.6 % above (T-1) ln V, KL O(0.1), gradient
+    # norm far above the clip threshold (the clip is active)
+    make_case("text_yahoo_seeded", V=20001, ni=512, H=1024, nz=32, B=32, T=200, klw=0.5, model_seed=783435,
+              noise_seed=27, data_seed=38, model_scale=0.05, head_scale=0.2, pred_scale=0.3, store_params=False)
 
 
 if __name__ == "__main__":

@@ -255,3 +255,164 @@ def check_bf16_native_operands_equal_on_the_fly(device, V=333, ni=24, H=64, nz=8
     assert abs(s1["norm"] - s0["norm"]) <= 1e-4 * abs(s0["norm"]), (s1["norm"], s0["norm"])
     for k in g0:       # max-norm relative; 5e-3 ~ one flipped bf16 rounding (2^-8) in a recurrent operand, amplified through BPTT
         assert rel_err(g1[k], g0[k]) < 5e-3, (k, rel_err(g1[k], g0[k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# joint step after aggressive mode ends (text.py:418-421: encoder AND decoder stepped) and the fixed-K loop of the stress config
+def check_update_both_and_fixed_k(device, V=97, ni=12, H=20, nz=4, B=6, K=4, precision="f32", tol=5e-4):
+    """inner_loop(fixed_k=K) takes exactly K encoder steps on the batches the seeded host stream picks (text.py:389) with no
+    data-dependent exit, then step(update='both') moves encoder and decoder (text.py:418-424 with aggressive_flag off);
+    every step against oracle.inner_step on the same batches and noise."""
+    import numpy as np
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    P = O.random_params(V, ni, H, nz, seed=51, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    Ts = [5, 8, 6]
+    batches = [O.synthetic_batch(B, T, V, seed=60 + i) for i, T in enumerate(Ts)]
+    klw = 0.7
+
+    def noise_for(step, x):
+        return O.draw_noise(x.shape[0], x.shape[1], ni, H, nz, seed=700 + step)
+    rs = np.random.RandomState(9)
+    Pr = {k: v.clone() for k, v in P.items()}
+    x = batches[0]
+    for step in range(K):
+        eps, mi, mo = noise_for(step, x)
+        Pr.update(O.inner_step(Pr, x, klw, eps, mi, mo)["new_params"])
+        x = batches[int(rs.randint(0, len(batches)))]
+    eps, mi, mo = noise_for(K, batches[1])
+    rj = O.inner_step(Pr, batches[1], klw, eps, mi, mo, update="both")
+    Pr.update(rj["new_params"])
+
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision)
+    counter = {"n": 0}
+
+    def dev_noise(n):
+        e, a, b = n
+        return e.to(device), a.to(torch.uint8).to(device), b.to(torch.uint8).to(device)
+
+    def noise_fn(xb):
+        n = dev_noise(noise_for(counter["n"], xb))
+        counter["n"] += 1
+        return n
+    # window=1 would break at the first window; fixed_k must ignore the exit test altogether
+    steps = tr.inner_loop([b.to(device) for b in batches], batches[0].to(device), klw, np_rng=np.random.RandomState(9),
+                          max_iter=100, window=1, fixed_k=K, noise_fn=noise_fn)
+    assert steps == K, steps
+    tr.step(batches[1].to(device), klw, noise=dev_noise(noise_for(K, batches[1])), update="both")
+    st = tr.read_stats()
+    assert abs(st["loss_sum"] - float(rj["loss"].sum())) < tol * abs(float(rj["loss"].sum()))     # the joint step alone
+    assert abs(st["norm"] - rj["total_norm"]) < tol * rj["total_norm"]
+    sd = vae.state_dict()
+    for k in ALL_KEYS:
+        assert rel_err(sd[k], Pr[k]) < tol, (k, rel_err(sd[k], Pr[k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Omniglot: the aggressive loop of image.py:295-327 and an eval-mode forward after a decoder update
+def _image_params(vae):
+    return {k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}
+
+
+def check_image_inner_loop(device, B=6, N=40, window=2, max_iter=7, seed=5):
+    """image.py:295-327 replayed literally (np.random.choice(N, B, replace=False) batch pick, torch.bernoulli dynamic
+    binarisation, window test on the mean loss per example, break) with the CPU oracle doing the arithmetic (Adam state
+    and BatchNorm running statistics carried along), against AggressiveImageTrainer.inner_loop on the same picks, the
+    same binarisation draws and the same eps."""
+    import numpy as np
+    from oracle import image_vae_oracle as IO
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    vae = build_image_vae(device, 31)
+    P = _image_params(vae)
+    g = torch.Generator().manual_seed(seed)
+    x_train = torch.rand(N, 1, 28, 28, generator=g)
+    klw = 0.7
+
+    def binarize(step, probs):
+        gg = torch.Generator().manual_seed(4000 + step)
+        return (torch.rand(probs.shape, generator=gg) < probs.cpu()).float()
+
+    def eps_for(step):
+        gg = torch.Generator().manual_seed(5000 + step)
+        return torch.randn(B, 1, 32, generator=gg)
+    first = binarize(999, x_train[:B])
+    # ---- reference control flow, oracle arithmetic
+    rs = np.random.RandomState(11)
+    Pr = {k: v.clone() for k, v in P.items()}
+    adam = None
+    sub_iter, x = 1, first
+    burn_n, burn_pre, burn_cur = 0, 1e4, 0.0
+    ref_steps = 0
+    while sub_iter < max_iter:
+        burn_n += x.shape[0]
+        r = IO.inner_step_adam(Pr, x, klw, eps_for(ref_steps), adam=adam)
+        burn_cur += float(r["loss"].sum())
+        adam = r["adam"]
+        Pr.update(r["new_params"]); Pr.update(r["new_stats"]); Pr.update(r["masked_weights"])
+        ref_steps += 1
+        id_ = rs.choice(N, B, replace=False)
+        x = binarize(ref_steps, x_train[torch.from_numpy(id_)])
+        if sub_iter % window == 0:
+            burn_cur = burn_cur / burn_n
+            if burn_pre - burn_cur < 0:
+                break
+            burn_pre = burn_cur
+            burn_cur = burn_n = 0
+        sub_iter += 1
+    # ---- the fused driver
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0)
+    cnt = {"eps": 0, "bin": 0}
+
+    def eps_fn(xb):
+        e = eps_for(cnt["eps"]).to(device)
+        cnt["eps"] += 1
+        return e
+
+    def binarize_fn(probs):
+        cnt["bin"] += 1
+        return binarize(cnt["bin"], probs).to(device)
+    steps = tr.inner_loop(x_train.to(device), first.to(device), klw, batch_size=B, np_rng=np.random.RandomState(11),
+                          max_iter=max_iter, window=window, eps_fn=eps_fn, binarize_fn=binarize_fn)
+    assert steps == ref_steps, (steps, ref_steps)
+    sd = vae.state_dict()
+    for k in sd:
+        if k.startswith("encoder.") and not k.endswith("num_batches_tracked"):
+            # Adam moves every weight by ~lr per step whatever the gradient's size: compare the accumulated UPDATE
+            ref_u, got_u = Pr[k] - P[k], sd[k].cpu() - P[k]
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                # the statistics see activations computed from weights that Adam moved: a 5 % difference in a few of the
+                # ~lr-sized updates (see below) shows up here at the 1e-3 level
+                assert rel_err(sd[k], Pr[k]) < 5e-3, (k, rel_err(sd[k], Pr[k]))
+            else:
+                assert float((got_u - ref_u).abs().max()) < 0.05 * 1e-3 * steps + 1e-7, (k, float((got_u - ref_u).abs().max()))
+    return steps
+
+
+def check_image_eval_after_decoder_update(device, B=6):
+    """MaskedConv2d multiplies its weight by the mask on EVERY forward (dec_pixelcnn_v2.py:29), eval mode included.  After a
+    step that updates the decoder (update='both') the masked taps carry non-zero values (their gradients are kept); an
+    eval-mode loss must still not see the target pixel: compare with the oracle in eval mode on the updated weights."""
+    from oracle import image_vae_oracle as IO
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    vae = build_image_vae(device, 33)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(B, 1, 28, 28, generator=g) < 0.4).float()
+    eps = torch.randn(B, 1, 32, generator=g)
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0)
+    tr.step(x.to(device), 1.0, eps=eps.to(device), update="both")
+    sd = _image_params(vae)
+    dirty = 0.0
+    for k in sd:
+        if k.endswith(".mask"):
+            dirty = max(dirty, float((sd[k.replace(".mask", ".weight")] * (1 - sd[k])).abs().max()))
+    assert dirty > 0.0            # the decoder Adam step did move the masked taps
+    vae.eval()
+    with torch.no_grad():
+        loss, rec, kl = vae.loss(x.to(device), 1.0, nsamples=1, noise=(eps.to(device), None, None))
+    vae.train()
+    c = IO.Ctx(sd, train=False)
+    with torch.no_grad():
+        l_r, rec_r, kl_r = IO.vae_loss(c, x, 1.0, eps)
+    assert rel_err(rec, rec_r) < 1e-4, rel_err(rec, rec_r)
+    assert rel_err(kl, kl_r) < 1e-4

@@ -35,3 +35,7 @@ def test_inner_loop_exit_logic_emulated(emu_backend):
 
 def test_bf16_native_operands_equal_on_the_fly_emulated(emu_backend):
     pc.check_bf16_native_operands_equal_on_the_fly("cpu", V=133, ni=16, H=24, nz=4, B=5, T=6)
+
+
+def test_update_both_and_fixed_k_emulated(emu_backend):
+    pc.check_update_both_and_fixed_k("cpu")

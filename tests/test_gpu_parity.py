@@ -95,18 +95,28 @@ def test_bf16_native_operands_equal_on_the_fly(hip_device):
     pc.check_bf16_native_operands_equal_on_the_fly(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30)
 
 
-def test_yelp_full_size_fixture(hip_device):
-    """BASELINE.json configs[1] shape (B=32, T=100, V=19997, ni=512, H=1024, nz=32): weights regenerated from the
-    reference seed through the same nn.Module construction order, outputs from the reference run."""
-    fx = load("text_yelp_seeded")
+def _seeded_full_size_vae(fx, device):
+    """Weights regenerated from the reference seed through the same nn.Module construction order (+ the same post-init
+    redraws of the encoder head / vocabulary projection the fixture script applied); checked against the stored samples."""
     V, ni, H, nz = int(fx["V"]), int(fx["ni"]), int(fx["H"]), int(fx["nz"])
     vae = build_vae(V, ni, H, nz, "cpu", seed=int(fx["model_seed"]), model_scale=float(fx["model_scale"]),
                     emb_scale=float(fx["emb_scale"]))
+    with torch.no_grad():
+        if "head_scale" in fx and float(fx["head_scale"]) > 0:
+            vae.encoder.linear.weight.uniform_(-float(fx["head_scale"]), float(fx["head_scale"]))
+        if "pred_scale" in fx and float(fx["pred_scale"]) > 0:
+            vae.decoder.pred_linear.weight.uniform_(-float(fx["pred_scale"]), float(fx["pred_scale"]))
     sd = vae.state_dict()
     for k in ALL_KEYS:   # the regenerated weights ARE the reference's
         idx = torch.from_numpy(fx["sample_idx/" + k])
         assert torch.equal(sd[k].reshape(-1)[idx], torch.from_numpy(fx["sample_param/" + k])), k
-    vae = vae.to(hip_device)
+    return vae.to(device)
+
+
+def _check_full_size_fixture_dropin(hip_device, name):
+    """text.py:373-387 on the drop-in modules (exact-f32 path) against a full-size fixture from the reference run."""
+    fx = load(name)
+    vae = _seeded_full_size_vae(fx, hip_device)
     x = torch.from_numpy(fx["x"]).to(hip_device)
     noise = tuple(torch.from_numpy(fx[k]).to(hip_device) for k in ("eps", "mask_in", "mask_out"))
     enc_opt = torch.optim.SGD(vae.encoder.parameters(), lr=1.0)
@@ -131,9 +141,88 @@ def test_yelp_full_size_fixture(hip_device):
     assert abs(total - float(fx["total_norm64"])) / float(fx["total_norm64"]) < 1e-4
     enc_opt.step()
     sd = vae.state_dict()
+    coef_ref = min(1.0, 5.0 / (float(fx["total_norm"]) + 1e-6))
+    coef_got = min(1.0, 5.0 / (total + 1e-6))
     for k in ENC_KEYS:
         idx = torch.from_numpy(fx["sample_idx/" + k]).to(hip_device)
-        assert float((sd[k].reshape(-1)[idx].cpu() - torch.from_numpy(fx["sample_new/" + k])).abs().max()) < 1e-6, k
+        p0 = torch.from_numpy(fx["sample_param/" + k])
+        # with the clip active the reference's coefficient inherits its fp32 norm's error: compare de-clipped updates
+        upd_ref = (torch.from_numpy(fx["sample_new/" + k]) - p0) / coef_ref
+        upd_got = (sd[k].reshape(-1)[idx].cpu() - p0) / coef_got
+        assert float((upd_got - upd_ref).abs().max()) < 1e-4 * float(upd_ref.abs().max()) + 1e-6, k
+
+
+def test_yelp_full_size_fixture(hip_device):
+    """BASELINE.json configs[1] shape (B=32, T=100, V=19997, ni=512, H=1024, nz=32): weights regenerated from the
+    reference seed through the same nn.Module construction order, outputs from the reference run."""
+    _check_full_size_fixture_dropin(hip_device, "text_yelp_seeded")
+
+
+def test_yahoo_full_size_fixture(hip_device):
+    """BASELINE.json's metric configuration (B=32, T=200, V=20001, ni=512, H=1024, nz=32) on weights where the logits
+    matter (loss 2.6 % above (T-1) ln V, clip active): exact-f32 path vs the reference run, <= 1e-4."""
+    _check_full_size_fixture_dropin(hip_device, "text_yahoo_seeded")
+
+
+def test_bf16_headline_path_at_headline_shape(hip_device):
+    """The arithmetic the bench line is quoted on -- bf16 operand images, bf16 recurrent operands, persistent XCD-group
+    LSTM launches -- at the bench shape itself (B=32, T=200, V=20001, H=1024) against the REFERENCE run of the same
+    seeded model, inputs and noise (tests/golden/text_yahoo_seeded.npz).  The model-dependent part of the loss is
+    rec - (T-1) ln V (48.7 per sequence here); bf16 operand rounding over 200 steps of BPTT is what this test sees and
+    a T=14 test does not.  Measured deltas are written to gpurun_out/ and asserted below."""
+    import json, math, os
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    fx = load("text_yahoo_seeded")
+    vae = _seeded_full_size_vae(fx, hip_device)
+    p0 = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    x = torch.from_numpy(fx["x"]).to(hip_device)
+    noise = tuple(torch.from_numpy(fx[k]).to(hip_device) for k in ("eps", "mask_in", "mask_out"))
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+    tr.step(x, float(fx["kl_weight"]), noise=noise)
+    st = tr.read_stats()                                   # raises if a persistent launch reported a hand-off timeout
+    B, T, V = int(fx["B"]), int(fx["T"]), int(fx["V"])
+    base = B * (T - 1) * math.log(V)
+    named = dict(vae.named_parameters())
+    out = {"persistent_used": bool(tr.enc.persistent and torch.cuda.get_device_properties(hip_device).multi_processor_count >= 256)}
+    out["loss_rel"] = abs(st["loss_sum"] - float(fx["loss"].sum())) / abs(float(fx["loss"].sum()))
+    out["rec_rel"] = abs(st["rec_sum"] - float(fx["rec"].sum())) / abs(float(fx["rec"].sum()))
+    out["rec_excess_rel"] = abs(st["rec_sum"] - float(fx["rec"].sum())) / abs(float(fx["rec"].sum()) - base)
+    out["kl_rel"] = abs(st["kl_sum"] - float(fx["kl"].sum())) / abs(float(fx["kl"].sum()))
+    out["norm_rel"] = abs(st["norm"] - float(fx["total_norm64"])) / float(fx["total_norm64"])
+    coef = min(1.0, 5.0 / (float(fx["total_norm64"]) + 1e-6))
+    gn, gs = {}, {}
+    for k in ALL_KEYS:                                      # .grad holds the CLIPPED gradient, as clip_grad_norm_ leaves it
+        g = named[k].grad
+        ref_n = float(fx["gradnorm/" + k]) * coef
+        gn[k] = abs(float(g.double().norm()) - ref_n) / ref_n
+        idx = torch.from_numpy(fx["sample_idx/" + k]).to(hip_device)
+        rms = ref_n / max(1.0, g.numel() ** 0.5)
+        gs[k] = float((g.reshape(-1)[idx].cpu() - torch.from_numpy(fx["sample_grad/" + k]) * coef).abs().max()) / rms
+    out["gradnorm_rel_max"] = max(gn.values())
+    out["gradnorm_rel"] = gn
+    out["grad_sample_err_over_rms_max"] = max(gs.values())
+    upd = {}
+    coef_ref = min(1.0, 5.0 / (float(fx["total_norm"]) + 1e-6))
+    for k in ENC_KEYS:
+        idx = torch.from_numpy(fx["sample_idx/" + k]).to(hip_device)
+        q0 = torch.from_numpy(fx["sample_param/" + k])
+        u_ref = (torch.from_numpy(fx["sample_new/" + k]) - q0) / coef_ref
+        u_got = (vae.state_dict()[k].reshape(-1)[idx].cpu() - q0) / min(1.0, 5.0 / (st["norm"] + 1e-6))
+        upd[k] = float((u_got - u_ref).abs().max()) / (float(u_ref.abs().max()) + 1e-30)
+    out["enc_update_rel_max"] = max(upd.values())
+    for k in DEC_KEYS:                                      # encoder-only step: decoder untouched
+        assert torch.equal(vae.state_dict()[k], p0[k]), k
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bf16_headline_parity.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("bf16 headline parity:", json.dumps(out))
+    # Bounds = ~5-10x the deltas measured on MI355X (profiles/r02_bf16_headline_parity.json: loss 1.8e-6, rec excess 7.5e-5,
+    # KL 2.1e-4, norm 1.3e-6, per-tensor grad norms <= 1.5e-4, sampled grad entries within 1.9 % of the tensor's RMS,
+    # encoder update 2.8e-3): the bf16 configuration meets the north-star's 1e-4 ELBO bound at the headline shape.
+    assert out["loss_rel"] < 1e-4 and out["rec_rel"] < 1e-4, out
+    assert out["rec_excess_rel"] < 1e-3 and out["kl_rel"] < 2e-3, out
+    assert out["norm_rel"] < 1e-4 and out["gradnorm_rel_max"] < 2e-3, out
+    assert out["grad_sample_err_over_rms_max"] < 0.1 and out["enc_update_rel_max"] < 2e-2, out
 
 
 def test_yahoo_bench_config_against_oracle(hip_device):
@@ -273,3 +362,52 @@ def test_inner_loop_with_data_dependent_exit(hip_device, window, max_iter):
         max_iter = 14          # the reference's `sub_iter < 100` bound, shortened for the CPU oracle replica
     steps = pc.check_inner_loop_exit_logic(hip_device, window=window, max_iter=max_iter)
     assert 1 <= steps < max_iter
+
+
+def test_update_both_and_fixed_k(hip_device):
+    """text.py:418-424 with aggressive mode off (encoder and decoder both stepped) after a fixed-K inner loop (the stress
+    configuration's loop form: no data-dependent exit)."""
+    pc.check_update_both_and_fixed_k(hip_device)
+    pc.check_update_both_and_fixed_k(hip_device, V=301, ni=32, H=64, nz=8, B=32, K=3)
+
+
+def test_stress_batch_at_h1024(hip_device):
+    """BASELINE.json configs[4] shape class: H = 1024 with B = 128 sequences per GPU, bf16 configuration.  The persistent
+    BPTT launch covers B <= 32 and the persistent forward B <= 64, so this batch runs on the launch-per-step kernels
+    (engine._persistent_ok declines); one fused step against the f32 oracle to the bf16 path's documented delta, then a
+    fixed-K loop (K = 3) on a pool of such batches stays finite and moves only the encoder."""
+    import numpy as np
+    from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    V, ni, H, nz, B, T, klw = 2000, 64, 1024, 16, 128, 10, 0.5
+    P = O.random_params(V, ni, H, nz, seed=61, scale=0.03, head_scale=0.2)
+    x = O.synthetic_batch(B, T, V, seed=62)
+    eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=63)
+    r = O.inner_step(P, x, klw, eps, m_in, m_out)
+    vae = build_vae(V, ni, H, nz, hip_device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+    img = tr.enc._b16(B, T)
+    assert img is not None and not engine._persistent_ok(tr.enc, img, B, H, hip_device, engine._PERSIST_MAX_B)
+    tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+    st = tr.read_stats()
+    assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
+    assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
+    named = dict(vae.named_parameters())
+    assert max(rel_err(named[k].grad, r["grads"][k] * r["coef"]) for k in ALL_KEYS) < 5e-2
+    dec0 = {k: vae.state_dict()[k].clone() for k in DEC_KEYS}
+    pool = [O.synthetic_batch(B, T, V, seed=70 + i).to(hip_device) for i in range(4)]
+    steps = tr.inner_loop(pool, pool[0], klw, np_rng=np.random.RandomState(3), fixed_k=3)
+    assert steps == 3
+    sd = vae.state_dict()
+    assert all(bool(torch.isfinite(sd[k]).all()) for k in ALL_KEYS)
+    assert all(torch.equal(sd[k], dec0[k]) for k in DEC_KEYS)
+
+
+def test_image_inner_loop_with_data_dependent_exit(hip_device):
+    """image.py:295-327 end to end: same random picks, same binarisation draws, same windowed exit, same encoder."""
+    steps = pc.check_image_inner_loop(hip_device)
+    assert 1 <= steps < 7
+
+
+def test_image_eval_forward_after_decoder_update(hip_device):
+    pc.check_image_eval_after_decoder_update(hip_device)

@@ -88,6 +88,66 @@ __global__ void rng_advance_kernel(uint64_t* state, uint64_t inc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += inc;
 }
 
+// All the noise of one VAE.loss call in ONE launch (same draws as rng_normal substream 0 + rng_keepmask substreams 1, 2
+// followed by rng_advance): blocks [0, nb0) fill eps, [nb0, nb0+nb1) the dropout_in keep-mask, the rest the dropout_out
+// keep-mask.  The offset is advanced by whichever block finishes last (ticket in state[2]); every block has read the
+// state before it takes its ticket.
+struct NoiseP {
+    float* eps; long n_eps;
+    uint8_t* m1; long n1; float keep1;
+    uint8_t* m2; long n2; float keep2;
+    uint64_t* state; uint64_t inc;
+    unsigned nb0, nb1;
+};
+
+__global__ __launch_bounds__(256) void rng_noise_step_kernel(NoiseP p) {
+    const unsigned bid = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    if (bid < p.nb0) {
+        const long i = (long)bid * 256 + tid;
+        if (i * 4 < p.n_eps) {
+            const U4 r = draw(p.state, 0, (uint64_t)i);
+            const float u1 = u01(r.x), u2 = u01(r.y), u3 = u01(r.z), u4 = u01(r.w);
+            const float r1 = sqrtf(-2.f * logf(u1)), r2 = sqrtf(-2.f * logf(u3));
+            const float t1 = 6.283185307179586f * u2, t2 = 6.283185307179586f * u4;
+            const float v[4] = {r1 * cosf(t1), r1 * sinf(t1), r2 * cosf(t2), r2 * sinf(t2)};
+            for (int j = 0; j < 4; ++j)
+                if (i * 4 + j < p.n_eps) p.eps[i * 4 + j] = v[j];
+        }
+    } else {
+        const bool first = bid < p.nb0 + p.nb1;
+        uint8_t* out = first ? p.m1 : p.m2;
+        const long n = first ? p.n1 : p.n2;
+        const long i = (long)(bid - p.nb0 - (first ? 0u : p.nb1)) * 256 + tid;
+        if (i * 8 < n) {
+            const U4 r = draw(p.state, first ? 1 : 2, (uint64_t)i);
+            const uint32_t thr = (uint32_t)((first ? p.keep1 : p.keep2) * 65536.0f);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            if (i * 8 + 8 <= n && ((((uintptr_t)out) & 7) == 0)) {
+                uint32_t lo = 0, hi = 0;
+                for (int j = 0; j < 4; ++j) {
+                    lo |= (((w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) < thr ? 1u : 0u) << (8 * j);
+                    hi |= (((w[2 + (j >> 1)] >> ((j & 1) * 16)) & 0xFFFFu) < thr ? 1u : 0u) << (8 * j);
+                }
+                *reinterpret_cast<uint2*>(out + i * 8) = make_uint2(lo, hi);
+            } else {
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t h = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if (i * 8 + j < n) out[i * 8 + j] = (h < thr) ? 1 : 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(p.state + 2);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            p.state[1] += p.inc;
+            *ticket = 0u;
+        }
+    }
+}
+
 }  // namespace
 
 // state: device uint64[2] = {seed, offset}
@@ -121,6 +181,23 @@ extern "C" int lv_rng_bernoulli_f32(const float* p, float* out, long n, const ui
 extern "C" int lv_rng_advance(uint64_t* state, uint64_t inc, void* stream) {
     if (!state) return LV_ERR_ARG;
     LV_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, stream, state, inc);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// eps (normal, substream 0), the dropout_in keep-mask (substream 1) and the dropout_out keep-mask (substream 2) of one
+// VAE.loss call, then offset += inc, in one launch.  state: device uint64[3] = {seed, offset, ticket (0 between calls)};
+// either mask may be NULL (eval mode).
+extern "C" int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long n_in, float keep_in, uint8_t* mask_out,
+                                 long n_out, float keep_out, uint64_t* state, uint64_t inc, void* stream) {
+    if (!eps || !state || n_eps < 0 || n_in < 0 || n_out < 0) return LV_ERR_ARG;
+    if (!mask_in) n_in = 0;
+    if (!mask_out) n_out = 0;
+    NoiseP p{eps, n_eps, mask_in, n_in, keep_in, mask_out, n_out, keep_out, state, inc,
+             (unsigned)lv_cdiv((n_eps + 3) / 4, 256), (unsigned)lv_cdiv((n_in + 7) / 8, 256)};
+    const unsigned nb = p.nb0 + p.nb1 + (unsigned)lv_cdiv((n_out + 7) / 8, 256);
+    if (nb == 0) return LV_OK;
+    LV_LAUNCH(rng_noise_step_kernel, dim3(nb), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
