@@ -39,6 +39,8 @@ WORKLOADS = {
     "yahoo": dict(V=20001, ni=512, H=1024, nz=32, B=32, T=200),
     "yelp": dict(V=19997, ni=512, H=1024, nz=32, B=32, T=100),
     "toy": dict(V=1004, ni=50, H=50, nz=1, B=16, T=12),
+    # BASELINE.json configs[4]: Yahoo dims, B=128 per GPU, fixed K=50 inner steps (no data-dependent exit)
+    "stress": dict(V=20001, ni=512, H=1024, nz=32, B=128, T=200),
     # BASELINE.json configs[3]: Omniglot ResNet-enc + PixelCNN-dec, 28x28 binary (parity-test case; bench line on request)
     "omniglot": dict(B=50),
 }
@@ -126,10 +128,22 @@ def bench_omniglot(args, dev, rank, world):
         print(json.dumps(out))
 
 
+def lstm_algorithmic_bytes(kind, T, B, H, wb, per_step_weights):
+    """Algorithmic HBM bytes of one recurrence (SURVEY.md 8d accounting: every saved activation written once forward and
+    read once backward, the recurrent weights read once per launch).
+      forward, per timestep:  gx in (16 B per unit-row) + gate records out (16) + c, h out (4 + 4) [+ dropped h out (4) +
+                              keep-mask in (1) for the decoder]                       = 40 (45) * B * H
+      BPTT, per timestep:     gate records in (16) + c in (4) + bf16 dG image out (8) [+ dh_ext in (4) + mask in (1)] = 28 (33) * B * H
+    per_step_weights: the launch-per-step kernels re-read W_hh (wb bytes per element) every timestep."""
+    per_t = {"fwd_enc": 40, "fwd_dec": 45, "bwd_dec": 33, "bwd_enc": 28}[kind] * B * H
+    w = wb * 4 * H * H
+    return per_t * T + w * (T if per_step_weights else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed inner-loop bodies (default 20; stress: 50 = one fixed-K loop)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="yahoo", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", type=int, default=0, help="replay the step as captured hipGraphs (no per-kernel events)")
@@ -139,8 +153,16 @@ def main():
     ap.add_argument("--persistent", type=int, default=1, help="forward LSTM recurrences as one persistent launch (bf16 path)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="decoder weight-gradient GEMMs on a side stream under the BPTT chains (auto: on for f32, off for bf16)")
-    ap.add_argument("--pool", type=int, default=64)
+    ap.add_argument("--dp-mode", default="strict", choices=["strict", "encoder_only"],
+                    help="data-parallel gradient exchange: strict = encoder + decoder buffers (reference clip norm), "
+                         "encoder_only = encoder buffer only (documented deviation)")
+    ap.add_argument("--pool", type=int, default=None)
     args = ap.parse_args()
+    stress = args.workload == "stress"
+    if args.steps is None:
+        args.steps = 50 if stress else 20
+    if args.pool is None:
+        args.pool = 16 if stress else 64
 
     from vae_lagging_encoder_amd import dist as lvdist
     from vae_lagging_encoder_amd import engine
@@ -161,8 +183,8 @@ def main():
 
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
-    sync = lvdist.GradSync(mode="strict") if world > 1 else None
-    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435 + rank, grad_sync=sync, use_graph=bool(args.graph),
+    sync = lvdist.GradSync(mode=args.dp_mode) if world > 1 else None
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, grad_sync=sync, use_graph=bool(args.graph),
                                precision=args.dtype)
     if args.overlap != "auto":
         tr.dec.overlap = (args.overlap == "on")
@@ -173,6 +195,15 @@ def main():
 
     def one_step():
         tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
+
+    def timed_region():
+        if stress:
+            # BASELINE.json configs[4]: fixed K inner steps, no data-dependent exit (text.py:371-400 with the break removed)
+            n = tr.inner_loop(pool, pool[0], kl_weight, np_rng=rs, max_iter=10 ** 9, fixed_k=args.steps)
+            assert n == args.steps
+        else:
+            for _ in range(args.steps):
+                one_step()
 
     def warm_up():
         for _ in range(args.warmup):
@@ -207,8 +238,7 @@ def main():
     tr.reset_stats()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    timed_region()
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
@@ -229,42 +259,64 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s LSTM-VAE aggressive inner step (fwd+bwd+clip+encoder SGD), B=%d/GPU, T=%d, V=%d, "
-                               "ni=%d, H=%d, nz=%d" % (args.workload, B, T, V, ni, H, nz),
+                               "ni=%d, H=%d, nz=%d%s" % ("yahoo" if stress else args.workload, B, T, V, ni, H, nz,
+                                                          ", fixed K=%d inner steps per loop (stress)" % args.steps if stress else ""),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
-                   "hipgraph": bool(args.graph)},
-        "mean_loss_per_seq": round(stats["loss_sum"] / (B * args.steps), 4),
+                   "dp_exchange": (args.dp_mode if world > 1 else None), "hipgraph": bool(args.graph)},
     }
+    if not stress:
+        out["mean_loss_per_seq"] = round(stats["loss_sum"] / (B * args.steps), 4)
     step_flops = 3 * fwd_flops(V, ni, H, nz, B, T)
+    step_s = dt / args.steps
+    # whole-step views SURVEY.md 8d prescribes: algorithmic bytes (56 MB/sequence at the Yahoo shape: every parameter read
+    # once forward and once backward, every gradient written once and read once, saved activations written and read once,
+    # logits never materialised) and algorithmic flops per sequence, against the chip's peaks; and the latency floor of the
+    # four dependent recurrences (>= 1.45 us per dependent hand-off, guide price list)
+    mb_per_seq = {"yahoo": 56.0, "yelp": 1430.0 / 32, "stress": 3990.0 / 128}.get(args.workload)
+    gf_per_seq = step_flops / B / 1e9
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    per_gpu = value / world
+    out["whole_step"] = {
+        "tflops": round(step_flops / step_s / 1e12, 2), "mfma_frac": round(per_gpu * gf_per_seq / 1e3 / peak_mfma, 4),
+        "hbm_GBs_algorithmic": round(per_gpu * mb_per_seq / 1e3, 1) if mb_per_seq else None,
+        "hbm_frac": round(per_gpu * mb_per_seq / 1e3 / PEAK_HBM_GBS, 4) if mb_per_seq else None,
+        "gflop_per_seq": round(gf_per_seq, 2), "mb_per_seq": mb_per_seq,
+        "chain_floor_ms": round((4 * T - 2) * 1.45e-3, 3),
+        "note": "neither roofline binds at B=32: the floor is the serial chain of 4T-2 dependent LSTM timesteps"}
     if prof:
-        # live HIP-event timing of the two kernel groups that make up the step, on their launch stream
+        # live HIP-event timing of the kernel groups that make up the step, on their launch stream
         groups = {}
         for name, recs in prof.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
             groups[name] = dict(ms=ms, work=sum(w for _, _, w, _ in recs), launches=sum(n for _, _, _, n in recs))
         gname = "gemm_" + args.dtype
         gemm = groups.get(gname, dict(ms=0.0, work=0.0, launches=0))
-        lstm_ms = sum(groups[k]["ms"] for k in ("lstm_fwd", "lstm_bwd") if k in groups)
-        lstm_launches = sum(groups[k]["launches"] for k in ("lstm_fwd", "lstm_bwd") if k in groups)
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
         gemm_roof = {
-            "bound": "mfma", "kernel": "lv_gemm_b16_kernel" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(gemm_tf / peak, 4), "traffic": None,
+            "bound": "mfma", "kernel": "lv_gemm_b16_kernel" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2),
+            "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(gemm_tf / peak_mfma, 4), "traffic": None,
             "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
             "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
-        # LSTM recurrence.  Algorithmic HBM bytes: W_hh (4H*H, 2 B/element when the recurrent product runs on the bf16 pipe)
-        # once per LAUNCH + one timestep of f32 state / gates per timestep.  Launch-per-step kernels re-read W_hh every
-        # timestep; the persistent kernels (one launch per recurrence) read it once and keep it in registers.
         wb = 2.0 if args.dtype == "bf16" else 4.0
-        fwd_g = groups.get("lstm_fwd", dict(work=0, launches=0, ms=0.0))      # work = timesteps
-        bwd_g = groups.get("lstm_bwd", dict(work=0, launches=0, ms=0.0))
-        persistent = lstm_launches > 0 and lstm_launches < fwd_g["work"] + bwd_g["work"]
-        state_fwd = 4.0 * (B * H * 3 + B * 4 * H * 2)
-        state_bwd = 4.0 * (B * 4 * H * 4 + B * H * 10)
-        w_reads = lstm_launches if persistent else (fwd_g["work"] + bwd_g["work"])
-        lstm_bytes = wb * 4 * H * H * w_reads + state_fwd * fwd_g["work"] + state_bwd * bwd_g["work"]
+        kinds = ("fwd_enc", "fwd_dec", "bwd_dec", "bwd_enc")
+        lstm_ms = lstm_bytes = 0.0
+        lstm_launches = steps_total = 0
+        per_kind = {}
+        persistent = False
+        for k in kinds:
+            gk = groups.get("lstm_" + k)
+            if not gk:
+                continue
+            Tk = T if k.endswith("enc") else T - 1
+            calls = int(round(gk["work"] / Tk))
+            per_step_w = gk["launches"] > calls                 # launch-per-step kernels re-read W_hh every timestep
+            persistent = persistent or not per_step_w
+            by = lstm_algorithmic_bytes(k, Tk, B, H, wb, per_step_w) * calls
+            per_kind[k] = {"us_per_timestep": round(1e3 * gk["ms"] / gk["work"], 3), "ms_per_step": round(gk["ms"] / args.steps, 4),
+                           "algorithmic_MB_per_call": round(by / calls / 1e6, 1),
+                           "GBs": round(by / (gk["ms"] * 1e-3) / 1e9, 1)}
+            lstm_ms += gk["ms"]; lstm_bytes += by; lstm_launches += gk["launches"]; steps_total += gk["work"]
         lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
-        steps_total = fwd_g["work"] + bwd_g["work"]
         lstm_roof = {
             "bound": "hbm",
             "kernel": ("lstm_{fwd,bwd}_persist_kernel (one launch per recurrence, W_hh register-resident, tagged-granule hand-off per timestep)"
@@ -274,7 +326,10 @@ def main():
             "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3),
             "timesteps_per_step": int(steps_total // args.steps),
             "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
-            "note": "latency-bound chain of dependent timesteps: the HBM fraction is what a perfectly overlapped version would be bound by"}
+            "algorithmic_bytes_per_launch": round(lstm_bytes / max(1, lstm_launches)),
+            "per_recurrence": per_kind,
+            "note": "latency-bound chain of dependent timesteps (hand-off price list: 2.4-3.0 us for an 8 KB all-gather inside a 32-CU "
+                    "group): us_per_timestep is the actionable number, the HBM fraction is what a perfectly overlapped version would be bound by"}
         # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
@@ -283,23 +338,23 @@ def main():
             if tr_:
                 lstm_roof["traffic"] = round(tr_["lstm_persist_MB_per_launch" if persistent else "lstm_MB_per_launch"] * 1e6)
                 gemm_roof["traffic"] = round(tr_["gemm_MB_per_launch"] * 1e6)
-                lstm_roof["algorithmic_bytes_per_launch"] = round(lstm_bytes / max(1, lstm_launches))
-                lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+                lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = pmc.get("source_short", "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)")
+                if "whole_step_GB" in tr_:
+                    out["whole_step"]["hbm_GB_per_step_pmc"] = tr_["whole_step_GB"]
         except (OSError, ValueError, KeyError):
             pass
         if gemm["ms"] >= lstm_ms:
             out["roofline"], out["roofline_secondary"] = gemm_roof, lstm_roof
         else:
             out["roofline"], out["roofline_secondary"] = lstm_roof, gemm_roof
-        out["whole_step_tflops"] = round(step_flops / (dt / args.steps) / 1e12, 2)
+        out["rest_ms_per_step"] = round(1e3 * step_s - (gemm["ms"] + lstm_ms) / args.steps, 4)
     else:
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        out["roofline"] = {"bound": "mfma", "achieved": round(step_flops / (dt / args.steps) / 1e12, 2),
-                           "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(step_flops / (dt / args.steps) / 1e12 / peak, 4),
+        out["roofline"] = {"bound": "mfma", "achieved": round(step_flops / step_s / 1e12, 2),
+                           "peak": peak_mfma, "unit": "TFLOP/s",
+                           "frac": round(step_flops / step_s / 1e12 / peak_mfma, 4),
                            "traffic": None, "note": "whole-step algorithmic flops (graph replay: no per-kernel events)"}
 
-    if world == 1 and args.dtype != "f32" and not args.graph:
+    if world == 1 and args.dtype != "f32" and not args.graph and not stress:
         # the exact-f32 parity path on the same workload (short run, same process) for the record
         tr.enc.precision = tr.dec.precision = "f32"
         for _ in range(2):
@@ -315,45 +370,71 @@ def main():
         out["f32_parity_path"] = {"value": round(B * n32 / d32, 2), "unit": "seq/s", "ms_per_step": round(1e3 * d32 / n32, 4),
                                   "steps": n32, "note": "exact-f32 MFMA GEMMs; ELBO parity <= 1e-4 vs the reference CPU path"}
     if world == 1 and not args.no_cpu_baseline:
-        # The reference's CPU op sequence (oracle 'aten' path = torch CPU ATen ops, oneDNN LSTM) on this box's host
-        # cores, on a BOUNDED sample of the same workload: SB of the B sequences of one batch at full length T
-        # (per-sequence cost is what the metric counts), <= 64 threads (oneDNN's LSTM backward degrades badly with
-        # hundreds of threads: a full B=32 step took 278 s on the 256-core host), ~10-30 s of CPU work.
-        from oracle import text_vae_oracle as O            # the checker, used here only as the timed CPU baseline
-        nthreads = min(64, os.cpu_count() or 1)
-        torch.set_num_threads(nthreads)
-        SB = min(B, 8)
-        P = {k: v.detach().cpu() for k, v in vae.state_dict().items() if k in O.ALL_KEYS}
-        xb = pool[0].cpu()
-        eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=1)
-        xs, es, mis, mos = xb[:SB].contiguous(), eps[:SB].contiguous(), m_in[:SB].contiguous(), m_out[:SB].contiguous()
-        tw = time.perf_counter()
-        O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")              # warm-up
-        warm = time.perf_counter() - tw
-        n_timed, t_cpu = 0, 0.0
-        while n_timed < 3 and (n_timed + 1) * warm + t_cpu < 25.0:
-            tc = time.perf_counter()
-            O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")
-            t_cpu += time.perf_counter() - tc
-            n_timed += 1
-        if n_timed == 0:
-            n_timed, t_cpu = 1, warm
-        out["cpu_baseline"] = {"value": round(SB * n_timed / t_cpu, 3), "unit": "seq/s", "cores": nthreads,
-                               "kind": "port",
-                               "sample": "%d timed inner step(s) on %d of the %d sequences of one batch at full length T=%d "
-                                         "(after 1 warm-up), torch CPU ATen ops (oneDNN LSTM) = the reference's CPU path "
-                                         "restated in oracle/" % (n_timed, SB, B, T)}
-        # ELBO delta of the HIP path vs the oracle on the identical (sub)batch and noise (north_star: <= 1e-4 rel, f32)
-        r = O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten") if n_timed == 0 else None
-        r = r or O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten") if warm < 15 else None
-        if r is not None:
-            vae2 = build_vae(V, ni, H, nz, dev, params=P)
-            tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0, precision=args.dtype)
-            tr2.step(xs.to(dev), kl_weight, noise=(es.to(dev), mis.to(torch.uint8).to(dev), mos.to(torch.uint8).to(dev)))
-            s2 = tr2.read_stats()
-            out["elbo_rel_delta_vs_cpu"] = float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum()))))
-        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        cpu_baseline_and_elbo(out, args, vae, pool, kl_weight, V, ni, H, nz, B, T, dev, value)
     print(json.dumps(out))
+
+
+def cpu_baseline_and_elbo(out, args, vae, pool, kl_weight, V, ni, H, nz, B, T, dev, value):
+    """`cpu_baseline`: the reference's CPU op sequence (oracle 'aten' path = torch CPU ATen ops, oneDNN LSTM, validated
+    bit-identical to the imported reference by tests/golden/make_golden.py) timed on this box's host cores on ONE FULL batch
+    of the workload (B sequences at full length T), at the best of a thread-count sweep (oneDNN's LSTM backward degrades badly
+    with hundreds of threads).  `elbo_delta`: one fused step of the timed arithmetic vs the oracle on a NON-degenerate model
+    (weights 5x the reference init, wide encoder head and vocabulary projection: loss ~2.6 % above (T-1) ln V) -- at the
+    reference init the loss is (T-1) ln V whatever the model computes, which cannot fail."""
+    from oracle import text_vae_oracle as O            # the checker, used here only as the timed CPU baseline / ELBO check
+    from vae_lagging_encoder_amd.factory import build_text_vae as build_vae
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    ncpu = os.cpu_count() or 1
+    P = {k: v.detach().cpu() for k, v in vae.state_dict().items() if k in O.ALL_KEYS}
+    xb = pool[0].cpu()
+    Bc = min(B, 32)                                       # stress: a 32-sequence slice of the 128 (per-sequence cost is the metric)
+    eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=1)
+    xs, es, mis, mos = xb[:Bc].contiguous(), eps[:Bc].contiguous(), m_in[:Bc].contiguous(), m_out[:Bc].contiguous()
+    sweep, budget, spent = {}, 30.0, 0.0
+    for nt in [n for n in (16, 32, 64, 8) if n <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        if not sweep:
+            tw = time.perf_counter()
+            O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")              # warm-up (pages the weights in)
+            spent += time.perf_counter() - tw
+        tc = time.perf_counter()
+        O.inner_step(P, xs, kl_weight, es, mis, mos, impl="aten")
+        d = time.perf_counter() - tc
+        spent += d
+        sweep[nt] = round(Bc / d, 3)
+        if spent > budget:
+            break
+    best = max(sweep, key=lambda k: sweep[k])
+    out["cpu_baseline"] = {"value": sweep[best], "unit": "seq/s", "cores": best, "kind": "port",
+                           "sample": "one timed inner step per thread count on a full batch of %d sequences at full length T=%d "
+                                     "(after 1 warm-up), torch CPU ATen ops (oneDNN LSTM) = the reference's CPU path restated in "
+                                     "oracle/; best of the sweep" % (Bc, T),
+                           "thread_sweep_seq_per_s": {str(k): v for k, v in sorted(sweep.items())}, "host_cpus": ncpu}
+    out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    # ELBO delta on a model where the logits matter, identical batch and noise
+    torch.set_num_threads(best)
+    SB = 8
+    Pn = O.random_params(V, ni, H, nz, seed=7, scale=0.05, head_scale=0.2)
+    g = torch.Generator().manual_seed(8)
+    Pn["decoder.pred_linear.weight"] = ((torch.rand(V, H, generator=g, dtype=torch.float64) * 2 - 1) * 0.3).float()
+    xs, es, mis, mos = xb[:SB].contiguous(), eps[:SB].contiguous(), m_in[:SB].contiguous(), m_out[:SB].contiguous()
+    r = O.inner_step(Pn, xs, 0.5, es, mis, mos, impl="aten")
+    base = SB * (T - 1) * float(np.log(V))
+    deltas = {}
+    for prec in ([args.dtype, "f32"] if args.dtype != "f32" else ["f32"]):
+        vae2 = build_vae(V, ni, H, nz, dev, params=Pn)
+        tr2 = AggressiveTextTrainer(vae2, lr=1.0, clip=5.0, precision=prec)
+        tr2.step(xs.to(dev), 0.5, noise=(es.to(dev), mis.to(torch.uint8).to(dev), mos.to(torch.uint8).to(dev)))
+        s2 = tr2.read_stats()
+        deltas[prec] = {
+            "elbo_rel": float("%.3e" % (abs(s2["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())))),
+            "rec_rel": float("%.3e" % (abs(s2["rec_sum"] - float(r["rec"].sum())) / abs(float(r["rec"].sum())))),
+            "kl_rel": float("%.3e" % (abs(s2["kl_sum"] - float(r["kl"].sum())) / abs(float(r["kl"].sum())))),
+            "grad_norm_rel": float("%.3e" % (abs(s2["norm"] - r["total_norm"]) / r["total_norm"]))}
+    out["elbo_delta_vs_cpu"] = {"per_dtype": deltas, "loss_per_seq": round(float(r["loss"].mean()), 3),
+                                "loss_excess_over_uniform_per_seq": round((float(r["rec"].sum()) - base) / SB, 3),
+                                "sample": "%d sequences at T=%d, non-degenerate weights (scale 0.05, head 0.2, vocabulary projection 0.3)" % (SB, T)}
+    out["elbo_rel_delta_vs_cpu"] = deltas[args.dtype]["elbo_rel"]
 
 
 if __name__ == "__main__":

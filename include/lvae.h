@@ -80,19 +80,25 @@ int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs,
                         const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
 /* The same forward recurrence as ONE persistent launch: 256 workgroups in 8 XCD-sized groups, each group carries a
  * slice of the batch through all T steps with its slice of W_hh held in registers and hands h_t around inside the
- * group through tagged 8-byte granules (lv_lstm_persist.hip).  gx unit-major as for lv_lstm_fwd_bf16_ug; ws of
- * lv_lstm_persist_ws_floats() floats; *status (device int, zeroed by the caller) becomes non-zero if a hand-off timed
- * out.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 64 and the device has >= 256 CUs: use lv_lstm_fwd_bf16_ug then. */
-long lv_lstm_persist_ws_floats(void);
-int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float* hs, float* cs, float* gates,
-                             const uint8_t* dmask, float dscale, float* hdrop, float* ws, int* status,
+ * group through tagged 8-byte granules (lv_lstm_persist.hip).  gx unit-major as for lv_lstm_fwd_bf16_ug; wpk = the
+ * packed register image of W_hh built by lv_lstm_persist_pack(whh, wpk, 0, H) (lv_lstm_persist_wpk_floats() floats; a
+ * caller whose weights do not change between calls -- the decoder during the aggressive inner loop, text.py:371-400 --
+ * packs once); xch = exchange buffer of lv_lstm_persist_xch_floats() floats; *status (device int, zeroed by the caller)
+ * becomes non-zero if a hand-off timed out.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 64 and the device has >= 256
+ * CUs: use lv_lstm_fwd_bf16_ug then. */
+long lv_lstm_persist_wpk_floats(void);
+long lv_lstm_persist_xch_floats(void);
+int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void* stream);
+int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
+                             const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
                              int T, int B, int H, void* stream);
 /* BPTT as one persistent launch (same decomposition; dG[t] is what travels between steps and the gate-gradient math of
  * a step runs where its dh is completed, so a timestep is one phase instead of two launches).  Arguments as
- * lv_lstm_bwd_bf16_img plus ws / status as above.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 32, >= 256 CUs. */
+ * lv_lstm_bwd_bf16_img with wpk = lv_lstm_persist_pack(whh, wpk, 1, H), xch / status as above; dG16 16-byte aligned.
+ * LV_ERR_UNSUPPORTED unless H == 1024, B <= 32, >= 256 CUs. */
 int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                             const float* whh, const float* gates, const float* hs, const float* cs,
-                             float* dG, uint16_t* dG16, float* dGsum, float* ws, int* status, float* dh0, float* dc0,
+                             const float* wpk, const float* gates, const float* hs, const float* cs,
+                             float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                              int tanh_init, int T, int B, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
@@ -152,6 +158,31 @@ int lv_vae_loss_f32(const float* nll, const float* kl, const float* kl_weight_de
 /* upstream grads (each may be NULL) -> rowscale[b] = g_loss+g_rec, dkl[b] = kl_weight*g_loss+g_kl */
 int lv_loss_bwd_scales_f32(const float* g_loss, const float* g_rec, const float* g_kl, const float* kl_weight_dev,
                            float* rowscale, float* dkl, int B, void* stream);
+/* The fused driver's form of the three entries above plus the running report sums (text.py:381,426-427), one launch:
+ * rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + w*kl[b]; acc_dev[0..2] += sum_b (loss, rec, kl); rowscale[b] = g_loss[b];
+ * dkl[b] = w*g_loss[b] (the seeds of loss.mean().backward(), text.py:382-384) */
+int lv_loss_assemble_f32(const float* nll, const float* kl, const float* kl_weight_dev, const float* g_loss,
+                         float* loss, float* rec, float* rowscale, float* dkl, float* acc_dev, int T, int B, void* stream);
+
+/* ---- the batch-sized ends of the two LSTM networks, one launch each (lv_head.hip) --------------------------------------
+ * LSTMEncoder's head + GaussianEncoderBase.encode (enc_lstm.py:62-64, encoder.py:40-57): mulv = hT . W_lin^T,
+ * z = mu + eps*exp(logvar/2), kl = 0.5*sum(mu^2 + exp(logvar) - logvar - 1).  hT [B][H], W_lin [2nz][H], eps/z [B][ns][nz] */
+int lv_enc_head_fwd_f32(const float* hT, const float* w_lin, const float* eps, float* mulv, float* z, float* kl,
+                        int B, int H, int ns, int nz, void* stream);
+/* ... and its backward: (dz, dkl) -> dmulv [B][2nz], dhT [B][H], gW_lin [2nz][H] ('=') */
+int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const float* dz, const float* dkl, const float* hT,
+                        const float* w_lin, float* dmulv, float* dhT, float* gw_lin, int B, int H, int ns, int nz,
+                        void* stream);
+/* LSTMDecoder.decode's z-dependent prologue (dec_lstm.py:95-101): c0 = z W_trans^T, h0 = tanh(c0) (G7) and
+ * Zp = z W_ih[:, col0:col0+nz]^T + b_ih + b_hh, the contribution of cat((word_embed, z_), -1) to the input projection;
+ * Zp gate-major [B][4H], or with column 4u+g (unit_major != 0) for the unit-major Gx epilogue */
+int lv_dec_init_f32(const float* z, const float* w_trans, const float* w_ih, long ld_wih, int col0, const float* b_ih,
+                    const float* b_hh, float* c0, float* h0, float* zp, int unit_major, int B, int H, int nz, void* stream);
+/* ... and its backward from the BPTT's sums: dGsum [B][4H] (gate-major), dc0 [B][H] -> gW_ih[:, col0:col0+nz] (ld_gwih),
+ * g_b_ih, g_b_hh, gW_trans ('=') and dz [B][nz] */
+int lv_dec_tail_bwd_f32(const float* dGsum, const float* dc0, const float* z, const float* w_ih, long ld_wih, int col0,
+                        const float* w_trans, float* gw_ih, long ld_gwih, float* gw_trans, float* gb_ih, float* gb_hh,
+                        float* dz, int B, int H, int nz, void* stream);
 
 /* small elementwise / reductions used by the sequencing (h0 = tanh(c0) dec_lstm.py:100; bias grads) */
 int lv_tanh_f32(const float* in, float* out, long n, void* stream);
@@ -165,6 +196,10 @@ int lv_add_scalar_f32(float* x_dev, float v, void* stream);
 int lv_sumsq_workspace_floats(void);
 int lv_sumsq_f32(const float* x, long n, float* ws, float* out_dev, int accumulate, void* stream);
 int lv_clip_coef_f32(const float* sumsq_dev, float max_norm, float* coef_dev, float* norm_out_dev, void* stream);
+/* clip_grad_norm_ over two flat gradient buffers at once (encoder + decoder: the norm spans both, G1): one streaming pass
+ * over both, then sum + norm + coefficient in one single-workgroup launch.  ws: lv_sumsq_workspace_floats() floats */
+int lv_clip_norm2_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
+                      float* sumsq_dev, float* coef_dev, float* norm_dev, void* stream);
 int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
                     void* stream);
 int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream);
@@ -176,6 +211,10 @@ int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float
 int lv_rng_normal_f32(float* out, long n, const uint64_t* state_dev, uint64_t substream, void* stream);
 int lv_rng_keepmask_u8(uint8_t* out, long n, float keep_prob, const uint64_t* state_dev, uint64_t substream, void* stream);
 int lv_rng_advance(uint64_t* state_dev, uint64_t inc, void* stream);
+/* all the noise of one VAE.loss call in one launch: eps (substream 0), dropout_in / dropout_out keep-masks (substreams
+ * 1, 2; either may be NULL), then offset += inc.  state_dev: uint64[3] = {seed, offset, ticket (0 between calls)} */
+int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long n_in, float keep_in, uint8_t* mask_out, long n_out,
+                      float keep_out, uint64_t* state_dev, uint64_t inc, void* stream);
 int lv_rng_bernoulli_f32(const float* p, float* out, long n, const uint64_t* state_dev, uint64_t substream,
                          void* stream);   /* torch.bernoulli(batch): dynamic binarisation, image.py:287,318 */
 

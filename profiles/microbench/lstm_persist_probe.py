@@ -8,10 +8,14 @@ T, B, H = 200, 32, 1024
 gx = torch.randn(T, B, 4 * H, device=dev) * 0.5
 whh = torch.randn(4 * H, H, device=dev) / H ** 0.5
 hs = torch.zeros(T + 1, B, H, device=dev); cs = torch.zeros(T + 1, B, H, device=dev)
-gates = torch.empty(T, 4 * 64 * 64 * 8 * 8, device=dev)   # oversized: also holds the ABL=8 experiment's log records
+gates = torch.empty(T, B, 4 * H, device=dev)
 hdrop = torch.empty(T, B, H, device=dev)
 mask = (torch.rand(B, T, H, device=dev) < 0.5).to(torch.uint8)
-wsp = torch.empty(lib.lv_lstm_persist_ws_floats(), device=dev)
+wsp = torch.empty(lib.lv_lstm_persist_xch_floats(), device=dev)
+wpk_f = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+wpk_b = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+lib.lv_lstm_persist_pack(P(whh), P(wpk_f), 0, H, s)
+lib.lv_lstm_persist_pack(P(whh), P(wpk_b), 1, H, s)
 ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
 st = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -26,7 +30,7 @@ def t(f, n=10):
 
 
 a = t(lambda: lib.lv_lstm_fwd_bf16_ug(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(ws), T, B, H, s))
-b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(wpk_f), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
 print("launch per step : %8.1f us  (%.2f us/step)" % (a, a / T))
 print("persistent      : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
 
@@ -37,6 +41,6 @@ dO = torch.randn(T, B, H, device=dev)
 dG16 = torch.empty(T, B, 4 * H, dtype=torch.int16, device=dev)
 dGsum = torch.empty(B, 4 * H, device=dev); dc0 = torch.empty(B, H, device=dev)
 a = t(lambda: lib.lv_lstm_bwd_bf16_img(P(dO), None, P(mask), 2.0, P(whh), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(ws), None, P(dc0), 1, T, B, H, s))
-b = t(lambda: lib.lv_lstm_bwd_bf16_persist(P(dO), None, P(mask), 2.0, P(whh), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
+b = t(lambda: lib.lv_lstm_bwd_bf16_persist(P(dO), None, P(mask), 2.0, P(wpk_b), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
 print("BPTT two launches per step : %8.1f us  (%.2f us/step)" % (a, a / T))
 print("BPTT persistent            : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))

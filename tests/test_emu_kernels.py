@@ -124,3 +124,38 @@ def test_batchnorm(emu_backend, cfg):
 
 def test_bce_dec_input_bernoulli(emu_backend):
     K.test_sigmoid_bce_and_dec_input(emu_backend, CPU)
+
+
+@pytest.mark.parametrize("cfg", [(5, 50, 3, 1), (7, 70, 1, 40), (4, 64, 1, 8)])
+def test_enc_head(emu_backend, cfg):
+    K.test_enc_head_fwd_bwd(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(5, 50, 1, 50, 0), (7, 36, 5, 20, 1), (3, 16, 40, 8, 0)])
+def test_dec_init_and_tail(emu_backend, cfg):
+    K.test_dec_init_and_tail(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1, 3), (70, 130)])
+def test_loss_assemble(emu_backend, cfg):
+    K.test_loss_assemble(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1000, 77), (5, 1), (70000, 9000)])
+def test_clip_norm2(emu_backend, cfg):
+    K.test_clip_norm2(emu_backend, CPU, *cfg)
+
+
+def test_noise_step(emu_backend):
+    from vae_lagging_encoder_amd.engine import P
+    n_eps, n_in, n_out = 40, 8 * 300 + 3, 77
+    st = torch.tensor([783435, 5, 0], dtype=torch.int64)
+    eps = torch.empty(n_eps); m1 = torch.empty(n_in, dtype=torch.uint8); m2 = torch.empty(n_out, dtype=torch.uint8)
+    emu_backend.lv_rng_noise_step(P(eps), n_eps, P(m1), n_in, 0.5, P(m2), n_out, 0.3, P(st), 1, None)
+    assert st.tolist() == [783435, 6, 0]
+    st2 = torch.tensor([783435, 5], dtype=torch.int64)
+    e2 = torch.empty_like(eps); a2 = torch.empty_like(m1); b2 = torch.empty_like(m2)
+    emu_backend.lv_rng_normal_f32(P(e2), n_eps, P(st2), 0, None)
+    emu_backend.lv_rng_keepmask_u8(P(a2), n_in, 0.5, P(st2), 1, None)
+    emu_backend.lv_rng_keepmask_u8(P(b2), n_out, 0.3, P(st2), 2, None)
+    assert torch.equal(eps, e2) and torch.equal(m1, a2) and torch.equal(m2, b2)

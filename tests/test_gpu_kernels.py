@@ -338,9 +338,11 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
         gates = torch.empty(T, B, 4 * H, device=dev)
         hdrop = torch.empty(T, B, H, device=dev)
         if persistent:
-            ws = torch.full((lib.lv_lstm_persist_ws_floats(),), float("nan"), device=dev)
+            wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
+            ws = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_fwd_bf16_persist(P(gxu), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
+            lib.lv_lstm_persist_pack(P(whh), P(wpk), 0, H, _s(dev))
+            lib.lv_lstm_fwd_bf16_persist(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
                                          P(ws), P(status), T, B, H, _s(dev))
             assert int(status.item()) == 0
         else:
@@ -392,8 +394,12 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     m8 = mask.to(torch.uint8).contiguous()
     ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
     lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
-    common = (P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
-              P(whh), P(gates), P(hs), P(cs))
+    wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
+    lib.lv_lstm_persist_pack(P(whh), P(wpk), 1, H, _s(dev))
+
+    def common(weights):
+        return (P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
+                P(weights), P(gates), P(hs), P(cs))
     outs = []
     for persistent in (True, False):
         dG = torch.empty(T, B, 4 * H, device=dev)
@@ -402,15 +408,15 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         dh0 = torch.empty(B, H, device=dev)
         dc0 = torch.empty(B, H, device=dev)
         if persistent:
-            wsp = torch.full((lib.lv_lstm_persist_ws_floats(),), float("nan"), device=dev)
+            wsp = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_bwd_bf16_persist(*common, None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init),
+            lib.lv_lstm_bwd_bf16_persist(*common(wpk), None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init),
                                          T, B, H, _s(dev))
             assert int(status.item()) == 0
             dG = torch.cat([dG16.view(torch.bfloat16).float()])      # image-only kernel: compare through the bf16 image
         else:
             ws.fill_(float("nan"))
-            lib.lv_lstm_bwd_bf16_img(*common, P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
+            lib.lv_lstm_bwd_bf16_img(*common(whh), P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
         if not persistent:
             assert torch.equal(dG16.cpu(), dG.cpu().to(torch.bfloat16).view(torch.int16))
         sc, tol = float(gx64.grad.abs().max()), 300.0
@@ -740,3 +746,122 @@ def test_sigmoid_bce_and_dec_input(lib, hip_device):
     out = torch.empty(20000, device=dev)
     lib.lv_rng_bernoulli_f32(P(probs), P(out), 20000, P(st), 7, _s(dev))
     assert set(out.unique().tolist()) <= {0.0, 1.0} and abs(float(out.mean()) - float(probs.mean())) < 0.02
+
+
+# ---- fused glue kernels of one inner step (lv_head.hip, lv_loss_assemble, lv_clip_norm2, lv_rng_noise_step) --------------
+@pytest.mark.parametrize("B,H,ns,nz", [(32, 1024, 1, 32), (5, 50, 3, 1), (7, 70, 1, 40), (128, 256, 1, 32)])
+def test_enc_head_fwd_bwd(lib, hip_device, B, H, ns, nz):
+    dev = hip_device
+    g = torch.Generator().manual_seed(B + H)
+    hT = torch.randn(B, H, generator=g)
+    W = torch.randn(2 * nz, H, generator=g) / H ** 0.5
+    eps = torch.randn(B, ns, nz, generator=g)
+    hT64, W64 = hT.double().requires_grad_(True), W.double().requires_grad_(True)
+    mulv_r = hT64 @ W64.t()
+    mu, lv = mulv_r[:, :nz], mulv_r[:, nz:]
+    z_r = mu.unsqueeze(1) + eps.double() * (0.5 * lv).exp().unsqueeze(1)
+    kl_r = 0.5 * (mu.pow(2) + lv.exp() - lv - 1).sum(1)
+    gz = torch.randn(B, ns, nz, generator=g)
+    gk = torch.randn(B, generator=g)
+    ((z_r * gz.double()).sum() + (kl_r * gk.double()).sum()).backward()
+    d = [t.to(dev) for t in (hT, W, eps, gz, gk)]
+    mulv = torch.empty(B, 2 * nz, device=dev); z = torch.empty(B, ns, nz, device=dev); kl = torch.empty(B, device=dev)
+    lib.lv_enc_head_fwd_f32(P(d[0]), P(d[1]), P(d[2]), P(mulv), P(z), P(kl), B, H, ns, nz, _s(dev))
+    assert float((mulv.cpu().double() - mulv_r.detach()).abs().max()) < 1e-5 * float(mulv_r.abs().max())
+    assert float((z.cpu().double() - z_r.detach()).abs().max()) < 1e-5 * float(z_r.abs().max())
+    assert float((kl.cpu().double() - kl_r.detach()).abs().max()) < 1e-5 * float(kl_r.abs().max())
+    dmulv = torch.empty(B, 2 * nz, device=dev); dhT = torch.empty(B, H, device=dev); gW = torch.empty(2 * nz, H, device=dev)
+    lib.lv_enc_head_bwd_f32(P(mulv), P(d[2]), P(d[3]), P(d[4]), P(d[0]), P(d[1]), P(dmulv), P(dhT), P(gW), B, H, ns, nz, _s(dev))
+    assert float((dhT.cpu().double() - hT64.grad).abs().max()) < 2e-5 * float(hT64.grad.abs().max())
+    assert float((gW.cpu().double() - W64.grad).abs().max()) < 2e-5 * float(W64.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,H,nz,ni,unit_major", [(32, 1024, 32, 512, 1), (5, 50, 1, 50, 0), (7, 36, 5, 20, 1), (128, 64, 40, 8, 0)])
+def test_dec_init_and_tail(lib, hip_device, B, H, nz, ni, unit_major):
+    dev = hip_device
+    g = torch.Generator().manual_seed(B * 3 + H)
+    z = torch.randn(B, nz, generator=g)
+    wtr = torch.randn(H, nz, generator=g)
+    wih = torch.randn(4 * H, ni + nz, generator=g)
+    bih, bhh = torch.randn(4 * H, generator=g), torch.randn(4 * H, generator=g)
+    c0_r = z.double() @ wtr.double().t()
+    zp_r = z.double() @ wih[:, ni:].double().t() + bih.double() + bhh.double()
+    d = [t.to(dev) for t in (z, wtr, wih, bih, bhh)]
+    c0 = torch.empty(B, H, device=dev); h0 = torch.empty(B, H, device=dev); zp = torch.empty(B, 4 * H, device=dev)
+    lib.lv_dec_init_f32(P(d[0]), P(d[1]), P(d[2]), ni + nz, ni, P(d[3]), P(d[4]), P(c0), P(h0), P(zp), unit_major, B, H, nz, _s(dev))
+    if unit_major:
+        zp = zp.view(B, H, 4).permute(0, 2, 1).reshape(B, 4 * H)
+    assert float((c0.cpu().double() - c0_r).abs().max()) < 1e-5 * float(c0_r.abs().max())
+    assert float((h0.cpu().double() - torch.tanh(c0_r)).abs().max()) < 1e-5
+    assert float((zp.cpu().double() - zp_r).abs().max()) < 1e-5 * float(zp_r.abs().max())
+    # tail
+    dGsum = torch.randn(B, 4 * H, generator=g)
+    dc0 = torch.randn(B, H, generator=g)
+    gwih = torch.full((4 * H, ni + nz), 7.0, device=dev)
+    gwtr = torch.empty(H, nz, device=dev); gb1 = torch.empty(4 * H, device=dev); gb2 = torch.empty(4 * H, device=dev)
+    dz = torch.empty(B, nz, device=dev)
+    lib.lv_dec_tail_bwd_f32(P(dGsum.to(dev)), P(dc0.to(dev)), P(d[0]), P(d[2]), ni + nz, ni, P(d[1]), P(gwih), ni + nz, P(gwtr),
+                            P(gb1), P(gb2), P(dz), B, H, nz, _s(dev))
+    r_gwih = dGsum.double().t() @ z.double()
+    r_gwtr = dc0.double().t() @ z.double()
+    r_b = dGsum.double().sum(0)
+    r_dz = dGsum.double() @ wih[:, ni:].double() + dc0.double() @ wtr.double()
+    assert float((gwih[:, ni:].cpu().double() - r_gwih).abs().max()) < 2e-5 * float(r_gwih.abs().max())
+    assert bool((gwih[:, :ni] == 7.0).all())                       # the word-embedding columns are not touched
+    assert float((gwtr.cpu().double() - r_gwtr).abs().max()) < 2e-5 * float(r_gwtr.abs().max())
+    assert float((gb1.cpu().double() - r_b).abs().max()) < 2e-5 * float(r_b.abs().max()) and torch.equal(gb1, gb2)
+    assert float((dz.cpu().double() - r_dz).abs().max()) < 5e-5 * float(r_dz.abs().max())
+
+
+@pytest.mark.parametrize("T,B", [(199, 32), (1, 3), (70, 130)])
+def test_loss_assemble(lib, hip_device, T, B):
+    dev = hip_device
+    g = torch.Generator().manual_seed(T + B)
+    nll = torch.rand(T, B, generator=g) * 10
+    kl = torch.rand(B, generator=g)
+    gl = torch.full((B,), 1.0 / B)
+    klw = torch.tensor([0.37])
+    acc = torch.tensor([1.0, 2.0, 3.0], device=dev)
+    outs = [torch.empty(B, device=dev) for _ in range(4)]
+    lib.lv_loss_assemble_f32(P(nll.to(dev)), P(kl.to(dev)), P(klw.to(dev)), P(gl.to(dev)), P(outs[0]), P(outs[1]), P(outs[2]),
+                             P(outs[3]), P(acc), T, B, _s(dev))
+    rec_r = nll.double().sum(0)
+    loss_r = rec_r + 0.37 * kl.double()
+    assert float((outs[1].cpu().double() - rec_r).abs().max()) < 1e-5 * float(rec_r.abs().max())
+    assert float((outs[0].cpu().double() - loss_r).abs().max()) < 1e-5 * float(loss_r.abs().max())
+    assert torch.allclose(outs[2].cpu(), gl) and torch.allclose(outs[3].cpu(), 0.37 * gl)
+    want = torch.tensor([1.0 + float(loss_r.sum()), 2.0 + float(rec_r.sum()), 3.0 + float(kl.double().sum())])
+    assert float((acc.cpu() - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("n1,n2", [(1000, 77), (1 << 20, (1 << 21) + 13), (5, 1)])
+def test_clip_norm2(lib, hip_device, n1, n2):
+    dev = hip_device
+    g = torch.Generator().manual_seed(n1 + n2)
+    a, b = torch.randn(n1, generator=g), torch.randn(n2, generator=g) * 0.01
+    ws = torch.empty(lib.lv_sumsq_workspace_floats(), device=dev)
+    out = torch.zeros(3, device=dev)
+    lib.lv_clip_norm2_f32(P(a.to(dev)), n1, P(b.to(dev)), n2, P(ws), 5.0, P(out, 0), P(out, 1), P(out, 2), _s(dev))
+    nrm = float((a.double().pow(2).sum() + b.double().pow(2).sum()).sqrt())
+    o = out.cpu().tolist()
+    assert abs(o[2] - nrm) < 1e-5 * nrm and abs(o[0] - nrm * nrm) < 1e-5 * nrm * nrm
+    assert abs(o[1] - min(1.0, 5.0 / (nrm + 1e-6))) < 1e-5
+
+
+def test_noise_step_equals_separate_draws(lib, hip_device):
+    dev = hip_device
+    n_eps, n_in, n_out = 32 * 32, 32 * 199 * 512 + 3, 5 * 7 * 11
+    st = torch.tensor([783435, 5, 0], dtype=torch.int64, device=dev)
+    eps = torch.empty(n_eps, device=dev); m1 = torch.empty(n_in, dtype=torch.uint8, device=dev)
+    m2 = torch.empty(n_out, dtype=torch.uint8, device=dev)
+    lib.lv_rng_noise_step(P(eps), n_eps, P(m1), n_in, 0.5, P(m2), n_out, 0.3, P(st), 1, _s(dev))
+    assert st.cpu().tolist() == [783435, 6, 0]
+    st2 = torch.tensor([783435, 5], dtype=torch.int64, device=dev)
+    e2 = torch.empty_like(eps); a2 = torch.empty_like(m1); b2 = torch.empty_like(m2)
+    lib.lv_rng_normal_f32(P(e2), n_eps, P(st2), 0, _s(dev))
+    lib.lv_rng_keepmask_u8(P(a2), n_in, 0.5, P(st2), 1, _s(dev))
+    lib.lv_rng_keepmask_u8(P(b2), n_out, 0.3, P(st2), 2, _s(dev))
+    assert torch.equal(eps, e2) and torch.equal(m1, a2) and torch.equal(m2, b2)
+    # eval mode: no masks
+    lib.lv_rng_noise_step(P(eps), n_eps, None, 0, 0.5, None, 0, 0.5, P(st), 1, _s(dev))
+    assert st.cpu().tolist() == [783435, 7, 0] and not torch.equal(eps, e2)

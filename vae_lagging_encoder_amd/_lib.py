@@ -26,7 +26,16 @@ SIGNATURES = {
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
-    "lv_lstm_persist_ws_floats": [],
+    "lv_lstm_persist_wpk_floats": [],
+    "lv_lstm_persist_xch_floats": [],
+    "lv_lstm_persist_pack": [_vp, _vp, _i, _i, _vp],
+    "lv_loss_assemble_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lv_enc_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_enc_head_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_dec_init_f32": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_dec_tail_bwd_f32": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_clip_norm2_f32": [_vp, _l, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp],
+    "lv_rng_noise_step": [_vp, _l, _vp, _l, _f, _vp, _l, _f, _vp, _u64, _vp],
     "lv_lstm_fwd_bf16_persist": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
@@ -96,13 +105,13 @@ class Lib(object):
                 missing.append(name)
                 continue
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_long if name in ("lv_lstm_ws_floats", "lv_lstm_persist_ws_floats") else ctypes.c_int
+            fn.restype = ctypes.c_long if name in ("lv_lstm_ws_floats", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats") else ctypes.c_int
             setattr(self, "_raw_" + name, fn)
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
-                           "lv_lstm_persist_ws_floats"}
+                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

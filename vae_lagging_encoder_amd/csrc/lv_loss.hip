@@ -190,6 +190,35 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
     }
 }
 
+// Loss assembly of one VAE.loss call + everything the trainer derives from it, in one single-workgroup launch:
+// rec[b] = sum_t nll[t][b] (one wave per sequence, as vae_loss_kernel), loss[b] = rec[b] + w*kl[b],
+// acc[0..2] += sum_b (loss, rec, kl) (the running sums text.py:381,426-427 read), and the backward seeds of
+// mean_b(loss_b): rowscale[b] = g_loss[b], dkl[b] = w*g_loss[b].
+__global__ __launch_bounds__(256) void loss_assemble_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
+                                                            const float* __restrict__ klw, const float* __restrict__ g_loss,
+                                                            float* __restrict__ loss, float* __restrict__ rec,
+                                                            float* __restrict__ rowscale, float* __restrict__ dkl,
+                                                            float* __restrict__ acc, int T, int B) {
+    __shared__ float red[3][4];
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const float kw = klw[0];
+    float sl = 0.f, sr = 0.f, sk = 0.f;
+    for (int b = w; b < B; b += 4) {
+        float s = 0.f;
+        for (int t = l; t < T; t += 64) s += nll[(long)t * B + b];
+        s = lv_wave_sum(s);
+        if (l == 0) {
+            const float k = kl[b], lo = s + kw * k, g = g_loss[b];
+            rec[b] = s; loss[b] = lo;
+            rowscale[b] = g; dkl[b] = kw * g;
+            sl += lo; sr += s; sk += k;
+        }
+    }
+    if (l == 0) { red[0][w] = sl; red[1][w] = sr; red[2][w] = sk; }
+    __syncthreads();
+    if (tid < 3) acc[tid] += (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
 // upstream grads (each may be null) -> per-row scales used by the backward kernels
 __global__ __launch_bounds__(256) void loss_bwd_scales_kernel(const float* g_loss, const float* g_rec, const float* g_kl,
                                                               const float* klw, float* rowscale, float* dkl, int B) {
@@ -321,6 +350,19 @@ extern "C" int lv_add_f32(const float* a, const float* b, float* out, long n, vo
     if (!a || !b || !out || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
     LV_LAUNCH(add_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// VAE.loss assembly (modules/vae.py:95-98) + the running report sums (text.py:381,426-427) + the backward seeds of
+// loss.mean().backward() (text.py:382-384) in one launch.  nll [T][B]; kl, g_loss [B]; acc: device float[3] (+=).
+extern "C" int lv_loss_assemble_f32(const float* nll, const float* kl, const float* kl_weight_dev, const float* g_loss,
+                                    float* loss, float* rec, float* rowscale, float* dkl, float* acc, int T, int B,
+                                    void* stream) {
+    if (!nll || !kl || !kl_weight_dev || !g_loss || !loss || !rec || !rowscale || !dkl || !acc) return LV_ERR_ARG;
+    if (T < 0 || B <= 0) return LV_ERR_SHAPE;
+    LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(256), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale, dkl,
+              acc, T, B);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -20,8 +20,9 @@
 // Every spin is bounded: a workgroup that waits longer than ~1 s raises *status and the whole launch drains.
 // Requirements (else LV_ERR_UNSUPPORTED and the caller uses the launch-per-step kernels): H == 1024, B <= 64,
 // a 256-CU device (all 256 workgroups must be resident at once), gx in unit-major column order.
+// The packed weight images are built by lv_lstm_persist_pack and passed in: a caller whose weights do not change between
+// calls (the decoder during the aggressive inner loop) packs once.
 #include "lv_device.h"
-#include <stdlib.h>
 
 #ifndef LV_EMU   // the CI emulator runs workgroups one after another: spin-synchronised persistent kernels cannot run there
 
@@ -75,14 +76,11 @@ struct PersistFwdP {
 
 constexpr int SB = 8;               // timesteps per I/O block (see below)
 
-// ABL (profiles/microbench only, product = 0): 1 = no MFMAs, 2 = no result stores, 4 = no gx / mask loads
-//
 // Global loads and stores of a wave retire in order on gfx9 (one vmcnt), so ANY load or store issued inside a step
 // ends up in front of the next hand-off poll and the poll waits for it (measured: +2.3 us per step for the result
 // stores alone).  The recurrence therefore does its bulk I/O in blocks of SB steps: the gate pre-activations of the
 // next block are fetched and the results of the previous block are written at block boundaries, and in between a
 // step touches global memory for the hand-off only.  Each lane owns ONE (batch row, unit) pair for the whole call.
-template <int ABL>
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
     __shared__ __attribute__((aligned(16))) uint32_t hl[2][PRMAX * HPITCH];   // gathered h_{t-1}, [parity][row][k/2]
     __shared__ float pre[4][16][33];                                         // per wave: MFMA tile [row][col]
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
             const int t = tb + s2;
             gxb[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
             keepb[s2] = 1.f;
-            if (own && t < T && !(ABL & 4)) {
+            if (own && t < T) {
                 gxb[s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx) * 4);
                 if (p.hdrop && p.dmask) keepb[s2] = p.dmask[((long)(b0 + prow) * T + t) * PH + punit] ? p.dscale : 0.f;
             }
@@ -144,7 +142,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
 #pragma unroll
         for (int s2 = 0; s2 < SB; ++s2) {
             const int t = tb + s2;
-            if (own && t < T && !(ABL & 2)) {
+            if (own && t < T) {
                 // streaming stores: the results are consumed by later kernels only, and a write-allocating store of a
                 // partial line makes L2 fetch the line first -- measured 3.85 -> 3.46 us per step with the nt hint
                 __builtin_nontemporal_store(f32x4{recb[s2].x, recb[s2].y, recb[s2].z, recb[s2].w},
@@ -204,13 +202,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
 #pragma unroll
             for (int ks = 0; ks < PKS; ++ks) {
                 const uint4 a = arowp[ks * 4];
-                if (ABL & 1) {
-                    acc[(ks & 1) * 2 + 0][0] += (float)((a.x ^ wreg[ks][0].x) & 0xFF);
-                    acc[(ks & 1) * 2 + 1][0] += (float)((a.y ^ wreg[ks][1].y) & 0xFF);
-                } else {
-                    acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
-                    acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
-                }
+                acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
+                acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
             }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -288,6 +281,7 @@ struct PersistBwdP {
 __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     __shared__ __attribute__((aligned(16))) uint32_t gl[BR * GPITCH];        // gathered dG[t+1], [row][n'/2]
     __shared__ float red[2][4][16][33];                                      // [phase parity][wave]: quarter product [row][unit]
+    __shared__ __attribute__((aligned(16))) uint16_t og[SB][BR][4][32];      // dG of one I/O block: [step][row][gate][unit in WG]
     __shared__ int s_abort;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
@@ -341,20 +335,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
             ctb[s2] = (own && t + 1 >= 0) ? p.cs[(long)(t + 1) * BH + pidx] : 0.f;
         }
     };
+    // The dG image is gate-major ([t][b][g*H + u]: the contraction index of the weight-gradient GEMMs), a lane holds the four
+    // gates of ONE unit: written directly that is four 2-byte stores per step, each a partial-line write (measured by PMC:
+    // 262 MB written per launch for a 52 MB image).  The block's values are transposed through LDS instead, so that the
+    // workgroup writes (step, row, gate) segments of 32 units = 64 B as 16-byte streaming stores: 2 per thread per block.
     auto store_block = [&](int t_hi) {
+        if (own) {
 #pragma unroll
-        for (int s2 = 0; s2 < SB; ++s2) {
-            const int t = t_hi - s2;
-            if (own && t >= 0) {
-                const long gi = (long)t * B * 4 * PH + (long)(b0 + prow) * 4 * PH + punit;
-                {
-                    p.dG16[gi] = (uint16_t)(outb[s2][0] & 0xFFFFu);
-                    p.dG16[gi + PH] = (uint16_t)(outb[s2][0] >> 16);
-                    p.dG16[gi + 2L * PH] = (uint16_t)(outb[s2][1] & 0xFFFFu);
-                    p.dG16[gi + 3L * PH] = (uint16_t)(outb[s2][1] >> 16);
-                }
+            for (int s2 = 0; s2 < SB; ++s2) {
+                og[s2][prow][0][uw] = (uint16_t)(outb[s2][0] & 0xFFFFu);
+                og[s2][prow][1][uw] = (uint16_t)(outb[s2][0] >> 16);
+                og[s2][prow][2][uw] = (uint16_t)(outb[s2][1] & 0xFFFFu);
+                og[s2][prow][3][uw] = (uint16_t)(outb[s2][1] >> 16);
             }
         }
+        __syncthreads();
+        for (int c = tid; c < SB * BR * 4 * 4; c += 256) {      // 16-byte chunks: [step][row][gate][quarter of 32 units]
+            const int q = c & 3, g = (c >> 2) & 3, r = (c >> 4) & 3, s2 = c >> 6;
+            const int t = t_hi - s2;
+            if (t >= 0 && r < rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&og[s2][r][g][8 * q]);      // 8 bf16, moved as raw bits
+                uint16_t* dst = p.dG16 + ((long)t * B + (b0 + r)) * 4 * PH + (long)g * PH + 32 * member + 8 * q;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+            }
+        }
+        __syncthreads();                                        // og is rewritten at the next block boundary
     };
     load_block(T - 1);
     __syncthreads();
@@ -474,76 +479,93 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     }
 }
 
-}  // namespace
+constexpr long WPK_BYTES = 128L * PKS * 2 * 64 * 16;                           // one packed bf16 image of W_hh (8 MB)
+constexpr long XCH_FWD_BYTES = 2L * PGROUPS * 16 * (PH / 2) * 8;                 // h exchange, two parities
+constexpr long XCH_BWD_BYTES = 2L * PGROUPS * BR * (2 * PH) * 8;                 // dG exchange, two parities
 
-extern "C" long lv_lstm_persist_ws_floats(void) {
-    const long fwd = 128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * 16 * (PH / 2) * 8;         // packed W_hh + h exchange
-    const long bwd = 128L * PKS * 2 * 64 * 16 + 2L * PGROUPS * BR * (2 * PH) * 8;         // packed W_hh^T + dG exchange
-    return (fwd > bwd ? fwd : bwd) / 4 + 64;
+// compute units of the current device (cached per device ordinal; the persistent launches need 256 resident workgroups)
+int device_cus() {
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        __atomic_store_n(&cache[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
 }
 
-// BPTT in one persistent launch.  Arguments as lv_lstm_bwd_bf16_img plus ws of lv_lstm_persist_ws_floats() floats and a
-// device status word.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 32 and the device has >= 256 CUs.
+}  // namespace
+
+extern "C" long lv_lstm_persist_wpk_floats(void) { return WPK_BYTES / 4; }
+extern "C" long lv_lstm_persist_xch_floats(void) { return (XCH_FWD_BYTES > XCH_BWD_BYTES ? XCH_FWD_BYTES : XCH_BWD_BYTES) / 4 + 64; }
+
+// W_hh [4H][H] f32 -> the register image of the forward (backward = 0) or BPTT (backward = 1) persistent kernel:
+// lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
+extern "C" int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
+    if (!whh || !wpk) return LV_ERR_ARG;
+    if (H != PH) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
+    const dim3 grid((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), block(256);
+    if (backward) LV_LAUNCH(pack_w_persist_bwd_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    else LV_LAUNCH(pack_w_persist_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// BPTT in one persistent launch.  Arguments as lv_lstm_bwd_bf16_img with W_hh replaced by its packed image
+// (lv_lstm_persist_pack(..., backward = 1)), an exchange buffer of lv_lstm_persist_xch_floats() floats and a device status
+// word.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 32 and the device has >= 256 CUs.
 extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                                        const float* whh, const float* gates, const float* hs, const float* cs,
-                                        float* dG, uint16_t* dG16, float* dGsum, float* ws, int* status, float* dh0, float* dc0,
+                                        const float* wpk, const float* gates, const float* hs, const float* cs,
+                                        float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                                         int tanh_init, int T, int B, int H, void* stream) {
-    if (!whh || !gates || !cs || (!dG && !dG16) || !dGsum || !ws || !status) return LV_ERR_ARG;
+    if (!wpk || !gates || !cs || (!dG && !dG16) || !dGsum || !xch || !status) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
     if (H != PH || B > BR * PGROUPS || dG || !dG16) return LV_ERR_UNSUPPORTED;   // image-only: the f32 dG copy is not produced
-    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0) return LV_ERR_ALIGN;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return LV_ERR_UNSUPPORTED;
-    if (cus < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
-    uint4* wpk = reinterpret_cast<uint4*>(ws);
-    gran_t* gxch = reinterpret_cast<gran_t*>(ws + 128L * PKS * 2 * 64 * 4);
-    LV_LAUNCH(pack_w_persist_bwd_kernel, dim3((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), dim3(256), 0, stream, whh, wpk);
-    hipMemsetAsync(gxch, 0, (size_t)2 * PGROUPS * BR * (2 * PH) * sizeof(gran_t), (hipStream_t)stream);
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
+    gran_t* gxch = reinterpret_cast<gran_t*>(xch);
+    hipMemsetAsync(gxch, 0, (size_t)XCH_BWD_BYTES, (hipStream_t)stream);
     const int R = (B + PGROUPS - 1) / PGROUPS;
-    PersistBwdP p{dh_ext, dh_last, dmask, dscale, wpk, gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    PersistBwdP p{dh_ext, dh_last, dmask, dscale, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init,
+                  gxch, status, T, B, R};
     LV_LAUNCH(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
-// Forward recurrence in one persistent launch.  Arguments as lv_lstm_fwd_bf16_ug (gx unit-major) plus ws of
-// lv_lstm_persist_ws_floats() floats and a device status word (0 = ok; written non-zero if a hand-off timed out).
-extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* whh, float* hs, float* cs, float* gates,
-                                        const uint8_t* dmask, float dscale, float* hdrop, float* ws, int* status,
+// Forward recurrence in one persistent launch.  Arguments as lv_lstm_fwd_bf16_ug (gx unit-major) with W_hh replaced by
+// its packed image (lv_lstm_persist_pack(..., backward = 0)), an exchange buffer and a device status word (0 = ok;
+// written non-zero if a hand-off timed out).
+extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
+                                        const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
                                         int T, int B, int H, void* stream) {
-    if (!gx || !whh || !hs || !cs || !gates || !ws || !status) return LV_ERR_ARG;
+    if (!gx || !wpk || !hs || !cs || !gates || !xch || !status) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (dmask && !hdrop) return LV_ERR_ARG;
     if (H != PH || B > PRMAX * PGROUPS) return LV_ERR_UNSUPPORTED;
-    if ((((uintptr_t)ws) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0) return LV_ERR_ALIGN;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return LV_ERR_UNSUPPORTED;
-    if (cus < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
     if (T == 0) return LV_OK;
-    uint4* wpk = reinterpret_cast<uint4*>(ws);
-    gran_t* hx = reinterpret_cast<gran_t*>(ws + 128L * PKS * 2 * 64 * 4);
-    LV_LAUNCH(pack_w_persist_kernel, dim3((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), dim3(256), 0, stream, whh, wpk);
-    hipMemsetAsync(hx, 0, (size_t)2 * PGROUPS * 16 * (PH / 2) * sizeof(gran_t), (hipStream_t)stream);
+    gran_t* hx = reinterpret_cast<gran_t*>(xch);
+    hipMemsetAsync(hx, 0, (size_t)XCH_FWD_BYTES, (hipStream_t)stream);
     const int R = (B + PGROUPS - 1) / PGROUPS;
-    PersistFwdP p{gx, wpk, hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
-    const char* abl = getenv("LVAE_PERSIST_ABL");          // measurement knob (profiles/microbench/lstm_persist_probe.py)
-    const int a = abl ? atoi(abl) : 0;
-    const dim3 grid(PGROUPS * PMEMBERS), block(256);
-    if (a == 1) LV_LAUNCH(lstm_fwd_persist_kernel<1>, grid, block, 0, stream, p);
-    else if (a == 2) LV_LAUNCH(lstm_fwd_persist_kernel<2>, grid, block, 0, stream, p);
-    else if (a == 4) LV_LAUNCH(lstm_fwd_persist_kernel<4>, grid, block, 0, stream, p);
-    else if (a == 7) LV_LAUNCH(lstm_fwd_persist_kernel<7>, grid, block, 0, stream, p);
-    else LV_LAUNCH(lstm_fwd_persist_kernel<0>, grid, block, 0, stream, p);
+    PersistFwdP p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
+    LV_LAUNCH(lstm_fwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
 #else   // LV_EMU
 
-extern "C" long lv_lstm_persist_ws_floats(void) { return 64; }
+extern "C" long lv_lstm_persist_wpk_floats(void) { return 64; }
+extern "C" long lv_lstm_persist_xch_floats(void) { return 64; }
+extern "C" int lv_lstm_persist_pack(const float*, float*, int, int, void*) { return LV_ERR_UNSUPPORTED; }
 extern "C" int lv_lstm_fwd_bf16_persist(const float*, const float*, float*, float*, float*, const uint8_t*, float, float*,
                                         float*, int*, int, int, int, void*) {
     return LV_ERR_UNSUPPORTED;

@@ -56,6 +56,63 @@ __global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restri
     }
 }
 
+// stage 1 over TWO buffers in one launch: blocks [0, nb1) reduce x1, blocks [nb1, nb1 + nb2) reduce x2
+__global__ __launch_bounds__(256) void sumsq2_stage1_kernel(const float* __restrict__ x1, long n1, int nb1,
+                                                            const float* __restrict__ x2, long n2, int nb2,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int tid = (int)threadIdx.x;
+    const bool first = (int)blockIdx.x < nb1;
+    const float* x = first ? x1 : x2;
+    const long n = first ? n1 : n2;
+    const int nblk = first ? nb1 : nb2;
+    const int blk = first ? (int)blockIdx.x : (int)blockIdx.x - nb1;
+    const long per = (((n + nblk - 1) / nblk) + 3) & ~3L;
+    const long beg = (long)blk * per;
+    long end = beg + per;
+    if (end > n) end = n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (beg < end) {
+        if ((((uintptr_t)x) & 15) == 0) {
+            const long nv = (end - beg) / 4;
+            const float4* x4 = reinterpret_cast<const float4*>(x + beg);
+            for (long i = tid; i < nv; i += 256) {
+                const float4 v = x4[i];
+                s0 += v.x * v.x; s1 += v.y * v.y; s2 += v.z * v.z; s3 += v.w * v.w;
+            }
+            for (long i = beg + nv * 4 + tid; i < end; i += 256) s0 += x[i] * x[i];
+        } else {
+            for (long i = beg + tid; i < end; i += 256) s0 += x[i] * x[i];
+        }
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// stage 2 + clip coefficient: sumsq = sum(partial) in double; norm = sqrt; coef = min(1, max_norm / (norm + 1e-6))
+__global__ __launch_bounds__(256) void clip_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
+                                                          float* sumsq, float* coef, float* norm_out) {
+    __shared__ double red[4];
+    const int tid = (int)threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < nblk; i += 256) s += (double)partial[i];
+    s = lv_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float ss = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        const float nrm = sqrtf(ss);
+        float c = max_norm / (nrm + 1e-6f);
+        if (c > 1.f) c = 1.f;
+        if (sumsq) sumsq[0] = ss;
+        coef[0] = c;
+        if (norm_out) norm_out[0] = nrm;
+    }
+}
+
 // norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -150,7 +207,7 @@ __global__ void add_scalar_kernel(float* x, float v) {
 
 }  // namespace
 
-extern "C" int lv_sumsq_workspace_floats() { return NORM_BLOCKS; }
+extern "C" int lv_sumsq_workspace_floats() { return 2 * NORM_BLOCKS; }
 
 // out[0] (=|+=) sum(x[i]^2); ws: lv_sumsq_workspace_floats() floats.  Deterministic two-stage reduction.
 extern "C" int lv_sumsq_f32(const float* x, long n, float* ws, float* out, int accumulate, void* stream) {
@@ -217,6 +274,23 @@ extern "C" int lv_sum_accum_f32(const float* x, long n, float* out_dev, void* st
 extern "C" int lv_add_scalar_f32(float* x_dev, float v, void* stream) {
     if (!x_dev) return LV_ERR_ARG;
     LV_LAUNCH(add_scalar_kernel, dim3(1), dim3(64), 0, stream, x_dev, v);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// clip_grad_norm_ over two flat gradient buffers (encoder, decoder: the norm spans both) in two launches:
+// one streaming pass over both buffers, then sum + norm + coefficient.  ws: lv_sumsq_workspace_floats() floats.
+extern "C" int lv_clip_norm2_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
+                                 float* sumsq_dev, float* coef_dev, float* norm_dev, void* stream) {
+    if (!g1 || !g2 || !ws || !coef_dev || n1 < 0 || n2 < 0) return LV_ERR_ARG;
+    long nb1 = (n1 + 8191) / 8192, nb2 = (n2 + 8191) / 8192;
+    if (nb1 < 1) nb1 = 1;
+    if (nb1 > NORM_BLOCKS) nb1 = NORM_BLOCKS;
+    if (nb2 < 1) nb2 = 1;
+    if (nb2 > NORM_BLOCKS) nb2 = NORM_BLOCKS;
+    LV_LAUNCH(sumsq2_stage1_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, stream, g1, n1, (int)nb1, g2, n2, (int)nb2, ws);
+    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), max_norm, sumsq_dev, coef_dev,
+              norm_dev);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -210,12 +210,10 @@ class _AuxStream(object):
 
 
 def reset_persistent_status(eng):
-    """Clear the status words (after the caller has handled a reported timeout, e.g. by turning `persistent` off)."""
-    if eng.wsc is not None:
-        for w in eng.wsc.cache.values():
-            st = getattr(w, "persist_status", None)
-            if st is not None:
-                st.zero_()
+    """Clear the status word (after the caller has handled a reported timeout, e.g. by turning `persistent` off)."""
+    st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
+    if st is not None:
+        st.zero_()
 
 
 _PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
@@ -227,6 +225,57 @@ def _persistent_ok(eng, img, B, H, device, max_b):
             and torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
 
 
+def weights_version(eng):
+    """Changes whenever the module's weights may have changed: in-place torch updates bump the parameters' version
+    counters (optimizer.step, load_state_dict, user edits), raw-pointer updates by the fused trainer bump eng.wgen."""
+    return (sum(p._version for p in eng.flat.params), eng.wgen)
+
+
+def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
+    """Engine-level bf16 images of the module's weights for the throughput path -- W_ih rows in unit-major gate order
+    (4u + g: Gx comes out with each unit's (i,f,g,o) side by side), W_ih^T [ni][4H] (contraction index of dX), for the
+    decoder also pred_linear.weight / its transpose, and the packed register images of W_hh for the persistent
+    recurrences -- rebuilt when weights_version() changed, or on every call when eng.cache_weight_images is off.
+    The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only), so its images
+    are built once per outer iteration."""
+    wi = eng._wimg
+    V, ni, H = eng.dims()[:3]
+    v = eng.flat.views
+    c = eng.wsc
+    if wi is None:
+        wi = eng._wimg = _NS()
+        wi.ver = object()
+        wi.W = wi.WT = wi.pred = wi.predT = wi.fwd = wi.bwd = None
+        if lstm:
+            wi.W = c.i16(4 * H, ni)
+            wi.WT = c.i16(ni, 4 * H)
+        wi.ldv = _round_up(V, 32)
+        if pred:
+            wi.pred = c.i16(V, H)
+            wi.predT = c.i16(H, wi.ldv)
+        wi.packed = False
+    ver = weights_version(eng) if eng.cache_weight_images else object()
+    stale = wi.ver != ver
+    if stale:
+        wih = v["lstm.weight_ih_l0"]
+        if wi.W is not None:
+            lib.lv_cvt_bf16_gates_f32(P(wih), wih.shape[1], H, ni, P(wi.W), ni, P(wi.WT), 4 * H, s)
+        if wi.pred is not None:
+            lib.lv_cvt_bf16_f32(P(v["pred_linear.weight"]), H, V, H, P(wi.pred), H, P(wi.predT), wi.ldv, s)
+        wi.ver = ver
+        wi.packed = False
+    if want_persist and not wi.packed:
+        if wi.fwd is None:
+            n = lib.lv_lstm_persist_wpk_floats()
+            wi.fwd, wi.bwd = c.f32(n), c.f32(n)
+            wi.xch = c.f32(lib.lv_lstm_persist_xch_floats())
+            wi.status = torch.zeros(1, dtype=torch.int32, device=device)
+        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 0, H, s)
+        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 1, H, s)
+        wi.packed = True
+    return wi
+
+
 def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, device):
     """The forward recurrence of one LSTM layer: exact f32, bf16 launch-per-step, or (bf16 image path on a >= 256-CU
     device, H = 1024, B <= 64) the single persistent launch of lv_lstm_persist.hip."""
@@ -236,10 +285,8 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
     elif img is None:
         lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
     elif _persistent_ok(eng, img, B, H, device, _PERSIST_MAX_B):
-        if getattr(w, "persist_ws", None) is None:
-            w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
-            w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
-        lib.lv_lstm_fwd_bf16_persist(*args, P(w.persist_ws), P(w.persist_status), T, B, H, s)
+        wi = eng._wimg          # packed by _weight_images(want_persist=True) at the top of the forward
+        lib.lv_lstm_fwd_bf16_persist(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
@@ -248,15 +295,12 @@ _PERSIST_BWD_MAX_B = 32
 
 
 def check_persistent_status(eng):
-    """Raise if a persistent LSTM launch of this engine ever reported a hand-off timeout (device status words; one
-    host read per workspace -- call it where the host synchronises anyway)."""
-    if eng.wsc is None:
-        return
-    for w in eng.wsc.cache.values():
-        st = getattr(w, "persist_status", None)
-        if st is not None and int(st.item()) != 0:
-            raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups "
-                                 "were resident, e.g. another kernel held compute units for seconds" % int(st.item()))
+    """Raise if a persistent LSTM launch of this engine ever reported a hand-off timeout (device status word; one host
+    read -- call it where the host synchronises anyway)."""
+    st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
+    if st is not None and int(st.item()) != 0:
+        raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups "
+                             "were resident, e.g. another kernel held compute units for seconds" % int(st.item()))
 
 
 def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, dc0, tanh_init, T, B, H, device):
@@ -268,11 +312,9 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
     dG = P(w.dG) if img is None else None
     dG16 = P(img.dG) if img is not None else None
     if _persistent_ok(eng, img, B, H, device, _PERSIST_BWD_MAX_B):
-        if getattr(w, "persist_ws", None) is None:
-            w.persist_ws = torch.empty(lib.lv_lstm_persist_ws_floats(), dtype=torch.float32, device=device)
-            w.persist_status = torch.zeros(1, dtype=torch.int32, device=device)
-        lib.lv_lstm_bwd_bf16_persist(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
-                                     P(w.persist_ws), P(w.persist_status), dh0, dc0, tanh_init, T, B, H, s)
+        wi = eng._wimg
+        lib.lv_lstm_bwd_bf16_persist(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
+                                     P(wi.xch), P(wi.status), dh0, dc0, tanh_init, T, B, H, s)
     else:
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
                                  P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
@@ -287,9 +329,6 @@ class _LstmImages(object):
         self.ldr = _round_up(TB, 8)
         self.X = c.i16(TB, ni)              # layer input rows            [T*B][ni]
         self.XT = c.i16(ni, self.ldr)       # ... transposed              [ni][T*B]
-        self.W = c.i16(4 * H, ni)           # W_ih (input columns), rows in UNIT-major gate order (4u + g): Gx comes
-        #                                     out with each unit's (i,f,g,o) side by side (lv_lstm_fwd_bf16_ug)
-        self.WT = c.i16(ni, 4 * H)          # W_ih^T, standard gate-major order (contraction index of dX) [ni][4H]
         self.addend = None                  # unit-major copy of the Gx epilogue addend (biases / z-projection)
         self.dG = c.i16(TB, 4 * H)          # gate pre-activation grads   [T*B][4H]
         self.hT = c.i16(H, self.ldr)        # h_{t-1} rows, transposed    [H][T*B]
@@ -298,25 +337,30 @@ class _LstmImages(object):
     def usable(precision, native16, ni, H):
         return precision == "bf16" and native16 and ni % 8 == 0 and H % 8 == 0
 
-    def forward(self, lib, s, X, W_ih, ld_w, Gx, add_a, add_b, rows, wsc):
-        """Gx[r][4u + g] = X[r] . W_ih[g*H + u] + (add_a + add_b)[r % rows][g*H + u]; add_a/add_b: gate-major [rows][4H]
-        (add_b may be None)."""
+    def forward(self, lib, s, X, W16, Gx, add_a, add_b, rows, wsc, addend_um=None):
+        """Gx[r][4u + g] = X[r] . W_ih[g*H + u] + (add_a + add_b)[r % rows][g*H + u]; W16: the unit-major bf16 image of W_ih
+        (engine-level, _weight_images); add_a/add_b: gate-major [rows][4H] (add_b may be None), or addend_um: the addend
+        already in unit-major order."""
         TB, ni, H = self.TB, self.ni, self.H
-        if self.addend is None or self.addend.shape[0] != rows:
-            self.addend = wsc.f32(rows, 4 * H)
-        lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
+        if addend_um is not None:
+            addend = addend_um
+        else:
+            if self.addend is None or self.addend.shape[0] != rows:
+                self.addend = wsc.f32(rows, 4 * H)
+            lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
+            addend = P(self.addend)
         lib.lv_cvt_bf16_f32(X, ni, TB, ni, P(self.X), ni, P(self.XT), self.ldr, s)
-        lib.lv_cvt_bf16_gates_f32(W_ih, ld_w, H, ni, P(self.W), ni, P(self.WT), 4 * H, s)
-        _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, P(self.W), ni, Gx, 4 * H,
-                add1=P(self.addend), ld1=4 * H if rows > 1 else 0, mod1=rows)
+        _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, W16, ni, Gx, 4 * H,
+                add1=addend, ld1=4 * H if rows > 1 else 0, mod1=rows)
 
-    def backward(self, lib, s, dG, h_prev, dX, gW_ih, ld_gw, gW_hh, ws=None):
-        """dG: the f32 gate gradients, or None when the BPTT kernel already wrote their bf16 image into self.dG."""
+    def backward(self, lib, s, dG, h_prev, WT16, dX, gW_ih, ld_gw, gW_hh, ws=None):
+        """dG: the f32 gate gradients, or None when the BPTT kernel already wrote their bf16 image into self.dG; WT16: the
+        bf16 image of W_ih^T [ni][4H] (engine-level)."""
         TB, ni, H = self.TB, self.ni, self.H
         if dG is not None:
             lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
         lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
-        _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, P(self.WT), 4 * H, dX, ni, ws=ws)
+        _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, WT16, 4 * H, dX, ni, ws=ws)
         _gemm16(lib, s, 1, 4 * H, ni, TB, P(self.dG), 4 * H, P(self.XT), self.ldr, gW_ih, ld_gw, ws=ws)
         _gemm16(lib, s, 1, 4 * H, H, TB, P(self.dG), 4 * H, P(self.hT), self.ldr, gW_hh, H, ws=ws)
 
@@ -341,6 +385,9 @@ class LSTMEncoderEngine(object):
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
+        self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
+        self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
+        self._wimg = None
         self._aux = _AuxStream()
 
     def _b16(self, B, T):
@@ -348,6 +395,17 @@ class LSTMEncoderEngine(object):
         if not _LstmImages.usable(self.precision, self.native16, ni, H):
             return None
         return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H))
+
+    def refresh_weight_images(self, B, device):
+        """Bring the bf16 weight images (and, where the persistent launches apply, the packed recurrent weights) up to
+        date on the current stream; a no-op when caching is on and the weights have not changed."""
+        V, ni, H, nz2 = self.dims()
+        if not _LstmImages.usable(self.precision, self.native16, ni, H):
+            return None
+        self.ensure(device)
+        persist = self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and torch.device(device).type == "cuda" and \
+            torch.cuda.get_device_properties(device).multi_processor_count >= 256
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist)
 
     def ensure(self, device):
         device = torch.device(device)
@@ -374,10 +432,12 @@ class LSTMEncoderEngine(object):
             w = _NS()
             w.X = c.f32(T * B, ni)
             w.Gx = c.f32(T * B, 4 * H)
-            w.hs = c.f32(T + 1, B, H)
-            w.cs = c.f32(T + 1, B, H)
+            # index 0 = the initial state: zero for the encoder (enc_lstm.py:60), and no kernel ever writes slot 0
+            w.hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=c.device)
+            w.cs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=c.device)
             w.gates = c.f32(T * B, 4 * H)
             w.mulv = c.f32(B, nz2)
+            w.dmulv = c.f32(B, nz2)
             w.dG = c.f32(T * B, 4 * H)
             w.dGsum = c.f32(B, 4 * H)
             w.lstm_ws = c.f32(self.lib.lv_lstm_ws_floats(B, H))
@@ -389,8 +449,10 @@ class LSTMEncoderEngine(object):
             return w
         return c.get((B, T), build)
 
-    def forward(self, x):
-        """x int64 [B][T] on device -> mulv [B][2nz] (mu | logvar).  Keeps activations for backward()."""
+    def forward(self, x, head=None):
+        """x int64 [B][T] on device -> mulv [B][2nz] (mu | logvar).  Keeps activations for backward().
+
+        head = (eps [B][ns][nz], z, kl): also reparameterise and compute the KL in the head's launch (fused driver)."""
         assert x.dtype == torch.int64 and x.dim() == 2
         x = x.contiguous()
         B, T = x.shape
@@ -405,22 +467,28 @@ class LSTMEncoderEngine(object):
         img = self._b16(B, T)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
-            img.forward(lib, s, P(w.X), P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]),
-                        1, self.wsc)
+            wi = self.refresh_weight_images(B, x.device)
+            img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, self.wsc)
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
-        w.hs[0].zero_()
-        w.cs[0].zero_()
-        with _prof("lstm_fwd", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
+        with _prof("lstm_fwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
             _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
-        _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
+        if head is not None:
+            eps, z, kl = head
+            lib.lv_enc_head_fwd_f32(P(w.hs, T * B * H), P(v["linear.weight"]), P(eps), P(w.mulv), P(z), P(kl), B, H,
+                                    eps.shape[1], nz2 // 2, s)
+        else:
+            _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
         self.gen += 1
         self.last = (x, B, T, self.gen)
         return w.mulv
 
-    def backward(self, dmulv, gen=None):
-        """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics)."""
+    def backward(self, dmulv, gen=None, head=None):
+        """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics).
+
+        head = (eps, dz [B][ns][nz], dkl [B]) instead of dmulv: the backward of reparameterise + KL runs in the head's
+        launch (fused driver; dmulv is then produced into the workspace)."""
         x, B, T, g = self.last
         if gen is not None and gen != g:
             raise _lib.LvaeError("encoder activations were overwritten by a later forward(); the HIP engine keeps "
@@ -430,16 +498,21 @@ class LSTMEncoderEngine(object):
         V, ni, H, nz2 = self.dims()
         w = self._ws(B, T)
         v, gv = f.views, f.gviews
-        dmulv = dmulv.contiguous()
-        # head: dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T
-        _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
-        _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
+        if head is not None:
+            eps, dz, dkl = head
+            lib.lv_enc_head_bwd_f32(P(w.mulv), P(eps), P(dz), P(dkl), P(w.hs, T * B * H), P(v["linear.weight"]), P(w.dmulv),
+                                    P(w.dhT), P(gv["linear.weight"]), B, H, eps.shape[1], nz2 // 2, s)
+        else:
+            dmulv = dmulv.contiguous()
+            # head: dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T
+            _gemm(lib, s, 0, 0, B, H, nz2, P(dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
+            _gemm(lib, s, 1, 0, nz2, H, B, P(dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
         img = self._b16(B, T)
-        with _prof("lstm_bwd", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_BWD_MAX_B) else 2 * T):
+        with _prof("lstm_bwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_BWD_MAX_B) else 2 * T):
             _lstm_backward(self, lib, s, img, w, None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), None, None, 0, T, B, H, x.device)
         # input-side grads
         if img is not None:
-            img.backward(lib, s, None, P(w.hs), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
+            img.backward(lib, s, None, P(w.hs), P(self._wimg.WT), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
         else:
             _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
             _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision)
@@ -465,6 +538,11 @@ class LSTMDecoderEngine(object):
         self.overlap = None       # None = auto policy (_overlap_on); True / False force it
         self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
+        # The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only): its bf16
+        # weight images and packed recurrent weights are rebuilt only when weights_version() changes.
+        self.cache_weight_images = True
+        self.wgen = 0
+        self._wimg = None
         self._side = None
         self._side_ws = None
         self._pending = None
@@ -572,11 +650,22 @@ class LSTMDecoderEngine(object):
             b.ldv = _round_up(V, 32)
             b.O = c.i16(Td * Bd, H)           # dropout(h_t) rows      [T*B][H]
             b.OT = c.i16(H, b.ldr)            # ... transposed         [H][T*B]
-            b.W = c.i16(V, H)                 # pred_linear.weight     [V][H]
-            b.WT = c.i16(H, b.ldv)            # ... transposed         [H][V]
+            # (pred_linear.weight [V][H] and its transpose [H][V]: engine-level images, _weight_images)
             b.dl = c.i16(Td * Bd, b.ldv)      # dlogits                [T*B][V]
             return b
         return c.get(("b16", Bd, Td), build)
+
+    def refresh_weight_images(self, B, device):
+        """See LSTMEncoderEngine.refresh_weight_images; covers pred_linear.weight as well."""
+        V, ni, H, nz = self.dims()
+        use_pred = self.precision == "bf16" and self.native16 and H % 8 == 0
+        use_lstm = _LstmImages.usable(self.precision, self.native16, ni, H)
+        if not (use_pred or use_lstm):
+            return None
+        self.ensure(device)
+        persist = use_lstm and self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and \
+            torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist, lstm=use_lstm, pred=use_pred)
 
     def _lstm_images(self, Bd, Td):
         V, ni, H, nz = self.dims()
@@ -584,7 +673,7 @@ class LSTMDecoderEngine(object):
             return None
         return self.wsc.get(("b16lstm", Bd, Td), lambda: _LstmImages(self.wsc, Td * Bd, ni, H))
 
-    def forward(self, x, z, mask_in, mask_out, p_in, p_out):
+    def forward(self, x, z, mask_in, mask_out, p_in, p_out, want_rec=True):
         """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
         batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B]."""
         assert x.dtype == torch.int64 and x.dim() == 2
@@ -607,31 +696,31 @@ class LSTMDecoderEngine(object):
             assert mask_out.dtype == torch.uint8 and tuple(mask_out.shape) == (B, Td, H) and mask_out.is_contiguous()
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
         self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s))
-        # c0 = z W_trans^T ; h0 = tanh(c0)   (dec_lstm.py:99-101)
-        _gemm(lib, s, 0, 1, B, H, nz, P(z2), nz, P(v["trans_linear.weight"]), nz, P(w.cs), H)
-        lib.lv_tanh_f32(P(w.cs), P(w.hs), B * H, s)
-        # Zp = z W_ih[:, ni:]^T + b_ih + b_hh ; Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised)
+        # c0 = z W_trans^T ; h0 = tanh(c0) (dec_lstm.py:99-101) ; Zp = z W_ih[:, ni:]^T + b_ih + b_hh, so that
+        # Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised) -- one launch
         wih = v["lstm.weight_ih_l0"]
-        _gemm(lib, s, 0, 1, B, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
-              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         img = self._lstm_images(B, Td)
+        lib.lv_dec_init_f32(P(z2), P(v["trans_linear.weight"]), P(wih), ni + nz, ni, P(v["lstm.bias_ih_l0"]),
+                            P(v["lstm.bias_hh_l0"]), P(w.cs), P(w.hs), P(w.Zp), 1 if img is not None else 0, B, H, nz, s)
         if img is not None:
-            img.forward(lib, s, P(w.X), P(wih), ni + nz, P(w.Gx), P(w.Zp), None, B, self.wsc)
+            wi = self.refresh_weight_images(B, x.device)
+            img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), None, None, B, self.wsc, addend_um=P(w.Zp))
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
-        with _prof("lstm_fwd", float(Td), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else Td):
+        with _prof("lstm_fwd_dec", float(Td), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else Td):
             _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), P(mask_out), sc_out, P(w.O), Td, B, H, x.device)
         b16 = self._b16(B, Td)
         if b16 is not None:
             lib.lv_cvt_bf16_f32(P(w.O), H, Td * B, H, P(b16.O), H, P(b16.OT), b16.ldr, s)
-            lib.lv_cvt_bf16_f32(P(v["pred_linear.weight"]), H, V, H, P(b16.W), H, P(b16.WT), b16.ldv, s)
-            _gemm16(lib, s, 0, Td * B, V, H, P(b16.O), H, P(b16.W), H, P(w.logits), w.ldl)
+            wi = self.refresh_weight_images(B, x.device)
+            _gemm16(lib, s, 0, Td * B, V, H, P(b16.O), H, P(wi.pred), H, P(w.logits), w.ldl)
         else:
             _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
         lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
-        # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0)
-        lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
+        if want_rec:
+            # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0); the fused driver sums nll itself
+            lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
         self.gen += 1
         self.last = (x, z2, mask_in, mask_out, sc_in, sc_out, B, T, self.gen)
         return w.rec
@@ -666,34 +755,33 @@ class LSTMDecoderEngine(object):
                 _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
                        self.precision, ws=sws)
         if b16 is not None:
-            _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(b16.WT), b16.ldv, P(w.dO), H)
+            _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(self._wimg.predT), b16.ldv, P(w.dO), H)
         else:
             _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         img = self._lstm_images(B, Td)
-        with _prof("lstm_bwd", float(Td), 1 if _persistent_ok(self, img, B, H, dev, _PERSIST_BWD_MAX_B) else 2 * Td):
+        with _prof("lstm_bwd_dec", float(Td), 1 if _persistent_ok(self, img, B, H, dev, _PERSIST_BWD_MAX_B) else 2 * Td):
             _lstm_backward(self, lib, s, img, w, P(w.dO), None, P(mask_out), sc_out, P(v["lstm.weight_hh_l0"]), None, P(w.dc0), 1,
                            Td, B, H, dev)
         ctx, sws = self._fork(dev)                    # side: everything that only needs dG (runs under the encoder's backward)
         with ctx:
             s2 = stream_ptr(dev)
             if img is not None:
-                img.backward(lib, s2, None, P(w.hs), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
+                img.backward(lib, s2, None, P(w.hs), P(self._wimg.WT), P(w.dX), P(gwih), ni + nz, P(gv["lstm.weight_hh_l0"]), ws=sws)
             else:
                 _gemm(lib, s2, 0, 0, Td * B, ni, 4 * H, P(w.dG), 4 * H, P(wih), ni + nz, P(w.dX), ni, prec=self.precision, ws=sws)
                 _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, ws=sws)
                 _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
                        self.precision, ws=sws)
-            _gemm(lib, s2, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz, ws=sws)
-            lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s2)
             gv["embed.weight"].zero_()
             self._aux.join(dev)                        # token sort queued by forward()
             lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
                                      V - 1, 0, s2)
         self._mark_pending(dev)
-        # dz = dGsum . W_ih[:, ni:] + dc0 . W_trans ; dW_trans = dc0^T . z   (critical path: feeds the encoder's backward)
-        _gemm(lib, s, 0, 0, B, nz, 4 * H, P(w.dGsum), 4 * H, P(wih, ni), ni + nz, P(w.dz), nz)
-        _gemm(lib, s, 0, 0, B, nz, H, P(w.dc0), H, P(v["trans_linear.weight"]), nz, P(w.dz), nz, acc=1)
-        _gemm(lib, s, 1, 0, H, nz, B, P(w.dc0), H, P(z2), nz, P(gv["trans_linear.weight"]), nz)
+        # batch-sized tail in one launch (critical path: dz feeds the encoder's backward): the z-columns of dW_ih, both
+        # bias gradients, dW_trans, and dz = dGsum . W_ih[:, ni:] + dc0 . W_trans
+        lib.lv_dec_tail_bwd_f32(P(w.dGsum), P(w.dc0), P(z2), P(wih), ni + nz, ni, P(v["trans_linear.weight"]), P(gwih), ni + nz,
+                                P(gv["trans_linear.weight"]), P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), P(w.dz),
+                                B, H, nz, s)
         return w.dz
 
 

@@ -52,7 +52,8 @@ class AggressiveTextTrainer(object):
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
         # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
-        self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0], dtype=torch.int64, device=d)
+        # third word: the ticket of lv_rng_noise_step (0 between calls)
+        self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0, 0], dtype=torch.int64, device=d)
         self.static = {}
 
     # -- scalar views ------------------------------------------------------------------------------
@@ -96,38 +97,27 @@ class AggressiveTextTrainer(object):
         return st
 
     # -- the step ----------------------------------------------------------------------------------------
-    def _draw_noise(self, st, s):
-        """Throughput mode: eps and both dropout keep-masks from the on-device Philox stream."""
-        lib = self.lib
-        p_in, p_out = self.vae.decoder.dropout_in.p, self.vae.decoder.dropout_out.p
-        lib.lv_rng_normal_f32(P(st.eps), st.eps.numel(), P(self.rng_state), 0, s)
-        lib.lv_rng_keepmask_u8(P(st.m_in), st.m_in.numel(), 1.0 - p_in, P(self.rng_state), 1, s)
-        lib.lv_rng_keepmask_u8(P(st.m_out), st.m_out.numel(), 1.0 - p_out, P(self.rng_state), 2, s)
-        lib.lv_rng_advance(P(self.rng_state), 1, s)
-
     def _fwd_bwd(self, st, draw):
         lib, s = self.lib, _eng.stream_ptr(self.device)
         B, T = st.x.shape
         dec = self.vae.decoder
         train = self.vae.training
-        if draw and train:
-            self._draw_noise(st, s)
-        elif draw:
-            lib.lv_rng_normal_f32(P(st.eps), st.eps.numel(), P(self.rng_state), 0, s)
-            lib.lv_rng_advance(P(self.rng_state), 1, s)
-        m_in = st.m_in if (train and dec.dropout_in.p > 0) else None
-        m_out = st.m_out if (train and dec.dropout_out.p > 0) else None
-        mulv = self.enc.forward(st.x)
-        nz = mulv.shape[1] // 2
-        lib.lv_reparam_kl_fwd_f32(P(mulv), P(st.eps), P(st.z), P(st.kl), B, 1, nz, s)
-        self.dec.forward(st.x, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p)
+        use_in = train and dec.dropout_in.p > 0
+        use_out = train and dec.dropout_out.p > 0
+        if draw:
+            # throughput mode: eps and both dropout keep-masks from the on-device Philox stream, one launch
+            lib.lv_rng_noise_step(P(st.eps), st.eps.numel(), P(st.m_in) if use_in else None, st.m_in.numel(),
+                                  1.0 - dec.dropout_in.p, P(st.m_out) if use_out else None, st.m_out.numel(),
+                                  1.0 - dec.dropout_out.p, P(self.rng_state), 1, s)
+        m_in = st.m_in if use_in else None
+        m_out = st.m_out if use_out else None
+        # encoder: ... LSTM, then head + reparameterise + KL in one launch
+        mulv = self.enc.forward(st.x, head=(st.eps, st.z, st.kl))
+        self.dec.forward(st.x, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p, want_rec=False)
         w = self.dec._ws(B, T - 1)
-        lib.lv_vae_loss_f32(P(w.nll), P(st.kl), self._s(0), P(st.loss), P(st.rec), T - 1, B, s)
-        lib.lv_sum_accum_f32(P(st.loss), B, self._s(5), s)
-        lib.lv_sum_accum_f32(P(st.rec), B, self._s(6), s)
-        lib.lv_sum_accum_f32(P(st.kl), B, self._s(7), s)
-        # backward of mean_b(loss_b)
-        lib.lv_loss_bwd_scales_f32(P(st.gl), None, None, self._s(0), P(st.rowscale), P(st.dkl), B, s)
+        # rec, loss, the running report sums and the seeds of mean_b(loss_b).backward(), one launch
+        lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
+                                 self._s(5), T - 1, B, s)
         dz = self.dec.backward(st.rowscale)
         if self.grad_sync is not None and not self._capturing and not (self.enc.persistent and self.enc.precision == "bf16"):
             # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward.
@@ -135,16 +125,14 @@ class AggressiveTextTrainer(object):
             # by the collective's kernels would leave part of its grid spinning -- both reductions then go out in sync().
             self.dec.join()
             self.grad_sync.start_decoder(self.dec.flat)
-        lib.lv_reparam_kl_bwd_f32(P(mulv), P(st.eps), P(dz), P(st.dkl), P(st.dmulv), B, 1, nz, s)
-        self.enc.backward(st.dmulv)
+        self.enc.backward(None, head=(st.eps, dz, st.dkl))
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
 
     def _clip_and_step(self, update):
         lib, s = self.lib, _eng.stream_ptr(self.device)
         ef, df = self.enc.flat, self.dec.flat
-        lib.lv_sumsq_f32(P(ef.grad), ef.numel, P(self.norm_ws), self._s(2), 0, s)
-        lib.lv_sumsq_f32(P(df.grad), df.numel, P(self.norm_ws), self._s(2), 1, s)
-        lib.lv_clip_coef_f32(self._s(2), self.clip, self._s(3), self._s(4), s)
+        lib.lv_clip_norm2_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
+                              self._s(4), s)
         # clip_grad_norm_ scales every grad in place; the update only touches the stepped side
         if update in ("encoder", "both"):
             lib.lv_sgd_step_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, s)
@@ -179,20 +167,31 @@ class AggressiveTextTrainer(object):
                 st.m_in.copy_(m_in)
             if m_out is not None:
                 st.m_out.copy_(m_out)
-        if not self.use_graph:
-            self._run(st, update, draw)
-            return
-        key = (update, draw, self.vae.training)
-        g = st.graphs.get(key)
-        if g is None:
-            # eager warm-up (allocates every workspace), then capture
-            self._run(st, update, draw)
-            torch.cuda.synchronize(self.device)
-            g = self._capture(st, update, draw)
-            st.graphs[key] = g
-            return
-        for part in g:
-            part()
+        try:
+            if not self.use_graph:
+                self._run(st, update, draw)
+                return
+            # cached weight images (the frozen decoder's) are brought up to date OUTSIDE the captured region: a graph
+            # replays exactly what was queued at capture time, and at capture time they are fresh
+            self.enc.refresh_weight_images(B, self.device)
+            self.dec.refresh_weight_images(B, self.device)
+            key = (update, draw, self.vae.training)
+            g = st.graphs.get(key)
+            if g is None:
+                # eager warm-up (allocates every workspace), then capture
+                self._run(st, update, draw)
+                torch.cuda.synchronize(self.device)
+                g = self._capture(st, update, draw)
+                st.graphs[key] = g
+                return
+            for part in g:
+                part()
+        finally:
+            # raw-pointer weight updates are invisible to torch's version counters
+            if update in ("encoder", "both"):
+                self.enc.wgen += 1
+            if update in ("decoder", "both"):
+                self.dec.wgen += 1
 
     def _capture(self, st, update, draw):
         """Capture the step as hipGraph(s).  With a gradient all-reduce the step is split around it
