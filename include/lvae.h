@@ -169,20 +169,23 @@ int lv_loss_assemble_f32(const float* nll, const float* kl, const float* kl_weig
  * z = mu + eps*exp(logvar/2), kl = 0.5*sum(mu^2 + exp(logvar) - logvar - 1).  hT [B][H], W_lin [2nz][H], eps/z [B][ns][nz] */
 int lv_enc_head_fwd_f32(const float* hT, const float* w_lin, const float* eps, float* mulv, float* z, float* kl,
                         int B, int H, int ns, int nz, void* stream);
-/* ... and its backward: (dz, dkl) -> dmulv [B][2nz], dhT [B][H], gW_lin [2nz][H] ('=') */
-int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const float* dz, const float* dkl, const float* hT,
-                        const float* w_lin, float* dmulv, float* dhT, float* gw_lin, int B, int H, int ns, int nz,
-                        void* stream);
+/* ... and its backward: (dz, dkl) -> dmulv [B][2nz], dhT [B][H], gW_lin [2nz][H] ('=').  dz: [dz_parts][B][ns][nz],
+ * summed over the leading index in order (1 for a plain gradient; lv_dec_tail_parts(H) after lv_dec_tail_bwd_f32) */
+int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const float* dz, int dz_parts, const float* dkl,
+                        const float* hT, const float* w_lin, float* dmulv, float* dhT, float* gw_lin, int B, int H, int ns,
+                        int nz, void* stream);
 /* LSTMDecoder.decode's z-dependent prologue (dec_lstm.py:95-101): c0 = z W_trans^T, h0 = tanh(c0) (G7) and
  * Zp = z W_ih[:, col0:col0+nz]^T + b_ih + b_hh, the contribution of cat((word_embed, z_), -1) to the input projection;
  * Zp gate-major [B][4H], or with column 4u+g (unit_major != 0) for the unit-major Gx epilogue */
 int lv_dec_init_f32(const float* z, const float* w_trans, const float* w_ih, long ld_wih, int col0, const float* b_ih,
                     const float* b_hh, float* c0, float* h0, float* zp, int unit_major, int B, int H, int nz, void* stream);
 /* ... and its backward from the BPTT's sums: dGsum [B][4H] (gate-major), dc0 [B][H] -> gW_ih[:, col0:col0+nz] (ld_gwih),
- * g_b_ih, g_b_hh, gW_trans ('=') and dz [B][nz] */
+ * g_b_ih, g_b_hh, gW_trans ('=') and dz = dGsum . W_ih[:, col0:] + dc0 . W_trans as lv_dec_tail_parts(H) partial sums
+ * dz_parts [parts][B][nz] over slices of the contraction (summed in order by lv_enc_head_bwd_f32 / lv_colsum_f32) */
+int lv_dec_tail_parts(int H);
 int lv_dec_tail_bwd_f32(const float* dGsum, const float* dc0, const float* z, const float* w_ih, long ld_wih, int col0,
                         const float* w_trans, float* gw_ih, long ld_gwih, float* gw_trans, float* gb_ih, float* gb_hh,
-                        float* dz, int B, int H, int nz, void* stream);
+                        float* dz_parts, int B, int H, int nz, void* stream);
 
 /* small elementwise / reductions used by the sequencing (h0 = tanh(c0) dec_lstm.py:100; bias grads) */
 int lv_tanh_f32(const float* in, float* out, long n, void* stream);
@@ -212,7 +215,7 @@ int lv_rng_normal_f32(float* out, long n, const uint64_t* state_dev, uint64_t su
 int lv_rng_keepmask_u8(uint8_t* out, long n, float keep_prob, const uint64_t* state_dev, uint64_t substream, void* stream);
 int lv_rng_advance(uint64_t* state_dev, uint64_t inc, void* stream);
 /* all the noise of one VAE.loss call in one launch: eps (substream 0), dropout_in / dropout_out keep-masks (substreams
- * 1, 2; either may be NULL), then offset += inc.  state_dev: uint64[3] = {seed, offset, ticket (0 between calls)} */
+ * 1, 2; either may be NULL), then offset += inc (lv_rng_advance queued behind it).  state_dev: uint64[2] = {seed, offset} */
 int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long n_in, float keep_in, uint8_t* mask_out, long n_out,
                       float keep_out, uint64_t* state_dev, uint64_t inc, void* stream);
 int lv_rng_bernoulli_f32(const float* p, float* out, long n, const uint64_t* state_dev, uint64_t substream,

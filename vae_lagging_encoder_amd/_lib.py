@@ -31,7 +31,8 @@ SIGNATURES = {
     "lv_lstm_persist_pack": [_vp, _vp, _i, _i, _vp],
     "lv_loss_assemble_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "lv_enc_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "lv_enc_head_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_enc_head_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_dec_tail_parts": [_i],
     "lv_dec_init_f32": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_dec_tail_bwd_f32": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_clip_norm2_f32": [_vp, _l, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp],
@@ -110,7 +111,7 @@ class Lib(object):
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):

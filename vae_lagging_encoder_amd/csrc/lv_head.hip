@@ -13,7 +13,7 @@
 namespace {
 
 // ---- encoder head forward: mulv = h_T . W_lin^T ; z = mu + eps*exp(lv/2) ; KL = 0.5*sum(mu^2 + exp(lv) - lv - 1) -------
-// one workgroup per batch row
+// one workgroup per batch row; a wave owns outputs o = w, w+4, ... and keeps 16 of them in flight (independent loads)
 __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restrict__ hT, const float* __restrict__ wlin,
                                                            const float* __restrict__ eps, float* __restrict__ mulv,
                                                            float* __restrict__ z, float* __restrict__ kl,
@@ -23,14 +23,27 @@ __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restri
     float* sm = sh + H;                                   // [2nz] mu | logvar
     float* sk = sm + 2 * nz;                              // [nz] KL terms
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int nz2 = 2 * nz;
     for (int h = tid; h < H; h += 256) sh[h] = hT[(long)b * H + h];
     __syncthreads();
-    for (int o = w; o < 2 * nz; o += 4) {                 // one wave per output, lanes stride the contraction
-        const float* wr = wlin + (long)o * H;
-        float s = 0.f;
-        for (int h = l; h < H; h += 64) s = fmaf(sh[h], wr[h], s);
-        s = lv_wave_sum(s);
-        if (l == 0) { sm[o] = s; mulv[(long)b * 2 * nz + o] = s; }
+    for (int o0 = 0; o0 < nz2; o0 += 64) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int h = l; h < H; h += 64) {
+            const float x = sh[h];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o = o0 + w + 4 * i;
+                acc[i] = fmaf(x, wlin[(long)(o < nz2 ? o : 0) * H + h], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = o0 + w + 4 * i;
+            const float s = lv_wave_sum(acc[i]);
+            if (l == 0 && o < nz2) { sm[o] = s; mulv[(long)b * nz2 + o] = s; }
+        }
     }
     __syncthreads();
     for (int j = tid; j < nz; j += 256) {
@@ -51,9 +64,11 @@ __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restri
 }
 
 // ---- encoder head backward: dmulv from (dz, dKL); dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T --------------------------
-// one workgroup per 64 columns h; 4 sub-groups split the batch rows (dh_T) and the 2nz rows (dW_lin)
+// grid (ceil(H/64), SLICES): a workgroup covers 64 columns h; the B + 2nz output rows (dh_T rows, then dW_lin rows) are
+// dealt round-robin to SLICES x 4 workers.  dz may arrive as `parts` partial sums [parts][B][ns][nz] (lv_dec_tail_bwd).
+constexpr int HB_SLICES = 8;
 __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
-                                                           const float* __restrict__ dz, const float* __restrict__ dkl,
+                                                           const float* __restrict__ dz, int parts, const float* __restrict__ dkl,
                                                            const float* __restrict__ hT, const float* __restrict__ wlin,
                                                            float* __restrict__ dmulv, float* __restrict__ dhT,
                                                            float* __restrict__ gwlin, int B, int H, int ns, int nz) {
@@ -61,6 +76,7 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
     float* sd = reinterpret_cast<float*>(smem);           // [B][2nz] dmulv
     const int tid = (int)threadIdx.x;
     const int nz2 = 2 * nz;
+    const long pstride = (long)B * ns * nz;
     for (int i = tid; i < B * nz; i += 256) {
         const int b = i / nz, j = i % nz;
         const float m = mulv[(long)b * nz2 + j], lv = mulv[(long)b * nz2 + nz + j];
@@ -68,7 +84,8 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
         float gz = 0.f, gze = 0.f;
         for (int s = 0; s < ns; ++s) {
             const long zi = ((long)b * ns + s) * nz + j;
-            const float g = dz[zi];
+            float g = 0.f;
+            for (int q = 0; q < parts; ++q) g += dz[q * pstride + zi];
             gz += g;
             gze += g * eps[zi];
         }
@@ -76,27 +93,39 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
         const float dm = gz + gk * m, dl = gze * (0.5f * sdv) + gk * (0.5f * (expf(lv) - 1.f));
         sd[b * nz2 + j] = dm;
         sd[b * nz2 + nz + j] = dl;
-        if (blockIdx.x == 0) { dmulv[(long)b * nz2 + j] = dm; dmulv[(long)b * nz2 + nz + j] = dl; }
+        if (blockIdx.x == 0 && blockIdx.y == 0) { dmulv[(long)b * nz2 + j] = dm; dmulv[(long)b * nz2 + nz + j] = dl; }
     }
     __syncthreads();
-    const int h = (int)blockIdx.x * 64 + (tid & 63), g = tid >> 6;
+    const int h = (int)blockIdx.x * 64 + (tid & 63);
     if (h >= H) return;
-    for (int b = g; b < B; b += 4) {                      // dh_T[b][h] = sum_j dmulv[b][j] W_lin[j][h]
-        float s = 0.f;
-        for (int j = 0; j < nz2; ++j) s = fmaf(sd[b * nz2 + j], wlin[(long)j * H + h], s);
-        dhT[(long)b * H + h] = s;
-    }
-    for (int j = g; j < nz2; j += 4) {                    // dW_lin[j][h] = sum_b dmulv[b][j] h_T[b][h]
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s = fmaf(sd[b * nz2 + j], hT[(long)b * H + h], s);
-        gwlin[(long)j * H + h] = s;
+    const int worker = (int)blockIdx.y * 4 + (tid >> 6);
+    for (int r = worker; r < B + nz2; r += HB_SLICES * 4) {
+        float s0 = 0.f, s1 = 0.f;
+        if (r < B) {                                      // dh_T[r][h] = sum_j dmulv[r][j] W_lin[j][h]
+            int j = 0;
+            for (; j + 1 < nz2; j += 2) {
+                s0 = fmaf(sd[r * nz2 + j], wlin[(long)j * H + h], s0);
+                s1 = fmaf(sd[r * nz2 + j + 1], wlin[(long)(j + 1) * H + h], s1);
+            }
+            if (j < nz2) s0 = fmaf(sd[r * nz2 + j], wlin[(long)j * H + h], s0);
+            dhT[(long)r * H + h] = s0 + s1;
+        } else {                                          // dW_lin[j][h] = sum_b dmulv[b][j] h_T[b][h]
+            const int j = r - B;
+            int b = 0;
+            for (; b + 1 < B; b += 2) {
+                s0 = fmaf(sd[b * nz2 + j], hT[(long)b * H + h], s0);
+                s1 = fmaf(sd[(b + 1) * nz2 + j], hT[(long)(b + 1) * H + h], s1);
+            }
+            if (b < B) s0 = fmaf(sd[b * nz2 + j], hT[(long)b * H + h], s0);
+            gwlin[(long)j * H + h] = s0 + s1;
+        }
     }
 }
 
 // ---- decoder initial state and the z-part of its input projection ------------------------------------------------------
 // thread n < H: c0[b][n] = z[b] . W_trans[n], h0 = tanh(c0); thread H + n', n' < 4H: Zp[b][n'] = z[b] . W_ih[n'][col0:] + b_ih + b_hh
-// (written gate-major, or unit-major 4u+g when unit_major != 0).  z staged in LDS; a thread keeps its weight row in
-// registers and walks the batch.
+// (written gate-major, or unit-major 4u+g when unit_major != 0).  z staged in LDS; a thread keeps (a 32-wide chunk of) its
+// weight row in registers and walks the batch.
 constexpr int NZC = 32;      // latent chunk held in registers
 __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__ z, const float* __restrict__ wtr,
                                                        const float* __restrict__ wih, long ld_wih, int col0,
@@ -116,31 +145,44 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
     const float bias = init ? 0.f : bih[r] + bhh[r];
     long ocol = r;
     if (!init && unit_major) ocol = 4L * (r % H) + r / H;
-    for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int k0 = 0; k0 < nz; k0 += NZC) {
-            const int kn = nz - k0 < NZC ? nz - k0 : NZC;
-            for (int k = 0; k < kn; ++k) s = fmaf(sz[b * nz + k0 + k], wrow[k0 + k], s);
-        }
-        if (init) {
-            c0[(long)b * H + r] = s;
-            h0[(long)b * H + r] = tanhf(s);
-        } else {
-            zp[(long)b * 4 * H + ocol] = s + bias;
+    float* orow = init ? c0 + r : zp + ocol;
+    const long ostride = init ? (long)H : 4L * H;
+    for (int k0 = 0; k0 < nz; k0 += NZC) {
+        const int kn = nz - k0 < NZC ? nz - k0 : NZC;
+        float wr[NZC];
+#pragma unroll
+        for (int k = 0; k < NZC; ++k) wr[k] = k < kn ? wrow[k0 + k] : 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* zb = sz + b * nz + k0;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NZC; k += 2) {
+                s0 = fmaf(k < kn ? zb[k] : 0.f, wr[k], s0);
+                s1 = fmaf(k + 1 < kn ? zb[k + 1] : 0.f, wr[k + 1], s1);
+            }
+            const float s = s0 + s1;
+            float* o = orow + (long)b * ostride;
+            if (k0 == 0) *o = s + bias;
+            else *o += s;
         }
     }
+    if (init)
+        for (int b = 0; b < B; ++b) h0[(long)b * H + r] = tanhf(c0[(long)b * H + r]);
 }
 
 // ---- decoder tail of the backward ---------------------------------------------------------------------------------------
 // blocks [0, nA): thread n < 4H: gW_ih[n][col0 + k] = sum_b dGsum[b][n] z[b][k], g_bih[n] = g_bhh[n] = sum_b dGsum[b][n];
 //                 thread 4H + j, j < H: gW_trans[j][k] = sum_b dc0[b][j] z[b][k]
-// blocks [nA, nA + B): dz[b][k] = sum_n dGsum[b][n] W_ih[n][col0 + k] + sum_j dc0[b][j] W_trans[j][k]
+// blocks [nA, nA + parts): partial dz over a slice of DZ_ROWS contraction rows of the stacked [W_ih[:, col0:] ; W_trans]:
+//                 dzp[part][b][k] = sum_{rows of the slice} d[b][row] W[row][k]   (the consumer sums the parts in order)
+constexpr int DZ_ROWS = 128;
+constexpr int DZ_BC = 32;       // batch rows staged per pass
 __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restrict__ dGsum, const float* __restrict__ dc0,
                                                            const float* __restrict__ z, const float* __restrict__ wih,
                                                            long ld_wih, int col0, const float* __restrict__ wtr,
                                                            float* __restrict__ gwih, long ld_gwih, float* __restrict__ gwtr,
                                                            float* __restrict__ gbih, float* __restrict__ gbhh,
-                                                           float* __restrict__ dz, int nA, int B, int H, int nz) {
+                                                           float* __restrict__ dzp, int nA, int B, int H, int nz) {
     LV_DYN_SHARED(smem);
     float* sm = reinterpret_cast<float*>(smem);
     const int tid = (int)threadIdx.x;
@@ -165,37 +207,53 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
             for (int b = 0; b < B; ++b) {
                 const float v = col[(long)b * cs];
                 tot += v;
+                const float* zb = sz + b * nz + k0;
 #pragma unroll
-                for (int k = 0; k < NZC; ++k)
-                    if (k < kn) acc[k] = fmaf(v, sz[b * nz + k0 + k], acc[k]);
+                for (int k = 0; k < NZC; ++k) acc[k] = fmaf(v, k < kn ? zb[k] : 0.f, acc[k]);
             }
 #pragma unroll
             for (int k = 0; k < NZC; ++k)
                 if (k < kn) orow[k0 + k] = acc[k];
         }
-        if (nz == 0) for (int b = 0; b < B; ++b) tot += col[(long)b * cs];
         if (gate) { gbih[r] = tot; gbhh[r] = tot; }
         return;
     }
-    // ---- dz row b: 8 parts x 32 latent lanes; part p walks rows n = p, p + 8, ...
-    const int b = (int)blockIdx.x - nA;
-    const int kl = tid & 31, part = tid >> 5;
-    float* red = sm;                                      // [8][32]
-    for (int k0 = 0; k0 < nz; k0 += 32) {
-        const int k = k0 + kl;
-        float s = 0.f;
-        if (k < nz) {
-            for (int n = part; n < 4 * H; n += 8) s = fmaf(dGsum[(long)b * 4 * H + n], wih[(long)n * ld_wih + col0 + k], s);
-            for (int j = part; j < H; j += 8) s = fmaf(dc0[(long)b * H + j], wtr[(long)j * nz + k], s);
-        }
-        red[part * 32 + kl] = s;
+    // ---- partial dz: this block's slice of the stacked contraction rows; thread = (latent k = tid & 31, batch lane tid >> 5);
+    // the batch is walked in chunks of DZ_BC rows staged in LDS
+    const int part = (int)blockIdx.x - nA;
+    const int row0 = part * DZ_ROWS;
+    const int nrows = 5 * H - row0 < DZ_ROWS ? 5 * H - row0 : DZ_ROWS;
+    float* sdv = sm;                                      // [DZ_BC][DZ_ROWS] a chunk of the slice of d = [dGsum | dc0]
+    const int kl = tid & 31, bg = tid >> 5;
+    for (int bc = 0; bc < B; bc += DZ_BC) {
+        const int nb = B - bc < DZ_BC ? B - bc : DZ_BC;
         __syncthreads();
-        if (part == 0 && k < nz) {
-            float t = 0.f;
-            for (int p2 = 0; p2 < 8; ++p2) t += red[p2 * 32 + kl];
-            dz[(long)b * nz + k] = t;
+        for (int i = tid; i < DZ_BC * DZ_ROWS; i += 256) {
+            const int bl = i / DZ_ROWS, rr = i % DZ_ROWS;
+            const int row = row0 + rr, b = bc + bl;
+            float v = 0.f;
+            if (rr < nrows && bl < nb) v = row < 4 * H ? dGsum[(long)b * 4 * H + row] : dc0[(long)b * H + (row - 4 * H)];
+            sdv[i] = v;
         }
         __syncthreads();
+        for (int k0 = 0; k0 < nz; k0 += 32) {
+            const int k = k0 + kl;
+            if (k >= nz) continue;
+            float acc[DZ_BC / 8];
+#pragma unroll
+            for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = 0.f;
+            for (int rr = 0; rr < nrows; ++rr) {
+                const int row = row0 + rr;
+                const float wv = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
+#pragma unroll
+                for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = fmaf(sdv[(bg + 8 * q) * DZ_ROWS + rr], wv, acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < DZ_BC / 8; ++q) {
+                const int bl = bg + 8 * q;
+                if (bl < nb) dzp[((long)part * B + bc + bl) * nz + k] = acc[q];
+            }
+        }
     }
 }
 
@@ -214,17 +272,18 @@ extern "C" int lv_enc_head_fwd_f32(const float* hT, const float* wlin, const flo
     return LV_OK;
 }
 
-// Backward of the same: (dz [B][ns][nz], dkl [B]) -> dmulv [B][2nz], dhT [B][H] (gradient entering the BPTT at the last
-// step), gW_lin [2nz][H] ('=' semantics).
-extern "C" int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const float* dz, const float* dkl, const float* hT,
-                                   const float* wlin, float* dmulv, float* dhT, float* gwlin, int B, int H, int ns, int nz,
-                                   void* stream) {
+// Backward of the same: (dz, dkl [B]) -> dmulv [B][2nz], dhT [B][H] (gradient entering the BPTT at the last step),
+// gW_lin [2nz][H] ('=' semantics).  dz: [dz_parts][B][ns][nz], summed over the leading index in order (dz_parts = 1 for a
+// plain gradient; lv_dec_tail_bwd_f32 hands over lv_dec_tail_parts(H) partial sums).
+extern "C" int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const float* dz, int dz_parts, const float* dkl,
+                                   const float* hT, const float* wlin, float* dmulv, float* dhT, float* gwlin, int B, int H,
+                                   int ns, int nz, void* stream) {
     if (!mulv || !eps || !dz || !dkl || !hT || !wlin || !dmulv || !dhT || !gwlin) return LV_ERR_ARG;
-    if (B <= 0 || H <= 0 || ns <= 0 || nz <= 0) return LV_ERR_SHAPE;
+    if (B <= 0 || H <= 0 || ns <= 0 || nz <= 0 || dz_parts <= 0) return LV_ERR_SHAPE;
     const size_t sh = (size_t)B * 2 * nz * sizeof(float);
     if (sh > 60000) return LV_ERR_UNSUPPORTED;
-    LV_LAUNCH(enc_head_bwd_kernel, dim3((unsigned)lv_cdiv(H, 64)), dim3(256), sh, stream, mulv, eps, dz, dkl, hT, wlin, dmulv,
-              dhT, gwlin, B, H, ns, nz);
+    LV_LAUNCH(enc_head_bwd_kernel, dim3((unsigned)lv_cdiv(H, 64), HB_SLICES), dim3(256), sh, stream, mulv, eps, dz, dz_parts, dkl,
+              hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -245,19 +304,25 @@ extern "C" int lv_dec_init_f32(const float* z, const float* wtr, const float* wi
     return LV_OK;
 }
 
+// number of partial sums lv_dec_tail_bwd_f32 writes for dz
+extern "C" int lv_dec_tail_parts(int H) { return lv_cdiv(5L * H, DZ_ROWS); }
+
 // Backward of the same, fed by the BPTT's sums: dGsum [B][4H] (gate-major, sum over time of the gate gradients) and
-// dc0 [B][H] -> gW_ih[:, col0:col0+nz], g_b_ih, g_b_hh, gW_trans ('=' semantics) and dz [B][nz].
+// dc0 [B][H] -> gW_ih[:, col0:col0+nz], g_b_ih, g_b_hh, gW_trans ('=' semantics) and dz = dGsum . W_ih[:, col0:] +
+// dc0 . W_trans as lv_dec_tail_parts(H) partial sums dz_parts [parts][B][nz] over slices of the contraction (summed in
+// order by the consumer: lv_enc_head_bwd_f32, or lv_colsum_f32 over the leading index).
 extern "C" int lv_dec_tail_bwd_f32(const float* dGsum, const float* dc0, const float* z, const float* wih, long ld_wih, int col0,
-                                   const float* wtr, float* gwih, long ld_gwih, float* gwtr, float* gbih, float* gbhh, float* dz,
-                                   int B, int H, int nz, void* stream) {
-    if (!dGsum || !dc0 || !z || !wih || !wtr || !gwih || !gwtr || !gbih || !gbhh || !dz) return LV_ERR_ARG;
+                                   const float* wtr, float* gwih, long ld_gwih, float* gwtr, float* gbih, float* gbhh,
+                                   float* dz_parts, int B, int H, int nz, void* stream) {
+    if (!dGsum || !dc0 || !z || !wih || !wtr || !gwih || !gwtr || !gbih || !gbhh || !dz_parts) return LV_ERR_ARG;
     if (B <= 0 || H <= 0 || nz <= 0 || ld_wih < col0 + nz || ld_gwih < col0 + nz) return LV_ERR_SHAPE;
     size_t sh = (size_t)B * nz * sizeof(float);
-    if (sh < 8 * 32 * sizeof(float)) sh = 8 * 32 * sizeof(float);
     if (sh > 60000) return LV_ERR_UNSUPPORTED;
+    if (sh < (size_t)DZ_BC * DZ_ROWS * sizeof(float)) sh = (size_t)DZ_BC * DZ_ROWS * sizeof(float);
     const int nA = lv_cdiv(5L * H, 256);
-    LV_LAUNCH(dec_tail_bwd_kernel, dim3((unsigned)(nA + B)), dim3(256), sh, stream, dGsum, dc0, z, wih, ld_wih, col0, wtr, gwih,
-              ld_gwih, gwtr, gbih, gbhh, dz, nA, B, H, nz);
+    const int parts = lv_cdiv(5L * H, DZ_ROWS);
+    LV_LAUNCH(dec_tail_bwd_kernel, dim3((unsigned)(nA + parts)), dim3(256), sh, stream, dGsum, dc0, z, wih, ld_wih, col0, wtr, gwih,
+              ld_gwih, gwtr, gbih, gbhh, dz_parts, nA, B, H, nz);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

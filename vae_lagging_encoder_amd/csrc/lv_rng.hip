@@ -90,8 +90,8 @@ __global__ void rng_advance_kernel(uint64_t* state, uint64_t inc) {
 
 // All the noise of one VAE.loss call in ONE launch (same draws as rng_normal substream 0 + rng_keepmask substreams 1, 2
 // followed by rng_advance): blocks [0, nb0) fill eps, [nb0, nb0+nb1) the dropout_in keep-mask, the rest the dropout_out
-// keep-mask.  The offset is advanced by whichever block finishes last (ticket in state[2]); every block has read the
-// state before it takes its ticket.
+// keep-mask.  The offset is advanced by rng_advance_kernel, queued right behind it by the same entry point (a last-block
+// ticket inside this kernel was measured at 59 us: ~2000 blocks serialising on one atomic).
 struct NoiseP {
     float* eps; long n_eps;
     uint8_t* m1; long n1; float keep1;
@@ -138,14 +138,6 @@ __global__ __launch_bounds__(256) void rng_noise_step_kernel(NoiseP p) {
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned* ticket = reinterpret_cast<unsigned*>(p.state + 2);
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            p.state[1] += p.inc;
-            *ticket = 0u;
-        }
-    }
 }
 
 }  // namespace
@@ -186,8 +178,8 @@ extern "C" int lv_rng_advance(uint64_t* state, uint64_t inc, void* stream) {
 }
 
 // eps (normal, substream 0), the dropout_in keep-mask (substream 1) and the dropout_out keep-mask (substream 2) of one
-// VAE.loss call, then offset += inc, in one launch.  state: device uint64[3] = {seed, offset, ticket (0 between calls)};
-// either mask may be NULL (eval mode).
+// VAE.loss call in one launch, then offset += inc.  state: device uint64[2] = {seed, offset}; either mask may be NULL
+// (eval mode).
 extern "C" int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long n_in, float keep_in, uint8_t* mask_out,
                                  long n_out, float keep_out, uint64_t* state, uint64_t inc, void* stream) {
     if (!eps || !state || n_eps < 0 || n_in < 0 || n_out < 0) return LV_ERR_ARG;
@@ -196,8 +188,8 @@ extern "C" int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long 
     NoiseP p{eps, n_eps, mask_in, n_in, keep_in, mask_out, n_out, keep_out, state, inc,
              (unsigned)lv_cdiv((n_eps + 3) / 4, 256), (unsigned)lv_cdiv((n_in + 7) / 8, 256)};
     const unsigned nb = p.nb0 + p.nb1 + (unsigned)lv_cdiv((n_out + 7) / 8, 256);
-    if (nb == 0) return LV_OK;
-    LV_LAUNCH(rng_noise_step_kernel, dim3(nb), dim3(256), 0, stream, p);
+    if (nb > 0) LV_LAUNCH(rng_noise_step_kernel, dim3(nb), dim3(256), 0, stream, p);
+    LV_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, stream, state, inc);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -487,8 +487,8 @@ class LSTMEncoderEngine(object):
     def backward(self, dmulv, gen=None, head=None):
         """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics).
 
-        head = (eps, dz [B][ns][nz], dkl [B]) instead of dmulv: the backward of reparameterise + KL runs in the head's
-        launch (fused driver; dmulv is then produced into the workspace)."""
+        head = (eps, dz [parts][B][ns][nz], parts, dkl [B]) instead of dmulv: the backward of reparameterise + KL runs in
+        the head's launch (fused driver; dmulv is then produced into the workspace)."""
         x, B, T, g = self.last
         if gen is not None and gen != g:
             raise _lib.LvaeError("encoder activations were overwritten by a later forward(); the HIP engine keeps "
@@ -499,8 +499,8 @@ class LSTMEncoderEngine(object):
         w = self._ws(B, T)
         v, gv = f.views, f.gviews
         if head is not None:
-            eps, dz, dkl = head
-            lib.lv_enc_head_bwd_f32(P(w.mulv), P(eps), P(dz), P(dkl), P(w.hs, T * B * H), P(v["linear.weight"]), P(w.dmulv),
+            eps, dz, parts, dkl = head
+            lib.lv_enc_head_bwd_f32(P(w.mulv), P(eps), P(dz), parts, P(dkl), P(w.hs, T * B * H), P(v["linear.weight"]), P(w.dmulv),
                                     P(w.dhT), P(gv["linear.weight"]), B, H, eps.shape[1], nz2 // 2, s)
         else:
             dmulv = dmulv.contiguous()
@@ -627,6 +627,8 @@ class LSTMDecoderEngine(object):
             w.dc0 = c.f32(Bd, H)
             w.dX = c.f32(Td * Bd, ni)
             w.dz = c.f32(Bd, nz)
+            w.dz_parts = self.lib.lv_dec_tail_parts(H)
+            w.dzp = c.f32(w.dz_parts, Bd, nz)
             w.srows = c.i32(Td * Bd)
             w.stok = c.i32(Td * Bd)
             w.stmp = c.i32(2 * Td * Bd)
@@ -725,8 +727,9 @@ class LSTMDecoderEngine(object):
         self.last = (x, z2, mask_in, mask_out, sc_in, sc_out, B, T, self.gen)
         return w.rec
 
-    def backward(self, drec, gen=None):
-        """drec [B] = dL/d rec_b -> fills self.flat.grad; returns dz [B][nz]."""
+    def backward(self, drec, gen=None, partial_dz=False):
+        """drec [B] = dL/d rec_b -> fills self.flat.grad; returns dz [B][nz] (partial_dz: the tail kernel's partial sums
+        [parts][B][nz] and their count instead)."""
         x, z2, mask_in, mask_out, sc_in, sc_out, B, T, g = self.last
         if gen is not None and gen != g:
             raise _lib.LvaeError("decoder activations were overwritten by a later forward(); the HIP engine keeps "
@@ -780,8 +783,11 @@ class LSTMDecoderEngine(object):
         # batch-sized tail in one launch (critical path: dz feeds the encoder's backward): the z-columns of dW_ih, both
         # bias gradients, dW_trans, and dz = dGsum . W_ih[:, ni:] + dc0 . W_trans
         lib.lv_dec_tail_bwd_f32(P(w.dGsum), P(w.dc0), P(z2), P(wih), ni + nz, ni, P(v["trans_linear.weight"]), P(gwih), ni + nz,
-                                P(gv["trans_linear.weight"]), P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), P(w.dz),
+                                P(gv["trans_linear.weight"]), P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), P(w.dzp),
                                 B, H, nz, s)
+        if partial_dz:
+            return w.dzp, w.dz_parts         # the fused driver's encoder head sums the parts itself
+        lib.lv_colsum_f32(P(w.dzp), B * nz, w.dz_parts, B * nz, P(w.dz), None, s)
         return w.dz
 
 

@@ -52,8 +52,7 @@ class AggressiveTextTrainer(object):
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
         # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
-        # third word: the ticket of lv_rng_noise_step (0 between calls)
-        self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0, 0], dtype=torch.int64, device=d)
+        self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0], dtype=torch.int64, device=d)
         self.static = {}
 
     # -- scalar views ------------------------------------------------------------------------------
@@ -118,14 +117,14 @@ class AggressiveTextTrainer(object):
         # rec, loss, the running report sums and the seeds of mean_b(loss_b).backward(), one launch
         lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
                                  self._s(5), T - 1, B, s)
-        dz = self.dec.backward(st.rowscale)
+        dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
         if self.grad_sync is not None and not self._capturing and not (self.enc.persistent and self.enc.precision == "bf16"):
             # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward.
             # Not beside a PERSISTENT encoder BPTT: that launch needs every CU resident at once, and compute units held
             # by the collective's kernels would leave part of its grid spinning -- both reductions then go out in sync().
             self.dec.join()
             self.grad_sync.start_decoder(self.dec.flat)
-        self.enc.backward(None, head=(st.eps, dz, st.dkl))
+        self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl))
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
 
     def _clip_and_step(self, update):
