@@ -65,7 +65,7 @@ if os.path.exists(alt):
     libs["alt"] = _lib.bind(ctypes.CDLL(alt), alt)
 small = [("Gx", 0, TB, 4 * H, ni, X16, ni, Wi16, ni, Gx, 4 * H), ("dX", 0, TB, ni, 4 * H, dG16, 4 * H, WiT16, 4 * H, dX, ni),
          ("dW_ih", 1, 4 * H, ni, TB, dG16, 4 * H, XT16, TB, dWi, ni), ("dW_hh", 1, 4 * H, H, TB, dG16, 4 * H, hT16, TB, dWh, H),
-         ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H)]
+         ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H), ("logits", 0, R, V, H, O16, H, W16, H, logits, ldl)]
 for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc in small:
     line = "%-6s M=%5d N=%5d K=%5d" % (name, M, N, K)
     for ln, L in libs.items():

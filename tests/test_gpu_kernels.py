@@ -803,7 +803,8 @@ def test_dec_init_and_tail(lib, hip_device, B, H, nz, ni, unit_major):
     gwtr = torch.empty(H, nz, device=dev); gb1 = torch.empty(4 * H, device=dev); gb2 = torch.empty(4 * H, device=dev)
     parts = lib.lv_dec_tail_parts(H)
     dzp = torch.full((parts, B, nz), float("nan"), device=dev)
-    lib.lv_dec_tail_bwd_f32(P(dGsum.to(dev)), P(dc0.to(dev)), P(d[0]), P(d[2]), ni + nz, ni, P(d[1]), P(gwih), ni + nz, P(gwtr),
+    dGsum_d, dc0_d = dGsum.to(dev), dc0.to(dev)          # named: P() of a temporary would dangle
+    lib.lv_dec_tail_bwd_f32(P(dGsum_d), P(dc0_d), P(d[0]), P(d[2]), ni + nz, ni, P(d[1]), P(gwih), ni + nz, P(gwtr),
                             P(gb1), P(gb2), P(dzp), B, H, nz, _s(dev))
     dz = dzp.sum(0)
     r_gwih = dGsum.double().t() @ z.double()
@@ -828,7 +829,8 @@ def test_loss_assemble(lib, hip_device, T, B):
     klw = torch.tensor([0.37])
     acc = torch.tensor([1.0, 2.0, 3.0], device=dev)
     outs = [torch.empty(B, device=dev) for _ in range(4)]
-    lib.lv_loss_assemble_f32(P(nll.to(dev)), P(kl.to(dev)), P(klw.to(dev)), P(gl.to(dev)), P(outs[0]), P(outs[1]), P(outs[2]),
+    nll_d, kl_d, klw_d, gl_d = nll.to(dev), kl.to(dev), klw.to(dev), gl.to(dev)      # named: P() of a temporary would dangle
+    lib.lv_loss_assemble_f32(P(nll_d), P(kl_d), P(klw_d), P(gl_d), P(outs[0]), P(outs[1]), P(outs[2]),
                              P(outs[3]), P(acc), T, B, _s(dev))
     rec_r = nll.double().sum(0)
     loss_r = rec_r + 0.37 * kl.double()
@@ -846,7 +848,8 @@ def test_clip_norm2(lib, hip_device, n1, n2):
     a, b = torch.randn(n1, generator=g), torch.randn(n2, generator=g) * 0.01
     ws = torch.empty(lib.lv_sumsq_workspace_floats(), device=dev)
     out = torch.zeros(3, device=dev)
-    lib.lv_clip_norm2_f32(P(a.to(dev)), n1, P(b.to(dev)), n2, P(ws), 5.0, P(out, 0), P(out, 1), P(out, 2), _s(dev))
+    a_d, b_d = a.to(dev), b.to(dev)
+    lib.lv_clip_norm2_f32(P(a_d), n1, P(b_d), n2, P(ws), 5.0, P(out, 0), P(out, 1), P(out, 2), _s(dev))
     nrm = float((a.double().pow(2).sum() + b.double().pow(2).sum()).sqrt())
     o = out.cpu().tolist()
     assert abs(o[2] - nrm) < 1e-5 * nrm and abs(o[0] - nrm * nrm) < 1e-5 * nrm * nrm

@@ -15,6 +15,9 @@ static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu
 #define LV_SCHED_BARRIER() do { } while (0)
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
+// LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
+static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
+#define LV_WAIT_VMEM() do { } while (0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,6 +47,14 @@ __device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
                                                    c, 0, 0, 0);
 }
+// global -> LDS without passing through registers (global_load_lds_dwordx4): lane l's 16 bytes at g land at
+// lds_wave_base + 16*l; lds_wave_base must be wave-uniform.  The data is ordered for LDS readers by the issuing wave's
+// vmcnt(0) (LV_WAIT_VMEM) followed by a workgroup barrier.
+__device__ __forceinline__ void lv_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
 #include <stdint.h>

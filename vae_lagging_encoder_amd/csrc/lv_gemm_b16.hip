@@ -285,6 +285,190 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
         }
 }
 
+#ifndef LV_B16_GLDS
+#define LV_B16_GLDS 1       // NT form through LDS-DMA staging (0: register staging for both forms; A/B knob of the microbench)
+#endif
+
+// NT form (both operands K-contiguous) with LDS-DMA staging: global_load_lds_dwordx4 moves a K tile straight into LDS, so
+// the 32 KB per K tile never pass through VGPRs and the ds_write pass (13 issue cycles per 1 KB, the busiest LDS port of
+// the register-staged kernel) disappears.  The DMA fixes the LDS image: a wave instruction fills 1 KB in lane order, i.e.
+// 8 rows x 128 B of the row-major tile [128 rows][8 slots of 16 B].  A fragment read (32 lanes = 32 consecutive rows of one
+// k-chunk) on that image would be a 16-way bank conflict, so the swizzle goes on the SOURCE side: slot s of row r holds
+// k-chunk c = s ^ ((r >> 1) & 7) -- the 8 lanes of a row still read that row's one 128-byte line (permuted), and the 16
+// lanes of every ds_read_b128 lane group land on 16 distinct 16-byte bank slots.  The single ragged K tile at the end of
+// a K that is not a multiple of 64 is staged through registers (predicated, zero-filled) into the same image.
+// 16 bytes of a row whose last `valid` (1..7, or >= 8) elements are inside K: one aligned load, the tail masked to zero
+// (rows are 16-byte aligned and ld % 8 == 0, so the load stays inside the row pitch)
+__device__ __forceinline__ uint4 load_chunk_masked(const uint16_t* __restrict__ p, int valid) {
+    uint4 q = *reinterpret_cast<const uint4*>(p);
+    if (valid >= 8) return q;
+    uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        wv[i] &= (2 * i < valid ? 0xFFFFu : 0u) | (2 * i + 1 < valid ? 0xFFFF0000u : 0u);
+    return make_uint4(wv[0], wv[1], wv[2], wv[3]);
+}
+
+typedef uint4 LdsTile[BT][NCH];
+
+__global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
+    // four separate LDS objects: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove disjoint
+    // (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
+    __shared__ __attribute__((aligned(1024))) LdsTile As0, As1, Bs0, Bs1;
+
+    const int nblk = p.tilesM * p.tilesN;
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid % 8, q = nblk / 8, r = nblk % 8;
+    const int s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const int G = 8;
+    const int nig = G * p.tilesN;
+    const int group = s / nig;
+    const int first_m = group * G;
+    const int gsz = (p.tilesM - first_m) < G ? (p.tilesM - first_m) : G;
+    const int tm = first_m + (s % nig) % gsz;
+    const int tn = (s % nig) / gsz;
+    const int m0 = tm * BT, n0 = tn * BT;
+
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = l & 31, lh = l >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)blockIdx.y * p.kt_per_split;
+    int kt1 = kt0 + p.kt_per_split;
+    if (kt1 > nk_all) kt1 = nk_all;
+    const int nfull = p.K / BK;
+
+    // staging units of this thread: wave w fills row blocks u = 4w + i (8 rows each); lane = (row l>>3, slot l&7)
+    const uint16_t* ga[4];
+    const uint16_t* gb[4];
+    int kch[4];                                        // k offset (elements) of the chunk this lane fetches
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * w + i) + (l >> 3);
+        const int c = (l & 7) ^ ((row >> 1) & 7);
+        kch[i] = 8 * c;
+        int ra = m0 + row, rb = n0 + row;
+        if (ra > p.M - 1) ra = p.M - 1;                // clamped, not predicated: such rows only reach C rows / columns
+        if (rb > p.N - 1) rb = p.N - 1;                // that are never written
+        ga[i] = p.A + (long)ra * p.lda + kch[i];
+        gb[i] = p.B + (long)rb * p.ldb + kch[i];
+    }
+    auto stage_dma = [&](int kt, LdsTile& Ad, LdsTile& Bd) {        // a complete K tile: LDS-DMA
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lv_glds16(ga[i] + k0, &Ad[8 * (4 * w + i)][0]);
+            lv_glds16(gb[i] + k0, &Bd[8 * (4 * w + i)][0]);
+        }
+    };
+    auto stage_ragged = [&](int kt, LdsTile& Ad, LdsTile& Bd) {     // the ragged last tile: masked loads through registers
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (4 * w + i) + (l >> 3);
+            const int k = k0 + kch[i];
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            Ad[row][l & 7] = k < p.K ? load_chunk_masked(ga[i] + k0, p.K - k) : z4;
+            Bd[row][l & 7] = k < p.K ? load_chunk_masked(gb[i] + k0, p.K - k) : z4;
+        }
+    };
+
+    const int arow = wm * 64 + li, brow = wn * 64 + li;
+    const int ax0 = (arow >> 1) & 7, ax1 = ((arow + 32) >> 1) & 7;       // swizzle keys of this lane's fragment rows
+    const int bx0 = (brow >> 1) & 7, bx1 = ((brow + 32) >> 1) & 7;
+    // 16 MFMAs over the K tile in (Ac, Bc), then the hand-over: this wave's DMA into the other pair has landed
+    // (vmcnt(0)), everybody's has and everybody is done reading this pair (barrier)
+    auto mma_tile = [&](LdsTile& Ac, LdsTile& Bc) {
+        uint4 fa[2][2], fb[2][2];
+        {
+            const int c = lh;
+            fa[0][0] = Ac[arow][c ^ ax0]; fa[0][1] = Ac[arow + 32][c ^ ax1];
+            fb[0][0] = Bc[brow][c ^ bx0]; fb[0][1] = Bc[brow + 32][c ^ bx1];
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 16) {
+                const int c = 2 * (ks + 1) + lh;
+                fa[nxt][0] = Ac[arow][c ^ ax0]; fa[nxt][1] = Ac[arow + 32][c ^ ax1];
+                fb[nxt][0] = Bc[brow][c ^ bx0]; fb[nxt][1] = Bc[brow + 32][c ^ bx1];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+        }
+        LV_WAIT_VMEM();
+        __syncthreads();
+    };
+
+    const int ntiles = kt1 - kt0;                                    // K tiles of this workgroup; tile i lives in pair i & 1
+    const int nmain = (kt1 < nfull ? kt1 : nfull) - kt0;             // ... of which the first nmain are complete
+    if (ntiles > 0) {
+        if (nmain > 0) stage_dma(kt0, As0, Bs0);
+        else stage_ragged(kt0, As0, Bs0);
+    }
+    LV_WAIT_VMEM();
+    __syncthreads();
+    int i = 0;
+    // hot loop: branch-free pairs of tiles, each followed by another complete tile (a conditional staging path inside this
+    // loop made the compiler shuttle all 64 accumulators AGPR -> VGPR -> AGPR every iteration)
+    for (; i + 2 < nmain; i += 2) {
+        stage_dma(kt0 + i + 1, As1, Bs1);
+        LV_SCHED_BARRIER();          // keep the DMA issue AHEAD of the tile's MFMAs (left alone, the scheduler sinks it to
+        mma_tile(As0, Bs0);          // just before the vmcnt(0) and the whole transfer latency is exposed)
+        stage_dma(kt0 + i + 2, As0, Bs0);
+        LV_SCHED_BARRIER();
+        mma_tile(As1, Bs1);
+    }
+    for (; i < ntiles; ++i) {                                        // the last <= 3 tiles
+        const int nx = i + 1;
+        if ((i & 1) == 0) {
+            if (nx < nmain) stage_dma(kt0 + nx, As1, Bs1);
+            else if (nx < ntiles) stage_ragged(kt0 + nx, As1, Bs1);
+            mma_tile(As0, Bs0);
+        } else {
+            if (nx < nmain) stage_dma(kt0 + nx, As0, Bs0);
+            else if (nx < ntiles) stage_ragged(kt0 + nx, As0, Bs0);
+            mma_tile(As1, Bs1);
+        }
+    }
+
+    const bool split = p.splits > 1;
+    float* const out = split ? p.ws + (long)blockIdx.y * p.M * p.N : p.C;
+    const long ldo = split ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (l & 31);
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                const int row = m0 + wm * 64 + rr;
+                if (row >= p.M) continue;
+                float* c = out + (long)row * ldo + col;
+                if (split) { *c = acc[i][j][e]; continue; }
+                float v = p.alpha * acc[i][j][e];
+                if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+                if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+                if (p.accumulate) v += *c;
+                *c = v;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long MN = (long)p.M * p.N;
@@ -378,6 +562,7 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     p.splits = splits;
     dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
     if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
+    else if (LV_B16_GLDS) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel, grid, block, 0, stream, p);
     else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
     if (splits > 1)
         LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);

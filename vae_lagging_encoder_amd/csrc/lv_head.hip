@@ -99,24 +99,34 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
     const int h = (int)blockIdx.x * 64 + (tid & 63);
     if (h >= H) return;
     const int worker = (int)blockIdx.y * 4 + (tid >> 6);
+    // Loads are issued in batches of 8 with a compile-time trip count: a thread that walks a runtime-length loop of
+    // load -> fma pairs pays one memory round trip per iteration (the first version of this kernel took 66 us that way).
     for (int r = worker; r < B + nz2; r += HB_SLICES * 4) {
         float s0 = 0.f, s1 = 0.f;
         if (r < B) {                                      // dh_T[r][h] = sum_j dmulv[r][j] W_lin[j][h]
-            int j = 0;
-            for (; j + 1 < nz2; j += 2) {
-                s0 = fmaf(sd[r * nz2 + j], wlin[(long)j * H + h], s0);
-                s1 = fmaf(sd[r * nz2 + j + 1], wlin[(long)(j + 1) * H + h], s1);
+            for (int j0 = 0; j0 < nz2; j0 += 8) {
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = wlin[(long)(j0 + u < nz2 ? j0 + u : 0) * H + h];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    s0 = fmaf(j0 + u < nz2 ? sd[r * nz2 + j0 + u] : 0.f, wv[u], s0);
+                    s1 = fmaf(j0 + u + 1 < nz2 ? sd[r * nz2 + j0 + u + 1] : 0.f, wv[u + 1], s1);
+                }
             }
-            if (j < nz2) s0 = fmaf(sd[r * nz2 + j], wlin[(long)j * H + h], s0);
             dhT[(long)r * H + h] = s0 + s1;
         } else {                                          // dW_lin[j][h] = sum_b dmulv[b][j] h_T[b][h]
             const int j = r - B;
-            int b = 0;
-            for (; b + 1 < B; b += 2) {
-                s0 = fmaf(sd[b * nz2 + j], hT[(long)b * H + h], s0);
-                s1 = fmaf(sd[(b + 1) * nz2 + j], hT[(long)(b + 1) * H + h], s1);
+            for (int b0 = 0; b0 < B; b0 += 8) {
+                float hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = hT[(long)(b0 + u < B ? b0 + u : 0) * H + h];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    s0 = fmaf(b0 + u < B ? sd[(b0 + u) * nz2 + j] : 0.f, hv[u], s0);
+                    s1 = fmaf(b0 + u + 1 < B ? sd[(b0 + u + 1) * nz2 + j] : 0.f, hv[u + 1], s1);
+                }
             }
-            if (b < B) s0 = fmaf(sd[b * nz2 + j], hT[(long)b * H + h], s0);
             gwlin[(long)j * H + h] = s0 + s1;
         }
     }
@@ -147,11 +157,12 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
     if (!init && unit_major) ocol = 4L * (r % H) + r / H;
     float* orow = init ? c0 + r : zp + ocol;
     const long ostride = init ? (long)H : 4L * H;
+    const bool one_chunk = nz <= NZC;
     for (int k0 = 0; k0 < nz; k0 += NZC) {
         const int kn = nz - k0 < NZC ? nz - k0 : NZC;
         float wr[NZC];
 #pragma unroll
-        for (int k = 0; k < NZC; ++k) wr[k] = k < kn ? wrow[k0 + k] : 0.f;
+        for (int k = 0; k < NZC; ++k) wr[k] = wrow[k0 + (k < kn ? k : 0)];
         for (int b = 0; b < B; ++b) {
             const float* zb = sz + b * nz + k0;
             float s0 = 0.f, s1 = 0.f;
@@ -164,9 +175,10 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
             float* o = orow + (long)b * ostride;
             if (k0 == 0) *o = s + bias;
             else *o += s;
+            if (init && one_chunk) h0[(long)b * H + r] = tanhf(s);
         }
     }
-    if (init)
+    if (init && !one_chunk)
         for (int b = 0; b < B; ++b) h0[(long)b * H + r] = tanhf(c0[(long)b * H + r]);
 }
 
@@ -204,12 +216,19 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < NZC; ++k) acc[k] = 0.f;
             tot = 0.f;
-            for (int b = 0; b < B; ++b) {
-                const float v = col[(long)b * cs];
-                tot += v;
-                const float* zb = sz + b * nz + k0;
+            for (int b0 = 0; b0 < B; b0 += 8) {           // 8 column loads in flight (see enc_head_bwd_kernel)
+                float v[8];
 #pragma unroll
-                for (int k = 0; k < NZC; ++k) acc[k] = fmaf(v, k < kn ? zb[k] : 0.f, acc[k]);
+                for (int u = 0; u < 8; ++u) v[u] = col[(long)(b0 + u < B ? b0 + u : 0) * cs];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (b0 + u < B) {
+                        tot += v[u];
+                        const float* zb = sz + (b0 + u) * nz + k0;
+#pragma unroll
+                        for (int k = 0; k < NZC; ++k) acc[k] = fmaf(v[u], k < kn ? zb[k] : 0.f, acc[k]);
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < NZC; ++k)
@@ -242,11 +261,19 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
             float acc[DZ_BC / 8];
 #pragma unroll
             for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = 0.f;
-            for (int rr = 0; rr < nrows; ++rr) {
-                const int row = row0 + rr;
-                const float wv = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
+            for (int r0 = 0; r0 < nrows; r0 += 8) {
+                float wv[8];
 #pragma unroll
-                for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = fmaf(sdv[(bg + 8 * q) * DZ_ROWS + rr], wv, acc[q]);
+                for (int u = 0; u < 8; ++u) {
+                    const int row = row0 + (r0 + u < nrows ? r0 + u : 0);
+                    wv[u] = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float w1 = r0 + u < nrows ? wv[u] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = fmaf(sdv[(bg + 8 * q) * DZ_ROWS + (r0 + u < nrows ? r0 + u : 0)], w1, acc[q]);
+                }
             }
 #pragma unroll
             for (int q = 0; q < DZ_BC / 8; ++q) {

@@ -194,16 +194,17 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
 // rec[b] = sum_t nll[t][b] (one wave per sequence, as vae_loss_kernel), loss[b] = rec[b] + w*kl[b],
 // acc[0..2] += sum_b (loss, rec, kl) (the running sums text.py:381,426-427 read), and the backward seeds of
 // mean_b(loss_b): rowscale[b] = g_loss[b], dkl[b] = w*g_loss[b].
-__global__ __launch_bounds__(256) void loss_assemble_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
+constexpr int LA_WAVES = 16;
+__global__ __launch_bounds__(64 * LA_WAVES) void loss_assemble_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
                                                             const float* __restrict__ klw, const float* __restrict__ g_loss,
                                                             float* __restrict__ loss, float* __restrict__ rec,
                                                             float* __restrict__ rowscale, float* __restrict__ dkl,
                                                             float* __restrict__ acc, int T, int B) {
-    __shared__ float red[3][4];
+    __shared__ float red[3][LA_WAVES];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const float kw = klw[0];
     float sl = 0.f, sr = 0.f, sk = 0.f;
-    for (int b = w; b < B; b += 4) {
+    for (int b = w; b < B; b += LA_WAVES) {
         float s = 0.f;
         for (int t = l; t < T; t += 64) s += nll[(long)t * B + b];
         s = lv_wave_sum(s);
@@ -216,7 +217,11 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(const float* __restr
     }
     if (l == 0) { red[0][w] = sl; red[1][w] = sr; red[2][w] = sk; }
     __syncthreads();
-    if (tid < 3) acc[tid] += (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+    if (tid < 3) {
+        float t = 0.f;
+        for (int i = 0; i < LA_WAVES; ++i) t += red[tid][i];
+        acc[tid] += t;
+    }
 }
 
 // upstream grads (each may be null) -> per-row scales used by the backward kernels
@@ -361,8 +366,8 @@ extern "C" int lv_loss_assemble_f32(const float* nll, const float* kl, const flo
                                     void* stream) {
     if (!nll || !kl || !kl_weight_dev || !g_loss || !loss || !rec || !rowscale || !dkl || !acc) return LV_ERR_ARG;
     if (T < 0 || B <= 0) return LV_ERR_SHAPE;
-    LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(256), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale, dkl,
-              acc, T, B);
+    LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(64 * LA_WAVES), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale,
+              dkl, acc, T, B);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
