@@ -51,6 +51,7 @@ def _oracle_vs_hip(device, V, ni, H, nz, B, T, klw, seed, head_scale=0.2, scale=
     dict(V=1004, ni=50, H=50, nz=1, B=16, T=12, klw=1.0, seed=3),            # toy.py dims, scalar z
     dict(V=5000, ni=128, H=256, nz=32, B=128, T=30, klw=0.5, seed=4),        # stress batch size
     dict(V=300, ni=32, H=64, nz=8, B=130, T=6, klw=0.5, seed=5),             # B > 128: two batch chunks
+    dict(V=200, ni=16, H=32, nz=32, B=256, T=5, klw=0.5, seed=6),            # beyond the fused head / tail kernels' LDS budget
 ])
 def test_fused_step_matches_oracle(hip_device, cfg):
     out, _ = _oracle_vs_hip(hip_device, **cfg)

@@ -310,11 +310,19 @@ __device__ __forceinline__ uint4 load_chunk_masked(const uint16_t* __restrict__ 
 }
 
 typedef uint4 LdsTile[BT][NCH];
+template <bool SINGLE> struct SecondPair { LdsTile a, b; };
+template <> struct SecondPair<true> { int unused; };
 
+// SINGLE = false: two buffer pairs (64 KB, 2 workgroups per CU), the DMA of tile k+1 runs under the MFMAs of tile k -- best
+// for long K loops (dO: 384 vs 478 us).  SINGLE = true: one pair (32 KB, 3 workgroups per CU), load -> barrier -> MFMA ->
+// barrier with the other workgroups hiding the transfer -- best when a workgroup only sees a few K tiles and prologue /
+// epilogue dominate (Gx, K = 512: 55 vs 63 us; dX under split-K: 55 vs 60 us).  Measured: profiles/r02e_gemm_shapes.txt.
+template <bool SINGLE>
 __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
-    // four separate LDS objects: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove disjoint
-    // (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
-    __shared__ __attribute__((aligned(1024))) LdsTile As0, As1, Bs0, Bs1;
+    // separate LDS objects per buffer: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove
+    // disjoint (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
+    __shared__ __attribute__((aligned(1024))) LdsTile As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) SecondPair<SINGLE> second;
 
     const int nblk = p.tilesM * p.tilesN;
     const int bid = (int)blockIdx.x;
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
     const int bx0 = (brow >> 1) & 7, bx1 = ((brow + 32) >> 1) & 7;
     // 16 MFMAs over the K tile in (Ac, Bc), then the hand-over: this wave's DMA into the other pair has landed
     // (vmcnt(0)), everybody's has and everybody is done reading this pair (barrier)
-    auto mma_tile = [&](LdsTile& Ac, LdsTile& Bc) {
+    auto mma_tile = [&](LdsTile& Ac, LdsTile& Bc, bool hand_over = true) {
         uint4 fa[2][2], fb[2][2];
         {
             const int c = lh;
@@ -408,12 +416,23 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
         }
-        LV_WAIT_VMEM();
+        if (hand_over) LV_WAIT_VMEM();
         __syncthreads();
     };
 
     const int ntiles = kt1 - kt0;                                    // K tiles of this workgroup; tile i lives in pair i & 1
     const int nmain = (kt1 < nfull ? kt1 : nfull) - kt0;             // ... of which the first nmain are complete
+    if constexpr (SINGLE) {
+    for (int i = 0; i < ntiles; ++i) {
+        if (i < nmain) stage_dma(kt0 + i, As0, Bs0);
+        else stage_ragged(kt0 + i, As0, Bs0);
+        LV_WAIT_VMEM();
+        __syncthreads();
+        mma_tile(As0, Bs0, false);
+    }
+    } else {
+    LdsTile& As1 = second.a;
+    LdsTile& Bs1 = second.b;
     if (ntiles > 0) {
         if (nmain > 0) stage_dma(kt0, As0, Bs0);
         else stage_ragged(kt0, As0, Bs0);
@@ -442,6 +461,8 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
             else if (nx < ntiles) stage_ragged(kt0 + nx, As0, Bs0);
             mma_tile(As1, Bs1);
         }
+    }
+
     }
 
     const bool split = p.splits > 1;
@@ -562,7 +583,8 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     p.splits = splits;
     dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
     if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
-    else if (LV_B16_GLDS) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel, grid, block, 0, stream, p);
+    else if (LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<false>, grid, block, 0, stream, p);
+    else if (LV_B16_GLDS) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<true>, grid, block, 0, stream, p);
     else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
     if (splits > 1)
         LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);

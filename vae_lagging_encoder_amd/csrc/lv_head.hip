@@ -64,223 +64,197 @@ __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restri
 }
 
 // ---- encoder head backward: dmulv from (dz, dKL); dh_T = dmulv . W_lin ; dW_lin = dmulv^T . h_T --------------------------
-// grid (ceil(H/64), SLICES): a workgroup covers 64 columns h; the B + 2nz output rows (dh_T rows, then dW_lin rows) are
-// dealt round-robin to SLICES x 4 workers.  dz may arrive as `parts` partial sums [parts][B][ns][nz] (lv_dec_tail_bwd).
-constexpr int HB_SLICES = 8;
+// grid ceil(H/64): a workgroup covers 64 columns h.  Everything it needs -- dmulv [B][2nz], the W_lin columns [2nz][64]
+// and the h_T columns [B][64] -- is staged in LDS with fully parallel loads first; the dot products then run out of LDS
+// (a thread that walks a runtime-length loop of global load -> fma pairs pays one memory round trip per iteration: the
+// first versions of these kernels took 60-250 us that way).  dz may arrive as `parts` partial sums [parts][B][ns][nz].
+template <int HB_COLS>
 __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps,
                                                            const float* __restrict__ dz, int parts, const float* __restrict__ dkl,
                                                            const float* __restrict__ hT, const float* __restrict__ wlin,
                                                            float* __restrict__ dmulv, float* __restrict__ dhT,
                                                            float* __restrict__ gwlin, int B, int H, int ns, int nz) {
     LV_DYN_SHARED(smem);
-    float* sd = reinterpret_cast<float*>(smem);           // [B][2nz] dmulv
-    const int tid = (int)threadIdx.x;
     const int nz2 = 2 * nz;
+    float* sd = reinterpret_cast<float*>(smem);           // [B][2nz]   dmulv
+    float* sw = sd + B * nz2;                             // [2nz][64]  W_lin columns of this block
+    float* shh = sw + nz2 * HB_COLS;                      // [B][64]    h_T columns of this block
+    const int tid = (int)threadIdx.x;
+    const int h0 = (int)blockIdx.x * HB_COLS;
     const long pstride = (long)B * ns * nz;
+    for (int i = tid; i < nz2 * HB_COLS; i += 256) {
+        const int j = i / HB_COLS, c = i % HB_COLS;
+        sw[i] = h0 + c < H ? wlin[(long)j * H + h0 + c] : 0.f;
+    }
+    for (int i = tid; i < B * HB_COLS; i += 256) {
+        const int bb = i / HB_COLS, c = i % HB_COLS;
+        shh[i] = h0 + c < H ? hT[(long)bb * H + h0 + c] : 0.f;
+    }
     for (int i = tid; i < B * nz; i += 256) {
-        const int b = i / nz, j = i % nz;
-        const float m = mulv[(long)b * nz2 + j], lv = mulv[(long)b * nz2 + nz + j];
+        const int bb = i / nz, j = i % nz;
+        const float m = mulv[(long)bb * nz2 + j], lv = mulv[(long)bb * nz2 + nz + j];
         const float sdv = expf(0.5f * lv);
         float gz = 0.f, gze = 0.f;
         for (int s = 0; s < ns; ++s) {
-            const long zi = ((long)b * ns + s) * nz + j;
+            const long zi = ((long)bb * ns + s) * nz + j;
             float g = 0.f;
-            for (int q = 0; q < parts; ++q) g += dz[q * pstride + zi];
+            for (int q0 = 0; q0 < parts; q0 += 8) {       // the partial sums, 8 loads in flight, summed in order
+                float pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pv[u] = q0 + u < parts ? dz[(q0 + u) * pstride + zi] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g += pv[u];
+            }
             gz += g;
             gze += g * eps[zi];
         }
-        const float gk = dkl[b];
+        const float gk = dkl[bb];
         const float dm = gz + gk * m, dl = gze * (0.5f * sdv) + gk * (0.5f * (expf(lv) - 1.f));
-        sd[b * nz2 + j] = dm;
-        sd[b * nz2 + nz + j] = dl;
-        if (blockIdx.x == 0 && blockIdx.y == 0) { dmulv[(long)b * nz2 + j] = dm; dmulv[(long)b * nz2 + nz + j] = dl; }
+        sd[bb * nz2 + j] = dm;
+        sd[bb * nz2 + nz + j] = dl;
+        if (blockIdx.x == 0) { dmulv[(long)bb * nz2 + j] = dm; dmulv[(long)bb * nz2 + nz + j] = dl; }
     }
     __syncthreads();
-    const int h = (int)blockIdx.x * 64 + (tid & 63);
-    if (h >= H) return;
-    const int worker = (int)blockIdx.y * 4 + (tid >> 6);
-    // Loads are issued in batches of 8 with a compile-time trip count: a thread that walks a runtime-length loop of
-    // load -> fma pairs pays one memory round trip per iteration (the first version of this kernel took 66 us that way).
-    for (int r = worker; r < B + nz2; r += HB_SLICES * 4) {
+    const int c = tid % HB_COLS, g4 = tid / HB_COLS;
+    if (h0 + c >= H) return;
+    for (int r = g4; r < B + nz2; r += 256 / HB_COLS) {
         float s0 = 0.f, s1 = 0.f;
         if (r < B) {                                      // dh_T[r][h] = sum_j dmulv[r][j] W_lin[j][h]
-            for (int j0 = 0; j0 < nz2; j0 += 8) {
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = wlin[(long)(j0 + u < nz2 ? j0 + u : 0) * H + h];
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    s0 = fmaf(j0 + u < nz2 ? sd[r * nz2 + j0 + u] : 0.f, wv[u], s0);
-                    s1 = fmaf(j0 + u + 1 < nz2 ? sd[r * nz2 + j0 + u + 1] : 0.f, wv[u + 1], s1);
-                }
+            int j = 0;
+            for (; j + 1 < nz2; j += 2) {
+                s0 = fmaf(sd[r * nz2 + j], sw[j * HB_COLS + c], s0);
+                s1 = fmaf(sd[r * nz2 + j + 1], sw[(j + 1) * HB_COLS + c], s1);
             }
-            dhT[(long)r * H + h] = s0 + s1;
+            if (j < nz2) s0 = fmaf(sd[r * nz2 + j], sw[j * HB_COLS + c], s0);
+            dhT[(long)r * H + h0 + c] = s0 + s1;
         } else {                                          // dW_lin[j][h] = sum_b dmulv[b][j] h_T[b][h]
             const int j = r - B;
-            for (int b0 = 0; b0 < B; b0 += 8) {
-                float hv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) hv[u] = hT[(long)(b0 + u < B ? b0 + u : 0) * H + h];
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    s0 = fmaf(b0 + u < B ? sd[(b0 + u) * nz2 + j] : 0.f, hv[u], s0);
-                    s1 = fmaf(b0 + u + 1 < B ? sd[(b0 + u + 1) * nz2 + j] : 0.f, hv[u + 1], s1);
-                }
+            int bb = 0;
+            for (; bb + 1 < B; bb += 2) {
+                s0 = fmaf(sd[bb * nz2 + j], shh[bb * HB_COLS + c], s0);
+                s1 = fmaf(sd[(bb + 1) * nz2 + j], shh[(bb + 1) * HB_COLS + c], s1);
             }
-            gwlin[(long)j * H + h] = s0 + s1;
+            if (bb < B) s0 = fmaf(sd[bb * nz2 + j], shh[bb * HB_COLS + c], s0);
+            gwlin[(long)j * H + h0 + c] = s0 + s1;
         }
     }
 }
 
 // ---- decoder initial state and the z-part of its input projection ------------------------------------------------------
-// thread n < H: c0[b][n] = z[b] . W_trans[n], h0 = tanh(c0); thread H + n', n' < 4H: Zp[b][n'] = z[b] . W_ih[n'][col0:] + b_ih + b_hh
-// (written gate-major, or unit-major 4u+g when unit_major != 0).  z staged in LDS; a thread keeps (a 32-wide chunk of) its
-// weight row in registers and walks the batch.
-constexpr int NZC = 32;      // latent chunk held in registers
+// rows n < H of the stacked weight [W_trans ; W_ih[:, col0:]]: c0[b][n] = z[b] . W_trans[n], h0 = tanh(c0); rows H + n', n' < 4H:
+// Zp[b][n'] = z[b] . W_ih[n'][col0:] + b_ih + b_hh (written gate-major, or unit-major 4u+g when unit_major != 0).
+// A workgroup takes DI_ROWS stacked rows: their weights ([rows][nz]) and z ([B][nz]) are staged in LDS with parallel loads;
+// thread = (row, batch quarter) then runs nz-long dots out of LDS (row pitch nz + 1: conflict-free across rows).
+constexpr int DI_ROWS = 64;
 __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__ z, const float* __restrict__ wtr,
                                                        const float* __restrict__ wih, long ld_wih, int col0,
                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
                                                        float* __restrict__ c0, float* __restrict__ h0, float* __restrict__ zp,
                                                        int unit_major, int B, int H, int nz) {
     LV_DYN_SHARED(smem);
+    const int pw = nz + 1;
     float* sz = reinterpret_cast<float*>(smem);           // [B][nz]
+    float* swt = sz + B * nz;                             // [DI_ROWS][nz + 1]
     const int tid = (int)threadIdx.x;
+    const int n0 = (int)blockIdx.x * DI_ROWS;
     for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
+    for (int i = tid; i < DI_ROWS * nz; i += 256) {
+        const int rr = i / nz, k = i % nz, n = n0 + rr;
+        float v = 0.f;
+        if (n < 5 * H) v = n < H ? wtr[(long)n * nz + k] : wih[(long)(n - H) * ld_wih + col0 + k];
+        swt[rr * pw + k] = v;
+    }
     __syncthreads();
-    const int n = (int)blockIdx.x * 256 + tid;
+    const int rr = tid & 63, bq = tid >> 6;
+    const int n = n0 + rr;
     if (n >= 5 * H) return;
     const bool init = n < H;
     const int r = init ? n : n - H;
-    const float* wrow = init ? wtr + (long)r * nz : wih + (long)r * ld_wih + col0;
     const float bias = init ? 0.f : bih[r] + bhh[r];
     long ocol = r;
     if (!init && unit_major) ocol = 4L * (r % H) + r / H;
-    float* orow = init ? c0 + r : zp + ocol;
-    const long ostride = init ? (long)H : 4L * H;
-    const bool one_chunk = nz <= NZC;
-    for (int k0 = 0; k0 < nz; k0 += NZC) {
-        const int kn = nz - k0 < NZC ? nz - k0 : NZC;
-        float wr[NZC];
-#pragma unroll
-        for (int k = 0; k < NZC; ++k) wr[k] = wrow[k0 + (k < kn ? k : 0)];
-        for (int b = 0; b < B; ++b) {
-            const float* zb = sz + b * nz + k0;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < NZC; k += 2) {
-                s0 = fmaf(k < kn ? zb[k] : 0.f, wr[k], s0);
-                s1 = fmaf(k + 1 < kn ? zb[k + 1] : 0.f, wr[k + 1], s1);
-            }
-            const float s = s0 + s1;
-            float* o = orow + (long)b * ostride;
-            if (k0 == 0) *o = s + bias;
-            else *o += s;
-            if (init && one_chunk) h0[(long)b * H + r] = tanhf(s);
-        }
+    const float* wr = swt + rr * pw;
+    for (int b = bq; b < B; b += 4) {
+        const float* zb = sz + b * nz;
+        float s0 = 0.f, s1 = 0.f;
+        int k = 0;
+        for (; k + 1 < nz; k += 2) { s0 = fmaf(zb[k], wr[k], s0); s1 = fmaf(zb[k + 1], wr[k + 1], s1); }
+        if (k < nz) s0 = fmaf(zb[k], wr[k], s0);
+        const float sv = s0 + s1;
+        if (init) { c0[(long)b * H + r] = sv; h0[(long)b * H + r] = tanhf(sv); }
+        else zp[(long)b * 4 * H + ocol] = sv + bias;
     }
-    if (init && !one_chunk)
-        for (int b = 0; b < B; ++b) h0[(long)b * H + r] = tanhf(c0[(long)b * H + r]);
 }
 
 // ---- decoder tail of the backward ---------------------------------------------------------------------------------------
-// blocks [0, nA): thread n < 4H: gW_ih[n][col0 + k] = sum_b dGsum[b][n] z[b][k], g_bih[n] = g_bhh[n] = sum_b dGsum[b][n];
-//                 thread 4H + j, j < H: gW_trans[j][k] = sum_b dc0[b][j] z[b][k]
-// blocks [nA, nA + parts): partial dz over a slice of DZ_ROWS contraction rows of the stacked [W_ih[:, col0:] ; W_trans]:
-//                 dzp[part][b][k] = sum_{rows of the slice} d[b][row] W[row][k]   (the consumer sums the parts in order)
-constexpr int DZ_ROWS = 128;
-constexpr int DZ_BC = 32;       // batch rows staged per pass
+// Stacked contraction rows: row < 4H is gate row n (d = dGsum[:, n], weights W_ih[n][col0:]), row 4H + j is unit j
+// (d = dc0[:, j], weights W_trans[j]).  Workgroup `part` takes DZ_ROWS of them, stages d [B][rows], the weights [rows][nz]
+// and z [B][nz] in LDS with parallel loads, then
+//   * weight gradients: out[row][k] = sum_b d[b][row] z[b][k] (gW_ih[:, col0:] / gW_trans) -- lanes run over k, so a row's nz
+//     outputs are one contiguous store -- and the bias gradients g_bih[n] = g_bhh[n] = sum_b d[b][n];
+//   * its partial of dz: dzp[part][b][k] = sum_{rows} d[b][row] W[row][k]   (the consumer sums the parts in order).
+constexpr int DZ_ROWS = 64;
 __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restrict__ dGsum, const float* __restrict__ dc0,
                                                            const float* __restrict__ z, const float* __restrict__ wih,
                                                            long ld_wih, int col0, const float* __restrict__ wtr,
                                                            float* __restrict__ gwih, long ld_gwih, float* __restrict__ gwtr,
                                                            float* __restrict__ gbih, float* __restrict__ gbhh,
-                                                           float* __restrict__ dzp, int nA, int B, int H, int nz) {
+                                                           float* __restrict__ dzp, int B, int H, int nz) {
     LV_DYN_SHARED(smem);
-    float* sm = reinterpret_cast<float*>(smem);
+    const int pd = DZ_ROWS + 1;
+    float* sz = reinterpret_cast<float*>(smem);           // [B][nz]
+    float* sdv = sz + B * nz;                             // [B][DZ_ROWS + 1]
+    float* swt = sdv + B * pd;                            // [DZ_ROWS][nz]
     const int tid = (int)threadIdx.x;
-    if ((int)blockIdx.x < nA) {
-        float* sz = sm;                                   // [B][nz]
-        for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
-        __syncthreads();
-        const int n = (int)blockIdx.x * 256 + tid;
-        if (n >= 5 * H) return;
-        const bool gate = n < 4 * H;
-        const int r = gate ? n : n - 4 * H;
-        const float* col = gate ? dGsum + r : dc0 + r;
-        const long cs = gate ? 4L * H : (long)H;
-        float* orow = gate ? gwih + (long)r * ld_gwih + col0 : gwtr + (long)r * nz;
-        float tot = 0.f;
-        for (int k0 = 0; k0 < nz; k0 += NZC) {
-            const int kn = nz - k0 < NZC ? nz - k0 : NZC;
-            float acc[NZC];
-#pragma unroll
-            for (int k = 0; k < NZC; ++k) acc[k] = 0.f;
-            tot = 0.f;
-            for (int b0 = 0; b0 < B; b0 += 8) {           // 8 column loads in flight (see enc_head_bwd_kernel)
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = col[(long)(b0 + u < B ? b0 + u : 0) * cs];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (b0 + u < B) {
-                        tot += v[u];
-                        const float* zb = sz + (b0 + u) * nz + k0;
-#pragma unroll
-                        for (int k = 0; k < NZC; ++k) acc[k] = fmaf(v[u], k < kn ? zb[k] : 0.f, acc[k]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NZC; ++k)
-                if (k < kn) orow[k0 + k] = acc[k];
-        }
-        if (gate) { gbih[r] = tot; gbhh[r] = tot; }
-        return;
-    }
-    // ---- partial dz: this block's slice of the stacked contraction rows; thread = (latent k = tid & 31, batch lane tid >> 5);
-    // the batch is walked in chunks of DZ_BC rows staged in LDS
-    const int part = (int)blockIdx.x - nA;
+    const int part = (int)blockIdx.x;
     const int row0 = part * DZ_ROWS;
     const int nrows = 5 * H - row0 < DZ_ROWS ? 5 * H - row0 : DZ_ROWS;
-    float* sdv = sm;                                      // [DZ_BC][DZ_ROWS] a chunk of the slice of d = [dGsum | dc0]
-    const int kl = tid & 31, bg = tid >> 5;
-    for (int bc = 0; bc < B; bc += DZ_BC) {
-        const int nb = B - bc < DZ_BC ? B - bc : DZ_BC;
-        __syncthreads();
-        for (int i = tid; i < DZ_BC * DZ_ROWS; i += 256) {
-            const int bl = i / DZ_ROWS, rr = i % DZ_ROWS;
-            const int row = row0 + rr, b = bc + bl;
-            float v = 0.f;
-            if (rr < nrows && bl < nb) v = row < 4 * H ? dGsum[(long)b * 4 * H + row] : dc0[(long)b * H + (row - 4 * H)];
-            sdv[i] = v;
+    for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
+    for (int i = tid; i < B * DZ_ROWS; i += 256) {
+        const int b = i / DZ_ROWS, rr = i % DZ_ROWS, row = row0 + rr;
+        float v = 0.f;
+        if (rr < nrows) v = row < 4 * H ? dGsum[(long)b * 4 * H + row] : dc0[(long)b * H + (row - 4 * H)];
+        sdv[b * pd + rr] = v;
+    }
+    for (int i = tid; i < DZ_ROWS * nz; i += 256) {
+        const int rr = i / nz, k = i % nz, row = row0 + rr;
+        float v = 0.f;
+        if (rr < nrows) v = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
+        swt[i] = v;
+    }
+    __syncthreads();
+    // weight gradients: (row, k) pairs dealt to the threads with k fastest
+    for (int i = tid; i < nrows * nz; i += 256) {
+        const int rr = i / nz, k = i % nz, row = row0 + rr;
+        float s0 = 0.f, s1 = 0.f;
+        int b = 0;
+        for (; b + 1 < B; b += 2) {
+            s0 = fmaf(sdv[b * pd + rr], sz[b * nz + k], s0);
+            s1 = fmaf(sdv[(b + 1) * pd + rr], sz[(b + 1) * nz + k], s1);
         }
-        __syncthreads();
-        for (int k0 = 0; k0 < nz; k0 += 32) {
-            const int k = k0 + kl;
-            if (k >= nz) continue;
-            float acc[DZ_BC / 8];
-#pragma unroll
-            for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = 0.f;
-            for (int r0 = 0; r0 < nrows; r0 += 8) {
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int row = row0 + (r0 + u < nrows ? r0 + u : 0);
-                    wv[u] = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float w1 = r0 + u < nrows ? wv[u] : 0.f;
-#pragma unroll
-                    for (int q = 0; q < DZ_BC / 8; ++q) acc[q] = fmaf(sdv[(bg + 8 * q) * DZ_ROWS + (r0 + u < nrows ? r0 + u : 0)], w1, acc[q]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < DZ_BC / 8; ++q) {
-                const int bl = bg + 8 * q;
-                if (bl < nb) dzp[((long)part * B + bc + bl) * nz + k] = acc[q];
-            }
+        if (b < B) s0 = fmaf(sdv[b * pd + rr], sz[b * nz + k], s0);
+        if (row < 4 * H) gwih[(long)row * ld_gwih + col0 + k] = s0 + s1;
+        else gwtr[(long)(row - 4 * H) * nz + k] = s0 + s1;
+    }
+    for (int rr = tid; rr < nrows; rr += 256) {           // bias gradients (gate rows only)
+        const int row = row0 + rr;
+        if (row < 4 * H) {
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += sdv[b * pd + rr];
+            gbih[row] = t; gbhh[row] = t;
         }
+    }
+    // partial dz: (b, k) pairs dealt to the threads with k fastest
+    for (int i = tid; i < B * nz; i += 256) {
+        const int b = i / nz, k = i % nz;
+        float s0 = 0.f, s1 = 0.f;
+        int rr = 0;
+        for (; rr + 1 < nrows; rr += 2) {
+            s0 = fmaf(sdv[b * pd + rr], swt[rr * nz + k], s0);
+            s1 = fmaf(sdv[b * pd + rr + 1], swt[(rr + 1) * nz + k], s1);
+        }
+        if (rr < nrows) s0 = fmaf(sdv[b * pd + rr], swt[rr * nz + k], s0);
+        dzp[((long)part * B + b) * nz + k] = s0 + s1;
     }
 }
 
@@ -307,10 +281,15 @@ extern "C" int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const fl
                                    int ns, int nz, void* stream) {
     if (!mulv || !eps || !dz || !dkl || !hT || !wlin || !dmulv || !dhT || !gwlin) return LV_ERR_ARG;
     if (B <= 0 || H <= 0 || ns <= 0 || nz <= 0 || dz_parts <= 0) return LV_ERR_SHAPE;
-    const size_t sh = (size_t)B * 2 * nz * sizeof(float);
-    if (sh > 60000) return LV_ERR_UNSUPPORTED;
-    LV_LAUNCH(enc_head_bwd_kernel, dim3((unsigned)lv_cdiv(H, 64), HB_SLICES), dim3(256), sh, stream, mulv, eps, dz, dz_parts, dkl,
-              hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
+    const size_t base = (size_t)B * 2 * nz, per_col = (size_t)2 * nz + B;
+    if ((base + per_col * 64) * sizeof(float) <= 64000)
+        LV_LAUNCH(enc_head_bwd_kernel<64>, dim3((unsigned)lv_cdiv(H, 64)), dim3(256), (base + per_col * 64) * sizeof(float), stream,
+                  mulv, eps, dz, dz_parts, dkl, hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
+    else if ((base + per_col * 16) * sizeof(float) <= 64000)
+        LV_LAUNCH(enc_head_bwd_kernel<16>, dim3((unsigned)lv_cdiv(H, 16)), dim3(256), (base + per_col * 16) * sizeof(float), stream,
+                  mulv, eps, dz, dz_parts, dkl, hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
+    else
+        return LV_ERR_UNSUPPORTED;
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -323,9 +302,9 @@ extern "C" int lv_dec_init_f32(const float* z, const float* wtr, const float* wi
                                void* stream) {
     if (!z || !wtr || !wih || !bih || !bhh || !c0 || !h0 || !zp) return LV_ERR_ARG;
     if (B <= 0 || H <= 0 || nz <= 0 || ld_wih < col0 + nz) return LV_ERR_SHAPE;
-    const size_t sh = (size_t)B * nz * sizeof(float);
-    if (sh > 60000) return LV_ERR_UNSUPPORTED;
-    LV_LAUNCH(dec_init_kernel, dim3((unsigned)lv_cdiv(5L * H, 256)), dim3(256), sh, stream, z, wtr, wih, ld_wih, col0, bih, bhh,
+    const size_t sh = ((size_t)B * nz + (size_t)DI_ROWS * (nz + 1)) * sizeof(float);
+    if (sh > 64000) return LV_ERR_UNSUPPORTED;
+    LV_LAUNCH(dec_init_kernel, dim3((unsigned)lv_cdiv(5L * H, DI_ROWS)), dim3(256), sh, stream, z, wtr, wih, ld_wih, col0, bih, bhh,
               c0, h0, zp, unit_major, B, H, nz);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -343,13 +322,11 @@ extern "C" int lv_dec_tail_bwd_f32(const float* dGsum, const float* dc0, const f
                                    float* dz_parts, int B, int H, int nz, void* stream) {
     if (!dGsum || !dc0 || !z || !wih || !wtr || !gwih || !gwtr || !gbih || !gbhh || !dz_parts) return LV_ERR_ARG;
     if (B <= 0 || H <= 0 || nz <= 0 || ld_wih < col0 + nz || ld_gwih < col0 + nz) return LV_ERR_SHAPE;
-    size_t sh = (size_t)B * nz * sizeof(float);
-    if (sh > 60000) return LV_ERR_UNSUPPORTED;
-    if (sh < (size_t)DZ_BC * DZ_ROWS * sizeof(float)) sh = (size_t)DZ_BC * DZ_ROWS * sizeof(float);
-    const int nA = lv_cdiv(5L * H, 256);
+    const size_t sh = ((size_t)B * nz + (size_t)B * (DZ_ROWS + 1) + (size_t)DZ_ROWS * nz) * sizeof(float);
+    if (sh > 64000) return LV_ERR_UNSUPPORTED;
     const int parts = lv_cdiv(5L * H, DZ_ROWS);
-    LV_LAUNCH(dec_tail_bwd_kernel, dim3((unsigned)(nA + parts)), dim3(256), sh, stream, dGsum, dc0, z, wih, ld_wih, col0, wtr, gwih,
-              ld_gwih, gwtr, gbih, gbhh, dz_parts, nA, B, H, nz);
+    LV_LAUNCH(dec_tail_bwd_kernel, dim3((unsigned)parts), dim3(256), sh, stream, dGsum, dc0, z, wih, ld_wih, col0, wtr, gwih,
+              ld_gwih, gwtr, gbih, gbhh, dz_parts, B, H, nz);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

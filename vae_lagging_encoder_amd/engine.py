@@ -474,7 +474,11 @@ class LSTMEncoderEngine(object):
                   prec=self.precision, **biases)
         with _prof("lstm_fwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
             _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
-        if head is not None:
+        if head is not None and not fused_ends_ok(B, nz2 // 2, head[0].shape[1]):
+            eps, z, kl = head
+            _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
+            lib.lv_reparam_kl_fwd_f32(P(w.mulv), P(eps), P(z), P(kl), B, eps.shape[1], nz2 // 2, s)
+        elif head is not None:
             eps, z, kl = head
             lib.lv_enc_head_fwd_f32(P(w.hs, T * B * H), P(v["linear.weight"]), P(eps), P(w.mulv), P(z), P(kl), B, H,
                                     eps.shape[1], nz2 // 2, s)
@@ -498,7 +502,13 @@ class LSTMEncoderEngine(object):
         V, ni, H, nz2 = self.dims()
         w = self._ws(B, T)
         v, gv = f.views, f.gviews
-        if head is not None:
+        if head is not None and not fused_ends_ok(B, nz2 // 2, head[0].shape[1]):
+            eps, dz, parts, dkl = head
+            assert parts == 1
+            lib.lv_reparam_kl_bwd_f32(P(w.mulv), P(eps), P(dz), P(dkl), P(w.dmulv), B, eps.shape[1], nz2 // 2, s)
+            _gemm(lib, s, 0, 0, B, H, nz2, P(w.dmulv), nz2, P(v["linear.weight"]), H, P(w.dhT), H)
+            _gemm(lib, s, 1, 0, nz2, H, B, P(w.dmulv), nz2, P(w.hs, T * B * H), H, P(gv["linear.weight"]), H)
+        elif head is not None:
             eps, dz, parts, dkl = head
             lib.lv_enc_head_bwd_f32(P(w.mulv), P(eps), P(dz), parts, P(dkl), P(w.hs, T * B * H), P(v["linear.weight"]), P(w.dmulv),
                                     P(w.dhT), P(gv["linear.weight"]), B, H, eps.shape[1], nz2 // 2, s)
@@ -702,11 +712,21 @@ class LSTMDecoderEngine(object):
         # Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised) -- one launch
         wih = v["lstm.weight_ih_l0"]
         img = self._lstm_images(B, Td)
-        lib.lv_dec_init_f32(P(z2), P(v["trans_linear.weight"]), P(wih), ni + nz, ni, P(v["lstm.bias_ih_l0"]),
-                            P(v["lstm.bias_hh_l0"]), P(w.cs), P(w.hs), P(w.Zp), 1 if img is not None else 0, B, H, nz, s)
+        fused = fused_ends_ok(B, nz)
+        if fused:
+            lib.lv_dec_init_f32(P(z2), P(v["trans_linear.weight"]), P(wih), ni + nz, ni, P(v["lstm.bias_ih_l0"]),
+                                P(v["lstm.bias_hh_l0"]), P(w.cs), P(w.hs), P(w.Zp), 1 if img is not None else 0, B, H, nz, s)
+        else:
+            _gemm(lib, s, 0, 1, B, H, nz, P(z2), nz, P(v["trans_linear.weight"]), nz, P(w.cs), H)
+            lib.lv_tanh_f32(P(w.cs), P(w.hs), B * H, s)
+            _gemm(lib, s, 0, 1, B, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
+                  add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
             wi = self.refresh_weight_images(B, x.device)
-            img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), None, None, B, self.wsc, addend_um=P(w.Zp))
+            if fused:
+                img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), None, None, B, self.wsc, addend_um=P(w.Zp))
+            else:
+                img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), P(w.Zp), None, B, self.wsc)
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
@@ -780,6 +800,13 @@ class LSTMDecoderEngine(object):
             lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
                                      V - 1, 0, s2)
         self._mark_pending(dev)
+        if not fused_ends_ok(B, nz):
+            _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
+            lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
+            _gemm(lib, s, 0, 0, B, nz, 4 * H, P(w.dGsum), 4 * H, P(wih, ni), ni + nz, P(w.dz), nz)
+            _gemm(lib, s, 0, 0, B, nz, H, P(w.dc0), H, P(v["trans_linear.weight"]), nz, P(w.dz), nz, acc=1)
+            _gemm(lib, s, 1, 0, H, nz, B, P(w.dc0), H, P(z2), nz, P(gv["trans_linear.weight"]), nz)
+            return (w.dz, 1) if partial_dz else w.dz
         # batch-sized tail in one launch (critical path: dz feeds the encoder's backward): the z-columns of dW_ih, both
         # bias gradients, dW_trans, and dz = dGsum . W_ih[:, ni:] + dc0 . W_trans
         lib.lv_dec_tail_bwd_f32(P(w.dGsum), P(w.dc0), P(z2), P(wih), ni + nz, ni, P(v["trans_linear.weight"]), P(gwih), ni + nz,
@@ -789,6 +816,12 @@ class LSTMDecoderEngine(object):
             return w.dzp, w.dz_parts         # the fused driver's encoder head sums the parts itself
         lib.lv_colsum_f32(P(w.dzp), B * nz, w.dz_parts, B * nz, P(w.dz), None, s)
         return w.dz
+
+
+def fused_ends_ok(B, nz, ns=1):
+    """LDS budgets of lv_head.hip (64 KB of dynamic LDS): encoder head (B*2nz + 16*(2nz + B) floats at the narrowest column
+    block), decoder init / tail (B*nz + B*65 + 64*nz floats).  Beyond them the engines use the GEMM-based sequences."""
+    return (B * 2 * nz + 16 * (2 * nz + B)) * 4 <= 64000 and (B * nz + B * 65 + 64 * (nz + 1)) * 4 <= 64000 and ns >= 1
 
 
 def reparam_kl_forward(mulv, eps):
