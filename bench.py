@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the f32 parity side run (profiling passes: only the timed arithmetic runs)")
     ap.add_argument("--persistent", type=int, default=1, help="forward LSTM recurrences as one persistent launch (bf16 path)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="decoder weight-gradient GEMMs on a side stream under the BPTT chains (auto: on for f32, off for bf16)")
@@ -354,7 +355,7 @@ def main():
                            "frac": round(step_flops / step_s / 1e12 / peak_mfma, 4),
                            "traffic": None, "note": "whole-step algorithmic flops (graph replay: no per-kernel events)"}
 
-    if world == 1 and args.dtype != "f32" and not args.graph and not stress:
+    if world == 1 and args.dtype != "f32" and not args.graph and not stress and not args.no_side_runs:
         # the exact-f32 parity path on the same workload (short run, same process) for the record
         tr.enc.precision = tr.dec.precision = "f32"
         for _ in range(2):

@@ -38,9 +38,10 @@ def main(fetch_csv, write_csv):
         print("%-100s %8d %16.3f %16.3f %16.3f" % (n[:100], max(nf, nw), rd, wr, rd + wr))
 
 
-def groups(fetch_csv, write_csv):
-    """Launch-weighted HBM MB per launch of the two kernel groups bench.py reports, split by precision:
-    bf16 = lstm_step_*<..., true> + lv_gemm_b16_kernel; f32 = lstm_step_*<..., false> / <KS> + lv_gemm_f32_kernel<*, *, 2>."""
+def groups(fetch_csv, write_csv, steps=None):
+    """Launch-weighted HBM MB per launch of the kernel groups bench.py reports, split by precision:
+    bf16 = lstm_step_*<..., true> / lstm_*_persist_kernel + lv_gemm_b16*; f32 = lstm_step_*<..., false> + lv_gemm_f32_kernel<*, *, 2>.
+    steps: inner steps the profiled command ran (timed + warm-up) -> whole-step GB over ALL kernels."""
     f = load(fetch_csv, "FETCH_SIZE")
     w = load(write_csv, "WRITE_SIZE")
 
@@ -53,23 +54,27 @@ def groups(fetch_csv, write_csv):
             nw, vw = w.get(name, [0, 0.0])
             tot += (vf * 1024 * 2 + vw * 1024) / 1e6
             n += max(nf, nw)
-        return round(tot / max(n, 1), 3), n
+        return round(tot / max(n, 1), 3), n, tot
     is_lstm = lambda n: "lstm_step_" in n
     is_pers = lambda n: "lstm_fwd_persist_kernel" in n or "lstm_bwd_persist_kernel" in n
     bf = lambda n: "true>" in n
     out = {
         "bf16": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and bf(n))[0],
                  "lstm_persist_MB_per_launch": mb(is_pers)[0],
-                 "gemm_MB_per_launch": mb(lambda n: "lv_gemm_b16_kernel" in n)[0]},
+                 "lstm_fwd_persist_MB_per_launch": mb(lambda n: "lstm_fwd_persist_kernel" in n)[0],
+                 "lstm_bwd_persist_MB_per_launch": mb(lambda n: "lstm_bwd_persist_kernel" in n)[0],
+                 "gemm_MB_per_launch": mb(lambda n: "lv_gemm_b16" in n)[0]},
         "f32": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and not bf(n))[0],
                 "gemm_MB_per_launch": mb(lambda n: "lv_gemm_f32_kernel" in n and ", 2>" in n)[0]},
     }
+    if steps:
+        out["bf16"]["whole_step_GB"] = round(mb(lambda n: True)[2] / 1e3 / steps, 3)
     return out
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "--json":
         import json
-        print(json.dumps(groups(sys.argv[1], sys.argv[2]), indent=1))
+        print(json.dumps(groups(sys.argv[1], sys.argv[2], int(sys.argv[4]) if len(sys.argv) > 4 else None), indent=1))
     else:
         main(sys.argv[1], sys.argv[2])

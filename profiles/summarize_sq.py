@@ -2,8 +2,10 @@
 
     python profiles/summarize_sq.py <counter_collection.csv>
 
-MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) (the gfx94x derived-metric formula; ROCm 7.2
-ships no gfx950 section, /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots").  SQ_WAVE_CYCLES / SQ_WAIT_* /
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): the gfx94x derived-metric formula (ROCm 7.2
+ships no gfx950 section, /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots") with GRBM_GUI_ACTIVE divided by the 8
+XCC instances rocprofv3 sums it over (calibration: lv_gemm_b16_nt_glds at 690 TFLOP/s = 27.6 % of the 2.5 PF peak reads 24.8 %
+this way, 3.1 % without the division).  SQ_WAVE_CYCLES / SQ_WAIT_* /
 SQ_ACTIVE_INST_* count quad-cycles and are reported as shares of SQ_WAVE_CYCLES (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY
 ~ WAVE_CYCLES).
 """
@@ -24,7 +26,7 @@ def main(path):
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         wc = c.get("SQ_WAVE_CYCLES", 0.0)
         rows.append((gui, k, max(n[k].values()),
-                     100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 256 * 4) if gui else 0.0,
+                     100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 256 * 4) if gui else 0.0,
                      100.0 * c.get("SQ_WAIT_ANY", 0.0) / wc if wc else 0.0,
                      100.0 * c.get("SQ_WAIT_INST_ANY", 0.0) / wc if wc else 0.0,
                      100.0 * c.get("SQ_WAIT_INST_LDS", 0.0) / wc if wc else 0.0,

@@ -33,7 +33,9 @@ def _worker(rank, world, port, name, mode, q):
         per = B // world
         sl = slice(rank * per, (rank + 1) * per)
         vae = build_vae(V, ni, H, nz, "cpu", params=fixture_params(fx))
-        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, grad_sync=GradSync(mode=mode))
+        mode, decoder = mode.split("/")
+        gs = GradSync(mode=mode, decoder=decoder)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, grad_sync=gs)
         x = torch.from_numpy(fx["x"])[sl].contiguous()
         noise = (torch.from_numpy(fx["eps"])[sl].contiguous(), torch.from_numpy(fx["mask_in"])[sl].contiguous(),
                  torch.from_numpy(fx["mask_out"])[sl].contiguous())
@@ -41,6 +43,11 @@ def _worker(rank, world, port, name, mode, q):
         st = tr.read_stats()
         sd = vae.state_dict()
         errs = {k: float((sd[k] - torch.from_numpy(fx["new/" + k])).abs().max() / np.abs(fx["new/" + k]).max()) for k in ENC_KEYS}
+        # what the exchange left in the decoder's .grad: the global mean gradient (allreduce) or the local one (norm)
+        dec_g = vae.decoder.pred_linear.weight.grad
+        ref_g = torch.from_numpy(fx["grad/decoder.pred_linear.weight"]) * float(fx["coef"])
+        errs["_dec_grad_is_global"] = float((dec_g - ref_g).abs().max() / ref_g.abs().max())
+        errs["_bytes"] = gs.bytes_per_step(tr.enc.flat, tr.dec.flat)
         q.put((rank, st["norm"], st["loss_sum"], errs, None))
         dist.destroy_process_group()
     except Exception as e:  # noqa
@@ -48,8 +55,9 @@ def _worker(rank, world, port, name, mode, q):
         q.put((rank, None, None, None, traceback.format_exc()))
 
 
+@pytest.mark.parametrize("decoder", ["norm", "allreduce"])
 @pytest.mark.parametrize("name", ["text_small_wide"])
-def test_two_rank_strict_dp_equals_single_process_reference(name):
+def test_two_rank_strict_dp_equals_single_process_reference(name, decoder):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     from build_emu import build_emu
     build_emu()   # build once in the parent
@@ -58,18 +66,25 @@ def test_two_rank_strict_dp_equals_single_process_reference(name):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, "strict", q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, "strict/" + decoder, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    bytes_by_mode = []
     for rank, norm, loss_sum, errs, tb in res:
         assert tb is None, tb
         # every rank sees the GLOBAL clipped norm (fixture has norm > 5: the clip is active)
         assert abs(norm - float(fx["total_norm"])) / float(fx["total_norm"]) < 1e-4
+        glob = errs.pop("_dec_grad_is_global")
+        nbytes = errs.pop("_bytes")
         for k, e in errs.items():
             assert e < 1e-4, (rank, k, e)
+        # "norm": the decoder gradient travelled as a reduce-scatter + one scalar (its .grad stays local, and differs from the
+        # global mean); "allreduce": every replica holds the clipped global mean gradient, as the reference's .grad would
+        assert (glob < 1e-4) == (decoder == "allreduce"), (decoder, glob)
+        bytes_by_mode.append(nbytes)
     # the ranks' local loss sums add up to the reference's batch loss sum
     assert abs(sum(r[2] for r in res) - float(fx["loss"].sum())) / abs(float(fx["loss"].sum())) < 1e-4
 

@@ -90,6 +90,22 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
         const int bb = i / HB_COLS, c = i % HB_COLS;
         shh[i] = h0 + c < H ? hT[(long)bb * H + h0 + c] : 0.f;
     }
+    // dz = sum of the partial sums (in order), staged in LDS first: (element, part) pairs are spread over all threads, 8
+    // loads in flight each, so the pass costs a few memory round trips whatever the part count
+    float* sg = shh + B * HB_COLS;                         // [B*ns*nz] summed dz
+    const int ne = B * ns * nz;
+    for (int e = tid; e < ne; e += 256) {
+        float g = 0.f;
+        for (int q0 = 0; q0 < parts; q0 += 8) {
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = dz[(long)(q0 + u < parts ? q0 + u : 0) * pstride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += q0 + u < parts ? pv[u] : 0.f;
+        }
+        sg[e] = g;
+    }
+    __syncthreads();
     for (int i = tid; i < B * nz; i += 256) {
         const int bb = i / nz, j = i % nz;
         const float m = mulv[(long)bb * nz2 + j], lv = mulv[(long)bb * nz2 + nz + j];
@@ -97,14 +113,7 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
         float gz = 0.f, gze = 0.f;
         for (int s = 0; s < ns; ++s) {
             const long zi = ((long)bb * ns + s) * nz + j;
-            float g = 0.f;
-            for (int q0 = 0; q0 < parts; q0 += 8) {       // the partial sums, 8 loads in flight, summed in order
-                float pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) pv[u] = q0 + u < parts ? dz[(q0 + u) * pstride + zi] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g += pv[u];
-            }
+            const float g = sg[zi];
             gz += g;
             gze += g * eps[zi];
         }
@@ -281,11 +290,8 @@ extern "C" int lv_enc_head_bwd_f32(const float* mulv, const float* eps, const fl
                                    int ns, int nz, void* stream) {
     if (!mulv || !eps || !dz || !dkl || !hT || !wlin || !dmulv || !dhT || !gwlin) return LV_ERR_ARG;
     if (B <= 0 || H <= 0 || ns <= 0 || nz <= 0 || dz_parts <= 0) return LV_ERR_SHAPE;
-    const size_t base = (size_t)B * 2 * nz, per_col = (size_t)2 * nz + B;
-    if ((base + per_col * 64) * sizeof(float) <= 64000)
-        LV_LAUNCH(enc_head_bwd_kernel<64>, dim3((unsigned)lv_cdiv(H, 64)), dim3(256), (base + per_col * 64) * sizeof(float), stream,
-                  mulv, eps, dz, dz_parts, dkl, hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
-    else if ((base + per_col * 16) * sizeof(float) <= 64000)
+    const size_t base = (size_t)B * 2 * nz + (size_t)B * ns * nz, per_col = (size_t)2 * nz + B;
+    if ((base + per_col * 16) * sizeof(float) <= 64000)
         LV_LAUNCH(enc_head_bwd_kernel<16>, dim3((unsigned)lv_cdiv(H, 16)), dim3(256), (base + per_col * 16) * sizeof(float), stream,
                   mulv, eps, dz, dz_parts, dkl, hT, wlin, dmulv, dhT, gwlin, B, H, ns, nz);
     else

@@ -37,15 +37,33 @@ def init_from_env(backend=None):
 
 
 class GradSync(object):
-    """Mean all-reduce of the flat gradient buffers of (encoder, decoder)."""
+    """Gradient exchange of the data-parallel inner loop: mean over ranks of the flat gradient buffers of (encoder, decoder).
 
-    def __init__(self, group=None, mode="strict"):
+    mode "strict": the clip norm spans encoder AND decoder gradients (text.py:385), so both enter the exchange.
+      decoder="allreduce": both flat buffers are mean-all-reduced (66 MB + 149 MB fp32 at the Yahoo shape).
+      decoder="norm" (default where the backend has reduce-scatter): in an ENCODER-ONLY step (text.py:387) the decoder
+        gradient is needed for one number only -- its contribution to the clip norm; the encoder-only step discards it.
+        The decoder buffer is then reduce-scattered (each rank receives 1/P of the summed vector: half the bytes of an
+        all-reduce), every rank takes the sum of squares of its shard of the MEAN gradient, and a scalar all-reduce adds
+        them up: exactly the reference's norm of the global mean gradient, 149 MB -> 75 MB of decoder traffic per step.  The
+        decoder's .grad buffers keep the LOCAL gradient (nobody reads them before the next zero_grad).  Steps that update
+        the decoder (text.py:418-424) all-reduce it in full.
+    mode "encoder_only": only the encoder buffer is exchanged and the local decoder-gradient norm enters the clip norm -- a
+      documented deviation from the reference (replicas stay identical, the clip coefficient differs slightly per step).
+    """
+
+    def __init__(self, group=None, mode="strict", decoder="auto"):
         assert mode in ("strict", "encoder_only")
+        assert decoder in ("auto", "norm", "allreduce")
         self.group = group
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.decoder = decoder
         self._inv = None
+        self._h_dec = None
+        self._shard = None
+        self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
 
     def _scale(self, flat):
         lib = _eng.backend_for(flat.device)
@@ -53,26 +71,75 @@ class GradSync(object):
             self._inv = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.device)
         lib.lv_scale_f32(P(flat.grad), flat.numel, P(self._inv), _eng.stream_ptr(flat.device))
 
-    def start_decoder(self, dec_flat):
+    def _norm_only(self, dec_flat, update):
+        return (self.mode == "strict" and update == "encoder" and self.decoder in ("auto", "norm")
+                and dec_flat.grad_padded.numel() % self.world == 0)
+
+    def start_decoder(self, dec_flat, update="encoder"):
         """Issue the decoder-gradient all-reduce as soon as the decoder's backward has been queued: RCCL runs it on
-        its own stream underneath the encoder's BPTT (strict mode only).  Completed by sync()."""
-        if self.world == 1 or self.mode != "strict":
+        its own stream underneath the encoder's BPTT (strict mode, full all-reduce only).  Completed by sync()."""
+        if self.world == 1 or self.mode != "strict" or self._norm_only(dec_flat, update):
             return
         self._h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def sync(self, enc_flat, dec_flat):
+    def sync(self, enc_flat, dec_flat, update="encoder"):
+        """Exchange the gradients of one step.  Returns None when both buffers now hold the global mean gradient, or a
+        device scalar with the sum of squares of the mean decoder gradient when only that was exchanged (the trainer adds
+        it to the encoder's sum of squares for the clip coefficient)."""
         if self.world == 1:
-            return
-        h_dec = getattr(self, "_h_dec", None)
-        self._h_dec = None
-        if self.mode == "strict" and h_dec is None:
-            h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if h_dec is not None:
-            h_dec.wait()
-            self._scale(dec_flat)
+            return None
+        h_dec, self._h_dec = self._h_dec, None
+        lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
+        ss = None
+        if self._norm_only(dec_flat, update):
+            src = dec_flat.grad_padded
+            n = src.numel() // self.world
+            self.ss_handle(dec_flat, update)
+            h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if dist.get_backend(self.group) == "gloo":
+                # gloo has no reduce-scatter: the CPU tests take the shard out of an all-reduced copy (same sums)
+                tmp = src.clone()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                self._shard.copy_(tmp[self.rank * n:(self.rank + 1) * n])
+            else:
+                dist.reduce_scatter_tensor(self._shard, src, op=dist.ReduceOp.SUM, group=self.group)
+            lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
+            lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
+            dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
+            ss = self._ss
+        else:
+            if self.mode == "strict" and h_dec is None:
+                h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if h_dec is not None:
+                h_dec.wait()
+                self._scale(dec_flat)
         h_enc.wait()
         self._scale(enc_flat)
+        return ss
+
+    def ss_handle(self, dec_flat, update="encoder"):
+        """The device scalar sync() will return for this kind of step (None when it returns None); no communication."""
+        if self.world == 1 or not self._norm_only(dec_flat, update):
+            return None
+        src = dec_flat.grad_padded
+        n = src.numel() // self.world
+        if self._shard is None or self._shard.numel() != n or self._shard.device != src.device:
+            lib = _eng.backend_for(src.device)
+            self._shard = torch.empty(n, dtype=torch.float32, device=src.device)
+            self._ss = torch.zeros(1, dtype=torch.float32, device=src.device)
+            self._ws = torch.empty(lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=src.device)
+            self._inv2 = torch.full((1,), 1.0 / (self.world * self.world), dtype=torch.float32, device=src.device)
+        return self._ss
+
+    def bytes_per_step(self, enc_flat, dec_flat, update="encoder"):
+        """fp32 bytes each rank sends per step (ring algorithms: 2(P-1)/P x buffer for an all-reduce, (P-1)/P for a
+        reduce-scatter) -- for the schedule table in DESIGN.md."""
+        f = (self.world - 1) / max(1, self.world)
+        enc = 2 * f * 4 * enc_flat.numel
+        if self.mode != "strict":
+            return enc
+        return enc + (f if self._norm_only(dec_flat, update) else 2 * f) * 4 * dec_flat.numel
 
     def window_mean(self, loss_sum, num_words):
         """Global mean loss per word of one exit window (text.py:393-396): sum of the ranks' loss sums over the sum of

@@ -71,7 +71,10 @@ class FlatBuffer(object):
         self.numel = off
         self.device = torch.device(device)
         self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # gradients: zero tail padding to a multiple of 1024 elements, so the buffer splits evenly across any power-of-two
+        # world size (reduce-scatter of dist.GradSync); kernels only ever touch [0, numel)
+        self.grad_padded = torch.zeros(_round_up(off, 1024), dtype=torch.float32, device=self.device)
+        self.grad = self.grad_padded[:off]
         self.views, self.gviews = {}, {}
         for n, p in named_params:
             o = self.offsets[n]
@@ -821,7 +824,7 @@ class LSTMDecoderEngine(object):
 def fused_ends_ok(B, nz, ns=1):
     """LDS budgets of lv_head.hip (64 KB of dynamic LDS): encoder head (B*2nz + 16*(2nz + B) floats at the narrowest column
     block), decoder init / tail (B*nz + B*65 + 64*nz floats).  Beyond them the engines use the GEMM-based sequences."""
-    return (B * 2 * nz + 16 * (2 * nz + B)) * 4 <= 64000 and (B * nz + B * 65 + 64 * (nz + 1)) * 4 <= 64000 and ns >= 1
+    return (B * 2 * nz + B * ns * nz + 16 * (2 * nz + B)) * 4 <= 64000 and (B * nz + B * 65 + 64 * (nz + 1)) * 4 <= 64000
 
 
 def reparam_kl_forward(mulv, eps):

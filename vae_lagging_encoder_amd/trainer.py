@@ -45,6 +45,7 @@ class AggressiveTextTrainer(object):
         self.grad_sync = grad_sync
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._capturing = False
+        self._update = "encoder"
         d = self.device
         # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum]
         self.scal = torch.zeros(8, dtype=torch.float32, device=d)
@@ -123,15 +124,21 @@ class AggressiveTextTrainer(object):
             # Not beside a PERSISTENT encoder BPTT: that launch needs every CU resident at once, and compute units held
             # by the collective's kernels would leave part of its grid spinning -- both reductions then go out in sync().
             self.dec.join()
-            self.grad_sync.start_decoder(self.dec.flat)
+            self.grad_sync.start_decoder(self.dec.flat, self._update)
         self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl))
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
 
-    def _clip_and_step(self, update):
+    def _clip_and_step(self, update, dec_ss=None):
         lib, s = self.lib, _eng.stream_ptr(self.device)
         ef, df = self.enc.flat, self.dec.flat
-        lib.lv_clip_norm2_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
-                              self._s(4), s)
+        if dec_ss is None:
+            lib.lv_clip_norm2_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
+                                  self._s(4), s)
+        else:
+            # data parallel, encoder-only step: the decoder gradient was exchanged as its sum of squares only (GradSync)
+            lib.lv_sumsq_f32(P(ef.grad), ef.numel, P(self.norm_ws), self._s(2), 0, s)
+            lib.lv_sum_accum_f32(P(dec_ss), 1, self._s(2), s)
+            lib.lv_clip_coef_f32(self._s(2), self.clip, self._s(3), self._s(4), s)
         # clip_grad_norm_ scales every grad in place; the update only touches the stepped side
         if update in ("encoder", "both"):
             lib.lv_sgd_step_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, s)
@@ -143,10 +150,12 @@ class AggressiveTextTrainer(object):
             lib.lv_scale_f32(P(df.grad), df.numel, self._s(3), s)
 
     def _run(self, st, update, draw):
+        self._update = update
         self._fwd_bwd(st, draw)
+        dec_ss = None
         if self.grad_sync is not None:
-            self.grad_sync.sync(self.enc.flat, self.dec.flat)
-        self._clip_and_step(update)
+            dec_ss = self.grad_sync.sync(self.enc.flat, self.dec.flat, update)
+        self._clip_and_step(update, dec_ss)
 
     def step(self, x, kl_weight, noise=None, update="encoder"):
         """One body of the aggressive loop on batch x (int64 [B][T] on device).
@@ -211,9 +220,12 @@ class AggressiveTextTrainer(object):
         if self.grad_sync is None:
             parts.append(cap(lambda: (self._fwd_bwd(st, draw), self._clip_and_step(update))))
         else:
+            self._update = update
             parts.append(cap(lambda: self._fwd_bwd(st, draw)))
-            parts.append(lambda: self.grad_sync.sync(self.enc.flat, self.dec.flat))
-            parts.append(cap(lambda: self._clip_and_step(update)))
+            # the exchange returns the same device scalar (or None) on every call of a given `update`: safe to capture
+            ss = self.grad_sync.ss_handle(self.dec.flat, update)
+            parts.append(lambda: self.grad_sync.sync(self.enc.flat, self.dec.flat, update))
+            parts.append(cap(lambda: self._clip_and_step(update, ss)))
         return parts
 
     # -- the loop of text.py:366-400 ------------------------------------------------------------------------
