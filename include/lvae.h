@@ -221,6 +221,21 @@ int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long n_in, float
 int lv_rng_bernoulli_f32(const float* p, float* out, long n, const uint64_t* state_dev, uint64_t substream,
                          void* stream);   /* torch.bernoulli(batch): dynamic binarisation, image.py:287,318 */
 
+/* ---- evaluation statistics on top of the hot path's forward (lv_eval.hip) ----------------------------
+ * log q(z|x) of GaussianEncoderBase.eval_inference_dist (modules/encoders/encoder.py:81-109) for z [B][ns][nz] -> out [B][ns];
+ * mu == NULL: the standard normal prior of VAE.eval_prior_dist (modules/vae.py:135-145) */
+int lv_gauss_logpdf_f32(const float* z, const float* mu, const float* logvar, float* out, int B, int ns, int nz, void* stream);
+/* log_sum_exp(value, dim=-1) (modules/utils.py:3-16) over the rows of in [R][C] (ld), plus the constant `add`
+ * (VAE.nll_iw, modules/vae.py:127: - log(nsamples)) */
+int lv_logsumexp_rows_f32(const float* in, long ld, int R, int C, float add, float* out, void* stream);
+/* GaussianEncoderBase.calc_mi (encoder.py:111-145) from the encoder's (mu, logvar) [Bx][nz] and the samples z [Bz][nz]:
+ * out_dev[0] = MI estimate, [1] = E log q(z|x), [2] = E log q(z); ws: Bz floats */
+int lv_calc_mi_f32(const float* mu, const float* logvar, const float* z, float* ws, float* out_dev, int Bx, int Bz, int nz,
+                   void* stream);
+/* calc_au (text.py:200-227) accumulators over posterior means mu [B][nz]: acc_dev[k] += sum_b mu[b][k] (mean == NULL) or
+ * sum_b (mu[b][k] - mean[k])^2 */
+int lv_au_accum_f32(const float* mu, const float* mean, float* acc_dev, int B, int nz, void* stream);
+
 /* ---- Omniglot path: ResNetEncoderV2 (modules/encoders/enc_resnet_v2.py:27-126) and PixelCNNDecoderV2
  * (modules/decoders/dec_pixelcnn_v2.py:12-195).  Activations NHWC ([N*H*W][C]); a convolution = lv_im2col_f32 +
  * lv_gemm_* against weights packed [Cout][taps][Cin]; 1x1 convolutions are plain GEMMs.  `ntaps` = length of the

@@ -416,3 +416,60 @@ def check_image_eval_after_decoder_update(device, B=6):
         l_r, rec_r, kl_r = IO.vae_loss(c, x, 1.0, eps)
     assert rel_err(rec, rec_r) < 1e-4, rel_err(rec, rec_r)
     assert rel_err(kl, kl_r) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation statistics: text.py:120-227 on the reference vs vae_lagging_encoder_amd.evaluation
+def check_eval_against_fixture(device):
+    """test / calc_mi / calc_au / calc_iwnll / nll_iw / eval_inference_dist on the drop-in modules against the numbers the
+    reference's text.py reported on the same seeded model, batches and Gaussian draws (tests/golden/eval_small.npz)."""
+    import argparse
+    from vae_lagging_encoder_amd import evaluation as E
+    fx = load("eval_small")
+    V, ni, H, nz, nb = (int(fx[k]) for k in ("V", "ni", "H", "nz", "nb"))
+    vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
+    vae.eval()
+    batches = [torch.from_numpy(fx["x/%d" % i]).to(device) for i in range(nb)]
+    orig = vae.encoder._draw_eps
+
+    def feed(prefix):
+        """Replace the encoder's Gaussian draw by the reference's recorded draws, in program order."""
+        state = {"i": 0}
+
+        def draw(batch, nsamples, nzz, dev, eps=None):
+            e = torch.from_numpy(fx["%s/%d" % (prefix, state["i"])])
+            state["i"] += 1
+            assert tuple(e.shape) == (batch, nsamples, nzz), (prefix, state["i"], tuple(e.shape), (batch, nsamples, nzz))
+            return e.to(dev)
+        vae.encoder._draw_eps = draw
+        return state
+    try:
+        with torch.no_grad():
+            feed("mi_eps")
+            mi = E.calc_mi(vae, batches)
+            assert abs(mi - float(fx["mi"])) < 2e-4 * max(1.0, abs(float(fx["mi"]))), (mi, float(fx["mi"]))
+            vae.encoder._draw_eps = orig
+            n_au, au_var = E.calc_au(vae, batches, delta=0.01)
+            assert n_au == int(fx["au"])
+            assert rel_err(au_var, fx["au_var"]) < 1e-4
+            args = argparse.Namespace(nsamples=1, iw_nsamples=20)
+            feed("test_eps")
+            res = E.test(vae, batches, "VAL", args, verbose=False, np_rng=np.random.RandomState(7))
+            ref = fx["test"]
+            for got, want in zip(res[:4], ref[:4]):
+                assert abs(got - want) < 1e-4 * abs(want), (res, ref)
+            assert abs(res[4] - ref[4]) < 2e-4 * max(1.0, abs(ref[4]))
+            feed("iw_eps")
+            nll, ppl = E.calc_iwnll(vae, batches, args, ns=10, np_rng=np.random.RandomState(8))
+            assert abs(nll - fx["iwnll"][0]) < 1e-4 * abs(fx["iwnll"][0]) and abs(ppl - fx["iwnll"][1]) < 2e-4 * abs(fx["iwnll"][1])
+            feed("nll_iw_b0_eps")
+            v = vae.nll_iw(batches[0], nsamples=20, ns=10)
+            assert rel_err(v, fx["nll_iw_b0"]) < 1e-4
+            vae.encoder._draw_eps = orig
+            mu, lv = vae.encoder(batches[1])
+            z = torch.from_numpy(fx["infer_z"]).to(device)
+            assert rel_err(vae.eval_inference_dist(batches[1], z, (mu, lv)), fx["infer_logq"]) < 1e-4
+            assert rel_err(vae.eval_prior_dist(z), fx["prior_logp"]) < 1e-5
+    finally:
+        vae.encoder._draw_eps = orig
+        vae.train()

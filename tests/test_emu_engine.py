@@ -39,3 +39,7 @@ def test_bf16_native_operands_equal_on_the_fly_emulated(emu_backend):
 
 def test_update_both_and_fixed_k_emulated(emu_backend):
     pc.check_update_both_and_fixed_k("cpu")
+
+
+def test_eval_statistics_against_reference_fixture_emulated(emu_backend):
+    pc.check_eval_against_fixture("cpu")

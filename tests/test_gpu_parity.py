@@ -412,3 +412,8 @@ def test_image_inner_loop_with_data_dependent_exit(hip_device):
 
 def test_image_eval_forward_after_decoder_update(hip_device):
     pc.check_image_eval_after_decoder_update(hip_device)
+
+
+def test_eval_statistics_against_reference_fixture(hip_device):
+    """test / calc_mi / calc_au / calc_iwnll / nll_iw / eval_inference_dist vs the reference's text.py."""
+    pc.check_eval_against_fixture(hip_device)

@@ -69,6 +69,10 @@ SIGNATURES = {
     "lv_adam_step_f32": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _f, _f, _f, _i, _vp],
     "lv_add_scalar_f32": [_vp, _f, _vp],
     "lv_sum_accum_f32": [_vp, _l, _vp, _vp],
+    "lv_gauss_logpdf_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_logsumexp_rows_f32": [_vp, _l, _i, _i, _f, _vp, _vp],
+    "lv_calc_mi_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_au_accum_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "lv_rng_normal_f32": [_vp, _l, _vp, _u64, _vp],
     "lv_rng_keepmask_u8": [_vp, _l, _f, _vp, _u64, _vp],
     "lv_rng_advance": [_vp, _u64, _vp],

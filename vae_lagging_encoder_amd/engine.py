@@ -850,3 +850,45 @@ def reparam_kl_backward(mulv, eps, dz, dkl):
     lib.lv_reparam_kl_bwd_f32(P(mulv.contiguous()), P(eps.contiguous()), P(dz.contiguous()), P(dkl.contiguous()),
                               P(dmulv), B, ns, nz, s)
     return dmulv
+
+
+# ---- evaluation statistics (lv_eval.hip) ------------------------------------------------------------------
+def gauss_logpdf(z, mu, logvar):
+    """z [B][ns][nz]; mu, logvar [B][nz] or None (standard normal) -> log density [B][ns]."""
+    lib, s = backend_for(z.device), stream_ptr(z.device)
+    B, ns, nz = z.shape
+    z = z.contiguous().float()
+    out = torch.empty(B, ns, dtype=torch.float32, device=z.device)
+    if mu is not None:
+        mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
+    lib.lv_gauss_logpdf_f32(P(z), P(mu), P(logvar), P(out), B, ns, nz, s)
+    return out
+
+
+def logsumexp_rows(x, add=0.0):
+    """x [R][C] -> log(sum_c exp(x[r][c])) + add, [R]."""
+    lib, s = backend_for(x.device), stream_ptr(x.device)
+    x = x.contiguous().float()
+    R, C = x.shape
+    out = torch.empty(R, dtype=torch.float32, device=x.device)
+    lib.lv_logsumexp_rows_f32(P(x), C, R, C, float(add), P(out), s)
+    return out
+
+
+def calc_mi(mu, logvar, z):
+    """mu, logvar [Bx][nz], z [Bz][nz] -> device tensor (MI, E log q(z|x), E log q(z))."""
+    lib, s = backend_for(mu.device), stream_ptr(mu.device)
+    mu, logvar, z = mu.contiguous().float(), logvar.contiguous().float(), z.contiguous().float()
+    Bx, nz = mu.shape
+    Bz = z.shape[0]
+    ws = torch.empty(Bz, dtype=torch.float32, device=mu.device)
+    out = torch.empty(3, dtype=torch.float32, device=mu.device)
+    lib.lv_calc_mi_f32(P(mu), P(logvar), P(z), P(ws), P(out), Bx, Bz, nz, s)
+    return out
+
+
+def au_accumulate(mu, mean, acc):
+    """acc[k] += sum_b mu[b][k] (mean None) or sum_b (mu[b][k] - mean[k])^2."""
+    lib, s = backend_for(mu.device), stream_ptr(mu.device)
+    mu = mu.contiguous().float()
+    lib.lv_au_accum_f32(P(mu), P(mean), P(acc), mu.shape[0], mu.shape[1], s)

@@ -4,15 +4,12 @@ Hot path: `encode` and `reparameterize` run the fused 
 lv_reparam_kl_{fwd,bwd}_f32 (z = mu + eps*exp(0.5 logvar); KL = 0.5*sum(mu^2 + e^lv - lv - 1), wave64 shuffle
 reduction over nz).  eps is drawn with torch's device generator exactly where the reference draws it
 (encoder.py:77), or injected through the optional `eps=` argument (parity tests).
-The evaluation helpers (eval_inference_dist, calc_mi: SURVEY.md 8f "next" rows) are plain tensor algebra.
+The evaluation helpers (eval_inference_dist, calc_mi: SURVEY.md 8f row 1) run the kernels of lv_eval.hip.
 """
-import math
-
 import torch
 import torch.nn as nn
 
 from ... import engine as _eng
-from ..utils import log_sum_exp
 
 
 class _ReparamKLFn(torch.autograd.Function):
@@ -76,22 +73,13 @@ class GaussianEncoderBase(nn.Module):
         return z
 
     def eval_inference_dist(self, x, z, param=None):
-        """log q(z|x) for z (batch, nsamples, nz) -> (batch, nsamples)."""
-        nz = z.size(2)
+        """log q(z|x) for z (batch, nsamples, nz) -> (batch, nsamples)   (reference encoder.py:81-109; lv_gauss_logpdf_f32)."""
         mu, logvar = param if param else self.forward(x)
-        mu, logvar = mu.unsqueeze(1), logvar.unsqueeze(1)
-        dev = z - mu
-        return -0.5 * ((dev ** 2) / logvar.exp()).sum(dim=-1) - 0.5 * (nz * math.log(2 * math.pi) + logvar.sum(-1))
+        return _eng.gauss_logpdf(z, mu, logvar)
 
-    def calc_mi(self, x):
-        """I(x;z) under q: E_x E_q log q(z|x) - E_x E_q log q(z), aggregate posterior from the same batch."""
+    def calc_mi(self, x, eps=None):
+        """I(x;z) under q: E_x E_q log q(z|x) - E_x E_q log q(z), aggregate posterior from the same batch (reference
+        encoder.py:111-145).  One HIP launch pair on top of the encoder forward: no (z_batch, x_batch, nz) temporary."""
         mu, logvar = self.forward(x)
-        x_batch, nz = mu.size()
-        neg_entropy = (-0.5 * nz * math.log(2 * math.pi) - 0.5 * (1 + logvar).sum(-1)).mean()
-        z_samples = self.reparameterize(mu, logvar, 1)             # (z_batch, 1, nz)
-        mu, logvar = mu.unsqueeze(0), logvar.unsqueeze(0)
-        dev = z_samples - mu                                        # (z_batch, x_batch, nz)
-        log_density = -0.5 * ((dev ** 2) / logvar.exp()).sum(dim=-1) - \
-            0.5 * (nz * math.log(2 * math.pi) + logvar.sum(-1))
-        log_qz = log_sum_exp(log_density, dim=1) - math.log(x_batch)
-        return (neg_entropy - log_qz.mean(-1)).item()
+        z = self.reparameterize(mu, logvar, 1, eps=eps)            # (z_batch, 1, nz)
+        return float(_eng.calc_mi(mu, logvar, z.reshape(z.shape[0], -1))[0].item())

@@ -9,6 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import engine as _eng
 from .utils import log_sum_exp
 
 _GENERATORS = {"beam": "beam_search_decode", "greedy": "greedy_decode", "sample": "sample_decode"}
@@ -66,15 +67,19 @@ class VAE(nn.Module):
 
     # ---- evaluation (reference vae.py:100-227) -------------------------------------------------------------
     def nll_iw(self, x, nsamples, ns=100):
-        """Importance-weighted estimate of -log p(x) from `nsamples` draws, `ns` at a time -> (batch,)."""
+        """Importance-weighted estimate of -log p(x) from `nsamples` draws, `ns` at a time -> (batch,)   (reference
+        vae.py:100-129).  The decoder pass over batch*ns sequences is the hot path's HIP forward; log p(z), log q(z|x) and
+        the final log_sum_exp are lv_eval.hip kernels."""
         log_w = []
         for _ in range(int(nsamples / ns)):
             z, stats = self.encoder.sample(x, ns)
             log_w.append(self.eval_complete_ll(x, z) - self.eval_inference_dist(x, z, stats))
-        return math.log(nsamples) - log_sum_exp(torch.cat(log_w, dim=-1), dim=-1)
+        return -_eng.logsumexp_rows(torch.cat(log_w, dim=-1), -math.log(nsamples))
 
     def eval_prior_dist(self, zrange):
-        """log N(z; 0, I) summed over the latent dimension."""
+        """log N(z; 0, I) summed over the latent dimension (reference vae.py:135-145)."""
+        if zrange.dim() == 3:
+            return _eng.gauss_logpdf(zrange, None, None)
         return self.prior.log_prob(zrange).sum(dim=-1)
 
     def eval_cond_ll(self, x, z):
