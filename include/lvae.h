@@ -236,6 +236,15 @@ int lv_calc_mi_f32(const float* mu, const float* logvar, const float* z, float* 
  * sum_b (mu[b][k] - mean[k])^2 */
 int lv_au_accum_f32(const float* mu, const float* mean, float* acc_dev, int B, int nz, void* stream);
 
+/* ---- generation helpers (lv_eval.hip; SURVEY.md 8f row 4: modules/decoders/dec_lstm.py:163-367) -------------------------
+ * torch.argmax(logits, dim=1) (greedy_decode, dec_lstm.py:304): lowest index among equal maxima */
+int lv_argmax_rows_f32(const float* in, long ld, int R, int C, int64_t* idx, void* stream);
+/* F.log_softmax(logits, -1) + the live hypotheses' running log-probabilities addrow[r] (beam_search_decode, dec_lstm.py:214-218) */
+int lv_log_softmax_rows_f32(const float* in, long ld, int R, int C, const float* addrow, float* out, long ldo, void* stream);
+/* categorical draw from softmax(logits[r]) by inverse CDF with the uniform u[r] (sample_decode's torch.multinomial,
+ * dec_lstm.py:351-352): idx[r] = first c with cumsum softmax >= u[r] */
+int lv_sample_rows_f32(const float* in, long ld, int R, int C, const float* u, int64_t* idx, void* stream);
+
 /* ---- Omniglot path: ResNetEncoderV2 (modules/encoders/enc_resnet_v2.py:27-126) and PixelCNNDecoderV2
  * (modules/decoders/dec_pixelcnn_v2.py:12-195).  Activations NHWC ([N*H*W][C]); a convolution = lv_im2col_f32 +
  * lv_gemm_* against weights packed [Cout][taps][Cin]; 1x1 convolutions are plain GEMMs.  `ntaps` = length of the

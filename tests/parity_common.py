@@ -473,3 +473,43 @@ def check_eval_against_fixture(device):
     finally:
         vae.encoder._draw_eps = orig
         vae.train()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# generation: greedy / beam decoding vs the reference, sampling by its properties
+def check_generation_against_fixture(device):
+    fx = load("generate_small")
+    V, ni, H, nz = (int(fx[k]) for k in ("V", "ni", "H", "nz"))
+    vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
+    vae.eval()
+    z = torch.from_numpy(fx["z"]).to(device)
+
+    def ids(sents):
+        return [[int(w[1:]) for w in s] for s in sents]
+    greedy = ids(vae.decode(z, "greedy"))
+    beam = ids(vae.decode(z, "beam", K=4))
+    for name, got in (("greedy", greedy), ("beam", beam)):
+        for i, s in enumerate(got):
+            n = int(fx[name + "_len"][i])
+            assert s == list(fx[name + "_ids"][i][:n]), (name, i, s[:12], list(fx[name + "_ids"][i][:12]))
+    # sampling: valid words, stops right after </s>, at most 99 words, reproducible from a seeded generator, and the
+    # inverse-CDF pick follows softmax(logits) (chi-square-free check: empirical frequencies of a 6-word distribution)
+    gen = torch.Generator(device=device).manual_seed(3)
+    a = ids(vae.decode(z, "sample") if False else vae.decoder.sample_decode(z, generator=gen))
+    gen = torch.Generator(device=device).manual_seed(3)
+    b = ids(vae.decoder.sample_decode(z, generator=gen))
+    assert a == b
+    for s in a:
+        assert 1 <= len(s) <= 99 and all(0 <= w < V for w in s)
+        assert 2 not in s[:-1]
+    st = vae.decoder._stepper(device)
+    logits = torch.tensor([[0.0, 1.0, -1.0, 2.0, 0.5, -3.0]], device=device).repeat(4000, 1)
+    u = torch.rand(4000, generator=torch.Generator().manual_seed(1)).to(device)
+    pick = st.sample(logits, u).cpu()
+    p = torch.softmax(logits[0].cpu(), 0)
+    freq = torch.bincount(pick, minlength=6).float() / 4000
+    assert float((freq - p).abs().max()) < 0.03, (freq, p)
+    cdf = torch.cumsum(p.double(), 0)
+    want = torch.searchsorted(cdf, u.cpu().double().clamp(max=float(cdf[-1]) - 1e-9))
+    assert float((pick != want).float().mean()) < 0.002           # boundary draws may fall either side in f32
+    vae.train()

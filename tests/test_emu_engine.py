@@ -43,3 +43,7 @@ def test_update_both_and_fixed_k_emulated(emu_backend):
 
 def test_eval_statistics_against_reference_fixture_emulated(emu_backend):
     pc.check_eval_against_fixture("cpu")
+
+
+def test_generation_against_reference_fixture_emulated(emu_backend):
+    pc.check_generation_against_fixture("cpu")

@@ -417,3 +417,8 @@ def test_image_eval_forward_after_decoder_update(hip_device):
 def test_eval_statistics_against_reference_fixture(hip_device):
     """test / calc_mi / calc_au / calc_iwnll / nll_iw / eval_inference_dist vs the reference's text.py."""
     pc.check_eval_against_fixture(hip_device)
+
+
+def test_generation_against_reference_fixture(hip_device):
+    """greedy and beam-search decoding reproduce the reference's sentences; sampling by its properties."""
+    pc.check_generation_against_fixture(hip_device)

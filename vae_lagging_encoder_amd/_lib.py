@@ -73,6 +73,9 @@ SIGNATURES = {
     "lv_logsumexp_rows_f32": [_vp, _l, _i, _i, _f, _vp, _vp],
     "lv_calc_mi_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_au_accum_f32": [_vp, _vp, _vp, _i, _i, _vp],
+    "lv_argmax_rows_f32": [_vp, _l, _i, _i, _vp, _vp],
+    "lv_log_softmax_rows_f32": [_vp, _l, _i, _i, _vp, _vp, _l, _vp],
+    "lv_sample_rows_f32": [_vp, _l, _i, _i, _vp, _vp, _vp],
     "lv_rng_normal_f32": [_vp, _l, _vp, _u64, _vp],
     "lv_rng_keepmask_u8": [_vp, _l, _f, _vp, _u64, _vp],
     "lv_rng_advance": [_vp, _u64, _vp],

@@ -169,3 +169,117 @@ extern "C" int lv_au_accum_f32(const float* mu, const float* mean, float* acc_de
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
+
+// ---- generation (greedy / sample / beam decoding, modules/decoders/dec_lstm.py:163-367) -----------------
+namespace {
+
+// one wave per row: idx[r] = argmax_c in[r][c] (lowest index among equal maxima, as torch.argmax on CPU)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ in, long ld, int R, int C,
+                                                          int64_t* __restrict__ idx) {
+    const int r = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int l = (int)threadIdx.x & 63;
+    if (r >= R) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = l; c < C; c += 64) {
+        const float v = in[(long)r * ld + c];
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(bi, d, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (l == 0) idx[r] = bi == 0x7fffffff ? 0 : bi;
+}
+
+// out[r][c] = in[r][c] - logsumexp_c in[r][:]  (+ addrow[r]): F.log_softmax (+ the hypothesis' running log-probability)
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ in, long ld, int R, int C,
+                                                               const float* __restrict__ addrow, float* __restrict__ out, long ldo) {
+    __shared__ float sm[4], ss[4];
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    float m = -INFINITY, s = 0.f;
+    for (int c = tid; c < C; c += 256) lse_merge(m, s, in[(long)r * ld + c], 1.f);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float m2 = __shfl_xor(m, d, 64), s2 = __shfl_xor(s, d, 64);
+        lse_merge(m, s, m2, s2);
+    }
+    if (l == 0) { sm[w] = m; ss[w] = s; }
+    __syncthreads();
+    float M = sm[0], S = ss[0];
+    for (int i = 1; i < 4; ++i) lse_merge(M, S, sm[i], ss[i]);
+    const float L = M + logf(S) - (addrow ? addrow[r] : 0.f);
+    for (int c = tid; c < C; c += 256) out[(long)r * ldo + c] = in[(long)r * ld + c] - L;
+}
+
+// categorical draw from softmax(in[r][:]) by inverse CDF with the uniform u[r] in [0,1): single wave per row, two passes
+// (logsumexp, then a blocked running sum); idx[r] = first c with cumsum_c softmax >= u
+__global__ __launch_bounds__(64) void sample_rows_kernel(const float* __restrict__ in, long ld, int R, int C,
+                                                         const float* __restrict__ u, int64_t* __restrict__ idx) {
+    const int r = (int)blockIdx.x, l = (int)threadIdx.x;
+    float m = -INFINITY, s = 0.f;
+    for (int c = l; c < C; c += 64) lse_merge(m, s, in[(long)r * ld + c], 1.f);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float m2 = __shfl_xor(m, d, 64), s2 = __shfl_xor(s, d, 64);
+        lse_merge(m, s, m2, s2);
+    }
+    const float target = u[r] * s;                     // in units of exp(x - m)
+    float run = 0.f;
+    int found = C - 1;
+    bool done = false;
+    for (int c0 = 0; c0 < C && !done; c0 += 64) {      // blocks of 64 consecutive columns, inclusive scan inside the wave
+        const int c = c0 + l;
+        float p = c < C ? expf(in[(long)r * ld + c] - m) : 0.f;
+        float sc = p;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(sc, d, 64);
+            if (l >= d) sc += o;
+        }
+        const bool hit = c < C && run + sc >= target;
+        // lowest lane that hit
+        int first = hit ? l : 64;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(first, d, 64);
+            first = o < first ? o : first;
+        }
+        if (first < 64) { found = c0 + first; done = true; }
+        run += __shfl(sc, 63, 64);
+    }
+    if (l == 0) idx[r] = found;
+}
+
+}  // namespace
+
+// torch.argmax(logits, dim=1) of LSTMDecoder.greedy_decode (dec_lstm.py:304)
+extern "C" int lv_argmax_rows_f32(const float* in, long ld, int R, int C, int64_t* idx, void* stream) {
+    if (!in || !idx) return LV_ERR_ARG;
+    if (R <= 0 || C <= 0 || ld < C) return LV_ERR_SHAPE;
+    LV_LAUNCH(argmax_rows_kernel, dim3((unsigned)lv_cdiv(R, 4)), dim3(256), 0, stream, in, ld, R, C, idx);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// F.log_softmax(logits, dim=-1) + the live hypotheses' running log-probabilities (beam_search_decode, dec_lstm.py:214-218)
+extern "C" int lv_log_softmax_rows_f32(const float* in, long ld, int R, int C, const float* addrow, float* out, long ldo,
+                                       void* stream) {
+    if (!in || !out) return LV_ERR_ARG;
+    if (R <= 0 || C <= 0 || ld < C || ldo < C) return LV_ERR_SHAPE;
+    LV_LAUNCH(log_softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, stream, in, ld, R, C, addrow, out, ldo);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// torch.multinomial(F.softmax(logits, dim=1), 1) of LSTMDecoder.sample_decode (dec_lstm.py:351-352) as an inverse-CDF draw
+// from the caller's uniforms u [R] (lv_rng_* or torch): idx[r] = first c with cumsum softmax(logits[r])[c] >= u[r]
+extern "C" int lv_sample_rows_f32(const float* in, long ld, int R, int C, const float* u, int64_t* idx, void* stream) {
+    if (!in || !u || !idx) return LV_ERR_ARG;
+    if (R <= 0 || C <= 0 || ld < C) return LV_ERR_SHAPE;
+    LV_LAUNCH(sample_rows_kernel, dim3((unsigned)R), dim3(64), 0, stream, in, ld, R, C, u, idx);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

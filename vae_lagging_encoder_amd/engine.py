@@ -892,3 +892,89 @@ def au_accumulate(mu, mean, acc):
     lib, s = backend_for(mu.device), stream_ptr(mu.device)
     mu = mu.contiguous().float()
     lib.lv_au_accum_f32(P(mu), P(mean), P(acc), mu.shape[0], mu.shape[1], s)
+
+
+# ---- generation -------------------------------------------------------------------------------------------
+class LSTMDecodeStepper(object):
+    """One decoder timestep at a time for greedy / sample / beam decoding (reference modules/decoders/dec_lstm.py:163-367):
+    embed(token) ++ z -> LSTM cell -> pred_linear, through the same C-ABI kernels as the training path in exact f32
+    (lv_embed_gather_f32, lv_gemm_f32 with the z-projection folded into its epilogue, lv_lstm_fwd_f32 with T = 1)."""
+
+    def __init__(self, eng, device):
+        self.eng = eng
+        self.device = torch.device(device)
+        eng.ensure(self.device)
+        self.lib = eng.lib
+        self.ws = {}
+
+    def _w(self, n):
+        w = self.ws.get(n)
+        if w is None:
+            V, ni, H, nz = self.eng.dims()
+            d = self.device
+            w = _NS()
+            w.X = torch.empty(n, ni, dtype=torch.float32, device=d)
+            w.Zp = torch.empty(n, 4 * H, dtype=torch.float32, device=d)
+            w.Gx = torch.empty(n, 4 * H, dtype=torch.float32, device=d)
+            w.hs = torch.empty(2, n, H, dtype=torch.float32, device=d)
+            w.cs = torch.empty(2, n, H, dtype=torch.float32, device=d)
+            w.gates = torch.empty(n, 4 * H, dtype=torch.float32, device=d)
+            w.lstm_ws = torch.empty(self.lib.lv_lstm_ws_floats(n, H), dtype=torch.float32, device=d)
+            w.ldl = _round_up(V, 32)
+            w.logits = torch.empty(n, w.ldl, dtype=torch.float32, device=d)
+            self.ws[n] = w
+        return w
+
+    def init_state(self, z2):
+        """z2 [n][nz] -> (h0, c0) [n][H]: c0 = trans_linear(z), h0 = tanh(c0)   (dec_lstm.py:181-182, 284-285)."""
+        V, ni, H, nz = self.eng.dims()
+        v = self.eng.flat.views
+        lib, s = self.lib, stream_ptr(self.device)
+        n = z2.shape[0]
+        z2 = z2.contiguous().float()
+        c0 = torch.empty(n, H, dtype=torch.float32, device=self.device)
+        _gemm(lib, s, 0, 1, n, H, nz, P(z2), nz, P(v["trans_linear.weight"]), nz, P(c0), H)
+        h0 = torch.empty_like(c0)
+        lib.lv_tanh_f32(P(c0), P(h0), n * H, s)
+        return h0, c0
+
+    def step(self, tokens, z2, h, c):
+        """tokens int64 [n], z2 [n][nz], (h, c) [n][H] -> logits [n][V] (a view, valid until the next call), (h', c')."""
+        V, ni, H, nz = self.eng.dims()
+        v = self.eng.flat.views
+        lib, s = self.lib, stream_ptr(self.device)
+        n = tokens.shape[0]
+        w = self._w(n)
+        tok = tokens.reshape(n, 1).contiguous()
+        z2 = z2.contiguous().float()
+        lib.lv_embed_gather_f32(P(v["embed.weight"]), P(tok), 1, None, 1.0, P(w.X), 1, n, ni, V, s)
+        wih = v["lstm.weight_ih_l0"]
+        _gemm(lib, s, 0, 1, n, 4 * H, nz, P(z2), nz, P(wih, ni), ni + nz, P(w.Zp), 4 * H,
+              add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
+        _gemm(lib, s, 0, 1, n, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H, add1=P(w.Zp), ld1=4 * H, mod1=n)
+        w.hs[0].copy_(h)
+        w.cs[0].copy_(c)
+        lib.lv_lstm_fwd_f32(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(w.gates), None, 1.0, None, P(w.lstm_ws), 1, n, H, s)
+        _gemm(lib, s, 0, 1, n, V, H, P(w.hs, n * H), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl)
+        return w.logits[:, :V], w.hs[1].clone(), w.cs[1].clone()
+
+    def argmax(self, logits):
+        n, V = logits.shape
+        idx = torch.empty(n, dtype=torch.int64, device=self.device)
+        self.lib.lv_argmax_rows_f32(P(logits), logits.stride(0), n, V, P(idx), stream_ptr(self.device))
+        return idx
+
+    def sample(self, logits, u):
+        n, V = logits.shape
+        idx = torch.empty(n, dtype=torch.int64, device=self.device)
+        u = u.contiguous().float()
+        self.lib.lv_sample_rows_f32(P(logits), logits.stride(0), n, V, P(u), P(idx), stream_ptr(self.device))
+        return idx
+
+    def log_softmax(self, logits, addrow=None):
+        n, V = logits.shape
+        out = torch.empty(n, V, dtype=torch.float32, device=self.device)
+        if addrow is not None:
+            addrow = addrow.contiguous().float()
+        self.lib.lv_log_softmax_rows_f32(P(logits), logits.stride(0), n, V, P(addrow), P(out), V, stream_ptr(self.device))
+        return out

@@ -4,8 +4,8 @@ Same constructor, containers, construction order and state_dict keys (`embed.wei
 (SURVEY.md G3), `trans_linear.weight`, `lstm.*_l0`, `pred_linear.weight`).  `reconstruct_error` runs the HIP path:
 embedding gather fused with dropout_in, z-projection folded into the input GEMM epilogue (the cat((embed, z)) is
 never materialised), fused LSTM step kernels with dropout_out in the epilogue, f32 MFMA vocabulary projection,
-row softmax-NLL; hand-written backward.  Generation (beam/greedy/sample, reference lines 163-367) is outside the
-hot path (SURVEY.md section 8 scope table) and not provided.
+row softmax-NLL; hand-written backward.  Generation (beam / greedy / sample decoding, reference lines 163-367;
+SURVEY.md 8f row 4) steps the same kernels one token at a time through engine.LSTMDecodeStepper.
 """
 import torch
 import torch.nn as nn
@@ -119,11 +119,96 @@ class LSTMDecoder(DecoderBase):
             V = len(self.vocab)
             return w.logits[:, :V].reshape(T, B * ns, V).transpose(0, 1).contiguous()
 
-    def beam_search_decode(self, z, K=5):
-        raise NotImplementedError("generation is outside the MI355X hot path (SURVEY.md section 8: out of scope)")
+    # ---- generation (reference dec_lstm.py:163-367) ------------------------------------------------------
+    def _stepper(self, device):
+        st = getattr(self, "_gen", None)
+        if st is None or st.device != torch.device(device):
+            st = self._gen = _eng.LSTMDecodeStepper(self._hip, device)
+        return st
+
+    def _roll_out(self, z, pick):
+        """Shared loop of greedy_decode / sample_decode (dec_lstm.py:270-367): every sentence starts at <s>, a step feeds the
+        picked word back, a sentence stops after emitting </s>, at most 99 words."""
+        batch_size = z.size(0)
+        dev = z.device
+        st = self._stepper(dev)
+        z2 = z.reshape(batch_size, -1).float()
+        with torch.no_grad():
+            h, c = st.init_state(z2)
+            tok = torch.full((batch_size,), self.vocab["<s>"], dtype=torch.int64, device=dev)
+            end = self.vocab["</s>"]
+            alive = torch.ones(batch_size, dtype=torch.bool, device=dev)
+            picked, masks = [], []
+            length_c = 1
+            while length_c < 100:
+                logits, h, c = st.step(tok, z2, h, c)
+                tok = pick(st, logits)
+                picked.append(tok)
+                masks.append(alive)
+                alive = alive & (tok != end)
+                length_c += 1
+                if not bool(alive.any().item()):            # the reference's mask.sum().item() != 0 test (one host read per step)
+                    break
+        ids = torch.stack(picked, dim=1).cpu().tolist()
+        keep = torch.stack(masks, dim=1).cpu().tolist()
+        return [[self.vocab.id2word(w) for w, k in zip(row, krow) if k] for row, krow in zip(ids, keep)]
 
     def greedy_decode(self, z):
-        raise NotImplementedError("generation is outside the MI355X hot path (SURVEY.md section 8: out of scope)")
+        """Greedy decoding from z (batch_size, nz) -> list of word lists (reference dec_lstm.py:270-318)."""
+        return self._roll_out(z, lambda st, logits: st.argmax(logits))
 
-    def sample_decode(self, z):
-        raise NotImplementedError("generation is outside the MI355X hot path (SURVEY.md section 8: out of scope)")
+    def sample_decode(self, z, generator=None):
+        """Ancestral sampling from z (reference dec_lstm.py:320-367).  The categorical draw is an inverse-CDF pick from a device
+        uniform (torch.rand; `generator` makes it reproducible) instead of torch.multinomial's sampler: same distribution,
+        different stream."""
+        def pick(st, logits):
+            u = torch.rand(logits.shape[0], device=logits.device, generator=generator)
+            return st.sample(logits, u)
+        return self._roll_out(z, pick)
+
+    def beam_search_decode(self, z, K=5):
+        """Beam search, sentence by sentence (reference dec_lstm.py:163-268): live hypotheses are expanded together, the K -
+        len(completed) best continuations over (hypothesis, word) survive, a hypothesis completes when it emits </s>, the
+        best by total log-probability is returned with <s> in front."""
+        batch_size = z.size(0)
+        dev = z.device
+        st = self._stepper(dev)
+        z2 = z.reshape(batch_size, -1).float()
+        V = len(self.vocab)
+        end = self.vocab["</s>"]
+        decoded = []
+        with torch.no_grad():
+            h_init, c_init = st.init_state(z2)
+            for idx in range(batch_size):
+                # a hypothesis: (word ids so far, log-probability); states live in (h, c) rows aligned with `live`
+                live = [([self.vocab["<s>"]], 0.0)]
+                h, c = h_init[idx:idx + 1].clone(), c_init[idx:idx + 1].clone()
+                completed = []
+                t = 0
+                while len(completed) < K and t < 100:
+                    t += 1
+                    n = len(live)
+                    tok = torch.tensor([hyp[0][-1] for hyp in live], dtype=torch.int64, device=dev)
+                    logits, h, c = st.step(tok, z2[idx:idx + 1].expand(n, -1), h, c)
+                    prev = torch.tensor([hyp[1] for hyp in live], dtype=torch.float32, device=dev)
+                    scores = st.log_softmax(logits, prev).reshape(-1)
+                    log_prob, indexes = torch.topk(scores, K - len(completed))
+                    live_ids = (indexes // V).tolist()
+                    word_ids = (indexes % V).tolist()
+                    new_live, keep_rows = [], []
+                    for live_id, word_id, lp in zip(live_ids, word_ids, log_prob.tolist()):
+                        hyp = (live[live_id][0] + [word_id], lp)
+                        if word_id == end:
+                            completed.append(hyp)
+                        else:
+                            new_live.append(hyp)
+                            keep_rows.append(live_id)
+                    live = new_live
+                    if len(completed) == K or not live:
+                        break
+                    rows = torch.tensor(keep_rows, dtype=torch.int64, device=dev)
+                    h, c = h.index_select(0, rows), c.index_select(0, rows)
+                completed.extend(live)
+                best = max(completed, key=lambda hyp: hyp[1]) if completed else ([self.vocab["<s>"]], 0.0)
+                decoded.append([self.vocab.id2word(w) for w in best[0]])
+        return decoded
