@@ -513,3 +513,29 @@ def check_generation_against_fixture(device):
     want = torch.searchsorted(cdf, u.cpu().double().clamp(max=float(cdf[-1]) - 1e-9))
     assert float((pick != want).float().mean()) < 0.002           # boundary draws may fall either side in f32
     vae.train()
+
+
+def check_pixelcnn_ancestral_sampling(device, B=2):
+    """PixelCNNDecoderV2.decode (dec_pixelcnn_v2.py:201-232) in eval mode: (i) the final probabilities equal the CPU oracle's
+    eval forward on the produced image; (ii) autoregressive consistency: pixel (i, j) was thresholded from a pass that saw
+    exactly the pixels before it, so it must equal [final prob at (i, j) >= 0.5] -- the masks make that probability a
+    function of earlier pixels only (any leak of the pixel itself or of later ones breaks the equality)."""
+    from oracle import image_vae_oracle as IO
+    vae = build_image_vae(device, 35)
+    vae.eval()
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(B, 32, generator=g).to(device)
+    img, probs = vae.decoder.decode(z, deterministic=True)
+    assert tuple(img.shape) == (B, 1, 28, 28) and float(((img != 0) & (img != 1)).float().sum()) == 0
+    sd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    c = IO.Ctx(sd, train=False)
+    with torch.no_grad():
+        bce = IO.decoder_reconstruct_error(c, img.cpu(), z.cpu().view(B, 1, 32))
+    p = probs.cpu().double().clamp(1e-12, 1 - 1e-12)
+    x = img.cpu().double()
+    bce_ours = -((p + 1e-12).log() * x + (1 - p + 1e-12).log() * (1 - x)).view(B, -1).sum(1)
+    assert rel_err(bce_ours, bce.view(-1)) < 1e-4
+    margin = (probs.cpu() - 0.5).abs()
+    decided = margin > 1e-4                                     # pixels whose probability sits on the threshold may go either way
+    assert bool(((probs.cpu() >= 0.5).float() == img.cpu())[decided].all())
+    vae.train()

@@ -422,3 +422,8 @@ def test_eval_statistics_against_reference_fixture(hip_device):
 def test_generation_against_reference_fixture(hip_device):
     """greedy and beam-search decoding reproduce the reference's sentences; sampling by its properties."""
     pc.check_generation_against_fixture(hip_device)
+
+
+def test_pixelcnn_ancestral_sampling(hip_device):
+    """SURVEY.md 8f row 4 (image half): PixelCNNDecoderV2.decode, 784 decoder passes."""
+    pc.check_pixelcnn_ancestral_sampling(hip_device)

@@ -90,3 +90,68 @@ def test_image_inner_loop_control_flow(emu_backend):
         for got, id_ in zip(state["picked"], ids):
             assert torch.equal(got, x_train[torch.from_numpy(id_)])
         assert steps == (30 if losses[0] == 5.0 else 99), steps
+
+
+def test_outer_loop_policy(emu_backend):
+    """text.py:447-489 as host logic: aggressive training stops the first time the validation MI drops; the learning rate
+    halves after 2 epochs without improvement once epoch >= 15 (the best weights are reloaded), training stops after 5
+    decays; the KL weight anneals linearly to 1 over warm_up epochs."""
+    import argparse
+    import torch
+    from vae_lagging_encoder_amd import evaluation as E
+    from vae_lagging_encoder_amd.factory import build_text_vae, synthetic_batch
+    from vae_lagging_encoder_amd.training import TextTrainingLoop
+    vae = build_text_vae(53, 8, 16, 4, "cpu", seed=1)
+    batches = [synthetic_batch(4, 6, 53, seed=i) for i in range(5)]
+    args = argparse.Namespace(kl_start=0.1, warm_up=2, batch_size=4, epochs=3, aggressive=1, nsamples=1, test_nepoch=5,
+                              iw_nsamples=20, momentum=0)
+    logs = []
+    loop = TextTrainingLoop(vae, batches, batches[:2], batches[:1], args, log=logs.append)
+    assert abs(loop.anneal_rate - 0.9 / (2 * 5)) < 1e-12
+    # MI sequence 0.3, 0.5, 0.4: the drop at the third check ends aggressive training, and pre_mi always tracks the last value
+    mis = iter([0.3, 0.5, 0.4])
+    saved = E.calc_mi
+    E.calc_mi = lambda model, data: next(mis)
+    try:
+        for want in (True, True, False):
+            loop.check_aggressive()
+            assert loop.aggressive is want
+        assert loop.pre_mi == 0.4 and "STOP BURNING" in logs
+    finally:
+        E.calc_mi = saved
+    # learning-rate policy: nothing before epoch 15; then a decay every second non-improving epoch; stop at the fifth
+    w0 = vae.state_dict()["encoder.linear.weight"].clone()
+    assert loop.end_of_epoch(0, 10.0, 10.0, 1.0, 50.0) is False and loop.best["loss"] == 10.0
+    with torch.no_grad():
+        vae.encoder.linear.weight.add_(1.0)                     # weights drift away from the best checkpoint
+    for ep in range(1, 15):
+        assert loop.end_of_epoch(ep, 11.0, 11.0, 1.0, 60.0) is False
+    assert loop.opt["lr"] == 1.0 and loop.decay_cnt == 0
+    stop_epoch = None
+    for ep in range(15, 40):            # decays at epochs 15 (14 stale epochs already counted), 17, 19, 21, 23 -> stop
+        if loop.end_of_epoch(ep, 11.0 + 0.1 * ep, 11.0, 1.0, 60.0):
+            stop_epoch = ep
+            break
+    assert stop_epoch == 23 and loop.decay_cnt == 5 and abs(loop.opt["lr"] - 0.5 ** 5) < 1e-12
+    assert float(loop.trainer.scal[1]) == loop.opt["lr"]          # the fused step's device-resident learning rate follows
+    assert torch.equal(vae.state_dict()["encoder.linear.weight"], w0)   # a decay reloads the best weights
+
+
+def test_outer_loop_runs_end_to_end(emu_backend):
+    """Two epochs of the whole driver on the emulator: inner loops, joint steps, MI-based stop check, validation, history."""
+    import argparse
+    import numpy as np
+    from vae_lagging_encoder_amd.factory import build_text_vae, synthetic_batch
+    from vae_lagging_encoder_amd.training import TextTrainingLoop
+    vae = build_text_vae(53, 8, 16, 4, "cpu", seed=2, model_scale=0.1)
+    train = [synthetic_batch(4, T, 53, seed=10 + i) for i, T in enumerate((5, 6, 4))]
+    args = argparse.Namespace(kl_start=0.1, warm_up=1, batch_size=4, epochs=2, aggressive=1, nsamples=1, test_nepoch=1,
+                              iw_nsamples=20, momentum=0)
+    loop = TextTrainingLoop(vae, train, train[:2], train[:1], args, log=lambda *_: None, np_rng=np.random.RandomState(3))
+    loop.trainer.inner_loop.__func__            # (bound method exists)
+    orig = loop.trainer.inner_loop
+    calls = []
+    loop.trainer.inner_loop = lambda *a, **k: calls.append(1) or orig(*a, max_iter=4, window=2, **{kk: v for kk, v in k.items()})
+    out = loop.run()
+    assert out["epochs"] == 2 and len(calls) >= 3 and np.isfinite(out["best_loss"])
+    assert loop.history[-1]["kl_weight"] == 1.0                         # warm_up = 1 epoch ... reached by the end of epoch 2

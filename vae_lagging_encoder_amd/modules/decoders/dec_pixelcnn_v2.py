@@ -197,5 +197,27 @@ class PixelCNNDecoderV2(DecoderBase):
     def log_probability(self, x, z):
         return -self.reconstruct_error(x, z)
 
-    def decode(self, z, deterministic=False):
-        raise NotImplementedError("ancestral sampling is outside the MI355X hot path (SURVEY.md section 8: out of scope)")
+    def forward_probs(self, x_img, z2d):
+        """Pixel probabilities sigma(logit) (batch, 1, 28, 28) of the decoder on image x_img given z2d (batch, nz), through the
+        HIP forward (reference PixelCNNDecoderV2.forward, dec_pixelcnn_v2.py:165-170).  Inference only."""
+        with torch.no_grad():
+            self._hip.ensure(x_img.device)
+            self._hip.forward(x_img.contiguous().float(), z2d.contiguous().float())
+            B = x_img.shape[0]
+            return torch.sigmoid(self._hip.logit.t.view(B, 1, _SIDE, _SIDE))
+
+    def decode(self, z, deterministic=False, generator=None):
+        """Ancestral sampling (reference dec_pixelcnn_v2.py:201-232): the image is filled pixel by pixel in
+        raster order, each from one full decoder pass over the image so far (784 passes) -- thresholded at 0.5 when
+        `deterministic`, else a Bernoulli draw; a last pass gives the probabilities.  -> (img (batch, 1, 28, 28), probs)."""
+        batch_size = z.size(0)
+        z2d = z.reshape(batch_size, -1)
+        img = torch.zeros(batch_size, self.nc, _SIDE, _SIDE, device=z.device)
+        for i in range(_SIDE):
+            for j in range(_SIDE):
+                p = self.forward_probs(img, z2d)[:, :, i, j]
+                if deterministic:
+                    img[:, :, i, j] = (p >= 0.5).float()
+                else:
+                    img[:, :, i, j] = (torch.rand(p.shape, device=p.device, generator=generator) < p).float()
+        return img, self.forward_probs(img, z2d)

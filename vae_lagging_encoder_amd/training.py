@@ -1,0 +1,147 @@
+"""Outer training loop of the reference's text.py, as a reusable driver around the fused inner loop.
+
+text.py:325-510, restated: per epoch a random permutation of the equal-length batches; per batch the KL weight anneals
+linearly (kl_start -> 1 over `warm_up` epochs), the AGGRESSIVE inner loop runs while the flag is set (encoder-only steps until
+the windowed loss stops improving: AggressiveTextTrainer.inner_loop = text.py:366-400), then one joint step (decoder only while
+aggressive, encoder + decoder afterwards, text.py:407-424).  Once per epoch worth of iterations the mutual information on the
+validation set decides whether aggressive training goes on ("STOP BURNING" when it drops, text.py:447-455).  Epoch end:
+validation loss / NLL / KL / PPL / MI / active units, best-checkpoint bookkeeping, learning-rate decay (x0.5 after
+`decay_epoch` = 2 epochs without improvement once epoch >= 15, reload the best weights, stop after `max_decay` = 5 decays,
+text.py:463-489), a test-set pass every `test_nepoch` epochs.  The arithmetic is the HIP hot path throughout; the policy is
+plain host code with the reference's constants and comparison operators.
+"""
+import copy
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import evaluation as E
+from .trainer import AggressiveTextTrainer
+
+CLIP_GRAD = 5.0          # text.py:17-20
+DECAY_EPOCH = 2
+LR_DECAY = 0.5
+MAX_DECAY = 5
+
+
+class TextTrainingLoop(object):
+    """args fields read (text.py's argparse names): kl_start, warm_up, batch_size, epochs, aggressive, nsamples, test_nepoch,
+    iw_nsamples, momentum (must be 0: the fused step is plain SGD, the reference default)."""
+
+    def __init__(self, vae, train_batches, val_batches, test_batches, args, n_train_sentences=None, trainer=None,
+                 log=print, np_rng=None, seed=783435):
+        self.vae, self.args, self.log = vae, args, log
+        self.train_batches, self.val_batches, self.test_batches = train_batches, val_batches, test_batches
+        if getattr(args, "momentum", 0) != 0:
+            raise ValueError("the fused driver implements optim.SGD(momentum=0), the reference's default (text.py:325-326)")
+        self.trainer = trainer if trainer is not None else AggressiveTextTrainer(vae, lr=1.0, clip=CLIP_GRAD, seed=seed)
+        self.rng = np_rng if np_rng is not None else np.random
+        n = n_train_sentences if n_train_sentences is not None else sum(int(b.shape[0]) for b in train_batches)
+        self.n_train = n
+        self.kl_weight = float(args.kl_start)
+        self.anneal_rate = (1.0 - args.kl_start) / (args.warm_up * (n / args.batch_size))      # text.py:339
+        self.opt = {"not_improved": 0, "lr": 1.0, "best_loss": 1e4}                              # text.py:251
+        self.aggressive = bool(args.aggressive)
+        self.iter_ = self.decay_cnt = 0
+        self.pre_mi = 0.0
+        self.best = {"loss": 1e4, "nll": 0.0, "kl": 0.0, "ppl": 0.0, "state": None}
+        self.history = []
+
+    # -- pieces the tests drive directly --------------------------------------------------------------------------------------
+    def _eval_mi_au(self):
+        self.vae.eval()
+        with torch.no_grad():
+            mi = E.calc_mi(self.vae, self.val_batches)
+            au, _ = E.calc_au(self.vae, self.val_batches)
+        self.vae.train()
+        return mi, au
+
+    def check_aggressive(self):
+        """text.py:447-455: called when a full epoch worth of iterations has passed while aggressive."""
+        self.vae.eval()
+        with torch.no_grad():
+            cur_mi = E.calc_mi(self.vae, self.val_batches)
+        self.vae.train()
+        self.log("pre mi:%.4f. cur mi:%.4f" % (self.pre_mi, cur_mi))
+        if cur_mi - self.pre_mi < 0:
+            self.aggressive = False
+            self.log("STOP BURNING")
+        self.pre_mi = cur_mi
+
+    def end_of_epoch(self, epoch, loss, nll, kl, ppl):
+        """Best-checkpoint and learning-rate policy (text.py:463-489).  Returns True when training should stop."""
+        if loss < self.best["loss"]:
+            self.log("update best loss")
+            self.best.update(loss=loss, nll=nll, kl=kl, ppl=ppl, state=copy.deepcopy(self.vae.state_dict()))
+        if loss > self.opt["best_loss"]:
+            self.opt["not_improved"] += 1
+            if self.opt["not_improved"] >= DECAY_EPOCH and epoch >= 15:
+                self.opt["best_loss"] = loss
+                self.opt["not_improved"] = 0
+                self.opt["lr"] *= LR_DECAY
+                if self.best["state"] is not None:
+                    self.vae.load_state_dict(self.best["state"])
+                self.log("new lr: %f" % self.opt["lr"])
+                self.decay_cnt += 1
+                self.trainer.set_lr(self.opt["lr"])
+        else:
+            self.opt["not_improved"] = 0
+            self.opt["best_loss"] = loss
+        return self.decay_cnt == MAX_DECAY
+
+    # -- the loop ---------------------------------------------------------------------------------------------------------------
+    def run(self):
+        args, tr = self.args, self.trainer
+        log_niter = max(1, (self.n_train // args.batch_size) // 10)                               # text.py:263
+        start = time.time()
+        self.vae.train()
+        for epoch in range(args.epochs):
+            rep_rec = rep_kl = 0.0
+            rep_sents = 0
+            for i in self.rng.permutation(len(self.train_batches)):
+                batch = self.train_batches[i]
+                bsz, slen = batch.shape
+                rep_sents += bsz
+                self.kl_weight = min(1.0, self.kl_weight + self.anneal_rate)
+                if self.aggressive:
+                    tr.inner_loop(self.train_batches, batch, self.kl_weight, np_rng=self.rng)
+                tr.reset_stats()
+                tr.step(batch, self.kl_weight, update="decoder" if self.aggressive else "both")
+                st = tr.read_stats()
+                rep_rec += st["rec_sum"]
+                rep_kl += st["kl_sum"]
+                if self.iter_ % log_niter == 0:
+                    train_loss = (rep_rec + rep_kl) / rep_sents
+                    if self.aggressive or epoch == 0:
+                        mi, au = self._eval_mi_au()
+                        self.log("epoch: %d, iter: %d, avg_loss: %.4f, kl: %.4f, mi: %.4f, recon: %.4f,au %d, time elapsed %.2fs" % (
+                            epoch, self.iter_, train_loss, rep_kl / rep_sents, mi, rep_rec / rep_sents, au, time.time() - start))
+                    else:
+                        self.log("epoch: %d, iter: %d, avg_loss: %.4f, kl: %.4f, recon: %.4f,time elapsed %.2fs" % (
+                            epoch, self.iter_, train_loss, rep_kl / rep_sents, rep_rec / rep_sents, time.time() - start))
+                    rep_rec = rep_kl = 0.0
+                    rep_sents = 0
+                self.iter_ += 1
+                if self.aggressive and self.iter_ % len(self.train_batches) == 0:
+                    self.check_aggressive()
+            self.log("kl weight %.4f" % self.kl_weight)
+            self.vae.eval()
+            with torch.no_grad():
+                loss, nll, kl, ppl, mi = E.test(self.vae, self.val_batches, "VAL", args, verbose=False, np_rng=self.rng)
+                au, _ = E.calc_au(self.vae, self.val_batches)
+            self.log("VAL --- avg_loss: %.4f, kl: %.4f, mi: %.4f, nll: %.4f, ppl: %.4f, %d active units" % (loss, kl, mi, nll, ppl, au))
+            self.history.append(dict(epoch=epoch, loss=loss, nll=nll, kl=kl, ppl=ppl, mi=mi, au=au, aggressive=self.aggressive,
+                                     kl_weight=self.kl_weight, lr=self.opt["lr"]))
+            stop = self.end_of_epoch(epoch, loss, nll, kl, ppl)
+            if stop:
+                break
+            if epoch % getattr(args, "test_nepoch", 5) == 0 and self.test_batches:
+                with torch.no_grad():
+                    E.test(self.vae, self.test_batches, "TEST", args, verbose=False, np_rng=self.rng)
+            self.vae.train()
+        if self.best["state"] is not None:
+            self.vae.load_state_dict(self.best["state"])
+        return dict(best_loss=self.best["loss"], best_nll=self.best["nll"], best_kl=self.best["kl"], best_ppl=self.best["ppl"],
+                    epochs=len(self.history), history=self.history)
