@@ -50,6 +50,18 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
                 const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C, long ldc, int accumulate,
                 const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
                 float* ws, long ws_floats, void* stream);
+/* LSTMDecoder's vocabulary projection fused with the statistics of nn.CrossEntropyLoss (modules/decoders/dec_lstm.py:117,
+ * 140-146): logits = A . B^T (operands as lv_gemm_b16, transA = 0) written once as IEEE binary16 [M][ldl16] (RNE of the f32
+ * accumulators; the f32 logits image is never produced) + per-row statistics over 64-column pieces, part [M][parts] (max,
+ * sum exp(x - max)) with parts = lv_gemm_b16_nll_parts(N), + tgt_logit [M] = the logit of row r's target token
+ * ids[(r % Bsz) * ids_stride + r / Bsz + tgt_off].  lv_softmax_nll_merge_f32 finishes lse / nll; lv_softmax_nll_bwd_h16 is the
+ * backward over the binary16 image.  ldl16 % 8 == 0. */
+int lv_gemm_b16_nll_parts(int N);
+int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, uint16_t* logits16, long ldl16,
+                    const int64_t* ids, long ids_stride, int tgt_off, int Bsz, float* part, float* tgt_logit, void* stream);
+int lv_softmax_nll_merge_f32(const float* part, int nparts, const float* tgt_logit, float* lse, float* nll, int R, void* stream);
+int lv_softmax_nll_bwd_h16(const uint16_t* logits16, long ldl, const float* lse, const int64_t* ids, long ids_stride, int tgt_off,
+                           const float* rowscale, uint16_t* dlogits, long ldo, int T, int B, int V, void* stream);
 /* src f32 [R][C](lds) -> dst bf16 [R][C](ldd) and/or dstT bf16 [C][R](ldt), round-to-nearest-even; either may be NULL */
 int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
                     void* stream);

@@ -159,3 +159,8 @@ def test_noise_step(emu_backend):
     emu_backend.lv_rng_keepmask_u8(P(a2), n_in, 0.5, P(st2), 1, None)
     emu_backend.lv_rng_keepmask_u8(P(b2), n_out, 0.3, P(st2), 2, None)
     assert torch.equal(eps, e2) and torch.equal(m1, a2) and torch.equal(m2, b2)
+
+
+@pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (1, 3, 130, 8)])
+def test_gemm_b16_nll_fused(emu_backend, cfg):
+    K.test_gemm_b16_nll_fused(emu_backend, CPU, *cfg)

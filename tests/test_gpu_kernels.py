@@ -873,3 +873,46 @@ def test_noise_step_equals_separate_draws(lib, hip_device):
     # eval mode: no masks
     lib.lv_rng_noise_step(P(eps), n_eps, None, 0, 0.5, None, 0, 0.5, P(st), 1, _s(dev))
     assert st.cpu().tolist() == [783435, 7] and not torch.equal(eps, e2)
+
+
+@pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (4, 33, 1000, 128)])
+def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
+    """lv_gemm_b16_nll + lv_softmax_nll_merge_f32 + lv_softmax_nll_bwd_h16 against float64: binary16 logits image = RNE of the
+    exact product of the bf16 operands, lse / nll taken from the ROUNDED logits, gradient rows sum to zero."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(T * 7 + V)
+    R = T * B
+    ldv = (V + 31) // 32 * 32
+    O = (torch.randn(R, H, generator=g)).to(torch.bfloat16)
+    W = (torch.randn(V, H, generator=g) * (3.0 / H ** 0.5)).to(torch.bfloat16)
+    x = torch.randint(0, V, (B, T + 1), generator=g)
+    ref = (O.double() @ W.double().t())                                   # [R][V], rows r = t*B + b
+    ref16 = ref.to(torch.float16)
+    O16, W16 = O.view(torch.int16).to(dev), W.view(torch.int16).to(dev)
+    l16 = torch.full((R, ldv), 0x7E00, dtype=torch.int16, device=dev)
+    nparts = lib.lv_gemm_b16_nll_parts(V)
+    part = torch.full((R, 2 * nparts), float("nan"), device=dev)
+    tgt = torch.full((R,), float("nan"), device=dev)
+    xd = x.to(dev)
+    lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldv, P(xd), T + 1, 1, B, P(part), P(tgt), _s(dev))
+    got16 = l16[:, :V].cpu().view(torch.float16)
+    # binary16 RNE of an f32 accumulation of exact bf16 products: within 1 ulp of the float64 result's rounding
+    assert float((got16.double() - ref16.double()).abs().max()) <= 2.0 * float(ref16.double().abs().max()) * 2 ** -11
+    lse = torch.empty(R, device=dev); nll = torch.empty(R, device=dev)
+    lib.lv_softmax_nll_merge_f32(P(part), nparts, P(tgt), P(lse), P(nll), R, _s(dev))
+    tg = x[:, 1:].t().reshape(-1)                                          # row r = t*B + b -> x[b][t+1]
+    lse_r = torch.logsumexp(got16.double(), dim=1)
+    nll_r = lse_r - got16.double().gather(1, tg.unsqueeze(1)).squeeze(1)
+    assert float((lse.cpu().double() - lse_r).abs().max()) < 1e-5 * float(lse_r.abs().max())
+    assert float((nll.cpu().double() - nll_r).abs().max()) < 1e-5 * float(nll_r.abs().max()) + 1e-5
+    rs = torch.rand(B, generator=g) + 0.5
+    dl = torch.full((R, ldv), 0x7FC0, dtype=torch.int16, device=dev)
+    rs_d = rs.to(dev)
+    lib.lv_softmax_nll_bwd_h16(P(l16), ldv, P(lse), P(xd), T + 1, 1, P(rs_d), P(dl), ldv, T, B, V, _s(dev))
+    gref = torch.softmax(got16.double(), dim=1)
+    gref[torch.arange(R), tg] -= 1.0
+    gref = gref * rs[torch.arange(R) % B].double().unsqueeze(1)
+    got = dl[:, :V].cpu().view(torch.bfloat16).double()
+    assert float((got - gref).abs().max()) < 2 ** -8 * float(gref.abs().max()) + 1e-7
+    assert float(got.sum(1).abs().max()) < 2 ** -7 * float(rs.max())      # rows sum to ~0 up to the bf16 rounding of the (p_target - 1) entry
+    assert bool((dl[:, V:] == 0).all())

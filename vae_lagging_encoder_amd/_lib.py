@@ -22,6 +22,10 @@ SIGNATURES = {
     "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_b16_nll_parts": [_i],
+    "lv_gemm_b16_nll": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp],
+    "lv_softmax_nll_merge_f32": [_vp, _i, _vp, _vp, _vp, _i, _vp],
+    "lv_softmax_nll_bwd_h16": [_vp, _l, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_cvt_bf16_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
@@ -118,7 +122,7 @@ class Lib(object):
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):

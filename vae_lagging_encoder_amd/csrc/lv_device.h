@@ -18,6 +18,45 @@ static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
 #define LV_WAIT_VMEM() do { } while (0)
+// IEEE binary16 <-> f32 in software (round-to-nearest-even, as v_cvt_f16_f32 does): g++ 11 has no _Float16
+static inline uint16_t lv_f32_to_f16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x7F800000u) return (uint16_t)(sign | (u > 0x7F800000u ? 0x7E00u : 0x7C00u));       // nan / inf
+    if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                       // rounds to inf
+    if (u < 0x33000001u) return (uint16_t)sign;                                                    // rounds to zero
+    if (u < 0x38800000u) {                                                                         // subnormal half
+        const int shift = 126 - (int)(u >> 23);                                                    // 14 .. 24 bits to drop
+        const uint32_t mant = (u & 0x7FFFFFu) | 0x800000u;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((u - 0x38000000u) >> 13);
+    const uint32_t rem = u & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+static inline float lv_f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+            u = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3FFu) << 13);
+        }
+    } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -55,6 +94,18 @@ __device__ __forceinline__ void lv_glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// IEEE binary16 <-> f32 (v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even)
+__device__ __forceinline__ uint16_t lv_f32_to_f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+__device__ __forceinline__ float lv_f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
 #endif
 
 #include <stdint.h>

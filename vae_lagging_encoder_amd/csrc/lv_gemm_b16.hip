@@ -44,6 +44,11 @@ struct GemmQ {
     int tilesM, tilesN;
     int splits, kt_per_split;
     float* ws;
+    // fused vocabulary projection + token-NLL statistics (lv_gemm_b16_nll): C is written as binary16 and never as f32
+    uint16_t* C16; long ldc16;
+    const int64_t* ids; long ids_stride; int tgt_off; int Bsz;
+    float2* part; int nparts;          // [M][nparts] (max, sum exp(x - max)) of each 64-column piece of a row
+    float* tgt;                        // [M] the target token's logit
 };
 
 __device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int valid) {
@@ -317,7 +322,7 @@ template <> struct SecondPair<true> { int unused; };
 // for long K loops (dO: 384 vs 478 us).  SINGLE = true: one pair (32 KB, 3 workgroups per CU), load -> barrier -> MFMA ->
 // barrier with the other workgroups hiding the transfer -- best when a workgroup only sees a few K tiles and prologue /
 // epilogue dominate (Gx, K = 512: 55 vs 63 us; dX under split-K: 55 vs 60 us).  Measured: profiles/r02e_gemm_shapes.txt.
-template <bool SINGLE>
+template <bool SINGLE, bool NLL = false>
 __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
     // separate LDS objects per buffer: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove
     // disjoint (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
@@ -465,6 +470,67 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
 
     }
 
+    if constexpr (NLL) {
+        // ---- fused epilogue of the vocabulary projection: the 128 x 128 tile goes through LDS as binary16 (the K loop's
+        // 32 KB are free now: rows 0..63 in As0, 64..127 in Bs0), so that (i) the logits leave as 16-byte row segments
+        // instead of 4-byte pieces -- half the bytes of the f32 image, which is never written -- and (ii) every thread owns
+        // half a tile row (64 consecutive logits) and emits its (max, sum exp) for the online-softmax merge, plus the
+        // target token's logit if it falls into its piece.  Statistics are taken from the ROUNDED values: forward and
+        // backward then see the same logits and sum_c softmax = 1 holds exactly for the gradient.
+        uint16_t* const tile0 = reinterpret_cast<uint16_t*>(&As0[0][0]);
+        uint16_t* const tile1 = reinterpret_cast<uint16_t*>(&Bs0[0][0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                    (rr < 64 ? tile0 : tile1)[(rr & 63) * BT + cl] = lv_f32_to_f16_bits(p.alpha * acc[i][j][e]);
+                }
+            }
+        __syncthreads();
+        const int rr = t >> 1, half = t & 1;
+        const int row = m0 + rr;
+        if (row < p.M) {
+            const uint16_t* src = (rr < 64 ? tile0 : tile1) + (rr & 63) * BT + 64 * half;
+            const int c0 = n0 + 64 * half;
+            uint4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = reinterpret_cast<const uint4*>(src)[k];
+            uint16_t* dst = p.C16 + (long)row * p.ldc16 + c0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + 8 * k + 8 <= p.ldc16) reinterpret_cast<uint4*>(dst)[k] = q[k];
+            float v[64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t wv[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+                for (int h2 = 0; h2 < 4; ++h2) {
+                    v[8 * k + 2 * h2] = lv_f16_bits_to_f32((uint16_t)(wv[h2] & 0xFFFFu));
+                    v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                if (c0 + k < p.N) mx = fmaxf(mx, v[k]);
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                if (c0 + k < p.N) sm += expf(v[k] - mx);
+            p.part[(long)row * p.nparts + 2 * tn + half] = make_float2(mx, sm);
+            const int tt = row / p.Bsz, bb = row % p.Bsz;
+            long tg = p.ids[(long)bb * p.ids_stride + tt + p.tgt_off];
+            if (tg < 0) tg = 0;
+            if (tg >= p.N) tg = p.N - 1;
+            const int tl = (int)tg - c0;
+            if (tl >= 0 && tl < 64) p.tgt[row] = lv_f16_bits_to_f32(src[tl]);
+        }
+        return;
+    }
     const bool split = p.splits > 1;
     float* const out = split ? p.ws + (long)blockIdx.y * p.M * p.N : p.C;
     const long ldo = split ? p.N : p.ldc;
@@ -613,6 +679,39 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
     if (C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(4 * H, 64)), dim3(256), 0, stream, src, lds, 4 * H, C,
               dst, ldd, dstT, ldt, H);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+
+// LSTMDecoder's vocabulary projection fused with the statistics of nn.CrossEntropyLoss (modules/decoders/dec_lstm.py:117,
+// 140-146): logits = A . B^T (bf16 operands as lv_gemm_b16, transA = 0) are written ONCE, as binary16 [M][ldl16] (RNE of the
+// f32 accumulators; the f32 logits image of the unfused route -- 510 MB at the Yahoo shape -- is never produced), together
+// with per-row partial statistics over 64-column pieces, part [M][nparts] (max, sum exp(x - max)), nparts =
+// lv_gemm_b16_nll_parts(N), and tgt_logit [M], the logit of row r's target token ids[(r % Bsz) * ids_stride + r / Bsz +
+// tgt_off].  lv_softmax_nll_merge_f32 turns them into lse / nll; lv_softmax_nll_bwd_h16 reads the binary16 image back.
+extern "C" int lv_gemm_b16_nll_parts(int N) { return 2 * lv_cdiv(N, BT); }
+
+extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                               uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
+                               float* part, float* tgt_logit, void* stream) {
+    if (M < 0 || N <= 0 || K <= 0 || Bsz <= 0) return LV_ERR_SHAPE;
+    if (M == 0) return LV_OK;
+    if (!A || !B || !logits16 || !ids || !part || !tgt_logit) return LV_ERR_ARG;
+    if (lda < K || ldb < K || ldl16 < N) return LV_ERR_SHAPE;
+    if (lda % 8 != 0 || ldb % 8 != 0 || ldl16 % 8 != 0 || (((uintptr_t)A) & 15) != 0 || (((uintptr_t)B) & 15) != 0 ||
+        (((uintptr_t)logits16) & 15) != 0 || (((uintptr_t)part) & 7) != 0)
+        return LV_ERR_ALIGN;
+    GemmQ p{};
+    p.A = A; p.B = B; p.C = nullptr; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = 0; p.alpha = 1.f; p.accumulate = 0;
+    p.add1 = nullptr; p.add2 = nullptr; p.mod1 = p.mod2 = 1; p.ws = nullptr;
+    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
+    p.splits = 1; p.kt_per_split = lv_cdiv(K, BK);
+    p.C16 = logits16; p.ldc16 = ldl16; p.ids = ids; p.ids_stride = ids_stride; p.tgt_off = tgt_off; p.Bsz = Bsz;
+    p.part = reinterpret_cast<float2*>(part); p.nparts = 2 * p.tilesN; p.tgt = tgt_logit;
+    dim3 grid((unsigned)((long)p.tilesM * p.tilesN), 1), block(256);
+    LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, true>), grid, block, 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -173,6 +173,70 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_b16_kernel(const float* _
     for (long k = V + tid; k < ldo; k += 256) orow[k] = 0;      // keep the row padding finite (zero)
 }
 
+// Fused route (lv_gemm_b16_nll): merge the per-piece (max, sum exp) statistics of every logits row -- one wave per row,
+// fixed merge order -- into lse[r], and nll[r] = lse[r] - target logit.
+__global__ __launch_bounds__(256) void softmax_nll_merge_kernel(const float2* __restrict__ part, int nparts,
+                                                                const float* __restrict__ tgt, float* __restrict__ lse,
+                                                                float* __restrict__ nll, int R) {
+    const int r = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int l = (int)threadIdx.x & 63;
+    if (r >= R) return;
+    float m = -INFINITY, s = 0.f;
+    for (int i = l; i < nparts; i += 64) {
+        const float2 q = part[(long)r * nparts + i];
+        ms_merge(m, s, q.x, q.y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float m2 = __shfl_xor(m, d, 64), s2 = __shfl_xor(s, d, 64);
+        ms_merge(m, s, m2, s2);
+    }
+    if (l == 0) {
+        const float L = m + logf(s);
+        lse[r] = L;
+        nll[r] = L - tgt[r];
+    }
+}
+
+// dlogits as a bf16 image from the binary16 logits image of the fused route: (exp(x - lse) - [c == target]) * rowscale[b]
+__global__ __launch_bounds__(256) void softmax_nll_bwd_h16_kernel(const uint16_t* __restrict__ logits16, long ldl,
+                                                                  const float* __restrict__ lse, const int64_t* __restrict__ ids,
+                                                                  long ids_stride, int tgt_off, const float* __restrict__ rowscale,
+                                                                  uint16_t* __restrict__ out, long ldo, int T, int B, int V) {
+    const int r = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const uint16_t* row = logits16 + (long)r * ldl;
+    uint16_t* orow = out + (long)r * ldo;
+    const int t = r / B, b = r % B;
+    long tg = ids[(long)b * ids_stride + t + tgt_off];
+    if (tg < 0) tg = 0;
+    if (tg >= V) tg = V - 1;
+    const float L = lse[r], sc = rowscale[b];
+    const int itg = (int)tg;
+    const bool vec = (ldl % 8 == 0) && ((((uintptr_t)logits16) & 15) == 0) && (ldo % 8 == 0) && ((((uintptr_t)out) & 15) == 0);
+    int done = 0;
+    if (vec) {
+        const int V8 = V & ~7;
+        for (int k = tid * 8; k < V8; k += 2048) {
+            const uint4 q = *reinterpret_cast<const uint4*>(row + k);
+            const uint32_t wv[4] = {q.x, q.y, q.z, q.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float x0 = lv_f16_bits_to_f32((uint16_t)(wv[h] & 0xFFFFu)), x1 = lv_f16_bits_to_f32((uint16_t)(wv[h] >> 16));
+                const float g0 = (expf(x0 - L) - (k + 2 * h == itg ? 1.f : 0.f)) * sc;
+                const float g1 = (expf(x1 - L) - (k + 2 * h + 1 == itg ? 1.f : 0.f)) * sc;
+                o[h] = lv_pack_bf16x2(g0, g1);
+            }
+            *reinterpret_cast<uint4*>(orow + k) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        done = V8;
+    }
+    for (int k = done + tid; k < V; k += 256)
+        orow[k] = (uint16_t)lv_f32_to_bf16_bits((expf(lv_f16_bits_to_f32(row[k]) - L) - (k == itg ? 1.f : 0.f)) * sc);
+    for (long k = V + tid; k < ldo; k += 256) orow[k] = 0;      // keep the row padding finite (zero)
+}
+
 // rec[b] = sum_t nll[t][b]; loss[b] = rec[b] + kl_weight * kl[b].  One wave per sequence: lanes stride over t (each
 // keeps a sequential partial), then a fixed-shape butterfly -- deterministic, and one memory round trip instead of T.
 __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ nll, const float* __restrict__ kl,
@@ -368,6 +432,32 @@ extern "C" int lv_loss_assemble_f32(const float* nll, const float* kl, const flo
     if (T < 0 || B <= 0) return LV_ERR_SHAPE;
     LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(64 * LA_WAVES), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale,
               dkl, acc, T, B);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// Second half of the fused vocabulary projection + NLL (lv_gemm_b16_nll): part [R][nparts] (max, sum exp) pairs and the target
+// logits -> lse [R], nll [R].
+extern "C" int lv_softmax_nll_merge_f32(const float* part, int nparts, const float* tgt_logit, float* lse, float* nll, int R,
+                                        void* stream) {
+    if (!part || !tgt_logit || !lse || !nll) return LV_ERR_ARG;
+    if (R < 0 || nparts <= 0) return LV_ERR_SHAPE;
+    if (R == 0) return LV_OK;
+    LV_LAUNCH(softmax_nll_merge_kernel, dim3((unsigned)lv_cdiv(R, 4)), dim3(256), 0, stream, reinterpret_cast<const float2*>(part),
+              nparts, tgt_logit, lse, nll, R);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// lv_softmax_nll_bwd_b16 reading the binary16 logits image of the fused route.
+extern "C" int lv_softmax_nll_bwd_h16(const uint16_t* logits16, long ldl, const float* lse, const int64_t* ids, long ids_stride,
+                                      int tgt_off, const float* rowscale, uint16_t* dlogits, long ldo, int T, int B, int V,
+                                      void* stream) {
+    if (!logits16 || !ids || !lse || !rowscale || !dlogits) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || V <= 0 || ldl < V || ldo < V) return LV_ERR_SHAPE;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(softmax_nll_bwd_h16_kernel, dim3((unsigned)(T * B)), dim3(256), 0, stream, logits16, ldl, lse, ids, ids_stride,
+              tgt_off, rowscale, dlogits, ldo, T, B, V);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -121,6 +121,16 @@ class _NS(object):
     pass
 
 
+class _DecWS(_NS):
+    """Decoder workspace; `logits` (f32 [T*B][ldl], 510 MB at the bench shape) is created on first use."""
+
+    @property
+    def logits(self):
+        if self._logits is None:
+            self._logits = self._alloc()
+        return self._logits
+
+
 # bench.py's roofline leg: when set to a dict, kernel-launch groups are bracketed by HIP events recorded on the launch
 # stream and (start, end, work, launches) is appended under the group name (measurement only; None normally).
 # work = flops for the GEMM groups, timesteps for the LSTM groups.
@@ -554,6 +564,8 @@ class LSTMDecoderEngine(object):
         # The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only): its bf16
         # weight images and packed recurrent weights are rebuilt only when weights_version() changes.
         self.cache_weight_images = True
+        # bf16 image path: vocabulary projection fused with the NLL statistics, binary16 logits (lv_gemm_b16_nll)
+        self.fused_nll = True
         self.wgen = 0
         self._wimg = None
         self._side = None
@@ -620,8 +632,9 @@ class LSTMDecoderEngine(object):
         ldl = _round_up(V, 32)
 
         def build():
-            w = _NS()
+            w = _DecWS()
             w.ldl = ldl
+            w._alloc = lambda: c.f32(Td * Bd, ldl)
             w.X = c.f32(Td * Bd, ni)
             w.Zp = c.f32(Bd, 4 * H)
             w.Gx = c.f32(Td * Bd, 4 * H)
@@ -629,7 +642,7 @@ class LSTMDecoderEngine(object):
             w.cs = c.f32(Td + 1, Bd, H)
             w.gates = c.f32(Td * Bd, 4 * H)
             w.O = c.f32(Td * Bd, H)
-            w.logits = c.f32(Td * Bd, ldl)
+            w._logits = None                 # f32 logits image: allocated on first use (the fused bf16 route never needs it)
             w.lse = c.f32(Td * Bd)
             w.nll = c.f32(Td * Bd)
             w.rec = c.f32(Bd)
@@ -667,6 +680,11 @@ class LSTMDecoderEngine(object):
             b.OT = c.i16(H, b.ldr)            # ... transposed         [H][T*B]
             # (pred_linear.weight [V][H] and its transpose [H][V]: engine-level images, _weight_images)
             b.dl = c.i16(Td * Bd, b.ldv)      # dlogits                [T*B][V]
+            # fused projection + NLL statistics (lv_gemm_b16_nll): binary16 logits image, per-piece (max, sum exp), target logit
+            b.l16 = c.i16(Td * Bd, b.ldv)
+            b.nparts = self.lib.lv_gemm_b16_nll_parts(V)
+            b.part = c.f32(Td * Bd, 2 * b.nparts)
+            b.tgt = c.f32(Td * Bd)
             return b
         return c.get(("b16", Bd, Td), build)
 
@@ -739,10 +757,18 @@ class LSTMDecoderEngine(object):
         if b16 is not None:
             lib.lv_cvt_bf16_f32(P(w.O), H, Td * B, H, P(b16.O), H, P(b16.OT), b16.ldr, s)
             wi = self.refresh_weight_images(B, x.device)
-            _gemm16(lib, s, 0, Td * B, V, H, P(b16.O), H, P(wi.pred), H, P(w.logits), w.ldl)
+            if self.fused_nll:
+                # logits leave the GEMM once, as binary16, with the online-softmax statistics taken in its epilogue
+                with _prof("gemm_bf16", 2.0 * Td * B * V * H):
+                    lib.lv_gemm_b16_nll(Td * B, V, H, P(b16.O), H, P(wi.pred), H, P(b16.l16), b16.ldv, P(x), T, 1, B,
+                                        P(b16.part), P(b16.tgt), s)
+                lib.lv_softmax_nll_merge_f32(P(b16.part), b16.nparts, P(b16.tgt), P(w.lse), P(w.nll), Td * B, s)
+            else:
+                _gemm16(lib, s, 0, Td * B, V, H, P(b16.O), H, P(wi.pred), H, P(w.logits), w.ldl)
         else:
             _gemm(lib, s, 0, 1, Td * B, V, H, P(w.O), H, P(v["pred_linear.weight"]), H, P(w.logits), w.ldl, prec=self.precision)
-        lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
+        if not (b16 is not None and self.fused_nll):
+            lib.lv_softmax_nll_fwd_f32(P(w.logits), w.ldl, P(x), T, 1, P(w.lse), P(w.nll), Td, B, V, s)
         if want_rec:
             # rec[b] = sum_t nll[t][b]  (loss assembly kernel with kl weight 0); the fused driver sums nll itself
             lib.lv_vae_loss_f32(P(w.nll), P(w.klz), P(w.zero1), P(w.loss), P(w.rec), Td, B, s)
@@ -768,7 +794,9 @@ class LSTMDecoderEngine(object):
         gwih = gv["lstm.weight_ih_l0"]
         dev = x.device
         b16 = self._b16(B, Td)
-        if b16 is not None:
+        if b16 is not None and self.fused_nll:
+            lib.lv_softmax_nll_bwd_h16(P(b16.l16), b16.ldv, P(w.lse), P(x), T, 1, P(drec), P(b16.dl), b16.ldv, Td, B, V, s)
+        elif b16 is not None:
             lib.lv_softmax_nll_bwd_b16(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), P(b16.dl), b16.ldv, Td, B, V, s)
         else:
             lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)

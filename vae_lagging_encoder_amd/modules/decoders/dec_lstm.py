@@ -114,7 +114,11 @@ class LSTMDecoder(DecoderBase):
         with torch.no_grad():
             # run the teacher-forced path on `input` as the source sequence: append a dummy target column
             x = torch.cat((input, input[:, -1:]), dim=1)
-            self.reconstruct_error(x, z)
+            fused, self._hip.fused_nll = self._hip.fused_nll, False       # this view needs the f32 logits image
+            try:
+                self.reconstruct_error(x, z)
+            finally:
+                self._hip.fused_nll = fused
             w = self._hip._ws(B * ns, T)
             V = len(self.vocab)
             return w.logits[:, :V].reshape(T, B * ns, V).transpose(0, 1).contiguous()
