@@ -269,6 +269,16 @@ int lv_col2im_f32(const float* dcol, long ldcol, float* dx, int N, int H, int W,
 int lv_conv_pack_w_f32(const float* w /*[Cout][Cin][KK]*/, float* wg /*[Cout][KK][Cin]*/, int Cout, int Cin, int KK, void* stream);
 int lv_conv_unpack_dw_f32(const float* dwg, float* dw, int Cout, int Cin, int KK, int accumulate, void* stream);
 int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream);   /* MaskedConv2d.forward: weight.data.mul_(mask) */
+/* Direct (implicit-GEMM) 32 -> 32 convolutions on 28 x 28 maps: the masked k x k convolutions of PixelCNNBlock
+ * (dec_pixelcnn_v2.py:12-62), no im2col buffer; masked taps are skipped in forward / data gradient (the type-B taps are a raster
+ * prefix), the weight gradient covers all k*k taps (lv_conv_direct.hip).  in / out NHWC [N][28][28][32]; k odd <= 7. */
+long lv_conv32_wpack_floats(int ntaps);
+int lv_conv32_pack_f32(const float* w /*[32][32][k*k]*/, float* wp, int k, int ntaps, int transpose, void* stream);
+int lv_conv32_f32(const float* in, const float* wp, float* out, int N, int k, int ntaps, int mirror, int accumulate, void* stream);
+int lv_conv32_wgrad_slabs(int N);
+long lv_conv32_wgrad_ws_floats(int N, int k);
+int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*k]*/, float* ws, int N, int k, int accumulate,
+                        void* stream);
 /* nn.BatchNorm2d in train mode (batch statistics, running stats momentum update with unbiased variance) fused with the
  * residual add and nn.ELU that follow it in ResNetBlock / PixelCNNBlock; backward with ELU' from the saved output */
 int lv_bn_workspace_floats(int C);

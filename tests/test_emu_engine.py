@@ -47,3 +47,9 @@ def test_eval_statistics_against_reference_fixture_emulated(emu_backend):
 
 def test_generation_against_reference_fixture_emulated(emu_backend):
     pc.check_generation_against_fixture("cpu")
+
+
+def test_image_step_fused_emulated(emu_backend):
+    """The Omniglot inner step (ResNet encoder + PixelCNN decoder, direct 32 -> 32 convolutions, BN, Adam) against the reference
+    fixture on the emulator build of the same kernel sources (~1 min)."""
+    pc.check_image_step_fused("image_b6", "cpu")

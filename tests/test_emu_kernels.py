@@ -164,3 +164,8 @@ def test_noise_step(emu_backend):
 @pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (1, 3, 130, 8)])
 def test_gemm_b16_nll_fused(emu_backend, cfg):
     K.test_gemm_b16_nll_fused(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False)])
+def test_conv32_direct(emu_backend, cfg):
+    K.test_conv32_direct_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)

@@ -916,3 +916,45 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
     assert float((got - gref).abs().max()) < 2 ** -8 * float(gref.abs().max()) + 1e-7
     assert float(got.sum(1).abs().max()) < 2 ** -7 * float(rs.max())      # rows sum to ~0 up to the bf16 rounding of the (p_target - 1) entry
     assert bool((dl[:, V:] == 0).all())
+
+
+@pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (1, 7, False)])
+def test_conv32_direct_fwd_dgrad_wgrad(lib, hip_device, N, k, masked):
+    """lv_conv32_* (direct 32 -> 32 convolution on 28 x 28 maps) against torch conv2d in float64: forward and data gradient over
+    the mask's tap prefix, weight gradient over all taps (the reference keeps gradients on masked taps)."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(N * 10 + k)
+    C, S = 32, 28
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5
+    dy = torch.randn(N, C, S, S, generator=g)
+    nt = (k // 2) * k + k // 2 + 1 if masked else k * k
+    mask = torch.zeros(k * k)
+    mask[:nt] = 1
+    wm = (w.reshape(C, C, k * k) * mask).reshape(C, C, k, k)                 # what MaskedConv2d leaves in the weight
+    x64 = x.double().requires_grad_(True)
+    w64 = wm.double().requires_grad_(True)
+    y_r = torch.nn.functional.conv2d(x64, w64, padding=k // 2)
+    y_r.backward(dy.double())
+    xn, dyn = _nhwc(x).to(dev), _nhwc(dy).to(dev)
+    wd = wm.contiguous().to(dev)
+    wp = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    wpt = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    lib.lv_conv32_pack_f32(P(wd), P(wp), k, nt, 0, _s(dev))
+    lib.lv_conv32_pack_f32(P(wd), P(wpt), k, nt, 1, _s(dev))
+    y = torch.full((N * S * S, C), float("nan"), device=dev)
+    lib.lv_conv32_f32(P(xn), P(wp), P(y), N, k, nt, 0, 0, _s(dev))
+    assert float((_nchw(y.cpu(), N, S, S).double() - y_r.detach()).abs().max()) < 1e-5 * float(y_r.abs().max())
+    dx = torch.full((N * S * S, C), float("nan"), device=dev)
+    lib.lv_conv32_f32(P(dyn), P(wpt), P(dx), N, k, nt, 1, 0, _s(dev))
+    assert float((_nchw(dx.cpu(), N, S, S).double() - x64.grad).abs().max()) < 1e-5 * float(x64.grad.abs().max())
+    # accumulate flag
+    lib.lv_conv32_f32(P(dyn), P(wpt), P(dx), N, k, nt, 1, 1, _s(dev))
+    assert float((_nchw(dx.cpu(), N, S, S).double() - 2 * x64.grad).abs().max()) < 2e-5 * float(x64.grad.abs().max())
+    # weight gradient: ALL taps (gradient of the unmasked convolution wrt w at the masked weights)
+    wfull = wm.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wfull, padding=k // 2).backward(dy.double())
+    ws = torch.full((lib.lv_conv32_wgrad_ws_floats(N, k),), float("nan"), device=dev)
+    dw = torch.full((C, C, k, k), float("nan"), device=dev)
+    lib.lv_conv32_wgrad_f32(P(xn), P(dyn), P(dw), P(ws), N, k, 0, _s(dev))
+    assert float((dw.cpu().double() - wfull.grad).abs().max()) < 2e-5 * float(wfull.grad.abs().max())

@@ -88,6 +88,12 @@ SIGNATURES = {
     "lv_col2im_f32": [_vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lv_conv_pack_w_f32": [_vp, _vp, _i, _i, _i, _vp],
     "lv_conv_unpack_dw_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_conv32_wpack_floats": [_i],
+    "lv_conv32_pack_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "lv_conv32_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lv_conv32_wgrad_slabs": [_i],
+    "lv_conv32_wgrad_ws_floats": [_i, _i],
+    "lv_conv32_wgrad_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],
     "lv_bn_workspace_floats": [_i],
     "lv_bn_fwd_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _vp],
@@ -97,6 +103,10 @@ SIGNATURES = {
     "lv_dec_input_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_dec_input_bwd_f32": [_vp, _vp, _i, _i, _i, _vp],
 }
+
+
+_LONG_FNS = ("lv_lstm_ws_floats", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_conv32_wpack_floats",
+             "lv_conv32_wgrad_ws_floats")
 
 
 class LvaeError(RuntimeError):
@@ -117,12 +127,13 @@ class Lib(object):
                 missing.append(name)
                 continue
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_long if name in ("lv_lstm_ws_floats", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats") else ctypes.c_int
+            fn.restype = ctypes.c_long if name in _LONG_FNS else ctypes.c_int
             setattr(self, "_raw_" + name, fn)
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
+                           "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):

@@ -144,8 +144,11 @@ __device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + exp
 // three orders below the bf16 rounding of the operands they sit next to.  The f32 parity path keeps expf / tanhf.
 #ifdef LV_EMU
 __device__ __forceinline__ float lv_sigmoid_fast(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float lv_exp_fast(float x) { return expf(x); }
 #else
 __device__ __forceinline__ float lv_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// hardware exp2 (v_exp_f32), ~2 ulp: for values that are rounded to bf16 right afterwards
+__device__ __forceinline__ float lv_exp_fast(float x) { return __expf(x); }
 #endif
 __device__ __forceinline__ float lv_tanh_fast(float x) { return 2.0f * lv_sigmoid_fast(2.0f * x) - 1.0f; }
 

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_h16_kernel(const uint16_t
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const float x0 = lv_f16_bits_to_f32((uint16_t)(wv[h] & 0xFFFFu)), x1 = lv_f16_bits_to_f32((uint16_t)(wv[h] >> 16));
-                const float g0 = (expf(x0 - L) - (k + 2 * h == itg ? 1.f : 0.f)) * sc;
-                const float g1 = (expf(x1 - L) - (k + 2 * h + 1 == itg ? 1.f : 0.f)) * sc;
+                const float g0 = (lv_exp_fast(x0 - L) - (k + 2 * h == itg ? 1.f : 0.f)) * sc;
+                const float g1 = (lv_exp_fast(x1 - L) - (k + 2 * h + 1 == itg ? 1.f : 0.f)) * sc;
                 o[h] = lv_pack_bf16x2(g0, g1);
             }
             *reinterpret_cast<uint4*>(orow + k) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void softmax_nll_bwd_h16_kernel(const uint16_t
         done = V8;
     }
     for (int k = done + tid; k < V; k += 256)
-        orow[k] = (uint16_t)lv_f32_to_bf16_bits((expf(lv_f16_bits_to_f32(row[k]) - L) - (k == itg ? 1.f : 0.f)) * sc);
+        orow[k] = (uint16_t)lv_f32_to_bf16_bits((lv_exp_fast(lv_f16_bits_to_f32(row[k]) - L) - (k == itg ? 1.f : 0.f)) * sc);
     for (long k = V + tid; k < ldo; k += 256) orow[k] = 0;      // keep the row padding finite (zero)
 }
 

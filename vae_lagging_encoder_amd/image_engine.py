@@ -25,8 +25,17 @@ class Act(object):
         return self.N * self.H * self.W
 
 
+def pack_conv32(lib, s, ent):
+    """(Re)build the packed forward / data-gradient weight images of one direct convolution; MaskedConv2d's in-place
+    weight.data.mul_(mask) (dec_pixelcnn_v2.py:29, G5) happens here, once per weight version."""
+    if ent["mask"] is not None:
+        lib.lv_mul_inplace_f32(P(ent["weight"]), P(ent["mask"]), ent["weight"].numel(), s)
+    lib.lv_conv32_pack_f32(P(ent["weight"]), P(ent["wp"]), ent["k"], ent["nt"], 0, s)
+    lib.lv_conv32_pack_f32(P(ent["weight"]), P(ent["wpt"]), ent["k"], ent["nt"], 1, s)
+
+
 class Tape(object):
-    def __init__(self, device, precision="f32", train=True):
+    def __init__(self, device, precision="f32", train=True, wcache=None, wver=None):
         self.device = torch.device(device)
         self.lib = backend_for(self.device)
         self.precision = precision
@@ -34,6 +43,10 @@ class Tape(object):
         self.back = []
         self.grads = {}
         self._bn_ws = {}
+        # packed weight images of the direct convolutions, kept across steps by the owning engine and rebuilt when its
+        # weights change (the decoder is frozen during the aggressive inner loop, image.py:300-327)
+        self.wcache = wcache if wcache is not None else {}
+        self.wver = wver
 
     # -- helpers -------------------------------------------------------------------------------------------------
     def s(self):
@@ -78,6 +91,10 @@ class Tape(object):
         Ho = (x.H + 2 * pad - kh) // stride + 1
         Wo = (x.W + 2 * pad - kw) // stride + 1
         Pout = x.N * Ho * Wo
+        direct32 = (Cin == 32 and Cout == 32 and stride == 1 and x.H == 28 and x.W == 28 and kh == kw and pad == kh // 2
+                    and kh in (3, 5, 7))
+        if direct32:
+            return self._conv32(x, weight, gview, kh, nt, mask)
         if mask is not None:
             # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
             # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
@@ -115,6 +132,35 @@ class Tape(object):
                     dcol = self.f32(Pout, K)
                     _gemm(lib, s, 0, 0, Pout, K, Cout, P(dy), Cout, P(wg), ldk, P(dcol), K, prec=self.precision)
                     lib.lv_col2im_f32(P(dcol), K, P(dx), x.N, x.H, x.W, Cin, Ho, Wo, kh, kw, pad, stride, nt, 0, s)
+                self.add_grad(x, dx)
+        self.back.append(bwd)
+        return out
+
+    def _conv32(self, x, weight, gview, k, nt, mask):
+        """32 -> 32 channel k x k convolution on a 28 x 28 map without an im2col buffer (lv_conv_direct.hip): forward and data
+        gradient over the mask's tap prefix, weight gradient over all taps."""
+        lib, s = self.lib, self.s()
+        ent = self.wcache.get(id(weight))
+        if ent is None:
+            n = lib.lv_conv32_wpack_floats(nt)
+            ent = self.wcache[id(weight)] = dict(ver=object(), wp=self.f32(n), wpt=self.f32(n), weight=weight, k=k, nt=nt, mask=mask)
+        if self.wver is None or ent["ver"] != self.wver:
+            pack_conv32(lib, s, ent)
+            ent["ver"] = self.wver if self.wver is not None else object()
+        wp, wpt = ent["wp"], ent["wpt"]
+        y = self.f32(x.P, 32)
+        lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
+        out = Act(y, x.N, 28, 28, 32)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            ws = self.f32(lib.lv_conv32_wgrad_ws_floats(x.N, k))
+            lib.lv_conv32_wgrad_f32(P(x.t), P(dy), P(gview), P(ws), x.N, k, 0, s)
+            if x.needs_grad:
+                dx = self.f32(x.P, 32)
+                lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
         return out
@@ -318,6 +364,8 @@ class ImageDecoderEngine(object):
         self.flat = None
         self.precision = "f32"
         self.gen = 0
+        self.wgen = 0             # bumped by the fused trainer after a raw-pointer weight update
+        self._wcache = {}
 
     def ensure(self, device):
         device = torch.device(device)
@@ -325,10 +373,26 @@ class ImageDecoderEngine(object):
             self.flat = FlatBuffer(list(self.m.named_parameters()), device)
         return self.flat
 
+    def weights_version(self):
+        f = self.flat
+        return (sum(p._version for p in f.params), self.wgen, id(f))
+
+    def refresh_packs(self, device):
+        """Bring the cached packed conv weights up to date on the current stream (the fused trainer calls this outside a
+        captured region, so that a replayed graph never carries -- or misses -- a repack)."""
+        self.ensure(device)
+        ver = self.weights_version()
+        lib, s = backend_for(device), stream_ptr(device)
+        for ent in self._wcache.values():
+            if ent["ver"] != ver:
+                pack_conv32(lib, s, ent)
+                ent["ver"] = ver
+
     def forward(self, x_img, z2d):
         """-> rec [B] (BCE summed over pixels)."""
         f = self.ensure(x_img.device)
-        tp = Tape(x_img.device, self.precision, train=self.m.training)
+        wver = self.weights_version()
+        tp = Tape(x_img.device, self.precision, train=self.m.training, wcache=self._wcache, wver=wver)
         self.tape = tp
         B = x_img.shape[0]
         self.zact = Act(z2d.contiguous(), B, 1, 1, z2d.shape[1])

@@ -370,11 +370,19 @@ class AggressiveImageTrainer(object):
         B = x.shape[0]
         nz = self.vae.nz
         self.scal[0] = float(kl_weight)
+        try:
+            self._step(x, eps, update, d, B, nz)
+        finally:
+            if update in ("decoder", "both"):
+                self.dec.wgen += 1          # raw-pointer update: invalidates the cached packed conv weights
+
+    def _step(self, x, eps, update, d, B, nz):
         if not self.use_graph:
             if eps is not None:
                 eps = eps.to(d).float().contiguous()
             self._body(x, eps, update)
             return
+        self.dec.refresh_packs(d)
         key = (B, update, eps is None, self.vae.training)
         st = self._static.get(key)
         if st is None:
