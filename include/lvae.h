@@ -279,6 +279,14 @@ int lv_conv32_wgrad_slabs(int N);
 long lv_conv32_wgrad_ws_floats(int N, int k);
 int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*k]*/, float* ws, int N, int k, int accumulate,
                         void* stream);
+/* Pointwise (1 x 1) convolutions between 32 / 64 channels (PixelCNNBlock's bottleneck and expansion convolutions,
+ * dec_pixelcnn_v2.py:41-43,49-51): out [P][Cout] (=|+=) in [P][Cin] . W^T, W [Cout][Cin]; w_transposed = 1: W given as
+ * [Cin][Cout] (the data gradient of the convolution that owns it); the weight gradient sums dy^T x over all P pixels. */
+int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed, int accumulate,
+                   void* stream);
+long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
+int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
+                         void* stream);
 /* nn.BatchNorm2d in train mode (batch statistics, running stats momentum update with unbiased variance) fused with the
  * residual add and nn.ELU that follow it in ResNetBlock / PixelCNNBlock; backward with ELU' from the saved output */
 int lv_bn_workspace_floats(int C);

@@ -117,7 +117,8 @@ def test_conv(emu_backend, cfg):
     K.test_conv_im2col_gemm_fwd_bwd(emu_backend, CPU, *cfg)
 
 
-@pytest.mark.parametrize("cfg", [(3, 8, 5, True, True), (2, 64, 6, False, False), (2, 300, 3, True, True)])
+@pytest.mark.parametrize("cfg", [(3, 8, 5, True, True), (2, 64, 6, False, False), (2, 300, 3, True, True), (3, 16, 9, True, True),
+                                 (7, 256, 4, True, True), (6, 32, 28, True, True), (6, 128, 2, False, False)])
 def test_batchnorm(emu_backend, cfg):
     K.test_batchnorm_train_fwd_bwd(emu_backend, CPU, *cfg)
 
@@ -169,3 +170,8 @@ def test_gemm_b16_nll_fused(emu_backend, cfg):
 @pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False)])
 def test_conv32_direct(emu_backend, cfg):
     K.test_conv32_direct_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1000, 64, 32), (300, 32, 64), (129, 64, 64), (70, 32, 32)])
+def test_conv1x1(emu_backend, cfg):
+    K.test_conv1x1_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)

@@ -672,7 +672,8 @@ def test_conv_im2col_gemm_fwd_bwd(lib, hip_device, N, Cin, Cout, H, k, stride, p
 
 
 @pytest.mark.parametrize("N,C,H,act,use_res", [(3, 8, 5, True, True), (4, 32, 7, True, False), (2, 64, 6, False, False),
-                                                (5, 512, 1, True, False), (2, 300, 3, True, True)])
+                                                (5, 512, 1, True, False), (2, 300, 3, True, True), (3, 16, 9, True, True),
+                                                (7, 256, 4, True, True), (50, 32, 28, True, True), (6, 128, 2, False, False)])
 def test_batchnorm_train_fwd_bwd(lib, hip_device, N, C, H, act, use_res):
     import torch.nn.functional as F
     dev = hip_device
@@ -958,3 +959,28 @@ def test_conv32_direct_fwd_dgrad_wgrad(lib, hip_device, N, k, masked):
     dw = torch.full((C, C, k, k), float("nan"), device=dev)
     lib.lv_conv32_wgrad_f32(P(xn), P(dyn), P(dw), P(ws), N, k, 0, _s(dev))
     assert float((dw.cpu().double() - wfull.grad).abs().max()) < 2e-5 * float(wfull.grad.abs().max())
+
+
+@pytest.mark.parametrize("P_,Cin,Cout", [(39200, 64, 32), (1000, 32, 64), (300, 64, 64), (129, 32, 32)])
+def test_conv1x1_fwd_dgrad_wgrad(lib, hip_device, P_, Cin, Cout):
+    dev = hip_device
+    g = torch.Generator().manual_seed(P_ + Cin)
+    x = torch.randn(P_, Cin, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    dy = torch.randn(P_, Cout, generator=g)
+    xd, wd, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    y = torch.full((P_, Cout), float("nan"), device=dev)
+    lib.lv_conv1x1_f32(P(xd), P(wd), P(y), P_, Cin, Cout, 0, 0, _s(dev))
+    ref = x.double() @ w.double().t()
+    assert float((y.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    dx = torch.full((P_, Cin), float("nan"), device=dev)
+    lib.lv_conv1x1_f32(P(dyd), P(wd), P(dx), P_, Cout, Cin, 1, 0, _s(dev))        # dx = dy . W, W handed as stored
+    refdx = dy.double() @ w.double()
+    assert float((dx.cpu().double() - refdx).abs().max()) < 1e-5 * float(refdx.abs().max())
+    lib.lv_conv1x1_f32(P(dyd), P(wd), P(dx), P_, Cout, Cin, 1, 1, _s(dev))
+    assert float((dx.cpu().double() - 2 * refdx).abs().max()) < 2e-5 * float(refdx.abs().max())
+    ws = torch.full((lib.lv_conv1x1_wgrad_ws_floats(Cin, Cout),), float("nan"), device=dev)
+    dw = torch.full((Cout, Cin), float("nan"), device=dev)
+    lib.lv_conv1x1_wgrad_f32(P(xd), P(dyd), P(dw), P(ws), P_, Cin, Cout, 0, _s(dev))
+    refdw = dy.double().t() @ x.double()
+    assert float((dw.cpu().double() - refdw).abs().max()) < 2e-5 * float(refdw.abs().max())

@@ -232,6 +232,185 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
     }
 }
 
+// ---- vector path (C a power of two in [16, 256]; every BatchNorm of the two networks) -------------------------------------
+// Two launches per direction instead of three: the reduction writes <= BN_V4_BLOCKS per-block partials with float4 loads, and
+// every workgroup of the apply kernel re-derives the per-channel totals from them (f64, fixed order: <= 64 KB of L2 reads per
+// workgroup) instead of waiting for a separate one-workgroup "finish" launch (5-6 us each, 162 of them per Omniglot step).
+constexpr int BN_V4_BLOCKS = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, int act,
+                                                           float* __restrict__ dv_out, float* __restrict__ partial,
+                                                           long P, int C, int nblk) {
+    __shared__ __attribute__((aligned(16))) float sred[4][2][256];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int CT4 = C >> 2, RPB = 256 / CT4;
+    const int c4 = tid & (CT4 - 1), rsub = tid / CT4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, mu = a0, is = a0;
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
+        is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
+    }
+    for (long r = (long)blockIdx.x * RPB + rsub; r < P; r += (long)nblk * RPB) {
+        const long i = r * C + 4 * c4;
+        if (MODE == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+            a1.x += v.x * v.x; a1.y += v.y * v.y; a1.z += v.z * v.z; a1.w += v.w * v.w;
+        } else {
+            float4 g = *reinterpret_cast<const float4*>(dy + i);
+            const float4 xv = *reinterpret_cast<const float4*>(x + i);
+            if (act) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + i);
+                g.x = yy.x > 0.f ? g.x : g.x * (yy.x + 1.f);
+                g.y = yy.y > 0.f ? g.y : g.y * (yy.y + 1.f);
+                g.z = yy.z > 0.f ? g.z : g.z * (yy.z + 1.f);
+                g.w = yy.w > 0.f ? g.w : g.w * (yy.w + 1.f);
+            }
+            *reinterpret_cast<float4*>(dv_out + i) = g;
+            a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
+            a1.x += g.x * ((xv.x - mu.x) * is.x); a1.y += g.y * ((xv.y - mu.y) * is.y);
+            a1.z += g.z * ((xv.z - mu.z) * is.z); a1.w += g.w * ((xv.w - mu.w) * is.w);
+        }
+    }
+    // lanes of a wave with equal c4 (lane bits >= log2 CT4), then the 4 waves through LDS: a fixed order
+    for (int off = CT4; off < 64; off <<= 1) {
+        a0.x += __shfl_xor(a0.x, off, 64); a0.y += __shfl_xor(a0.y, off, 64);
+        a0.z += __shfl_xor(a0.z, off, 64); a0.w += __shfl_xor(a0.w, off, 64);
+        a1.x += __shfl_xor(a1.x, off, 64); a1.y += __shfl_xor(a1.y, off, 64);
+        a1.z += __shfl_xor(a1.z, off, 64); a1.w += __shfl_xor(a1.w, off, 64);
+    }
+    if (lane < CT4) {
+        *reinterpret_cast<float4*>(&sred[wv][0][4 * lane]) = a0;
+        *reinterpret_cast<float4*>(&sred[wv][1][4 * lane]) = a1;
+    }
+    __syncthreads();
+    // CT4 == 64: each wave's 64 lanes are 64 distinct channel groups and rsub == wv; CT4 < 64: lanes < CT4 hold wave totals
+    for (int t = tid; t < 2 * C; t += 256) {
+        const int q = t / C, c = t % C;
+        partial[((long)blockIdx.x * 2 + q) * C + c] = ((sred[0][q][c] + sred[1][q][c]) + sred[2][q][c]) + sred[3][q][c];
+    }
+}
+
+// per-(q, c) totals of the per-block partials, all 256 threads cooperating; tot: 2*C doubles, scratch: 256 doubles (LDS)
+__device__ __forceinline__ void bn_block_totals(const float* __restrict__ partial, int nblk, int C, double* tot, double* scratch) {
+    const int tid = (int)threadIdx.x, npair = 2 * C;
+    for (int base = 0; base < npair; base += 256) {
+        const int cnt = npair - base < 256 ? npair - base : 256;
+        const int tpp = 256 / cnt, pr = tid % cnt, sub = tid / cnt;
+        double s = 0.0;
+        if (sub < tpp)
+            for (int b = sub; b < nblk; b += tpp) s += (double)partial[(long)b * npair + base + pr];
+        scratch[tid] = s;
+        __syncthreads();
+        if (tid < cnt) {
+            double t = 0.0;
+            for (int k = 0; k < tpp; ++k) t += scratch[tid + k * cnt];
+            tot[base + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ res, int act, float* __restrict__ y,
+                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                              long P, int C, float eps, float momentum) {
+    __shared__ double tot[512], scratch[256];
+    __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sbe[256];
+    const int tid = (int)threadIdx.x;
+    bn_block_totals(partial, nblk, C, tot, scratch);
+    if (tid < C) {
+        const double m = tot[tid] / (double)P;
+        double var = tot[C + tid] / (double)P - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+        smu[tid] = mf; sis[tid] = isf; sga[tid] = gamma[tid]; sbe[tid] = beta[tid];
+        if (blockIdx.x == 0) {
+            mean_out[tid] = mf;
+            invstd_out[tid] = isf;
+            if (run_mean) {
+                const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+                run_mean[tid] = (float)((1.0 - momentum) * (double)run_mean[tid] + momentum * m);
+                run_var[tid] = (float)((1.0 - momentum) * (double)run_var[tid] + momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const long n4 = P * (C >> 2), gs = (long)gridDim.x * 256;
+    const int CT4 = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += gs) {
+        const int c = 4 * (int)(i & (CT4 - 1));
+        const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i);
+        const float4 m4 = *reinterpret_cast<const float4*>(&smu[c]), i4 = *reinterpret_cast<const float4*>(&sis[c]);
+        const float4 g4 = *reinterpret_cast<const float4*>(&sga[c]), b4 = *reinterpret_cast<const float4*>(&sbe[c]);
+        float4 v;
+        v.x = (xv.x - m4.x) * i4.x * g4.x + b4.x; v.y = (xv.y - m4.y) * i4.y * g4.y + b4.y;
+        v.z = (xv.z - m4.z) * i4.z * g4.z + b4.z; v.w = (xv.w - m4.w) * i4.w * g4.w + b4.w;
+        if (res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(res + 4 * i);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        if (act) {
+            v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+            v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
+        }
+        *reinterpret_cast<float4*>(y + 4 * i) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ dv,
+                                                              const float* __restrict__ partial, int nblk,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
+                                                              long P, int C, float invP) {
+    __shared__ double tot[512], scratch[256];
+    __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sdg[256], sdb[256];
+    const int tid = (int)threadIdx.x;
+    bn_block_totals(partial, nblk, C, tot, scratch);
+    if (tid < C) {
+        const double s = tot[tid], q = tot[C + tid];
+        smu[tid] = mean[tid]; sis[tid] = invstd[tid]; sga[tid] = gamma[tid];
+        sdb[tid] = (float)s; sdg[tid] = (float)q;
+        if (blockIdx.x == 0) {
+            dbeta[tid] = (float)(s + (accumulate ? (double)dbeta[tid] : 0.0));
+            dgamma[tid] = (float)(q + (accumulate ? (double)dgamma[tid] : 0.0));
+        }
+    }
+    __syncthreads();
+    const long n4 = P * (C >> 2), gs = (long)gridDim.x * 256;
+    const int CT4 = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += gs) {
+        const int c = 4 * (int)(i & (CT4 - 1));
+        const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i), d4 = *reinterpret_cast<const float4*>(dv + 4 * i);
+        const float4 m4 = *reinterpret_cast<const float4*>(&smu[c]), i4 = *reinterpret_cast<const float4*>(&sis[c]);
+        const float4 g4 = *reinterpret_cast<const float4*>(&sga[c]);
+        const float4 dg = *reinterpret_cast<const float4*>(&sdg[c]), db = *reinterpret_cast<const float4*>(&sdb[c]);
+        float4 o;
+        o.x = g4.x * i4.x * (d4.x - db.x * invP - ((xv.x - m4.x) * i4.x) * dg.x * invP);
+        o.y = g4.y * i4.y * (d4.y - db.y * invP - ((xv.y - m4.y) * i4.y) * dg.y * invP);
+        o.z = g4.z * i4.z * (d4.z - db.z * invP - ((xv.z - m4.z) * i4.z) * dg.z * invP);
+        o.w = g4.w * i4.w * (d4.w - db.w * invP - ((xv.w - m4.w) * i4.w) * dg.w * invP);
+        *reinterpret_cast<float4*>(dx + 4 * i) = o;
+    }
+}
+
+static inline bool bn_v4_ok(int C) { return C >= 16 && C <= 256 && (C & (C - 1)) == 0; }
+static inline int bn_v4_blocks(long P, int C) {
+    const int rpb = 256 / (C >> 2);
+    long nb = (P + 4L * rpb - 1) / (4L * rpb);          // >= 4 rows per thread
+    return (int)(nb < 1 ? 1 : nb > BN_V4_BLOCKS ? BN_V4_BLOCKS : nb);
+}
+static inline unsigned bn_v4_apply_grid(long n4) {
+    const long g = lv_cdiv(n4, 256);
+    return (unsigned)(g > 512 ? 512 : g);
+}
+
 // rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
 __global__ __launch_bounds__(256) void sigmoid_bce_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ x,
                                                               float* __restrict__ rec, int npix, float eps) {
@@ -352,6 +531,15 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
                              float eps, float momentum, float* ws, long P, int C, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !invstd || !ws) return LV_ERR_ARG;
     if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
+    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {
+        const int nb = bn_v4_blocks(P, C);
+        LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
+                  (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
+        LV_LAUNCH(bn_apply_fwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, (const float*)ws, nb, gamma, beta,
+                  res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
     int nblk = (int)((P + 63) / 64);
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
@@ -373,6 +561,14 @@ extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, co
     if (!x || !dy || !mean || !invstd || !gamma || !dv || !dx || !dgamma || !dbeta || !ws) return LV_ERR_ARG;
     if (act_elu && !y) return LV_ERR_ARG;
     if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
+    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
+        const int nb = bn_v4_blocks(P, C);
+        LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nb);
+        LV_LAUNCH(bn_apply_bwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, (const float*)dv,
+                  (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
     int nblk = (int)((P + 63) / 64);
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     float* dgl = ws + (long)BN_BLOCKS * 2 * C;

@@ -217,3 +217,177 @@ extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, f
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
+
+// =====================================================================================================================
+// Pointwise (1 x 1) convolutions between 32 and 64 channels (the bottleneck / expansion convolutions of PixelCNNBlock,
+// dec_pixelcnn_v2.py:41-43,49-51, and the decoder head): out[p][co] = sum_ci in[p][ci] W[co][ci] over P = N*28*28 pixels.
+// As tile GEMMs these are M = 39200, N <= 64, K <= 64 problems on 128 x 128 x 16 tiles (32 us each, plus split-K for the
+// gradients); here a workgroup takes 128 pixels, stages them and the whole weight matrix (<= 16 KB) in LDS with coalesced
+// loads and runs K/2 v_mfma_f32_32x32x2_f32 per 32-pixel wave and 32-channel output block.  The data gradient is the same
+// kernel with the weight matrix read transposed; the weight gradient accumulates dy^T x over a slab of pixels in registers
+// (one 32 x 32 block per wave) and a fixed-order reduction sums the slabs.
+namespace {
+
+constexpr int PWP = 128;               // pixels per workgroup
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                      long P, int w_transposed, int accumulate) {
+    constexpr int PA = CIN + 4;        // LDS pitches (floats): 16-byte slots per row odd -> conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float sa[PWP * PA];
+    __shared__ __attribute__((aligned(16))) float sw[COUT * PA];
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const long p0 = (long)blockIdx.x * PWP;
+    for (int i = tid; i < PWP * (CIN / 4); i += 256) {
+        const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + pp < P) v = *reinterpret_cast<const float4*>(in + (p0 + pp) * CIN + 4 * c4);
+        *reinterpret_cast<float4*>(&sa[pp * PA + 4 * c4]) = v;
+    }
+    // sw[co][ci] = W[co][ci]  (w stored [COUT][CIN]), or W^T when the caller hands the [CIN][COUT] matrix of the forward
+    for (int i = tid; i < COUT * CIN; i += 256) {
+        const int ci = i % CIN, co = i / CIN;
+        sw[co * PA + ci] = w_transposed ? w[(long)ci * COUT + co] : w[i];
+    }
+    __syncthreads();
+    const int kh = l >> 5;
+    const float* a = &sa[(wv * 32 + (l & 31)) * PA + (CIN / 2) * kh];
+    float av[CIN / 2];
+#pragma unroll
+    for (int s = 0; s < CIN / 2; s += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(a + s);
+        av[s] = q.x; av[s + 1] = q.y; av[s + 2] = q.z; av[s + 3] = q.w;
+    }
+#pragma unroll
+    for (int nb = 0; nb < COUT / 32; ++nb) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float* b = &sw[(nb * 32 + (l & 31)) * PA + (CIN / 2) * kh];
+#pragma unroll
+        for (int s = 0; s < CIN / 2; s += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(b + s);
+            acc = lv_mfma_32x32x2(av[s], q.x, acc);
+            acc = lv_mfma_32x32x2(av[s + 1], q.y, acc);
+            acc = lv_mfma_32x32x2(av[s + 2], q.z, acc);
+            acc = lv_mfma_32x32x2(av[s + 3], q.w, acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long pp = p0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            if (pp < P) {
+                float* o = out + pp * COUT + nb * 32 + (l & 31);
+                *o = accumulate ? *o + acc[e] : acc[e];
+            }
+        }
+    }
+}
+
+// stage 1 of the weight gradient: dwp[slab][co][ci] = sum over the slab's pixels of dy[p][co] x[p][ci]; the (COUT/32) x (CIN/32)
+// output blocks are dealt to the 4 waves (at most 4 blocks)
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dwp, long P, long pix_per_slab) {
+    constexpr int PX = CIN + 1, PY = COUT + 1;          // scalar LDS reads along the channel index: odd pitch
+    __shared__ float sx[PWP * PX];
+    __shared__ float sy[PWP * PY];
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
+    constexpr int NBLK = (COUT / 32) * (CIN / 32);
+    const int blk = wv % NBLK, ksplit = wv / NBLK;       // waves beyond NBLK split the pixel range of a block
+    constexpr int KS = 4 / NBLK > 0 ? 4 / NBLK : 1;
+    const int cob = blk / (CIN / 32), cib = blk % (CIN / 32);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const long s0 = (long)blockIdx.x * pix_per_slab;
+    const long s1 = s0 + pix_per_slab < P ? s0 + pix_per_slab : P;
+    const int kp = l >> 5, cl = l & 31;
+    for (long p0 = s0; p0 < s1; p0 += PWP) {
+        __syncthreads();
+        for (int i = tid; i < PWP * CIN; i += 256) {
+            const int c = i % CIN, pp = i / CIN;
+            sx[pp * PX + c] = p0 + pp < s1 ? x[(p0 + pp) * CIN + c] : 0.f;
+        }
+        for (int i = tid; i < PWP * COUT; i += 256) {
+            const int c = i % COUT, pp = i / COUT;
+            sy[pp * PY + c] = p0 + pp < s1 ? dy[(p0 + pp) * COUT + c] : 0.f;
+        }
+        __syncthreads();
+        if (wv < NBLK * KS) {
+            // D[co][ci] += dy[p][co] * x[p][ci], two pixels per MFMA; this wave's share of the 128 staged pixels
+            const int m0 = ksplit * (PWP / 2 / KS), m1 = m0 + PWP / 2 / KS;
+            for (int m = m0; m < m1; ++m) {
+                const int pp = 2 * m + kp;
+                acc = lv_mfma_32x32x2(sy[pp * PY + cob * 32 + cl], sx[pp * PX + cib * 32 + cl], acc);
+            }
+        }
+    }
+    // partial layout [slab][KS][COUT][CIN]
+    if (wv < NBLK * KS) {
+        float* o = dwp + ((long)blockIdx.x * KS + ksplit) * COUT * CIN;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);      // co within the block
+            o[(long)(cob * 32 + row) * CIN + cib * 32 + cl] = acc[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int n,
+                                                                   int parts, int accumulate) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int b0 = 0; b0 < parts; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = dwp[(long)(b0 + u < parts ? b0 + u : 0) * n + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += b0 + u < parts ? v[u] : 0.f;
+    }
+    dw[idx] = accumulate ? dw[idx] + s : s;
+}
+
+constexpr int PW_SLABS = 128;
+
+}  // namespace
+
+// out [P][Cout] (=|+=) in [P][Cin] . W^T with W [Cout][Cin] (w_transposed = 0) or given as [Cin][Cout] (w_transposed = 1: the
+// data gradient of the forward convolution whose weight this is).  (Cin, Cout) in {32, 64}^2; else LV_ERR_UNSUPPORTED.
+extern "C" int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed,
+                              int accumulate, void* stream) {
+    if (!in || !w || !out) return LV_ERR_ARG;
+    if (P <= 0) return LV_ERR_SHAPE;
+    if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
+    const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(256);
+    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
+    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
+    else return LV_ERR_UNSUPPORTED;
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_SLABS * 4 * Cin * Cout; }
+
+// dw [Cout][Cin] (=|+=) dy^T . x over P pixels; ws: lv_conv1x1_wgrad_ws_floats floats
+extern "C" int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
+                                    void* stream) {
+    if (!x || !dy || !dw || !ws) return LV_ERR_ARG;
+    if (P <= 0) return LV_ERR_SHAPE;
+    long per = lv_cdiv(P, PW_SLABS);
+    per = (per + PWP - 1) / PWP * PWP;
+    const int slabs = lv_cdiv(P, per);
+    const dim3 grid((unsigned)slabs), block(256);
+    int ks;
+    if (Cin == 64 && Cout == 32) { ks = 2; LV_LAUNCH((conv1x1_wgrad_kernel<64, 32>), grid, block, 0, stream, x, dy, ws, P, per); }
+    else if (Cin == 32 && Cout == 64) { ks = 2; LV_LAUNCH((conv1x1_wgrad_kernel<32, 64>), grid, block, 0, stream, x, dy, ws, P, per); }
+    else if (Cin == 64 && Cout == 64) { ks = 1; LV_LAUNCH((conv1x1_wgrad_kernel<64, 64>), grid, block, 0, stream, x, dy, ws, P, per); }
+    else if (Cin == 32 && Cout == 32) { ks = 4; LV_LAUNCH((conv1x1_wgrad_kernel<32, 32>), grid, block, 0, stream, x, dy, ws, P, per); }
+    else return LV_ERR_UNSUPPORTED;
+    LV_LAUNCH(conv1x1_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)Cin * Cout, 256)), dim3(256), 0, stream, (const float*)ws, dw,
+              Cin * Cout, slabs * ks, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

@@ -320,6 +320,14 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// `a` and `out` may alias (no __restrict__): the in-place gradient accumulation of the image tape
+__global__ __launch_bounds__(256) void add_v4_kernel(const float* a, const float* b, float* out, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = *reinterpret_cast<const float4*>(a + 4 * i), y = *reinterpret_cast<const float4*>(b + 4 * i);
+    *reinterpret_cast<float4*>(out + 4 * i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
 }  // namespace
 
 extern "C" int lv_reparam_kl_fwd_f32(const float* mulv, const float* eps, float* z, float* kl,
@@ -418,6 +426,11 @@ extern "C" int lv_colsum_f32(const float* in, long ld, int R, int C, float* out,
 extern "C" int lv_add_f32(const float* a, const float* b, float* out, long n, void* stream) {
     if (!a || !b || !out || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
+    if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0) {
+        LV_LAUNCH(add_v4_kernel, dim3((unsigned)lv_cdiv(n / 4, 256)), dim3(256), 0, stream, a, b, out, n / 4);
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
     LV_LAUNCH(add_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, a, b, out, n);
     LV_CHECK_LAUNCH();
     return LV_OK;

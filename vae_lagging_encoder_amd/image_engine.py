@@ -43,6 +43,7 @@ class Tape(object):
         self.back = []
         self.grads = {}
         self._bn_ws = {}
+        self.bn_seen = []              # num_batches_tracked buffers of the BatchNorms run in train mode (bumped once, together)
         # packed weight images of the direct convolutions, kept across steps by the owning engine and rebuilt when its
         # weights change (the decoder is frozen during the aggressive inner loop, image.py:300-327)
         self.wcache = wcache if wcache is not None else {}
@@ -61,6 +62,12 @@ class Tape(object):
             w = self.f32(self.lib.lv_bn_workspace_floats(C) + 2 * C)
             self._bn_ws[C] = w
         return w
+
+    def bump_bn_counters(self):
+        """BatchNorm2d.num_batches_tracked += 1 for every layer this forward ran in train mode: one fused launch."""
+        if self.bn_seen:
+            torch._foreach_add_(self.bn_seen, 1)
+            self.bn_seen = []
 
     def add_grad(self, act, g):
         """Accumulate g (a [P,C] tensor this tape owns) into the gradient of `act`."""
@@ -95,6 +102,8 @@ class Tape(object):
                     and kh in (3, 5, 7))
         if direct32:
             return self._conv32(x, weight, gview, kh, nt, mask)
+        if KK == 1 and stride == 1 and pad == 0 and mask is None and Cin in (32, 64) and Cout in (32, 64):
+            return self._conv1x1(x, weight, gview)
         if mask is not None:
             # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
             # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
@@ -165,6 +174,27 @@ class Tape(object):
         self.back.append(bwd)
         return out
 
+    def _conv1x1(self, x, weight, gview):
+        """Pointwise convolution between 32 / 64 channels (lv_conv1x1_*: one pass over the pixels, no split-K)."""
+        lib, s = self.lib, self.s()
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        y = self.f32(x.P, Cout)
+        lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
+        out = Act(y, x.N, x.H, x.W, Cout)
+
+        def bwd():
+            dy = self.grad_of(out)
+            if dy is None:
+                return
+            ws = self.f32(lib.lv_conv1x1_wgrad_ws_floats(Cin, Cout))
+            lib.lv_conv1x1_wgrad_f32(P(x.t), P(dy), P(gview), P(ws), x.P, Cin, Cout, 0, s)
+            if x.needs_grad:
+                dx = self.f32(x.P, Cin)
+                lib.lv_conv1x1_f32(P(dy), P(weight), P(dx), x.P, Cout, Cin, 1, 0, s)
+                self.add_grad(x, dx)
+        self.back.append(bwd)
+        return out
+
     def bn(self, x, bn, g_gamma, g_beta, res=None, act=True):
         """nn.BatchNorm2d (+ residual add) (+ nn.ELU).  Train mode: batch statistics + running-stat update."""
         lib, s = self.lib, self.s()
@@ -176,7 +206,7 @@ class Tape(object):
             lib.lv_bn_fwd_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
                               P(mean), P(invstd), P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum,
                               P(self.bn_ws(C)), Pn, C, s)
-            bn.num_batches_tracked += 1
+            self.bn_seen.append(bn.num_batches_tracked)
         else:
             # eval mode (evaluation helpers only): normalise with the running statistics (tensor algebra)
             mean.copy_(bn.running_mean)
@@ -348,6 +378,7 @@ class ImageEncoderEngine(object):
         f = self.ensure(x_img.device)
         self.tape = Tape(x_img.device, self.precision, train=self.m.training)
         self.out = encoder_forward(self.tape, f, self.m, x_img)
+        self.tape.bump_bn_counters()
         self.gen += 1
         return self.out.t
 
@@ -397,6 +428,7 @@ class ImageDecoderEngine(object):
         B = x_img.shape[0]
         self.zact = Act(z2d.contiguous(), B, 1, 1, z2d.shape[1])
         self.logit, self.xflat = decoder_forward(tp, f, self.m, x_img, self.zact.t, self.zact)
+        tp.bump_bn_counters()
         self.rec = tp.f32(B)
         tp.lib.lv_sigmoid_bce_fwd_f32(P(self.logit.t), P(self.xflat), P(self.rec), B, 28 * 28, 1e-12, tp.s())
         self.gen += 1
