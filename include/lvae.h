@@ -275,7 +275,7 @@ int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream);   /* Mas
 long lv_conv32_wpack_floats(int ntaps);
 int lv_conv32_pack_f32(const float* w /*[32][32][k*k]*/, float* wp, int k, int ntaps, int transpose, void* stream);
 int lv_conv32_f32(const float* in, const float* wp, float* out, int N, int k, int ntaps, int mirror, int accumulate, void* stream);
-int lv_conv32_wgrad_slabs(int N);
+int lv_conv32_wgrad_slabs(int N, int k);
 long lv_conv32_wgrad_ws_floats(int N, int k);
 int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*k]*/, float* ws, int N, int k, int accumulate,
                         void* stream);

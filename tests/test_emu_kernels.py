@@ -167,7 +167,7 @@ def test_gemm_b16_nll_fused(emu_backend, cfg):
     K.test_gemm_b16_nll_fused(emu_backend, CPU, *cfg)
 
 
-@pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False)])
+@pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False), (20, 7, True), (40, 3, True)])
 def test_conv32_direct(emu_backend, cfg):
     K.test_conv32_direct_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)
 

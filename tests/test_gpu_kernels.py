@@ -919,7 +919,8 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
     assert bool((dl[:, V:] == 0).all())
 
 
-@pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (1, 7, False)])
+@pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (1, 7, False), (50, 7, True), (50, 5, True),
+                                         (50, 3, True), (37, 5, False)])
 def test_conv32_direct_fwd_dgrad_wgrad(lib, hip_device, N, k, masked):
     """lv_conv32_* (direct 32 -> 32 convolution on 28 x 28 maps) against torch conv2d in float64: forward and data gradient over
     the mask's tap prefix, weight gradient over all taps (the reference keeps gradients on masked taps)."""

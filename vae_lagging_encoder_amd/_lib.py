@@ -91,7 +91,7 @@ SIGNATURES = {
     "lv_conv32_wpack_floats": [_i],
     "lv_conv32_pack_f32": [_vp, _vp, _i, _i, _i, _vp],
     "lv_conv32_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "lv_conv32_wgrad_slabs": [_i],
+    "lv_conv32_wgrad_slabs": [_i, _i],
     "lv_conv32_wgrad_ws_floats": [_i, _i],
     "lv_conv32_wgrad_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_f32": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],

@@ -294,24 +294,41 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
     }
 }
 
-// per-(q, c) totals of the per-block partials, all 256 threads cooperating; tot: 2*C doubles, scratch: 256 doubles (LDS)
+// per-(q, c) totals of the per-block partials, all 256 threads cooperating: thread t sums float4 group t % (C/2) over blocks
+// t / (C/2), + 256/(C/2), ... (16 independent loads in flight per batch: a runtime-length load -> add loop would pay one L2
+// round trip per block), f64, fixed order; tot: 2*C doubles, scratch: 1024 doubles (LDS)
 __device__ __forceinline__ void bn_block_totals(const float* __restrict__ partial, int nblk, int C, double* tot, double* scratch) {
-    const int tid = (int)threadIdx.x, npair = 2 * C;
-    for (int base = 0; base < npair; base += 256) {
-        const int cnt = npair - base < 256 ? npair - base : 256;
-        const int tpp = 256 / cnt, pr = tid % cnt, sub = tid / cnt;
-        double s = 0.0;
-        if (sub < tpp)
-            for (int b = sub; b < nblk; b += tpp) s += (double)partial[(long)b * npair + base + pr];
-        scratch[tid] = s;
-        __syncthreads();
-        if (tid < cnt) {
-            double t = 0.0;
-            for (int k = 0; k < tpp; ++k) t += scratch[tid + k * cnt];
-            tot[base + tid] = t;
-        }
-        __syncthreads();
+    const int tid = (int)threadIdx.x, npair = 2 * C, NF4 = C >> 1, nsub = 256 / NF4;
+    const int pg = tid & (NF4 - 1), bsub = tid / NF4;
+    const float4* p4 = reinterpret_cast<const float4*>(partial) + pg;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = bsub;
+    for (; b + 15 * nsub < nblk; b += 16 * nsub) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p4[(long)(b + u * nsub) * NF4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
     }
+    {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int bb = b + u * nsub;
+            v[u] = bb < nblk ? p4[(long)bb * NF4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+    }
+    double* sc = scratch + (long)bsub * npair + 4 * pg;
+    sc[0] = s0; sc[1] = s1; sc[2] = s2; sc[3] = s3;
+    __syncthreads();
+    for (int t = tid; t < npair; t += 256) {
+        double acc = 0.0;
+        for (int k = 0; k < nsub; ++k) acc += scratch[(long)k * npair + t];
+        tot[t] = acc;
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk,
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
                                                               float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                               float* __restrict__ run_mean, float* __restrict__ run_var,
                                                               long P, int C, float eps, float momentum) {
-    __shared__ double tot[512], scratch[256];
+    __shared__ double tot[512], scratch[1024];
     __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sbe[256];
     const int tid = (int)threadIdx.x;
     bn_block_totals(partial, nblk, C, tot, scratch);
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __res
                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
                                                               long P, int C, float invP) {
-    __shared__ double tot[512], scratch[256];
+    __shared__ double tot[512], scratch[1024];
     __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sdg[256], sdb[256];
     const int tid = (int)threadIdx.x;
     bn_block_totals(partial, nblk, C, tot, scratch);

@@ -60,20 +60,37 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int px = (l & 31) < IW ? (l & 31) : IW - 1;        // lanes 28..31 shadow pixel 27: their rows of the result are dropped
     const int kh = l >> 5;
-    for (int t = 0; t < ntaps; ++t) {
+    // the tap's weight fragment comes from L2 (4 KB per tap, shared by every workgroup): two register sets, the fetch of tap
+    // t + 1 issued (and pinned there: the scheduler would sink it below the MFMAs) before tap t multiplies
+    auto fetch_b = [&](float (&b)[16], int t) {
+        const float* bw = wp + (long)(t < ntaps ? t : ntaps - 1) * 16 * 64 + l;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b[s] = bw[s * 64];
+    };
+    auto tap = [&](const float (&b)[16], int t) {
         int dy = t / k - p, dx = t % k - p;
         if (mirror) { dy = -dy; dx = -dx; }
         const float* a = &halo[((w + p + dy) * HW + (px + p + dx)) * PP + 16 * kh];
         const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
         const float4 a2 = *reinterpret_cast<const float4*>(a + 8), a3 = *reinterpret_cast<const float4*>(a + 12);
         const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-        const float* bw = wp + (long)t * 16 * 64 + l;
-        float bv[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bv[s] = bw[s * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = lv_mfma_32x32x2(av[s], bv[s], acc);
+        for (int s = 0; s < 16; ++s) acc = lv_mfma_32x32x2(av[s], b[s], acc);
+    };
+    float b0[16], b1[16];
+    fetch_b(b0, 0);
+    int t = 0;
+    for (; t + 1 < ntaps; t += 2) {
+        fetch_b(b1, t + 1);
+        LV_SCHED_BARRIER();
+        tap(b0, t);
+        LV_SCHED_BARRIER();
+        fetch_b(b0, t + 2);
+        LV_SCHED_BARRIER();
+        tap(b1, t + 1);
+        LV_SCHED_BARRIER();
     }
+    if (t < ntaps) tap(b0, t);
     const int r = r0 + w;
     const int col = l & 31;
 #pragma unroll
@@ -86,17 +103,61 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     }
 }
 
-// weight gradient, stage 1.  grid (slabs, 4 tap groups); slab = a contiguous range of 4-row tiles; wave w of group g owns
-// taps t = 4 * j + w ... (taps dealt round-robin over the 16 waves of the 4 groups): dwp[slab][t][ci][co] = sum over the slab's
-// pixels of x[pixel + off_t][ci] * dy[pixel][co].
-constexpr int WG_TAPS = 4;             // taps per wave at most (k = 7: 49 taps over 16 waves -> 4)
+// weight gradient, stage 1.  grid (slabs, G tap groups), G = 4 / 2 / 1 for k = 7 / 5 / 3; slab = a contiguous range of 4-row
+// tiles; wave w of group g owns taps t = (4g + w) + 4G*q, q < 4: dwp[slab][t][ci][co] = sum over the slab's pixels of
+// x[pixel + off_t][ci] * dy[pixel][co], two pixels per v_mfma_f32_32x32x2_f32 (k = the pixel pair).  The dy operand of a pixel
+// pair is read from LDS once and reused by the wave's taps; LDS pixel pitch 32 floats puts the two pixels of a pair on disjoint
+// bank halves (conflict-free ds_read_b32).  The next tile's rows are fetched into registers while the current tile is
+// multiplied, so the staging cost is the LDS write only.
+constexpr int WG_TAPS = 4;             // taps per wave at most
+constexpr int WPP = 32;                // LDS pixel pitch of the weight-gradient kernel
+constexpr int WG_HALO_F4 = ((TR + KMAX - 1) * (IW + KMAX - 1) * (CC / 4) + 255) / 256;       // float4 per thread, halo (k = 7)
+constexpr int WG_GY_F4 = (TR * IW * (CC / 4) + 255) / 256;
+
+__device__ __forceinline__ void wgrad_fetch(const float* __restrict__ x, const float* __restrict__ dy, int tile, int p, int HW,
+                                            int HR, int tid, float4 (&hv)[WG_HALO_F4], float4 (&gv)[WG_GY_F4]) {
+    const int n = tile / (IH / TR), r0 = (tile % (IH / TR)) * TR;
+#pragma unroll
+    for (int u = 0; u < WG_HALO_F4; ++u) {
+        const int i = tid + 256 * u;
+        const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
+        const int yy = r0 - p + hy, xx = hx - p;
+        hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hy < HR && yy >= 0 && yy < IH && xx >= 0 && xx < IW)
+            hv[u] = *reinterpret_cast<const float4*>(x + (((long)n * IH + yy) * IW + xx) * CC + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < WG_GY_F4; ++u) {
+        const int i = tid + 256 * u;
+        gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < TR * IW * (CC / 4)) gv[u] = *reinterpret_cast<const float4*>(dy + ((long)n * IH + r0) * IW * CC + 4L * i);
+    }
+}
+
+// one staged tile: D_q[ci][co] += x[pixel + off_q][ci] * dy[pixel][co] over the tile's 112 pixels, two per MFMA, NQ taps
+template <int NQ>
+__device__ __forceinline__ void wgrad_tile(const float* halo, const float* gy, int HW, int kp, int ci, const int (&base)[WG_TAPS],
+                                           f32x16 (&acc)[WG_TAPS]) {
+    for (int py = 0; py < TR; ++py) {
+        const float* hrow = halo + py * HW * WPP;
+        const float* grow = gy + (py * IW + kp) * WPP + ci;
+#pragma unroll 7
+        for (int xx = 0; xx < IW / 2; ++xx) {                // pixels 2xx + kp of row py
+            const float b = grow[2 * xx * WPP];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = lv_mfma_32x32x2(hrow[base[q] + 2 * xx * WPP], b, acc[q]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dwp, int N, int k, int tiles_per_slab) {
-    __shared__ __attribute__((aligned(16))) float halo[(TR + KMAX - 1) * (IW + KMAX - 1) * PP];
-    __shared__ __attribute__((aligned(16))) float gy[TR * IW * PP];
+    __shared__ __attribute__((aligned(16))) float halo[(TR + KMAX - 1) * (IW + KMAX - 1) * WPP];
+    __shared__ __attribute__((aligned(16))) float gy[TR * IW * WPP];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int KK = k * k, p = k / 2, HW = IW + 2 * p, HR = TR + 2 * p;
-    const int gw = (int)blockIdx.y * 4 + w;                  // wave index among the 16 that share the taps
+    const int nw = 4 * (int)gridDim.y;                       // waves that share the taps
+    const int gw = (int)blockIdx.y * 4 + w;
     f32x16 acc[WG_TAPS];
 #pragma unroll
     for (int q = 0; q < WG_TAPS; ++q)
@@ -106,40 +167,45 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restri
     const int t0 = (int)blockIdx.x * tiles_per_slab;
     const int t1 = t0 + tiles_per_slab < ntiles ? t0 + tiles_per_slab : ntiles;
     const int ci = l & 31, kp = l >> 5;
+    // LDS offset of this lane's x operand for pixel pair 0 of row 0, per tap; taps beyond k*k alias tap 0 and are not stored
+    int base[WG_TAPS];
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < WG_TAPS; ++q) {
+        const int t = gw + nw * q;
+        if (t < KK) nq = q + 1;
+        const int tt = t < KK ? t : 0;
+        base[q] = ((tt / k) * HW + (kp + tt % k)) * WPP + ci;
+    }
+    nq = lv_wave_uniform(nq);
+    float4 hv[WG_HALO_F4], gv[WG_GY_F4];
+    if (t0 < t1) wgrad_fetch(x, dy, t0, p, HW, HR, tid, hv, gv);
     for (int tile = t0; tile < t1; ++tile) {
-        const int n = tile / (IH / TR), r0 = (tile % (IH / TR)) * TR;
-        __syncthreads();
-        for (int i = tid; i < HR * HW * (CC / 4); i += 256) {
-            const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
-            const int yy = r0 - p + hy, xx = hx - p;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < IH && xx >= 0 && xx < IW)
-                v = *reinterpret_cast<const float4*>(x + (((long)n * IH + yy) * IW + xx) * CC + 4 * c4);
-            *reinterpret_cast<float4*>(&halo[(hy * HW + hx) * PP + 4 * c4]) = v;
-        }
-        for (int i = tid; i < TR * IW * (CC / 4); i += 256) {
-            const int c4 = i % (CC / 4), pix = i / (CC / 4);
-            *reinterpret_cast<float4*>(&gy[pix * PP + 4 * c4]) =
-                *reinterpret_cast<const float4*>(dy + (((long)n * IH + r0) * IW + pix) * CC + 4 * c4);
-        }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < WG_TAPS; ++q) {
-            const int t = gw + 16 * q;
-            if (t >= KK) continue;
-            const int dyo = t / k - p, dxo = t % k - p;
-            for (int m = 0; m < TR * IW / 2; ++m) {          // two pixels per MFMA: pixel 2m + kp
-                const int pix = 2 * m + kp, py = pix / IW, pxx = pix % IW;
-                const float a = halo[((py + p + dyo) * HW + (pxx + p + dxo)) * PP + ci];
-                const float b = gy[pix * PP + ci];
-                acc[q] = lv_mfma_32x32x2(a, b, acc[q]);      // D[ci][co] += x[pixel + off][ci] * dy[pixel][co]
-            }
+        for (int u = 0; u < WG_HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            if (i < HR * HW * (CC / 4)) *reinterpret_cast<float4*>(&halo[(i / (CC / 4)) * WPP + 4 * (i % (CC / 4))]) = hv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WG_GY_F4; ++u) {
+            const int i = tid + 256 * u;
+            if (i < TR * IW * (CC / 4)) *reinterpret_cast<float4*>(&gy[4 * i]) = gv[u];
+        }
+        __syncthreads();
+        if (tile + 1 < t1) wgrad_fetch(x, dy, tile + 1, p, HW, HR, tid, hv, gv);
+        switch (nq) {          // wave-uniform: the tap loop below is unrolled with no predication
+            case 1: wgrad_tile<1>(halo, gy, HW, kp, ci, base, acc); break;
+            case 2: wgrad_tile<2>(halo, gy, HW, kp, ci, base, acc); break;
+            case 3: wgrad_tile<3>(halo, gy, HW, kp, ci, base, acc); break;
+            case 4: wgrad_tile<4>(halo, gy, HW, kp, ci, base, acc); break;
+            default: break;
         }
     }
     float* outp = dwp + (long)blockIdx.x * KK * CC * CC;
 #pragma unroll
     for (int q = 0; q < WG_TAPS; ++q) {
-        const int t = gw + 16 * q;
+        const int t = gw + nw * q;
         if (t >= KK) continue;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -171,11 +237,12 @@ __global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* _
 
 // floats of the packed weight image for `ntaps` taps / of the weight-gradient scratch for N images and a k x k kernel
 extern "C" long lv_conv32_wpack_floats(int ntaps) { return (long)ntaps * 16 * 64; }
-extern "C" int lv_conv32_wgrad_slabs(int N) {
-    const int ntiles = N * (IH / TR);
-    return ntiles < 64 ? ntiles : 64;
+static inline int wgrad_groups(int k) { return k >= 7 ? 4 : k >= 5 ? 2 : 1; }
+extern "C" int lv_conv32_wgrad_slabs(int N, int k) {
+    const int ntiles = N * (IH / TR), cap = 256 / wgrad_groups(k);
+    return ntiles < cap ? ntiles : cap;
 }
-extern "C" long lv_conv32_wgrad_ws_floats(int N, int k) { return (long)lv_conv32_wgrad_slabs(N) * k * k * CC * CC; }
+extern "C" long lv_conv32_wgrad_ws_floats(int N, int k) { return (long)lv_conv32_wgrad_slabs(N, k) * k * k * CC * CC; }
 
 // pack the first `ntaps` (raster order) taps of w [32][32][k*k] (the reference's nn.Conv2d layout) for lv_conv32_f32;
 // transpose != 0: the data-gradient image (roles of the channel indices swapped)
@@ -208,10 +275,10 @@ extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, f
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1)) return LV_ERR_SHAPE;
     if (((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return LV_ERR_ALIGN;
     const int ntiles = N * (IH / TR);
-    const int slabs = lv_conv32_wgrad_slabs(N);
+    const int slabs = lv_conv32_wgrad_slabs(N, k);
     const int tps = lv_cdiv(ntiles, slabs);
     const int used = lv_cdiv(ntiles, tps);
-    LV_LAUNCH(conv32_wgrad_kernel, dim3((unsigned)used, 4), dim3(256), 0, stream, x, dy, ws, N, k, tps);
+    LV_LAUNCH(conv32_wgrad_kernel, dim3((unsigned)used, (unsigned)wgrad_groups(k)), dim3(256), 0, stream, x, dy, ws, N, k, tps);
     LV_LAUNCH(conv32_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)k * k * CC * CC, 256)), dim3(256), 0, stream, (const float*)ws,
               dw, k * k, used, accumulate);
     LV_CHECK_LAUNCH();
@@ -283,72 +350,102 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     }
 }
 
-// stage 1 of the weight gradient: dwp[slab][co][ci] = sum over the slab's pixels of dy[p][co] x[p][ci]; the (COUT/32) x (CIN/32)
-// output blocks are dealt to the 4 waves (at most 4 blocks)
+// stage 1 of the weight gradient: every wave takes a contiguous run of pixels and accumulates the whole dy^T x matrix
+// ((COUT/32) x (CIN/32) MFMA blocks) with operands loaded straight from global memory -- for v_mfma_f32_32x32x2_f32 with
+// k = pixel both operands are channel-contiguous per pixel, i.e. each load is two coalesced 128-byte rows -- in batches of
+// PW_U pixel pairs so that all of a batch's loads are in flight together.  The 8 waves of a workgroup are summed through
+// LDS in a fixed tree and the workgroup writes one partial: dwp[wg][co][ci].
+constexpr int PW_U = 10;
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ dwp, long P, long pix_per_slab) {
-    constexpr int PX = CIN + 1, PY = COUT + 1;          // scalar LDS reads along the channel index: odd pitch
-    __shared__ float sx[PWP * PX];
-    __shared__ float sy[PWP * PY];
+__global__ __launch_bounds__(512) void conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dwp, long P, long pix_per_wave) {
+    constexpr int NA = COUT / 32, NB = CIN / 32, NACC = NA * NB;
+    __shared__ float red[4][NACC * 16 * 64];
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    constexpr int NBLK = (COUT / 32) * (CIN / 32);
-    const int blk = wv % NBLK, ksplit = wv / NBLK;       // waves beyond NBLK split the pixel range of a block
-    constexpr int KS = 4 / NBLK > 0 ? 4 / NBLK : 1;
-    const int cob = blk / (CIN / 32), cib = blk % (CIN / 32);
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const long s0 = (long)blockIdx.x * pix_per_slab;
-    const long s1 = s0 + pix_per_slab < P ? s0 + pix_per_slab : P;
     const int kp = l >> 5, cl = l & 31;
-    for (long p0 = s0; p0 < s1; p0 += PWP) {
-        __syncthreads();
-        for (int i = tid; i < PWP * CIN; i += 256) {
-            const int c = i % CIN, pp = i / CIN;
-            sx[pp * PX + c] = p0 + pp < s1 ? x[(p0 + pp) * CIN + c] : 0.f;
-        }
-        for (int i = tid; i < PWP * COUT; i += 256) {
-            const int c = i % COUT, pp = i / COUT;
-            sy[pp * PY + c] = p0 + pp < s1 ? dy[(p0 + pp) * COUT + c] : 0.f;
-        }
-        __syncthreads();
-        if (wv < NBLK * KS) {
-            // D[co][ci] += dy[p][co] * x[p][ci], two pixels per MFMA; this wave's share of the 128 staged pixels
-            const int m0 = ksplit * (PWP / 2 / KS), m1 = m0 + PWP / 2 / KS;
-            for (int m = m0; m < m1; ++m) {
-                const int pp = 2 * m + kp;
-                acc = lv_mfma_32x32x2(sy[pp * PY + cob * 32 + cl], sx[pp * PX + cib * 32 + cl], acc);
-            }
-        }
-    }
-    // partial layout [slab][KS][COUT][CIN]
-    if (wv < NBLK * KS) {
-        float* o = dwp + ((long)blockIdx.x * KS + ksplit) * COUT * CIN;
+    f32x16 acc[NACC];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);      // co within the block
-            o[(long)(cob * 32 + row) * CIN + cib * 32 + cl] = acc[e];
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const long p0 = ((long)blockIdx.x * 8 + wv) * pix_per_wave;
+    const long p1 = p0 + pix_per_wave < P ? p0 + pix_per_wave : P;
+    for (long p = p0; p < p1; p += 2 * PW_U) {
+        float a[PW_U][NA], b[PW_U][NB];
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u) {
+            const long pp = p + 2 * u + kp;
+            const bool ok = pp < p1;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a[u][i] = ok ? dy[pp * COUT + 32 * i + cl] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) b[u][j] = ok ? x[pp * CIN + 32 * j + cl] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < PW_U; ++u)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i * NB + j] = lv_mfma_32x32x2(a[u][i], b[u][j], acc[i * NB + j]);
+    }
+    // 8 -> 4 -> 2 -> 1 waves
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[wv - half][(q * 16 + e) * 64 + l] = acc[q][e];
+        }
+        __syncthreads();
+        if (wv < half) {
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][e] += red[wv][(q * 16 + e) * 64 + l];
+        }
+        __syncthreads();
+    }
+    if (wv == 0) {
+        float* o = dwp + (long)blockIdx.x * COUT * CIN;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);      // co within the block
+                    o[(long)(32 * i + row) * CIN + 32 * j + cl] = acc[i * NB + j][e];
+                }
     }
 }
 
+// stage 2: dw[idx] (=|+=) sum_part dwp[part][idx]; a workgroup owns 32 outputs (8 float4 lanes) and deals the partials to its
+// 32 thread groups (all loads of a thread in flight together), then sums the groups in a fixed order through LDS
+constexpr int PW_PARTS_MAX = 256;
 __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int n,
                                                                    int parts, int accumulate) {
-    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (idx >= n) return;
-    float s = 0.f;
-    for (int b0 = 0; b0 < parts; b0 += 8) {
-        float v[8];
+    __shared__ __attribute__((aligned(16))) float sred[32][32];
+    const int tid = (int)threadIdx.x, f4 = tid & 7, sub = tid >> 3;
+    const long base = (long)blockIdx.x * 32 + 4 * f4;
+    float4 v[PW_PARTS_MAX / 32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = dwp[(long)(b0 + u < parts ? b0 + u : 0) * n + idx];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += b0 + u < parts ? v[u] : 0.f;
+    for (int u = 0; u < PW_PARTS_MAX / 32; ++u) {
+        const int part = sub + 32 * u;
+        v[u] = part < parts ? *reinterpret_cast<const float4*>(dwp + (long)part * n + base) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    dw[idx] = accumulate ? dw[idx] + s : s;
+    float4 s = v[0];
+#pragma unroll
+    for (int u = 1; u < PW_PARTS_MAX / 32; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    *reinterpret_cast<float4*>(&sred[sub][4 * f4]) = s;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += sred[k][tid];
+        const long idx = (long)blockIdx.x * 32 + tid;
+        dw[idx] = accumulate ? dw[idx] + t : t;
+    }
 }
-
-constexpr int PW_SLABS = 128;
 
 }  // namespace
 
@@ -369,25 +466,26 @@ extern "C" int lv_conv1x1_f32(const float* in, const float* w, float* out, long 
     return LV_OK;
 }
 
-extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_SLABS * 4 * Cin * Cout; }
+extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_PARTS_MAX * Cin * Cout; }
 
 // dw [Cout][Cin] (=|+=) dy^T . x over P pixels; ws: lv_conv1x1_wgrad_ws_floats floats
 extern "C" int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
                                     void* stream) {
     if (!x || !dy || !dw || !ws) return LV_ERR_ARG;
     if (P <= 0) return LV_ERR_SHAPE;
-    long per = lv_cdiv(P, PW_SLABS);
-    per = (per + PWP - 1) / PWP * PWP;
-    const int slabs = lv_cdiv(P, per);
-    const dim3 grid((unsigned)slabs), block(256);
-    int ks;
-    if (Cin == 64 && Cout == 32) { ks = 2; LV_LAUNCH((conv1x1_wgrad_kernel<64, 32>), grid, block, 0, stream, x, dy, ws, P, per); }
-    else if (Cin == 32 && Cout == 64) { ks = 2; LV_LAUNCH((conv1x1_wgrad_kernel<32, 64>), grid, block, 0, stream, x, dy, ws, P, per); }
-    else if (Cin == 64 && Cout == 64) { ks = 1; LV_LAUNCH((conv1x1_wgrad_kernel<64, 64>), grid, block, 0, stream, x, dy, ws, P, per); }
-    else if (Cin == 32 && Cout == 32) { ks = 4; LV_LAUNCH((conv1x1_wgrad_kernel<32, 32>), grid, block, 0, stream, x, dy, ws, P, per); }
+    // an even number of pixels per wave (a pixel pair per MFMA), at least one batch each, at most PW_PARTS_MAX workgroups
+    long ppw = lv_cdiv(P, (long)PW_PARTS_MAX * 8);
+    if (ppw < 2 * PW_U) ppw = 2 * PW_U;
+    ppw = (ppw + 1) / 2 * 2;
+    const int wgs = (int)lv_cdiv(P, ppw * 8);
+    const dim3 grid((unsigned)wgs), block(512);
+    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_wgrad_kernel<64, 32>), grid, block, 0, stream, x, dy, ws, P, ppw);
+    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_wgrad_kernel<32, 64>), grid, block, 0, stream, x, dy, ws, P, ppw);
+    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_wgrad_kernel<64, 64>), grid, block, 0, stream, x, dy, ws, P, ppw);
+    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_wgrad_kernel<32, 32>), grid, block, 0, stream, x, dy, ws, P, ppw);
     else return LV_ERR_UNSUPPORTED;
-    LV_LAUNCH(conv1x1_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)Cin * Cout, 256)), dim3(256), 0, stream, (const float*)ws, dw,
-              Cin * Cout, slabs * ks, accumulate);
+    LV_LAUNCH(conv1x1_wgrad_reduce_kernel, dim3((unsigned)(Cin * Cout / 32)), dim3(256), 0, stream, (const float*)ws, dw, Cin * Cout,
+              wgs, accumulate);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

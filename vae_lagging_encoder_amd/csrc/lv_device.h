@@ -13,6 +13,7 @@
 static inline f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) { return lv_emu_mfma_16x16x4(a, b, c); }
 static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu_mfma_32x32x2(a, b, c); }
 #define LV_SCHED_BARRIER() do { } while (0)
+static inline int lv_wave_uniform(int v) { return v; }
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
@@ -66,6 +67,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LV_DYN_SHARED(name) extern __shared__ __attribute__((aligned(16))) char name[]
 // pin instruction order across this point (keeps a block of independent loads issued ahead of their consumers)
 #define LV_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// a value every lane of the wave agrees on, moved to a scalar register (branches on it are scalar branches, not exec masks)
+__device__ __forceinline__ int lv_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]
 __device__ __forceinline__ f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
