@@ -285,6 +285,16 @@ int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*
 int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed, int accumulate,
                    void* stream);
 long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
+/* Forward convolutions that also leave the stage-1 partials (per-workgroup per-channel sum and sum of squares of their
+ * outputs, [blocks][2][Cout]) of the nn.BatchNorm2d that follows them in PixelCNNBlock (dec_pixelcnn_v2.py:41-52), consumed
+ * by lv_bn_fwd_partials_f32: the normalisation's statistics pass over the activation is saved. */
+int lv_conv32_blocks(int N);
+int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream);
+long lv_conv1x1_blocks(long P);
+int lv_conv1x1_bnstat_f32(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, void* stream);
+int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu, float* y,
+                           float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum,
+                           const float* partial, int nblk, long P, int C, void* stream);
 int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
                          void* stream);
 /* nn.BatchNorm2d in train mode (batch statistics, running stats momentum update with unbiased variance) fused with the

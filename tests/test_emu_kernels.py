@@ -175,3 +175,8 @@ def test_conv32_direct(emu_backend, cfg):
 @pytest.mark.parametrize("cfg", [(1000, 64, 32), (300, 32, 64), (129, 64, 64), (70, 32, 32)])
 def test_conv1x1(emu_backend, cfg):
     K.test_conv1x1_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(3, 5, 64, 32), (2, 3, 32, 64)])
+def test_conv_bnstat(emu_backend, cfg):
+    K.test_conv_bnstat_feeds_batchnorm(emu_backend, CPU, *cfg)

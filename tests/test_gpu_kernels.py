@@ -985,3 +985,59 @@ def test_conv1x1_fwd_dgrad_wgrad(lib, hip_device, P_, Cin, Cout):
     lib.lv_conv1x1_wgrad_f32(P(xd), P(dyd), P(dw), P(ws), P_, Cin, Cout, 0, _s(dev))
     refdw = dy.double().t() @ x.double()
     assert float((dw.cpu().double() - refdw).abs().max()) < 2e-5 * float(refdw.abs().max())
+
+
+@pytest.mark.parametrize("N,k,Cin,Cout", [(3, 5, 64, 32), (50, 3, 32, 64), (2, 7, 64, 64)])
+def test_conv_bnstat_feeds_batchnorm(lib, hip_device, N, k, Cin, Cout):
+    """The convolutions that also emit the following BatchNorm's stage-1 partials (lv_conv32_bnstat_f32, lv_conv1x1_bnstat_f32):
+    same outputs as the plain entries, and lv_bn_fwd_partials_f32 on their partials == lv_bn_fwd_f32 on the activation."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(N + k)
+
+    def bn_both(y, C, nblk, part):
+        Pn = y.shape[0]
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        res = torch.randn(Pn, C, generator=g).to(dev)
+        outs = []
+        for fused in (False, True):
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            o, mean, invstd = torch.empty(Pn, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+            if fused:
+                lib.lv_bn_fwd_partials_f32(P(y), P(gamma), P(beta), P(res), 1, P(o), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1,
+                                           P(part), nblk, Pn, C, _s(dev))
+            else:
+                ws = torch.empty(lib.lv_bn_workspace_floats(C) + 2 * C, device=dev)
+                lib.lv_bn_fwd_f32(P(y), P(gamma), P(beta), P(res), 1, P(o), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1, P(ws), Pn, C,
+                                  _s(dev))
+            outs.append((o.cpu(), mean.cpu(), invstd.cpu(), rm.cpu(), rv.cpu()))
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+    # 32 -> 32 k x k
+    x = torch.randn(N * 784, 32, generator=g).to(dev)
+    w = (torch.randn(32, 32, k, k, generator=g) / (32 * k) ** 0.5).to(dev)
+    nt = (k // 2) * k + k // 2 + 1
+    wp = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    lib.lv_conv32_pack_f32(P(w), P(wp), k, nt, 0, _s(dev))
+    y0, y1 = torch.empty(N * 784, 32, device=dev), torch.empty(N * 784, 32, device=dev)
+    nblk = lib.lv_conv32_blocks(N)
+    part = torch.full((nblk, 2, 32), float("nan"), device=dev)
+    lib.lv_conv32_f32(P(x), P(wp), P(y0), N, k, nt, 0, 0, _s(dev))
+    lib.lv_conv32_bnstat_f32(P(x), P(wp), P(y1), P(part), N, k, nt, _s(dev))
+    assert torch.equal(y0.cpu(), y1.cpu())
+    ref = torch.stack((y0.double().sum(0), (y0.double() ** 2).sum(0))).cpu()
+    assert float((part.double().sum(0).cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    bn_both(y1, 32, nblk, part)
+    # pointwise
+    Pn = N * 784
+    x = torch.randn(Pn, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).to(dev)
+    y0, y1 = torch.empty(Pn, Cout, device=dev), torch.empty(Pn, Cout, device=dev)
+    nblk = int(lib.lv_conv1x1_blocks(Pn))
+    part = torch.full((nblk, 2, Cout), float("nan"), device=dev)
+    lib.lv_conv1x1_f32(P(x), P(w), P(y0), Pn, Cin, Cout, 0, 0, _s(dev))
+    lib.lv_conv1x1_bnstat_f32(P(x), P(w), P(y1), P(part), Pn, Cin, Cout, _s(dev))
+    assert torch.equal(y0.cpu(), y1.cpu())
+    ref = torch.stack((y0.double().sum(0), (y0.double() ** 2).sum(0))).cpu()
+    assert float((part.double().sum(0).cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    bn_both(y1, Cout, nblk, part)

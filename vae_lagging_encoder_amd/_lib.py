@@ -96,6 +96,11 @@ SIGNATURES = {
     "lv_conv32_wgrad_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_f32": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "lv_conv1x1_wgrad_ws_floats": [_i, _i],
+    "lv_conv32_blocks": [_i],
+    "lv_conv32_bnstat_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_conv1x1_blocks": [_l],
+    "lv_conv1x1_bnstat_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp],
+    "lv_bn_fwd_partials_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _l, _i, _vp],
     "lv_conv1x1_wgrad_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],
     "lv_bn_workspace_floats": [_i],
@@ -108,7 +113,7 @@ SIGNATURES = {
 }
 
 
-_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_conv32_wpack_floats",
+_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_conv32_wpack_floats",
              "lv_conv32_wgrad_ws_floats")
 
 
@@ -136,7 +141,7 @@ class Lib(object):
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
-                           "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+                           "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):

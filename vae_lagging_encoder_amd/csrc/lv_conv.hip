@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
 // every workgroup of the apply kernel re-derives the per-channel totals from them (f64, fixed order: <= 64 KB of L2 reads per
 // workgroup) instead of waiting for a separate one-workgroup "finish" launch (5-6 us each, 162 of them per Omniglot step).
 constexpr int BN_V4_BLOCKS = 256;
+constexpr int BN_V4_ITEMS = 4;            // float4 per thread of the apply kernels
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -253,26 +254,43 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
         mu = *reinterpret_cast<const float4*>(mean + 4 * c4);
         is = *reinterpret_cast<const float4*>(invstd + 4 * c4);
     }
-    for (long r = (long)blockIdx.x * RPB + rsub; r < P; r += (long)nblk * RPB) {
-        const long i = r * C + 4 * c4;
-        if (MODE == 0) {
-            const float4 v = *reinterpret_cast<const float4*>(x + i);
-            a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
-            a1.x += v.x * v.x; a1.y += v.y * v.y; a1.z += v.z * v.z; a1.w += v.w * v.w;
-        } else {
-            float4 g = *reinterpret_cast<const float4*>(dy + i);
-            const float4 xv = *reinterpret_cast<const float4*>(x + i);
-            if (act) {
-                const float4 yy = *reinterpret_cast<const float4*>(y + i);
-                g.x = yy.x > 0.f ? g.x : g.x * (yy.x + 1.f);
-                g.y = yy.y > 0.f ? g.y : g.y * (yy.y + 1.f);
-                g.z = yy.z > 0.f ? g.z : g.z * (yy.z + 1.f);
-                g.w = yy.w > 0.f ? g.w : g.w * (yy.w + 1.f);
+    // 4 rows per trip, their loads issued together (the trip count is data-dependent: the compiler will not batch on its own)
+    const long stride = (long)nblk * RPB;
+    for (long r = (long)blockIdx.x * RPB + rsub; r < P; r += 4 * stride) {
+        float4 xv[4], gv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long rr = r + u * stride;
+            const long i = (rr < P ? rr : r) * C + 4 * c4;
+            xv[u] = *reinterpret_cast<const float4*>(x + i);
+            if (MODE == 1) {
+                gv[u] = *reinterpret_cast<const float4*>(dy + i);
+                if (act) yv[u] = *reinterpret_cast<const float4*>(y + i);
             }
-            *reinterpret_cast<float4*>(dv_out + i) = g;
-            a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
-            a1.x += g.x * ((xv.x - mu.x) * is.x); a1.y += g.y * ((xv.y - mu.y) * is.y);
-            a1.z += g.z * ((xv.z - mu.z) * is.z); a1.w += g.w * ((xv.w - mu.w) * is.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long rr = r + u * stride;
+            if (rr >= P) break;
+            const long i = rr * C + 4 * c4;
+            if (MODE == 0) {
+                const float4 v = xv[u];
+                a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+                a1.x += v.x * v.x; a1.y += v.y * v.y; a1.z += v.z * v.z; a1.w += v.w * v.w;
+            } else {
+                float4 g = gv[u];
+                if (act) {
+                    const float4 yy = yv[u];
+                    g.x = yy.x > 0.f ? g.x : g.x * (yy.x + 1.f);
+                    g.y = yy.y > 0.f ? g.y : g.y * (yy.y + 1.f);
+                    g.z = yy.z > 0.f ? g.z : g.z * (yy.z + 1.f);
+                    g.w = yy.w > 0.f ? g.w : g.w * (yy.w + 1.f);
+                }
+                *reinterpret_cast<float4*>(dv_out + i) = g;
+                a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
+                a1.x += g.x * ((xv[u].x - mu.x) * is.x); a1.y += g.y * ((xv[u].y - mu.y) * is.y);
+                a1.z += g.z * ((xv[u].z - mu.z) * is.z); a1.w += g.w * ((xv[u].w - mu.w) * is.w);
+            }
         }
     }
     // lanes of a wave with equal c4 (lane bits >= log2 CT4), then the 4 waves through LDS: a fixed order
@@ -358,20 +376,30 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
         }
     }
     __syncthreads();
-    const long n4 = P * (C >> 2), gs = (long)gridDim.x * 256;
+    // BN_V4_ITEMS float4 per thread, loads first
+    const long n4 = P * (C >> 2);
     const int CT4 = C >> 2;
-    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += gs) {
+    const long i0 = (long)blockIdx.x * (256 * BN_V4_ITEMS) + tid;
+    float4 xs[BN_V4_ITEMS], rs[BN_V4_ITEMS];
+#pragma unroll
+    for (int u = 0; u < BN_V4_ITEMS; ++u) {
+        const long i = i0 + 256 * u;
+        const long ii = i < n4 ? i : 0;
+        xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
+        if (res) rs[u] = *reinterpret_cast<const float4*>(res + 4 * ii);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_V4_ITEMS; ++u) {
+        const long i = i0 + 256 * u;
+        if (i >= n4) break;
         const int c = 4 * (int)(i & (CT4 - 1));
-        const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i);
+        const float4 xv = xs[u];
         const float4 m4 = *reinterpret_cast<const float4*>(&smu[c]), i4 = *reinterpret_cast<const float4*>(&sis[c]);
         const float4 g4 = *reinterpret_cast<const float4*>(&sga[c]), b4 = *reinterpret_cast<const float4*>(&sbe[c]);
         float4 v;
         v.x = (xv.x - m4.x) * i4.x * g4.x + b4.x; v.y = (xv.y - m4.y) * i4.y * g4.y + b4.y;
         v.z = (xv.z - m4.z) * i4.z * g4.z + b4.z; v.w = (xv.w - m4.w) * i4.w * g4.w + b4.w;
-        if (res) {
-            const float4 r4 = *reinterpret_cast<const float4*>(res + 4 * i);
-            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-        }
+        if (res) { v.x += rs[u].x; v.y += rs[u].y; v.z += rs[u].z; v.w += rs[u].w; }
         if (act) {
             v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
             v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
@@ -400,11 +428,23 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __res
         }
     }
     __syncthreads();
-    const long n4 = P * (C >> 2), gs = (long)gridDim.x * 256;
+    const long n4 = P * (C >> 2);
     const int CT4 = C >> 2;
-    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += gs) {
+    const long i0 = (long)blockIdx.x * (256 * BN_V4_ITEMS) + tid;
+    float4 xs[BN_V4_ITEMS], ds[BN_V4_ITEMS];
+#pragma unroll
+    for (int u = 0; u < BN_V4_ITEMS; ++u) {
+        const long i = i0 + 256 * u;
+        const long ii = i < n4 ? i : 0;
+        xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
+        ds[u] = *reinterpret_cast<const float4*>(dv + 4 * ii);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_V4_ITEMS; ++u) {
+        const long i = i0 + 256 * u;
+        if (i >= n4) break;
         const int c = 4 * (int)(i & (CT4 - 1));
-        const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i), d4 = *reinterpret_cast<const float4*>(dv + 4 * i);
+        const float4 xv = xs[u], d4 = ds[u];
         const float4 m4 = *reinterpret_cast<const float4*>(&smu[c]), i4 = *reinterpret_cast<const float4*>(&sis[c]);
         const float4 g4 = *reinterpret_cast<const float4*>(&sga[c]);
         const float4 dg = *reinterpret_cast<const float4*>(&sdg[c]), db = *reinterpret_cast<const float4*>(&sdb[c]);
@@ -423,10 +463,7 @@ static inline int bn_v4_blocks(long P, int C) {
     long nb = (P + 4L * rpb - 1) / (4L * rpb);          // >= 4 rows per thread
     return (int)(nb < 1 ? 1 : nb > BN_V4_BLOCKS ? BN_V4_BLOCKS : nb);
 }
-static inline unsigned bn_v4_apply_grid(long n4) {
-    const long g = lv_cdiv(n4, 256);
-    return (unsigned)(g > 512 ? 512 : g);
-}
+static inline unsigned bn_v4_apply_grid(long n4) { return (unsigned)lv_cdiv(n4, 256L * BN_V4_ITEMS); }
 
 // rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
 __global__ __launch_bounds__(256) void sigmoid_bce_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ x,
@@ -565,6 +602,21 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
               mean, invstd, run_mean, run_var);
     LV_LAUNCH(bn_apply_fwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)mean, (const float*)invstd, gamma,
               beta, res, act_elu, y, P * C, C);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// The same forward with the stage-1 partials already written by the producing convolution (lv_conv32_bnstat_f32 /
+// lv_conv1x1_bnstat_f32): partial [nblk][2][C], nblk <= 512.  C must take the vector path (power of two in [16, 256]).
+extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu,
+                                      float* y, float* mean, float* invstd, float* run_mean, float* run_var, float eps,
+                                      float momentum, const float* partial, int nblk, long P, int C, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !invstd || !partial) return LV_ERR_ARG;
+    if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
+    if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
+    LV_LAUNCH(bn_apply_fwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
+              act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -24,6 +24,7 @@ constexpr int IW = 28, IH = 28;        // feature map
 constexpr int TR = 4;                  // image rows per workgroup (one per wave)
 constexpr int PP = 36;                 // LDS pixel pitch in floats (16-byte aligned, 9 sixteen-byte slots: odd -> no conflicts)
 constexpr int KMAX = 7;
+constexpr int HALO_F4 = ((TR + KMAX - 1) * (IW + KMAX - 1) * (CC / 4) + 255) / 256;      // float4 per thread: the k = 7 halo
 
 // wp[t][s][lane]: lane (j = l & 31, k = l >> 5) holds the B element of k-step s: weight of (ci = 16k + s) -> (co = j) at tap t.
 // transpose != 0 (data gradient): roles of ci / co swapped (the kernel negates the tap offsets itself).
@@ -39,20 +40,34 @@ __global__ __launch_bounds__(256) void conv32_pack_kernel(const float* __restric
 
 // y[n][r][x][co] = sum_{t < ntaps} sum_ci in[n][r + dy_t][x + dx_t][ci] * W_t[ci][co],  (dy_t, dx_t) = (t / k - p, t % k - p),
 // negated when `mirror` (data gradient: the prefix of the mirrored tap order).
+// bn_partial != nullptr: also writes this workgroup's per-channel (sum, sum of squares) of its 112 outputs as
+// bn_partial[block][2][32] -- the stage-1 partials of the BatchNorm that follows (lv_bn_fwd_partials_f32), saving its pass over y.
 __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
-                                                            float* __restrict__ out, int k, int ntaps, int mirror, int accumulate) {
+                                                            float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
+                                                            int mirror, int accumulate) {
     __shared__ __attribute__((aligned(16))) float halo[(TR + KMAX - 1) * (IW + KMAX - 1) * PP];
+    __shared__ float sstat[4][2][CC];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int n = (int)blockIdx.x / (IH / TR), r0 = ((int)blockIdx.x % (IH / TR)) * TR;
     const int p = k / 2, HW = IW + 2 * p, HR = TR + 2 * p;
-    // stage rows r0-p .. r0+TR-1+p, columns -p .. IW-1+p (zero outside the image)
-    for (int i = tid; i < HR * HW * (CC / 4); i += 256) {
-        const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
-        const int gy = r0 - p + hy, gx = hx - p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < IH && gx >= 0 && gx < IW)
-            v = *reinterpret_cast<const float4*>(in + (((long)n * IH + gy) * IW + gx) * CC + 4 * c4);
-        *reinterpret_cast<float4*>(&halo[(hy * HW + hx) * PP + 4 * c4]) = v;
+    // stage rows r0-p .. r0+TR-1+p, columns -p .. IW-1+p (zero outside the image): all of a thread's loads first (in flight
+    // together), then the LDS writes -- a load -> store loop would pay one memory round trip per iteration
+    {
+        float4 hv[HALO_F4];
+#pragma unroll
+        for (int u = 0; u < HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
+            const int gy = r0 - p + hy, gx = hx - p;
+            hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW)
+                hv[u] = *reinterpret_cast<const float4*>(in + (((long)n * IH + gy) * IW + gx) * CC + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            if (i < HR * HW * (CC / 4)) *reinterpret_cast<float4*>(&halo[(i / (CC / 4)) * PP + 4 * (i % (CC / 4))]) = hv[u];
+        }
     }
     __syncthreads();
     f32x16 acc;
@@ -93,12 +108,25 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     if (t < ntaps) tap(b0, t);
     const int r = r0 + w;
     const int col = l & 31;
+    float st0 = 0.f, st1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
         if (x < IW) {
             float* o = out + (((long)n * IH + r) * IW + x) * CC + col;
-            *o = accumulate ? *o + acc[e] : acc[e];
+            const float v = accumulate ? *o + acc[e] : acc[e];
+            *o = v;
+            st0 += v; st1 += v * v;
+        }
+    }
+    if (bn_partial) {
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        if (l < 32) { sstat[w][0][l] = st0; sstat[w][1][l] = st1; }
+        __syncthreads();
+        if (tid < 2 * CC) {
+            const int q = tid / CC, c = tid % CC;
+            bn_partial[((long)blockIdx.x * 2 + q) * CC + c] = ((sstat[0][q][c] + sstat[1][q][c]) + sstat[2][q][c]) + sstat[3][q][c];
         }
     }
 }
@@ -111,7 +139,7 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
 // multiplied, so the staging cost is the LDS write only.
 constexpr int WG_TAPS = 4;             // taps per wave at most
 constexpr int WPP = 32;                // LDS pixel pitch of the weight-gradient kernel
-constexpr int WG_HALO_F4 = ((TR + KMAX - 1) * (IW + KMAX - 1) * (CC / 4) + 255) / 256;       // float4 per thread, halo (k = 7)
+constexpr int WG_HALO_F4 = HALO_F4;
 constexpr int WG_GY_F4 = (TR * IW * (CC / 4) + 255) / 256;
 
 __device__ __forceinline__ void wgrad_fetch(const float* __restrict__ x, const float* __restrict__ dy, int tile, int p, int HW,
@@ -264,7 +292,19 @@ extern "C" int lv_conv32_f32(const float* in, const float* wp, float* out, int N
     if (!in || !wp || !out) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
-    LV_LAUNCH(conv32_direct_kernel, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, k, ntaps, mirror, accumulate);
+    LV_LAUNCH(conv32_direct_kernel, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps, mirror,
+              accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// forward convolution that also leaves the following BatchNorm's stage-1 partials: bn_partial [lv_conv32_blocks(N)][2][32]
+extern "C" int lv_conv32_blocks(int N) { return N * (IH / TR); }
+extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream) {
+    if (!in || !wp || !out || !bn_partial) return LV_ERR_ARG;
+    if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
+    if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
+    LV_LAUNCH(conv32_direct_kernel, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -295,24 +335,36 @@ extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, f
 // (one 32 x 32 block per wave) and a fixed-order reduction sums the slabs.
 namespace {
 
-constexpr int PWP = 128;               // pixels per workgroup
+constexpr int PWP = 160;               // pixels per workgroup (5 waves x 32): 39200 pixels -> 245 workgroups, one round on 256 CUs
+constexpr int PWT = 2 * PWP;           // threads
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                                                      long P, int w_transposed, int accumulate) {
+__global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                      float* __restrict__ bn_partial, long P, int w_transposed, int accumulate) {
     constexpr int PA = CIN + 4;        // LDS pitches (floats): 16-byte slots per row odd -> conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) float sa[PWP * PA];
     __shared__ __attribute__((aligned(16))) float sw[COUT * PA];
+    __shared__ float sstat[PWP / 32][2][COUT];
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const long p0 = (long)blockIdx.x * PWP;
-    for (int i = tid; i < PWP * (CIN / 4); i += 256) {
-        const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p0 + pp < P) v = *reinterpret_cast<const float4*>(in + (p0 + pp) * CIN + 4 * c4);
-        *reinterpret_cast<float4*>(&sa[pp * PA + 4 * c4]) = v;
+    constexpr int NF4 = PWP * (CIN / 4) / PWT;           // float4 per thread (8 or 4): loads first, then the LDS writes
+    {
+        float4 v[NF4];
+#pragma unroll
+        for (int u = 0; u < NF4; ++u) {
+            const int i = tid + PWT * u;
+            const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + pp < P) v[u] = *reinterpret_cast<const float4*>(in + (p0 + pp) * CIN + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < NF4; ++u) {
+            const int i = tid + PWT * u;
+            *reinterpret_cast<float4*>(&sa[(i / (CIN / 4)) * PA + 4 * (i % (CIN / 4))]) = v[u];
+        }
     }
     // sw[co][ci] = W[co][ci]  (w stored [COUT][CIN]), or W^T when the caller hands the [CIN][COUT] matrix of the forward
-    for (int i = tid; i < COUT * CIN; i += 256) {
+    for (int i = tid; i < COUT * CIN; i += PWT) {
         const int ci = i % CIN, co = i / CIN;
         sw[co * PA + ci] = w_transposed ? w[(long)ci * COUT + co] : w[i];
     }
@@ -339,13 +391,31 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
             acc = lv_mfma_32x32x2(av[s + 2], q.z, acc);
             acc = lv_mfma_32x32x2(av[s + 3], q.w, acc);
         }
+        float st0 = 0.f, st1 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const long pp = p0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
             if (pp < P) {
                 float* o = out + pp * COUT + nb * 32 + (l & 31);
-                *o = accumulate ? *o + acc[e] : acc[e];
+                const float v = accumulate ? *o + acc[e] : acc[e];
+                *o = v;
+                st0 += v; st1 += v * v;
             }
+        }
+        if (bn_partial) {
+            st0 += __shfl_xor(st0, 32, 64);
+            st1 += __shfl_xor(st1, 32, 64);
+            if (l < 32) { sstat[wv][0][nb * 32 + l] = st0; sstat[wv][1][nb * 32 + l] = st1; }
+        }
+    }
+    if (bn_partial) {
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int q = tid / COUT, c = tid % COUT;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < PWP / 32; ++k) t += sstat[k][q][c];
+            bn_partial[((long)blockIdx.x * 2 + q) * COUT + c] = t;
         }
     }
 }
@@ -449,6 +519,18 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
 
 }  // namespace
 
+static int conv1x1_launch(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, int w_transposed,
+                          int accumulate, void* stream) {
+    const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(PWT);
+    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else return LV_ERR_UNSUPPORTED;
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
 // out [P][Cout] (=|+=) in [P][Cin] . W^T with W [Cout][Cin] (w_transposed = 0) or given as [Cin][Cout] (w_transposed = 1: the
 // data gradient of the forward convolution whose weight this is).  (Cin, Cout) in {32, 64}^2; else LV_ERR_UNSUPPORTED.
 extern "C" int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed,
@@ -456,14 +538,17 @@ extern "C" int lv_conv1x1_f32(const float* in, const float* w, float* out, long 
     if (!in || !w || !out) return LV_ERR_ARG;
     if (P <= 0) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
-    const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(256);
-    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
-    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
-    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
-    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, P, w_transposed, accumulate);
-    else return LV_ERR_UNSUPPORTED;
-    LV_CHECK_LAUNCH();
-    return LV_OK;
+    return conv1x1_launch(in, w, out, nullptr, P, Cin, Cout, w_transposed, accumulate, stream);
+}
+
+// forward that also leaves the following BatchNorm's stage-1 partials: bn_partial [lv_conv1x1_blocks(P)][2][Cout]
+extern "C" long lv_conv1x1_blocks(long P) { return lv_cdiv(P, PWP); }
+extern "C" int lv_conv1x1_bnstat_f32(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout,
+                                     void* stream) {
+    if (!in || !w || !out || !bn_partial) return LV_ERR_ARG;
+    if (P <= 0) return LV_ERR_SHAPE;
+    if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
+    return conv1x1_launch(in, w, out, bn_partial, P, Cin, Cout, 0, 0, stream);
 }
 
 extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_PARTS_MAX * Cin * Cout; }

@@ -15,14 +15,18 @@ from .engine import P, FlatBuffer, _gemm, backend_for, stream_ptr
 
 class Act(object):
     """An NHWC activation: t is a contiguous [N*H*W, C] fp32 tensor."""
-    __slots__ = ("t", "N", "H", "W", "C", "needs_grad")
+    __slots__ = ("t", "N", "H", "W", "C", "needs_grad", "bn_nblk")
 
     def __init__(self, t, N, H, W, C, needs_grad=True):
         self.t, self.N, self.H, self.W, self.C, self.needs_grad = t, N, H, W, C, needs_grad
+        self.bn_nblk = 0       # > 0: the producer left this many BatchNorm stage-1 partial blocks in the tape's BN workspace
 
     @property
     def P(self):
         return self.N * self.H * self.W
+
+
+_BN_MAX_BLOCKS = 512          # partial blocks a BN workspace holds (lv_bn_workspace_floats)
 
 
 def pack_conv32(lib, s, ent):
@@ -87,9 +91,11 @@ class Tape(object):
         self.back = []
 
     # -- ops -----------------------------------------------------------------------------------------------------
-    def conv(self, x, weight, gview, stride=1, pad=0, ntaps=None, mask=None):
+    def conv(self, x, weight, gview, stride=1, pad=0, ntaps=None, mask=None, bn_stats=False):
         """nn.Conv2d(bias=False) / MaskedConv2d on NHWC x.  weight: [Cout][Cin][kh][kw] parameter view; gview: where
-        its gradient goes.  ntaps: raster-order tap prefix used by forward / data-gradient (None = all taps)."""
+        its gradient goes.  ntaps: raster-order tap prefix used by forward / data-gradient (None = all taps).
+        bn_stats: the output goes straight into a train-mode BatchNorm -- the direct kernels then leave its per-channel
+        partial sums in the tape's BN workspace (Act.bn_nblk > 0) and Tape.bn skips its statistics pass."""
         lib, s = self.lib, self.s()
         Cout, Cin, kh, kw = weight.shape
         assert Cin == x.C
@@ -101,9 +107,9 @@ class Tape(object):
         direct32 = (Cin == 32 and Cout == 32 and stride == 1 and x.H == 28 and x.W == 28 and kh == kw and pad == kh // 2
                     and kh in (3, 5, 7))
         if direct32:
-            return self._conv32(x, weight, gview, kh, nt, mask)
+            return self._conv32(x, weight, gview, kh, nt, mask, bn_stats and self.train)
         if KK == 1 and stride == 1 and pad == 0 and mask is None and Cin in (32, 64) and Cout in (32, 64):
-            return self._conv1x1(x, weight, gview)
+            return self._conv1x1(x, weight, gview, bn_stats and self.train)
         if mask is not None:
             # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
             # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
@@ -145,7 +151,7 @@ class Tape(object):
         self.back.append(bwd)
         return out
 
-    def _conv32(self, x, weight, gview, k, nt, mask):
+    def _conv32(self, x, weight, gview, k, nt, mask, bn_stats=False):
         """32 -> 32 channel k x k convolution on a 28 x 28 map without an im2col buffer (lv_conv_direct.hip): forward and data
         gradient over the mask's tap prefix, weight gradient over all taps."""
         lib, s = self.lib, self.s()
@@ -158,8 +164,12 @@ class Tape(object):
             ent["ver"] = self.wver if self.wver is not None else object()
         wp, wpt = ent["wp"], ent["wpt"]
         y = self.f32(x.P, 32)
-        lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
         out = Act(y, x.N, 28, 28, 32)
+        if bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS:
+            lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(self.bn_ws(32)), x.N, k, nt, s)
+            out.bn_nblk = lib.lv_conv32_blocks(x.N)
+        else:
+            lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
 
         def bwd():
             dy = self.grad_of(out)
@@ -174,13 +184,17 @@ class Tape(object):
         self.back.append(bwd)
         return out
 
-    def _conv1x1(self, x, weight, gview):
+    def _conv1x1(self, x, weight, gview, bn_stats=False):
         """Pointwise convolution between 32 / 64 channels (lv_conv1x1_*: one pass over the pixels, no split-K)."""
         lib, s = self.lib, self.s()
         Cout, Cin = weight.shape[0], weight.shape[1]
         y = self.f32(x.P, Cout)
-        lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
         out = Act(y, x.N, x.H, x.W, Cout)
+        if bn_stats and lib.lv_conv1x1_blocks(x.P) <= _BN_MAX_BLOCKS:
+            lib.lv_conv1x1_bnstat_f32(P(x.t), P(weight), P(y), P(self.bn_ws(Cout)), x.P, Cin, Cout, s)
+            out.bn_nblk = int(lib.lv_conv1x1_blocks(x.P))
+        else:
+            lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
 
         def bwd():
             dy = self.grad_of(out)
@@ -202,7 +216,13 @@ class Tape(object):
         y = self.f32(Pn, C)
         mean = self.f32(C)
         invstd = self.f32(C)
-        if self.train:
+        if self.train and x.bn_nblk:
+            # the producing convolution left the per-channel partial sums in the workspace
+            lib.lv_bn_fwd_partials_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
+                                       P(mean), P(invstd), P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum,
+                                       P(self.bn_ws(C)), x.bn_nblk, Pn, C, s)
+            self.bn_seen.append(bn.num_batches_tracked)
+        elif self.train:
             lib.lv_bn_fwd_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
                               P(mean), P(invstd), P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum,
                               P(self.bn_ws(C)), Pn, C, s)
@@ -309,12 +329,13 @@ def encoder_forward(tp, flat, enc, x_img):
 def pixelcnn_block(tp, flat, blk, x):
     m = blk.main
     k = m[3].kernel_size[0]
-    h = tp.conv(x, m[0].weight, _gv(flat, m[0].weight))
+    h = tp.conv(x, m[0].weight, _gv(flat, m[0].weight), bn_stats=True)
     h = tp.bn(h, m[1], _gv(flat, m[1].weight), _gv(flat, m[1].bias), act=True)
     # type-B mask: taps strictly before the centre in raster order plus the centre itself
-    h = tp.conv(h, m[3].weight, _gv(flat, m[3].weight), stride=1, pad=k // 2, ntaps=(k // 2) * k + k // 2 + 1, mask=m[3].mask)
+    h = tp.conv(h, m[3].weight, _gv(flat, m[3].weight), stride=1, pad=k // 2, ntaps=(k // 2) * k + k // 2 + 1, mask=m[3].mask,
+                bn_stats=True)
     h = tp.bn(h, m[4], _gv(flat, m[4].weight), _gv(flat, m[4].bias), act=True)
-    h = tp.conv(h, m[6].weight, _gv(flat, m[6].weight))
+    h = tp.conv(h, m[6].weight, _gv(flat, m[6].weight), bn_stats=True)
     return tp.bn(h, m[7], _gv(flat, m[7].weight), _gv(flat, m[7].bias), res=x, act=True)
 
 
@@ -355,7 +376,7 @@ def decoder_forward(tp, flat, dec, x_img, z2d, zact):
     assert len(direct_inputs) == 3
     out = tp.add(inp, pixelcnn_block(tp, flat, pcnn.direct_connects[-1], direct_inputs.pop(0)))
     c1, bn1, c2 = dec.main[1], dec.main[2], dec.main[4]
-    h = tp.conv(out, c1.weight, _gv(flat, c1.weight))
+    h = tp.conv(out, c1.weight, _gv(flat, c1.weight), bn_stats=True)
     h = tp.bn(h, bn1, _gv(flat, bn1.weight), _gv(flat, bn1.bias), act=True)
     logit = tp.conv(h, c2.weight, _gv(flat, c2.weight))
     return logit, xflat
