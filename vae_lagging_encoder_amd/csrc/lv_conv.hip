@@ -237,7 +237,6 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
 // every workgroup of the apply kernel re-derives the per-channel totals from them (f64, fixed order: <= 64 KB of L2 reads per
 // workgroup) instead of waiting for a separate one-workgroup "finish" launch (5-6 us each, 162 of them per Omniglot step).
 constexpr int BN_V4_BLOCKS = 256;
-constexpr int BN_V4_ITEMS = 4;            // float4 per thread of the apply kernels
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -349,6 +348,7 @@ __device__ __forceinline__ void bn_block_totals(const float* __restrict__ partia
     __syncthreads();
 }
 
+template <int BN_V4_ITEMS>
 __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ res, int act, float* __restrict__ y,
@@ -358,6 +358,18 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
     __shared__ double tot[512], scratch[1024];
     __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sbe[256];
     const int tid = (int)threadIdx.x;
+    // this thread's BN_V4_ITEMS float4 first: they do not depend on the statistics and stay in flight under the totals
+    const long n4 = P * (C >> 2);
+    const int CT4 = C >> 2;
+    const long i0 = (long)blockIdx.x * (256 * BN_V4_ITEMS) + tid;
+    float4 xs[BN_V4_ITEMS], rs[BN_V4_ITEMS];
+#pragma unroll
+    for (int u = 0; u < BN_V4_ITEMS; ++u) {
+        const long i = i0 + 256 * u;
+        const long ii = i < n4 ? i : 0;
+        xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
+        if (res) rs[u] = *reinterpret_cast<const float4*>(res + 4 * ii);
+    }
     bn_block_totals(partial, nblk, C, tot, scratch);
     if (tid < C) {
         const double m = tot[tid] / (double)P;
@@ -376,18 +388,6 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
         }
     }
     __syncthreads();
-    // BN_V4_ITEMS float4 per thread, loads first
-    const long n4 = P * (C >> 2);
-    const int CT4 = C >> 2;
-    const long i0 = (long)blockIdx.x * (256 * BN_V4_ITEMS) + tid;
-    float4 xs[BN_V4_ITEMS], rs[BN_V4_ITEMS];
-#pragma unroll
-    for (int u = 0; u < BN_V4_ITEMS; ++u) {
-        const long i = i0 + 256 * u;
-        const long ii = i < n4 ? i : 0;
-        xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
-        if (res) rs[u] = *reinterpret_cast<const float4*>(res + 4 * ii);
-    }
 #pragma unroll
     for (int u = 0; u < BN_V4_ITEMS; ++u) {
         const long i = i0 + 256 * u;
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
     }
 }
 
+template <int BN_V4_ITEMS>
 __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ dv,
                                                               const float* __restrict__ partial, int nblk,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -417,17 +418,6 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __res
     __shared__ double tot[512], scratch[1024];
     __shared__ __attribute__((aligned(16))) float smu[256], sis[256], sga[256], sdg[256], sdb[256];
     const int tid = (int)threadIdx.x;
-    bn_block_totals(partial, nblk, C, tot, scratch);
-    if (tid < C) {
-        const double s = tot[tid], q = tot[C + tid];
-        smu[tid] = mean[tid]; sis[tid] = invstd[tid]; sga[tid] = gamma[tid];
-        sdb[tid] = (float)s; sdg[tid] = (float)q;
-        if (blockIdx.x == 0) {
-            dbeta[tid] = (float)(s + (accumulate ? (double)dbeta[tid] : 0.0));
-            dgamma[tid] = (float)(q + (accumulate ? (double)dgamma[tid] : 0.0));
-        }
-    }
-    __syncthreads();
     const long n4 = P * (C >> 2);
     const int CT4 = C >> 2;
     const long i0 = (long)blockIdx.x * (256 * BN_V4_ITEMS) + tid;
@@ -439,6 +429,17 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __res
         xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
         ds[u] = *reinterpret_cast<const float4*>(dv + 4 * ii);
     }
+    bn_block_totals(partial, nblk, C, tot, scratch);
+    if (tid < C) {
+        const double s = tot[tid], q = tot[C + tid];
+        smu[tid] = mean[tid]; sis[tid] = invstd[tid]; sga[tid] = gamma[tid];
+        sdb[tid] = (float)s; sdg[tid] = (float)q;
+        if (blockIdx.x == 0) {
+            dbeta[tid] = (float)(s + (accumulate ? (double)dbeta[tid] : 0.0));
+            dgamma[tid] = (float)(q + (accumulate ? (double)dgamma[tid] : 0.0));
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < BN_V4_ITEMS; ++u) {
         const long i = i0 + 256 * u;
@@ -463,7 +464,10 @@ static inline int bn_v4_blocks(long P, int C) {
     long nb = (P + 4L * rpb - 1) / (4L * rpb);          // >= 4 rows per thread
     return (int)(nb < 1 ? 1 : nb > BN_V4_BLOCKS ? BN_V4_BLOCKS : nb);
 }
-static inline unsigned bn_v4_apply_grid(long n4) { return (unsigned)lv_cdiv(n4, 256L * BN_V4_ITEMS); }
+// float4 per thread of the apply kernels: every workgroup re-reads all the partials (nblk * 2C floats), so the wider layers
+// use fewer, fatter workgroups
+static inline int bn_v4_items(int C) { return C >= 64 ? 8 : 4; }
+static inline unsigned bn_v4_apply_grid(long n4, int items) { return (unsigned)lv_cdiv(n4, 256L * items); }
 
 // rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
 __global__ __launch_bounds__(256) void sigmoid_bce_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ x,
@@ -589,12 +593,16 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                   (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
-        LV_LAUNCH(bn_apply_fwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, (const float*)ws, nb, gamma, beta,
-                  res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+        if (bn_v4_items(C) == 8)
+            LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
+                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+        else
+            LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
+                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
-    int nblk = (int)((P + 63) / 64);
+    int nblk = (int)((P + 3) / 4);          // few rows per block: the rows of a block are read one after the other
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
@@ -615,8 +623,12 @@ extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const 
     if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
     if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
-    LV_LAUNCH(bn_apply_fwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
-              act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+    if (bn_v4_items(C) == 8)
+        LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
+                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+    else
+        LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
+                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -633,12 +645,16 @@ extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, co
     if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nb);
-        LV_LAUNCH(bn_apply_bwd_v4_kernel, dim3(bn_v4_apply_grid(P * (C >> 2))), dim3(256), 0, stream, x, (const float*)dv,
-                  (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+        if (bn_v4_items(C) == 8)
+            LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)dv,
+                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+        else
+            LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)dv,
+                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
-    int nblk = (int)((P + 63) / 64);
+    int nblk = (int)((P + 3) / 4);
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     float* dgl = ws + (long)BN_BLOCKS * 2 * C;
     float* dbl = dgl + C;
