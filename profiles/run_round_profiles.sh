@@ -1,0 +1,38 @@
+#!/bin/bash
+# Regenerates the judged measurement set of a round on the GPU box (through gpurun):
+#   bash profiles/run_round_profiles.sh r02p
+# writes gpurun_out/<tag>_*; copy what is to be judged into profiles/.  PMC passes are separate runs with --kernel-trace only.
+set -u
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+python bench.py --graph 1 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_hipgraph.json 2>/dev/null
+python bench.py --workload yelp --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yelp.json 2>/dev/null
+python bench.py --workload stress --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_stress.json 2>/dev/null
+python bench.py --dtype f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yahoo_f32.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $O/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
+python $R/profiles/summarize_rocpd.py $O/prof_${TAG}/${TAG}_results.db > $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt
+for W in yahoo yelp; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${C}_${W}_${TAG} -o p -- \
+      python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
+  done
+  python $R/profiles/summarize_pmc.py $O/pmc_FETCH_SIZE_${W}_${TAG}/p_counter_collection.csv $O/pmc_WRITE_SIZE_${W}_${TAG}/p_counter_collection.csv \
+      > $O/${TAG}_pmc_hbm_traffic_${W}_bf16.txt
+  python $R/profiles/summarize_pmc.py $O/pmc_FETCH_SIZE_${W}_${TAG}/p_counter_collection.csv $O/pmc_WRITE_SIZE_${W}_${TAG}/p_counter_collection.csv \
+      --json 3 > $O/${TAG}_pmc_groups_${W}.json
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq_${TAG} -o p -- \
+  python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
+python $R/profiles/summarize_sq.py $O/pmc_sq_${TAG}/p_counter_collection.csv > $O/${TAG}_pmc_sq_mfma_busy_yahoo_bf16.txt 2>&1
+cd $R
+cut -c1-400 $O/${TAG}_bench_default.json
+cut -c1-200 $O/${TAG}_bench_hipgraph.json $O/${TAG}_bench_yelp.json $O/${TAG}_bench_stress.json $O/${TAG}_bench_yahoo_f32.json
+head -14 $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt | cut -c1-170
+head -8 $O/${TAG}_pmc_hbm_traffic_yahoo_bf16.txt | cut -c1-170
+cat $O/${TAG}_pmc_groups_yahoo.json | tr -d '\n' | cut -c1-600; echo
+head -8 $O/${TAG}_pmc_sq_mfma_busy_yahoo_bf16.txt | cut -c1-170
