@@ -199,7 +199,9 @@ class _AuxStream(object):
         self.stream = None
         self.done = None
 
-    def run(self, device, fn):
+    def run(self, device, fn, keep=()):
+        """keep: tensors fn reads on the side stream (told to the caching allocator, so that a caller that drops them
+        right after a forward-only call cannot have them recycled underneath the side stream)."""
         device = torch.device(device)
         # inline on the test backend, and under hipGraph capture: a forked branch in a replayed graph was measured to
         # cost ~0.5 ms per step (DESIGN.md section 5), far more than the 0.15 ms the side stream saves in eager mode
@@ -211,6 +213,8 @@ class _AuxStream(object):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         self.stream.wait_event(ev)
+        for t in keep:
+            t.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             fn(self.stream.cuda_stream)
             self.done = torch.cuda.Event()
@@ -476,7 +480,8 @@ class LSTMEncoderEngine(object):
         v = f.views
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
         # the backward's token sort depends on x only: queue it now, beside the forward chain
-        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s))
+        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
+                      keep=(x,))
         img = self._b16(B, T)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
@@ -728,7 +733,8 @@ class LSTMDecoderEngine(object):
         if mask_out is not None:
             assert mask_out.dtype == torch.uint8 and tuple(mask_out.shape) == (B, Td, H) and mask_out.is_contiguous()
         lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
-        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s))
+        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
+                      keep=(x,))
         # c0 = z W_trans^T ; h0 = tanh(c0) (dec_lstm.py:99-101) ; Zp = z W_ih[:, ni:]^T + b_ih + b_hh, so that
         # Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised) -- one launch
         wih = v["lstm.weight_ih_l0"]
