@@ -106,10 +106,12 @@ struct Fiber {
 struct State {
     std::recursive_mutex launch_mu;
     std::vector<Fiber> fibers;             // the live set (one block, or the whole grid in a concurrent launch)
+    std::vector<int> ring_next, ring_prev; // circular list of the fibers that have not finished (global yields walk it in O(1))
     std::vector<Block> blocks;
     size_t nstacks = 0;
     char* stacks = nullptr;
     int cur = -1, nlive = 0, remaining = 0;
+    bool concurrent = false;               // every workgroup live at once: all waits pass the turn along the global ring
     void* main_sp = nullptr;
     std::function<void()> job;
     dim3 grid, block;
@@ -154,13 +156,21 @@ inline void yield_in(int base, int n) {
     int nx = next_in(base, n);
     if (nx >= 0) switch_to(nx);
 }
-inline void yield_all() { yield_in(0, st().nlive); }
+inline void yield_all() {
+    State& s = st();
+    const int nx = s.ring_next[s.cur];
+    if (nx != s.cur) switch_to(nx);
+}
 
 inline void bar_wait(Bar& b, int base, int span) {
     const unsigned g = b.gen;
     if (++b.arrived >= b.count) { b.arrived = 0; ++b.gen; return; }
     while (b.gen == g) {
-        int nx = next_in(base, span);
+        // In a concurrent launch a waiter hands the turn to its GLOBAL successor: switching inside the block / wave would trap
+        // the scheduler there as soon as one of its fibers polls for another workgroup's data (the poller's ring successor is
+        // a local waiter, which would hand the turn straight back).
+        State& s = st();
+        int nx = s.concurrent ? (s.ring_next[s.cur] != s.cur ? s.ring_next[s.cur] : -1) : next_in(base, span);
         if (nx < 0) { fprintf(stderr, "lv_emu: barrier can never complete (divergent barrier?)\n"); abort(); }
         switch_to(nx);
     }
@@ -182,6 +192,7 @@ inline void launch_impl(dim3 grid, dim3 block, size_t shmem, F&& f, bool concurr
     s.grid = grid; s.block = block;
     s.dyn.assign(shmem + 64, 0);
     s.job = std::function<void()>(f);
+    s.concurrent = concurrent;
     const int live_blocks = concurrent ? (int)nblocks : 1;
     const int nlive = live_blocks * nthreads;
     if ((size_t)nlive > s.nstacks) {
@@ -409,4 +420,5 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -43,7 +43,11 @@ static void fiber_main() {
     --s.remaining;
     bar_leave(f.blk->bar);
     bar_leave(f.blk->waves[f.lin / kWave].bar);
-    int nx = next_in(0, s.nlive);
+    // unlink from the ring of unfinished fibers; the successor runs next
+    const int me = s.cur, nxt = s.ring_next[me], prv = s.ring_prev[me];
+    s.ring_next[prv] = nxt;
+    s.ring_prev[nxt] = prv;
+    const int nx = nxt != me ? nxt : -1;
     void* dummy;
     if (nx >= 0) { s.cur = nx; lv_emu_switch(&dummy, s.fibers[nx].sp); }
     else { s.cur = -1; lv_emu_switch(&dummy, s.main_sp); }
@@ -66,6 +70,9 @@ void run_live(int nlive) {
         for (int k = 1; k <= 6; ++k) sp[-k] = nullptr;
         f.sp = (void*)(sp - 6);
     }
+    s.ring_next.resize((size_t)nlive);
+    s.ring_prev.resize((size_t)nlive);
+    for (int i = 0; i < nlive; ++i) { s.ring_next[i] = (i + 1) % nlive; s.ring_prev[i] = (i + nlive - 1) % nlive; }
     s.cur = 0;
     lv_emu_switch(&s.main_sp, s.fibers[0].sp);
     if (s.remaining != 0) { fprintf(stderr, "lv_emu: %d fibers never finished\n", s.remaining); abort(); }

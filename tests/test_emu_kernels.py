@@ -180,3 +180,13 @@ def test_conv1x1(emu_backend, cfg):
 @pytest.mark.parametrize("cfg", [(3, 5, 64, 32), (2, 3, 32, 64)])
 def test_conv_bnstat(emu_backend, cfg):
     K.test_conv_bnstat_feeds_batchnorm(emu_backend, CPU, *cfg)
+
+
+def test_lstm_fwd_persistent_emulated(emu_backend):
+    """The persistent forward recurrence with every workgroup of its grid live at once (fibers; hand-off polls yield)."""
+    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True)
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, True, True, True, False), (2, 2, False, False, True, True)])
+def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
+    K.test_lstm_bwd_persistent(emu_backend, CPU, *cfg)

@@ -14,6 +14,19 @@ static inline f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) { return lv_emu_m
 static inline f32x16 lv_mfma_32x32x2(float a, float b, f32x16 c) { return lv_emu_mfma_32x32x2(a, b, c); }
 #define LV_SCHED_BARRIER() do { } while (0)
 static inline int lv_wave_uniform(int v) { return v; }
+// persistent (spin-synchronised) kernels: every workgroup of the grid live at once, block-private LDS objects, polls yield
+#define LV_LAUNCH_RESIDENT(kern, grid, block, shmem, stream, ...) \
+    lv_emu::launch_concurrent((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+#define LV_BLOCK_SHARED(T, name) T& name = *reinterpret_cast<T*>(lv_emu::block_shared(sizeof(T)))
+static inline unsigned long long lv_agent_load_u64(const unsigned long long* p) {
+    lv_emu::yield_all();                     // somebody else has to run for the value to change
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+static inline void lv_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+#define LV_WAIT_LDS() lv_emu::wave_sync()      // lanes are fibers here: 'the wave's own LDS writes are visible' needs a rendezvous
+template <class T> static inline void lv_store_nt(T v, T* p) { *p = v; }
+static inline int lv_device_cus() { return 1 << 20; }
+#define LV_SPIN_LIMIT (1 << 15)             // polls per wait before a hand-off is reported lost (a poll = one scheduling round here)
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
@@ -69,6 +82,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LV_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // a value every lane of the wave agrees on, moved to a scalar register (branches on it are scalar branches, not exec masks)
 __device__ __forceinline__ int lv_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// persistent (spin-synchronised) kernels: an ordinary launch whose grid the caller sized to be resident at once
+#define LV_LAUNCH_RESIDENT(kern, grid, block, shmem, stream, ...) LV_LAUNCH(kern, grid, block, shmem, stream, __VA_ARGS__)
+#define LV_BLOCK_SHARED(T, name) __shared__ T name
+// agent-scope relaxed 64-bit accesses (sc1: served by L2, never by another CU's stale L1) for tagged hand-off granules
+__device__ __forceinline__ unsigned long long lv_agent_load_u64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lv_agent_store_u64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define LV_SPIN_LIMIT (1 << 22)             // polls per wait before a hand-off is reported lost (~1 s)
+// lgkmcnt(0): a wave's own LDS accesses are ordered; enough when the data is wave-private
+#define LV_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)
+// streaming store: consumed by later kernels only (no write-allocate fetch of a partially written line)
+template <class T> __device__ __forceinline__ void lv_store_nt(T v, T* p) { __builtin_nontemporal_store(v, p); }
+// compute units of the current device (cached per ordinal; the persistent launches need their whole grid resident)
+static inline int lv_device_cus() {
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        __atomic_store_n(&cache[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
 // v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]
 __device__ __forceinline__ f32x4 lv_mfma_16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

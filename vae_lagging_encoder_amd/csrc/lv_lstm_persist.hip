@@ -24,8 +24,6 @@
 // calls (the decoder during the aggressive inner loop) packs once.
 #include "lv_device.h"
 
-#ifndef LV_EMU   // the CI emulator runs workgroups one after another: spin-synchronised persistent kernels cannot run there
-
 namespace {
 
 constexpr int PH = 1024;            // hidden size this kernel is built for
@@ -36,16 +34,12 @@ constexpr int PUW = 8;              // hidden units per wave
 constexpr int HPITCH = PH / 2 + 16; // LDS row pitch of the gathered h image in dwords: rows 16 banks apart, so the A-fragment
                                     // reads of 4 rows x 4 k-quads hit 16 distinct bank groups
 constexpr int PRMAX = 8;            // batch rows per group this build supports (LDS: 2 x PRMAX x HPITCH dwords)
-constexpr int SPIN_LIMIT = 1 << 22;
+constexpr int SPIN_LIMIT = LV_SPIN_LIMIT;
 
 typedef unsigned long long gran_t;  // (tag << 32) | two bf16
 
-__device__ __forceinline__ gran_t gran_load(const gran_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void gran_store(gran_t* p, gran_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ gran_t gran_load(const gran_t* p) { return lv_agent_load_u64(p); }
+__device__ __forceinline__ void gran_store(gran_t* p, gran_t v) { lv_agent_store_u64(p, v); }
 
 // Wpk[wave_id (128)][ks (32)][nb (2)][lane (64)] : lane (c = l&15, kq = l>>4) holds W_hh[gate*H + unit][32ks + 8kq .. +7]
 // with unit = 8*wave_id + 4*nb + (c>>2), gate = c&3 -- the B operand of v_mfma_f32_16x16x32_bf16 for that column.
@@ -81,10 +75,16 @@ constexpr int SB = 8;               // timesteps per I/O block (see below)
 // stores alone).  The recurrence therefore does its bulk I/O in blocks of SB steps: the gate pre-activations of the
 // next block are fetched and the results of the previous block are written at block boundaries, and in between a
 // step touches global memory for the hand-off only.  Each lane owns ONE (batch row, unit) pair for the whole call.
+struct __attribute__((aligned(16))) FwdLds {
+    uint32_t hl[2][PRMAX * HPITCH];     // gathered h_{t-1}, [parity][row][k/2]
+    float pre[4][16][33];               // per wave: MFMA tile [row][col]
+    int abort;
+};
 __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
-    __shared__ __attribute__((aligned(16))) uint32_t hl[2][PRMAX * HPITCH];   // gathered h_{t-1}, [parity][row][k/2]
-    __shared__ float pre[4][16][33];                                         // per wave: MFMA tile [row][col]
-    __shared__ int s_abort;
+    LV_BLOCK_SHARED(FwdLds, sm);
+    uint32_t (&hl)[2][PRMAX * HPITCH] = sm.hl;
+    float (&pre)[4][16][33] = sm.pre;
+    int& s_abort = sm.abort;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
     const int wave_id = member * 4 + w;
@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
             if (own && t < T) {
                 // streaming stores: the results are consumed by later kernels only, and a write-allocating store of a
                 // partial line makes L2 fetch the line first -- measured 3.85 -> 3.46 us per step with the nt hint
-                __builtin_nontemporal_store(f32x4{recb[s2].x, recb[s2].y, recb[s2].z, recb[s2].w},
-                                            reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx) * 4));
-                __builtin_nontemporal_store(cb[s2], p.cs + (long)(t + 1) * BH + pidx);
-                __builtin_nontemporal_store(hb[s2], p.hs + (long)(t + 1) * BH + pidx);
-                if (p.hdrop) __builtin_nontemporal_store(hdb[s2], p.hdrop + (long)t * BH + pidx);
+                lv_store_nt(f32x4{recb[s2].x, recb[s2].y, recb[s2].z, recb[s2].w},
+                            reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx) * 4));
+                lv_store_nt(cb[s2], p.cs + (long)(t + 1) * BH + pidx);
+                lv_store_nt(hb[s2], p.hs + (long)(t + 1) * BH + pidx);
+                if (p.hdrop) lv_store_nt(hdb[s2], p.hdrop + (long)t * BH + pidx);
             }
         }
     };
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pre[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): wave-private tile, the wave's own LDS accesses are ordered
+            LV_WAIT_LDS();        // lgkmcnt(0): wave-private tile, the wave's own LDS accesses are ordered
 
             // ---- epilogue: gates, cell update, hand-off of h_t ------------------------------------------------------------
             float h = 0.f;
@@ -278,11 +278,18 @@ struct PersistBwdP {
     int T, B, R;
 };
 
+struct __attribute__((aligned(16))) BwdLds {
+    uint32_t gl[BR * GPITCH];           // gathered dG[t+1], [row][n'/2]
+    uint16_t og[SB][BR][4][32];         // dG of one I/O block: [step][row][gate][unit in WG]
+    float red[2][4][16][33];            // [phase parity][wave]: quarter product [row][unit]
+    int abort;
+};
 __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
-    __shared__ __attribute__((aligned(16))) uint32_t gl[BR * GPITCH];        // gathered dG[t+1], [row][n'/2]
-    __shared__ float red[2][4][16][33];                                      // [phase parity][wave]: quarter product [row][unit]
-    __shared__ __attribute__((aligned(16))) uint16_t og[SB][BR][4][32];      // dG of one I/O block: [step][row][gate][unit in WG]
-    __shared__ int s_abort;
+    LV_BLOCK_SHARED(BwdLds, sm);
+    uint32_t (&gl)[BR * GPITCH] = sm.gl;
+    float (&red)[2][4][16][33] = sm.red;
+    uint16_t (&og)[SB][BR][4][32] = sm.og;
+    int& s_abort = sm.abort;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
     const int wave_id = member * 4 + w;
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
             if (t >= 0 && r < rows) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(&og[s2][r][g][8 * q]);      // 8 bf16, moved as raw bits
                 uint16_t* dst = p.dG16 + ((long)t * B + (b0 + r)) * 4 * PH + (long)g * PH + 32 * member + 8 * q;
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                lv_store_nt(v, reinterpret_cast<f32x4*>(dst));
             }
         }
         __syncthreads();                                        // og is rewritten at the next block boundary
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
             }
         }
         if (!fine) s_abort = 1;
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave reads back what its own lanes just wrote
+        LV_WAIT_LDS();            // lgkmcnt(0): the wave reads back what its own lanes just wrote
         f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const uint4* arowp = reinterpret_cast<const uint4*>(gl + arow * GPITCH + 512 * w) + kq;     // K-quarter w: 1024 n' = 512 dwords
 #pragma unroll
@@ -483,19 +490,6 @@ constexpr long WPK_BYTES = 128L * PKS * 2 * 64 * 16;                           /
 constexpr long XCH_FWD_BYTES = 2L * PGROUPS * 16 * (PH / 2) * 8;                 // h exchange, two parities
 constexpr long XCH_BWD_BYTES = 2L * PGROUPS * BR * (2 * PH) * 8;                 // dG exchange, two parities
 
-// compute units of the current device (cached per device ordinal; the persistent launches need 256 resident workgroups)
-int device_cus() {
-    static int cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int c = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
-    if (c == 0) {
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        __atomic_store_n(&cache[dev], c, __ATOMIC_RELAXED);
-    }
-    return c;
-}
-
 }  // namespace
 
 extern "C" long lv_lstm_persist_wpk_floats(void) { return WPK_BYTES / 4; }
@@ -527,13 +521,13 @@ extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_las
     if (H != PH || B > BR * PGROUPS || dG || !dG16) return LV_ERR_UNSUPPORTED;   // image-only: the f32 dG copy is not produced
     if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
         return LV_ERR_ALIGN;
-    if (device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
     gran_t* gxch = reinterpret_cast<gran_t*>(xch);
     hipMemsetAsync(gxch, 0, (size_t)XCH_BWD_BYTES, (hipStream_t)stream);
     const int R = (B + PGROUPS - 1) / PGROUPS;
     PersistBwdP p{dh_ext, dh_last, dmask, dscale, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init,
                   gxch, status, T, B, R};
-    LV_LAUNCH(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
+    LV_LAUNCH_RESIDENT(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -550,30 +544,13 @@ extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float
     if (H != PH || B > PRMAX * PGROUPS) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
         return LV_ERR_ALIGN;
-    if (device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
     if (T == 0) return LV_OK;
     gran_t* hx = reinterpret_cast<gran_t*>(xch);
     hipMemsetAsync(hx, 0, (size_t)XCH_FWD_BYTES, (hipStream_t)stream);
     const int R = (B + PGROUPS - 1) / PGROUPS;
     PersistFwdP p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
-    LV_LAUNCH(lstm_fwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
+    LV_LAUNCH_RESIDENT(lstm_fwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
-
-#else   // LV_EMU
-
-extern "C" long lv_lstm_persist_wpk_floats(void) { return 64; }
-extern "C" long lv_lstm_persist_xch_floats(void) { return 64; }
-extern "C" int lv_lstm_persist_pack(const float*, float*, int, int, void*) { return LV_ERR_UNSUPPORTED; }
-extern "C" int lv_lstm_fwd_bf16_persist(const float*, const float*, float*, float*, float*, const uint8_t*, float, float*,
-                                        float*, int*, int, int, int, void*) {
-    return LV_ERR_UNSUPPORTED;
-}
-extern "C" int lv_lstm_bwd_bf16_persist(const float*, const float*, const uint8_t*, float, const float*, const float*, const float*,
-                                        const float*, float*, uint16_t*, float*, float*, int*, float*, float*, int, int, int, int,
-                                        void*) {
-    return LV_ERR_UNSUPPORTED;
-}
-
-#endif
