@@ -112,6 +112,13 @@ int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const ui
                              const float* wpk, const float* gates, const float* hs, const float* cs,
                              float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                              int tanh_init, int T, int B, int H, void* stream);
+/* the same recurrence in its reduce-scatter form (weights packed with lv_lstm_persist_pack(..., backward = 2)): every
+ * workgroup sends partial sums of dh to the owners of the units instead of gathering all of dG -- a quarter of the hand-off
+ * granules per timestep; same arguments and outputs (up to f32 summation order). */
+int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                             const float* wpk, const float* gates, const float* hs, const float* cs,
+                             float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
+                             int tanh_init, int T, int B, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,

@@ -43,4 +43,9 @@ dGsum = torch.empty(B, 4 * H, device=dev); dc0 = torch.empty(B, H, device=dev)
 a = t(lambda: lib.lv_lstm_bwd_bf16_img(P(dO), None, P(mask), 2.0, P(whh), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(ws), None, P(dc0), 1, T, B, H, s))
 b = t(lambda: lib.lv_lstm_bwd_bf16_persist(P(dO), None, P(mask), 2.0, P(wpk_b), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
 print("BPTT two launches per step : %8.1f us  (%.2f us/step)" % (a, a / T))
-print("BPTT persistent            : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+print("BPTT persistent (all-gather): %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+wpk_r = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+lib.lv_lstm_persist_pack(P(whh), P(wpk_r), 2, H, s)
+st.zero_()
+b = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(P(dO), None, P(mask), 2.0, P(wpk_r), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
+print("BPTT persistent (reduce-scatter): %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))

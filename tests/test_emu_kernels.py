@@ -187,6 +187,7 @@ def test_lstm_fwd_persistent_emulated(emu_backend):
     K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True)
 
 
-@pytest.mark.parametrize("cfg", [(3, 3, True, True, True, False), (2, 2, False, False, True, True)])
+@pytest.mark.parametrize("cfg", [(3, 3, True, True, True, False, "rs"), (2, 2, False, False, True, True, "rs"),
+                                 (10, 5, True, False, True, True, "rs"), (4, 3, True, True, True, False, "ag")])
 def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent(emu_backend, CPU, *cfg)

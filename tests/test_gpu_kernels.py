@@ -361,9 +361,10 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
     (6, 32, True, True, True, False), (1, 5, False, False, True, True), (9, 32, True, False, True, True),
     (40, 32, False, True, True, False), (3, 13, True, True, True, True), (17, 8, False, False, False, True),
 ])
-def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last):
-    """The one-launch persistent BPTT (H = 1024) against the float64 autograd of the same recurrence (bf16-recurrence
-    tolerance) and against the two-launch-per-step kernels on the same saved activations."""
+def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs"):
+    """The one-launch persistent BPTT (H = 1024; variant "rs" = reduce-scatter hand-off, "ag" = all-gather hand-off) against
+    the float64 autograd of the same recurrence (bf16-recurrence tolerance) and against the two-launch-per-step kernels on
+    the same saved activations."""
     dev, H = hip_device, 1024
     g = torch.Generator().manual_seed(T * 100 + B + 7)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
@@ -391,7 +392,8 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
     lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
     wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
-    lib.lv_lstm_persist_pack(P(whh), P(wpk), 1, H, _s(dev))
+    lib.lv_lstm_persist_pack(P(whh), P(wpk), 2 if variant == "rs" else 1, H, _s(dev))
+    persist_bwd = lib.lv_lstm_bwd_bf16_persist_rs if variant == "rs" else lib.lv_lstm_bwd_bf16_persist
 
     def common(weights):
         return (P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
@@ -406,8 +408,7 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         if persistent:
             wsp = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_bwd_bf16_persist(*common(wpk), None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init),
-                                         T, B, H, _s(dev))
+            persist_bwd(*common(wpk), None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
             assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
             dG = torch.cat([dG16.view(torch.bfloat16).float()])      # image-only kernel: compare through the bf16 image
         else:
@@ -425,6 +426,11 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         outs.append((dG.clone(), dGsum.clone(), dc0.clone()))
     sc = float(outs[1][0].abs().max())
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
+
+
+@pytest.mark.parametrize("T,B,use_mask,tanh_init,use_ext,use_last", [(6, 32, True, True, True, False), (40, 30, False, False, True, True)])
+def test_lstm_bwd_persistent_allgather_form(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last):
+    test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="ag")
 
 
 def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):

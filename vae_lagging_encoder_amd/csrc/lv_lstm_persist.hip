@@ -486,23 +486,288 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
     }
 }
 
+// =====================================================================================================================
+// BPTT, reduce-scatter form.  The kernel above all-gathers dG[t] (R x 4H values) into every workgroup: 8192 granules per
+// workgroup and timestep at R = 4, four times the forward's hand-off, and the step costs 5.1-5.6 us against 3.2-3.8 us.
+// Here a workgroup keeps the dG of its OWN 32 units (it computes them), multiplies them with its 128 gate ROWS of W_hh --
+// a partial sum of dh_{t-1} for ALL 1024 units -- and sends every other workgroup the 32-unit slice that workgroup owns:
+// 32 x R f32 partials per (sender, receiver) pair, two per 8-byte granule as 28-bit floats (sign, exponent, 19 mantissa
+// bits: 1e-6 relative, three orders below the bf16 rounding of the operands) next to an 8-bit phase tag.  A workgroup then
+// receives 32 senders x 64 granules = 2048 granules per timestep -- the forward's count -- and sums them in a fixed order.
+// Same decomposition otherwise: 8 groups x 32 workgroups, a group owns R <= 4 batch rows, W_hh slice in registers (wave w
+// holds its workgroup's 128 k-rows x output columns [256w, 256w+256)), bulk I/O in SB-step blocks, bounded spins.
+//   per timestep: poll 8 granules per lane (one round) -> sum over senders (registers + 2 shuffles: no barrier) -> gate
+//   gradients -> dG image of the workgroup in LDS -> ONE barrier -> 64 MFMAs per wave -> wave-private transpose -> 8 granule
+//   stores per lane (each wave sends to the 8 workgroups that own its 256 columns; a wave store is 512 contiguous bytes).
+constexpr int RS_KS = 4;                         // MFMA k-steps over the workgroup's 128 gate rows
+constexpr int RS_NB = 16;                        // 16-column blocks per wave
+constexpr int DPITCH = 64 + 4;                   // dwords per row of the dG image (128 bf16 + pad: rows 4 bank groups apart)
+constexpr int PPITCH = 256 + 8;                  // floats per row of a wave's partial tile
+
+__device__ __forceinline__ uint32_t rs_tag(int k) { return 1u + (uint32_t)(k - 1) % 255u; }      // phase k >= 1 -> 1..255
+__device__ __forceinline__ gran_t rs_pack(float a, float b, uint32_t tag) {
+    uint32_t ua, ub;
+    memcpy(&ua, &a, 4);
+    memcpy(&ub, &b, 4);
+    return (gran_t)((ua + 8u) >> 4) | ((gran_t)((ub + 8u) >> 4) << 28) | ((gran_t)tag << 56);
+}
+__device__ __forceinline__ float rs_lo(gran_t g) {
+    const uint32_t u = ((uint32_t)g & 0x0FFFFFFFu) << 4;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __forceinline__ float rs_hi(gran_t g) {
+    const uint32_t u = ((uint32_t)(g >> 28) & 0x0FFFFFFFu) << 4;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Wrs[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)]: lane (c, kq) holds, for output column j = 256w + 16nb + c, the 8
+// weights W_hh[gate*H + unit][j] of the local gate rows n'' = 32ks + 8kq + e (unit = 32m + (n'' >> 2), gate = n'' & 3)
+__global__ __launch_bounds__(256) void pack_w_persist_bwd_rs_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * RS_KS * RS_NB * 64) return;
+    const int l = (int)(idx & 63);
+    const int nb = (int)((idx >> 6) % RS_NB);
+    const int ks = (int)((idx / (64 * RS_NB)) % RS_KS);
+    const int wave_id = (int)(idx / (64L * RS_NB * RS_KS));
+    const int m = wave_id >> 2, w = wave_id & 3;
+    const int c = l & 15, kq = l >> 4;
+    const int j = 256 * w + 16 * nb + c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int np = 32 * ks + 8 * kq + e;
+        v[e] = whh[((long)(np & 3) * PH + 32 * m + (np >> 2)) * PH + j];
+    }
+    wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+
+struct __attribute__((aligned(16))) BwdRsLds {
+    uint32_t dgl[2][16 * DPITCH];       // [step parity] dG of this workgroup's 128 gate rows as the MFMA A image, rows < R valid
+    float part[4][BR][PPITCH];          // per wave: its 256 output columns (wave-private)
+    uint16_t og[SB][BR][4][32];         // dG of one I/O block: [step][row][gate][unit in WG]
+    int abort;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistBwdP p) {
+    LV_BLOCK_SHARED(BwdRsLds, sm);
+    uint16_t (&og)[SB][BR][4][32] = sm.og;
+    int& s_abort = sm.abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    if (rows == 0) return;
+    if (tid == 0) s_abort = 0;
+
+    uint4 wreg[RS_KS][RS_NB];
+    {
+        const uint4* wp = p.wpk + (long)wave_id * RS_KS * RS_NB * 64 + l;
+#pragma unroll
+        for (int ks = 0; ks < RS_KS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < RS_NB; ++nb) wreg[ks][nb] = wp[(ks * RS_NB + nb) * 64];
+    }
+
+    // this lane's (row, unit) pair: lanes 0..31 of each wave; wave w receives the sums of rows {2(w>>1), 2(w>>1)+1} x units
+    // [16(w&1), 16(w&1)+16) of the workgroup -- exactly the pairs its first 32 lanes own
+    const int prow = 2 * (w >> 1) + ((l >> 4) & 1), uw = 16 * (w & 1) + (l & 15);
+    const int punit = 32 * member + uw;
+    const bool own = l < 32 && prow < rows;
+    const long BH = (long)B * PH;
+    const long pidx = (long)(b0 + (own ? prow : 0)) * PH + punit;
+    // exchange: [parity][group][receiver (32)][sender (32)][64 granules: (row pair rp, unit u) at rp*32 + u]
+    const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * 64;
+    gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * 64;
+    const gran_t* const rx = px_g + (long)member * PMEMBERS * 64 + (8 * (l >> 4)) * 64 + 16 * w + (l & 15);   // + j*64 per sender
+    gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * 64 + l;                                   // + j*PMEMBERS*64 per receiver
+
+    float dc_rec = 0.f;
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float dhb[SB], keepb[SB], ctb[SB + 1];
+    float4 recb[SB];
+    uint32_t outb[SB][2];
+    auto load_block = [&](int t_hi) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = t_hi - s2;
+            dhb[s2] = 0.f; keepb[s2] = 1.f; recb[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (own && t >= 0) {
+                if (p.dh_ext) dhb[s2] = p.dh_ext[(long)t * BH + pidx];
+                if (p.dh_ext && p.dmask) keepb[s2] = p.dmask[((long)(b0 + prow) * T + t) * PH + punit] ? p.dscale : 0.f;
+                recb[s2] = *reinterpret_cast<const float4*>(p.gates + ((long)t * BH + pidx) * 4);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 <= SB; ++s2) {
+            const int t = t_hi - s2;
+            ctb[s2] = (own && t + 1 >= 0) ? p.cs[(long)(t + 1) * BH + pidx] : 0.f;
+        }
+    };
+    auto store_block = [&](int t_hi) {
+        if (own) {
+#pragma unroll
+            for (int s2 = 0; s2 < SB; ++s2) {
+                og[s2][prow][0][uw] = (uint16_t)(outb[s2][0] & 0xFFFFu);
+                og[s2][prow][1][uw] = (uint16_t)(outb[s2][0] >> 16);
+                og[s2][prow][2][uw] = (uint16_t)(outb[s2][1] & 0xFFFFu);
+                og[s2][prow][3][uw] = (uint16_t)(outb[s2][1] >> 16);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < SB * BR * 4 * 4; c += 256) {      // 16-byte chunks: [step][row][gate][quarter of 32 units]
+            const int q = c & 3, g = (c >> 2) & 3, r = (c >> 4) & 3, s2 = c >> 6;
+            const int t = t_hi - s2;
+            if (t >= 0 && r < rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&og[s2][r][g][8 * q]);
+                uint16_t* dst = p.dG16 + ((long)t * B + (b0 + r)) * 4 * PH + (long)g * PH + 32 * member + 8 * q;
+                lv_store_nt(v, reinterpret_cast<f32x4*>(dst));
+            }
+        }
+        __syncthreads();
+    };
+    load_block(T - 1);
+    __syncthreads();
+
+    const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
+    const bool closing = p.dh0 || p.tanh_init;
+
+    // receive phase k: the 32 senders' partial sums of dh for this workgroup's units; lanes < 32 get their pair's total
+    auto receive = [&](int k, float& dh_rec) -> bool {
+        const gran_t* src = rx + (long)(k & 1) * px_par;
+        const uint32_t want = rs_tag(k);
+        gran_t v[8];
+        int spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = gran_load(src + j * 64);
+                ok = ok && (uint32_t)(v[j] >> 56) == want;
+            }
+            ok = __all(ok);
+            if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+        } while (!ok);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a += rs_lo(v[j]); b += rs_hi(v[j]); }
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        dh_rec = (l & 16) ? b : a;
+        return true;
+    };
+    // multiply the dG image of step parity `par` with this wave's columns and send phase k to their owners
+    auto send = [&](int par, int k) {
+        const uint32_t* img = sm.dgl[par];
+        uint4 afr[RS_KS];
+#pragma unroll
+        for (int ks = 0; ks < RS_KS; ++ks) afr[ks] = *reinterpret_cast<const uint4*>(img + arow * DPITCH + 16 * ks + 4 * kq);
+        float (*pt)[PPITCH] = sm.part[w];
+#pragma unroll
+        for (int c4 = 0; c4 < RS_NB / 4; ++c4) {
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < RS_KS; ++ks)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = lv_mfma_16x16x32_bf16(afr[ks], wreg[ks][4 * c4 + n], acc[n]);
+            if (l < 16) {                       // rows 0..3 of the 16 x 16 tiles
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < BR; ++r) pt[r][16 * (4 * c4 + n) + l] = acc[n][r];
+            }
+        }
+        LV_WAIT_LDS();
+        const uint32_t tag = rs_tag(k);
+        gran_t* dst = tx + (long)(k & 1) * px_par;
+        const int rp = l >> 5, u = l & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            gran_store(dst + (long)j * PMEMBERS * 64, rs_pack(pt[2 * rp][32 * j + u], pt[2 * rp + 1][32 * j + u], tag));
+    };
+
+    for (int t_hi = T - 1; t_hi >= 0; t_hi -= SB) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = t_hi - s2;
+            if (t < 0) break;
+            float dh_rec = 0.f;
+            if (t < T - 1) receive(T - 1 - t, dh_rec);        // on a timeout s_abort is set: everybody leaves after the barrier below
+            float da[4] = {0.f, 0.f, 0.f, 0.f};
+            if (own) {
+                float dh = dhb[s2] * keepb[s2] + dh_rec;
+                if (t == T - 1 && p.dh_last) dh += p.dh_last[pidx];
+                const float ig = recb[s2].x, fg = recb[s2].y, gg = recb[s2].z, og_ = recb[s2].w;
+                const float tc = lv_tanh_fast(ctb[s2]);
+                const float dc = dh * og_ * (1.f - tc * tc) + dc_rec;
+                const float d_o = dh * tc;
+                const float d_i = dc * gg, d_g = dc * ig, d_f = dc * ctb[s2 + 1];
+                da[0] = d_i * ig * (1.f - ig);
+                da[1] = d_f * fg * (1.f - fg);
+                da[2] = d_g * (1.f - gg * gg);
+                da[3] = d_o * og_ * (1.f - og_);
+                dc_rec = dc * fg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gsum[g] += da[g];
+            }
+            const uint32_t lo = lv_pack_bf16x2(da[0], da[1]), hi = lv_pack_bf16x2(da[2], da[3]);
+            outb[s2][0] = lo; outb[s2][1] = hi;
+            const int par = (T - t) & 1;
+            if (own) { sm.dgl[par][prow * DPITCH + 2 * uw] = lo; sm.dgl[par][prow * DPITCH + 2 * uw + 1] = hi; }
+            __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity)
+            if (s_abort) break;
+            if (t > 0 || closing) send(par, T - t);
+        }
+        if (s_abort) { if (tid == 0) atomicExch(p.status, 200 + (t_hi < 0 ? 0 : t_hi)); return; }
+        store_block(t_hi);
+        load_block(t_hi - SB);
+    }
+
+    if (own) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.dGsum[(long)(b0 + prow) * 4 * PH + (long)g * PH + punit] = gsum[g];
+    }
+    if (closing) {
+        float s0 = 0.f;
+        const bool fine = receive(T, s0);
+        __syncthreads();
+        if (!fine || s_abort) { if (tid == 0) atomicExch(p.status, 300); return; }
+        if (own) {
+            if (p.dh0) p.dh0[pidx] = s0;
+            float dc = dc_rec;
+            if (p.tanh_init) { const float h0 = p.hs[pidx]; dc += s0 * (1.f - h0 * h0); }
+            if (p.dc0) p.dc0[pidx] = dc;
+        }
+    } else if (own && p.dc0) {
+        p.dc0[pidx] = dc_rec;
+    }
+}
+
 constexpr long WPK_BYTES = 128L * PKS * 2 * 64 * 16;                           // one packed bf16 image of W_hh (8 MB)
 constexpr long XCH_FWD_BYTES = 2L * PGROUPS * 16 * (PH / 2) * 8;                 // h exchange, two parities
 constexpr long XCH_BWD_BYTES = 2L * PGROUPS * BR * (2 * PH) * 8;                 // dG exchange, two parities
+constexpr long XCH_RS_BYTES = 2L * PGROUPS * PMEMBERS * PMEMBERS * 64 * 8;       // partial-sum exchange (reduce-scatter BPTT), two parities
 
 }  // namespace
 
 extern "C" long lv_lstm_persist_wpk_floats(void) { return WPK_BYTES / 4; }
-extern "C" long lv_lstm_persist_xch_floats(void) { return (XCH_FWD_BYTES > XCH_BWD_BYTES ? XCH_FWD_BYTES : XCH_BWD_BYTES) / 4 + 64; }
+extern "C" long lv_lstm_persist_xch_floats(void) { return XCH_RS_BYTES / 4 + 64; }      // the largest of the three exchanges
 
-// W_hh [4H][H] f32 -> the register image of the forward (backward = 0) or BPTT (backward = 1) persistent kernel:
+// W_hh [4H][H] f32 -> the register image of the forward (backward = 0), all-gather BPTT (1) or reduce-scatter BPTT (2) kernel:
 // lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
 extern "C" int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
     if (!whh || !wpk) return LV_ERR_ARG;
     if (H != PH) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
     const dim3 grid((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), block(256);
-    if (backward) LV_LAUNCH(pack_w_persist_bwd_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    if (backward == 2) LV_LAUNCH(pack_w_persist_bwd_rs_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    else if (backward) LV_LAUNCH(pack_w_persist_bwd_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else LV_LAUNCH(pack_w_persist_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -528,6 +793,29 @@ extern "C" int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_las
     PersistBwdP p{dh_ext, dh_last, dmask, dscale, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init,
                   gxch, status, T, B, R};
     LV_LAUNCH_RESIDENT(lstm_bwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// The same BPTT in its reduce-scatter form (lstm_bwd_persist_rs_kernel; weights packed with backward = 2): a quarter of the
+// hand-off granules per timestep.  Same arguments, same outputs up to f32 summation order.
+extern "C" int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
+                                           const float* wpk, const float* gates, const float* hs, const float* cs,
+                                           float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
+                                           int tanh_init, int T, int B, int H, void* stream) {
+    if (!wpk || !gates || !cs || (!dG && !dG16) || !dGsum || !xch || !status) return LV_ERR_ARG;
+    if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (tanh_init && !hs) return LV_ERR_ARG;
+    if (H != PH || B > BR * PGROUPS || dG || !dG16) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
+    gran_t* gxch = reinterpret_cast<gran_t*>(xch);
+    hipMemsetAsync(gxch, 0, (size_t)XCH_RS_BYTES, (hipStream_t)stream);
+    const int R = (B + PGROUPS - 1) / PGROUPS;
+    PersistBwdP p{dh_ext, dh_last, dmask, dscale, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init,
+                  gxch, status, T, B, R};
+    LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -234,6 +234,9 @@ def reset_persistent_status(eng):
 
 
 _PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
+# hand-off of the persistent BPTT: "rs" = reduce-scatter of partial dh sums (2048 granules per workgroup and timestep),
+# "ag" = all-gather of dG (8192); read when the weight images are packed
+PERSIST_BWD_FORM = "rs"
 _PERSIST_MAX_B = 64
 
 
@@ -288,7 +291,8 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
             wi.xch = c.f32(lib.lv_lstm_persist_xch_floats())
             wi.status = torch.zeros(1, dtype=torch.int32, device=device)
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 0, H, s)
-        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 1, H, s)
+        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 2 if PERSIST_BWD_FORM == "rs" else 1, H, s)
+        wi.bwd_form = PERSIST_BWD_FORM
         wi.packed = True
     return wi
 
@@ -330,8 +334,9 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
     dG16 = P(img.dG) if img is not None else None
     if _persistent_ok(eng, img, B, H, device, _PERSIST_BWD_MAX_B):
         wi = eng._wimg
-        lib.lv_lstm_bwd_bf16_persist(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
-                                     P(wi.xch), P(wi.status), dh0, dc0, tanh_init, T, B, H, s)
+        fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
+        fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
+           dh0, dc0, tanh_init, T, B, H, s)
     else:
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
                                  P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
