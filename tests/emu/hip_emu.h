@@ -412,6 +412,27 @@ static inline f32x4 lv_emu_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_4x4x4_16b_bf16: block = l >> 2; lane holds 4 bf16 (k) of A row (l & 3) / B column (l & 3); D[r][l & 3] in register r
+static inline f32x4 lv_emu_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) {
+    auto& w = lv_emu::my_wave();
+    int l = lv_emu::lane();
+    w.qa[l] = make_uint4(a.x, a.y, 0, 0); w.qb[l] = make_uint4(b.x, b.y, 0, 0);
+    lv_emu::wave_sync();
+    f32x4 d = c;
+    const int blk = l & ~3;
+    unsigned short eb[4];
+    memcpy(eb, &w.qb[l], 8);
+    for (int r = 0; r < 4; ++r) {
+        unsigned short ea[4];
+        memcpy(ea, &w.qa[blk + r], 8);
+        float acc = c[r];
+        for (int e = 0; e < 4; ++e) acc = fmaf(lv_emu_bf16_to_f32(ea[e]), lv_emu_bf16_to_f32(eb[e]), acc);
+        d[r] = acc;
+    }
+    lv_emu::wave_sync();
+    return d;
+}
+
 // ---- runtime API subset used by the host side of the C ABI -------------------------------
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }

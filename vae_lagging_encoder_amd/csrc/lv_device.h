@@ -29,6 +29,7 @@ static inline int lv_device_cus() { return 1 << 20; }
 #define LV_SPIN_LIMIT (1 << 15)             // polls per wait before a hand-off is reported lost (a poll = one scheduling round here)
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
+static inline f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) { return lv_emu_mfma_4x4x4_16b_bf16(a, b, c); }
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
 #define LV_WAIT_VMEM() do { } while (0)
@@ -128,6 +129,13 @@ __device__ __forceinline__ f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16
 __device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
                                                    c, 0, 0, 0);
+}
+// v_mfma_f32_4x4x4_16b_bf16: 16 independent 4 x 4 x 4 products.  Lane l belongs to block l >> 2; a = 4 bf16 (k = 0..3) of A row
+// (l & 3), b = 4 bf16 of B column (l & 3); D[row r][col l & 3] of the block in register r.  2 passes: for a 4-row A it does the
+// useful work of a 16x16x32 MFMA (whose other 12 rows would be padding) in half the matrix-pipe time.
+typedef short lv_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(*reinterpret_cast<lv_s16x4*>(&a), *reinterpret_cast<lv_s16x4*>(&b), c, 0, 0, 0);
 }
 // global -> LDS without passing through registers (global_load_lds_dwordx4): lane l's 16 bytes at g land at
 // lds_wave_base + 16*l; lds_wave_base must be wave-uniform.  The data is ordered for LDS readers by the issuing wave's

@@ -497,12 +497,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
 // Same decomposition otherwise: 8 groups x 32 workgroups, a group owns R <= 4 batch rows, W_hh slice in registers (wave w
 // holds its workgroup's 128 k-rows x output columns [256w, 256w+256)), bulk I/O in SB-step blocks, bounded spins.
 //   per timestep: poll 8 granules per lane (one round) -> sum over senders (registers + 2 shuffles: no barrier) -> gate
-//   gradients -> dG image of the workgroup in LDS -> ONE barrier -> 64 MFMAs per wave -> wave-private transpose -> 8 granule
-//   stores per lane (each wave sends to the 8 workgroups that own its 256 columns; a wave store is 512 contiguous bytes).
-constexpr int RS_KS = 4;                         // MFMA k-steps over the workgroup's 128 gate rows
-constexpr int RS_NB = 16;                        // 16-column blocks per wave
+//   gradients -> dG image of the workgroup in LDS -> ONE barrier -> 128 v_mfma_f32_4x4x4_16b_bf16 per wave (the batch slice IS
+//   4 rows: the 16-block MFMA does the work of a 16-row tile's useful quarter in half the pipe time, and its D layout -- all
+//   4 rows of one output column in one lane -- is the granule layout) -> 8 granule stores per lane straight from the
+//   accumulators (each wave sends to the 8 workgroups that own its 256 columns; a wave store is two 256-byte runs).
+constexpr int RS_KG = 32;                        // 4-wide k groups over the workgroup's 128 gate rows
+constexpr int RS_SG = 4;                         // 64-column super groups per wave (16 blocks x 4 columns per MFMA)
 constexpr int DPITCH = 64 + 4;                   // dwords per row of the dG image (128 bf16 + pad: rows 4 bank groups apart)
-constexpr int PPITCH = 256 + 8;                  // floats per row of a wave's partial tile
 
 __device__ __forceinline__ uint32_t rs_tag(int k) { return 1u + (uint32_t)(k - 1) % 255u; }      // phase k >= 1 -> 1..255
 __device__ __forceinline__ gran_t rs_pack(float a, float b, uint32_t tag) {
@@ -524,30 +525,31 @@ __device__ __forceinline__ float rs_hi(gran_t g) {
     return f;
 }
 
-// Wrs[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)]: lane (c, kq) holds, for output column j = 256w + 16nb + c, the 8
-// weights W_hh[gate*H + unit][j] of the local gate rows n'' = 32ks + 8kq + e (unit = 32m + (n'' >> 2), gate = n'' & 3)
+// Wrs[wave_id (128) = 4m + w][kg (32)][sgp (2)][lane (64)] uint4: lane l holds, for output columns j = 256w + 64(2 sgp + h) + l
+// (h = 0, 1: .xy / .zw), the 4 weights W_hh[gate*H + unit][j] of the local gate rows n'' = 4kg + e (unit = 32m + kg, gate = e)
 __global__ __launch_bounds__(256) void pack_w_persist_bwd_rs_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 128L * RS_KS * RS_NB * 64) return;
+    if (idx >= 128L * RS_KG * 2 * 64) return;
     const int l = (int)(idx & 63);
-    const int nb = (int)((idx >> 6) % RS_NB);
-    const int ks = (int)((idx / (64 * RS_NB)) % RS_KS);
-    const int wave_id = (int)(idx / (64L * RS_NB * RS_KS));
+    const int sgp = (int)((idx >> 6) & 1);
+    const int kg = (int)((idx >> 7) % RS_KG);
+    const int wave_id = (int)(idx / (64L * 2 * RS_KG));
     const int m = wave_id >> 2, w = wave_id & 3;
-    const int c = l & 15, kq = l >> 4;
-    const int j = 256 * w + 16 * nb + c;
-    float v[8];
+    uint32_t o[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int np = 32 * ks + 8 * kq + e;
-        v[e] = whh[((long)(np & 3) * PH + 32 * m + (np >> 2)) * PH + j];
+    for (int h = 0; h < 2; ++h) {
+        const int j = 256 * w + 64 * (2 * sgp + h) + l;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = whh[((long)e * PH + 32 * m + kg) * PH + j];
+        o[2 * h] = lv_pack_bf16x2(v[0], v[1]);
+        o[2 * h + 1] = lv_pack_bf16x2(v[2], v[3]);
     }
-    wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+    wpk[idx] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 struct __attribute__((aligned(16))) BwdRsLds {
     uint32_t dgl[2][16 * DPITCH];       // [step parity] dG of this workgroup's 128 gate rows as the MFMA A image, rows < R valid
-    float part[4][BR][PPITCH];          // per wave: its 256 output columns (wave-private)
     uint16_t og[SB][BR][4][32];         // dG of one I/O block: [step][row][gate][unit in WG]
     int abort;
 };
@@ -565,13 +567,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistBwdP p)
     if (rows == 0) return;
     if (tid == 0) s_abort = 0;
 
-    uint4 wreg[RS_KS][RS_NB];
+    uint4 wreg[RS_KG][2];               // [k group][super-group pair]: .xy / .zw = the B operands of super groups 2 sgp, 2 sgp + 1
     {
-        const uint4* wp = p.wpk + (long)wave_id * RS_KS * RS_NB * 64 + l;
+        const uint4* wp = p.wpk + (long)wave_id * RS_KG * 2 * 64 + l;
 #pragma unroll
-        for (int ks = 0; ks < RS_KS; ++ks)
+        for (int kg = 0; kg < RS_KG; ++kg)
 #pragma unroll
-            for (int nb = 0; nb < RS_NB; ++nb) wreg[ks][nb] = wp[(ks * RS_NB + nb) * 64];
+            for (int sgp = 0; sgp < 2; ++sgp) wreg[kg][sgp] = wp[(kg * 2 + sgp) * 64];
     }
 
     // this lane's (row, unit) pair: lanes 0..31 of each wave; wave w receives the sums of rows {2(w>>1), 2(w>>1)+1} x units
@@ -585,7 +587,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistBwdP p)
     const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * 64;
     gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * 64;
     const gran_t* const rx = px_g + (long)member * PMEMBERS * 64 + (8 * (l >> 4)) * 64 + 16 * w + (l & 15);   // + j*64 per sender
-    gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * 64 + l;                                   // + j*PMEMBERS*64 per receiver
+    // lane l of super group sg holds output column 64 sg + l: receiver 8w + 2sg + (l >> 5), its unit l & 31
+    gran_t* const tx = px_g + ((long)(8 * w + (l >> 5)) * PMEMBERS + member) * 64 + (l & 31);                 // + sg*2*PMEMBERS*64, + 32 for rows 2,3
 
     float dc_rec = 0.f;
     float gsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistBwdP p)
     load_block(T - 1);
     __syncthreads();
 
-    const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
+    const int arow = (l & 3) < rows ? (l & 3) : 0;      // A row of this lane; rows beyond the slice re-read row 0 (their D rows are ignored)
     const bool closing = p.dh0 || p.tanh_init;
 
     // receive phase k: the 32 senders' partial sums of dh for this workgroup's units; lanes < 32 get their pair's total
@@ -664,32 +667,30 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs_kernel(PersistBwdP p)
     };
     // multiply the dG image of step parity `par` with this wave's columns and send phase k to their owners
     auto send = [&](int par, int k) {
-        const uint32_t* img = sm.dgl[par];
-        uint4 afr[RS_KS];
+        const uint32_t* img = sm.dgl[par] + arow * DPITCH;
+        uint4 afr[RS_KG / 2];            // this lane's A row, all 128 k: 16 broadcast reads
 #pragma unroll
-        for (int ks = 0; ks < RS_KS; ++ks) afr[ks] = *reinterpret_cast<const uint4*>(img + arow * DPITCH + 16 * ks + 4 * kq);
-        float (*pt)[PPITCH] = sm.part[w];
-#pragma unroll
-        for (int c4 = 0; c4 < RS_NB / 4; ++c4) {
-            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < RS_KS; ++ks)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[n] = lv_mfma_16x16x32_bf16(afr[ks], wreg[ks][4 * c4 + n], acc[n]);
-            if (l < 16) {                       // rows 0..3 of the 16 x 16 tiles
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int r = 0; r < BR; ++r) pt[r][16 * (4 * c4 + n) + l] = acc[n][r];
-            }
-        }
-        LV_WAIT_LDS();
+        for (int q = 0; q < RS_KG / 2; ++q) afr[q] = *reinterpret_cast<const uint4*>(img + 4 * q);
         const uint32_t tag = rs_tag(k);
         gran_t* dst = tx + (long)(k & 1) * px_par;
-        const int rp = l >> 5, u = l & 31;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            gran_store(dst + (long)j * PMEMBERS * 64, rs_pack(pt[2 * rp][32 * j + u], pt[2 * rp + 1][32 * j + u], tag));
+        for (int sgp = 0; sgp < 2; ++sgp) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < RS_KG / 2; ++q) {
+                acc0 = lv_mfma_4x4x4_16b_bf16(make_uint2(afr[q].x, afr[q].y), make_uint2(wreg[2 * q][sgp].x, wreg[2 * q][sgp].y), acc0);
+                acc1 = lv_mfma_4x4x4_16b_bf16(make_uint2(afr[q].x, afr[q].y), make_uint2(wreg[2 * q][sgp].z, wreg[2 * q][sgp].w), acc1);
+                acc0 = lv_mfma_4x4x4_16b_bf16(make_uint2(afr[q].z, afr[q].w), make_uint2(wreg[2 * q + 1][sgp].x, wreg[2 * q + 1][sgp].y), acc0);
+                acc1 = lv_mfma_4x4x4_16b_bf16(make_uint2(afr[q].z, afr[q].w), make_uint2(wreg[2 * q + 1][sgp].z, wreg[2 * q + 1][sgp].w), acc1);
+            }
+            // the two super groups' columns go out while the next pair multiplies
+            gran_t* d0 = dst + (long)(2 * sgp) * 2 * PMEMBERS * 64;
+            gran_t* d1 = d0 + 2L * PMEMBERS * 64;
+            gran_store(d0, rs_pack(acc0[0], acc0[1], tag));
+            gran_store(d0 + 32, rs_pack(acc0[2], acc0[3], tag));
+            gran_store(d1, rs_pack(acc1[0], acc1[1], tag));
+            gran_store(d1 + 32, rs_pack(acc1[2], acc1[3], tag));
+        }
     };
 
     for (int t_hi = T - 1; t_hi >= 0; t_hi -= SB) {
@@ -765,7 +766,7 @@ extern "C" int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, 
     if (!whh || !wpk) return LV_ERR_ARG;
     if (H != PH) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
-    const dim3 grid((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), block(256);
+    const dim3 grid((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), block(256);      // every image: 128 x 32 x 2 x 64 uint4
     if (backward == 2) LV_LAUNCH(pack_w_persist_bwd_rs_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else if (backward) LV_LAUNCH(pack_w_persist_bwd_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else LV_LAUNCH(pack_w_persist_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
