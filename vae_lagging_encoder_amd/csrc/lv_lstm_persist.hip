@@ -34,7 +34,6 @@ constexpr int PUW = 8;              // hidden units per wave
 constexpr int HPITCH = PH / 2 + 16; // LDS row pitch of the gathered h image in dwords: rows 16 banks apart, so the A-fragment
                                     // reads of 4 rows x 4 k-quads hit 16 distinct bank groups
 constexpr int PRMAX = 8;            // batch rows per group this build supports (LDS: 2 x PRMAX x HPITCH dwords)
-constexpr int FG2 = 64;             // pairs of 4x4x4 MFMA steps per K half (512 k = 128 steps)
 constexpr int SPIN_LIMIT = LV_SPIN_LIMIT;
 
 typedef unsigned long long gran_t;  // (tag << 32) | two bf16
@@ -42,25 +41,20 @@ typedef unsigned long long gran_t;  // (tag << 32) | two bf16
 __device__ __forceinline__ gran_t gran_load(const gran_t* p) { return lv_agent_load_u64(p); }
 __device__ __forceinline__ void gran_store(gran_t* p, gran_t v) { lv_agent_store_u64(p, v); }
 
-// Wpk[wave_id (128)][g2 (64)][lane (64)] uint4: the B operands of v_mfma_f32_4x4x4_16b_bf16 steps g = 2 g2 (.xy) and 2 g2 + 1 (.zw).
-// Lane l is in block b = l >> 2: gate column (unit 8 wave_id + (b & 7), gate l & 3) and K half b >> 3; step g contracts over
-// k = 4 (g + 128 (b >> 3)) .. + 3.  The two K halves of a column (lanes l, l ^ 32) are added after the last step.
+// Wpk[wave_id (128)][ks (32)][nb (2)][lane (64)] : lane (c = l&15, kq = l>>4) holds W_hh[gate*H + unit][32ks + 8kq .. +7]
+// with unit = 8*wave_id + 4*nb + (c>>2), gate = c&3 -- the B operand of v_mfma_f32_16x16x32_bf16 for that column.
 __global__ __launch_bounds__(256) void pack_w_persist_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 128L * FG2 * 64) return;
+    if (idx >= 128L * PKS * 2 * 64) return;
     const int l = (int)(idx & 63);
-    const int g2 = (int)((idx >> 6) % FG2);
-    const int wave_id = (int)(idx / (64L * FG2));
-    const int b = l >> 2;
-    const int unit = PUW * wave_id + (b & 7), gate = l & 3, kh = b >> 3;
-    uint32_t o[4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float* row = whh + ((long)gate * PH + unit) * PH + 4 * ((2 * g2 + h) + 128 * kh);
-        o[2 * h] = lv_pack_bf16x2(row[0], row[1]);
-        o[2 * h + 1] = lv_pack_bf16x2(row[2], row[3]);
-    }
-    wpk[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    const int nb = (int)((idx >> 6) & 1);
+    const int ks = (int)((idx >> 7) % PKS);
+    const int wave_id = (int)(idx / (64L * 2 * PKS));
+    const int c = l & 15, kq = l >> 4;
+    const int unit = PUW * wave_id + 4 * nb + (c >> 2), gate = c & 3;
+    const float* row = whh + ((long)gate * PH + unit) * PH + 32 * ks + 8 * kq;
+    wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
+                          lv_pack_bf16x2(row[6], row[7]));
 }
 
 struct PersistFwdP {
@@ -101,11 +95,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
     if (tid == 0) s_abort = 0;
 
     // ---- weights: registers for the whole call --------------------------------------------------------------------------
-    uint4 wreg[FG2];
+    uint4 wreg[PKS][2];
     {
-        const uint4* wp = p.wpk + (long)wave_id * FG2 * 64 + l;
+        const uint4* wp = p.wpk + (long)wave_id * PKS * 2 * 64 + l;
 #pragma unroll
-        for (int g2 = 0; g2 < FG2; ++g2) wreg[g2] = wp[g2 * 64];
+        for (int ks = 0; ks < PKS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wreg[ks][nb] = wp[(ks * 2 + nb) * 64];
     }
 
     // ---- this lane's (row, unit) pair -------------------------------------------------------------------------------------
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
 
     // A-operand rows beyond the group's batch rows read a valid LDS row (row 0): their products land in MFMA output rows
     // nobody owns, so no predicate sits between the LDS reads and the MFMAs
-    const int kh = l >> 5;                             // K half of this lane's MFMA block
+    const int arow = (l & 15) < rows ? (l & 15) : 0, kq = l >> 4;
     const int ngran = rows * (PH / 2);                 // granules of one state of this group
     const int gq = (ngran + 3) / 4;                    // this wave gathers granules [w*gq, w*gq + gq)
 
@@ -200,26 +196,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
             __syncthreads();
             if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
 
-            // ---- recurrent product: this wave's 32 gate columns, K from LDS x registers; 4 batch rows per pass ------------
-            for (int rb = 0; rb < rows; rb += 4) {
-                // A rows beyond the group's batch rows read a valid LDS row: their D rows are never used
-                const int ar = rb + (l & 3) < rows ? rb + (l & 3) : 0;
-                const uint4* ap = reinterpret_cast<const uint4*>(dst + ar * HPITCH + 256 * kh);
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            // ---- recurrent product: this wave's 32 gate columns, K from LDS x registers ---------------------------------
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const uint4* arowp = reinterpret_cast<const uint4*>(dst + arow * HPITCH) + kq;
 #pragma unroll
-                for (int g2 = 0; g2 < FG2; ++g2) {
-                    const uint4 a = ap[g2];
-                    acc0 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.x, a.y), make_uint2(wreg[g2].x, wreg[g2].y), acc0);
-                    acc1 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.z, a.w), make_uint2(wreg[g2].z, wreg[g2].w), acc1);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc0[r] + acc1[r];
-                    v += __shfl_xor(v, 32, 64);                          // the other K half of the same column
-                    if (l < 32) pre[w][rb + r][l] = v;                   // column l = 4 * unit + gate
-                }
+            for (int ks = 0; ks < PKS; ++ks) {
+                const uint4 a = arowp[ks * 4];
+                acc[(ks & 1) * 2 + 0] = lv_mfma_16x16x32_bf16(a, wreg[ks][0], acc[(ks & 1) * 2 + 0]);
+                acc[(ks & 1) * 2 + 1] = lv_mfma_16x16x32_bf16(a, wreg[ks][1], acc[(ks & 1) * 2 + 1]);
             }
-            LV_WAIT_LDS();                             // wave-private tile, the wave's own LDS accesses are ordered
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[w][(l >> 4) * 4 + r][nb * 16 + (l & 15)] = acc[nb][r] + acc[2 + nb][r];
+            LV_WAIT_LDS();        // lgkmcnt(0): wave-private tile, the wave's own LDS accesses are ordered
 
             // ---- epilogue: gates, cell update, hand-off of h_t ------------------------------------------------------------
             float h = 0.f;
