@@ -320,7 +320,7 @@ def main():
         lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
         lstm_roof = {
             "bound": "hbm",
-            "kernel": ("lstm_{fwd,bwd}_persist_kernel (one launch per recurrence, W_hh register-resident, tagged-granule hand-off per timestep)"
+            "kernel": ("lstm_fwd_persist_kernel / lstm_bwd_persist_rs_kernel (one launch per recurrence, W_hh register-resident, tagged-granule hand-off per timestep: all-gather of h forward, reduce-scatter of partial dh sums in BPTT)"
                        if persistent else "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)"),
             "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
             "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),

@@ -56,13 +56,13 @@ def groups(fetch_csv, write_csv, steps=None):
             n += max(nf, nw)
         return round(tot / max(n, 1), 3), n, tot
     is_lstm = lambda n: "lstm_step_" in n
-    is_pers = lambda n: "lstm_fwd_persist_kernel" in n or "lstm_bwd_persist_kernel" in n
+    is_pers = lambda n: "lstm_fwd_persist" in n or "lstm_bwd_persist" in n
     bf = lambda n: "true>" in n
     out = {
         "bf16": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and bf(n))[0],
                  "lstm_persist_MB_per_launch": mb(is_pers)[0],
-                 "lstm_fwd_persist_MB_per_launch": mb(lambda n: "lstm_fwd_persist_kernel" in n)[0],
-                 "lstm_bwd_persist_MB_per_launch": mb(lambda n: "lstm_bwd_persist_kernel" in n)[0],
+                 "lstm_fwd_persist_MB_per_launch": mb(lambda n: "lstm_fwd_persist" in n)[0],
+                 "lstm_bwd_persist_MB_per_launch": mb(lambda n: "lstm_bwd_persist" in n)[0],
                  "gemm_MB_per_launch": mb(lambda n: "lv_gemm_b16" in n)[0]},
         "f32": {"lstm_MB_per_launch": mb(lambda n: is_lstm(n) and not bf(n))[0],
                 "gemm_MB_per_launch": mb(lambda n: "lv_gemm_f32_kernel" in n and ", 2>" in n)[0]},
