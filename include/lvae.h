@@ -65,6 +65,12 @@ int lv_softmax_nll_bwd_h16(const uint16_t* logits16, long ldl, const float* lse,
 /* src f32 [R][C](lds) -> dst bf16 [R][C](ldd) and/or dstT bf16 [C][R](ldt), round-to-nearest-even; either may be NULL */
 int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
                     void* stream);
+/* the same images with nn.Dropout folded in (dec_lstm.py:106, dropout_out on the decoder LSTM's output): src = h time-major
+ * [T*Bsz][C] (row t*Bsz + b), keep = the reference-layout mask [Bsz][T][C] (uint8): images of h * (keep ? kscale : 0).  And its
+ * backward on dO, in place.  (The persistent recurrences then run without a mask: +0.3 us per timestep otherwise.) */
+int lv_cvt_bf16_keep_f32(const float* src, long lds, int T, int Bsz, int C, const uint8_t* keep, float kscale,
+                         uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
+int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, int T, int Bsz, int C, void* stream);
 
 /* LSTM gate weight W [4H][C] (rows g*H + u): dst = bf16 image with rows in unit-major order (4u + g), dstT = bf16 image
  * of W^T [C][4H] in the standard order; either may be NULL */

@@ -49,3 +49,14 @@ lib.lv_lstm_persist_pack(P(whh), P(wpk_r), 2, H, s)
 st.zero_()
 b = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(P(dO), None, P(mask), 2.0, P(wpk_r), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
 print("BPTT persistent (reduce-scatter): %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+
+# ---- what the block I/O costs: the same launches with fewer per-step inputs / outputs -----------------------------------
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(wpk_f), P(hs), P(cs), P(gates), None, 1.0, None, P(wsp), P(st), T, B, H, s))
+print("forward persistent, no dropout mask / dropped output: %.2f us/step" % (b / T))
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(wpk_f), P(hs), P(cs), P(gates), None, 1.0, P(hdrop), P(wsp), P(st), T, B, H, s))
+print("forward persistent, dropped output without mask      : %.2f us/step" % (b / T))
+dlast = torch.randn(B, H, device=dev)
+b = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(P(dO), None, None, 1.0, P(wpk_r), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
+print("BPTT rs, dh_ext without mask: %.2f us/step" % (b / T))
+b = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(None, P(dlast), None, 1.0, P(wpk_r), P(gates_std), P(hs), P(cs), None, P(dG16), P(dGsum), P(wsp), P(st), None, P(dc0), 1, T, B, H, s))
+print("BPTT rs, dh_last only       : %.2f us/step" % (b / T))

@@ -191,3 +191,7 @@ def test_lstm_fwd_persistent_emulated(emu_backend):
                                  (10, 5, True, False, True, True, "rs"), (4, 3, True, True, True, False, "ag")])
 def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent(emu_backend, CPU, *cfg)
+
+
+def test_dropout_folded_into_image_conversion(emu_backend):
+    K.test_dropout_folded_into_image_conversion(emu_backend, CPU, 5, 3, 70)

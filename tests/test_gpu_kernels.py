@@ -1043,3 +1043,25 @@ def test_conv_bnstat_feeds_batchnorm(lib, hip_device, N, k, Cin, Cout):
     ref = torch.stack((y0.double().sum(0), (y0.double() ** 2).sum(0))).cpu()
     assert float((part.double().sum(0).cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
     bn_both(y1, Cout, nblk, part)
+
+
+@pytest.mark.parametrize("T,B,C", [(5, 3, 70), (7, 32, 128)])
+def test_dropout_folded_into_image_conversion(lib, hip_device, T, B, C):
+    """lv_cvt_bf16_keep_f32 / lv_keep_scale_f32: nn.Dropout on a time-major activation with the reference-layout mask
+    [B][T][C], identical (bit for bit) to masking first and converting afterwards."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(T + C)
+    h = torch.randn(T * B, C, generator=g)
+    keep = (torch.rand(B, T, C, generator=g) < 0.5).to(torch.uint8)
+    ktm = keep.permute(1, 0, 2).reshape(T * B, C).float() * 2.0            # time-major keep * scale
+    hd, kd = h.to(dev), keep.contiguous().to(dev)
+    ldd, ldt = (C + 7) // 8 * 8, (T * B + 7) // 8 * 8
+    out = torch.zeros(T * B, ldd, dtype=torch.int16, device=dev)
+    outT = torch.zeros(C, ldt, dtype=torch.int16, device=dev)
+    lib.lv_cvt_bf16_keep_f32(P(hd), C, T, B, C, P(kd), 2.0, P(out), ldd, P(outT), ldt, _s(dev))
+    ref = (h * ktm).to(torch.bfloat16).view(torch.int16)
+    assert torch.equal(out[:, :C].cpu(), ref)
+    assert torch.equal(outT[:, :T * B].cpu(), ref.t())
+    x = h.clone().to(dev)
+    lib.lv_keep_scale_f32(P(x), P(kd), 2.0, T, B, C, _s(dev))
+    assert torch.equal(x.cpu(), h * ktm)

@@ -158,6 +158,15 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
     }
 }
 
+__global__ __launch_bounds__(256) void keep_scale_kernel(float* __restrict__ x, const uint8_t* __restrict__ keep, float kscale, int T,
+                                                         int Bsz, int C, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long r = i / C;
+    const int c = (int)(i % C);
+    x[i] *= keep[((r % Bsz) * (long)T + r / Bsz) * C + c] ? kscale : 0.f;
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef) {
     const float c = coef[0];
     if (c == 1.0f) return;            // clip inactive (coef is exactly 1): x * 1 is x bit for bit, skip the pass
@@ -241,6 +250,18 @@ extern "C" int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, 
     if (!p || !g || !lr_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
     LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// x [T*Bsz][C] time-major (row t*Bsz + b) *= keep [Bsz][T][C] ? kscale : 0: the backward of nn.Dropout on the decoder LSTM's
+// output (dec_lstm.py:106), applied to dO once with loads along C instead of inside the persistent BPTT
+extern "C" int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, int T, int Bsz, int C, void* stream) {
+    if (!x || !keep) return LV_ERR_ARG;
+    if (T < 0 || Bsz <= 0 || C <= 0) return LV_ERR_SHAPE;
+    const long n = (long)T * Bsz * C;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(keep_scale_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, x, keep, kscale, T, Bsz, C, n);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
