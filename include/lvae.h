@@ -110,6 +110,12 @@ int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void
 int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
                              const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
                              int T, int B, int H, void* stream);
+/* the same recurrence with the contraction split over the workgroup's waves (weights packed with backward = 3): each wave
+ * gathers and multiplies its own K quarter, the quarter products meet in LDS after ONE barrier; same arguments and outputs (up
+ * to f32 summation order). */
+int lv_lstm_fwd_bf16_persist_ks(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
+                             const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
+                             int T, int B, int H, void* stream);
 /* BPTT as one persistent launch (same decomposition; dG[t] is what travels between steps and the gate-gradient math of
  * a step runs where its dh is completed, so a timestep is one phase instead of two launches).  Arguments as
  * lv_lstm_bwd_bf16_img with wpk = lv_lstm_persist_pack(whh, wpk, 1, H), xch / status as above; dG16 16-byte aligned.

@@ -32,7 +32,13 @@ def t(f, n=10):
 a = t(lambda: lib.lv_lstm_fwd_bf16_ug(P(gx), P(whh), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(ws), T, B, H, s))
 b = t(lambda: lib.lv_lstm_fwd_bf16_persist(P(gx), P(wpk_f), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
 print("launch per step : %8.1f us  (%.2f us/step)" % (a, a / T))
-print("persistent      : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+print("persistent (column split, 16x16x32): %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+wpk_k = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+lib.lv_lstm_persist_pack(P(whh), P(wpk_k), 3, H, s)
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist_ks(P(gx), P(wpk_k), P(hs), P(cs), P(gates), P(mask), 2.0, P(hdrop), P(wsp), P(st), T, B, H, s))
+print("persistent (K split, 4x4x4)         : %8.1f us  (%.2f us/step)   status %d" % (b, b / T, int(st.item())))
+b = t(lambda: lib.lv_lstm_fwd_bf16_persist_ks(P(gx), P(wpk_k), P(hs), P(cs), P(gates), None, 1.0, None, P(wsp), P(st), T, B, H, s))
+print("persistent (K split), no mask / dropped output: %.2f us/step" % (b / T))
 
 # ---- BPTT: one persistent launch vs elementwise + split-K matmul launches per step -------------------------------------
 gates_std = torch.empty(T, B, 4 * H, device=dev)

@@ -185,6 +185,9 @@ def test_conv_bnstat(emu_backend, cfg):
 def test_lstm_fwd_persistent_emulated(emu_backend):
     """The persistent forward recurrence with every workgroup of its grid live at once (fibers; hand-off polls yield)."""
     K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True)
+    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 20, True)              # 3 batch rows per group (ragged last group)
+    K.test_lstm_fwd_persistent(emu_backend, CPU, 2, 45, False)             # 6 rows per group: two 4-row passes
+    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True, variant="cols")
 
 
 @pytest.mark.parametrize("cfg", [(3, 3, True, True, True, False, "rs"), (2, 2, False, False, True, True, "rs"),

@@ -314,7 +314,7 @@ def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ex
 
 
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
-def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
+def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks"):
     """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
     and against the launch-per-step kernel fed the same unit-major gx."""
     dev, H = hip_device, 1024
@@ -339,8 +339,8 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask):
             wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
             ws = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_persist_pack(P(whh), P(wpk), 0, H, _s(dev))
-            lib.lv_lstm_fwd_bf16_persist(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
+            lib.lv_lstm_persist_pack(P(whh), P(wpk), 3 if variant == "ks" else 0, H, _s(dev))
+            (lib.lv_lstm_fwd_bf16_persist_ks if variant == "ks" else lib.lv_lstm_fwd_bf16_persist)(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
                                          P(ws), P(status), T, B, H, _s(dev))
             assert int(status.item()) == 0
         else:
@@ -426,6 +426,11 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         outs.append((dG.clone(), dGsum.clone(), dc0.clone()))
     sc = float(outs[1][0].abs().max())
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
+
+
+@pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (9, 64, True), (3, 13, False)])
+def test_lstm_fwd_persistent_column_split_form(lib, hip_device, T, B, use_mask):
+    test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="cols")
 
 
 @pytest.mark.parametrize("T,B,use_mask,tanh_init,use_ext,use_last", [(6, 32, True, True, True, False), (40, 30, False, False, True, True)])

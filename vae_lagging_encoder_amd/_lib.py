@@ -44,6 +44,7 @@ SIGNATURES = {
     "lv_clip_norm2_f32": [_vp, _l, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp],
     "lv_rng_noise_step": [_vp, _l, _vp, _l, _f, _vp, _l, _f, _vp, _u64, _vp],
     "lv_lstm_fwd_bf16_persist": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "lv_lstm_fwd_bf16_persist_ks": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist_rs": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],

@@ -235,6 +235,206 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(PersistFwdP p) {
 }
 
 // =====================================================================================================================
+// Forward recurrence, K-split form.  Same groups, same hand-off (all-gather of h_t as {2 x bf16, tag} granules); what changes
+// is who multiplies what.  A workgroup owns 32 units = 128 gate columns and its 4 waves split the CONTRACTION: wave w gathers
+// only K-quarter w of h_{t-1} (units [256w, 256w+256): R x 128 granules, into a wave-private part of the LDS image), starts
+// multiplying as soon as ITS quarter has landed -- no workgroup barrier between gather and product -- and contracts on
+// v_mfma_f32_4x4x4_16b_bf16 (the batch slice is 4 rows: half the matrix-pipe time of the 16-row tile; 128 steps per wave, 32
+// LDS reads of the lane's A row in hand-pipelined batches).  The four quarter products [R][128] meet in LDS, ONE barrier,
+// and each (row, unit) lane adds its 4 x 4 values and runs the gate math.  The barrier sits after the product instead of
+// before it, so the skew between the four gathers is absorbed by the multiplies.
+constexpr int FKG = 64;              // 4-wide k groups per K quarter
+constexpr int RPITCH = 128 + 4;      // floats per row of a wave's quarter product
+
+// Wks[wave_id (128) = 4m + w][kg (64)][lane (64)] uint4: .xy / .zw = the B operands of column super groups 0 / 1: lane l holds,
+// for gate column 64 sg + l of workgroup m (unit 32m + ((64 sg + l) >> 2), gate l & 3), the 4 weights of k = 256w + 4kg + e
+__global__ __launch_bounds__(256) void pack_w_persist_ks_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * FKG * 64) return;
+    const int l = (int)(idx & 63);
+    const int kg = (int)((idx >> 6) % FKG);
+    const int wave_id = (int)(idx / (64L * FKG));
+    const int m = wave_id >> 2, w = wave_id & 3;
+    uint32_t o[4];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+        const int col = 64 * sg + l;
+        const float* row = whh + ((long)(col & 3) * PH + 32 * m + (col >> 2)) * PH + 256 * w + 4 * kg;
+        o[2 * sg] = lv_pack_bf16x2(row[0], row[1]);
+        o[2 * sg + 1] = lv_pack_bf16x2(row[2], row[3]);
+    }
+    wpk[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+struct __attribute__((aligned(16))) FwdKsLds {
+    uint32_t hl[PRMAX * HPITCH];        // gathered h_{t-1}: [row][k/2]; wave w writes and reads dwords [128w, 128w+128) of every row
+    float red[2][4][PRMAX][RPITCH];     // [step parity][wave]: quarter product [row][gate column of the workgroup]
+    int abort;
+};
+
+__global__ __launch_bounds__(256) void lstm_fwd_persist_ks_kernel(PersistFwdP p) {
+    LV_BLOCK_SHARED(FwdKsLds, sm);
+    int& s_abort = sm.abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    if (rows == 0) return;
+    if (tid == 0) s_abort = 0;
+
+    uint4 wreg[FKG];
+    {
+        const uint4* wp = p.wpk + (long)wave_id * FKG * 64 + l;
+#pragma unroll
+        for (int kg = 0; kg < FKG; ++kg) wreg[kg] = wp[kg * 64];
+    }
+
+    // this thread's (row, unit) pair: 8 rows x 32 units of the workgroup
+    const int prow = tid >> 5, uw = tid & 31;
+    const int punit = 32 * member + uw;
+    const bool own = prow < rows;
+    const long BH = (long)B * PH;
+    const long pidx = (long)(b0 + (own ? prow : 0)) * PH + punit;
+    float c_state = own ? p.cs[pidx] : 0.f;
+    gran_t* const hx_g = p.hx + (long)group * 16 * (PH / 2);
+    const long hx_par = (long)PGROUPS * 16 * (PH / 2);
+    gran_t* const my_gran = hx_g + (long)prow * (PH / 2) + (punit >> 1);
+    const bool publisher = own && !(uw & 1);
+
+    {   // publish the initial state hs[0] as state 0 (tag 1)
+        const uint32_t mine = lv_f32_to_bf16_bits(own ? p.hs[pidx] : 0.f);
+        const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+        if (publisher) gran_store(my_gran, ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
+    }
+
+    float4 gxb[SB];
+    float keepb[SB];
+    float4 recb[SB];
+    float cb[SB], hb[SB], hdb[SB];
+    auto load_block = [&](int tb) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            gxb[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            keepb[s2] = 1.f;
+            if (own && t < T) {
+                gxb[s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx) * 4);
+                if (p.hdrop && p.dmask) keepb[s2] = p.dmask[((long)(b0 + prow) * T + t) * PH + punit] ? p.dscale : 0.f;
+            }
+        }
+    };
+    auto store_block = [&](int tb) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            if (own && t < T) {
+                lv_store_nt(f32x4{recb[s2].x, recb[s2].y, recb[s2].z, recb[s2].w},
+                            reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx) * 4));
+                lv_store_nt(cb[s2], p.cs + (long)(t + 1) * BH + pidx);
+                lv_store_nt(hb[s2], p.hs + (long)(t + 1) * BH + pidx);
+                if (p.hdrop) lv_store_nt(hdb[s2], p.hdrop + (long)t * BH + pidx);
+            }
+        }
+    };
+    load_block(0);
+    __syncthreads();
+
+    const int nq = rows * 128;                         // granules of this wave's K quarter
+    for (int tb = 0; tb < T; tb += SB) {
+#pragma unroll
+        for (int s2 = 0; s2 < SB; ++s2) {
+            const int t = tb + s2;
+            if (t >= T) break;
+            // ---- gather K-quarter w of state t (tag t+1) into this wave's part of the LDS image ---------------------------
+            const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
+            const uint32_t want = (uint32_t)(t + 1);
+            for (int base = 0; base < nq; base += 64 * 8) {
+                gran_t v[8];
+                int spins = 0;
+                bool ok;
+                do {
+                    ok = true;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = base + j * 64 + l;
+                        const bool in = q < nq;
+                        v[j] = gran_load(src + (in ? (q >> 7) * (PH / 2) + (q & 127) : 0));
+                        ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
+                    }
+                    ok = __all(ok);
+                    if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                } while (!ok);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = base + j * 64 + l;
+                    if (q < nq) sm.hl[(q >> 7) * HPITCH + 128 * w + (q & 127)] = (uint32_t)v[j];
+                }
+            }
+            LV_WAIT_LDS();                             // the wave reads back only what its own lanes wrote
+
+            // ---- this wave's quarter of the recurrent product: 4 batch rows per pass --------------------------------------
+            float (*rd)[RPITCH] = sm.red[t & 1][w];
+            for (int rb = 0; rb < rows; rb += 4) {
+                const int ar = rb + (l & 3) < rows ? rb + (l & 3) : 0;       // rows beyond the slice re-read row 0: their D rows are unused
+                const uint4* ap = reinterpret_cast<const uint4*>(sm.hl + ar * HPITCH + 128 * w);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                uint4 abuf[2][8];                      // the lane's A row in 4 batches of 8 reads, batch c + 1 requested before batch c multiplies
+#pragma unroll
+                for (int u = 0; u < 8; ++u) abuf[0][u] = ap[u];
+#pragma unroll
+                for (int c = 0; c < FKG / 16; ++c) {
+                    if (c + 1 < FKG / 16) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) abuf[(c + 1) & 1][u] = ap[8 * (c + 1) + u];
+                    }
+                    LV_SCHED_BARRIER();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint4 a = abuf[c & 1][u];
+                        const uint4 b0_ = wreg[16 * c + 2 * u], b1_ = wreg[16 * c + 2 * u + 1];
+                        acc0 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.x, a.y), make_uint2(b0_.x, b0_.y), acc0);
+                        acc1 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.x, a.y), make_uint2(b0_.z, b0_.w), acc1);
+                        acc0 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.z, a.w), make_uint2(b1_.x, b1_.y), acc0);
+                        acc1 = lv_mfma_4x4x4_16b_bf16(make_uint2(a.z, a.w), make_uint2(b1_.z, b1_.w), acc1);
+                    }
+                    LV_SCHED_BARRIER();
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rd[rb + r][l] = acc0[r]; rd[rb + r][64 + l] = acc1[r]; }
+            }
+            __syncthreads();                           // the four quarter products (double-buffered by step parity)
+            if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
+
+            // ---- epilogue: gates, cell update, hand-off of h_t ------------------------------------------------------------
+            float h = 0.f;
+            if (own) {
+                const float4 q0 = *reinterpret_cast<const float4*>(&sm.red[t & 1][0][prow][4 * uw]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&sm.red[t & 1][1][prow][4 * uw]);
+                const float4 q2 = *reinterpret_cast<const float4*>(&sm.red[t & 1][2][prow][4 * uw]);
+                const float4 q3 = *reinterpret_cast<const float4*>(&sm.red[t & 1][3][prow][4 * uw]);
+                const float ig = lv_sigmoid_fast(gxb[s2].x + ((q0.x + q1.x) + (q2.x + q3.x)));
+                const float fg = lv_sigmoid_fast(gxb[s2].y + ((q0.y + q1.y) + (q2.y + q3.y)));
+                const float gg = lv_tanh_fast(gxb[s2].z + ((q0.z + q1.z) + (q2.z + q3.z)));
+                const float og = lv_sigmoid_fast(gxb[s2].w + ((q0.w + q1.w) + (q2.w + q3.w)));
+                const float c = fg * c_state + ig * gg;
+                h = og * lv_tanh_fast(c);
+                c_state = c;
+                recb[s2] = make_float4(ig, fg, gg, og);
+                cb[s2] = c; hb[s2] = h; hdb[s2] = h * keepb[s2];
+            }
+            const uint32_t mine = lv_f32_to_bf16_bits(h);
+            const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+            if (publisher)
+                gran_store(my_gran + (long)((t + 1) & 1) * hx_par, ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
+        }
+        store_block(tb);
+        load_block(tb + SB);
+    }
+}
+
+// =====================================================================================================================
 // BPTT as one persistent launch.  Same decomposition (8 groups x 32 workgroups, a group owns a batch slice), mirrored:
 // what travels between steps is dG[t] (4 gate gradients per unit), published by the lane that computed it as two 8-byte
 // granules and gathered by every workgroup of the group into an LDS image [row][4H] in UNIT-major K order (n' = 4u + g).
@@ -760,14 +960,16 @@ constexpr long XCH_RS_BYTES = 2L * PGROUPS * PMEMBERS * PMEMBERS * 64 * 8;      
 extern "C" long lv_lstm_persist_wpk_floats(void) { return WPK_BYTES / 4; }
 extern "C" long lv_lstm_persist_xch_floats(void) { return XCH_RS_BYTES / 4 + 64; }      // the largest of the three exchanges
 
-// W_hh [4H][H] f32 -> the register image of the forward (backward = 0), all-gather BPTT (1) or reduce-scatter BPTT (2) kernel:
+// W_hh [4H][H] f32 -> the register image of the forward (backward = 0; 3 = its K-split form), all-gather BPTT (1) or
+// reduce-scatter BPTT (2) kernel:
 // lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
 extern "C" int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
     if (!whh || !wpk) return LV_ERR_ARG;
     if (H != PH) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
     const dim3 grid((unsigned)lv_cdiv(128L * PKS * 2 * 64, 256)), block(256);      // every image: 128 x 32 x 2 x 64 uint4
-    if (backward == 2) LV_LAUNCH(pack_w_persist_bwd_rs_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    if (backward == 3) LV_LAUNCH(pack_w_persist_ks_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    else if (backward == 2) LV_LAUNCH(pack_w_persist_bwd_rs_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else if (backward) LV_LAUNCH(pack_w_persist_bwd_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else LV_LAUNCH(pack_w_persist_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     LV_CHECK_LAUNCH();
@@ -840,6 +1042,30 @@ extern "C" int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float
     const int R = (B + PGROUPS - 1) / PGROUPS;
     PersistFwdP p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
     LV_LAUNCH_RESIDENT(lstm_fwd_persist_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// The same forward recurrence in its K-split form (weights packed with backward = 3; red LDS tile needs a 16-byte aligned gx).
+// Forward recurrence in one persistent launch.  Arguments as lv_lstm_fwd_bf16_ug (gx unit-major) with W_hh replaced by
+// its packed image (lv_lstm_persist_pack(..., backward = 0)), an exchange buffer and a device status word (0 = ok;
+// written non-zero if a hand-off timed out).
+extern "C" int lv_lstm_fwd_bf16_persist_ks(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
+                                        const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
+                                        int T, int B, int H, void* stream) {
+    if (!gx || !wpk || !hs || !cs || !gates || !xch || !status) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (dmask && !hdrop) return LV_ERR_ARG;
+    if (H != PH || B > PRMAX * PGROUPS) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // all 256 workgroups must be resident at once
+    if (T == 0) return LV_OK;
+    gran_t* hx = reinterpret_cast<gran_t*>(xch);
+    hipMemsetAsync(hx, 0, (size_t)XCH_FWD_BYTES, (hipStream_t)stream);
+    const int R = (B + PGROUPS - 1) / PGROUPS;
+    PersistFwdP p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, dmask, dscale, hdrop, hx, status, T, B, R};
+    LV_LAUNCH_RESIDENT(lstm_fwd_persist_ks_kernel, dim3(PGROUPS * PMEMBERS), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

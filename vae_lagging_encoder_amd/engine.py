@@ -237,6 +237,9 @@ _PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
 # hand-off of the persistent BPTT: "rs" = reduce-scatter of partial dh sums (2048 granules per workgroup and timestep),
 # "ag" = all-gather of dG (8192); read when the weight images are packed
 PERSIST_BWD_FORM = "rs"
+# product of the persistent forward: "ks" = contraction split over the workgroup's waves (4x4x4 MFMA, barrier after the product),
+# "cols" = gate columns split over the waves (16x16x32 MFMA, barrier before the product)
+PERSIST_FWD_FORM = "ks"
 _PERSIST_MAX_B = 64
 
 
@@ -290,7 +293,8 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
             wi.fwd, wi.bwd = c.f32(n), c.f32(n)
             wi.xch = c.f32(lib.lv_lstm_persist_xch_floats())
             wi.status = torch.zeros(1, dtype=torch.int32, device=device)
-        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 0, H, s)
+        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 3 if PERSIST_FWD_FORM == "ks" else 0, H, s)
+        wi.fwd_form = PERSIST_FWD_FORM
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 2 if PERSIST_BWD_FORM == "rs" else 1, H, s)
         wi.bwd_form = PERSIST_BWD_FORM
         wi.packed = True
@@ -307,7 +311,8 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
     elif _persistent_ok(eng, img, B, H, device, _PERSIST_MAX_B):
         wi = eng._wimg          # packed by _weight_images(want_persist=True) at the top of the forward
-        lib.lv_lstm_fwd_bf16_persist(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
+        fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
+        fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
