@@ -1,27 +1,33 @@
-// lv_lstm_persist.hip -- the LSTM forward recurrence as ONE persistent launch (bf16 recurrent operands, H = 1024).
+// lv_lstm_persist.hip -- the LSTM recurrences as ONE persistent launch each (bf16 recurrent operands, H = 1024).
 //
 // lv_lstm.hip pays one kernel boundary per timestep and re-reads its slice of W_hh from L2 / Infinity Cache every step
-// (measured: ~4.1 us per forward step, of which ~1 us is useful work).  Here the chip is cut along its XCDs instead:
+// (measured: ~4.5 us per forward step, 7.7 us per BPTT step).  Here the chip is cut along its XCDs instead:
 //
 //   * 256 workgroups, one per CU, in 8 groups of 32 (group = blockIdx % 8: one XCD under the usual round-robin
 //     placement -- only speed depends on that, never correctness).  A group owns a slice of the BATCH (rows
-//     [g*R, g*R+R), R = ceil(B/8) <= 8) and carries it through all T steps on its own; groups never talk.
-//   * inside a group the 4H gate columns are split 128 ways: a wave owns 8 hidden units = 32 gate columns and keeps
-//     its 32 x 1024 slice of W_hh in REGISTERS for the whole call (64 KB = 256 VGPRs per lane; one wave per SIMD), so
+//     [g*R, g*R+R), R = ceil(B/8)) and carries it through all T steps on its own; groups never talk.
+//   * every wave keeps its 64 KB slice of W_hh in REGISTERS for the whole call (256 VGPRs per lane; one wave per SIMD), so
 //     after the prologue no weight byte moves again.
-//   * per step the only traffic is the hand-off of h_t inside the group: R x 1024 bf16 published as 8-byte
-//     {2 x bf16, tag} granules with agent-scope relaxed 64-bit stores (write-through) and gathered by polling the
-//     tags -- each of a workgroup's 4 waves gathers a quarter into LDS.  profiles/microbench/xcd_gather_probe.hip
-//     measures this exchange at 1.7 us per step (8 KB per group), against 4.1 us for a launch-per-step.
-//   * a wave's MFMA output is exactly the gate pre-activations of its own units, so sigma/tanh, the cell update, the
-//     gate records for BPTT and the decoder's output dropout run in its epilogue as in lstm_step_fwd_kernel; the cell
-//     state never leaves the owning lane's registers.
+//   * per step the only traffic is a hand-off inside the group, as 8-byte tagged granules written with agent-scope relaxed
+//     64-bit stores (write-through) and read by polling the tags: no fences, no flags -- the tag travels with the data.
+//
+// Four kernels (the K-split forward and the reduce-scatter BPTT are the defaults; the other two are kept for A/B and tests):
+//   lstm_fwd_persist_kernel     forward, gate COLUMNS split over the waves: all-gather of h_t ({2 x bf16, tag} granules, 2048
+//                               per workgroup and step at R = 4) into an LDS image, barrier, 64 x v_mfma_f32_16x16x32_bf16.
+//   lstm_fwd_persist_ks_kernel  forward, CONTRACTION split over the waves: each wave gathers only its K quarter and multiplies
+//                               it at once (128 x v_mfma_f32_4x4x4_16b_bf16), the quarter products meet after one barrier.
+//   lstm_bwd_persist_kernel     BPTT, all-gather of dG[t] (4 gate gradients per unit: 8192 granules per workgroup and step).
+//   lstm_bwd_persist_rs_kernel  BPTT, reduce-scatter: a workgroup multiplies ITS units' dG with its 128 gate rows of W_hh and
+//                               sends every workgroup the partial sums of the 32 units it owns ({2 x 28-bit float, tag}
+//                               granules): 2048 granules received per workgroup and step, contraction on the 4x4x4 MFMA.
+//   Measured per timestep at B = 32 (R = 4): 3.15 / 3.06 / 5.32 / 3.0 us.
 //
 // Every spin is bounded: a workgroup that waits longer than ~1 s raises *status and the whole launch drains.
-// Requirements (else LV_ERR_UNSUPPORTED and the caller uses the launch-per-step kernels): H == 1024, B <= 64,
-// a 256-CU device (all 256 workgroups must be resident at once), gx in unit-major column order.
+// Requirements (else LV_ERR_UNSUPPORTED and the caller uses the launch-per-step kernels): H == 1024, B <= 64 (forward) /
+// 32 (BPTT), a 256-CU device (all 256 workgroups must be resident at once), gx in unit-major column order.
 // The packed weight images are built by lv_lstm_persist_pack and passed in: a caller whose weights do not change between
-// calls (the decoder during the aggressive inner loop) packs once.
+// calls (the decoder during the aggressive inner loop) packs once.  The same sources run on the CPU emulator with every
+// workgroup live as fibers (tests/emu): LV_LAUNCH_RESIDENT / LV_BLOCK_SHARED / lv_agent_* in lv_device.h.
 #include "lv_device.h"
 
 namespace {
