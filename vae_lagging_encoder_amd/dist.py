@@ -62,6 +62,8 @@ class GradSync(object):
         self.decoder = decoder
         self._inv = None
         self._h_dec = None
+        self._h_rs = None         # reduce-scatter issued early by start_decoder()
+        self._rs_tmp = None
         self._shard = None
         self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
 
@@ -76,11 +78,29 @@ class GradSync(object):
                 and dec_flat.grad_padded.numel() % self.world == 0)
 
     def start_decoder(self, dec_flat, update="encoder"):
-        """Issue the decoder-gradient all-reduce as soon as the decoder's backward has been queued: RCCL runs it on
-        its own stream underneath the encoder's BPTT (strict mode, full all-reduce only).  Completed by sync()."""
-        if self.world == 1 or self.mode != "strict" or self._norm_only(dec_flat, update):
+        """Issue the decoder-gradient exchange (strict mode) once the decoder's backward has been queued: RCCL runs it on its
+        own stream, behind everything queued on the compute stream so far and beside what is queued afterwards (the
+        encoder's backward, or its weight-gradient GEMMs when the BPTT is a persistent launch).  Completed by sync()."""
+        if self.world == 1 or self.mode != "strict":
+            return
+        if self._norm_only(dec_flat, update):
+            self._h_rs = self._reduce_scatter(dec_flat, update, async_op=True)
             return
         self._h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _reduce_scatter(self, dec_flat, update, async_op):
+        """Reduce-scatter of the (padded) decoder gradient into this rank's shard; returns a waitable handle or None."""
+        src = dec_flat.grad_padded
+        n = src.numel() // self.world
+        self.ss_handle(dec_flat, update)
+        if dist.get_backend(self.group) == "gloo":
+            # gloo has no reduce-scatter: the CPU tests take the shard out of an all-reduced copy (same sums)
+            self._rs_tmp = src.clone()
+            h = dist.all_reduce(self._rs_tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            self._rs_slice = (self.rank * n, (self.rank + 1) * n)
+            return h
+        self._rs_tmp = None
+        return dist.reduce_scatter_tensor(self._shard, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def sync(self, enc_flat, dec_flat, update="encoder"):
         """Exchange the gradients of one step.  Returns None when both buffers now hold the global mean gradient, or a
@@ -92,17 +112,16 @@ class GradSync(object):
         lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
         ss = None
         if self._norm_only(dec_flat, update):
-            src = dec_flat.grad_padded
-            n = src.numel() // self.world
-            self.ss_handle(dec_flat, update)
+            n = dec_flat.grad_padded.numel() // self.world
+            h_rs, self._h_rs = self._h_rs, None
+            if h_rs is None and self._rs_tmp is None:
+                h_rs = self._reduce_scatter(dec_flat, update, async_op=True)      # not started early (hipGraph split, direct callers)
             h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if dist.get_backend(self.group) == "gloo":
-                # gloo has no reduce-scatter: the CPU tests take the shard out of an all-reduced copy (same sums)
-                tmp = src.clone()
-                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
-                self._shard.copy_(tmp[self.rank * n:(self.rank + 1) * n])
-            else:
-                dist.reduce_scatter_tensor(self._shard, src, op=dist.ReduceOp.SUM, group=self.group)
+            if h_rs is not None:
+                h_rs.wait()
+            if self._rs_tmp is not None:
+                self._shard.copy_(self._rs_tmp[self._rs_slice[0]:self._rs_slice[1]])
+                self._rs_tmp = None
             lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
             lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
             dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)

@@ -516,8 +516,11 @@ class LSTMEncoderEngine(object):
         self.last = (x, B, T, self.gen)
         return w.mulv
 
-    def backward(self, dmulv, gen=None, head=None):
+    def backward(self, dmulv, gen=None, head=None, after_bptt=None):
         """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics).
+
+        after_bptt: called once the BPTT recurrence has been queued (data parallel: the point where a collective can be issued
+        so that it starts behind the persistent launch and runs under the weight-gradient GEMMs that follow).
 
         head = (eps, dz [parts][B][ns][nz], parts, dkl [B]) instead of dmulv: the backward of reparameterise + KL runs in
         the head's launch (fused driver; dmulv is then produced into the workspace)."""
@@ -548,6 +551,8 @@ class LSTMEncoderEngine(object):
         img = self._b16(B, T)
         with _prof("lstm_bwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_BWD_MAX_B) else 2 * T):
             _lstm_backward(self, lib, s, img, w, None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), None, None, 0, T, B, H, x.device)
+        if after_bptt is not None:
+            after_bptt()
         # input-side grads
         if img is not None:
             img.backward(lib, s, None, P(w.hs), P(self._wimg.WT), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))

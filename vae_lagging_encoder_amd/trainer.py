@@ -119,14 +119,25 @@ class AggressiveTextTrainer(object):
         lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
                                  self._s(5), T - 1, B, s)
         dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
-        if self.grad_sync is not None and not self._capturing and not (self.enc.persistent and self.enc.precision == "bf16"):
-            # data parallel: the decoder-gradient all-reduce (149 MB) starts now and runs under the encoder's backward.
-            # Not beside a PERSISTENT encoder BPTT: that launch needs every CU resident at once, and compute units held
-            # by the collective's kernels would leave part of its grid spinning -- both reductions then go out in sync().
-            self.dec.join()
-            self.grad_sync.start_decoder(self.dec.flat, self._update)
-        self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl))
+        hook = None
+        if self.grad_sync is not None and not self._capturing:
+            def start():
+                # data parallel: the decoder-gradient exchange (149 MB all-reduce, or 75 MB reduce-scatter when only its norm
+                # is needed) is issued as soon as it can run beside ordinary kernels
+                self.dec.join()
+                self.grad_sync.start_decoder(self.dec.flat, self._update)
+            if self._collective_after_bptt():
+                # not beside a PERSISTENT encoder BPTT (that launch needs every CU resident at once): issued right after the
+                # BPTT has been queued, so the collective starts behind it and runs under the encoder's weight-gradient GEMMs
+                hook = start
+            else:
+                start()                   # step kernels: the collective runs under the whole encoder backward
+        self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl), after_bptt=hook)
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
+
+    def _collective_after_bptt(self):
+        """True when the encoder's BPTT may be a persistent launch: a collective must then not be in flight beside it."""
+        return bool(self.enc.persistent and self.enc.precision == "bf16")
 
     def _clip_and_step(self, update, dec_ss=None):
         lib, s = self.lib, _eng.stream_ptr(self.device)
