@@ -33,6 +33,23 @@ static inline f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) { return l
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
 #define LV_WAIT_VMEM() do { } while (0)
+static inline uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {            // lane map: see the HIP definition below
+    auto& w = lv_emu::my_wave();
+    const int l = lv_emu::lane();
+    uint64_t blk;
+    memcpy(&blk, lds_ptr, 8);
+    w.u[l] = blk;
+    lv_emu::wave_sync();
+    uint16_t o[4];
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t b = w.u[(l & ~15) + 4 * j + ((l & 15) >> 2)];
+        o[j] = (uint16_t)(b >> (16 * (l & 3)));
+    }
+    lv_emu::wave_sync();
+    uint2 r;
+    memcpy(&r, o, 8);
+    return r;
+}
 // IEEE binary16 <-> f32 in software (round-to-nearest-even, as v_cvt_f16_f32 does): g++ 11 has no _Float16
 static inline uint16_t lv_f32_to_f16_bits(float x) {
     uint32_t u;
@@ -145,6 +162,15 @@ __device__ __forceinline__ void lv_glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// ds_read_b64_tr_b16 (LDS transpose read), lane map measured with profiles/microbench/ds_read_tr_probe.hip: inside each group
+// of 16 lanes every lane r supplies the address of FOUR consecutive 16-bit elements, a 16 x 4 matrix Mx[r][c]; lane i receives
+// out[j] = Mx[4j + (i >> 2)][i & 3].  Pointing lane r at T[k0 + (r >> 2)][m0 + 4 (r & 3)] of a row-major [k][m] tile therefore
+// gives lane i the four elements T[k0 + j][m0 + i]: a K-contiguous MFMA fragment out of an M-contiguous image.
+typedef short lv_s16x4_lds __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {
+    lv_s16x4_lds v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lv_s16x4_lds*)lds_ptr);
+    return *reinterpret_cast<uint2*>(&v);
+}
 // IEEE binary16 <-> f32 (v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even)
 __device__ __forceinline__ uint16_t lv_f32_to_f16_bits(float x) {
     const _Float16 h = (_Float16)x;

@@ -322,7 +322,12 @@ template <> struct SecondPair<true> { int unused; };
 // for long K loops (dO: 384 vs 478 us).  SINGLE = true: one pair (32 KB, 3 workgroups per CU), load -> barrier -> MFMA ->
 // barrier with the other workgroups hiding the transfer -- best when a workgroup only sees a few K tiles and prologue /
 // epilogue dominate (Gx, K = 512: 55 vs 63 us; dX under split-K: 55 vs 60 us).  Measured: profiles/r02e_gemm_shapes.txt.
-template <bool SINGLE, bool NLL = false>
+// TN = true (weight gradients: A stored [K][M], M-contiguous): the A tile arrives by the same DMA as [64 k][16 slots of 8 m] --
+// a wave instruction fills 4 k rows of 256 B -- with the 16-byte slots of row k permuted by s ^ 2(k & 3) on the source side,
+// and the K-contiguous MFMA fragment is taken out of that M-contiguous image by ds_read_b64_tr_b16 (two per fragment; the 16
+// addresses of a lane group are 4 k rows x 32 contiguous bytes, on distinct banks thanks to the permutation).  The
+// register-staged lv_gemm_b16_kernel<false> did this transposition with 16 integer ops per 8 x 4 block (dW_pred: 464 us).
+template <bool SINGLE, bool NLL = false, bool TN = false>
 __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
     // separate LDS objects per buffer: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove
     // disjoint (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
@@ -375,12 +380,20 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
         if (rb > p.N - 1) rb = p.N - 1;                // that are never written
         ga[i] = p.A + (long)ra * p.lda + kch[i];
         gb[i] = p.B + (long)rb * p.ldb + kch[i];
+        if constexpr (TN) {
+            // A stored [K][M]: this lane fetches, for k row 4(4w + i) + (l >> 4) of a tile, the 8 m values of slot l & 15
+            const int krow = 4 * (4 * w + i) + (l >> 4);
+            long mc = m0 / 8 + ((l & 15) ^ (2 * (krow & 3)));
+            if (mc > p.lda / 8 - 1) mc = p.lda / 8 - 1;             // clamped inside the row pitch: such m only reach unwritten C rows
+            ga[i] = p.A + (long)krow * p.lda + 8 * mc;
+        }
     }
     auto stage_dma = [&](int kt, LdsTile& Ad, LdsTile& Bd) {        // a complete K tile: LDS-DMA
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            lv_glds16(ga[i] + k0, &Ad[8 * (4 * w + i)][0]);
+            if constexpr (TN) lv_glds16(ga[i] + (long)k0 * p.lda, reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (4 * w + i));
+            else lv_glds16(ga[i] + k0, &Ad[8 * (4 * w + i)][0]);
             lv_glds16(gb[i] + k0, &Bd[8 * (4 * w + i)][0]);
         }
     };
@@ -391,7 +404,13 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
             const int row = 8 * (4 * w + i) + (l >> 3);
             const int k = k0 + kch[i];
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-            Ad[row][l & 7] = k < p.K ? load_chunk_masked(ga[i] + k0, p.K - k) : z4;
+            if constexpr (TN) {
+                const int krow = 4 * (4 * w + i) + (l >> 4);
+                reinterpret_cast<uint4*>(&Ad[0][0])[64 * (4 * w + i) + l] =
+                    k0 + krow < p.K ? *reinterpret_cast<const uint4*>(ga[i] + (long)k0 * p.lda) : z4;
+            } else {
+                Ad[row][l & 7] = k < p.K ? load_chunk_masked(ga[i] + k0, p.K - k) : z4;
+            }
             Bd[row][l & 7] = k < p.K ? load_chunk_masked(gb[i] + k0, p.K - k) : z4;
         }
     };
@@ -401,11 +420,32 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
     const int bx0 = (brow >> 1) & 7, bx1 = ((brow + 32) >> 1) & 7;
     // 16 MFMAs over the K tile in (Ac, Bc), then the hand-over: this wave's DMA into the other pair has landed
     // (vmcnt(0)), everybody's has and everybody is done reading this pair (barrier)
+    // TN: byte offset, inside the [64 k][256 B] image, of the 8 bytes this lane supplies to the transpose read of A fragment i2
+    // at k-step 0, first half: k row 8 lh + (r >> 2), m = wm*64 + 32 i2 + 16 (lane group & 1) + 4 (r & 3), r = l & 15
+    int atr[2] = {0, 0};
+    if constexpr (TN) {
+        const int r = l & 15, kr = r >> 2;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int mloc = wm * 64 + 32 * i2 + 16 * ((l >> 4) & 1) + 4 * (r & 3);
+            atr[i2] = (8 * lh + kr) * 256 + (((mloc >> 3) ^ (2 * kr)) * 16) + (mloc & 7) * 2;
+        }
+    }
+    auto a_frag = [&](LdsTile& Ac, int ks, int i2) -> uint4 {
+        if constexpr (TN) {
+            const char* base = reinterpret_cast<const char*>(&Ac[0][0]) + atr[i2] + ks * 16 * 256;
+            const uint2 lo = lv_ds_read_tr16_b64(base), hi = lv_ds_read_tr16_b64(base + 4 * 256);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            const int c = 2 * ks + lh;
+            return i2 ? Ac[arow + 32][c ^ ax1] : Ac[arow][c ^ ax0];
+        }
+    };
     auto mma_tile = [&](LdsTile& Ac, LdsTile& Bc, bool hand_over = true) {
         uint4 fa[2][2], fb[2][2];
         {
             const int c = lh;
-            fa[0][0] = Ac[arow][c ^ ax0]; fa[0][1] = Ac[arow + 32][c ^ ax1];
+            fa[0][0] = a_frag(Ac, 0, 0); fa[0][1] = a_frag(Ac, 0, 1);
             fb[0][0] = Bc[brow][c ^ bx0]; fb[0][1] = Bc[brow + 32][c ^ bx1];
         }
 #pragma unroll
@@ -413,7 +453,7 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < BK / 16) {
                 const int c = 2 * (ks + 1) + lh;
-                fa[nxt][0] = Ac[arow][c ^ ax0]; fa[nxt][1] = Ac[arow + 32][c ^ ax1];
+                fa[nxt][0] = a_frag(Ac, ks + 1, 0); fa[nxt][1] = a_frag(Ac, ks + 1, 1);
                 fb[nxt][0] = Bc[brow][c ^ bx0]; fb[nxt][1] = Bc[brow + 32][c ^ bx1];
             }
 #pragma unroll
@@ -653,7 +693,9 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     splits = lv_cdiv(nk, p.kt_per_split);
     p.splits = splits;
     dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
-    if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
+    if (transA && LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<false, false, true>), grid, block, 0, stream, p);
+    else if (transA && LV_B16_GLDS) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, false, true>), grid, block, 0, stream, p);
+    else if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
     else if (LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<false>, grid, block, 0, stream, p);
     else if (LV_B16_GLDS) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<true>, grid, block, 0, stream, p);
     else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
