@@ -62,7 +62,10 @@ import ctypes
 libs = {"default": lib}
 alt = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblvae_alt.so")
 if os.path.exists(alt):
-    libs["alt"] = _lib.bind(ctypes.CDLL(alt), alt)
+    try:
+        libs["alt"] = _lib.bind(ctypes.CDLL(alt), alt)      # an A/B build made with build_alt.sh (must be of the same ABI revision)
+    except Exception as e:
+        print("skipping stale A/B library:", str(e)[:80])
 small = [("Gx", 0, TB, 4 * H, ni, X16, ni, Wi16, ni, Gx, 4 * H), ("dX", 0, TB, ni, 4 * H, dG16, 4 * H, WiT16, 4 * H, dX, ni),
          ("dW_ih", 1, 4 * H, ni, TB, dG16, 4 * H, XT16, TB, dWi, ni), ("dW_hh", 1, 4 * H, H, TB, dG16, 4 * H, hT16, TB, dWh, H),
          ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H), ("logits", 0, R, V, H, O16, H, W16, H, logits, ldl)]
