@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void mul_inplace_kernel(float* __restrict__ w,
     if (i < n) w[i] *= m[i];
 }
 
-constexpr int BN_BLOCKS = 512;
+constexpr int BN_BLOCKS = 1024;
 
 // Per-channel column reductions over a [P][C] matrix, stage 1: block blk reduces rows blk, blk+nblk, ... (in groups
 // of 256/CT rows, CT = channels handled per pass) and writes partial[blk][q][c], q = 0,1.

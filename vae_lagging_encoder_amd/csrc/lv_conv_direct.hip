@@ -40,17 +40,24 @@ __global__ __launch_bounds__(256) void conv32_pack_kernel(const float* __restric
 
 // y[n][r][x][co] = sum_{t < ntaps} sum_ci in[n][r + dy_t][x + dx_t][ci] * W_t[ci][co],  (dy_t, dx_t) = (t / k - p, t % k - p),
 // negated when `mirror` (data gradient: the prefix of the mirrored tap order).
-// bn_partial != nullptr: also writes this workgroup's per-channel (sum, sum of squares) of its 112 outputs as
+// bn_partial != nullptr: also writes this workgroup's per-channel (sum, sum of squares) of its outputs as
 // bn_partial[block][2][32] -- the stage-1 partials of the BatchNorm that follows (lv_bn_fwd_partials_f32), saving its pass over y.
+// KS = 1: a workgroup owns 4 image rows, one per wave.  KS = 2: 2 rows, and two waves share a row by splitting the taps (their
+// accumulators meet in LDS): twice the workgroups of half the MFMA time each.  The work is MFMA-bound and a wave-row is its
+// indivisible unit; at the benchmark's 50 images 1400 units on 1024 SIMDs take 2 rounds, 2800 half units take 3 half rounds.
+template <int KS>
 __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
                                                             int mirror, int accumulate) {
-    __shared__ __attribute__((aligned(16))) float halo[(TR + KMAX - 1) * (IW + KMAX - 1) * PP];
-    __shared__ float sstat[4][2][CC];
+    constexpr int TRW = TR / KS;         // image rows per workgroup
+    __shared__ __attribute__((aligned(16))) float halo[(TRW + KMAX - 1) * (IW + KMAX - 1) * PP];
+    __shared__ float sstat[TRW][2][CC];
+    __shared__ float red[KS == 2 ? TRW * 16 * 64 : 1];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
-    const int n = (int)blockIdx.x / (IH / TR), r0 = ((int)blockIdx.x % (IH / TR)) * TR;
-    const int p = k / 2, HW = IW + 2 * p, HR = TR + 2 * p;
-    // stage rows r0-p .. r0+TR-1+p, columns -p .. IW-1+p (zero outside the image): all of a thread's loads first (in flight
+    const int wr = w % TRW, wk = w / TRW;                    // this wave's row of the tile and its share of the taps
+    const int n = (int)blockIdx.x / (IH / TRW), r0 = ((int)blockIdx.x % (IH / TRW)) * TRW;
+    const int p = k / 2, HW = IW + 2 * p, HR = TRW + 2 * p;
+    // stage rows r0-p .. r0+TRW-1+p, columns -p .. IW-1+p (zero outside the image): all of a thread's loads first (in flight
     // together), then the LDS writes -- a load -> store loop would pay one memory round trip per iteration
     {
         float4 hv[HALO_F4];
@@ -75,6 +82,8 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int px = (l & 31) < IW ? (l & 31) : IW - 1;        // lanes 28..31 shadow pixel 27: their rows of the result are dropped
     const int kh = l >> 5;
+    const int t_lo = wk == 0 ? 0 : (ntaps + 1) / 2;          // KS = 1: all taps
+    const int t_hi = (KS == 1 || wk == 1) ? ntaps : (ntaps + 1) / 2;
     // the tap's weight fragment comes from L2 (4 KB per tap, shared by every workgroup): two register sets, the fetch of tap
     // t + 1 issued (and pinned there: the scheduler would sink it below the MFMAs) before tap t multiplies
     auto fetch_b = [&](float (&b)[16], int t) {
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     auto tap = [&](const float (&b)[16], int t) {
         int dy = t / k - p, dx = t % k - p;
         if (mirror) { dy = -dy; dx = -dx; }
-        const float* a = &halo[((w + p + dy) * HW + (px + p + dx)) * PP + 16 * kh];
+        const float* a = &halo[((wr + p + dy) * HW + (px + p + dx)) * PP + 16 * kh];
         const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
         const float4 a2 = *reinterpret_cast<const float4*>(a + 8), a3 = *reinterpret_cast<const float4*>(a + 12);
         const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
@@ -93,9 +102,9 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
         for (int s = 0; s < 16; ++s) acc = lv_mfma_32x32x2(av[s], b[s], acc);
     };
     float b0[16], b1[16];
-    fetch_b(b0, 0);
-    int t = 0;
-    for (; t + 1 < ntaps; t += 2) {
+    fetch_b(b0, t_lo);
+    int t = t_lo;
+    for (; t + 1 < t_hi; t += 2) {
         fetch_b(b1, t + 1);
         LV_SCHED_BARRIER();
         tap(b0, t);
@@ -105,30 +114,53 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
         tap(b1, t + 1);
         LV_SCHED_BARRIER();
     }
-    if (t < ntaps) tap(b0, t);
-    const int r = r0 + w;
+    if (t < t_hi) tap(b0, t);
+    if constexpr (KS == 2) {             // the two tap halves of a row meet in LDS
+        if (wk == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wr * 16 + e) * 64 + l] = acc[e];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[(wr * 16 + e) * 64 + l];
+        }
+    }
+    const int r = r0 + wr;
     const int col = l & 31;
     float st0 = 0.f, st1 = 0.f;
+    if (wk == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-        if (x < IW) {
-            float* o = out + (((long)n * IH + r) * IW + x) * CC + col;
-            const float v = accumulate ? *o + acc[e] : acc[e];
-            *o = v;
-            st0 += v; st1 += v * v;
+        for (int e = 0; e < 16; ++e) {
+            const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            if (x < IW) {
+                float* o = out + (((long)n * IH + r) * IW + x) * CC + col;
+                const float v = accumulate ? *o + acc[e] : acc[e];
+                *o = v;
+                st0 += v; st1 += v * v;
+            }
         }
     }
     if (bn_partial) {
         st0 += __shfl_xor(st0, 32, 64);
         st1 += __shfl_xor(st1, 32, 64);
-        if (l < 32) { sstat[w][0][l] = st0; sstat[w][1][l] = st1; }
+        if (wk == 0 && l < 32) { sstat[wr][0][l] = st0; sstat[wr][1][l] = st1; }
         __syncthreads();
         if (tid < 2 * CC) {
             const int q = tid / CC, c = tid % CC;
-            bn_partial[((long)blockIdx.x * 2 + q) * CC + c] = ((sstat[0][q][c] + sstat[1][q][c]) + sstat[2][q][c]) + sstat[3][q][c];
+            float tsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TRW; ++i) tsum += sstat[i][q][c];
+            bn_partial[((long)blockIdx.x * 2 + q) * CC + c] = tsum;
         }
     }
+}
+
+// tap split (KS = 2) only where it shortens the schedule: wave-rows on 1024 SIMDs, rounds x time per unit
+static inline int conv32_ks(int N) {
+    const long units = (long)N * IH;                         // wave-rows
+    const long r1 = (units + 1023) / 1024 * 2, r2 = (2 * units + 1023) / 1024;       // in half units of time
+    return r2 < r1 ? 2 : 1;
 }
 
 // weight gradient, stage 1.  grid (slabs, G tap groups), G = 4 / 2 / 1 for k = 7 / 5 / 3; slab = a contiguous range of 4-row
@@ -292,19 +324,26 @@ extern "C" int lv_conv32_f32(const float* in, const float* wp, float* out, int N
     if (!in || !wp || !out) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
-    LV_LAUNCH(conv32_direct_kernel, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps, mirror,
-              accumulate);
+    if (conv32_ks(N) == 2)
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
+                  mirror, accumulate);
+    else
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
+                  mirror, accumulate);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
 // forward convolution that also leaves the following BatchNorm's stage-1 partials: bn_partial [lv_conv32_blocks(N)][2][32]
-extern "C" int lv_conv32_blocks(int N) { return N * (IH / TR); }
+extern "C" int lv_conv32_blocks(int N) { return N * (IH / (TR / conv32_ks(N))); }
 extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream) {
     if (!in || !wp || !out || !bn_partial) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
-    LV_LAUNCH(conv32_direct_kernel, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
+    if (conv32_ks(N) == 2)
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
+    else
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -26,7 +26,7 @@ class Act(object):
         return self.N * self.H * self.W
 
 
-_BN_MAX_BLOCKS = 512          # partial blocks a BN workspace holds (lv_bn_workspace_floats)
+_BN_MAX_BLOCKS = 1024         # partial blocks a BN workspace holds (lv_bn_workspace_floats)
 
 
 def pack_conv32(lib, s, ent):
