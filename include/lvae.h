@@ -304,6 +304,13 @@ int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*
 int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed, int accumulate,
                    void* stream);
 long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
+/* All weight-gradient reductions of a backward pass in one launch: lv_conv32_wgrad_f32 / lv_conv1x1_wgrad_f32 called with
+ * dw = NULL leave their partial blocks in ws (lv_conv32_wgrad_parts / lv_conv1x1_wgrad_parts of them), and
+ * lv_wgrad_reduce_batched sums every layer's partials into its gradient.  desc (HOST memory): 4 int64 per layer =
+ * {ws pointer, dw pointer, outputs | parts << 32, k*k (32 -> 32 convolution) or 0 (pointwise)}. */
+int lv_conv32_wgrad_parts(int N, int k);
+int lv_conv1x1_wgrad_parts(long P);
+int lv_wgrad_reduce_batched(const long long* desc, int ndesc, void* stream);
 /* Forward convolutions that also leave the stage-1 partials (per-workgroup per-channel sum and sum of squares of their
  * outputs, [blocks][2][Cout]) of the nn.BatchNorm2d that follows them in PixelCNNBlock (dec_pixelcnn_v2.py:41-52), consumed
  * by lv_bn_fwd_partials_f32: the normalisation's statistics pass over the activation is saved. */

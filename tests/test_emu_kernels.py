@@ -198,3 +198,7 @@ def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
 
 def test_dropout_folded_into_image_conversion(emu_backend):
     K.test_dropout_folded_into_image_conversion(emu_backend, CPU, 5, 3, 70)
+
+
+def test_wgrad_reduce_batched(emu_backend):
+    K.test_wgrad_reduce_batched(emu_backend, CPU)

@@ -1070,3 +1070,43 @@ def test_dropout_folded_into_image_conversion(lib, hip_device, T, B, C):
     x = h.clone().to(dev)
     lib.lv_keep_scale_f32(P(x), P(kd), 2.0, T, B, C, _s(dev))
     assert torch.equal(x.cpu(), h * ktm)
+
+
+def test_wgrad_reduce_batched(lib, hip_device):
+    """lv_wgrad_reduce_batched: the stage-2 reductions of several layers (32 -> 32 k x k and pointwise) in one launch give what
+    the per-layer entries give (same partials; pointwise bit for bit, k x k up to f32 summation order)."""
+    import ctypes
+    dev = hip_device
+    g = torch.Generator().manual_seed(11)
+    N = 9
+    layers, desc = [], []
+    for k in (3, 5):
+        x = torch.randn(N * 784, 32, generator=g).to(dev)
+        dy = torch.randn(N * 784, 32, generator=g).to(dev)
+        ws = torch.empty(lib.lv_conv32_wgrad_ws_floats(N, k), device=dev)
+        ref = torch.empty(32, 32, k, k, device=dev)
+        lib.lv_conv32_wgrad_f32(P(x), P(dy), P(ref), P(ws), N, k, 0, _s(dev))
+        ws2 = torch.full_like(ws, float("nan"))
+        lib.lv_conv32_wgrad_f32(P(x), P(dy), None, P(ws2), N, k, 0, _s(dev))
+        out = torch.full((32, 32, k, k), float("nan"), device=dev)
+        layers.append((ref, out, False, (x, dy, ws2)))
+        desc += [ws2.data_ptr(), out.data_ptr(), (k * k * 1024) | (lib.lv_conv32_wgrad_parts(N, k) << 32), k * k]
+    for Cin, Cout in ((64, 32), (32, 64)):
+        Pn = N * 784
+        x = torch.randn(Pn, Cin, generator=g).to(dev)
+        dy = torch.randn(Pn, Cout, generator=g).to(dev)
+        ws = torch.empty(lib.lv_conv1x1_wgrad_ws_floats(Cin, Cout), device=dev)
+        ref = torch.empty(Cout, Cin, device=dev)
+        lib.lv_conv1x1_wgrad_f32(P(x), P(dy), P(ref), P(ws), Pn, Cin, Cout, 0, _s(dev))
+        ws2 = torch.full_like(ws, float("nan"))
+        lib.lv_conv1x1_wgrad_f32(P(x), P(dy), None, P(ws2), Pn, Cin, Cout, 0, _s(dev))
+        out = torch.full((Cout, Cin), float("nan"), device=dev)
+        layers.append((ref, out, True, (x, dy, ws2)))
+        desc += [ws2.data_ptr(), out.data_ptr(), (Cin * Cout) | (lib.lv_conv1x1_wgrad_parts(Pn) << 32), 0]
+    arr = (ctypes.c_longlong * len(desc))(*desc)
+    lib.lv_wgrad_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(desc) // 4, _s(dev))
+    for ref, out, exact, _ in layers:
+        if exact:
+            assert torch.equal(ref.cpu(), out.cpu())
+        else:
+            assert float((ref - out).abs().max()) < 1e-5 * float(ref.abs().max())

@@ -100,6 +100,9 @@ SIGNATURES = {
     "lv_conv32_wgrad_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_f32": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "lv_conv1x1_wgrad_ws_floats": [_i, _i],
+    "lv_conv32_wgrad_parts": [_i, _i],
+    "lv_conv1x1_wgrad_parts": [_l],
+    "lv_wgrad_reduce_batched": [_vp, _i, _vp],
     "lv_conv32_blocks": [_i],
     "lv_conv32_bnstat_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_blocks": [_l],
@@ -145,7 +148,7 @@ class Lib(object):
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
-                           "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
+                           "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 
     def __getattr__(self, name):

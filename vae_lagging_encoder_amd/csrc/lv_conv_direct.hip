@@ -349,8 +349,14 @@ extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out
 }
 
 // weight gradient over ALL k*k taps: dw [32][32][k*k] (=|+=) sum_pixels dy[p][co] x[p + off_t][ci]; ws: lv_conv32_wgrad_ws_floats
+// partial blocks lv_conv32_wgrad_f32 leaves in ws ([parts][k*k][32 ci][32 co]) -- what lv_wgrad_reduce_batched needs to know
+extern "C" int lv_conv32_wgrad_parts(int N, int k) {
+    const int ntiles = N * (IH / TR);
+    return lv_cdiv(ntiles, lv_cdiv(ntiles, lv_conv32_wgrad_slabs(N, k)));
+}
+// dw == NULL: stage 1 only -- the partials stay in ws for a later lv_wgrad_reduce_batched
 extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, int N, int k, int accumulate, void* stream) {
-    if (!x || !dy || !dw || !ws) return LV_ERR_ARG;
+    if (!x || !dy || !ws) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1)) return LV_ERR_SHAPE;
     if (((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return LV_ERR_ALIGN;
     const int ntiles = N * (IH / TR);
@@ -358,8 +364,9 @@ extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, f
     const int tps = lv_cdiv(ntiles, slabs);
     const int used = lv_cdiv(ntiles, tps);
     LV_LAUNCH(conv32_wgrad_kernel, dim3((unsigned)used, (unsigned)wgrad_groups(k)), dim3(256), 0, stream, x, dy, ws, N, k, tps);
-    LV_LAUNCH(conv32_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)k * k * CC * CC, 256)), dim3(256), 0, stream, (const float*)ws,
-              dw, k * k, used, accumulate);
+    if (dw)
+        LV_LAUNCH(conv32_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)k * k * CC * CC, 256)), dim3(256), 0, stream, (const float*)ws,
+                  dw, k * k, used, accumulate);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -593,14 +600,20 @@ extern "C" int lv_conv1x1_bnstat_f32(const float* in, const float* w, float* out
 extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_PARTS_MAX * Cin * Cout; }
 
 // dw [Cout][Cin] (=|+=) dy^T . x over P pixels; ws: lv_conv1x1_wgrad_ws_floats floats
-extern "C" int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
-                                    void* stream) {
-    if (!x || !dy || !dw || !ws) return LV_ERR_ARG;
-    if (P <= 0) return LV_ERR_SHAPE;
+static inline long conv1x1_wgrad_ppw(long P) {
     // an even number of pixels per wave (a pixel pair per MFMA), at least one batch each, at most PW_PARTS_MAX workgroups
     long ppw = lv_cdiv(P, (long)PW_PARTS_MAX * 8);
     if (ppw < 2 * PW_U) ppw = 2 * PW_U;
-    ppw = (ppw + 1) / 2 * 2;
+    return (ppw + 1) / 2 * 2;
+}
+// partial blocks lv_conv1x1_wgrad_f32 leaves in ws ([parts][Cout][Cin])
+extern "C" int lv_conv1x1_wgrad_parts(long P) { return P > 0 ? (int)lv_cdiv(P, conv1x1_wgrad_ppw(P) * 8) : 0; }
+// dw == NULL: stage 1 only -- the partials stay in ws for a later lv_wgrad_reduce_batched
+extern "C" int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, long P, int Cin, int Cout, int accumulate,
+                                    void* stream) {
+    if (!x || !dy || !ws) return LV_ERR_ARG;
+    if (P <= 0) return LV_ERR_SHAPE;
+    const long ppw = conv1x1_wgrad_ppw(P);
     const int wgs = (int)lv_cdiv(P, ppw * 8);
     const dim3 grid((unsigned)wgs), block(512);
     if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_wgrad_kernel<64, 32>), grid, block, 0, stream, x, dy, ws, P, ppw);
@@ -608,8 +621,86 @@ extern "C" int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, 
     else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_wgrad_kernel<64, 64>), grid, block, 0, stream, x, dy, ws, P, ppw);
     else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_wgrad_kernel<32, 32>), grid, block, 0, stream, x, dy, ws, P, ppw);
     else return LV_ERR_UNSUPPORTED;
-    LV_LAUNCH(conv1x1_wgrad_reduce_kernel, dim3((unsigned)(Cin * Cout / 32)), dim3(256), 0, stream, (const float*)ws, dw, Cin * Cout,
-              wgs, accumulate);
+    if (dw)
+        LV_LAUNCH(conv1x1_wgrad_reduce_kernel, dim3((unsigned)(Cin * Cout / 32)), dim3(256), 0, stream, (const float*)ws, dw, Cin * Cout,
+                  wgs, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// ---- all weight-gradient reductions of a backward pass in ONE launch ------------------------------------------------------
+// The decoder's 23 + 47 stage-2 reductions are 5-9 us launches of a few dozen workgroups each (0.43 ms per Omniglot step);
+// nothing reads the reduced gradients before the clip norm at the end of the backward, so the stage-1 kernels leave their
+// partials in per-layer scratch and one kernel sums them all.  Descriptors travel as kernel arguments (no table in memory, no
+// host-to-device copy: capturable in a hipGraph).  Same sums in the same order as the per-layer kernels.
+namespace {
+constexpr int WB_MAX = 96;
+struct WgradDesc { const float* part; float* dst; int n; int parts; int kk; int pad; };       // kk = 0: pointwise layout; else k*k
+struct WgradBatch { int ndesc; int blk0[WB_MAX + 1]; WgradDesc d[WB_MAX]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WgradBatch bt) {
+    __shared__ __attribute__((aligned(16))) float sred[32][32];
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = bt.ndesc;                     // blk0[lo] <= b < blk0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b >= bt.blk0[mid]) lo = mid; else hi = mid;
+    }
+    const WgradDesc d = bt.d[lo];
+    const int tid = (int)threadIdx.x, f4 = tid & 7, sub = tid >> 3;
+    const long base = (long)(b - bt.blk0[lo]) * 32 + 4 * f4;
+    float4 v[PW_PARTS_MAX / 32];
+#pragma unroll
+    for (int u = 0; u < PW_PARTS_MAX / 32; ++u) {
+        const int part = sub + 32 * u;
+        v[u] = part < d.parts ? *reinterpret_cast<const float4*>(d.part + (long)part * d.n + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s = v[0];
+#pragma unroll
+    for (int u = 1; u < PW_PARTS_MAX / 32; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    *reinterpret_cast<float4*>(&sred[sub][4 * f4]) = s;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += sred[k][tid];
+        const long idx = (long)(b - bt.blk0[lo]) * 32 + tid;
+        if (d.kk == 0) d.dst[idx] = t;
+        else {                                     // partial layout [t][ci][co] -> the reference's [co][ci][t]
+            const int co = (int)(idx % CC), ci = (int)((idx / CC) % CC), tt = (int)(idx / (CC * CC));
+            d.dst[((long)co * CC + ci) * d.kk + tt] = t;
+        }
+    }
+}
+}  // namespace
+
+// desc: 4 x int64 per entry on the HOST: {partials pointer, destination pointer, n (outputs, a multiple of 32) | parts << 32,
+// k*k for a 32 -> 32 convolution (partials [parts][k*k][ci][co], destination [co][ci][k*k]) or 0 (pointwise: both [.][n])}
+extern "C" int lv_wgrad_reduce_batched(const long long* desc, int ndesc, void* stream) {
+    if (ndesc < 0 || (ndesc > 0 && !desc)) return LV_ERR_ARG;
+    for (int i0 = 0; i0 < ndesc; i0 += WB_MAX) {
+        WgradBatch bt;
+        const int m = ndesc - i0 < WB_MAX ? ndesc - i0 : WB_MAX;
+        bt.ndesc = m;
+        int blocks = 0;
+        for (int i = 0; i < m; ++i) {
+            const long long* e = desc + 4L * (i0 + i);
+            WgradDesc& d = bt.d[i];
+            d.part = reinterpret_cast<const float*>((uintptr_t)e[0]);
+            d.dst = reinterpret_cast<float*>((uintptr_t)e[1]);
+            d.n = (int)(e[2] & 0xFFFFFFFFll);
+            d.parts = (int)(e[2] >> 32);
+            d.kk = (int)e[3];
+            d.pad = 0;
+            if (!d.part || !d.dst) return LV_ERR_ARG;
+            if (d.n <= 0 || d.n % 32 != 0 || d.parts <= 0 || d.parts > PW_PARTS_MAX || d.kk < 0 || (d.kk > 0 && d.n != d.kk * CC * CC))
+                return LV_ERR_SHAPE;
+            if ((((uintptr_t)d.part) & 15) != 0) return LV_ERR_ALIGN;
+            bt.blk0[i] = blocks;
+            blocks += d.n / 32;
+        }
+        bt.blk0[m] = blocks;
+        LV_LAUNCH(wgrad_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bt);
+    }
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -48,6 +48,7 @@ class Tape(object):
         self.grads = {}
         self._bn_ws = {}
         self.bn_seen = []              # num_batches_tracked buffers of the BatchNorms run in train mode (bumped once, together)
+        self.wgrad_pending = []        # (partials, gradient view, outputs, parts, k*k) of the direct convolutions: reduced together
         # packed weight images of the direct convolutions, kept across steps by the owning engine and rebuilt when its
         # weights change (the decoder is frozen during the aggressive inner loop, image.py:300-327)
         self.wcache = wcache if wcache is not None else {}
@@ -89,6 +90,23 @@ class Tape(object):
         for fn in reversed(self.back):
             fn()
         self.back = []
+        self.flush_wgrads()
+
+    def flush_wgrads(self):
+        """Sum the weight-gradient partials of every direct convolution of this backward pass in one launch
+        (lv_wgrad_reduce_batched): 70 reductions of a few dozen workgroups each otherwise."""
+        if not self.wgrad_pending:
+            return
+        import ctypes
+        n = len(self.wgrad_pending)
+        desc = (ctypes.c_longlong * (4 * n))()
+        for i, (ws, gview, nout, parts, kk) in enumerate(self.wgrad_pending):
+            desc[4 * i] = ws.data_ptr()
+            desc[4 * i + 1] = gview.data_ptr()
+            desc[4 * i + 2] = nout | (parts << 32)
+            desc[4 * i + 3] = kk
+        self.lib.lv_wgrad_reduce_batched(ctypes.cast(desc, ctypes.c_void_p), n, self.s())
+        self.wgrad_pending = []        # (the stream orders the launch before any reuse of the scratch tensors released here)
 
     # -- ops -----------------------------------------------------------------------------------------------------
     def conv(self, x, weight, gview, stride=1, pad=0, ntaps=None, mask=None, bn_stats=False):
@@ -176,7 +194,8 @@ class Tape(object):
             if dy is None:
                 return
             ws = self.f32(lib.lv_conv32_wgrad_ws_floats(x.N, k))
-            lib.lv_conv32_wgrad_f32(P(x.t), P(dy), P(gview), P(ws), x.N, k, 0, s)
+            lib.lv_conv32_wgrad_f32(P(x.t), P(dy), None, P(ws), x.N, k, 0, s)          # stage 1: partials; reduced in flush_wgrads()
+            self.wgrad_pending.append((ws, gview, k * k * 1024, lib.lv_conv32_wgrad_parts(x.N, k), k * k))
             if x.needs_grad:
                 dx = self.f32(x.P, 32)
                 lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
@@ -201,7 +220,8 @@ class Tape(object):
             if dy is None:
                 return
             ws = self.f32(lib.lv_conv1x1_wgrad_ws_floats(Cin, Cout))
-            lib.lv_conv1x1_wgrad_f32(P(x.t), P(dy), P(gview), P(ws), x.P, Cin, Cout, 0, s)
+            lib.lv_conv1x1_wgrad_f32(P(x.t), P(dy), None, P(ws), x.P, Cin, Cout, 0, s)  # stage 1: partials; reduced in flush_wgrads()
+            self.wgrad_pending.append((ws, gview, Cin * Cout, lib.lv_conv1x1_wgrad_parts(x.P), 0))
             if x.needs_grad:
                 # (accumulating into an existing gradient in the kernel's epilogue was measured slower than a separate vectorised add:
                 # the read-modify-write of 4-byte pieces costs the pointwise kernel 4 us, the add kernel 3)
