@@ -466,15 +466,7 @@ static inline int bn_v4_blocks(long P, int C) {
 }
 // float4 per thread of the apply kernels: every workgroup re-reads all the partials (nblk * 2C floats), so the wider layers
 // use fewer, fatter workgroups
-// Every workgroup of an apply kernel re-reads all the partials (nblk * 2C floats); with many partial blocks (a tap-split
-// convolution leaves 700) that traffic exceeds the activation itself, so the float4 per thread grow until
-// (workgroups x nblk) <= P, i.e. the partial reads stay below one pass over the activation.
-static inline int bn_v4_items(int C, int nblk, long P) {
-    const long n4 = P * (C >> 2);
-    for (int items = 4; items < 16; items *= 2)
-        if (lv_cdiv(n4, 256L * items) * nblk <= P + P / 16) return items;
-    return 16;
-}
+static inline int bn_v4_items(int C) { return C >= 64 ? 8 : 4; }
 static inline unsigned bn_v4_apply_grid(long n4, int items) { return (unsigned)lv_cdiv(n4, 256L * items); }
 
 // rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
@@ -588,22 +580,6 @@ extern "C" int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream
     return LV_OK;
 }
 
-static void bn_apply_fwd_launch(const float* x, const float* partial, int nblk, const float* gamma, const float* beta, const float* res,
-                                int act_elu, float* y, float* mean, float* invstd, float* run_mean, float* run_var, long P, int C,
-                                float eps, float momentum, void* stream) {
-    const int items = bn_v4_items(C, nblk, P);
-    const dim3 grid(bn_v4_apply_grid(P * (C >> 2), items)), block(256);
-    if (items == 16)
-        LV_LAUNCH(bn_apply_fwd_v4_kernel<16>, grid, block, 0, stream, x, partial, nblk, gamma, beta, res, act_elu, y, mean, invstd, run_mean,
-                  run_var, P, C, eps, momentum);
-    else if (items == 8)
-        LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, grid, block, 0, stream, x, partial, nblk, gamma, beta, res, act_elu, y, mean, invstd, run_mean,
-                  run_var, P, C, eps, momentum);
-    else
-        LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, grid, block, 0, stream, x, partial, nblk, gamma, beta, res, act_elu, y, mean, invstd, run_mean,
-                  run_var, P, C, eps, momentum);
-}
-
 extern "C" int lv_bn_workspace_floats(int C) { return BN_BLOCKS * 2 * (C > 0 ? C : 1); }
 
 // BatchNorm2d (train) forward over x [P][C]: batch stats -> mean/invstd (saved), running stats (momentum, unbiased var),
@@ -617,8 +593,12 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                   (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
-        bn_apply_fwd_launch(x, (const float*)ws, nb, gamma, beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum,
-                            stream);
+        if (bn_v4_items(C) == 8)
+            LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
+                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+        else
+            LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
+                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
@@ -643,7 +623,12 @@ extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const 
     if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
     if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
-    bn_apply_fwd_launch(x, partial, nblk, gamma, beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum, stream);
+    if (bn_v4_items(C) == 8)
+        LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
+                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+    else
+        LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
+                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -660,18 +645,12 @@ extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, co
     if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nb);
-        const int items = bn_v4_items(C, nb, P);
-        const dim3 grid(bn_v4_apply_grid(P * (C >> 2), items)), block(256);
-        const float invP = 1.0f / (float)P;
-        if (items == 16)
-            LV_LAUNCH(bn_apply_bwd_v4_kernel<16>, grid, block, 0, stream, x, (const float*)dv, (const float*)ws, nb, mean, invstd, gamma,
-                      dgamma, dbeta, accumulate_param_grads, dx, P, C, invP);
-        else if (items == 8)
-            LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, grid, block, 0, stream, x, (const float*)dv, (const float*)ws, nb, mean, invstd, gamma,
-                      dgamma, dbeta, accumulate_param_grads, dx, P, C, invP);
+        if (bn_v4_items(C) == 8)
+            LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)dv,
+                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
         else
-            LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, grid, block, 0, stream, x, (const float*)dv, (const float*)ws, nb, mean, invstd, gamma,
-                      dgamma, dbeta, accumulate_param_grads, dx, P, C, invP);
+            LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)dv,
+                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
