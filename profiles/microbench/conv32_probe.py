@@ -67,8 +67,9 @@ for N in (50,):
         dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
         ws = torch.empty(lib.lv_bn_workspace_floats(C) + 2 * C, device=dev)
         t_f = timeit(lambda: lib.lv_bn_fwd_f32(P(x), P(g), P(b), P(res), 1, P(y), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1, P(ws), Pn, C, s))
-        t_p = timeit(lambda: lib.lv_bn_fwd_partials_f32(P(x), P(g), P(b), P(res), 1, P(y), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1, P(ws), 350, Pn, C, s))
+        t_p = timeit(lambda: lib.lv_bn_fwd_partials_f32(P(x), P(g), P(b), P(res), 1, P(y), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1, P(ws), 245, Pn, C, s))
+        t_p7 = timeit(lambda: lib.lv_bn_fwd_partials_f32(P(x), P(g), P(b), P(res), 1, P(y), P(mean), P(invstd), P(rm), P(rv), 1e-5, 0.1, P(ws), 700, Pn, C, s))
         t_b = timeit(lambda: lib.lv_bn_bwd_f32(P(x), P(dy), P(y), P(mean), P(invstd), P(g), 1, P(dv), P(dx), P(dg), P(db), 0, P(ws), Pn, C, s))
         mb = Pn * C * 4 / 1e6
-        print("BN C=%d  fwd(2 launches) %5.1f us  fwd from partials %5.1f us (%4.2f TB/s)  bwd(2 launches) %5.1f us (%4.2f TB/s)" %
-              (C, t_f, t_p, 3 * mb / t_p, t_b, 7 * mb / t_b))
+        print("BN C=%d  fwd(2 launches) %5.1f us  fwd from 245 / 700 partial blocks %5.1f / %5.1f us (%4.2f TB/s)  bwd(2 launches) %5.1f us (%4.2f TB/s)" %
+              (C, t_f, t_p, t_p7, 3 * mb / t_p, t_b, 7 * mb / t_b))
