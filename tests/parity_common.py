@@ -539,3 +539,43 @@ def check_pixelcnn_ancestral_sampling(device, B=2):
     decided = margin > 1e-4                                     # pixels whose probability sits on the threshold may go either way
     assert bool(((probs.cpu() >= 0.5).float() == img.cpu())[decided].all())
     vae.train()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a K-step trajectory of the throughput configuration at H = 1024 (persistent recurrences), step by step against the oracle
+def check_bf16_trajectory_h1024(device, K=4, B=32, T=60, V=2003, ni=64, nz=32):
+    """K consecutive inner steps (each on the encoder the previous step left) with the bf16 configuration at the hidden size
+    and batch the persistent LSTM launches are built for, against the f32 oracle fed the same batches and noise: per-step
+    loss / KL / clip norm, and the encoder after K updates.  What a single-step test cannot see is how the bf16 operand
+    rounding of one step feeds the next through the weights."""
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    H = 1024
+    P = O.random_params(V, ni, H, nz, seed=77, scale=0.03, emb_scale=0.3, head_scale=0.2)
+    batches = [O.synthetic_batch(B, T, V, seed=300 + i) for i in range(K)]
+    klw = 0.5
+    Pr = {k: v.clone() for k, v in P.items()}
+    ref = []
+    for i, x in enumerate(batches):
+        eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=400 + i)
+        r = O.inner_step(Pr, x, klw, eps, mi, mo)
+        ref.append((float(r["loss"].sum()), float(r["kl"].sum()), float(r["total_norm"])))
+        Pr.update(r["new_params"])
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+    out = []
+    for i, x in enumerate(batches):
+        eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=400 + i)
+        tr.reset_stats()
+        tr.step(x.to(device), klw, noise=(eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device)))
+        st = tr.read_stats()
+        out.append((st["loss_sum"], st["kl_sum"], st["norm"]))
+    errs = {"loss": max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(out, ref)),
+            "kl": max(abs(a[1] - b[1]) / abs(b[1]) for a, b in zip(out, ref)),
+            "norm": max(abs(a[2] - b[2]) / abs(b[2]) for a, b in zip(out, ref))}
+    sd = vae.state_dict()
+    errs["enc_w"] = max(rel_err(sd[k], Pr[k]) for k in ENC_KEYS)
+    # the update of the whole trajectory, relative to its own size (the weights barely move in K steps)
+    errs["enc_update"] = max(float((sd[k].cpu().double() - Pr[k].double()).abs().max()) /
+                             (float((Pr[k].double() - P[k].double()).abs().max()) + 1e-30) for k in ENC_KEYS)
+    return errs

@@ -226,6 +226,16 @@ def test_bf16_headline_path_at_headline_shape(hip_device):
     assert out["grad_sample_err_over_rms_max"] < 0.1 and out["enc_update_rel_max"] < 2e-2, out
 
 
+def test_bf16_trajectory_at_h1024_tracks_oracle(hip_device):
+    """Four consecutive inner steps of the throughput configuration at H = 1024, B = 32 (persistent K-split forward and
+    reduce-scatter BPTT on a full MI355X) against the f32 oracle: loss within 1e-4 at every step, the encoder within bf16-operand
+    tolerance after four updates."""
+    errs = pc.check_bf16_trajectory_h1024(hip_device)
+    print("bf16 trajectory:", errs)
+    assert errs["loss"] < 1e-4 and errs["norm"] < 2e-3 and errs["kl"] < 5e-3, errs
+    assert errs["enc_w"] < 2e-3 and errs["enc_update"] < 5e-2, errs
+
+
 def test_yahoo_bench_config_against_oracle(hip_device):
     """The bench workload itself (Yahoo dims B=32, T=200, V=20001): ELBO / KL / rec of one fused inner step vs the
     CPU oracle through the reference's ATen ops, <= 1e-4 relative (north_star)."""
