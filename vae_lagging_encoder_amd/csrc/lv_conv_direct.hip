@@ -169,7 +169,7 @@ static inline int conv32_ks(int N) {
 // pair is read from LDS once and reused by the wave's taps; LDS pixel pitch 32 floats puts the two pixels of a pair on disjoint
 // bank halves (conflict-free ds_read_b32).  The next tile's rows are fetched into registers while the current tile is
 // multiplied, so the staging cost is the LDS write only.
-constexpr int WG_TAPS = 4;             // taps per wave at most
+constexpr int WG_TAPS = 7;             // taps per wave at most (each on HALF of a tile's pixels)
 constexpr int WPP = 32;                // LDS pixel pitch of the weight-gradient kernel
 constexpr int WG_HALO_F4 = HALO_F4;
 constexpr int WG_GY_F4 = (TR * IW * (CC / 4) + 255) / 256;
@@ -194,11 +194,12 @@ __device__ __forceinline__ void wgrad_fetch(const float* __restrict__ x, const f
     }
 }
 
-// one staged tile: D_q[ci][co] += x[pixel + off_q][ci] * dy[pixel][co] over the tile's 112 pixels, two per MFMA, NQ taps
+// one staged tile: D_q[ci][co] += x[pixel + off_q][ci] * dy[pixel][co] over rows py0, py0 + 1 of the tile (56 pixels, two per
+// MFMA), NQ taps
 template <int NQ>
-__device__ __forceinline__ void wgrad_tile(const float* halo, const float* gy, int HW, int kp, int ci, const int (&base)[WG_TAPS],
-                                           f32x16 (&acc)[WG_TAPS]) {
-    for (int py = 0; py < TR; ++py) {
+__device__ __forceinline__ void wgrad_tile(const float* halo, const float* gy, int HW, int kp, int ci, int py0,
+                                           const int (&base)[WG_TAPS], f32x16 (&acc)[WG_TAPS]) {
+    for (int py = py0; py < py0 + TR / 2; ++py) {
         const float* hrow = halo + py * HW * WPP;
         const float* grow = gy + (py * IW + kp) * WPP + ci;
 #pragma unroll 7
@@ -212,12 +213,19 @@ __device__ __forceinline__ void wgrad_tile(const float* halo, const float* gy, i
 
 __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dwp, int N, int k, int tiles_per_slab) {
-    __shared__ __attribute__((aligned(16))) float halo[(TR + KMAX - 1) * (IW + KMAX - 1) * WPP];
-    __shared__ __attribute__((aligned(16))) float gy[TR * IW * WPP];
+    constexpr int HALO_N = (TR + KMAX - 1) * (IW + KMAX - 1) * WPP, GY_N = TR * IW * WPP;
+    static_assert(HALO_N + GY_N >= 2 * WG_TAPS * 16 * 64, "the end-of-slab exchange reuses the staging buffers");
+    __shared__ __attribute__((aligned(16))) float lds[HALO_N + GY_N];
+    float* const halo = lds;
+    float* const gy = lds + HALO_N;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int KK = k * k, p = k / 2, HW = IW + 2 * p, HR = TR + 2 * p;
-    const int nw = 4 * (int)gridDim.y;                       // waves that share the taps
-    const int gw = (int)blockIdx.y * 4 + w;
+    // Waves 2j and 2j + 1 of a workgroup share a TAP LANE and split every tile's pixels (rows 0-1 / rows 2-3): a lane's share is
+    // ceil(k*k / lanes) taps on half the pixels, i.e. the tap granularity is halved (k = 7: 7 x 1/2 = 3.5 tap-tiles per wave
+    // against 4 when every wave owns whole taps: 49 taps do not divide by 16 waves).  The two halves meet in LDS at the end.
+    const int nw = 2 * (int)gridDim.y;                       // tap lanes that share the taps
+    const int gw = (int)blockIdx.y * 2 + (w >> 1);
+    const int py0 = (TR / 2) * (w & 1);
     f32x16 acc[WG_TAPS];
 #pragma unroll
     for (int q = 0; q < WG_TAPS; ++q)
@@ -255,13 +263,29 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restri
         __syncthreads();
         if (tile + 1 < t1) wgrad_fetch(x, dy, tile + 1, p, HW, HR, tid, hv, gv);
         switch (nq) {          // wave-uniform: the tap loop below is unrolled with no predication
-            case 1: wgrad_tile<1>(halo, gy, HW, kp, ci, base, acc); break;
-            case 2: wgrad_tile<2>(halo, gy, HW, kp, ci, base, acc); break;
-            case 3: wgrad_tile<3>(halo, gy, HW, kp, ci, base, acc); break;
-            case 4: wgrad_tile<4>(halo, gy, HW, kp, ci, base, acc); break;
+            case 1: wgrad_tile<1>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 2: wgrad_tile<2>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 3: wgrad_tile<3>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 4: wgrad_tile<4>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 5: wgrad_tile<5>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 6: wgrad_tile<6>(halo, gy, HW, kp, ci, py0, base, acc); break;
+            case 7: wgrad_tile<7>(halo, gy, HW, kp, ci, py0, base, acc); break;
             default: break;
         }
     }
+    // the two pixel halves of a tap lane meet in LDS (the staging buffers are free now), then the even wave writes the partial
+    __syncthreads();
+    float* const xch = lds + (w >> 1) * (WG_TAPS * 16 * 64);             // 2 tap lanes x 28 KB inside the 56.5 KB of staging buffers
+    if (w & 1) {
+#pragma unroll
+        for (int q = 0; q < WG_TAPS; ++q)
+            if (q < nq) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xch[(q * 16 + e) * 64 + l] = acc[q][e];
+            }
+    }
+    __syncthreads();
+    if (w & 1) return;
     float* outp = dwp + (long)blockIdx.x * KK * CC * CC;
 #pragma unroll
     for (int q = 0; q < WG_TAPS; ++q) {
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);      // ci
-            outp[((long)t * CC + row) * CC + (l & 31)] = acc[q][e];
+            outp[((long)t * CC + row) * CC + (l & 31)] = acc[q][e] + xch[(q * 16 + e) * 64 + l];
         }
     }
 }
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* _
 
 // floats of the packed weight image for `ntaps` taps / of the weight-gradient scratch for N images and a k x k kernel
 extern "C" long lv_conv32_wpack_floats(int ntaps) { return (long)ntaps * 16 * 64; }
-static inline int wgrad_groups(int k) { return k >= 7 ? 4 : k >= 5 ? 2 : 1; }
+static inline int wgrad_groups(int k) { return k >= 7 ? 4 : k >= 5 ? 2 : 1; }     // x 2 tap lanes per workgroup
 extern "C" int lv_conv32_wgrad_slabs(int N, int k) {
     const int ntiles = N * (IH / TR), cap = 256 / wgrad_groups(k);
     return ntiles < cap ? ntiles : cap;
