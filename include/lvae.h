@@ -318,16 +318,6 @@ int lv_conv32_blocks(int N);
 int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream);
 long lv_conv1x1_blocks(long P);
 int lv_conv1x1_bnstat_f32(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, void* stream);
-/* ... and the CONSUMING forward convolutions with that BatchNorm + ELU folded into their input staging: x = the raw output of
- * the producing convolution, in_partial [in_nblk][2][Cin] its stage-1 partials; y <- ELU(BN(x)) (saved for the backward pass),
- * mean / invstd / running statistics as lv_bn_fwd_f32 leaves them, out <- conv(y), bn_partial (optional, a different buffer)
- * <- the stage-1 partials of out.  The separate normalisation pass over the activation disappears. */
-int lv_conv32_bnin_f32(const float* x, const float* in_partial, int in_nblk, const float* gamma, const float* beta, float* y,
-                       float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum, const float* wp,
-                       float* out, float* bn_partial, int N, int k, int ntaps, void* stream);
-int lv_conv1x1_bnin_f32(const float* x, const float* in_partial, int in_nblk, const float* gamma, const float* beta, float* y,
-                        float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum, const float* w,
-                        float* out, float* bn_partial, long P, int Cin, int Cout, void* stream);
 int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu, float* y,
                            float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum,
                            const float* partial, int nblk, long P, int C, void* stream);

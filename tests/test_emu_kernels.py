@@ -202,7 +202,3 @@ def test_dropout_folded_into_image_conversion(emu_backend):
 
 def test_wgrad_reduce_batched(emu_backend):
     K.test_wgrad_reduce_batched(emu_backend, CPU)
-
-
-def test_conv_with_batchnorm_folded_into_input(emu_backend):
-    K.test_conv_with_batchnorm_folded_into_input(emu_backend, CPU, 3, 5)

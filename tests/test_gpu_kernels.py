@@ -1110,58 +1110,3 @@ def test_wgrad_reduce_batched(lib, hip_device):
             assert torch.equal(ref.cpu(), out.cpu())
         else:
             assert float((ref - out).abs().max()) < 1e-5 * float(ref.abs().max())
-
-
-@pytest.mark.parametrize("N,k", [(3, 5), (40, 3), (50, 7)])
-def test_conv_with_batchnorm_folded_into_input(lib, hip_device, N, k):
-    """lv_conv32_bnin_f32 / lv_conv1x1_bnin_f32 (BatchNorm + ELU applied while the consuming convolution stages its input) give,
-    bit for bit, what the separate normalisation pass followed by the plain convolution gives: y, the convolution output, the
-    saved and running statistics, and the output's own BatchNorm partials."""
-    if hip_device.type != "cuda" and N > 3:
-        pytest.skip("large cases on the GPU only")
-    dev = hip_device
-    g = torch.Generator().manual_seed(N * 7 + k)
-    Pn = N * 784
-    nt = (k // 2) * k + k // 2 + 1
-
-    def stats():
-        return [torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.full((32,), 0.3, device=dev), torch.full((32,), 1.7, device=dev)]
-
-    # ---- producer: pointwise 64 -> 32 with statistics; consumer: 32 -> 32 k x k --------------------------------------------------
-    x0 = torch.randn(Pn, 64, generator=g).to(dev)
-    w0 = (torch.randn(32, 64, generator=g) / 8).to(dev)
-    raw = torch.empty(Pn, 32, device=dev)
-    nb_in = int(lib.lv_conv1x1_blocks(Pn))
-    part_in = torch.empty(nb_in, 2, 32, device=dev)
-    lib.lv_conv1x1_bnstat_f32(P(x0), P(w0), P(raw), P(part_in), Pn, 64, 32, _s(dev))
-    gamma, beta = (torch.rand(32, generator=g) + 0.5).to(dev), torch.randn(32, generator=g).to(dev)
-    w = (torch.randn(32, 32, k, k, generator=g) / (32 * k) ** 0.5).to(dev)
-    wp = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
-    lib.lv_conv32_pack_f32(P(w), P(wp), k, nt, 0, _s(dev))
-    nb_out = lib.lv_conv32_blocks(N)
-    y_r, out_r, part_r = torch.empty(Pn, 32, device=dev), torch.empty(Pn, 32, device=dev), torch.empty(nb_out, 2, 32, device=dev)
-    st_r = stats()
-    lib.lv_bn_fwd_partials_f32(P(raw), P(gamma), P(beta), None, 1, P(y_r), P(st_r[0]), P(st_r[1]), P(st_r[2]), P(st_r[3]), 1e-5, 0.1,
-                               P(part_in), nb_in, Pn, 32, _s(dev))
-    lib.lv_conv32_bnstat_f32(P(y_r), P(wp), P(out_r), P(part_r), N, k, nt, _s(dev))
-    y, out, part = torch.full_like(y_r, float("nan")), torch.full_like(out_r, float("nan")), torch.full_like(part_r, float("nan"))
-    st = stats()
-    lib.lv_conv32_bnin_f32(P(raw), P(part_in), nb_in, P(gamma), P(beta), P(y), P(st[0]), P(st[1]), P(st[2]), P(st[3]), 1e-5, 0.1,
-                           P(wp), P(out), P(part), N, k, nt, _s(dev))
-    for a, b in [(y, y_r), (out, out_r), (part, part_r)] + list(zip(st, st_r)):
-        assert torch.equal(a.cpu(), b.cpu())
-    # ---- producer: the 32 -> 32 convolution above; consumer: pointwise 32 -> 64 -------------------------------------------------
-    w1 = (torch.randn(64, 32, generator=g) / 6).to(dev)
-    g2, b2 = (torch.rand(32, generator=g) + 0.5).to(dev), torch.randn(32, generator=g).to(dev)
-    nb2 = int(lib.lv_conv1x1_blocks(Pn))
-    y2_r, o2_r, p2_r = torch.empty(Pn, 32, device=dev), torch.empty(Pn, 64, device=dev), torch.empty(nb2, 2, 64, device=dev)
-    st_r = stats()
-    lib.lv_bn_fwd_partials_f32(P(out_r), P(g2), P(b2), None, 1, P(y2_r), P(st_r[0]), P(st_r[1]), P(st_r[2]), P(st_r[3]), 1e-5, 0.1,
-                               P(part_r), nb_out, Pn, 32, _s(dev))
-    lib.lv_conv1x1_bnstat_f32(P(y2_r), P(w1), P(o2_r), P(p2_r), Pn, 32, 64, _s(dev))
-    y2, o2, p2 = torch.full_like(y2_r, float("nan")), torch.full_like(o2_r, float("nan")), torch.full_like(p2_r, float("nan"))
-    st = stats()
-    lib.lv_conv1x1_bnin_f32(P(out_r), P(part_r), nb_out, P(g2), P(b2), P(y2), P(st[0]), P(st[1]), P(st[2]), P(st[3]), 1e-5, 0.1,
-                            P(w1), P(o2), P(p2), Pn, 32, 64, _s(dev))
-    for a, b in [(y2, y2_r), (o2, o2_r), (p2, p2_r)] + list(zip(st, st_r)):
-        assert torch.equal(a.cpu(), b.cpu())

@@ -107,8 +107,6 @@ SIGNATURES = {
     "lv_conv32_bnstat_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_blocks": [_l],
     "lv_conv1x1_bnstat_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp],
-    "lv_conv32_bnin_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "lv_conv1x1_bnin_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _l, _i, _i, _vp],
     "lv_bn_fwd_partials_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _l, _i, _vp],
     "lv_conv1x1_wgrad_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],

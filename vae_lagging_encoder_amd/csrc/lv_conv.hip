@@ -15,7 +15,6 @@
 // residual add + ELU fused in one pass; backward = one reduction (dbeta, dgamma) + one apply pass, ELU' from the
 // saved output.
 #include "lv_device.h"
-#include "lv_bn_totals.h"
 
 namespace {
 
@@ -312,6 +311,43 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
     }
 }
 
+// per-(q, c) totals of the per-block partials, all 256 threads cooperating: thread t sums float4 group t % (C/2) over blocks
+// t / (C/2), + 256/(C/2), ... (16 independent loads in flight per batch: a runtime-length load -> add loop would pay one L2
+// round trip per block), f64, fixed order; tot: 2*C doubles, scratch: 1024 doubles (LDS)
+__device__ __forceinline__ void bn_block_totals(const float* __restrict__ partial, int nblk, int C, double* tot, double* scratch) {
+    const int tid = (int)threadIdx.x, npair = 2 * C, NF4 = C >> 1, nsub = 256 / NF4;
+    const int pg = tid & (NF4 - 1), bsub = tid / NF4;
+    const float4* p4 = reinterpret_cast<const float4*>(partial) + pg;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = bsub;
+    for (; b + 15 * nsub < nblk; b += 16 * nsub) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p4[(long)(b + u * nsub) * NF4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+    }
+    {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int bb = b + u * nsub;
+            v[u] = bb < nblk ? p4[(long)bb * NF4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+    }
+    double* sc = scratch + (long)bsub * npair + 4 * pg;
+    sc[0] = s0; sc[1] = s1; sc[2] = s2; sc[3] = s3;
+    __syncthreads();
+    for (int t = tid; t < npair; t += 256) {
+        double acc = 0.0;
+        for (int k = 0; k < nsub; ++k) acc += scratch[(long)k * npair + t];
+        tot[t] = acc;
+    }
+    __syncthreads();
+}
+
 template <int BN_V4_ITEMS>
 __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -334,11 +370,22 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_v4_kernel(const float* __res
         xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
         if (res) rs[u] = *reinterpret_cast<const float4*>(res + 4 * ii);
     }
-    lv_bn_block_totals(partial, nblk, C, tot, scratch);
+    bn_block_totals(partial, nblk, C, tot, scratch);
     if (tid < C) {
-        float mf, isf;
-        lv_bn_channel_stats(tot, C, tid, P, eps, momentum, blockIdx.x == 0, mean_out, invstd_out, run_mean, run_var, mf, isf);
+        const double m = tot[tid] / (double)P;
+        double var = tot[C + tid] / (double)P - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
         smu[tid] = mf; sis[tid] = isf; sga[tid] = gamma[tid]; sbe[tid] = beta[tid];
+        if (blockIdx.x == 0) {
+            mean_out[tid] = mf;
+            invstd_out[tid] = isf;
+            if (run_mean) {
+                const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+                run_mean[tid] = (float)((1.0 - momentum) * (double)run_mean[tid] + momentum * m);
+                run_var[tid] = (float)((1.0 - momentum) * (double)run_var[tid] + momentum * unb);
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -382,7 +429,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_v4_kernel(const float* __res
         xs[u] = *reinterpret_cast<const float4*>(x + 4 * ii);
         ds[u] = *reinterpret_cast<const float4*>(dv + 4 * ii);
     }
-    lv_bn_block_totals(partial, nblk, C, tot, scratch);
+    bn_block_totals(partial, nblk, C, tot, scratch);
     if (tid < C) {
         const double s = tot[tid], q = tot[C + tid];
         smu[tid] = mean[tid]; sis[tid] = invstd[tid]; sga[tid] = gamma[tid];

@@ -16,7 +16,6 @@
 // accumulates its taps' 32 x 32 blocks in registers over the whole slab (K = pixels), and a second kernel sums the slabs'
 // partials in a fixed order straight into the reference's [Cout][Cin][kh][kw] gradient layout.
 #include "lv_device.h"
-#include "lv_bn_totals.h"
 
 namespace {
 
@@ -46,20 +45,14 @@ __global__ __launch_bounds__(256) void conv32_pack_kernel(const float* __restric
 // KS = 1: a workgroup owns 4 image rows, one per wave.  KS = 2: 2 rows, and two waves share a row by splitting the taps (their
 // accumulators meet in LDS): twice the workgroups of half the MFMA time each.  The work is MFMA-bound and a wave-row is its
 // indivisible unit; at the benchmark's 50 images 1400 units on 1024 SIMDs take 2 rounds, 2800 half units take 3 half rounds.
-// BNIN: `in` is the raw output of the previous convolution and bi describes the BatchNorm + ELU that sits between the two
-// (dec_pixelcnn_v2.py:41-47): every workgroup re-derives the channel statistics from the producer's partial sums while its halo
-// loads are in flight, normalises + activates the values on their way into LDS, and writes the activated rows it owns to bi.y
-// (the backward pass needs them) -- the separate BatchNorm apply pass (read x, write y; 10.6 us, 46 per Omniglot step) is gone.
-template <int KS, bool BNIN>
+template <int KS>
 __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
-                                                            int mirror, int accumulate, LvBnIn bi) {
+                                                            int mirror, int accumulate) {
     constexpr int TRW = TR / KS;         // image rows per workgroup
     __shared__ __attribute__((aligned(16))) float halo[(TRW + KMAX - 1) * (IW + KMAX - 1) * PP];
     __shared__ float sstat[TRW][2][CC];
     __shared__ float red[KS == 2 ? TRW * 16 * 64 : 1];
-    __shared__ double bn_tot[BNIN ? 2 * CC : 1], bn_scr[BNIN ? 1024 : 1];
-    __shared__ __attribute__((aligned(16))) float bn_par[BNIN ? 4 * CC : 4];       // mean | invstd | gamma | beta
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wr = w % TRW, wk = w / TRW;                    // this wave's row of the tile and its share of the taps
     const int n = (int)blockIdx.x / (IH / TRW), r0 = ((int)blockIdx.x % (IH / TRW)) * TRW;
@@ -76,33 +69,6 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
             hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW)
                 hv[u] = *reinterpret_cast<const float4*>(in + (((long)n * IH + gy) * IW + gx) * CC + 4 * c4);
-        }
-        if constexpr (BNIN) {
-            // the halo loads above stay in flight under the statistics
-            lv_bn_block_totals(bi.partial, bi.nblk, CC, bn_tot, bn_scr);
-            if (tid < CC) {
-                float mf, isf;
-                lv_bn_channel_stats(bn_tot, CC, tid, bi.P, bi.eps, bi.momentum, blockIdx.x == 0, bi.mean, bi.invstd, bi.run_mean,
-                                    bi.run_var, mf, isf);
-                bn_par[tid] = mf; bn_par[CC + tid] = isf; bn_par[2 * CC + tid] = bi.gamma[tid]; bn_par[3 * CC + tid] = bi.beta[tid];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < HALO_F4; ++u) {
-                const int i = tid + 256 * u;
-                const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
-                const int gy = r0 - p + hy, gx = hx - p;
-                if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW) {      // the zero padding is padding of the ACTIVATED map
-                    const float4 m4 = *reinterpret_cast<const float4*>(&bn_par[4 * c4]), i4 = *reinterpret_cast<const float4*>(&bn_par[CC + 4 * c4]);
-                    const float4 g4 = *reinterpret_cast<const float4*>(&bn_par[2 * CC + 4 * c4]), b4 = *reinterpret_cast<const float4*>(&bn_par[3 * CC + 4 * c4]);
-                    float4 v = hv[u];
-                    v.x = lv_bn_elu(v.x, m4.x, i4.x, g4.x, b4.x); v.y = lv_bn_elu(v.y, m4.y, i4.y, g4.y, b4.y);
-                    v.z = lv_bn_elu(v.z, m4.z, i4.z, g4.z, b4.z); v.w = lv_bn_elu(v.w, m4.w, i4.w, g4.w, b4.w);
-                    hv[u] = v;
-                    if (hy >= p && hy < p + TRW)                                 // this workgroup's own rows: each pixel written exactly once
-                        *reinterpret_cast<float4*>(bi.y + (((long)n * IH + gy) * IW + gx) * CC + 4 * c4) = v;
-                }
-            }
         }
 #pragma unroll
         for (int u = 0; u < HALO_F4; ++u) {
@@ -383,11 +349,11 @@ extern "C" int lv_conv32_f32(const float* in, const float* wp, float* out, int N
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
     if (conv32_ks(N) == 2)
-        LV_LAUNCH((conv32_direct_kernel<2, false>), dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k,
-                  ntaps, mirror, accumulate, LvBnIn{});
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
+                  mirror, accumulate);
     else
-        LV_LAUNCH((conv32_direct_kernel<1, false>), dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k,
-                  ntaps, mirror, accumulate, LvBnIn{});
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
+                  mirror, accumulate);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -399,34 +365,9 @@ extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
     if (conv32_ks(N) == 2)
-        LV_LAUNCH((conv32_direct_kernel<2, false>), dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0,
-                  0, LvBnIn{});
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
     else
-        LV_LAUNCH((conv32_direct_kernel<1, false>), dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0,
-                  0, LvBnIn{});
-    LV_CHECK_LAUNCH();
-    return LV_OK;
-}
-
-// The forward convolution of a PixelCNNBlock's 32 -> 32 stage with the BatchNorm + ELU in front of it (dec_pixelcnn_v2.py:42-44)
-// folded in: x = the raw output of the block's first pointwise convolution, in_partial [in_nblk][2][32] its stage-1 BatchNorm
-// partials (lv_conv1x1_bnstat_f32); y <- ELU(BN(x)) (saved for the backward pass), mean / invstd / running statistics as
-// lv_bn_fwd_f32 leaves them, out <- conv(y); bn_partial (optional) <- the stage-1 partials of out, in a buffer distinct from
-// in_partial.
-extern "C" int lv_conv32_bnin_f32(const float* x, const float* in_partial, int in_nblk, const float* gamma, const float* beta,
-                                  float* y, float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum,
-                                  const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream) {
-    if (!x || !in_partial || !gamma || !beta || !y || !mean || !invstd || !wp || !out) return LV_ERR_ARG;
-    if (N <= 0 || in_nblk <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
-    if (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)in_partial)) & 15) != 0) return LV_ERR_ALIGN;
-    if (in_partial == bn_partial) return LV_ERR_ARG;
-    const LvBnIn bi{in_partial, in_nblk, gamma, beta, mean, invstd, run_mean, run_var, y, (long)N * IH * IW, eps, momentum};
-    if (conv32_ks(N) == 2)
-        LV_LAUNCH((conv32_direct_kernel<2, true>), dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, x, wp, out, bn_partial, k, ntaps, 0,
-                  0, bi);
-    else
-        LV_LAUNCH((conv32_direct_kernel<1, true>), dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, x, wp, out, bn_partial, k, ntaps, 0,
-                  0, bi);
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -467,15 +408,13 @@ namespace {
 constexpr int PWP = 160;               // pixels per workgroup (5 waves x 32): 39200 pixels -> 245 workgroups, one round on 256 CUs
 constexpr int PWT = 2 * PWP;           // threads
 
-template <int CIN, int COUT, bool BNIN>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                                                      float* __restrict__ bn_partial, long P, int w_transposed, int accumulate, LvBnIn bi) {
+                                                      float* __restrict__ bn_partial, long P, int w_transposed, int accumulate) {
     constexpr int PA = CIN + 4;        // LDS pitches (floats): 16-byte slots per row odd -> conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) float sa[PWP * PA];
     __shared__ __attribute__((aligned(16))) float sw[COUT * PA];
     __shared__ float sstat[PWP / 32][2][COUT];
-    __shared__ double bn_tot[BNIN ? 2 * CIN : 1], bn_scr[BNIN ? 1024 : 1];
-    __shared__ __attribute__((aligned(16))) float bn_par[BNIN ? 4 * CIN : 4];      // mean | invstd | gamma | beta (BNIN: see conv32_direct_kernel)
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const long p0 = (long)blockIdx.x * PWP;
     constexpr int NF4 = PWP * (CIN / 4) / PWT;           // float4 per thread (8 or 4): loads first, then the LDS writes
@@ -487,30 +426,6 @@ __global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ 
             const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p0 + pp < P) v[u] = *reinterpret_cast<const float4*>(in + (p0 + pp) * CIN + 4 * c4);
-        }
-        if constexpr (BNIN) {
-            lv_bn_block_totals(bi.partial, bi.nblk, CIN, bn_tot, bn_scr);
-            if (tid < CIN) {
-                float mf, isf;
-                lv_bn_channel_stats(bn_tot, CIN, tid, bi.P, bi.eps, bi.momentum, blockIdx.x == 0, bi.mean, bi.invstd, bi.run_mean,
-                                    bi.run_var, mf, isf);
-                bn_par[tid] = mf; bn_par[CIN + tid] = isf; bn_par[2 * CIN + tid] = bi.gamma[tid]; bn_par[3 * CIN + tid] = bi.beta[tid];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NF4; ++u) {
-                const int i = tid + PWT * u;
-                const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
-                if (p0 + pp < P) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(&bn_par[4 * c4]), i4 = *reinterpret_cast<const float4*>(&bn_par[CIN + 4 * c4]);
-                    const float4 g4 = *reinterpret_cast<const float4*>(&bn_par[2 * CIN + 4 * c4]), b4 = *reinterpret_cast<const float4*>(&bn_par[3 * CIN + 4 * c4]);
-                    float4 q = v[u];
-                    q.x = lv_bn_elu(q.x, m4.x, i4.x, g4.x, b4.x); q.y = lv_bn_elu(q.y, m4.y, i4.y, g4.y, b4.y);
-                    q.z = lv_bn_elu(q.z, m4.z, i4.z, g4.z, b4.z); q.w = lv_bn_elu(q.w, m4.w, i4.w, g4.w, b4.w);
-                    v[u] = q;
-                    *reinterpret_cast<float4*>(bi.y + (p0 + pp) * CIN + 4 * c4) = q;
-                }
-            }
         }
 #pragma unroll
         for (int u = 0; u < NF4; ++u) {
@@ -677,29 +592,10 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
 static int conv1x1_launch(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, int w_transposed,
                           int accumulate, void* stream) {
     const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(PWT);
-    const LvBnIn nb{};
-    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32, false>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, nb);
-    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64, false>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, nb);
-    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64, false>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, nb);
-    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32, false>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, nb);
-    else return LV_ERR_UNSUPPORTED;
-    LV_CHECK_LAUNCH();
-    return LV_OK;
-}
-
-// The forward pointwise convolution with the BatchNorm + ELU in front of it folded in (dec_pixelcnn_v2.py:45-49: the 32 -> 64
-// expansion after the masked convolution); arguments as lv_conv32_bnin_f32.  (Cin, Cout) = (32, 64) or (32, 32).
-extern "C" int lv_conv1x1_bnin_f32(const float* x, const float* in_partial, int in_nblk, const float* gamma, const float* beta,
-                                   float* y, float* mean, float* invstd, float* run_mean, float* run_var, float eps, float momentum,
-                                   const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, void* stream) {
-    if (!x || !in_partial || !gamma || !beta || !y || !mean || !invstd || !w || !out) return LV_ERR_ARG;
-    if (P <= 0 || in_nblk <= 0) return LV_ERR_SHAPE;
-    if (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)in_partial)) & 15) != 0) return LV_ERR_ALIGN;
-    if (in_partial == bn_partial) return LV_ERR_ARG;
-    const LvBnIn bi{in_partial, in_nblk, gamma, beta, mean, invstd, run_mean, run_var, y, P, eps, momentum};
-    const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(PWT);
-    if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64, true>), grid, block, 0, stream, x, w, out, bn_partial, P, 0, 0, bi);
-    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32, true>), grid, block, 0, stream, x, w, out, bn_partial, P, 0, 0, bi);
+    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
     else return LV_ERR_UNSUPPORTED;
     LV_CHECK_LAUNCH();
     return LV_OK;

@@ -15,13 +15,11 @@ from .engine import P, FlatBuffer, _gemm, backend_for, stream_ptr
 
 class Act(object):
     """An NHWC activation: t is a contiguous [N*H*W, C] fp32 tensor."""
-    __slots__ = ("t", "N", "H", "W", "C", "needs_grad", "bn_nblk", "bn_part", "pending")
+    __slots__ = ("t", "N", "H", "W", "C", "needs_grad", "bn_nblk")
 
     def __init__(self, t, N, H, W, C, needs_grad=True):
         self.t, self.N, self.H, self.W, self.C, self.needs_grad = t, N, H, W, C, needs_grad
-        self.bn_nblk = 0       # > 0: the producer left this many BatchNorm stage-1 partial blocks in bn_part
-        self.bn_part = None
-        self.pending = None    # (raw Act, BatchNorm2d, mean, invstd): t is still to be filled by the convolution that consumes it
+        self.bn_nblk = 0       # > 0: the producer left this many BatchNorm stage-1 partial blocks in the tape's BN workspace
 
     @property
     def P(self):
@@ -49,7 +47,6 @@ class Tape(object):
         self.back = []
         self.grads = {}
         self._bn_ws = {}
-        self._bn_slot = {}
         self.bn_seen = []              # num_batches_tracked buffers of the BatchNorms run in train mode (bumped once, together)
         self.wgrad_pending = []        # (partials, gradient view, outputs, parts, k*k) of the direct convolutions: reduced together
         # packed weight images of the direct convolutions, kept across steps by the owning engine and rebuilt when its
@@ -64,28 +61,12 @@ class Tape(object):
     def f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
-    def bn_ws(self, C, slot=0):
-        w = self._bn_ws.get((C, slot))
+    def bn_ws(self, C):
+        w = self._bn_ws.get(C)
         if w is None:
             w = self.f32(self.lib.lv_bn_workspace_floats(C) + 2 * C)
-            self._bn_ws[(C, slot)] = w
+            self._bn_ws[C] = w
         return w
-
-    def new_bn_part(self, C):
-        """Where a convolution leaves the BatchNorm partials of its output: two buffers per width, alternating -- a consuming
-        convolution reads its input's partials while it writes its output's."""
-        slot = self._bn_slot.get(C, 0) ^ 1
-        self._bn_slot[C] = slot
-        return self.bn_ws(C, slot)
-
-    def materialize(self, act):
-        """Run the BatchNorm a fused consumer would have applied (act.pending), for any other consumer."""
-        if act is None or act.pending is None:
-            return
-        raw, bn, mean, invstd = act.pending
-        act.pending = None
-        self.lib.lv_bn_fwd_partials_f32(P(raw.t), P(bn.weight), P(bn.bias), None, 1, P(act.t), P(mean), P(invstd), P(bn.running_mean),
-                                        P(bn.running_var), bn.eps, bn.momentum, P(raw.bn_part), raw.bn_nblk, raw.P, raw.C, self.s())
 
     def bump_bn_counters(self):
         """BatchNorm2d.num_batches_tracked += 1 for every layer this forward ran in train mode: one fused launch."""
@@ -147,7 +128,6 @@ class Tape(object):
             return self._conv32(x, weight, gview, kh, nt, mask, bn_stats and self.train)
         if KK == 1 and stride == 1 and pad == 0 and mask is None and Cin in (32, 64) and Cout in (32, 64):
             return self._conv1x1(x, weight, gview, bn_stats and self.train)
-        self.materialize(x)
         if mask is not None:
             # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
             # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
@@ -203,19 +183,9 @@ class Tape(object):
         wp, wpt = ent["wp"], ent["wpt"]
         y = self.f32(x.P, 32)
         out = Act(y, x.N, 28, 28, 32)
-        part = None
         if bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS:
-            part = self.new_bn_part(32)
-            out.bn_nblk, out.bn_part = lib.lv_conv32_blocks(x.N), part
-        if x.pending is not None:
-            # the BatchNorm + ELU in front of this convolution is applied while its input is staged; x.t (the activated map the
-            # backward pass reads) is written by the same launch
-            raw, bn, mean, invstd = x.pending
-            x.pending = None
-            lib.lv_conv32_bnin_f32(P(raw.t), P(raw.bn_part), raw.bn_nblk, P(bn.weight), P(bn.bias), P(x.t), P(mean), P(invstd),
-                                   P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum, P(wp), P(y), P(part), x.N, k, nt, s)
-        elif part is not None:
-            lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(part), x.N, k, nt, s)
+            lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(self.bn_ws(32)), x.N, k, nt, s)
+            out.bn_nblk = lib.lv_conv32_blocks(x.N)
         else:
             lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
 
@@ -239,22 +209,11 @@ class Tape(object):
         Cout, Cin = weight.shape[0], weight.shape[1]
         y = self.f32(x.P, Cout)
         out = Act(y, x.N, x.H, x.W, Cout)
-        part = None
         if bn_stats and lib.lv_conv1x1_blocks(x.P) <= _BN_MAX_BLOCKS:
-            part = self.new_bn_part(Cout)
-            out.bn_nblk, out.bn_part = int(lib.lv_conv1x1_blocks(x.P)), part
-        if x.pending is not None and Cin == 32:
-            raw, bn, mean, invstd = x.pending            # as in _conv32: BatchNorm + ELU folded into the input staging
-            x.pending = None
-            lib.lv_conv1x1_bnin_f32(P(raw.t), P(raw.bn_part), raw.bn_nblk, P(bn.weight), P(bn.bias), P(x.t), P(mean), P(invstd),
-                                    P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum, P(weight), P(y), P(part), x.P, Cin,
-                                    Cout, s)
+            lib.lv_conv1x1_bnstat_f32(P(x.t), P(weight), P(y), P(self.bn_ws(Cout)), x.P, Cin, Cout, s)
+            out.bn_nblk = int(lib.lv_conv1x1_blocks(x.P))
         else:
-            self.materialize(x)
-            if part is not None:
-                lib.lv_conv1x1_bnstat_f32(P(x.t), P(weight), P(y), P(part), x.P, Cin, Cout, s)
-            else:
-                lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
+            lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
 
         def bwd():
             dy = self.grad_of(out)
@@ -272,25 +231,18 @@ class Tape(object):
         self.back.append(bwd)
         return out
 
-    def bn(self, x, bn, g_gamma, g_beta, res=None, act=True, defer=False):
-        """nn.BatchNorm2d (+ residual add) (+ nn.ELU).  Train mode: batch statistics + running-stat update.
-        defer: the caller feeds the result straight into a direct convolution, which applies the normalisation while it stages
-        its input (lv_conv32_bnin_f32 / lv_conv1x1_bnin_f32) -- nothing is launched here (any other consumer materialises it)."""
+    def bn(self, x, bn, g_gamma, g_beta, res=None, act=True):
+        """nn.BatchNorm2d (+ residual add) (+ nn.ELU).  Train mode: batch statistics + running-stat update."""
         lib, s = self.lib, self.s()
-        self.materialize(x)
-        self.materialize(res)
         C, Pn = x.C, x.P
         y = self.f32(Pn, C)
         mean = self.f32(C)
         invstd = self.f32(C)
-        deferred = bool(defer and self.train and x.bn_nblk and res is None and act and C == 32)
-        if deferred:
-            self.bn_seen.append(bn.num_batches_tracked)
-        elif self.train and x.bn_nblk:
-            # the producing convolution left the per-channel partial sums in a workspace
+        if self.train and x.bn_nblk:
+            # the producing convolution left the per-channel partial sums in the workspace
             lib.lv_bn_fwd_partials_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
                                        P(mean), P(invstd), P(bn.running_mean), P(bn.running_var), bn.eps, bn.momentum,
-                                       P(x.bn_part), x.bn_nblk, Pn, C, s)
+                                       P(self.bn_ws(C)), x.bn_nblk, Pn, C, s)
             self.bn_seen.append(bn.num_batches_tracked)
         elif self.train:
             lib.lv_bn_fwd_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
@@ -306,8 +258,6 @@ class Tape(object):
                 yy = yy + res.t
             y.copy_(torch.nn.functional.elu(yy) if act else yy)
         out = Act(y, x.N, x.H, x.W, C)
-        if deferred:
-            out.pending = (x, bn, mean, invstd)
 
         def bwd():
             dy = self.grad_of(out)
@@ -326,8 +276,6 @@ class Tape(object):
 
     def add(self, a, b):
         lib, s = self.lib, self.s()
-        self.materialize(a)
-        self.materialize(b)
         y = self.f32(a.P, a.C)
         lib.lv_add_f32(P(a.t), P(b.t), P(y), y.numel(), s)
         out = Act(y, a.N, a.H, a.W, a.C)
@@ -404,11 +352,11 @@ def pixelcnn_block(tp, flat, blk, x):
     m = blk.main
     k = m[3].kernel_size[0]
     h = tp.conv(x, m[0].weight, _gv(flat, m[0].weight), bn_stats=True)
-    h = tp.bn(h, m[1], _gv(flat, m[1].weight), _gv(flat, m[1].bias), act=True, defer=True)
+    h = tp.bn(h, m[1], _gv(flat, m[1].weight), _gv(flat, m[1].bias), act=True)
     # type-B mask: taps strictly before the centre in raster order plus the centre itself
     h = tp.conv(h, m[3].weight, _gv(flat, m[3].weight), stride=1, pad=k // 2, ntaps=(k // 2) * k + k // 2 + 1, mask=m[3].mask,
                 bn_stats=True)
-    h = tp.bn(h, m[4], _gv(flat, m[4].weight), _gv(flat, m[4].bias), act=True, defer=True)
+    h = tp.bn(h, m[4], _gv(flat, m[4].weight), _gv(flat, m[4].bias), act=True)
     h = tp.conv(h, m[6].weight, _gv(flat, m[6].weight), bn_stats=True)
     return tp.bn(h, m[7], _gv(flat, m[7].weight), _gv(flat, m[7].bias), res=x, act=True)
 
