@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--dp-mode", default="strict", choices=["strict", "encoder_only"],
                     help="data-parallel gradient exchange: strict = encoder + decoder buffers (reference clip norm), "
                          "encoder_only = encoder buffer only (documented deviation)")
+    ap.add_argument("--dp-payload", default="f32", choices=["f32", "bf16"],
+                    help="wire format of the data-parallel gradient exchange (f32 = exact mean gradient; bf16 halves the bytes)")
     ap.add_argument("--pool", type=int, default=None)
     args = ap.parse_args()
     stress = args.workload == "stress"
@@ -184,7 +186,7 @@ def main():
 
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
-    sync = lvdist.GradSync(mode=args.dp_mode) if world > 1 else None
+    sync = lvdist.GradSync(mode=args.dp_mode, payload=args.dp_payload) if world > 1 else None
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, grad_sync=sync, use_graph=bool(args.graph),
                                precision=args.dtype)
     if args.overlap != "auto":
@@ -263,7 +265,8 @@ def main():
                                "ni=%d, H=%d, nz=%d%s" % ("yahoo" if stress else args.workload, B, T, V, ni, H, nz,
                                                           ", fixed K=%d inner steps per loop (stress)" % args.steps if stress else ""),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
-                   "dp_exchange": (args.dp_mode if world > 1 else None), "hipgraph": bool(args.graph)},
+                   "dp_exchange": ((args.dp_mode + ("/bf16-payload" if args.dp_payload == "bf16" else "")) if world > 1 else None),
+                   "hipgraph": bool(args.graph)},
     }
     if not stress:
         out["mean_loss_per_seq"] = round(stats["loss_sum"] / (B * args.steps), 4)

@@ -70,6 +70,8 @@ int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_t* dst, lon
  * backward on dO, in place.  (The persistent recurrences then run without a mask: +0.3 us per timestep otherwise.) */
 int lv_cvt_bf16_keep_f32(const float* src, long lds, int T, int Bsz, int C, const uint8_t* keep, float kscale,
                          uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
+/* dst f32 [n] = bf16 src [n] * scale: unpacks a bf16 gradient payload of the data-parallel exchange (dist.GradSync payload="bf16") */
+int lv_cvt_f32_bf16_scaled(const uint16_t* src, long n, float scale, float* dst, void* stream);
 int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, int T, int Bsz, int C, void* stream);
 
 /* LSTM gate weight W [4H][C] (rows g*H + u): dst = bf16 image with rows in unit-major order (4u + g), dstT = bf16 image

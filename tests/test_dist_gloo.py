@@ -35,7 +35,7 @@ def _worker(rank, world, port, name, mode, q):
         sl = slice(rank * per, (rank + 1) * per)
         vae = build_vae(V, ni, H, nz, "cpu", params=fixture_params(fx))
         mode, decoder = mode.split("/")[:2]
-        gs = GradSync(mode=mode, decoder=decoder)
+        gs = GradSync(mode=mode, decoder=decoder, payload="bf16" if name_suffix == "bf16" else "f32")
         tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, grad_sync=gs)
         if name_suffix == "hook":      # the schedule used beside persistent launches: exchange issued from inside the encoder backward
             tr._collective_after_bptt = lambda: True
@@ -58,7 +58,7 @@ def _worker(rank, world, port, name, mode, q):
         q.put((rank, None, None, None, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("decoder", ["norm", "allreduce", "norm/hook", "allreduce/hook"])
+@pytest.mark.parametrize("decoder", ["norm", "allreduce", "norm/hook", "allreduce/hook", "norm/bf16", "allreduce/bf16"])
 @pytest.mark.parametrize("name", ["text_small_wide"])
 def test_two_rank_strict_dp_equals_single_process_reference(name, decoder):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
@@ -78,15 +78,17 @@ def test_two_rank_strict_dp_equals_single_process_reference(name, decoder):
     bytes_by_mode = []
     for rank, norm, loss_sum, errs, tb in res:
         assert tb is None, tb
-        # every rank sees the GLOBAL clipped norm (fixture has norm > 5: the clip is active)
-        assert abs(norm - float(fx["total_norm"])) / float(fx["total_norm"]) < 1e-4
+        # every rank sees the GLOBAL clipped norm (fixture has norm > 5: the clip is active); a bf16 wire format rounds every
+        # gradient element to 8 bits of mantissa (2^-9 relative), which the norm averages out and the update does not
+        tol = 5e-3 if decoder.endswith("bf16") else 1e-4
+        assert abs(norm - float(fx["total_norm"])) / float(fx["total_norm"]) < tol
         glob = errs.pop("_dec_grad_is_global")
         nbytes = errs.pop("_bytes")
         for k, e in errs.items():
-            assert e < 1e-4, (rank, k, e)
+            assert e < tol, (rank, k, e)
         # "norm": the decoder gradient travelled as a reduce-scatter + one scalar (its .grad stays local, and differs from the
         # global mean); "allreduce": every replica holds the clipped global mean gradient, as the reference's .grad would
-        assert (glob < 1e-4) == decoder.startswith("allreduce"), (decoder, glob)
+        assert (glob < tol) == decoder.startswith("allreduce"), (decoder, glob)
         bytes_by_mode.append(nbytes)
     # the ranks' local loss sums add up to the reference's batch loss sum
     assert abs(sum(r[2] for r in res) - float(fx["loss"].sum())) / abs(float(fx["loss"].sum())) < 1e-4

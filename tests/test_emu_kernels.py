@@ -202,3 +202,8 @@ def test_dropout_folded_into_image_conversion(emu_backend):
 
 def test_wgrad_reduce_batched(emu_backend):
     K.test_wgrad_reduce_batched(emu_backend, CPU)
+
+
+def test_bf16_payload_unpack(emu_backend):
+    for n in (1, 7, 4099):
+        K.test_bf16_payload_unpack(emu_backend, CPU, n)

@@ -1110,3 +1110,16 @@ def test_wgrad_reduce_batched(lib, hip_device):
             assert torch.equal(ref.cpu(), out.cpu())
         else:
             assert float((ref - out).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_bf16_payload_unpack(lib, hip_device, n):
+    """lv_cvt_f32_bf16_scaled: bf16 -> f32 with a scale folded in (the way back from the data-parallel bf16 wire format)."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    b = x.to(torch.bfloat16)
+    src = b.view(torch.int16).to(dev)
+    dst = torch.full((n,), float("nan"), device=dev)
+    lib.lv_cvt_f32_bf16_scaled(P(src), n, 0.125, P(dst), _s(dev))
+    assert torch.equal(dst.cpu(), b.float() * 0.125)

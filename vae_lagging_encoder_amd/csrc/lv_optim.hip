@@ -158,6 +158,27 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
     }
 }
 
+__device__ __forceinline__ float bf16_bits_hi_to_f32(uint32_t bits_in_high_half) {      // bf16 = the high half of an f32
+    float f;
+    memcpy(&f, &bits_in_high_half, 4);
+    return f;
+}
+
+// dst[i] = bf16(src[i]) * scale: the way back from a bf16 gradient payload (data-parallel exchange), with the 1/world mean folded in
+__global__ __launch_bounds__(256) void cvt_f32_bf16_scaled_kernel(const uint16_t* __restrict__ src, long n, float scale,
+                                                                  float* __restrict__ dst) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const uint2 q = *reinterpret_cast<const uint2*>(src + i);
+        float4 o;
+        o.x = bf16_bits_hi_to_f32(q.x << 16) * scale; o.y = bf16_bits_hi_to_f32(q.x & 0xFFFF0000u) * scale;
+        o.z = bf16_bits_hi_to_f32(q.y << 16) * scale; o.w = bf16_bits_hi_to_f32(q.y & 0xFFFF0000u) * scale;
+        *reinterpret_cast<float4*>(dst + i) = o;
+    } else {
+        for (long j = i; j < n; ++j) dst[j] = bf16_bits_hi_to_f32((uint32_t)src[j] << 16) * scale;
+    }
+}
+
 __global__ __launch_bounds__(256) void keep_scale_kernel(float* __restrict__ x, const uint8_t* __restrict__ keep, float kscale, int T,
                                                          int Bsz, int C, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -262,6 +283,16 @@ extern "C" int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, in
     const long n = (long)T * Bsz * C;
     if (n == 0) return LV_OK;
     LV_LAUNCH(keep_scale_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, x, keep, kscale, T, Bsz, C, n);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// dst f32 [n] = bf16 src [n] * scale (src 8-byte aligned, dst 16-byte aligned): unpacks a bf16 gradient payload
+extern "C" int lv_cvt_f32_bf16_scaled(const uint16_t* src, long n, float scale, float* dst, void* stream) {
+    if (!src || !dst || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    if ((((uintptr_t)src) & 7) != 0 || (((uintptr_t)dst) & 15) != 0) return LV_ERR_ALIGN;
+    LV_LAUNCH(cvt_f32_bf16_scaled_kernel, dim3((unsigned)lv_cdiv(lv_cdiv(n, 4), 256)), dim3(256), 0, stream, src, n, scale, dst);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

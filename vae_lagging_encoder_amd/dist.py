@@ -50,11 +50,18 @@ class GradSync(object):
         the decoder (text.py:418-424) all-reduce it in full.
     mode "encoder_only": only the encoder buffer is exchanged and the local decoder-gradient norm enters the clip norm -- a
       documented deviation from the reference (replicas stay identical, the clip coefficient differs slightly per step).
+    payload "f32" (default) exchanges the fp32 gradients; "bf16" rounds them to bf16 for the wire (RNE, lv_cvt_bf16_f32), sums
+      in bf16 and unpacks with the 1/world mean folded in: half the bytes of every exchange, at a per-element relative error of
+      2^-9 on the mean gradient -- the size of the operand rounding the bf16 throughput configuration already accepts inside
+      its GEMMs, and not part of the fp32 parity path.  Replicas stay bit-identical to each other either way.
     """
 
-    def __init__(self, group=None, mode="strict", decoder="auto"):
+    def __init__(self, group=None, mode="strict", decoder="auto", payload="f32"):
         assert mode in ("strict", "encoder_only")
         assert decoder in ("auto", "norm", "allreduce")
+        assert payload in ("f32", "bf16")
+        self.payload = payload
+        self._b16 = {}            # bf16 wire images of the flat gradient buffers (payload "bf16")
         self.group = group
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -63,6 +70,7 @@ class GradSync(object):
         self._inv = None
         self._h_dec = None
         self._h_rs = None         # reduce-scatter issued early by start_decoder()
+        self._shard16 = None
         self._rs_tmp = None
         self._shard = None
         self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
@@ -72,6 +80,38 @@ class GradSync(object):
         if self._inv is None or self._inv.device != flat.device:
             self._inv = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.device)
         lib.lv_scale_f32(P(flat.grad), flat.numel, P(self._inv), _eng.stream_ptr(flat.device))
+
+    # ---- bf16 wire format -------------------------------------------------------------------------------------------
+    def _wire(self, flat):
+        """bf16 image of the (padded) flat gradient buffer; returns the int16 tensor (viewed as bfloat16 for the collective)."""
+        src = flat.grad_padded
+        n = src.numel()
+        t = self._b16.get(id(flat))
+        if t is None or t.numel() != n or t.device != src.device:
+            t = torch.empty(n, dtype=torch.int16, device=src.device)
+            self._b16[id(flat)] = t
+        lib = _eng.backend_for(src.device)
+        lib.lv_cvt_bf16_f32(P(src), 1024, n // 1024, 1024, P(t), 1024, None, 0, _eng.stream_ptr(src.device))
+        return t
+
+    def _unwire(self, flat, t16, scale):
+        lib = _eng.backend_for(t16.device)
+        lib.lv_cvt_f32_bf16_scaled(P(t16), flat.numel, scale, P(flat.grad), _eng.stream_ptr(t16.device))
+
+    def _all_reduce_mean_start(self, flat):
+        """Start the mean all-reduce of a flat gradient buffer; returns what _all_reduce_mean_finish needs."""
+        if self.payload == "bf16":
+            t16 = self._wire(flat)
+            return (dist.all_reduce(t16.view(torch.bfloat16), op=dist.ReduceOp.SUM, group=self.group, async_op=True), t16)
+        return (dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None)
+
+    def _all_reduce_mean_finish(self, flat, started):
+        h, t16 = started
+        h.wait()
+        if t16 is not None:
+            self._unwire(flat, t16, 1.0 / self.world)
+        else:
+            self._scale(flat)
 
     def _norm_only(self, dec_flat, update):
         return (self.mode == "strict" and update == "encoder" and self.decoder in ("auto", "norm")
@@ -86,13 +126,18 @@ class GradSync(object):
         if self._norm_only(dec_flat, update):
             self._h_rs = self._reduce_scatter(dec_flat, update, async_op=True)
             return
-        self._h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._h_dec = self._all_reduce_mean_start(dec_flat)
 
     def _reduce_scatter(self, dec_flat, update, async_op):
         """Reduce-scatter of the (padded) decoder gradient into this rank's shard; returns a waitable handle or None."""
         src = dec_flat.grad_padded
         n = src.numel() // self.world
         self.ss_handle(dec_flat, update)
+        bf = self.payload == "bf16"
+        if bf:
+            src = self._wire(dec_flat).view(torch.bfloat16)
+            if self._shard16 is None or self._shard16.numel() != n or self._shard16.device != src.device:
+                self._shard16 = torch.empty(n, dtype=torch.int16, device=src.device)
         if dist.get_backend(self.group) == "gloo":
             # gloo has no reduce-scatter: the CPU tests take the shard out of an all-reduced copy (same sums)
             self._rs_tmp = src.clone()
@@ -100,7 +145,8 @@ class GradSync(object):
             self._rs_slice = (self.rank * n, (self.rank + 1) * n)
             return h
         self._rs_tmp = None
-        return dist.reduce_scatter_tensor(self._shard, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        dst = self._shard16.view(torch.bfloat16) if bf else self._shard
+        return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def sync(self, enc_flat, dec_flat, update="encoder"):
         """Exchange the gradients of one step.  Returns None when both buffers now hold the global mean gradient, or a
@@ -116,25 +162,29 @@ class GradSync(object):
             h_rs, self._h_rs = self._h_rs, None
             if h_rs is None and self._rs_tmp is None:
                 h_rs = self._reduce_scatter(dec_flat, update, async_op=True)      # not started early (hipGraph split, direct callers)
-            h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            enc_started = self._all_reduce_mean_start(enc_flat)
             if h_rs is not None:
                 h_rs.wait()
             if self._rs_tmp is not None:
-                self._shard.copy_(self._rs_tmp[self._rs_slice[0]:self._rs_slice[1]])
+                piece = self._rs_tmp[self._rs_slice[0]:self._rs_slice[1]]
+                if self.payload == "bf16":
+                    self._shard16.copy_(piece.view(torch.int16))
+                else:
+                    self._shard.copy_(piece)
                 self._rs_tmp = None
+            if self.payload == "bf16":
+                lib.lv_cvt_f32_bf16_scaled(P(self._shard16), n, 1.0, P(self._shard), s)
             lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
             lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
             dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
             ss = self._ss
         else:
             if self.mode == "strict" and h_dec is None:
-                h_dec = dist.all_reduce(dec_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            h_enc = dist.all_reduce(enc_flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h_dec = self._all_reduce_mean_start(dec_flat)
+            enc_started = self._all_reduce_mean_start(enc_flat)
             if h_dec is not None:
-                h_dec.wait()
-                self._scale(dec_flat)
-        h_enc.wait()
-        self._scale(enc_flat)
+                self._all_reduce_mean_finish(dec_flat, h_dec)
+        self._all_reduce_mean_finish(enc_flat, enc_started)
         return ss
 
     def ss_handle(self, dec_flat, update="encoder"):
@@ -154,7 +204,7 @@ class GradSync(object):
     def bytes_per_step(self, enc_flat, dec_flat, update="encoder"):
         """fp32 bytes each rank sends per step (ring algorithms: 2(P-1)/P x buffer for an all-reduce, (P-1)/P for a
         reduce-scatter) -- for the schedule table in DESIGN.md."""
-        f = (self.world - 1) / max(1, self.world)
+        f = (self.world - 1) / max(1, self.world) * (0.5 if self.payload == "bf16" else 1.0)
         enc = 2 * f * 4 * enc_flat.numel
         if self.mode != "strict":
             return enc
