@@ -1,0 +1,30 @@
+"""Soak test (measurement tooling): many aggressive inner steps on batches of varying shape (B <= 32, T <= 200) through the
+persistent LSTM launches, checking the hand-off status word and the finiteness of the loss; prints steps/s.
+usage (GPU box): python profiles/microbench/soak_persistent.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+from vae_lagging_encoder_amd.factory import build_text_vae
+from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+dev = torch.device("cuda:0")
+V = 20001
+vae = build_text_vae(V, 512, 1024, 32, dev, seed=3)
+tr = AggressiveTextTrainer(vae, lr=0.05, clip=5.0, precision="bf16", seed=11)
+rs = np.random.RandomState(5)
+t0 = time.time()
+shapes = set()
+for i in range(steps):
+    B = int(rs.randint(1, 33))
+    T = int(rs.randint(3, 201))
+    shapes.add((B, T))
+    x = torch.from_numpy(rs.randint(4, V - 1, size=(B, T))).to(dev)
+    tr.step(x, 0.7)
+    if i % 100 == 99:
+        st = tr.read_stats()            # raises on a persistent hand-off timeout
+        assert np.isfinite(st["loss_sum"]), st
+        tr.reset_stats()
+torch.cuda.synchronize()
+print("soak ok: %d steps, %d distinct (B, T) shapes, %.1f steps/s" % (steps, len(shapes), steps / (time.time() - t0)))
