@@ -27,4 +27,6 @@ for i in range(steps):
         assert np.isfinite(st["loss_sum"]), st
         tr.reset_stats()
 torch.cuda.synchronize()
-print("soak ok: %d steps, %d distinct (B, T) shapes, %.1f steps/s" % (steps, len(shapes), steps / (time.time() - t0)))
+print("soak ok: %d steps, %d distinct (B, T) shapes, %.1f steps/s, peak device memory %.1f GB (workspace caches: enc %.1f GB / %d shapes"
+      ", dec %.1f GB / %d shapes)" % (steps, len(shapes), steps / (time.time() - t0), torch.cuda.max_memory_allocated() / 1e9,
+                                      tr.enc.wsc.total / 1e9, len(tr.enc.wsc.cache), tr.dec.wsc.total / 1e9, len(tr.dec.wsc.cache)))

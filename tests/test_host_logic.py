@@ -155,3 +155,41 @@ def test_outer_loop_runs_end_to_end(emu_backend):
     out = loop.run()
     assert out["epochs"] == 2 and len(calls) >= 3 and np.isfinite(out["best_loss"])
     assert loop.history[-1]["kl_weight"] == 1.0                         # warm_up = 1 epoch ... reached by the end of epoch 2
+
+
+def test_workspace_cache_drops_least_recently_used_shapes():
+    """engine._WS: shape-keyed workspaces are bounded by a byte budget (a corpus cycles through hundreds of (B, T) shapes);
+    the most recent shapes always survive, and nothing is dropped when hipGraphs hold pointers (evictable = False)."""
+    import torch
+    from vae_lagging_encoder_amd import engine as eng
+
+    def build(n):
+        ns = eng._NS()
+        ns.a = torch.zeros(n, dtype=torch.float32)
+        ns.sub = {"b": torch.zeros(n, dtype=torch.int16)}
+        return ns
+
+    c = eng._WS("cpu", budget_bytes=10 * 6000)
+    first = c.get(("ws", 1, 1), lambda: build(1000))
+    assert eng._tensor_bytes(first) == 6000
+    for i in range(2, 40):
+        c.get(("ws", 1, i), lambda: build(1000))
+        assert c.get(("ws", 1, i), None) is not None          # a hit never rebuilds
+    assert c.total <= 10 * 6000 and len(c.cache) == 10
+    assert ("ws", 1, 39) in c.cache and ("ws", 1, 1) not in c.cache
+    assert first.a.numel() == 1000                            # a dropped workspace stays valid for whoever still holds it
+    c.get(("ws", 1, 30), None)                                # touch -> most recent
+    for i in range(40, 49):
+        c.get(("ws", 1, i), lambda: build(1000))
+    assert ("ws", 1, 30) in c.cache and ("ws", 1, 31) not in c.cache
+    # the last 8 entries survive even a budget smaller than one step's workspaces
+    tiny = eng._WS("cpu", budget_bytes=1)
+    for i in range(20):
+        tiny.get(i, lambda: build(10))
+    assert len(tiny.cache) == 8
+    # hipGraph mode: nothing is dropped
+    keep = eng._WS("cpu", budget_bytes=1)
+    keep.evictable = False
+    for i in range(20):
+        keep.get(i, lambda: build(10))
+    assert len(keep.cache) == 20

@@ -93,18 +93,65 @@ class FlatBuffer(object):
             p.grad = self.gviews[n]
 
 
-class _WS(object):
-    """Shape-keyed cache of device workspaces."""
+def _tensor_bytes(obj, depth=0):
+    """Device bytes reachable from a workspace object (tensors in attributes / dict values / lists, nested up to 3 levels)."""
+    if torch.is_tensor(obj):
+        return obj.numel() * obj.element_size()
+    if depth > 3:
+        return 0
+    if isinstance(obj, dict):
+        return sum(_tensor_bytes(v, depth + 1) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_tensor_bytes(v, depth + 1) for v in obj)
+    d = getattr(obj, "__dict__", None)
+    return sum(_tensor_bytes(v, depth + 1) for v in d.values()) if d else 0
 
-    def __init__(self, device):
+
+# fraction of the device memory one engine's shape-keyed workspaces may hold before the least recently used shapes are dropped
+WORKSPACE_BUDGET_FRACTION = 0.2
+
+
+class _WS(object):
+    """Shape-keyed cache of device workspaces, least-recently-used shapes dropped beyond a byte budget.
+
+    A (B, T) batch shape owns ~1.5 GB of activations per engine at the Yahoo dims and real corpora cycle through hundreds of
+    sentence lengths (data/text_data.py batches by length): without a bound the cache grows to the whole device (a soak over
+    1500 random shapes ran a 288 GB MI355X out of memory).  The shapes of the step in flight are always the most recent, so
+    the budget only needs to cover one step.  `evictable = False` (set by the trainers in hipGraph mode, where captured graphs
+    hold raw pointers into these buffers) keeps everything: graph mode is meant for a fixed set of shape buckets."""
+
+    def __init__(self, device, budget_bytes=None):
+        import collections
         self.device = torch.device(device)
-        self.cache = {}
+        self.cache = collections.OrderedDict()
+        self.nbytes = {}
+        self.total = 0
+        self.evictable = True
+        if budget_bytes is None:
+            if self.device.type == "cuda":
+                budget_bytes = int(WORKSPACE_BUDGET_FRACTION * torch.cuda.get_device_properties(self.device).total_memory)
+            else:
+                budget_bytes = 8 << 30
+        self.budget = budget_bytes
 
     def get(self, key, builder):
         ws = self.cache.get(key)
-        if ws is None:
-            ws = builder()
-            self.cache[key] = ws
+        if ws is not None:
+            self.cache.move_to_end(key)
+            return ws
+        ws = builder()
+        nb = _tensor_bytes(ws)
+        self.cache[key] = ws
+        self.nbytes[key] = nb
+        self.total += nb
+        if self.evictable:
+            # drop old shapes (never one touched since the current key's shape was first used in this step: those sit at the end)
+            while self.total > self.budget and len(self.cache) > 8:
+                k = next(iter(self.cache))
+                if k == key:
+                    break
+                del self.cache[k]
+                self.total -= self.nbytes.pop(k)
         return ws
 
     def f32(self, *shape):
@@ -408,6 +455,7 @@ class LSTMEncoderEngine(object):
         self.m = module
         self.flat = None
         self.wsc = None
+        self.ws_evictable = True  # False under hipGraph capture (graphs hold pointers into the workspaces)
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
@@ -442,6 +490,7 @@ class LSTMEncoderEngine(object):
                      ("lstm.bias_hh_l0", self.m.lstm.bias_hh_l0), ("linear.weight", self.m.linear.weight)]
             self.flat = FlatBuffer(named, device)
             self.wsc = _WS(device)
+            self.wsc.evictable = self.ws_evictable
         self.lib = backend_for(device)
         return self.flat
 
@@ -573,6 +622,7 @@ class LSTMDecoderEngine(object):
         self.m = module
         self.flat = None
         self.wsc = None
+        self.ws_evictable = True  # False under hipGraph capture (graphs hold pointers into the workspaces)
         self.gen = 0
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         # The BPTT chains are latency-bound (one small launch per timestep) and leave most CUs idle: the decoder's
@@ -637,6 +687,7 @@ class LSTMDecoderEngine(object):
                      ("pred_linear.weight", m.pred_linear.weight)]
             self.flat = FlatBuffer(named, device)
             self.wsc = _WS(device)
+            self.wsc.evictable = self.ws_evictable
         self.lib = backend_for(device)
         return self.flat
 

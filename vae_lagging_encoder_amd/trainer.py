@@ -8,6 +8,7 @@ captured once per (B, T) bucket into a hipGraph and replayed (`use_graph=True`).
 `inner_loop()` reproduces the data-dependent exit of text.py:366-400 with one host read every 15 iterations
 instead of one per iteration.  Data parallelism (one process per GPU) plugs in through `dist.GradSync`.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -19,6 +20,10 @@ from .engine import P
 
 class _Static(object):
     pass
+
+
+# eager mode: how many (B, T) shapes keep their per-shape step buffers (inputs, masks, per-row scalars; ~7 MB each at the Yahoo dims)
+STATIC_SHAPES = 64
 
 
 def _rank_seed(seed, grad_sync):
@@ -54,7 +59,13 @@ class AggressiveTextTrainer(object):
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
         # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
         self.rng_state = torch.tensor([_rank_seed(seed, grad_sync), 0], dtype=torch.int64, device=d)
-        self.static = {}
+        self.static = collections.OrderedDict()
+        # hipGraph mode: captured graphs hold raw pointers into the engines' workspaces, so nothing may be dropped (graph mode is
+        # for a fixed set of (B, T) buckets); eager mode: least-recently-used shapes are dropped (engine._WS, STATIC_SHAPES)
+        for e in (self.enc, self.dec):
+            e.ws_evictable = not self.use_graph
+            if e.wsc is not None:
+                e.wsc.evictable = e.ws_evictable
 
     # -- scalar views ------------------------------------------------------------------------------
     def _s(self, i):
@@ -76,7 +87,9 @@ class AggressiveTextTrainer(object):
     # -- per-(B,T) static state ----------------------------------------------------------------------
     def _static_for(self, B, T):
         st = self.static.get((B, T))
-        if st is None:
+        if st is not None:
+            self.static.move_to_end((B, T))
+        else:
             d = self.device
             V, ni, H, nz = self.dec.dims()
             st = _Static()
@@ -94,6 +107,9 @@ class AggressiveTextTrainer(object):
             st.dmulv = torch.empty(B, 2 * nz, dtype=torch.float32, device=d)
             st.graphs = {}
             self.static[(B, T)] = st
+            if not self.use_graph:
+                while len(self.static) > STATIC_SHAPES:
+                    self.static.popitem(last=False)
         return st
 
     # -- the step ----------------------------------------------------------------------------------------
