@@ -68,13 +68,32 @@ if os.path.exists(alt):
         print("skipping stale A/B library:", str(e)[:80])
 small = [("Gx", 0, TB, 4 * H, ni, X16, ni, Wi16, ni, Gx, 4 * H), ("dX", 0, TB, ni, 4 * H, dG16, 4 * H, WiT16, 4 * H, dX, ni),
          ("dW_ih", 1, 4 * H, ni, TB, dG16, 4 * H, XT16, TB, dWi, ni), ("dW_hh", 1, 4 * H, H, TB, dG16, 4 * H, hT16, TB, dWh, H),
-         ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H), ("logits", 0, R, V, H, O16, H, W16, H, logits, ldl)]
+         ("dO", 0, R, H, V, dl16, ldl, W16T, ldl, dO, H), ("dW_pred", 1, V, H, R, dl16, ldl, O16T, R, dW, H), ("logits", 0, R, V, H, O16, H, W16, H, logits, ldl)]
+def timeit_med(fn, reps=3):
+    return sorted(timeit(fn, 8) for _ in range(reps))[reps // 2]
+
+
 for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc in small:
-    line = "%-6s M=%5d N=%5d K=%5d" % (name, M, N, K)
+    line = "%-7s M=%5d N=%5d K=%5d" % (name, M, N, K)
     for ln, L in libs.items():
-        us = timeit(lambda: L.lv_gemm_b16(tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s))
-        line += " | %s %7.1f us %6.1f TF" % (ln, us, 2.0 * M * N * K / us / 1e6)
+        for tile in (128, 256):
+            L.lv_gemm_b16_set_tile(tile)
+            us = timeit_med(lambda: L.lv_gemm_b16(tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s))
+            line += " | %s/%d %7.1f us %6.1f TF" % (ln, tile, us, 2.0 * M * N * K / us / 1e6)
+        L.lv_gemm_b16_set_tile(0)
     print(line)
+# the fused vocabulary projection + NLL statistics
+x = torch.randint(0, V, (B, T), device=dev)
+l16 = torch.empty(R, ldl, dtype=torch.int16, device=dev)
+part = torch.empty(R, 2 * lib.lv_gemm_b16_nll_parts(V), device=dev)
+tg = torch.empty(R, device=dev)
+line = "logits+NLL fused   M=%5d N=%5d K=%5d" % (R, V, H)
+for tile in (128, 256):
+    lib.lv_gemm_b16_set_tile(tile)
+    us = timeit_med(lambda: lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldl, P(x), T, 1, B, P(part), P(tg), s))
+    line += " | %d %7.1f us %6.1f TF" % (tile, us, GF / us / 1e6)
+lib.lv_gemm_b16_set_tile(0)
+print(line)
 for name, f_old, f_new in rows:
     a, b = timeit(f_old), timeit(f_new)
     print("%-8s on-the-fly %7.1f us %6.1f TF | pre-rounded %7.1f us %6.1f TF" % (name, a, GF / a / 1e6, b, GF / b / 1e6))

@@ -26,6 +26,12 @@ def test_gemm_b16(emu_backend, cfg):
     K.test_gemm_b16(emu_backend, CPU, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [(0, 130, 140, 37, False), (1, 70, 130, 50, False), (1, 300, 260, 200, False), (0, 258, 100, 1100, True),
+                                 (1, 131, 270, 1100, True), (0, 520, 30, 128, False)])
+def test_gemm_b16_tile256(emu_backend, cfg):
+    K.test_gemm_b16_tile256(emu_backend, CPU, *cfg)
+
+
 @pytest.mark.parametrize("R,C", [(1, 1), (64, 64), (70, 130), (200, 33)])
 def test_cvt_bf16(emu_backend, R, C):
     K.test_cvt_bf16(emu_backend, CPU, R, C)
@@ -165,6 +171,11 @@ def test_noise_step(emu_backend):
 @pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (1, 3, 130, 8)])
 def test_gemm_b16_nll_fused(emu_backend, cfg):
     K.test_gemm_b16_nll_fused(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 600, 64)])
+def test_gemm_b16_nll_fused_tile256(emu_backend, cfg):
+    K.test_gemm_b16_nll_fused_tile256(emu_backend, CPU, *cfg)
 
 
 @pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False), (20, 7, True), (40, 3, True)])

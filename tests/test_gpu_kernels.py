@@ -152,9 +152,10 @@ def test_lstm_fwd_unit_major_gx(lib, hip_device, T, B, H, use_mask):
     (0, 257, 129, 1000, True), (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False),
     (0, 3000, 2100, 512, False), (1, 1100, 1200, 2300, True),
 ])
-def test_gemm_b16(lib, hip_device, tA, M, N, K, split):
+def test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=None):
     """Pre-rounded bf16 operands: bit-identical to lv_gemm_bf16 on the f32 data when neither splits K (same MFMA
     chain), f32-accumulate-class agreement with a float64 product of the rounded operands always."""
+    exact = (not split) if exact is None else exact
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + 2)
     lda = ((M + 7) // 8) * 8 + 8 if tA else ((K + 7) // 8) * 8 + 8
     ldb = ((K + 7) // 8) * 8
@@ -177,10 +178,26 @@ def test_gemm_b16(lib, hip_device, tA, M, N, K, split):
     out = C1.cpu()
     assert torch.equal(out[:, N:], C0[:, N:])
     assert float((out[:, :N].double() - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 8
-    if not split:
+    if exact:
         lib.lv_gemm_bf16(tA, 1, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(C2), N + 3, 1, P(a1), N, 5, None, 0, 1, None, 0,
                          _s(hip_device))
         assert torch.equal(out, C2.cpu())
+
+
+@pytest.mark.parametrize("tA,M,N,K,split", [
+    (0, 130, 140, 37, False), (1, 70, 130, 50, False), (0, 1, 1, 1, False), (1, 300, 260, 200, False), (0, 257, 513, 1000, True),
+    (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False), (0, 3000, 2100, 512, False),
+    (1, 1100, 1200, 2304, True), (0, 4200, 4100, 320, True),
+])
+def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split):
+    """The 256 x 256 x 64 kernel (forced): same checks; with a workspace the tail tiles (tiles % 256) are cut along K and reduced in
+    piece order.  Bit-identical to the 128 x 128 chain when K is a multiple of 64 and nothing is cut (the ragged K tile is
+    accumulated first here, last there)."""
+    prev = lib.lv_gemm_b16_set_tile(256)
+    try:
+        test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=(not split) and K % 64 == 0)
+    finally:
+        lib.lv_gemm_b16_set_tile(prev)
 
 
 def test_gemm_b16_alignment_errors(lib, hip_device):
@@ -884,7 +901,7 @@ def test_noise_step_equals_separate_draws(lib, hip_device):
 
 
 @pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (4, 33, 1000, 128)])
-def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
+def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=0):
     """lv_gemm_b16_nll + lv_softmax_nll_merge_f32 + lv_softmax_nll_bwd_h16 against float64: binary16 logits image = RNE of the
     exact product of the bf16 operands, lse / nll taken from the ROUNDED logits, gradient rows sum to zero."""
     dev = hip_device
@@ -902,7 +919,22 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
     part = torch.full((R, 2 * nparts), float("nan"), device=dev)
     tgt = torch.full((R,), float("nan"), device=dev)
     xd = x.to(dev)
-    lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldv, P(xd), T + 1, 1, B, P(part), P(tgt), _s(dev))
+    prev = lib.lv_gemm_b16_set_tile(tile)
+    try:
+        lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldv, P(xd), T + 1, 1, B, P(part), P(tgt), _s(dev))
+    finally:
+        lib.lv_gemm_b16_set_tile(prev)
+    if tile and H % 64 == 0:                  # both tile sizes: the same logits image and statistics, bit for bit (a ragged K tile is
+                                              # accumulated first by the 256 kernel, last by the 128 one)
+        l16b = torch.full((R, ldv), 0x7E00, dtype=torch.int16, device=dev)
+        partb = torch.full((R, 2 * nparts), float("nan"), device=dev)
+        tgtb = torch.full((R,), float("nan"), device=dev)
+        other = lib.lv_gemm_b16_set_tile(384 - tile)
+        try:
+            lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16b), ldv, P(xd), T + 1, 1, B, P(partb), P(tgtb), _s(dev))
+        finally:
+            lib.lv_gemm_b16_set_tile(other)
+        assert torch.equal(l16[:, :V].cpu(), l16b[:, :V].cpu()) and torch.equal(part.cpu(), partb.cpu()) and torch.equal(tgt.cpu(), tgtb.cpu())
     got16 = l16[:, :V].cpu().view(torch.float16)
     # binary16 RNE of an f32 accumulation of exact bf16 products: within 1 ulp of the float64 result's rounding
     assert float((got16.double() - ref16.double()).abs().max()) <= 2.0 * float(ref16.double().abs().max()) * 2 ** -11
@@ -924,6 +956,11 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H):
     assert float((got - gref).abs().max()) < 2 ** -8 * float(gref.abs().max()) + 1e-7
     assert float(got.sum(1).abs().max()) < 2 ** -7 * float(rs.max())      # rows sum to ~0 up to the bf16 rounding of the (p_target - 1) entry
     assert bool((dl[:, V:] == 0).all())
+
+
+@pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 1000, 128), (40, 32, 20001, 1024)])
+def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H):
+    test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=256)
 
 
 @pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (1, 7, False), (50, 7, True), (50, 5, True),

@@ -290,6 +290,9 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
         }
 }
 
+#ifndef LV_B16_TN_SWZ
+#define LV_B16_TN_SWZ 2    // TN image: 16-byte slot of k row k is permuted by s ^ SWZ*(k & 3) (A/B knob of the microbench)
+#endif
 #ifndef LV_B16_GLDS
 #define LV_B16_GLDS 1       // NT form through LDS-DMA staging (0: register staging for both forms; A/B knob of the microbench)
 #endif
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
         if constexpr (TN) {
             // A stored [K][M]: this lane fetches, for k row 4(4w + i) + (l >> 4) of a tile, the 8 m values of slot l & 15
             const int krow = 4 * (4 * w + i) + (l >> 4);
-            long mc = m0 / 8 + ((l & 15) ^ (2 * (krow & 3)));
+            long mc = m0 / 8 + ((l & 15) ^ (LV_B16_TN_SWZ * (krow & 3)));
             if (mc > p.lda / 8 - 1) mc = p.lda / 8 - 1;             // clamped inside the row pitch: such m only reach unwritten C rows
             ga[i] = p.A + (long)krow * p.lda + 8 * mc;
         }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int mloc = wm * 64 + 32 * i2 + 16 * ((l >> 4) & 1) + 4 * (r & 3);
-            atr[i2] = (8 * lh + kr) * 256 + (((mloc >> 3) ^ (2 * kr)) * 16) + (mloc & 7) * 2;
+            atr[i2] = (8 * lh + kr) * 256 + (((mloc >> 3) ^ (LV_B16_TN_SWZ * kr)) * 16) + (mloc & 7) * 2;
         }
     }
     auto a_frag = [&](LdsTile& Ac, int ks, int i2) -> uint4 {
@@ -562,6 +565,8 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
             for (int k = 0; k < 64; ++k)
                 if (c0 + k < p.N) sm += expf(v[k] - mx);
             p.part[(long)row * p.nparts + 2 * tn + half] = make_float2(mx, sm);
+            if (tn == p.tilesN - 1)                     // pieces counted in 256-column tiles: the (empty) ones beyond this tile
+                for (int k = 2 * p.tilesN + half; k < p.nparts; k += 2) p.part[(long)row * p.nparts + k] = make_float2(-INFINITY, 0.f);
             const int tt = row / p.Bsz, bb = row % p.Bsz;
             long tg = p.ids[(long)bb * p.ids_stride + tt + p.tgt_off];
             if (tg < 0) tg = 0;
@@ -594,6 +599,342 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
                 *c = v;
             }
         }
+}
+
+// ---- 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_bf16), one workgroup per
+// CU: the same LDS-DMA staging, images and swizzles as the 128 x 128 kernel above at twice the tile edge, i.e. half the LDS
+// fragment bytes and half the L2 -> LDS bytes per MFMA and 32 MFMAs per wave between barriers instead of 16.  LDS: two buffer
+// pairs of 2 x 32 KB = 128 KB of the CU's 160.  For the large products only (the three vocabulary-sized GEMMs of the decoder):
+// a tile is 8.4 MFLOP per K step, so the grid is cut to the 256 CUs explicitly -- whole rounds of 256 tiles run their full K
+// range and write C directly; the TAIL (tiles % 256) is split along K into `tail_s` pieces per tile so that it fills a round too
+// (dW_pred: 316 tiles = 256 + 60 x 4 pieces; dO: 100 tiles x 5 pieces = two rounds), the pieces go to the workspace as dense
+// 256 x 256 slabs and tail_reduce_t256_kernel adds them in piece order (deterministic) and applies the epilogue.
+constexpr int BT2 = 256;
+typedef uint4 LdsTile2[BT2][NCH];
+
+struct Tail256 {
+    int full;          // tiles [0, full) run the whole K range (full % 256 == 0 or the launch has no tail)
+    int tail_s;        // pieces per tail tile (1: the tail tiles run whole as well)
+    int kt_per_piece;  // K tiles per piece
+};
+
+__device__ __forceinline__ void t256_tile_of(const GemmQ& p, int s, int& tm, int& tn) {
+    const int G = 8;
+    const int nig = G * p.tilesN;
+    const int group = s / nig;
+    const int first_m = group * G;
+    const int gsz = (p.tilesM - first_m) < G ? (p.tilesM - first_m) : G;
+    tm = first_m + (s % nig) % gsz;
+    tn = (s % nig) / gsz;
+}
+
+template <bool NLL, bool TN>
+__global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
+
+    const int bid = (int)blockIdx.x;
+    const int nk_all = (p.K + BK - 1) / BK;
+    int tile, kt0, kt1, piece = -1;
+    if (bid < q.full) {
+        // whole rounds: consecutive workgroup ids land on different XCDs; give each XCD (own L2) a contiguous range of tiles
+        const int xcd = bid % 8, per = q.full / 8;
+        tile = xcd * per + bid / 8;
+        kt0 = 0; kt1 = nk_all;
+    } else {
+        const int r = bid - q.full;
+        tile = q.full + r / q.tail_s;
+        piece = r % q.tail_s;
+        kt0 = piece * q.kt_per_piece;
+        kt1 = kt0 + q.kt_per_piece;
+        if (kt1 > nk_all) kt1 = nk_all;
+        if (q.tail_s == 1) piece = -1;
+    }
+    int tm, tn;
+    t256_tile_of(p, tile, tm, tn);
+    const int m0 = tm * BT2, n0 = tn * BT2;
+
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = lv_wave_uniform(t >> 6);   // wave id in SGPRs: the LDS-DMA destinations below are scalar (M0)
+    const int wm = w >> 2, wn = w & 3;
+    const int li = l & 31, lh = l >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nfull = p.K / BK;
+
+    // staging units of this thread: wave w fills the 1 KB pieces u = 4w + i of each image (8 rows of 128 B; TN A image: 2 k rows
+    // of 512 B)
+    uint32_t oa[4], ob[4];                             // element offsets from p.A / p.B (the launcher checks they fit 32 bits)
+    int kch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * w + i;
+        const int row = 8 * u + (l >> 3);
+        const int c = (l & 7) ^ ((row >> 1) & 7);
+        kch[i] = 8 * c;
+        int ra = m0 + row, rb = n0 + row;
+        if (ra > p.M - 1) ra = p.M - 1;                // clamped, not predicated (see the 128 x 128 kernel)
+        if (rb > p.N - 1) rb = p.N - 1;
+        oa[i] = (uint32_t)((long)ra * p.lda + kch[i]);
+        ob[i] = (uint32_t)((long)rb * p.ldb + kch[i]);
+        if constexpr (TN) {
+            // A stored [K][M]: k row 2u + (l >> 5) of the tile, 16-byte slot (l & 31) ^ 4 (k & 3) of its 32
+            const int krow = 2 * u + (l >> 5);
+            long mc = m0 / 8 + ((l & 31) ^ (4 * (krow & 3)));
+            if (mc > p.lda / 8 - 1) mc = p.lda / 8 - 1;
+            oa[i] = (uint32_t)((long)krow * p.lda + 8 * mc);
+        }
+    }
+    auto stage_dma = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
+        const uint32_t k0 = (uint32_t)(kt * BK);
+        const uint32_t ka = TN ? k0 * (uint32_t)p.lda : k0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (4 * w + i));
+            lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (4 * w + i));
+        }
+    };
+    auto stage_ragged = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = 4 * w + i;
+            const int k = k0 + kch[i];
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (TN) {
+                const int krow = 2 * u + (l >> 5);
+                reinterpret_cast<uint4*>(&Ad[0][0])[64 * u + l] =
+                    k0 + krow < p.K ? *reinterpret_cast<const uint4*>(p.A + (size_t)(oa[i] + (uint32_t)k0 * (uint32_t)p.lda)) : z4;
+            } else {
+                reinterpret_cast<uint4*>(&Ad[0][0])[64 * u + l] = k < p.K ? load_chunk_masked(p.A + (size_t)(oa[i] + (uint32_t)k0), p.K - k) : z4;
+            }
+            reinterpret_cast<uint4*>(&Bd[0][0])[64 * u + l] = k < p.K ? load_chunk_masked(p.B + (size_t)(ob[i] + (uint32_t)k0), p.K - k) : z4;
+        }
+    };
+
+    const int arow = wm * 128 + li, brow = wn * 64 + li;
+    const int sx = (li >> 1) & 7;                      // swizzle key of this lane's fragment rows (rows differ by multiples of 32)
+    int atr[4] = {0, 0, 0, 0};
+    if constexpr (TN) {
+        const int r = l & 15, kr = r >> 2;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int mloc = wm * 128 + 32 * i2 + 16 * ((l >> 4) & 1) + 4 * (r & 3);
+            atr[i2] = (8 * lh + kr) * 512 + (((mloc >> 3) ^ (4 * kr)) * 16) + (mloc & 7) * 2;
+        }
+    }
+    auto a_frag = [&](LdsTile2& Ac, int ks, int i2) -> uint4 {
+        if constexpr (TN) {
+            const char* base = reinterpret_cast<const char*>(&Ac[0][0]) + atr[i2] + ks * 16 * 512;
+            const uint2 lo = lv_ds_read_tr16_b64(base), hi = lv_ds_read_tr16_b64(base + 4 * 512);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            return Ac[arow + 32 * i2][(2 * ks + lh) ^ sx];
+        }
+    };
+    // One K tile: the fragments of k-step ks + 1 are requested BEFORE the 8 MFMAs of k-step ks (pinned with scheduling barriers:
+    // left alone the compiler reads each fragment group right before its MFMAs and waits out the LDS latency eight times per tile)
+    auto mma_tile = [&](LdsTile2& Ac, LdsTile2& Bc, bool hand_over = true) {
+        uint4 fa[2][4], fb[2][2];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) fa[0][i2] = a_frag(Ac, 0, i2);
+        fb[0][0] = Bc[brow][lh ^ sx]; fb[0][1] = Bc[brow + 32][lh ^ sx];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < BK / 16) {
+                const int c = 2 * (ks + 1) + lh;
+                fb[nxt][0] = Bc[brow][c ^ sx]; fb[nxt][1] = Bc[brow + 32][c ^ sx];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
+            }
+            LV_SCHED_BARRIER();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+            LV_SCHED_BARRIER();
+        }
+        if (hand_over) LV_WAIT_VMEM();
+        __syncthreads();
+    };
+
+    // The ragged tile at the end of a K that is not a multiple of 64 goes FIRST (masked loads through registers while the
+    // accumulators are still zero and not live: behind the main loop its staging code spilled them), then the complete tiles.
+    const int nmain = (kt1 < nfull ? kt1 : nfull) - kt0;
+    if (kt1 > kt0 + nmain) {
+        stage_ragged(kt1 - 1, As0, Bs0);
+        __syncthreads();
+        mma_tile(As0, Bs0, false);
+    }
+    if (nmain > 0) stage_dma(kt0, As0, Bs0);
+    LV_WAIT_VMEM();
+    __syncthreads();
+    // branch-free staging: the tile after the last one is the last one again (a harmless reload into the idle buffer), so the
+    // loop body is the only copy of the K-tile code besides the ragged prologue
+    const int klast = kt0 + nmain - 1;
+    for (int i = 0; i < nmain; i += 2) {
+        stage_dma(kt0 + i + 1 < klast ? kt0 + i + 1 : klast, As1, Bs1);
+        LV_SCHED_BARRIER();
+        mma_tile(As0, Bs0);
+        if (i + 1 >= nmain) break;
+        stage_dma(kt0 + i + 2 < klast ? kt0 + i + 2 : klast, As0, Bs0);
+        LV_SCHED_BARRIER();
+        mma_tile(As1, Bs1);
+    }
+
+    if constexpr (NLL) {
+        // fused epilogue of the vocabulary projection (see the 128 x 128 kernel): the 256 x 256 tile goes through the 128 KB of
+        // LDS as binary16 (64 rows of 512 B per buffer, 16-byte chunks permuted by chunk ^ (row & 15) so that the row-per-lane
+        // reads below are conflict-free), thread (row rr = t & 255, half = t >> 8) owns 128 consecutive logits = two 64-column
+        // pieces of the statistics
+        auto rowptr = [&](int rr) -> char* {            // 64 tile rows of 512 B per buffer
+            const int b = rr >> 6;
+            char* base = b == 0 ? reinterpret_cast<char*>(&As0[0][0]) : b == 1 ? reinterpret_cast<char*>(&Bs0[0][0])
+                       : b == 2 ? reinterpret_cast<char*>(&As1[0][0]) : reinterpret_cast<char*>(&Bs1[0][0]);
+            return base + (rr & 63) * 512;
+        };
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = wn * 64 + j * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                    char* rowp = rowptr(rr);
+                    *reinterpret_cast<uint16_t*>(rowp + ((((cl >> 3) ^ (rr & 15)) << 4) | ((cl & 7) << 1))) =
+                        lv_f32_to_f16_bits(p.alpha * acc[i2][j][e]);
+                }
+            }
+        __syncthreads();
+        const int rr = t & 255, half = t >> 8;
+        const int row = m0 + rr;
+        if (row < p.M) {
+            const char* rowp = rowptr(rr);
+            const int tt = row / p.Bsz, bb = row % p.Bsz;
+            long tg = p.ids[(long)bb * p.ids_stride + tt + p.tgt_off];
+            if (tg < 0) tg = 0;
+            if (tg >= p.N) tg = p.N - 1;
+#pragma unroll 1
+            for (int pc = 0; pc < 2; ++pc) {
+                const int cb = 128 * half + 64 * pc;       // first column of this piece inside the tile
+                const int c0 = n0 + cb;
+                uint4 qv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qv[k] = *reinterpret_cast<const uint4*>(rowp + ((((cb >> 3) + k) ^ (rr & 15)) << 4));
+                uint16_t* dst = p.C16 + (long)row * p.ldc16 + c0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + 8 * k + 8 <= p.ldc16) reinterpret_cast<uint4*>(dst)[k] = qv[k];
+                float v[64];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t wv[4] = {qv[k].x, qv[k].y, qv[k].z, qv[k].w};
+#pragma unroll
+                    for (int h2 = 0; h2 < 4; ++h2) {
+                        v[8 * k + 2 * h2] = lv_f16_bits_to_f32((uint16_t)(wv[h2] & 0xFFFFu));
+                        v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
+                    }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 64; ++k)
+                    if (c0 + k < p.N) mx = fmaxf(mx, v[k]);
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < 64; ++k)
+                    if (c0 + k < p.N) sm += expf(v[k] - mx);
+                p.part[(long)row * p.nparts + 4 * tn + 2 * half + pc] = make_float2(mx, sm);
+                const int tl = (int)tg - c0;
+                if (tl >= 0 && tl < 64) {
+                    const int cl = cb + tl;
+                    p.tgt[row] = lv_f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(rowp + ((((cl >> 3) ^ (rr & 15)) << 4) | ((cl & 7) << 1))));
+                }
+            }
+        }
+        return;
+    }
+    if (piece >= 0) {
+        // a K piece of a tail tile: dense 256 x 256 slab (no bounds: the reduce reads only what is inside C)
+        float* slab = p.ws + ((long)(tile - q.full) * q.tail_s + piece) * (BT2 * BT2);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                    slab[rr * BT2 + col] = acc[i2][j][e];
+                }
+            }
+        return;
+    }
+    const bool plain = !p.add1 && !p.add2 && !p.accumulate;
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (l & 31);
+            if (col >= p.N) continue;
+            const int rbase = m0 + wm * 128 + i2 * 32 + 4 * (l >> 5);
+            float* cb = p.C + (long)rbase * p.ldc + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);
+                const int row = rbase + ro;
+                if (row >= p.M) continue;
+                float* c = cb + (long)ro * p.ldc;
+                float v = p.alpha * acc[i2][j][e];
+                if (!plain) {
+                    if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+                    if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+                    if (p.accumulate) v += *c;
+                }
+                *c = v;
+            }
+        }
+}
+
+// the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)
+__global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 q) {
+    const int tile = q.full + (int)blockIdx.x / 8;
+    int tm, tn;
+    t256_tile_of(p, tile, tm, tn);
+    const float* slab = p.ws + (long)(tile - q.full) * q.tail_s * (BT2 * BT2);
+    const int t = (int)threadIdx.x;
+    const int c4 = (t & 63) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rr = ((int)blockIdx.x % 8) * 32 + 4 * it + (t >> 6);
+        const int row = tm * BT2 + rr;
+        if (row >= p.M) continue;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < q.tail_s; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (long)k * (BT2 * BT2) + rr * BT2 + c4);
+            sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+        }
+        const float sv[4] = {sacc.x, sacc.y, sacc.z, sacc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = tn * BT2 + c4 + e;
+            if (col >= p.N) continue;
+            float v = p.alpha * sv[e];
+            if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
+            if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+            float* c = p.C + (long)row * p.ldc + col;
+            if (p.accumulate) v += *c;
+            *c = v;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
@@ -653,6 +994,43 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
 
 }  // namespace
 
+// ---- tile selection ------------------------------------------------------------------------------------------------------
+static int g_b16_tile = 0;            // 0: by shape; 128 / 256: forced (tests and the microbenchmarks)
+
+// 0 = choose by shape (default), 128 / 256 = force that tile edge for lv_gemm_b16 / lv_gemm_b16_nll.  Returns the previous value.
+extern "C" int lv_gemm_b16_set_tile(int tile) {
+    const int prev = g_b16_tile;
+    if (tile == 0 || tile == 128 || tile == 256) g_b16_tile = tile;
+    return prev;
+}
+
+// the 256 x 256 kernel pays on the vocabulary-sized products (2.6e11 flop at the Yahoo shape); below ~1e11 the 128 x 128 kernel's
+// finer grid and shorter prologue win (measured: profiles/microbench/gemm_b16_shapes.py)
+static bool t256_wanted(int M, int N, int K) {
+    if (g_b16_tile) return g_b16_tile == 256;
+    return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
+}
+
+// How the tail (tiles % 256) of a 256 x 256 launch is cut along K: estimated microseconds for s pieces per tail tile =
+// rounds x K tiles per piece x ~2 us per tile step + the slab traffic of the reduce ((s + 1) passes over tail x 256 KB at ~4.5 TB/s)
+static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
+    Tail256 q;
+    q.full = (int)(tiles / 256 * 256);
+    q.tail_s = 1;
+    q.kt_per_piece = nk;
+    const long tail = tiles - q.full;
+    if (tail == 0) return q;
+    double best = (double)nk * 2.0;
+    for (int s = 2; s <= 16; ++s) {
+        if (nk / s < 4 || tail * s * (long)(BT2 * BT2) > ws_floats) break;
+        const double cost = (double)lv_cdiv(tail * s, 256) * lv_cdiv(nk, s) * 2.0 + (s + 1) * tail * 0.058;
+        if (cost < best) { best = cost; q.tail_s = s; }
+    }
+    q.kt_per_piece = lv_cdiv(nk, q.tail_s);
+    q.tail_s = lv_cdiv(nk, q.kt_per_piece);
+    return q;
+}
+
 // C[M,N] = alpha * op(A) . B^T (+ add1 + add2 (+ C)), bf16 operands, f32 accumulate/output.
 // A: transA == 0 -> stored [M][K] (lda >= K); transA == 1 -> stored [K][M] (lda >= M).  B: stored [N][K] (ldb >= K).
 // All leading dimensions % 8 == 0 and bases 16 B-aligned (else LV_ERR_ALIGN).  Rows may be read up to the next
@@ -676,8 +1054,20 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     p.add1 = add1; p.ld1 = ld1; p.mod1 = mod1 > 0 ? mod1 : 1;
     p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
     p.ws = ws;
-    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     const int nk = lv_cdiv(K > 0 ? K : 1, BK);
+    if (t256_wanted(M, N, K)) {
+        p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
+        p.splits = 1; p.kt_per_split = nk;
+        const Tail256 q = t256_plan((long)p.tilesM * p.tilesN, nk, ws ? ws_floats : 0);
+        const long tail = (long)p.tilesM * p.tilesN - q.full;
+        dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
+        if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
+        else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
+        if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
+    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     const long tiles = (long)p.tilesM * p.tilesN;
     // split-K (deterministic: partial slabs + ordered reduce) when the tile count alone cannot fill 256 CUs x 2
     int splits = 1;
@@ -751,7 +1141,8 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
 // with per-row partial statistics over 64-column pieces, part [M][nparts] (max, sum exp(x - max)), nparts =
 // lv_gemm_b16_nll_parts(N), and tgt_logit [M], the logit of row r's target token ids[(r % Bsz) * ids_stride + r / Bsz +
 // tgt_off].  lv_softmax_nll_merge_f32 turns them into lse / nll; lv_softmax_nll_bwd_h16 reads the binary16 image back.
-extern "C" int lv_gemm_b16_nll_parts(int N) { return 2 * lv_cdiv(N, BT); }
+// 64-column pieces of a row, counted in whole 256-column tiles (both tile sizes fill all of them)
+extern "C" int lv_gemm_b16_nll_parts(int N) { return 4 * lv_cdiv(N, BT2); }
 
 extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
@@ -767,10 +1158,19 @@ extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda,
     p.A = A; p.B = B; p.C = nullptr; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = 0; p.alpha = 1.f; p.accumulate = 0;
     p.add1 = nullptr; p.add2 = nullptr; p.mod1 = p.mod2 = 1; p.ws = nullptr;
-    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     p.splits = 1; p.kt_per_split = lv_cdiv(K, BK);
     p.C16 = logits16; p.ldc16 = ldl16; p.ids = ids; p.ids_stride = ids_stride; p.tgt_off = tgt_off; p.Bsz = Bsz;
-    p.part = reinterpret_cast<float2*>(part); p.nparts = 2 * p.tilesN; p.tgt = tgt_logit;
+    p.part = reinterpret_cast<float2*>(part); p.nparts = lv_gemm_b16_nll_parts(N); p.tgt = tgt_logit;
+    if (t256_wanted(M, N, K)) {
+        p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
+        Tail256 q;
+        const long tiles = (long)p.tilesM * p.tilesN;
+        q.full = (int)(tiles / 256 * 256); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
+        LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
+    p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
     dim3 grid((unsigned)((long)p.tilesM * p.tilesN), 1), block(256);
     LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, true>), grid, block, 0, stream, p);
     LV_CHECK_LAUNCH();
