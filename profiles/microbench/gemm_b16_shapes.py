@@ -73,6 +73,12 @@ def timeit_med(fn, reps=3):
     return sorted(timeit(fn, 8) for _ in range(reps))[reps // 2]
 
 
+S8 = 8192
+sqA = torch.randn(S8, S8, device=dev).to(torch.bfloat16).view(torch.int16)
+sqB = torch.randn(S8, S8, device=dev).to(torch.bfloat16).view(torch.int16)
+sqC = torch.empty(S8, S8, device=dev)
+small += [("sq8k", 0, S8, S8, S8, sqA, S8, sqB, S8, sqC, S8), ("sq8kTN", 1, S8, S8, S8, sqA, S8, sqB, S8, sqC, S8),
+          ("sq4k", 0, 4096, 4096, 4096, sqA, S8, sqB, S8, sqC, S8)]
 for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc in small:
     line = "%-7s M=%5d N=%5d K=%5d" % (name, M, N, K)
     for ln, L in libs.items():

@@ -19,6 +19,7 @@
 // ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
 // consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
 #include "lv_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -290,6 +291,9 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
         }
 }
 
+#ifndef LV_B16_T256_ORDER
+#define LV_B16_T256_ORDER 0   // 256 x 256 kernel: fragments of k-step ks+1 requested before (0) / in the middle of (1) the MFMAs of k-step ks
+#endif
 #ifndef LV_B16_TN_SWZ
 #define LV_B16_TN_SWZ 2    // TN image: 16-byte slot of k row k is permuted by s ^ SWZ*(k & 3) (A/B knob of the microbench)
 #endif
@@ -315,6 +319,28 @@ __device__ __forceinline__ uint4 load_chunk_masked(const uint16_t* __restrict__ 
     for (int i = 0; i < 4; ++i)
         wv[i] &= (2 * i < valid ? 0xFFFFu : 0u) | (2 * i + 1 < valid ? 0xFFFF0000u : 0u);
     return make_uint4(wv[0], wv[1], wv[2], wv[3]);
+}
+
+// (max, sum exp(x - max)) over the first `valid` of a 64-column piece of logits; the piece inside N takes the branch without
+// per-element bounds.  exp through the hardware exp2 (lv_exp_fast): the statistics epilogue is VALU-bound -- 64 precise expf per
+// thread and piece cost as much as the tile's whole K loop at K = 1024 -- and 1-2 ulp on terms that are summed 20 001 at a time
+// and enter the loss through a logarithm are far inside the binary16 rounding of the logits themselves.
+__device__ __forceinline__ void nll_piece_stats(const float (&v)[64], int valid, float& mx, float& sm) {
+    mx = -INFINITY;
+    sm = 0.f;
+    if (valid >= 64) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) mx = fmaxf(mx, v[k]);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) sm += lv_exp_fast(v[k] - mx);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            if (k < valid) mx = fmaxf(mx, v[k]);
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            if (k < valid) sm += lv_exp_fast(v[k] - mx);
+    }
 }
 
 typedef uint4 LdsTile[BT][NCH];
@@ -556,14 +582,8 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
                     v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
                 }
             }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 64; ++k)
-                if (c0 + k < p.N) mx = fmaxf(mx, v[k]);
-            float sm = 0.f;
-#pragma unroll
-            for (int k = 0; k < 64; ++k)
-                if (c0 + k < p.N) sm += expf(v[k] - mx);
+            float mx, sm;
+            nll_piece_stats(v, p.N - c0, mx, sm);
             p.part[(long)row * p.nparts + 2 * tn + half] = make_float2(mx, sm);
             if (tn == p.tilesN - 1)                     // pieces counted in 256-column tiles: the (empty) ones beyond this tile
                 for (int k = 2 * p.tilesN + half; k < p.nparts; k += 2) p.part[(long)row * p.nparts + k] = make_float2(-INFINITY, 0.f);
@@ -692,14 +712,15 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
             oa[i] = (uint32_t)((long)krow * p.lda + 8 * mc);
         }
     }
-    auto stage_dma = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
+    auto stage_unit = [&](int kt, int i, LdsTile2& Ad, LdsTile2& Bd) {     // 2 of the 8 DMA instructions of a K tile
         const uint32_t k0 = (uint32_t)(kt * BK);
         const uint32_t ka = TN ? k0 * (uint32_t)p.lda : k0;
+        lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (4 * w + i));
+        lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (4 * w + i));
+    };
+    auto stage_dma = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (4 * w + i));
-            lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (4 * w + i));
-        }
+        for (int i = 0; i < 4; ++i) stage_unit(kt, i, Ad, Bd);
     };
     auto stage_ragged = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
         const int k0 = kt * BK;
@@ -739,9 +760,12 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
             return Ac[arow + 32 * i2][(2 * ks + lh) ^ sx];
         }
     };
-    // One K tile: the fragments of k-step ks + 1 are requested BEFORE the 8 MFMAs of k-step ks (pinned with scheduling barriers:
-    // left alone the compiler reads each fragment group right before its MFMAs and waits out the LDS latency eight times per tile)
-    auto mma_tile = [&](LdsTile2& Ac, LdsTile2& Bc, bool hand_over = true) {
+    // One K tile (Ac, Bc) while the next one (kt_next) streams into (Ad, Bd).  Pinned with scheduling barriers: the fragments of
+    // k-step ks + 1 are requested BEFORE the 8 MFMAs of k-step ks (left alone the compiler reads each fragment group right before
+    // its MFMAs and waits out the LDS latency eight times per tile), and the tile's 8 DMA instructions go out two per k-step BETWEEN
+    // the MFMAs (an LDS-DMA instruction costs 60-180 issue cycles; at the top of the tile they would all run with the pipe empty).
+    auto mma_tile = [&](auto staging, LdsTile2& Ac, LdsTile2& Bc, int kt_next, LdsTile2& Ad, LdsTile2& Bd) {
+        constexpr bool STAGE = decltype(staging)::value;
         uint4 fa[2][4], fb[2][2];
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) fa[0][i2] = a_frag(Ac, 0, i2);
@@ -749,6 +773,7 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
+#if LV_B16_T256_ORDER == 0
             if (ks + 1 < BK / 16) {
                 const int c = 2 * (ks + 1) + lh;
                 fb[nxt][0] = Bc[brow][c ^ sx]; fb[nxt][1] = Bc[brow + 32][c ^ sx];
@@ -756,13 +781,29 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
                 for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
             }
             LV_SCHED_BARRIER();
+#endif
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+            LV_SCHED_BARRIER();
+#if LV_B16_T256_ORDER == 1
+            if (ks + 1 < BK / 16) {
+                const int c = 2 * (ks + 1) + lh;
+                fb[nxt][0] = Bc[brow][c ^ sx]; fb[nxt][1] = Bc[brow + 32][c ^ sx];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
+            }
+#endif
+            if constexpr (STAGE) stage_unit(kt_next, ks, Ad, Bd);
+            LV_SCHED_BARRIER();
+#pragma unroll
+            for (int i = 2; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
             LV_SCHED_BARRIER();
         }
-        if (hand_over) LV_WAIT_VMEM();
+        if constexpr (STAGE) LV_WAIT_VMEM();
         __syncthreads();
     };
 
@@ -772,7 +813,7 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     if (kt1 > kt0 + nmain) {
         stage_ragged(kt1 - 1, As0, Bs0);
         __syncthreads();
-        mma_tile(As0, Bs0, false);
+        mma_tile(std::false_type{}, As0, Bs0, -1, As1, Bs1);
     }
     if (nmain > 0) stage_dma(kt0, As0, Bs0);
     LV_WAIT_VMEM();
@@ -781,13 +822,9 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     // loop body is the only copy of the K-tile code besides the ragged prologue
     const int klast = kt0 + nmain - 1;
     for (int i = 0; i < nmain; i += 2) {
-        stage_dma(kt0 + i + 1 < klast ? kt0 + i + 1 : klast, As1, Bs1);
-        LV_SCHED_BARRIER();
-        mma_tile(As0, Bs0);
+        mma_tile(std::true_type{}, As0, Bs0, kt0 + i + 1 < klast ? kt0 + i + 1 : klast, As1, Bs1);
         if (i + 1 >= nmain) break;
-        stage_dma(kt0 + i + 2 < klast ? kt0 + i + 2 : klast, As0, Bs0);
-        LV_SCHED_BARRIER();
-        mma_tile(As1, Bs1);
+        mma_tile(std::true_type{}, As1, Bs1, kt0 + i + 2 < klast ? kt0 + i + 2 : klast, As0, Bs0);
     }
 
     if constexpr (NLL) {
@@ -844,14 +881,8 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
                         v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
                     }
                 }
-                float mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < 64; ++k)
-                    if (c0 + k < p.N) mx = fmaxf(mx, v[k]);
-                float sm = 0.f;
-#pragma unroll
-                for (int k = 0; k < 64; ++k)
-                    if (c0 + k < p.N) sm += expf(v[k] - mx);
+                float mx, sm;
+                nll_piece_stats(v, p.N - c0, mx, sm);
                 p.part[(long)row * p.nparts + 4 * tn + 2 * half + pc] = make_float2(mx, sm);
                 const int tl = (int)tg - c0;
                 if (tl >= 0 && tl < 64) {
