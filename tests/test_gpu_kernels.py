@@ -164,22 +164,23 @@ def test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=None):
     A[:, (M if tA else K):] = float("nan")          # row padding may be read but must never reach the result
     B[:, K:] = float("nan")
     C0 = torch.randn(M, N + 3, generator=g)
-    add1 = torch.randn(5, N, generator=g)
+    mod = 5 if M % 2 else 37                         # addend rows cycle with the output row (small modulus / >= 32: two index paths)
+    add1 = torch.randn(mod, N, generator=g)
     rb = lambda x: x.to(torch.bfloat16).double()
     Aop = (A[:, :M].t() if tA else A[:, :K])
     Bop = B[:, :K].t()
-    ref = 0.5 * (rb(Aop) @ rb(Bop)) + add1[torch.arange(M) % 5].double() + C0[:, :N].double()
+    ref = 0.5 * (rb(Aop) @ rb(Bop)) + add1[torch.arange(M) % mod].double() + C0[:, :N].double()
     A16, B16 = _bf16_bits(A).to(hip_device), _bf16_bits(B).to(hip_device)
     Ad, Bd, a1 = A.to(hip_device), B.to(hip_device), add1.to(hip_device)
     C1, C2 = C0.clone().to(hip_device), C0.clone().to(hip_device)
     ws = torch.empty(1 << 24, device=hip_device) if split else None
     wsp, wsn = (P(ws), ws.numel()) if split else (None, 0)
-    lib.lv_gemm_b16(tA, M, N, K, 0.5, P(A16), lda, P(B16), ldb, P(C1), N + 3, 1, P(a1), N, 5, None, 0, 1, wsp, wsn, _s(hip_device))
+    lib.lv_gemm_b16(tA, M, N, K, 0.5, P(A16), lda, P(B16), ldb, P(C1), N + 3, 1, P(a1), N, mod, None, 0, 1, wsp, wsn, _s(hip_device))
     out = C1.cpu()
     assert torch.equal(out[:, N:], C0[:, N:])
     assert float((out[:, :N].double() - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 8
     if exact:
-        lib.lv_gemm_bf16(tA, 1, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(C2), N + 3, 1, P(a1), N, 5, None, 0, 1, None, 0,
+        lib.lv_gemm_bf16(tA, 1, M, N, K, 0.5, P(Ad), lda, P(Bd), ldb, P(C2), N + 3, 1, P(a1), N, mod, None, 0, 1, None, 0,
                          _s(hip_device))
         assert torch.equal(out, C2.cpu())
 

@@ -190,6 +190,15 @@ __device__ __forceinline__ float lv_f16_bits_to_f32(uint16_t b) {
 
 #define LV_WAVE 64
 
+// (q0 + ro) mod m for 0 <= q0 < m, 0 <= ro < 32, without a division per element: the GEMM epilogue addends are indexed by
+// row % mod, and one (hardware-less) 32-bit modulo per output element cost the K = 512 input projection 55 -> 82 us.
+__device__ __forceinline__ int lv_wrap_row(int q0, int ro, int m) {
+    if (m == 1) return 0;
+    const int q = q0 + ro;
+    if (m >= 32) return q >= m ? q - m : q;
+    return q % m;
+}
+
 // ---- status codes returned through the C ABI (0 = ok, >0 = hipError_t, <0 = argument check) ----
 #define LV_OK 0
 #define LV_ERR_ARG (-1)

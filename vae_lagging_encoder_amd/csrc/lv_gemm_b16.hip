@@ -343,6 +343,50 @@ __device__ __forceinline__ void nll_piece_stats(const float (&v)[64], int valid,
     }
 }
 
+// One 32 x 32 accumulator fragment -> C (alpha, the two row-cyclic addends, accumulate).  The addend loads are gathered before
+// the stores (a bias -- mod 1 -- is ONE load per fragment; a per-batch-row addend is 16 independent loads): with a load and a
+// modulo per element inside the store loop the bias cost the K = 512 input projection 55 -> 72 us and the decoder's z addend
+// 55 -> 98 us.  One copy of this code per fragment and no second, unchecked variant: the epilogue is straight-line code run once
+// per workgroup, and doubling it for interior tiles made the 256 x 256 kernel SLOWER (instruction fetch: Gx 48 -> 64 us).
+__device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, int rbase, int col) {
+    constexpr bool CHK = true;
+    if (CHK && col >= p.N) return;
+    if (!p.add1 && !p.add2 && !p.accumulate) {           // plain store: no per-element branches
+        float* cb = p.C + (long)rbase * p.ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ro = (e & 3) + 8 * (e >> 2);
+            if (rbase + ro < p.M) cb[(long)ro * p.ldc] = p.alpha * a[e];
+        }
+        return;
+    }
+    float ad[16];
+    if (p.add1) {
+        if (p.mod1 == 1) {
+            const float t = p.add1[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ad[e] = t;
+        } else {
+            const int q1 = rbase % p.mod1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ad[e] = p.add1[(long)lv_wrap_row(q1, (e & 3) + 8 * (e >> 2), p.mod1) * p.ld1 + col];
+        }
+    }
+    const int q2 = p.add2 ? rbase % p.mod2 : 0;
+    float* cb = p.C + (long)rbase * p.ldc + col;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ro = (e & 3) + 8 * (e >> 2);
+        if (CHK && rbase + ro >= p.M) continue;
+        float* c = cb + (long)ro * p.ldc;
+        float v = p.alpha * a[e];
+        if (p.add1) v += ad[e];
+        if (p.add2) v += p.add2[(long)lv_wrap_row(q2, ro, p.mod2) * p.ld2 + col];     // second addend: rare, loaded in place
+        if (p.accumulate) v += *c;
+        *c = v;
+    }
+}
+
 typedef uint4 LdsTile[BT][NCH];
 template <bool SINGLE> struct SecondPair { LdsTile a, b; };
 template <> struct SecondPair<true> { int unused; };
@@ -596,29 +640,28 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
         }
         return;
     }
-    const bool split = p.splits > 1;
-    float* const out = split ? p.ws + (long)blockIdx.y * p.M * p.N : p.C;
-    const long ldo = split ? p.N : p.ldc;
+    if (p.splits > 1) {
+        float* const out = p.ws + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + (l & 31);
+                if (col >= p.N) continue;
+                const int rbase = m0 + wm * 64 + i * 32 + 4 * (l >> 5);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rbase + (e & 3) + 8 * (e >> 2);
+                    if (row < p.M) out[(long)row * p.N + col] = acc[i][j][e];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (l & 31);
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-                const int row = m0 + wm * 64 + rr;
-                if (row >= p.M) continue;
-                float* c = out + (long)row * ldo + col;
-                if (split) { *c = acc[i][j][e]; continue; }
-                float v = p.alpha * acc[i][j][e];
-                if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
-                if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
-                if (p.accumulate) v += *c;
-                *c = v;
-            }
-        }
+        for (int j = 0; j < 2; ++j)
+            store_frag_f32(p, acc[i][j], m0 + wm * 64 + i * 32 + 4 * (l >> 5), n0 + wn * 64 + j * 32 + (l & 31));
 }
 
 // ---- 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_bf16), one workgroup per
@@ -909,30 +952,11 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
             }
         return;
     }
-    const bool plain = !p.add1 && !p.add2 && !p.accumulate;
 #pragma unroll
     for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (l & 31);
-            if (col >= p.N) continue;
-            const int rbase = m0 + wm * 128 + i2 * 32 + 4 * (l >> 5);
-            float* cb = p.C + (long)rbase * p.ldc + col;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ro = (e & 3) + 8 * (e >> 2);
-                const int row = rbase + ro;
-                if (row >= p.M) continue;
-                float* c = cb + (long)ro * p.ldc;
-                float v = p.alpha * acc[i2][j][e];
-                if (!plain) {
-                    if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
-                    if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
-                    if (p.accumulate) v += *c;
-                }
-                *c = v;
-            }
-        }
+        for (int j = 0; j < 2; ++j)
+            store_frag_f32(p, acc[i2][j], m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), n0 + wn * 64 + j * 32 + (l & 31));
 }
 
 // the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)

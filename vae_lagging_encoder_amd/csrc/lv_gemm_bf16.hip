@@ -197,15 +197,18 @@ __global__ __launch_bounds__(256) void lv_gemm_bf16_kernel(GemmP p) {
         for (int j = 0; j < WT; ++j) {
             const int col = n0 + wn * 32 * WT + j * 32 + (l & 31);
             if (col >= p.N) continue;
+            const int rbase = m0 + wm * 32 * WT + i * 32 + 4 * (l >> 5);
+            const int q1 = p.add1 ? rbase % p.mod1 : 0, q2 = p.add2 ? rbase % p.mod2 : 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 32 * WT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                const int ro = (e & 3) + 8 * (e >> 2);
+                const int row = rbase + ro;
                 if (row >= p.M) continue;
                 float* c = out + (long)row * ldo + col;
                 if (split) { *c = acc[i][j][e]; continue; }
                 float v = p.alpha * acc[i][j][e];
-                if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
-                if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
+                if (p.add1) v += p.add1[(long)lv_wrap_row(q1, ro, p.mod1) * p.ld1 + col];
+                if (p.add2) v += p.add2[(long)lv_wrap_row(q2, ro, p.mod2) * p.ld2 + col];
                 if (p.accumulate) v += *c;
                 *c = v;
             }
