@@ -89,6 +89,10 @@ static inline float lv_f16_bits_to_f32(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
+// the value held by lane (l ^ 1)
+static inline float lv_lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
+// two f32 -> packed binary16 (RNE), lo in bits 0..15
+static inline uint32_t lv_pack_f16x2(float lo, float hi) { return (uint32_t)lv_f32_to_f16_bits(lo) | ((uint32_t)lv_f32_to_f16_bits(hi) << 16); }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -182,6 +186,19 @@ __device__ __forceinline__ float lv_f16_bits_to_f32(uint16_t b) {
     _Float16 h;
     __builtin_memcpy(&h, &b, 2);
     return (float)h;
+}
+// the value held by lane (l ^ 1): DPP quad_perm [1,0,3,2], no LDS crossbar
+__device__ __forceinline__ float lv_lane_xor1(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, r);
+}
+typedef _Float16 lv_h2 __attribute__((ext_vector_type(2)));
+typedef float lv_f2 __attribute__((ext_vector_type(2)));
+// two f32 -> packed binary16 (RNE), lo in bits 0..15
+__device__ __forceinline__ uint32_t lv_pack_f16x2(float lo, float hi) {
+    lv_f2 f; f.x = lo; f.y = hi;
+    const lv_h2 h = __builtin_convertvector(f, lv_h2);
+    return __builtin_bit_cast(uint32_t, h);
 }
 #endif
 

@@ -881,19 +881,30 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
                        : b == 2 ? reinterpret_cast<char*>(&As1[0][0]) : reinterpret_cast<char*>(&Bs1[0][0]);
             return base + (rr & 63) * 512;
         };
+        // Write phase: a lane holds ONE column of 16 rows per fragment, its neighbour (lane ^ 1) the next column.  Rows are taken
+        // in pairs (e, e + 1): the even lane sends its row e + 1 and keeps row e, the odd lane the other way round (one DPP move),
+        // so every lane stores one packed pair (two adjacent columns of one row) -- 64 ds_write_b32 per thread instead of 128
+        // ds_write_b16, one conversion instruction per pair.  Address = buffer + row * 512 + (chunk ^ (row & 15)) * 16 + ...; with
+        // row & 15 = (e & 3 | odd) | 4 lh | 8 (e >> 2 & 1) the lane part and the per-e part of the XOR separate.
+        const int odd = l & 1;
 #pragma unroll
-        for (int i2 = 0; i2 < 4; ++i2)
+        for (int i2 = 0; i2 < 4; ++i2) {
+            char* const bufp = rowptr(wm * 128 + i2 * 32);                  // row (i2 & 1) * 32 of its buffer
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int cl = wn * 64 + j * 32 + (l & 31);
+                const int clp = (wn * 64 + j * 32 + (l & 31)) & ~1;          // first column of this lane's pair
+                const int lane_off = (4 * lh + odd) * 512 + ((((clp >> 3) ^ (4 * lh) ^ odd) << 4) | ((clp & 7) << 1));
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-                    char* rowp = rowptr(rr);
-                    *reinterpret_cast<uint16_t*>(rowp + ((((cl >> 3) ^ (rr & 15)) << 4) | ((cl & 7) << 1))) =
-                        lv_f32_to_f16_bits(p.alpha * acc[i2][j][e]);
+                for (int e = 0; e < 16; e += 2) {
+                    const float mine0 = acc[i2][j][e], mine1 = acc[i2][j][e + 1];
+                    const float got = lv_lane_xor1(odd ? mine0 : mine1);
+                    const uint32_t pk = odd ? lv_pack_f16x2(got, mine1) : lv_pack_f16x2(mine0, got);
+                    const int key = (e & 3) | (8 * ((e >> 2) & 1));          // compile-time part of row & 15
+                    const int roff = ((e & 3) + 8 * (e >> 2)) * 512;
+                    *reinterpret_cast<uint32_t*>(bufp + roff + (lane_off ^ (key << 4))) = pk;
                 }
             }
+        }
         __syncthreads();
         const int rr = t & 255, half = t >> 8;
         const int row = m0 + rr;
