@@ -677,6 +677,7 @@ typedef uint4 LdsTile2[BT2][NCH];
 
 struct Tail256 {
     int full;          // tiles [0, full) run the whole K range (full % 256 == 0 or the launch has no tail)
+    int tail;          // tiles [full, full + tail): the last, partial round
     int tail_s;        // pieces per tail tile (1: the tail tiles run whole as well)
     int kt_per_piece;  // K tiles per piece
 };
@@ -705,9 +706,14 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
         tile = xcd * per + bid / 8;
         kt0 = 0; kt1 = nk_all;
     } else {
-        const int r = bid - q.full;
-        tile = q.full + r / q.tail_s;
-        piece = r % q.tail_s;
+        // tail workgroups: XCD x (= workgroup id % 8, own L2) gets a contiguous range of (piece, tile) pairs in piece-major order,
+        // i.e. neighbouring tiles over the SAME K range, so that its 32 co-resident workgroups share A and B tiles in L2 (with the
+        // pieces of a tile on consecutive workgroup ids -- eight different XCDs -- dO fetched 1030 MB per launch for 296 MB of operands)
+        const int r = bid - q.full, nw = q.tail * q.tail_s;
+        const int xcd = r % 8, qq = nw / 8, rem = nw % 8;
+        const int idx = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + r / 8;
+        tile = q.full + idx % q.tail;
+        piece = idx / q.tail;
         kt0 = piece * q.kt_per_piece;
         kt1 = kt0 + q.kt_per_piece;
         if (kt1 > nk_all) kt1 = nk_all;
@@ -1085,6 +1091,7 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
     q.tail_s = 1;
     q.kt_per_piece = nk;
     const long tail = tiles - q.full;
+    q.tail = (int)tail;
     if (tail == 0) return q;
     double best = (double)nk * 2.0;
     for (int s = 2; s <= 16; ++s) {
@@ -1231,7 +1238,7 @@ extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda,
         p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
-        q.full = (int)(tiles / 256 * 256); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
+        q.full = (int)(tiles / 256 * 256); q.tail = (int)(tiles - q.full); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
         LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
