@@ -167,6 +167,11 @@ int lv_lstm_bwd_f32(const float* dh_ext, const float* dh_last, const uint8_t* dm
  * aten::embedding_dense_backward as a deterministic sorted-segment sum (padding_idx row skipped: dec_lstm.py:28) */
 int lv_embed_gather_f32(const float* emb, const int64_t* ids, long ids_stride, const uint8_t* mask, float scale,
                         float* X, int T, int B, int ni, int V, void* stream);
+/* The same lookup written straight into the bf16 operand images lv_gemm_b16 consumes (throughput configuration): dst [T*Bsz][C]
+ * (row t*Bsz + b) and/or dstT [C][T*Bsz]; keep = the dropout keep-mask [Bsz][T][C] or NULL.  Bit-identical to
+ * lv_embed_gather_f32 + lv_cvt_bf16_f32 (enc_lstm.py:50-52, dec_lstm.py:86-93). */
+int lv_embed_gather_b16(const float* emb, const int64_t* ids, long ids_stride, const uint8_t* keep, float kscale,
+                        int T, int Bsz, int C, int V, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
 int lv_token_sort(const int64_t* ids, long ids_stride, int T, int B, int V,
                   int* out_rows, int* out_tok, int* tmp /* 2*T*B ints */, void* stream);
 int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,

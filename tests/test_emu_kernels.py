@@ -207,6 +207,11 @@ def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent(emu_backend, CPU, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [(5, 3, 70, 50, True), (3, 33, 128, 90, False)])
+def test_embed_gather_into_bf16_images(emu_backend, cfg):
+    K.test_embed_gather_into_bf16_images(emu_backend, CPU, *cfg)
+
+
 def test_dropout_folded_into_image_conversion(emu_backend):
     K.test_dropout_folded_into_image_conversion(emu_backend, CPU, 5, 3, 70)
 

@@ -1110,6 +1110,29 @@ def test_dropout_folded_into_image_conversion(lib, hip_device, T, B, C):
     assert torch.equal(x.cpu(), h * ktm)
 
 
+@pytest.mark.parametrize("T,B,C,V,masked", [(5, 3, 70, 50, True), (4, 32, 512, 2000, False), (7, 33, 128, 300, True)])
+def test_embed_gather_into_bf16_images(lib, hip_device, T, B, C, V, masked):
+    """lv_embed_gather_b16: embedding lookup (+ dropout) written straight into the bf16 images [T*B][C] / [C][T*B], bit for bit what
+    lv_embed_gather_f32 followed by lv_cvt_bf16_f32 produce; out-of-range ids are clamped like there."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(T * 3 + C)
+    emb = torch.randn(V, C, generator=g).to(dev)
+    ids = torch.randint(-1, V + 1, (B, T + 1), generator=g).to(dev)           # one more column than used (ids_stride != T), ids outside [0, V)
+    keep = (torch.rand(B, T, C, generator=g) < 0.6).to(torch.uint8).to(dev) if masked else None
+    X = torch.empty(T * B, C, device=dev)
+    lib.lv_embed_gather_f32(P(emb), P(ids), T + 1, P(keep), 1.25, P(X), T, B, C, V, _s(dev))
+    ldd, ldt = (C + 7) // 8 * 8, (T * B + 7) // 8 * 8
+    ref = torch.zeros(T * B, ldd, dtype=torch.int16, device=dev); refT = torch.zeros(C, ldt, dtype=torch.int16, device=dev)
+    lib.lv_cvt_bf16_f32(P(X), C, T * B, C, P(ref), ldd, P(refT), ldt, _s(dev))
+    out = torch.zeros(T * B, ldd, dtype=torch.int16, device=dev); outT = torch.zeros(C, ldt, dtype=torch.int16, device=dev)
+    lib.lv_embed_gather_b16(P(emb), P(ids), T + 1, P(keep), 1.25, T, B, C, V, P(out), ldd, P(outT), ldt, _s(dev))
+    assert torch.equal(out.cpu(), ref.cpu()) and torch.equal(outT.cpu(), refT.cpu())
+    rows = emb.cpu()[ids.cpu()[:, :T].clamp(0, V - 1)]                         # [B][T][C]
+    if masked:
+        rows = torch.where(keep.cpu().bool(), rows * 1.25, torch.zeros(()))
+    assert torch.equal(out[:, :C].cpu(), rows.permute(1, 0, 2).reshape(T * B, C).to(torch.bfloat16).view(torch.int16))
+
+
 def test_wgrad_reduce_batched(lib, hip_device):
     """lv_wgrad_reduce_batched: the stage-2 reductions of several layers (32 -> 32 k x k and pointwise) in one launch give what
     the per-layer entries give (same partials; pointwise bit for bit, k x k up to f32 summation order)."""

@@ -1031,9 +1031,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
 // keep != nullptr: src is a time-major activation [T*Bsz][C] (row t*Bsz + b) and keep the reference-layout dropout mask
 // [Bsz][T][C]: the image is taken of src * (keep ? kscale : 0) -- nn.Dropout applied while converting, with mask loads that run
 // along C (the persistent recurrence would read the same bytes 8 per row and step: +0.3 us per timestep measured).
+// gids != nullptr: the source rows are GATHERED -- row r = t*Bsz + b of the image is row clamp(gids[b * gstride + t], 0, gV - 1) of
+// src (nn.Embedding lookup fused with the conversion: the f32 activation matrix is never written).
 __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ src, long lds_, int R, int C,
                                                       uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt,
-                                                      int gate_H, const uint8_t* __restrict__ keep, float kscale, int Bsz) {
+                                                      int gate_H, const uint8_t* __restrict__ keep, float kscale, int Bsz,
+                                                      const int64_t* __restrict__ gids, long gstride, int gV) {
     __shared__ uint16_t tile[64][66];
     const int t = (int)threadIdx.x;
     const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
@@ -1044,8 +1047,17 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
         const long gr = r0 + r, gc = c0 + lane;
         uint16_t b = 0;
         if (gr < R && gc < C) {
-            float v = src[gr * lds_ + gc];
-            if (keep) v *= keep[((gr % Bsz) * (long)(R / Bsz) + gr / Bsz) * C + gc] ? kscale : 0.f;
+            long sr = gr;
+            if (gids) {
+                sr = gids[(gr % Bsz) * gstride + gr / Bsz];
+                sr = sr < 0 ? 0 : (sr >= gV ? gV - 1 : sr);
+            }
+            float v = src[sr * lds_ + gc];
+            if (keep) {
+                const bool kp = keep[((gr % Bsz) * (long)(R / Bsz) + gr / Bsz) * C + gc] != 0;
+                if (gids) v = kp ? v * kscale : 0.f;        // as lv_embed_gather_f32 writes it (+0 for a dropped element)
+                else v *= kp ? kscale : 0.f;                // as h * (keep * scale) rounds (a dropped negative element is -0)
+            }
             b = (uint16_t)lv_f32_to_bf16_bits(v);
             if (dst) {
                 const long dr = gate_H > 0 ? (gr % gate_H) * 4 + gr / gate_H : gr;
@@ -1175,7 +1187,7 @@ extern "C" int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_
     if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
-              dst, ldd, dstT, ldt, 0, (const uint8_t*)nullptr, 1.f, 1);
+              dst, ldd, dstT, ldt, 0, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -1189,7 +1201,23 @@ extern "C" int lv_cvt_bf16_keep_f32(const float* src, long lds, int T, int Bsz, 
     if (T < 0 || Bsz <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, (int)R, C,
-              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz);
+              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, (const int64_t*)nullptr, 0L, 0);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// nn.Embedding lookup (+ nn.Dropout) straight into the bf16 operand images of the input projection (enc_lstm.py:50-52,
+// dec_lstm.py:86-93): row r = t*Bsz + b of dst [T*Bsz][C] / column r of dstT [C][T*Bsz] = emb[clamp(ids[b*ids_stride + t])] *
+// (keep ? (keep[b][t][c] ? kscale : 0) : 1), RNE -- bit-identical to lv_embed_gather_f32 followed by lv_cvt_bf16_f32, without
+// the f32 matrix in between.  keep may be NULL (no dropout).
+extern "C" int lv_embed_gather_b16(const float* emb, const int64_t* ids, long ids_stride, const uint8_t* keep, float kscale,
+                                   int T, int Bsz, int C, int V, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream) {
+    if (!emb || !ids || (!dst && !dstT)) return LV_ERR_ARG;
+    const long R = (long)T * Bsz;
+    if (T < 0 || Bsz <= 0 || C < 0 || V <= 0 || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
+    if (R == 0 || C == 0) return LV_OK;
+    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, emb, (long)C, (int)R, C,
+              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, ids, ids_stride, V);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -1202,7 +1230,7 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
     if (H <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < 4 * H)) return LV_ERR_SHAPE;
     if (C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(4 * H, 64)), dim3(256), 0, stream, src, lds, 4 * H, C,
-              dst, ldd, dstT, ldt, H, (const uint8_t*)nullptr, 1.f, 1);
+              dst, ldd, dstT, ldt, H, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -411,10 +411,11 @@ class _LstmImages(object):
     def usable(precision, native16, ni, H):
         return precision == "bf16" and native16 and ni % 8 == 0 and H % 8 == 0
 
-    def forward(self, lib, s, X, W16, Gx, add_a, add_b, rows, wsc, addend_um=None):
+    def forward(self, lib, s, X, W16, Gx, add_a, add_b, rows, wsc, addend_um=None, gather=None):
         """Gx[r][4u + g] = X[r] . W_ih[g*H + u] + (add_a + add_b)[r % rows][g*H + u]; W16: the unit-major bf16 image of W_ih
         (engine-level, _weight_images); add_a/add_b: gate-major [rows][4H] (add_b may be None), or addend_um: the addend
-        already in unit-major order."""
+        already in unit-major order.  gather = (emb, ids, ids_stride, keep, kscale, T, B, V): the layer input is an embedding
+        lookup (+ dropout) -- its bf16 images are gathered straight from the table (lv_embed_gather_b16) and X (f32) is not read."""
         TB, ni, H = self.TB, self.ni, self.H
         if addend_um is not None:
             addend = addend_um
@@ -423,7 +424,11 @@ class _LstmImages(object):
                 self.addend = wsc.f32(rows, 4 * H)
             lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
             addend = P(self.addend)
-        lib.lv_cvt_bf16_f32(X, ni, TB, ni, P(self.X), ni, P(self.XT), self.ldr, s)
+        if gather is not None:
+            emb, ids, ids_stride, keep, kscale, T, B, V = gather
+            lib.lv_embed_gather_b16(emb, ids, ids_stride, keep, kscale, T, B, ni, V, P(self.X), ni, P(self.XT), self.ldr, s)
+        else:
+            lib.lv_cvt_bf16_f32(X, ni, TB, ni, P(self.X), ni, P(self.XT), self.ldr, s)
         _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, W16, ni, Gx, 4 * H,
                 add1=addend, ld1=4 * H if rows > 1 else 0, mod1=rows)
 
@@ -537,15 +542,17 @@ class LSTMEncoderEngine(object):
         V, ni, H, nz2 = self.dims()
         w = self._ws(B, T)
         v = f.views
-        lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
+        img = self._b16(B, T)
+        if img is None:
+            lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
         # the backward's token sort depends on x only: queue it now, beside the forward chain
         self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
                       keep=(x,))
-        img = self._b16(B, T)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
             wi = self.refresh_weight_images(B, x.device)
-            img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, self.wsc)
+            img.forward(lib, s, None, P(wi.W), P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, self.wsc,
+                        gather=(P(v["embed.weight"]), P(x), T, None, 1.0, T, B, V))
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
@@ -798,7 +805,9 @@ class LSTMDecoderEngine(object):
             assert mask_in.dtype == torch.uint8 and tuple(mask_in.shape) == (B, Td, ni) and mask_in.is_contiguous()
         if mask_out is not None:
             assert mask_out.dtype == torch.uint8 and tuple(mask_out.shape) == (B, Td, H) and mask_out.is_contiguous()
-        lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
+        gather = (P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, Td, B, V)
+        if self._lstm_images(B, Td) is None:
+            lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
         self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
                       keep=(x,))
         # c0 = z W_trans^T ; h0 = tanh(c0) (dec_lstm.py:99-101) ; Zp = z W_ih[:, ni:]^T + b_ih + b_hh, so that
@@ -817,9 +826,9 @@ class LSTMDecoderEngine(object):
         if img is not None:
             wi = self.refresh_weight_images(B, x.device)
             if fused:
-                img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), None, None, B, self.wsc, addend_um=P(w.Zp))
+                img.forward(lib, s, None, P(wi.W), P(w.Gx), None, None, B, self.wsc, addend_um=P(w.Zp), gather=gather)
             else:
-                img.forward(lib, s, P(w.X), P(wi.W), P(w.Gx), P(w.Zp), None, B, self.wsc)
+                img.forward(lib, s, None, P(wi.W), P(w.Gx), P(w.Zp), None, B, self.wsc, gather=gather)
         else:
             _gemm(lib, s, 0, 1, Td * B, 4 * H, ni, P(w.X), ni, P(wih), ni + nz, P(w.Gx), 4 * H,
                   add1=P(w.Zp), ld1=4 * H, mod1=B, prec=self.precision)
