@@ -959,6 +959,37 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=0):
     assert bool((dl[:, V:] == 0).all())
 
 
+@pytest.mark.parametrize("tA,M,N,K", [(0, 2100, 2304, 4100), (1, 4500, 1024, 3000), (0, 6368, 1024, 20001)])
+def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K):
+    """Race screen of the 256 x 256 kernel's LDS-DMA hand-over and of the K-split tail: the same launch twelve times, on operands
+    that are refilled in between (so the caches hold something else), must give the same bits every time -- a fragment read that
+    overtook its DMA, or a reduce that read a slab early, shows up as a sporadic difference."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(M + K)
+    lda = (((M if tA else K) + 7) // 8) * 8
+    ldb = ((K + 7) // 8) * 8
+    A16 = _bf16_bits(torch.randn(K if tA else M, lda, generator=g)).to(dev)
+    B16 = _bf16_bits(torch.randn(N, ldb, generator=g)).to(dev)
+    ws = torch.empty(1 << 25, device=dev)
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    prev = lib.lv_gemm_b16_set_tile(256)
+    try:
+        first = None
+        for it in range(12):
+            C = torch.full((M, N), float("nan"), device=dev)
+            ws.fill_(float(it))                      # stale slabs must never be read
+            scratch.fill_(it)                        # evict the operands from L2
+            lib.lv_gemm_b16(tA, M, N, K, 1.0, P(A16), lda, P(B16), ldb, P(C), N, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
+            out = C.cpu()
+            assert bool(torch.isfinite(out).all())
+            if first is None:
+                first = out
+            else:
+                assert torch.equal(out, first), "run %d differs" % it
+    finally:
+        lib.lv_gemm_b16_set_tile(prev)
+
+
 @pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 1000, 128), (40, 32, 20001, 1024)])
 def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H):
     test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=256)
