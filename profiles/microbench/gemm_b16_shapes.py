@@ -117,11 +117,12 @@ l16 = torch.empty(R, ldl, dtype=torch.int16, device=dev)
 part = torch.empty(R, 2 * lib.lv_gemm_b16_nll_parts(V), device=dev)
 tg = torch.empty(R, device=dev)
 line = "logits+NLL fused   M=%5d N=%5d K=%5d" % (R, V, H)
-for tile in (128, 256):
-    lib.lv_gemm_b16_set_tile(tile)
-    us = timeit_med(lambda: lib.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldl, P(x), T, 1, B, P(part), P(tg), s))
-    line += " | %d %7.1f us %6.1f TF" % (tile, us, GF / us / 1e6)
-lib.lv_gemm_b16_set_tile(0)
+for ln, L in libs.items():
+    for tile in (128, 256):
+        L.lv_gemm_b16_set_tile(tile)
+        us = timeit_med(lambda: L.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldl, P(x), T, 1, B, P(part), P(tg), s))
+        line += " | %s/%d %7.1f us %6.1f TF" % (ln, tile, us, GF / us / 1e6)
+    L.lv_gemm_b16_set_tile(0)
 print(line)
 for name, f_old, f_new in rows:
     a, b = timeit(f_old), timeit(f_new)
