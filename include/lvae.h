@@ -343,6 +343,12 @@ int lv_bn_fwd_f32(const float* x, const float* gamma, const float* beta, const f
 int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
                   const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                   int accumulate_param_grads, float* ws /* lv_bn_workspace_floats(C) + 2C */, long P, int C, void* stream);
+/* The same backward with the incoming gradient given as TWO summands, dy + dy2 (dy2 may be NULL): an activation with two
+ * consumers (every residual-block output of dec_pixelcnn_v2.py:33-62) receives two gradient tensors, and adding them while the
+ * reduction pass reads them saves the separate accumulation launch (3 passes over the tensor) for one more read. */
+int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
+                   const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
+                   int accumulate_param_grads, float* ws, long P, int C, void* stream);
 /* nn.Sigmoid + the BCE of PixelCNNDecoderV2.reconstruct_error (dec_pixelcnn_v2.py:190-195, eps = 1e-12) */
 int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream);
 int lv_sigmoid_bce_bwd_f32(const float* logit, const float* x, const float* drec, float* dlogit, int B, int npix,

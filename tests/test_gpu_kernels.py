@@ -740,6 +740,19 @@ def test_batchnorm_train_fwd_bwd(lib, hip_device, N, C, H, act, use_res):
     assert float((db.cpu().double() - b64.grad).abs().max()) < 2e-4 * float(b64.grad.abs().max())
     if use_res:
         assert float((_nchw(dv.cpu(), N, H, H).double() - r64.grad).abs().max()) < 2e-4 * float(r64.grad.abs().max())
+    # the incoming gradient as two summands (lv_bn_bwd2_f32): bit for bit what their f32 sum gives
+    part = torch.randn(Pn, C, generator=g).to(dev)
+    rest = dyd - part
+    both = part + rest
+    outs = []
+    for a, b in ((both, None), (part, rest)):
+        dv2, dx2 = torch.empty(Pn, C, device=dev), torch.empty(Pn, C, device=dev)
+        dg2, db2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        lib.lv_bn_bwd2_f32(P(xd), P(a), P(b), P(y), P(mean), P(invstd), P(gd), int(act), P(dv2), P(dx2), P(dg2), P(db2), 0, P(ws), Pn, C,
+                           _s(dev))
+        outs.append((dv2.cpu(), dx2.cpu(), dg2.cpu(), db2.cpu()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
 
 
 def test_sigmoid_bce_and_dec_input(lib, hip_device):

@@ -110,6 +110,7 @@ constexpr int BN_BLOCKS = 1024;
 // MODE 1 (backward):       dv = dy * elu'(y) (act) written to dv_out; q0 = sum dv, q1 = sum dv * xhat
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ dy2,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int act,
                                                         float* __restrict__ dv_out, float* __restrict__ partial,
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                     a0 += v; a1 += v * v;
                 } else {
                     float g = dy[i];
+                    if (dy2) g += dy2[i];
                     if (act) { const float yy = y[i]; g = yy > 0.f ? g : g * (yy + 1.f); }
                     dv_out[i] = g;
                     a0 += g; a1 += g * ((x[i] - mu) * is);
@@ -240,6 +242,7 @@ constexpr int BN_V4_BLOCKS = 256;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ dy2,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, int act,
                                                            float* __restrict__ dv_out, float* __restrict__ partial,
@@ -264,6 +267,10 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
             xv[u] = *reinterpret_cast<const float4*>(x + i);
             if (MODE == 1) {
                 gv[u] = *reinterpret_cast<const float4*>(dy + i);
+                if (dy2) {                    // the incoming gradient arrives as two summands (an activation with two consumers)
+                    const float4 g2 = *reinterpret_cast<const float4*>(dy2 + i);
+                    gv[u].x += g2.x; gv[u].y += g2.y; gv[u].z += g2.z; gv[u].w += g2.w;
+                }
                 if (act) yv[u] = *reinterpret_cast<const float4*>(y + i);
             }
         }
@@ -592,7 +599,7 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
     if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
-                  (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
+                  (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
         if (bn_v4_items(C) == 8)
             LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
                       beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
@@ -605,7 +612,7 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
     int nblk = (int)((P + 3) / 4);          // few rows per block: the rows of a block are read one after the other
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
-              (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
+              (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
     LV_LAUNCH(bn_finish_fwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, P, C, eps, momentum,
               mean, invstd, run_mean, run_var);
     LV_LAUNCH(bn_apply_fwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)mean, (const float*)invstd, gamma,
@@ -636,15 +643,15 @@ extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const 
 // BatchNorm2d (train) backward.  dy = grad wrt y (post-activation); y = saved output (for ELU').  Writes
 // dv = dy*elu'(y) (also the gradient of the residual input), dgamma/dbeta (=|+=), dx.
 // ws: lv_bn_workspace_floats(C) + 2*C floats.
-extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
+extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
                              const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                              int accumulate_param_grads, float* ws, long P, int C, void* stream) {
     if (!x || !dy || !mean || !invstd || !gamma || !dv || !dx || !dgamma || !dbeta || !ws) return LV_ERR_ARG;
     if (act_elu && !y) return LV_ERR_ARG;
     if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
-    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
+    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
-        LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nb);
+        LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, dy2, y, mean, invstd, act_elu, dv, ws, P, C, nb);
         if (bn_v4_items(C) == 8)
             LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)dv,
                       (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
@@ -658,13 +665,20 @@ extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, co
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     float* dgl = ws + (long)BN_BLOCKS * 2 * C;
     float* dbl = dgl + C;
-    LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
+    LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, dy2, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
     LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgl, dbl,
               dgamma, dbeta, accumulate_param_grads);
     LV_LAUNCH(bn_apply_bwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)dv, mean, invstd, gamma,
               (const float*)dgl, (const float*)dbl, dx, P * C, C, 1.0f / (float)P);
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+// dy2 == NULL
+extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
+                             const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
+                             int accumulate_param_grads, float* ws, long P, int C, void* stream) {
+    return lv_bn_bwd2_f32(x, dy, nullptr, y, mean, invstd, gamma, act_elu, dv, dx, dgamma, dbeta, accumulate_param_grads, ws, P, C, stream);
 }
 
 extern "C" int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream) {

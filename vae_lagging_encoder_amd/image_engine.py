@@ -75,16 +75,38 @@ class Tape(object):
             self.bn_seen = []
 
     def add_grad(self, act, g):
-        """Accumulate g (a [P,C] tensor this tape owns) into the gradient of `act`."""
+        """Add g (a [P,C] tensor; never written again, so one tensor may serve as the gradient of several activations) to the
+        gradient of `act`.  The sum is DEFERRED: up to two summands stay pending, so that a consumer which can read both
+        (BatchNorm backward, lv_bn_bwd2_f32) never needs the 3-pass accumulation launch; everybody else gets them summed into
+        a fresh buffer by grad_of()."""
         k = id(act)
         cur = self.grads.get(k)
         if cur is None:
-            self.grads[k] = g
+            self.grads[k] = [g]
+        elif len(cur) == 1:
+            cur.append(g)
         else:
-            self.lib.lv_add_f32(P(cur), P(g), P(cur), cur.numel(), self.s())
+            self.grads[k] = [self._sum2(cur[0], cur[1]), g]
+
+    def _sum2(self, a, b):
+        out = torch.empty_like(a)
+        self.lib.lv_add_f32(P(a), P(b), P(out), a.numel(), self.s())
+        return out
 
     def grad_of(self, act):
-        return self.grads.get(id(act))
+        cur = self.grads.get(id(act))
+        if cur is None:
+            return None
+        if len(cur) == 2:
+            cur[:] = [self._sum2(cur[0], cur[1])]
+        return cur[0]
+
+    def grad_pair(self, act):
+        """(g, g2): the pending summands of the gradient of `act` (g2 None when there is one; (None, None) when there is none)."""
+        cur = self.grads.get(id(act))
+        if cur is None:
+            return None, None
+        return cur[0], (cur[1] if len(cur) == 2 else None)
 
     def backward(self):
         for fn in reversed(self.back):
@@ -260,13 +282,13 @@ class Tape(object):
         out = Act(y, x.N, x.H, x.W, C)
 
         def bwd():
-            dy = self.grad_of(out)
+            dy, dy2 = self.grad_pair(out)
             if dy is None:
                 return
             dv = self.f32(Pn, C)
             dx = self.f32(Pn, C)
-            lib.lv_bn_bwd_f32(P(x.t), P(dy), P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx), P(g_gamma),
-                              P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
+            lib.lv_bn_bwd2_f32(P(x.t), P(dy), P(dy2), P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx), P(g_gamma),
+                               P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
             if res is not None and res.needs_grad:
                 self.add_grad(res, dv)
             if x.needs_grad:
@@ -285,7 +307,7 @@ class Tape(object):
             if dy is None:
                 return
             if a.needs_grad:
-                self.add_grad(a, dy.clone())
+                self.add_grad(a, dy)             # shared, not cloned: gradients are never updated in place
             if b.needs_grad:
                 self.add_grad(b, dy)
         self.back.append(bwd)
