@@ -349,6 +349,11 @@ int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* 
 int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
                    const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                    int accumulate_param_grads, float* ws, long P, int C, void* stream);
+/* ... and as up to FOUR summands dy + dy2 + dy3 + dy4 (given in order, the unused ones NULL; added left to right): the outputs of
+ * the PixelCNN's main blocks feed a residual add, a direct connection and the next block (dec_pixelcnn_v2.py:88-110). */
+int lv_bn_bwd4_f32(const float* x, const float* dy, const float* dy2, const float* dy3, const float* dy4, const float* y,
+                   const float* mean, const float* invstd, const float* gamma, int act_elu, float* dv, float* dx, float* dgamma,
+                   float* dbeta, int accumulate_param_grads, float* ws, long P, int C, void* stream);
 /* nn.Sigmoid + the BCE of PixelCNNDecoderV2.reconstruct_error (dec_pixelcnn_v2.py:190-195, eps = 1e-12) */
 int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream);
 int lv_sigmoid_bce_bwd_f32(const float* logit, const float* x, const float* drec, float* dlogit, int B, int npix,

@@ -740,19 +740,28 @@ def test_batchnorm_train_fwd_bwd(lib, hip_device, N, C, H, act, use_res):
     assert float((db.cpu().double() - b64.grad).abs().max()) < 2e-4 * float(b64.grad.abs().max())
     if use_res:
         assert float((_nchw(dv.cpu(), N, H, H).double() - r64.grad).abs().max()) < 2e-4 * float(r64.grad.abs().max())
-    # the incoming gradient as two summands (lv_bn_bwd2_f32): bit for bit what their f32 sum gives
-    part = torch.randn(Pn, C, generator=g).to(dev)
-    rest = dyd - part
-    both = part + rest
-    outs = []
-    for a, b in ((both, None), (part, rest)):
-        dv2, dx2 = torch.empty(Pn, C, device=dev), torch.empty(Pn, C, device=dev)
-        dg2, db2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        lib.lv_bn_bwd2_f32(P(xd), P(a), P(b), P(y), P(mean), P(invstd), P(gd), int(act), P(dv2), P(dx2), P(dg2), P(db2), 0, P(ws), Pn, C,
-                           _s(dev))
-        outs.append((dv2.cpu(), dx2.cpu(), dg2.cpu(), db2.cpu()))
-    for u, v in zip(*outs):
-        assert torch.equal(u, v)
+    # the incoming gradient as two / four summands (lv_bn_bwd2_f32 / lv_bn_bwd4_f32): bit for bit what their left-to-right f32 sum gives
+    t1 = torch.randn(Pn, C, generator=g).to(dev)
+    t2 = torch.randn(Pn, C, generator=g).to(dev)
+    t3 = torch.randn(Pn, C, generator=g).to(dev)
+    for terms in ((t1, dyd - t1), (t1, t2, t3), (t1, t2, t3, dyd)):
+        total = terms[0]
+        for t_ in terms[1:]:
+            total = total + t_
+        outs = []
+        for args in ((total,), terms):
+            dv2, dx2 = torch.empty(Pn, C, device=dev), torch.empty(Pn, C, device=dev)
+            dg2, db2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            ptrs = [P(a) for a in args] + [None] * (4 - len(args))
+            if len(args) <= 2:
+                lib.lv_bn_bwd2_f32(P(xd), ptrs[0], ptrs[1], P(y), P(mean), P(invstd), P(gd), int(act), P(dv2), P(dx2), P(dg2), P(db2), 0, P(ws),
+                                   Pn, C, _s(dev))
+            else:
+                lib.lv_bn_bwd4_f32(P(xd), ptrs[0], ptrs[1], ptrs[2], ptrs[3], P(y), P(mean), P(invstd), P(gd), int(act), P(dv2), P(dx2), P(dg2),
+                                   P(db2), 0, P(ws), Pn, C, _s(dev))
+            outs.append((dv2.cpu(), dx2.cpu(), dg2.cpu(), db2.cpu()))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
 
 
 def test_sigmoid_bce_and_dec_input(lib, hip_device):

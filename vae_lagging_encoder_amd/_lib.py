@@ -117,6 +117,7 @@ SIGNATURES = {
     "lv_bn_fwd_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _vp],
     "lv_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
     "lv_bn_bwd2_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
+    "lv_bn_bwd4_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
     "lv_sigmoid_bce_fwd_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
     "lv_sigmoid_bce_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "lv_dec_input_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],

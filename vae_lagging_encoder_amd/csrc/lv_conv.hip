@@ -110,7 +110,8 @@ constexpr int BN_BLOCKS = 1024;
 // MODE 1 (backward):       dv = dy * elu'(y) (act) written to dv_out; q0 = sum dv, q1 = sum dv * xhat
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        const float* __restrict__ dy2,
+                                                        const float* __restrict__ dy2, const float* __restrict__ dy3,
+                                                        const float* __restrict__ dy4,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int act,
                                                         float* __restrict__ dv_out, float* __restrict__ partial,
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
                 } else {
                     float g = dy[i];
                     if (dy2) g += dy2[i];
+                    if (dy3) g += dy3[i];
+                    if (dy4) g += dy4[i];
                     if (act) { const float yy = y[i]; g = yy > 0.f ? g : g * (yy + 1.f); }
                     dv_out[i] = g;
                     a0 += g; a1 += g * ((x[i] - mu) * is);
@@ -242,7 +245,8 @@ constexpr int BN_V4_BLOCKS = 256;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           const float* __restrict__ dy2,
+                                                           const float* __restrict__ dy2, const float* __restrict__ dy3,
+                                                           const float* __restrict__ dy4,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, int act,
                                                            float* __restrict__ dv_out, float* __restrict__ partial,
@@ -267,9 +271,17 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
             xv[u] = *reinterpret_cast<const float4*>(x + i);
             if (MODE == 1) {
                 gv[u] = *reinterpret_cast<const float4*>(dy + i);
-                if (dy2) {                    // the incoming gradient arrives as two summands (an activation with two consumers)
-                    const float4 g2 = *reinterpret_cast<const float4*>(dy2 + i);
+                if (dy2) {                    // the incoming gradient arrives as up to four summands (an activation with several
+                    const float4 g2 = *reinterpret_cast<const float4*>(dy2 + i);        // consumers), added in the order given
                     gv[u].x += g2.x; gv[u].y += g2.y; gv[u].z += g2.z; gv[u].w += g2.w;
+                }
+                if (dy3) {
+                    const float4 g3 = *reinterpret_cast<const float4*>(dy3 + i);
+                    gv[u].x += g3.x; gv[u].y += g3.y; gv[u].z += g3.z; gv[u].w += g3.w;
+                }
+                if (dy4) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(dy4 + i);
+                    gv[u].x += g4.x; gv[u].y += g4.y; gv[u].z += g4.z; gv[u].w += g4.w;
                 }
                 if (act) yv[u] = *reinterpret_cast<const float4*>(y + i);
             }
@@ -599,7 +611,8 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
     if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
-                  (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nb);
+                  (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+                  (float*)nullptr, ws, P, C, nb);
         if (bn_v4_items(C) == 8)
             LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
                       beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
@@ -612,7 +625,8 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
     int nblk = (int)((P + 3) / 4);          // few rows per block: the rows of a block are read one after the other
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     LV_LAUNCH((bn_reduce_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
-              (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr, ws, P, C, nblk);
+              (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
+              (float*)nullptr, ws, P, C, nblk);
     LV_LAUNCH(bn_finish_fwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, P, C, eps, momentum,
               mean, invstd, run_mean, run_var);
     LV_LAUNCH(bn_apply_fwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)mean, (const float*)invstd, gamma,
@@ -643,15 +657,16 @@ extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const 
 // BatchNorm2d (train) backward.  dy = grad wrt y (post-activation); y = saved output (for ELU').  Writes
 // dv = dy*elu'(y) (also the gradient of the residual input), dgamma/dbeta (=|+=), dx.
 // ws: lv_bn_workspace_floats(C) + 2*C floats.
-extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
+extern "C" int lv_bn_bwd4_f32(const float* x, const float* dy, const float* dy2, const float* dy3, const float* dy4, const float* y, const float* mean, const float* invstd,
                              const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                              int accumulate_param_grads, float* ws, long P, int C, void* stream) {
     if (!x || !dy || !mean || !invstd || !gamma || !dv || !dx || !dgamma || !dbeta || !ws) return LV_ERR_ARG;
     if (act_elu && !y) return LV_ERR_ARG;
+    if ((dy3 && !dy2) || (dy4 && !dy3)) return LV_ERR_ARG;       // summands are given in order
     if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
-    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
+    if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dy3 | (uintptr_t)dy4 | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
-        LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, dy2, y, mean, invstd, act_elu, dv, ws, P, C, nb);
+        LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, dy2, dy3, dy4, y, mean, invstd, act_elu, dv, ws, P, C, nb);
         if (bn_v4_items(C) == 8)
             LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)dv,
                       (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
@@ -665,7 +680,7 @@ extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2,
     if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
     float* dgl = ws + (long)BN_BLOCKS * 2 * C;
     float* dbl = dgl + C;
-    LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, dy2, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
+    LV_LAUNCH((bn_reduce_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, stream, x, dy, dy2, dy3, dy4, y, mean, invstd, act_elu, dv, ws, P, C, nblk);
     LV_LAUNCH(bn_finish_bwd_kernel, dim3((unsigned)lv_cdiv(C, 4)), dim3(256), 0, stream, (const float*)ws, nblk, C, dgl, dbl,
               dgamma, dbeta, accumulate_param_grads);
     LV_LAUNCH(bn_apply_bwd_kernel, dim3(conv_grid(P * C)), dim3(256), 0, stream, x, (const float*)dv, mean, invstd, gamma,
@@ -674,11 +689,19 @@ extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2,
     return LV_OK;
 }
 
+extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
+                              const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
+                              int accumulate_param_grads, float* ws, long P, int C, void* stream) {
+    return lv_bn_bwd4_f32(x, dy, dy2, nullptr, nullptr, y, mean, invstd, gamma, act_elu, dv, dx, dgamma, dbeta, accumulate_param_grads, ws, P, C,
+                          stream);
+}
+
 // dy2 == NULL
 extern "C" int lv_bn_bwd_f32(const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
                              const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                              int accumulate_param_grads, float* ws, long P, int C, void* stream) {
-    return lv_bn_bwd2_f32(x, dy, nullptr, y, mean, invstd, gamma, act_elu, dv, dx, dgamma, dbeta, accumulate_param_grads, ws, P, C, stream);
+    return lv_bn_bwd4_f32(x, dy, nullptr, nullptr, nullptr, y, mean, invstd, gamma, act_elu, dv, dx, dgamma, dbeta, accumulate_param_grads, ws, P, C,
+                          stream);
 }
 
 extern "C" int lv_sigmoid_bce_fwd_f32(const float* logit, const float* x, float* rec, int B, int npix, float eps, void* stream) {

@@ -74,19 +74,21 @@ class Tape(object):
             torch._foreach_add_(self.bn_seen, 1)
             self.bn_seen = []
 
+    MAX_PENDING = 4          # summands a consumer can read at once (lv_bn_bwd4_f32)
+
     def add_grad(self, act, g):
         """Add g (a [P,C] tensor; never written again, so one tensor may serve as the gradient of several activations) to the
-        gradient of `act`.  The sum is DEFERRED: up to two summands stay pending, so that a consumer which can read both
-        (BatchNorm backward, lv_bn_bwd2_f32) never needs the 3-pass accumulation launch; everybody else gets them summed into
-        a fresh buffer by grad_of()."""
+        gradient of `act`.  The sum is DEFERRED: up to four summands stay pending, so that a consumer which can read them all
+        (BatchNorm backward, lv_bn_bwd4_f32) never needs the 3-pass accumulation launches; a residual add passes its pending
+        summands on to both inputs (grad_terms); everybody else gets them summed into a fresh buffer by grad_of()."""
         k = id(act)
         cur = self.grads.get(k)
         if cur is None:
             self.grads[k] = [g]
-        elif len(cur) == 1:
-            cur.append(g)
-        else:
-            self.grads[k] = [self._sum2(cur[0], cur[1]), g]
+            return
+        if len(cur) == self.MAX_PENDING:
+            cur[:] = [self._sum2(cur[0], cur[1])] + cur[2:]
+        cur.append(g)
 
     def _sum2(self, a, b):
         out = torch.empty_like(a)
@@ -97,16 +99,13 @@ class Tape(object):
         cur = self.grads.get(id(act))
         if cur is None:
             return None
-        if len(cur) == 2:
-            cur[:] = [self._sum2(cur[0], cur[1])]
+        while len(cur) > 1:
+            cur[:] = [self._sum2(cur[0], cur[1])] + cur[2:]
         return cur[0]
 
-    def grad_pair(self, act):
-        """(g, g2): the pending summands of the gradient of `act` (g2 None when there is one; (None, None) when there is none)."""
-        cur = self.grads.get(id(act))
-        if cur is None:
-            return None, None
-        return cur[0], (cur[1] if len(cur) == 2 else None)
+    def grad_terms(self, act):
+        """The pending summands of the gradient of `act` (a list of 1..4 tensors in arrival order), or None."""
+        return self.grads.get(id(act))
 
     def backward(self):
         for fn in reversed(self.back):
@@ -282,13 +281,14 @@ class Tape(object):
         out = Act(y, x.N, x.H, x.W, C)
 
         def bwd():
-            dy, dy2 = self.grad_pair(out)
-            if dy is None:
+            terms = self.grad_terms(out)
+            if terms is None:
                 return
+            dys = [P(t_) for t_ in terms] + [None] * (4 - len(terms))
             dv = self.f32(Pn, C)
             dx = self.f32(Pn, C)
-            lib.lv_bn_bwd2_f32(P(x.t), P(dy), P(dy2), P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx), P(g_gamma),
-                               P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
+            lib.lv_bn_bwd4_f32(P(x.t), dys[0], dys[1], dys[2], dys[3], P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx),
+                               P(g_gamma), P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
             if res is not None and res.needs_grad:
                 self.add_grad(res, dv)
             if x.needs_grad:
@@ -303,13 +303,14 @@ class Tape(object):
         out = Act(y, a.N, a.H, a.W, a.C)
 
         def bwd():
-            dy = self.grad_of(out)
-            if dy is None:
+            terms = self.grad_terms(out)
+            if terms is None:
                 return
-            if a.needs_grad:
-                self.add_grad(a, dy)             # shared, not cloned: gradients are never updated in place
-            if b.needs_grad:
-                self.add_grad(b, dy)
+            for g in list(terms):                # d(a + b) passes every pending summand on to both inputs, shared, not cloned
+                if a.needs_grad:                 # (gradients are never updated in place)
+                    self.add_grad(a, g)
+                if b.needs_grad:
+                    self.add_grad(b, g)
         self.back.append(bwd)
         return out
 
