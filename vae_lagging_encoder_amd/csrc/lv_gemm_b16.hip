@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
 #ifndef LV_B16_T256_ORDER
 #define LV_B16_T256_ORDER 0   // 256 x 256 kernel: fragments of k-step ks+1 requested before (0) / in the middle of (1) the MFMAs of k-step ks
 #endif
+#ifndef LV_B16_SINGLE_WAVES
+#define LV_B16_SINGLE_WAVES 4   // single-buffer 128 x 128 kernel: waves per SIMD its register budget is cut to (0 = unconstrained: 161 registers, 3 workgroups per CU; 4: 123-128 registers, 4 per CU -- the 1600-tile input projection then needs two rounds instead of three: 47-53 -> 43 us)
+#endif
 #ifndef LV_B16_TN_SWZ
 #define LV_B16_TN_SWZ 2    // TN image: 16-byte slot of k row k is permuted by s ^ SWZ*(k & 3) (A/B knob of the microbench)
 #endif
@@ -401,7 +404,7 @@ template <> struct SecondPair<true> { int unused; };
 // addresses of a lane group are 4 k rows x 32 contiguous bytes, on distinct banks thanks to the permutation).  The
 // register-staged lv_gemm_b16_kernel<false> did this transposition with 16 integer ops per 8 x 4 block (dW_pred: 464 us).
 template <bool SINGLE, bool NLL = false, bool TN = false>
-__global__ __launch_bounds__(256) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
+__global__ __launch_bounds__(256, (SINGLE && !NLL && LV_B16_SINGLE_WAVES) ? LV_B16_SINGLE_WAVES : 1) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
     // separate LDS objects per buffer: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove
     // disjoint (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
     __shared__ __attribute__((aligned(1024))) LdsTile As0, Bs0;
