@@ -352,8 +352,7 @@ __device__ __forceinline__ void nll_piece_stats(const float (&v)[64], int valid,
 // 55 -> 98 us.  One copy of this code per fragment and no second, unchecked variant: the epilogue is straight-line code run once
 // per workgroup, and doubling it for interior tiles made the 256 x 256 kernel SLOWER (instruction fetch: Gx 48 -> 64 us).
 __device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, int rbase, int col) {
-    constexpr bool CHK = true;
-    if (CHK && col >= p.N) return;
+    if (col >= p.N) return;
     if (!p.add1 && !p.add2 && !p.accumulate) {           // plain store: no per-element branches
         float* cb = p.C + (long)rbase * p.ldc + col;
 #pragma unroll
@@ -380,7 +379,7 @@ __device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int ro = (e & 3) + 8 * (e >> 2);
-        if (CHK && rbase + ro >= p.M) continue;
+        if (rbase + ro >= p.M) continue;
         float* c = cb + (long)ro * p.ldc;
         float v = p.alpha * a[e];
         if (p.add1) v += ad[e];
