@@ -57,10 +57,17 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
  * ids[(r % Bsz) * ids_stride + r / Bsz + tgt_off].  lv_softmax_nll_merge_f32 finishes lse / nll; lv_softmax_nll_bwd_h16 is the
  * backward over the binary16 image.  ldl16 % 8 == 0. */
 int lv_gemm_b16_nll_parts(int N);
-/* Tile selection of lv_gemm_b16 / lv_gemm_b16_nll: 0 = by shape (default: the 256 x 256 x 64 kernel, one workgroup per CU, for
- * products of >= 1e11 flop -- the three vocabulary-sized GEMMs of dec_lstm.py:117,140-146 -- else 128 x 128 x 64), 128 / 256 =
- * force that tile edge (tests, microbenchmarks).  Process-wide; returns the previous setting. */
-int lv_gemm_b16_set_tile(int tile);
+/* The same two entries with the tile edge named by the caller instead of chosen by shape: tile = 0 (by shape: the 256 x 256 x 64
+ * kernel, one workgroup per CU, for products of >= 1e11 flop -- the three vocabulary-sized GEMMs of dec_lstm.py:117,140-146 --
+ * else 128 x 128 x 64), 128 or 256 (tests, microbenchmarks; anything else LV_ERR_ARG).  A per-call argument: the library keeps no
+ * process-wide state. */
+int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float alpha,
+                     const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C, long ldc, int accumulate,
+                     const float* add1, long ld1, int mod1, const float* add2, long ld2, int mod2,
+                     float* ws, long ws_floats, void* stream);
+int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, uint16_t* logits16,
+                         long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz, float* part, float* tgt_logit,
+                         void* stream);
 int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, uint16_t* logits16, long ldl16,
                     const int64_t* ids, long ids_stride, int tgt_off, int Bsz, float* part, float* tgt_logit, void* stream);
 int lv_softmax_nll_merge_f32(const float* part, int nparts, const float* tgt_logit, float* lse, float* nll, int R, void* stream);

@@ -83,10 +83,8 @@ for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc in small:
     line = "%-7s M=%5d N=%5d K=%5d" % (name, M, N, K)
     for ln, L in list(libs.items()) * (2 if len(libs) > 1 else 1):      # A/B libraries: two interleaved passes (the first timing of a kernel runs slow)
         for tile in (128, 256):
-            L.lv_gemm_b16_set_tile(tile)
-            us = timeit_med(lambda: L.lv_gemm_b16(tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s))
+            us = timeit_med(lambda: L.lv_gemm_b16_tile(tile, tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s))
             line += " | %s/%d %7.1f us %6.1f TF" % (ln, tile, us, 2.0 * M * N * K / us / 1e6)
-        L.lv_gemm_b16_set_tile(0)
     print(line)
 # the input projection as the step runs it: with the bias addend, and with output buffers that are not cache-resident
 bias = torch.randn(4 * H, device=dev)
@@ -95,21 +93,19 @@ outs = [torch.empty(TB, 4 * H, device=dev) for _ in range(4)]
 X544 = torch.randn(TB, 544, device=dev).to(torch.bfloat16).view(torch.int16)
 W544 = torch.randn(4 * H, 544, device=dev).to(torch.bfloat16).view(torch.int16)
 it = [0]
-def gx(variant):
+def gx(variant, tile=0):
     it[0] += 1
     C = outs[it[0] % 4] if "cold" in variant else Gx
     if "544" in variant:
-        lib.lv_gemm_b16(0, TB, 4 * H, 544, 1.0, P(X544), 544, P(W544), 544, P(C), 4 * H, 0, P(zp), 4 * H, B, None, 0, 1, P(ws), ws.numel(), s)
+        lib.lv_gemm_b16_tile(tile, 0, TB, 4 * H, 544, 1.0, P(X544), 544, P(W544), 544, P(C), 4 * H, 0, P(zp), 4 * H, B, None, 0, 1, P(ws), ws.numel(), s)
     elif "bias" in variant:
-        lib.lv_gemm_b16(0, TB, 4 * H, ni, 1.0, P(X16), ni, P(Wi16), ni, P(C), 4 * H, 0, P(bias), 0, 1, None, 0, 1, P(ws), ws.numel(), s)
+        lib.lv_gemm_b16_tile(tile, 0, TB, 4 * H, ni, 1.0, P(X16), ni, P(Wi16), ni, P(C), 4 * H, 0, P(bias), 0, 1, None, 0, 1, P(ws), ws.numel(), s)
     else:
-        lib.lv_gemm_b16(0, TB, 4 * H, ni, 1.0, P(X16), ni, P(Wi16), ni, P(C), 4 * H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
+        lib.lv_gemm_b16_tile(tile, 0, TB, 4 * H, ni, 1.0, P(X16), ni, P(Wi16), ni, P(C), 4 * H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
 for variant in ("plain", "bias", "cold", "bias cold", "544 zp", "544 zp cold"):
     line = "Gx %-12s" % variant
     for tile in (128, 256):
-        lib.lv_gemm_b16_set_tile(tile)
-        line += " | %d %7.1f us" % (tile, timeit_med(lambda: gx(variant)))
-    lib.lv_gemm_b16_set_tile(0)
+        line += " | %d %7.1f us" % (tile, timeit_med(lambda: gx(variant, tile)))
     print(line)
 # the fused vocabulary projection + NLL statistics
 x = torch.randint(0, V, (B, T), device=dev)
@@ -119,10 +115,8 @@ tg = torch.empty(R, device=dev)
 line = "logits+NLL fused   M=%5d N=%5d K=%5d" % (R, V, H)
 for ln, L in libs.items():
     for tile in (128, 256):
-        L.lv_gemm_b16_set_tile(tile)
-        us = timeit_med(lambda: L.lv_gemm_b16_nll(R, V, H, P(O16), H, P(W16), H, P(l16), ldl, P(x), T, 1, B, P(part), P(tg), s))
+        us = timeit_med(lambda: L.lv_gemm_b16_nll_tile(tile, R, V, H, P(O16), H, P(W16), H, P(l16), ldl, P(x), T, 1, B, P(part), P(tg), s))
         line += " | %s/%d %7.1f us %6.1f TF" % (ln, tile, us, GF / us / 1e6)
-    L.lv_gemm_b16_set_tile(0)
 print(line)
 for name, f_old, f_new in rows:
     a, b = timeit(f_old), timeit(f_new)

@@ -19,11 +19,12 @@ def emu_backend():
     import ctypes
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     from build_emu import build_emu
-    from vae_lagging_encoder_amd import _lib, engine
+    import install as emu_install
+    from vae_lagging_encoder_amd import _lib
     lib = _lib.bind(ctypes.CDLL(build_emu()), "tests/emu/liblvae_emu.so")
-    engine._install_test_backend(lib)
+    emu_install.install(lib)
     yield lib
-    engine._install_test_backend(None)
+    emu_install.install(None)
 
 
 @pytest.fixture(scope="session")

@@ -257,6 +257,35 @@ def check_bf16_native_operands_equal_on_the_fly(device, V=333, ni=24, H=64, nz=8
         assert rel_err(g1[k], g0[k]) < 5e-3, (k, rel_err(g1[k], g0[k]))
 
 
+def check_weight_images_follow_rebound_parameters(device, V=333, ni=24, H=64, nz=8, B=7, T=11):
+    """The decoder caches its bf16 weight images across calls (it is frozen for the whole inner loop).  `p.data = X` (what
+    `module._apply`, a `.half().float()` round trip or a hand-written load do) keeps the parameters' version counters, so the
+    cache must also be dropped when the engine re-binds its flat buffer -- otherwise the bf16 path keeps multiplying with the
+    OLD weights.  Two decoders, same final weights, one of them rebound after a first step: same loss."""
+    from oracle import text_vae_oracle as O
+    P0 = O.random_params(V, ni, H, nz, seed=41, scale=0.2, emb_scale=0.5, head_scale=0.5)
+    P1 = O.random_params(V, ni, H, nz, seed=42, scale=0.2, emb_scale=0.5, head_scale=0.5)
+    x = O.synthetic_batch(B, T, V, seed=43).to(device)
+    eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=44)
+    noise = (eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device))
+
+    def bf16(vae):
+        vae.encoder._hip.precision = vae.decoder._hip.precision = "bf16"
+        return vae
+    ref = bf16(build_vae(V, ni, H, nz, device, params=P1))
+    want = ref.loss(x, 0.6, noise=noise)[0].detach().cpu()
+    vae = bf16(build_vae(V, ni, H, nz, device, params=P0))
+    first = vae.loss(x, 0.6, noise=noise)[0].detach().cpu()
+    assert vae.decoder._hip._wimg is not None                 # the cached images exist (bf16 image route in use)
+    assert not torch.allclose(first, want, rtol=1e-3)
+    sd = vae.state_dict()
+    for k, p in vae.named_parameters():
+        p.data = P1[k].to(device).clone()                      # rebinding: _version is preserved
+        assert k in sd
+    got = vae.loss(x, 0.6, noise=noise)[0].detach().cpu()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # joint step after aggressive mode ends (text.py:418-421: encoder AND decoder stepped) and the fixed-K loop of the stress config
 def check_update_both_and_fixed_k(device, V=97, ni=12, H=20, nz=4, B=6, K=4, precision="f32", tol=5e-4):

@@ -3,6 +3,7 @@ signature table the ctypes binding uses.  No compute calls (no GPU needed)."""
 import ctypes
 import os
 import re
+import sys
 
 from vae_lagging_encoder_amd import _lib, build
 
@@ -46,14 +47,16 @@ def test_argument_checks_return_negative_status_without_touching_the_gpu():
 def test_package_has_no_cpu_fallback():
     import torch
     from vae_lagging_encoder_amd import engine
-    assert engine._TEST_BACKEND is None or True   # the session fixture may have installed the emulator
-    saved = engine._TEST_BACKEND
-    engine._install_test_backend(None)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import install as emu_install
+    saved = emu_install.install(None)       # the session fixture may have installed the emulator
     try:
         try:
             engine.backend_for(torch.device("cpu"))
             raise AssertionError("CPU tensors must be refused")
         except _lib.LvaeError:
             pass
+        # and the package itself carries no switch for it
+        assert not any("TEST_BACKEND" in n.upper() or "install_test" in n for n in dir(engine))
     finally:
-        engine._install_test_backend(saved)
+        emu_install.install(saved)

@@ -14,14 +14,17 @@ def test_inner_step_matches_reference_fixture_emulated(emu_backend, name):
 
 
 def test_cpu_tensors_refused_without_test_backend():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import install as emu_install
     from vae_lagging_encoder_amd import _lib, engine
-    saved = engine._TEST_BACKEND
-    engine._install_test_backend(None)
+    saved = emu_install.install(None)
     try:
         with pytest.raises(_lib.LvaeError):
             engine.backend_for(torch.device("cpu"))
     finally:
-        engine._install_test_backend(saved)
+        emu_install.install(saved)
 
 
 def test_fused_trainer_trajectory_emulated(emu_backend):
@@ -53,3 +56,7 @@ def test_image_step_fused_emulated(emu_backend):
     """The Omniglot inner step (ResNet encoder + PixelCNN decoder, direct 32 -> 32 convolutions, BN, Adam) against the reference
     fixture on the emulator build of the same kernel sources (~1 min)."""
     pc.check_image_step_fused("image_b6", "cpu")
+
+
+def test_weight_images_follow_rebound_parameters_emulated(emu_backend):
+    pc.check_weight_images_follow_rebound_parameters("cpu")

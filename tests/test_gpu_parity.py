@@ -96,6 +96,12 @@ def test_bf16_native_operands_equal_on_the_fly(hip_device):
     pc.check_bf16_native_operands_equal_on_the_fly(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30)
 
 
+@pytest.mark.gpu
+def test_weight_images_follow_rebound_parameters(hip_device):
+    pc.check_weight_images_follow_rebound_parameters(hip_device)
+    pc.check_weight_images_follow_rebound_parameters(hip_device, V=2003, ni=64, H=1024, nz=32, B=32, T=12)   # persistent route: packed W_hh too
+
+
 def _seeded_full_size_vae(fx, device):
     """Weights regenerated from the reference seed through the same nn.Module construction order (+ the same post-init
     redraws of the encoder head / vocabulary projection the fixture script applied); checked against the stored samples."""
@@ -165,15 +171,12 @@ def test_yahoo_full_size_fixture(hip_device):
     _check_full_size_fixture_dropin(hip_device, "text_yahoo_seeded")
 
 
-def test_bf16_headline_path_at_headline_shape(hip_device):
-    """The arithmetic the bench line is quoted on -- bf16 operand images, bf16 recurrent operands, persistent XCD-group
-    LSTM launches -- at the bench shape itself (B=32, T=200, V=20001, H=1024) against the REFERENCE run of the same
-    seeded model, inputs and noise (tests/golden/text_yahoo_seeded.npz).  The model-dependent part of the loss is
-    rec - (T-1) ln V (48.7 per sequence here); bf16 operand rounding over 200 steps of BPTT is what this test sees and
-    a T=14 test does not.  Measured deltas are written to gpurun_out/ and asserted below."""
+def _check_bf16_against_full_size_fixture(hip_device, name, out_name, kl_bound):
+    """One fused inner step in the throughput arithmetic against a full-size REFERENCE fixture; writes the measured deltas to
+    gpurun_out/<out_name>.json and returns them."""
     import json, math, os
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
-    fx = load("text_yahoo_seeded")
+    fx = load(name)
     vae = _seeded_full_size_vae(fx, hip_device)
     p0 = {k: v.detach().clone() for k, v in vae.state_dict().items()}
     x = torch.from_numpy(fx["x"]).to(hip_device)
@@ -214,16 +217,41 @@ def test_bf16_headline_path_at_headline_shape(hip_device):
     for k in DEC_KEYS:                                      # encoder-only step: decoder untouched
         assert torch.equal(vae.state_dict()[k], p0[k]), k
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "bf16_headline_parity.json"), "w") as fh:
+    with open(os.path.join("gpurun_out", out_name + ".json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print("bf16 headline parity:", json.dumps(out))
-    # Bounds = ~5-10x the deltas measured on MI355X (profiles/r02_bf16_headline_parity.json: loss 1.8e-6, rec excess 7.5e-5,
-    # KL 2.1e-4, norm 1.3e-6, per-tensor grad norms <= 1.5e-4, sampled grad entries within 1.9 % of the tensor's RMS,
-    # encoder update 2.8e-3): the bf16 configuration meets the north-star's 1e-4 ELBO bound at the headline shape.
+    print(out_name + ":", json.dumps(out))
+    # The bf16 configuration's contract: ELBO and reconstruction NLL within north_star's 1e-4 of the
+    # reference; KL within 1e-3 -- the KL is a function of the encoder's LAST hidden state alone, and 100-200 recurrent steps
+    # on bf16 operands move that state by ~1e-3 relative (the exact-f32 path meets 1e-4 on all three: the *_full_size_fixture
+    # tests above).  Bounds on the gradient side = ~5-10x the deltas measured on MI355X (profiles/r02_bf16_headline_parity.json:
+    # loss 1.8e-6, rec excess 7.5e-5, KL 2.1e-4, norm 1.3e-6, per-tensor grad norms <= 1.5e-4, sampled grad entries within
+    # 1.9 % of the tensor's RMS, encoder update 2.8e-3).
     assert out["loss_rel"] < 1e-4 and out["rec_rel"] < 1e-4, out
-    assert out["rec_excess_rel"] < 1e-3 and out["kl_rel"] < 2e-3, out
+    assert out["rec_excess_rel"] < 1e-3 and out["kl_rel"] < kl_bound, out
     assert out["norm_rel"] < 1e-4 and out["gradnorm_rel_max"] < 2e-3, out
     assert out["grad_sample_err_over_rms_max"] < 0.1 and out["enc_update_rel_max"] < 2e-2, out
+    return out
+
+
+def test_bf16_headline_path_at_headline_shape(hip_device):
+    """The arithmetic the bench line is quoted on -- bf16 operand images, bf16 recurrent operands, persistent XCD-group
+    LSTM launches -- at the bench shape itself (B=32, T=200, V=20001, H=1024) against the REFERENCE run of the same
+    seeded model, inputs and noise (tests/golden/text_yahoo_seeded.npz).  The model-dependent part of the loss is
+    rec - (T-1) ln V (48.7 per sequence here); bf16 operand rounding over 200 steps of BPTT is what this test sees and
+    a T=14 test does not."""
+    _check_bf16_against_full_size_fixture(hip_device, "text_yahoo_seeded", "bf16_headline_parity", kl_bound=1e-3)
+
+
+def test_bf16_yelp_shape_against_reference_fixture(hip_device):
+    """BASELINE.json configs[1] ("Yelp LSTM-VAE bf16, bsz=32"): the throughput arithmetic at T=100, V=19997 against the
+    reference run on NON-degenerate weights (tests/golden/text_yelp_wide_seeded.npz: logits that matter, KL 0.23, clip
+    coefficient 0.09) -- the fixture at the reference init has loss == (T-1) ln V whatever the model computes."""
+    _check_bf16_against_full_size_fixture(hip_device, "text_yelp_wide_seeded", "bf16_yelp_parity", kl_bound=1e-3)
+
+
+def test_yelp_wide_full_size_fixture(hip_device):
+    """The same non-degenerate Yelp-shaped fixture on the exact-f32 drop-in path, <= 1e-4 (north_star)."""
+    _check_full_size_fixture_dropin(hip_device, "text_yelp_wide_seeded")
 
 
 def test_bf16_trajectory_at_h1024_tracks_oracle(hip_device):
@@ -413,6 +441,48 @@ def test_stress_batch_at_h1024(hip_device):
     sd = vae.state_dict()
     assert all(bool(torch.isfinite(sd[k]).all()) for k in ALL_KEYS)
     assert all(torch.equal(sd[k], dec0[k]) for k in DEC_KEYS)
+
+
+def test_stress_config_at_full_size(hip_device):
+    """BASELINE.json configs[4] AT ITS OWN SIZE: Yahoo dims (V=20001, ni=512, H=1024, nz=32), B = 128 sequences, T = 200, fixed
+    K = 50 inner steps, bf16 configuration.  (i) step 1: per-sequence loss / rec / KL of a 32-row slice against the oracle's
+    forward on those rows (the rows of a batch are independent in the forward pass; the gradient is a batch mean and is covered
+    at B = 128 by test_stress_batch_at_h1024); (ii) the 50-step loop is finite, moves only the encoder, and is bit-reproducible
+    from the same seeds (Philox noise, same host batch picks)."""
+    import numpy as np
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    V, ni, H, nz, B, T, klw, K = 20001, 512, 1024, 32, 128, 200, 0.5, 50
+    P = O.random_params(V, ni, H, nz, seed=81, scale=0.03, head_scale=0.2)
+    pool = [O.synthetic_batch(B, T, V, seed=90 + i) for i in range(4)]
+    eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=83)
+    rows = slice(48, 80)
+    with torch.no_grad():
+        l_ref, rec_ref, kl_ref = O.vae_loss(P, pool[0][rows], klw, eps[rows], m_in[rows], m_out[rows], impl="aten")
+    finals = []
+    for rep in range(2):
+        vae = build_vae(V, ni, H, nz, hip_device, params=P)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16", seed=4242)
+        dpool = [b.to(hip_device) for b in pool]
+        if rep == 0:
+            st = tr._static_for(B, T)
+            tr.step(dpool[0], klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+            torch.cuda.synchronize()
+            for name, got, ref in (("loss", st.loss, l_ref), ("rec", st.rec, rec_ref), ("kl", st.kl, kl_ref)):
+                e = rel_err(got[rows], ref.reshape(-1))
+                assert e < (1e-4 if name != "kl" else 1e-3), (name, e)
+            # start the loop from the same weights in both repetitions
+            vae = build_vae(V, ni, H, nz, hip_device, params=P)
+            tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16", seed=4242)
+        dec0 = {k: vae.state_dict()[k].clone() for k in DEC_KEYS}
+        steps = tr.inner_loop(dpool, dpool[0], klw, np_rng=np.random.RandomState(5), fixed_k=K)
+        assert steps == K
+        sd = {k: v.clone() for k, v in vae.state_dict().items()}
+        assert all(bool(torch.isfinite(sd[k]).all()) for k in ALL_KEYS)
+        assert all(torch.equal(sd[k], dec0[k]) for k in DEC_KEYS)
+        assert any(not torch.equal(sd[k].cpu(), P[k]) for k in ENC_KEYS)
+        finals.append(sd)
+    for k in ALL_KEYS:
+        assert torch.equal(finals[0][k], finals[1][k]), k
 
 
 def test_image_inner_loop_with_data_dependent_exit(hip_device):

@@ -23,7 +23,8 @@ SIGNATURES = {
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16_nll_parts": [_i],
-    "lv_gemm_b16_set_tile": [_i],
+    "lv_gemm_b16_tile": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_b16_nll_tile": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp],
     "lv_gemm_b16_nll": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp],
     "lv_softmax_nll_merge_f32": [_vp, _i, _vp, _vp, _vp, _i, _vp],
     "lv_softmax_nll_bwd_h16": [_vp, _l, _vp, _vp, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp],
@@ -152,7 +153,7 @@ class Lib(object):
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_gemm_b16_set_tile", "lv_conv32_wpack_floats",
+        self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
 

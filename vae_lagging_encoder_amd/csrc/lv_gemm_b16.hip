@@ -1090,19 +1090,11 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
 }  // namespace
 
 // ---- tile selection ------------------------------------------------------------------------------------------------------
-static int g_b16_tile = 0;            // 0: by shape; 128 / 256: forced (tests and the microbenchmarks)
-
-// 0 = choose by shape (default), 128 / 256 = force that tile edge for lv_gemm_b16 / lv_gemm_b16_nll.  Returns the previous value.
-extern "C" int lv_gemm_b16_set_tile(int tile) {
-    const int prev = g_b16_tile;
-    if (tile == 0 || tile == 128 || tile == 256) g_b16_tile = tile;
-    return prev;
-}
-
 // the 256 x 256 kernel pays on the vocabulary-sized products (2.6e11 flop at the Yahoo shape); below ~1e11 the 128 x 128 kernel's
-// finer grid and shorter prologue win (measured: profiles/microbench/gemm_b16_shapes.py)
-static bool t256_wanted(int M, int N, int K) {
-    if (g_b16_tile) return g_b16_tile == 256;
+// finer grid and shorter prologue win (measured: profiles/microbench/gemm_b16_shapes.py).  tile: 0 = by shape, 128 / 256 = the
+// caller names the tile edge (lv_gemm_b16_tile / lv_gemm_b16_nll_tile: tests and microbenchmarks; no process-wide state).
+static bool t256_wanted(int tile, int M, int N, int K) {
+    if (tile) return tile == 256;
     return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
 }
 
@@ -1131,12 +1123,13 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
 // A: transA == 0 -> stored [M][K] (lda >= K); transA == 1 -> stored [K][M] (lda >= M).  B: stored [N][K] (ldb >= K).
 // All leading dimensions % 8 == 0 and bases 16 B-aligned (else LV_ERR_ALIGN).  Rows may be read up to the next
 // multiple of 8 elements past their logical end (never past ld); what lies there never reaches C.
-extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
-                           const uint16_t* A, long lda, const uint16_t* B, long ldb,
-                           float* C, long ldc, int accumulate,
-                           const float* add1, long ld1, int mod1,
-                           const float* add2, long ld2, int mod2,
-                           float* ws, long ws_floats, void* stream) {
+extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float alpha,
+                                const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                float* C, long ldc, int accumulate,
+                                const float* add1, long ld1, int mod1,
+                                const float* add2, long ld2, int mod2,
+                                float* ws, long ws_floats, void* stream) {
+    if (tile != 0 && tile != 128 && tile != 256) return LV_ERR_ARG;
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
@@ -1151,7 +1144,7 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
     p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
     p.ws = ws;
     const int nk = lv_cdiv(K > 0 ? K : 1, BK);
-    if (t256_wanted(M, N, K)) {
+    if (t256_wanted(tile, M, N, K)) {
         p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
         p.splits = 1; p.kt_per_split = nk;
         const Tail256 q = t256_plan((long)p.tilesM * p.tilesN, nk, ws ? ws_floats : 0);
@@ -1189,6 +1182,17 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
         LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+// The same with the tile edge chosen by shape (the product's entry).
+extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
+                           const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                           float* C, long ldc, int accumulate,
+                           const float* add1, long ld1, int mod1,
+                           const float* add2, long ld2, int mod2,
+                           float* ws, long ws_floats, void* stream) {
+    return lv_gemm_b16_tile(0, transA, M, N, K, alpha, A, lda, B, ldb, C, ldc, accumulate, add1, ld1, mod1, add2, ld2, mod2, ws,
+                            ws_floats, stream);
 }
 
 // src f32 [R][C] (lds) -> dst bf16 [R][C] (ldd) and/or dstT bf16 [C][R] (ldt); either destination may be null.
@@ -1256,9 +1260,10 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
 // 64-column pieces of a row, counted in whole 256-column tiles (both tile sizes fill all of them)
 extern "C" int lv_gemm_b16_nll_parts(int N) { return 4 * lv_cdiv(N, BT2); }
 
-extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
-                               uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
-                               float* part, float* tgt_logit, void* stream) {
+extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                    uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
+                                    float* part, float* tgt_logit, void* stream) {
+    if (tile != 0 && tile != 128 && tile != 256) return LV_ERR_ARG;
     if (M < 0 || N <= 0 || K <= 0 || Bsz <= 0) return LV_ERR_SHAPE;
     if (M == 0) return LV_OK;
     if (!A || !B || !logits16 || !ids || !part || !tgt_logit) return LV_ERR_ARG;
@@ -1273,7 +1278,7 @@ extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda,
     p.splits = 1; p.kt_per_split = lv_cdiv(K, BK);
     p.C16 = logits16; p.ldc16 = ldl16; p.ids = ids; p.ids_stride = ids_stride; p.tgt_off = tgt_off; p.Bsz = Bsz;
     p.part = reinterpret_cast<float2*>(part); p.nparts = lv_gemm_b16_nll_parts(N); p.tgt = tgt_logit;
-    if (t256_wanted(M, N, K)) {
+    if (t256_wanted(tile, M, N, K)) {
         p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
@@ -1287,4 +1292,10 @@ extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda,
     LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, true>), grid, block, 0, stream, p);
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+extern "C" int lv_gemm_b16_nll(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                               uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
+                               float* part, float* tgt_logit, void* stream) {
+    return lv_gemm_b16_nll_tile(0, M, N, K, A, lda, B, ldb, logits16, ldl16, ids, ids_stride, tgt_off, Bsz, part, tgt_logit, stream);
 }

@@ -69,8 +69,11 @@ class MonoTextData(object):
         with open(fname) as fin:
             for line in fin:
                 if label:
-                    lb, _, rest = line.partition("\t")
-                    words = rest.split()
+                    # the reference reads field 0 as the label and field 1 ONLY as the sentence (text_data.py:89-91): further
+                    # tab-separated columns are ignored, and a labelled line without a tab is an error there (IndexError), not a
+                    # dropped sentence
+                    fields = line.split("\t")
+                    lb, words = fields[0], fields[1].split()
                 else:
                     words = line.split()
                 if not words or (max_length and len(words) > max_length):

@@ -16,23 +16,13 @@ import torch
 from . import _lib
 
 # ---- backend selection -------------------------------------------------------------------------------
-_TEST_BACKEND = None   # set ONLY by tests (tests/emu) to run the host sequencing against the emulator build
-
-
-def _install_test_backend(lib):
-    """TEST HOOK (tests/emu only): route CPU tensors to an emulator build of the same kernel sources.
-
-    The product never calls this; without it, any non-CUDA tensor raises.  See tests/emu/README.md."""
-    global _TEST_BACKEND
-    _TEST_BACKEND = lib
-
-
 def backend_for(device):
+    """The C-ABI library for tensors on `device`: the gfx950 build for ROCm 'cuda' devices, nothing else.  (The GPU-less CI
+    substitutes this function from outside the package -- tests/emu/install.py -- to drive the same host code against an
+    emulator build of the kernel sources; the package itself has no such path.)"""
     device = torch.device(device)
     if device.type == "cuda":
         return _lib.load()
-    if _TEST_BACKEND is not None and device.type == "cpu":
-        return _TEST_BACKEND
     raise _lib.LvaeError(
         "vae_lagging_encoder_amd runs on MI355X (ROCm 'cuda' tensors) through its HIP extension; got a %s tensor. "
         "There is no CPU fallback." % device.type)
@@ -127,6 +117,7 @@ class _WS(object):
         self.nbytes = {}
         self.total = 0
         self.evictable = True
+        self.before_evict = None      # called once before workspaces are dropped (the engine orders its side streams first)
         if budget_bytes is None:
             if self.device.type == "cuda":
                 budget_bytes = int(WORKSPACE_BUDGET_FRACTION * torch.cuda.get_device_properties(self.device).total_memory)
@@ -144,15 +135,32 @@ class _WS(object):
         self.cache[key] = ws
         self.nbytes[key] = nb
         self.total += nb
-        if self.evictable:
-            # drop old shapes (never one touched since the current key's shape was first used in this step: those sit at the end)
-            while self.total > self.budget and len(self.cache) > 8:
-                k = next(iter(self.cache))
-                if k == key:
-                    break
-                del self.cache[k]
-                self.total -= self.nbytes.pop(k)
+        self._trim(key)
         return ws
+
+    def grew(self, key, nbytes):
+        """A workspace of `key` allocated another buffer after it was built (lazily created images): count it."""
+        if key in self.nbytes:
+            self.nbytes[key] += nbytes
+            self.total += nbytes
+            self._trim(key)
+
+    def _trim(self, key):
+        if not self.evictable:
+            return
+        # drop old shapes (never one touched since the current key's shape was first used in this step: those sit at the end)
+        told = False
+        while self.total > self.budget and len(self.cache) > 8:
+            k = next(iter(self.cache))
+            if k == key:
+                break
+            if not told and self.before_evict is not None:
+                # side-stream work of the previous step (weight-gradient GEMMs, token sort) may still read what is dropped here;
+                # the caching allocator would hand the memory to the current stream at once
+                self.before_evict()
+                told = True
+            del self.cache[k]
+            self.total -= self.nbytes.pop(k)
 
     def f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -175,6 +183,7 @@ class _DecWS(_NS):
     def logits(self):
         if self._logits is None:
             self._logits = self._alloc()
+            self._grew(self._logits.numel() * self._logits.element_size())
         return self._logits
 
 
@@ -398,8 +407,9 @@ class _LstmImages(object):
     """bf16 operand images of one LSTM layer's input-side GEMMs (Gx = X.W_ih^T forward; dX = dG.W_ih,
     dW_ih = dG^T.X, dW_hh = dG^T.h_prev backward), built with lv_cvt_bf16_f32 next to the f32 originals."""
 
-    def __init__(self, c, TB, ni, H):
+    def __init__(self, c, TB, ni, H, key=None):
         self.TB, self.ni, self.H = TB, ni, H
+        self.key = key                      # this object's key in the workspace cache (byte accounting of the lazy addend)
         self.ldr = _round_up(TB, 8)
         self.X = c.i16(TB, ni)              # layer input rows            [T*B][ni]
         self.XT = c.i16(ni, self.ldr)       # ... transposed              [ni][T*B]
@@ -422,6 +432,8 @@ class _LstmImages(object):
         else:
             if self.addend is None or self.addend.shape[0] != rows:
                 self.addend = wsc.f32(rows, 4 * H)
+                if self.key is not None:
+                    wsc.grew(self.key, rows * 4 * H * 4)
             lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
             addend = P(self.addend)
         if gather is not None:
@@ -470,11 +482,16 @@ class LSTMEncoderEngine(object):
         self._wimg = None
         self._aux = _AuxStream()
 
+    def _quiesce_side_streams(self):
+        dev = self.flat.device if self.flat is not None else None
+        if dev is not None and dev.type == "cuda" and self._aux.stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._aux.stream)
+
     def _b16(self, B, T):
         V, ni, H, nz2 = self.dims()
         if not _LstmImages.usable(self.precision, self.native16, ni, H):
             return None
-        return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H))
+        return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H, key=("b16", B, T)))
 
     def refresh_weight_images(self, B, device):
         """Bring the bf16 weight images (and, where the persistent launches apply, the packed recurrent weights) up to
@@ -496,6 +513,10 @@ class LSTMEncoderEngine(object):
             self.flat = FlatBuffer(named, device)
             self.wsc = _WS(device)
             self.wsc.evictable = self.ws_evictable
+            self.wsc.before_evict = self._quiesce_side_streams
+            # the cached bf16 / packed weight images describe the OLD flat buffer (p.data = X, module._apply and device moves keep
+            # the parameters' version counters, so weights_version() alone would not notice)
+            self._wimg = None
         self.lib = backend_for(device)
         return self.flat
 
@@ -650,6 +671,13 @@ class LSTMDecoderEngine(object):
         self._pending = None
         self._aux = _AuxStream()
 
+    def _quiesce_side_streams(self):
+        dev = self.flat.device if self.flat is not None else None
+        if dev is not None and dev.type == "cuda":
+            for st in (self._aux.stream, self._side):
+                if st is not None:
+                    torch.cuda.current_stream(dev).wait_stream(st)
+
     def _fork(self, device):
         """Returns a context manager that runs its body on the side stream, ordered after everything queued so far
         on the current stream (inline when overlap is off or on the test backend)."""
@@ -695,6 +723,10 @@ class LSTMDecoderEngine(object):
             self.flat = FlatBuffer(named, device)
             self.wsc = _WS(device)
             self.wsc.evictable = self.ws_evictable
+            self.wsc.before_evict = self._quiesce_side_streams
+            # the cached bf16 / packed weight images describe the OLD flat buffer (p.data = X, module._apply and device moves keep
+            # the parameters' version counters, so weights_version() alone would not notice)
+            self._wimg = None
         self.lib = backend_for(device)
         return self.flat
 
@@ -713,6 +745,7 @@ class LSTMDecoderEngine(object):
             w = _DecWS()
             w.ldl = ldl
             w._alloc = lambda: c.f32(Td * Bd, ldl)
+            w._grew = lambda nb: c.grew((Bd, Td), nb)
             w.X = c.f32(Td * Bd, ni)
             w.Zp = c.f32(Bd, 4 * H)
             w.Gx = c.f32(Td * Bd, 4 * H)
@@ -782,7 +815,7 @@ class LSTMDecoderEngine(object):
         V, ni, H, nz = self.dims()
         if not _LstmImages.usable(self.precision, self.native16, ni, H):
             return None
-        return self.wsc.get(("b16lstm", Bd, Td), lambda: _LstmImages(self.wsc, Td * Bd, ni, H))
+        return self.wsc.get(("b16lstm", Bd, Td), lambda: _LstmImages(self.wsc, Td * Bd, ni, H, key=("b16lstm", Bd, Td)))
 
     def forward(self, x, z, mask_in, mask_out, p_in, p_out, want_rec=True):
         """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
@@ -1030,6 +1063,12 @@ class LSTMDecodeStepper(object):
         self.lib = eng.lib
         self.ws = {}
 
+    def _refresh(self):
+        """The decoder's parameters may have been rebound since this stepper was built (p.data = X, a dtype round trip): bring
+        the flat copy up to date before reading it."""
+        self.eng.ensure(self.device)
+        self.lib = self.eng.lib
+
     def _w(self, n):
         w = self.ws.get(n)
         if w is None:
@@ -1050,6 +1089,7 @@ class LSTMDecodeStepper(object):
 
     def init_state(self, z2):
         """z2 [n][nz] -> (h0, c0) [n][H]: c0 = trans_linear(z), h0 = tanh(c0)   (dec_lstm.py:181-182, 284-285)."""
+        self._refresh()
         V, ni, H, nz = self.eng.dims()
         v = self.eng.flat.views
         lib, s = self.lib, stream_ptr(self.device)
@@ -1063,6 +1103,7 @@ class LSTMDecodeStepper(object):
 
     def step(self, tokens, z2, h, c):
         """tokens int64 [n], z2 [n][nz], (h, c) [n][H] -> logits [n][V] (a view, valid until the next call), (h', c')."""
+        self._refresh()
         V, ni, H, nz = self.eng.dims()
         v = self.eng.flat.views
         lib, s = self.lib, stream_ptr(self.device)

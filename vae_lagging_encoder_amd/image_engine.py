@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from . import engine as _eng
-from .engine import P, FlatBuffer, _gemm, backend_for, stream_ptr
+from .engine import P, FlatBuffer, _gemm, stream_ptr
 
 
 class Act(object):
@@ -41,7 +41,7 @@ def pack_conv32(lib, s, ent):
 class Tape(object):
     def __init__(self, device, precision="f32", train=True, wcache=None, wver=None):
         self.device = torch.device(device)
-        self.lib = backend_for(self.device)
+        self.lib = _eng.backend_for(self.device)
         self.precision = precision
         self.train = train
         self.back = []
@@ -479,7 +479,7 @@ class ImageDecoderEngine(object):
         captured region, so that a replayed graph never carries -- or misses -- a repack)."""
         self.ensure(device)
         ver = self.weights_version()
-        lib, s = backend_for(device), stream_ptr(device)
+        lib, s = _eng.backend_for(device), stream_ptr(device)
         for ent in self._wcache.values():
             if ent["ver"] != ver:
                 pack_conv32(lib, s, ent)

@@ -62,8 +62,10 @@ class AggressiveTextTrainer(object):
         self.static = collections.OrderedDict()
         # hipGraph mode: captured graphs hold raw pointers into the engines' workspaces, so nothing may be dropped (graph mode is
         # for a fixed set of (B, T) buckets); eager mode: least-recently-used shapes are dropped (engine._WS, STATIC_SHAPES)
+        # Sticky: once a hipGraph trainer has pinned an engine's workspaces, a later eager trainer on the same VAE must not
+        # re-enable eviction underneath the captured graphs.
         for e in (self.enc, self.dec):
-            e.ws_evictable = not self.use_graph
+            e.ws_evictable = e.ws_evictable and not self.use_graph
             if e.wsc is not None:
                 e.wsc.evictable = e.ws_evictable
 
