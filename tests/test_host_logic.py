@@ -193,3 +193,58 @@ def test_workspace_cache_drops_least_recently_used_shapes():
     for i in range(20):
         keep.get(i, lambda: build(10))
     assert len(keep.cache) == 20
+
+
+def test_image_outer_loop_policy():
+    """image.py:381-425 as host logic (no kernels: a stub trainer): aggressive training ends at the FIFTH end-of-epoch check whose
+    validation MI is below the best MI so far (not at the first drop, and the strikes need not be consecutive); the learning
+    rate halves after `decay_epoch` epochs that did not set a new best validation loss (no epoch gate), the best weights are
+    reloaded and both Adam optimizers start from scratch; five decays end training.  The transitions below were stepped through
+    by hand against image.py; the full loop is replayed against a recorded reference run in tests/test_policy_replay.py."""
+    import argparse
+    import torch
+    from vae_lagging_encoder_amd import evaluation as E
+    from vae_lagging_encoder_amd.training import ImageTrainingLoop
+
+    class StubTrainer(object):
+        def __init__(self):
+            self.resets = []
+            self.dec = argparse.Namespace(wgen=0)
+
+        def reset_optimizer(self, lr):
+            self.resets.append(lr)
+    vae = torch.nn.Linear(2, 2)
+    args = argparse.Namespace(kl_start=0.1, warm_up=2, batch_size=10, epochs=1, aggressive=1, nsamples=1, test_nepoch=5)
+    x = torch.rand(50, 1, 28, 28)
+    logs = []
+    loop = ImageTrainingLoop(vae, x, x[:20], None, args, trainer=StubTrainer(), log=logs.append, decay_epoch=2)
+    assert abs(loop.anneal_rate - 0.9 / (2 * 5)) < 1e-12 and loop.opt["lr"] == 0.001
+    # MI checks: best_mi only moves up; strikes at 0.4, 0.3, 0.45 (< 0.5), 0.2, 0.1 -> the fifth strike stops
+    mis = iter([0.2, 0.5, 0.4, 0.3, 0.45, 0.6, 0.2, 0.1])
+    saved = E.image_calc_mi
+    E.image_calc_mi = lambda model, loader: next(mis)
+    try:
+        flags = []
+        for _ in range(8):
+            loop.check_aggressive()
+            flags.append(loop.aggressive)
+    finally:
+        E.image_calc_mi = saved
+    assert flags == [True] * 7 + [False] and loop.best_mi == 0.6 and loop.mi_not_improved == 5 and "STOP BURNING" in logs
+    # learning-rate policy (decay_epoch = 2 here): new best at epochs 0 and 1; epochs 2, 3 are worse -> decay at 3; 4 improves
+    w0 = {k: v.clone() for k, v in vae.state_dict().items()}
+    assert loop.end_of_epoch(0, 10.0, 10.0, 1.0) is False
+    assert loop.end_of_epoch(1, 9.0, 9.0, 1.0) is False and loop.best["loss"] == 9.0
+    best_w = {k: v.clone() for k, v in vae.state_dict().items()}
+    with torch.no_grad():
+        vae.weight.add_(1.0)
+    assert loop.end_of_epoch(2, 9.5, 9.5, 1.0) is False and loop.opt["not_improved"] == 1 and loop.trainer.resets == []
+    assert loop.end_of_epoch(3, 9.0, 9.0, 1.0) is False          # equal to the best is neither `<` nor `>`: counters reset (image.py:423-425)
+    assert loop.opt["not_improved"] == 0
+    assert loop.end_of_epoch(4, 9.2, 9.2, 1.0) is False and loop.end_of_epoch(5, 9.3, 9.3, 1.0) is False
+    assert loop.trainer.resets == [0.0005] and loop.decay_cnt == 1 and loop.opt["lr"] == 0.0005
+    assert all(torch.equal(vae.state_dict()[k], best_w[k]) for k in best_w)           # the decay reloaded the best weights
+    stop = [loop.end_of_epoch(6 + i, 9.4 + 0.01 * i, 9.4, 1.0) for i in range(8)]
+    assert stop == [False, False, False, False, False, False, False, True] and loop.decay_cnt == 5
+    assert loop.trainer.resets == [0.001 * 0.5 ** k for k in range(1, 6)]
+    del w0

@@ -16,3 +16,31 @@ def load_image_triple(path, device=None):
             t = t.unsqueeze(1)
         out.append(t.to(device) if device is not None else t)
     return tuple(out)
+
+
+def sampler_order(n):
+    """The order torch.utils.data.RandomSampler gives a shuffled DataLoader pass (what image.py:219-221's loaders draw on every
+    `for datum in loader`): one int64 seed from torch's global generator, then randperm(n) from a private generator."""
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g).tolist()
+
+
+class ShuffledLoader(object):
+    """`DataLoader(TensorDataset(x, y), batch_size, shuffle=True)` of image.py:215-221 for a tensor that already lives on the
+    device: every iteration pass draws a fresh order (order_fn(n) -> list of indices; default `sampler_order`) and yields
+    (batch, None) pairs in chunks of batch_size, the last one short (drop_last = False)."""
+
+    def __init__(self, x, batch_size, order_fn=None):
+        self.x, self.batch_size = x, int(batch_size)
+        self.order_fn = order_fn if order_fn is not None else sampler_order
+
+    def __len__(self):
+        return (int(self.x.shape[0]) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = list(self.order_fn(int(self.x.shape[0])))
+        idx = torch.as_tensor(order, dtype=torch.int64, device=self.x.device)
+        for a in range(0, len(order), self.batch_size):
+            yield self.x[idx[a:a + self.batch_size]], None

@@ -50,17 +50,26 @@ class GradSync(object):
         the decoder (text.py:418-424) all-reduce it in full.
     mode "encoder_only": only the encoder buffer is exchanged and the local decoder-gradient norm enters the clip norm -- a
       documented deviation from the reference (replicas stay identical, the clip coefficient differs slightly per step).
-    payload "f32" (default) exchanges the fp32 gradients; "bf16" rounds them to bf16 for the wire (RNE, lv_cvt_bf16_f32), sums
-      in bf16 and unpacks with the 1/world mean folded in: half the bytes of every exchange, at a per-element relative error of
-      2^-9 on the mean gradient -- the size of the operand rounding the bf16 throughput configuration already accepts inside
-      its GEMMs, and not part of the fp32 parity path.  Replicas stay bit-identical to each other either way.
+    payload "f32" exchanges the fp32 gradients; "bf16" rounds them to bf16 for the wire (RNE, lv_cvt_bf16_f32), sums in bf16
+      and unpacks with the 1/world mean folded in: half the bytes of every exchange, at a per-element relative error of 2^-9
+      on the mean gradient -- the size of the operand rounding the bf16 throughput configuration already accepts inside its
+      GEMMs.  "auto" (default) follows the trainer's arithmetic: bf16 wire for the bf16 configuration, exact fp32 for the
+      fp32 parity path (`resolve_payload`, called by the trainer).  Replicas stay bit-identical to each other either way.
+
+    The encoder exchange -- the one the update has to wait for -- can be issued in BUCKETS as the encoder's backward produces
+    them (`start_encoder_bucket`: the 41 MB embedding gradient right after the embedding scatter, under the LSTM
+    weight-gradient GEMMs; the rest is picked up by `sync`).  `profile = True` brackets the phases of `sync` with HIP events
+    on the compute stream (`breakdown()`): what a step spends WAITING for each collective, i.e. the exposed communication.
     """
 
-    def __init__(self, group=None, mode="strict", decoder="auto", payload="f32"):
+    def __init__(self, group=None, mode="strict", decoder="auto", payload="auto"):
         assert mode in ("strict", "encoder_only")
         assert decoder in ("auto", "norm", "allreduce")
-        assert payload in ("f32", "bf16")
+        assert payload in ("auto", "f32", "bf16")
         self.payload = payload
+        self._buckets = []        # encoder buckets already in flight: (lo, hi, handle, wire tensor or None)
+        self.profile = False
+        self._prof = []           # per step: list of (name, start event, end event)
         self._b16 = {}            # bf16 wire images of the flat gradient buffers (payload "bf16")
         self.group = group
         self.mode = mode
@@ -71,47 +80,104 @@ class GradSync(object):
         self._h_dec = None
         self._h_rs = None         # reduce-scatter issued early by start_decoder()
         self._shard16 = None
-        self._rs_tmp = None
         self._shard = None
         self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
 
-    def _scale(self, flat):
+    def resolve_payload(self, precision):
+        """payload "auto" -> the wire format that matches the trainer's arithmetic (called once by the trainer)."""
+        if self.payload == "auto":
+            self.payload = "bf16" if precision == "bf16" else "f32"
+        return self.payload
+
+    def _scale(self, flat, lo=0, hi=None):
         lib = _eng.backend_for(flat.device)
         if self._inv is None or self._inv.device != flat.device:
             self._inv = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.device)
-        lib.lv_scale_f32(P(flat.grad), flat.numel, P(self._inv), _eng.stream_ptr(flat.device))
+        hi = flat.numel if hi is None else hi
+        lib.lv_scale_f32(P(flat.grad, lo), hi - lo, P(self._inv), _eng.stream_ptr(flat.device))
+
+    # ---- measurement ------------------------------------------------------------------------------------------------
+    class _Phase(object):
+        def __init__(self, gs, name, device):
+            self.on = gs.profile and torch.device(device).type == "cuda"
+            self.gs, self.name = gs, name
+
+        def __enter__(self):
+            if self.on:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def __exit__(self, *a):
+            if self.on:
+                self.e1.record()
+                self.gs._prof.append((self.name, self.e0, self.e1))
+
+    def breakdown(self, reset=True):
+        """Mean milliseconds per step the COMPUTE stream spent inside each phase of the exchange since the last call
+        (profile = True; call after a device synchronise): {phase: ms, ..., "steps": n}.  A phase's time is what the step
+        waited for that collective (plus its pack / unpack kernels) -- communication hidden under compute does not show."""
+        out, n = {}, {}
+        for name, e0, e1 in self._prof:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+            n[name] = n.get(name, 0) + 1
+        steps = max(n.values()) if n else 0
+        res = {k: v / max(1, steps) for k, v in out.items()}
+        res["steps"] = steps
+        if reset:
+            self._prof = []
+        return res
 
     # ---- bf16 wire format -------------------------------------------------------------------------------------------
-    def _wire(self, flat):
-        """bf16 image of the (padded) flat gradient buffer; returns the int16 tensor (viewed as bfloat16 for the collective)."""
+    def _wire(self, flat, lo=0, hi=None):
+        """bf16 image of elements [lo, hi) of the (padded) flat gradient buffer (lo, hi multiples of 1024; default: all of it);
+        returns the int16 view of that range (viewed as bfloat16 for the collective)."""
         src = flat.grad_padded
         n = src.numel()
+        hi = n if hi is None else hi
         t = self._b16.get(id(flat))
         if t is None or t.numel() != n or t.device != src.device:
             t = torch.empty(n, dtype=torch.int16, device=src.device)
             self._b16[id(flat)] = t
         lib = _eng.backend_for(src.device)
-        lib.lv_cvt_bf16_f32(P(src), 1024, n // 1024, 1024, P(t), 1024, None, 0, _eng.stream_ptr(src.device))
-        return t
+        lib.lv_cvt_bf16_f32(P(src, lo), 1024, (hi - lo) // 1024, 1024, P(t, lo), 1024, None, 0, _eng.stream_ptr(src.device))
+        return t[lo:hi]
 
-    def _unwire(self, flat, t16, scale):
+    def _unwire(self, flat, t16, scale, lo=0, hi=None):
         lib = _eng.backend_for(t16.device)
-        lib.lv_cvt_f32_bf16_scaled(P(t16), flat.numel, scale, P(flat.grad), _eng.stream_ptr(t16.device))
+        hi = flat.numel if hi is None else min(hi, flat.numel)
+        lib.lv_cvt_f32_bf16_scaled(P(t16), hi - lo, scale, P(flat.grad, lo), _eng.stream_ptr(t16.device))
 
-    def _all_reduce_mean_start(self, flat):
-        """Start the mean all-reduce of a flat gradient buffer; returns what _all_reduce_mean_finish needs."""
+    def _all_reduce_mean_start(self, flat, lo=0, hi=None):
+        """Start the mean all-reduce of (a 1024-aligned range of) a flat gradient buffer; returns what
+        _all_reduce_mean_finish needs."""
+        hi = flat.grad_padded.numel() if hi is None else hi
         if self.payload == "bf16":
-            t16 = self._wire(flat)
-            return (dist.all_reduce(t16.view(torch.bfloat16), op=dist.ReduceOp.SUM, group=self.group, async_op=True), t16)
-        return (dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None)
+            t16 = self._wire(flat, lo, hi)
+            return (dist.all_reduce(t16.view(torch.bfloat16), op=dist.ReduceOp.SUM, group=self.group, async_op=True), t16, lo, hi)
+        return (dist.all_reduce(flat.grad_padded[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, lo, hi)
 
     def _all_reduce_mean_finish(self, flat, started):
-        h, t16 = started
+        h, t16, lo, hi = started
         h.wait()
         if t16 is not None:
-            self._unwire(flat, t16, 1.0 / self.world)
+            self._unwire(flat, t16, 1.0 / self.world, lo, hi)
         else:
-            self._scale(flat)
+            self._scale(flat, lo, min(hi, flat.numel))
+
+    def start_encoder_bucket(self, enc_flat, lo, hi):
+        """Issue the mean all-reduce of encoder-gradient elements [lo, hi) now (lo, hi multiples of 1024 elements, or hi = the
+        padded end): called from inside the encoder's backward as soon as that part of the gradient is final, so that the
+        collective runs under the backward work still queued behind it.  sync() completes it and exchanges what is left."""
+        if self.world == 1:
+            return
+        pad = enc_flat.grad_padded.numel()
+        hi = min(hi, pad)
+        assert lo < hi
+        if self.payload == "bf16":          # the wire conversion works on rows of 1024 elements
+            assert lo % 1024 == 0 and (hi % 1024 == 0 or hi == pad), (lo, hi)
+        assert all(hi <= b[2] or lo >= b[3] for b in self._buckets), "encoder buckets must not overlap"
+        self._buckets.append(self._all_reduce_mean_start(enc_flat, lo, hi))
 
     def _norm_only(self, dec_flat, update):
         return (self.mode == "strict" and update == "encoder" and self.decoder in ("auto", "norm")
@@ -138,13 +204,8 @@ class GradSync(object):
             src = self._wire(dec_flat).view(torch.bfloat16)
             if self._shard16 is None or self._shard16.numel() != n or self._shard16.device != src.device:
                 self._shard16 = torch.empty(n, dtype=torch.int16, device=src.device)
-        if dist.get_backend(self.group) == "gloo":
-            # gloo has no reduce-scatter: the CPU tests take the shard out of an all-reduced copy (same sums)
-            self._rs_tmp = src.clone()
-            h = dist.all_reduce(self._rs_tmp, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-            self._rs_slice = (self.rank * n, (self.rank + 1) * n)
-            return h
-        self._rs_tmp = None
+        # the same call on RCCL and on gloo (torch >= 2.10's gloo has reduce_scatter_tensor, bf16 included): the CPU tests
+        # exercise the product's collective, not a substitute
         dst = self._shard16.view(torch.bfloat16) if bf else self._shard
         return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
@@ -157,35 +218,49 @@ class GradSync(object):
         h_dec, self._h_dec = self._h_dec, None
         lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
         ss = None
+        dev = enc_flat.device
         if self._norm_only(dec_flat, update):
             n = dec_flat.grad_padded.numel() // self.world
             h_rs, self._h_rs = self._h_rs, None
-            if h_rs is None and self._rs_tmp is None:
+            if h_rs is None:
                 h_rs = self._reduce_scatter(dec_flat, update, async_op=True)      # not started early (hipGraph split, direct callers)
-            enc_started = self._all_reduce_mean_start(enc_flat)
-            if h_rs is not None:
+            with self._Phase(self, "encoder_allreduce_issue", dev):
+                enc_rest = self._start_encoder_rest(enc_flat)
+            with self._Phase(self, "decoder_reduce_scatter_wait", dev):
                 h_rs.wait()
-            if self._rs_tmp is not None:
-                piece = self._rs_tmp[self._rs_slice[0]:self._rs_slice[1]]
                 if self.payload == "bf16":
-                    self._shard16.copy_(piece.view(torch.int16))
-                else:
-                    self._shard.copy_(piece)
-                self._rs_tmp = None
-            if self.payload == "bf16":
-                lib.lv_cvt_f32_bf16_scaled(P(self._shard16), n, 1.0, P(self._shard), s)
-            lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
-            lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
-            dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
+                    lib.lv_cvt_f32_bf16_scaled(P(self._shard16), n, 1.0, P(self._shard), s)
+                lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
+                lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
+            with self._Phase(self, "scalar_allreduce", dev):
+                dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
             ss = self._ss
         else:
             if self.mode == "strict" and h_dec is None:
                 h_dec = self._all_reduce_mean_start(dec_flat)
-            enc_started = self._all_reduce_mean_start(enc_flat)
+            with self._Phase(self, "encoder_allreduce_issue", dev):
+                enc_rest = self._start_encoder_rest(enc_flat)
             if h_dec is not None:
-                self._all_reduce_mean_finish(dec_flat, h_dec)
-        self._all_reduce_mean_finish(enc_flat, enc_started)
+                with self._Phase(self, "decoder_allreduce_wait", dev):
+                    self._all_reduce_mean_finish(dec_flat, h_dec)
+        with self._Phase(self, "encoder_allreduce_wait", dev):
+            for st in enc_rest:
+                self._all_reduce_mean_finish(enc_flat, st)
         return ss
+
+    def _start_encoder_rest(self, enc_flat):
+        """Issue the all-reduce of every encoder range no bucket has covered; returns all encoder handles in flight, lowest
+        range first (finished by sync in that order)."""
+        started, self._buckets = sorted(self._buckets, key=lambda b: b[2]), []
+        pad = enc_flat.grad_padded.numel()
+        gaps, pos = [], 0
+        for b in started:
+            if b[2] > pos:
+                gaps.append((pos, b[2]))
+            pos = b[3]
+        if pos < pad:
+            gaps.append((pos, pad))
+        return started + [self._all_reduce_mean_start(enc_flat, a, b) for a, b in gaps]
 
     def ss_handle(self, dec_flat, update="encoder"):
         """The device scalar sync() will return for this kind of step (None when it returns None); no communication."""
@@ -204,7 +279,7 @@ class GradSync(object):
     def bytes_per_step(self, enc_flat, dec_flat, update="encoder"):
         """fp32 bytes each rank sends per step (ring algorithms: 2(P-1)/P x buffer for an all-reduce, (P-1)/P for a
         reduce-scatter) -- for the schedule table in DESIGN.md."""
-        f = (self.world - 1) / max(1, self.world) * (0.5 if self.payload == "bf16" else 1.0)
+        f = (self.world - 1) / max(1, self.world) * (0.5 if self.payload == "bf16" else 1.0)      # "auto" counts as fp32 until resolved
         enc = 2 * f * 4 * enc_flat.numel
         if self.mode != "strict":
             return enc

@@ -444,14 +444,18 @@ class _LstmImages(object):
         _gemm16(lib, s, 0, TB, 4 * H, ni, P(self.X), ni, W16, ni, Gx, 4 * H,
                 add1=addend, ld1=4 * H if rows > 1 else 0, mod1=rows)
 
-    def backward(self, lib, s, dG, h_prev, WT16, dX, gW_ih, ld_gw, gW_hh, ws=None):
+    def backward(self, lib, s, dG, h_prev, WT16, dX, gW_ih, ld_gw, gW_hh, ws=None, between=None):
         """dG: the f32 gate gradients, or None when the BPTT kernel already wrote their bf16 image into self.dG; WT16: the
-        bf16 image of W_ih^T [ni][4H] (engine-level)."""
+        bf16 image of W_ih^T [ni][4H] (engine-level).  between(): called once dX is queued and before the two weight-gradient
+        products (the encoder scatters its embedding gradient there, so that a data-parallel exchange of it can start under
+        the weight-gradient GEMMs)."""
         TB, ni, H = self.TB, self.ni, self.H
         if dG is not None:
             lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
-        lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
         _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, WT16, 4 * H, dX, ni, ws=ws)
+        if between is not None:
+            between()
+        lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
         _gemm16(lib, s, 1, 4 * H, ni, TB, P(self.dG), 4 * H, P(self.XT), self.ldr, gW_ih, ld_gw, ws=ws)
         _gemm16(lib, s, 1, 4 * H, H, TB, P(self.dG), 4 * H, P(self.hT), self.ldr, gW_hh, H, ws=ws)
 
@@ -593,11 +597,13 @@ class LSTMEncoderEngine(object):
         self.last = (x, B, T, self.gen)
         return w.mulv
 
-    def backward(self, dmulv, gen=None, head=None, after_bptt=None):
+    def backward(self, dmulv, gen=None, head=None, after_bptt=None, after_embed=None):
         """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics).
 
         after_bptt: called once the BPTT recurrence has been queued (data parallel: the point where a collective can be issued
         so that it starts behind the persistent launch and runs under the weight-gradient GEMMs that follow).
+        after_embed: called once the embedding gradient -- the first 41 MB of the flat gradient buffer at the Yahoo shape -- has
+        been queued; the LSTM weight-gradient GEMMs follow it (data parallel: that bucket's all-reduce runs under them).
 
         head = (eps, dz [parts][B][ns][nz], parts, dkl [B]) instead of dmulv: the backward of reparameterise + KL runs in
         the head's launch (fused driver; dmulv is then produced into the workspace)."""
@@ -630,17 +636,23 @@ class LSTMEncoderEngine(object):
             _lstm_backward(self, lib, s, img, w, None, P(w.dhT), None, 1.0, P(v["lstm.weight_hh_l0"]), None, None, 0, T, B, H, x.device)
         if after_bptt is not None:
             after_bptt()
-        # input-side grads
+        def embed_grad():
+            # dX -> embedding rows (the embedding table leads the flat buffer: its gradient is the first, and largest, bucket)
+            gv["embed.weight"].zero_()
+            self._aux.join(x.device)                   # token sort queued by forward()
+            lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(w.srows), P(w.stok), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
+            if after_embed is not None:
+                after_embed()
+        # input-side grads: dX first, then the embedding scatter, then the two weight-gradient products
         if img is not None:
-            img.backward(lib, s, None, P(w.hs), P(self._wimg.WT), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]))
+            img.backward(lib, s, None, P(w.hs), P(self._wimg.WT), P(w.dX), P(gv["lstm.weight_ih_l0"]), ni, P(gv["lstm.weight_hh_l0"]),
+                         between=embed_grad)
         else:
             _gemm(lib, s, 0, 0, T * B, ni, 4 * H, P(w.dG), 4 * H, P(v["lstm.weight_ih_l0"]), ni, P(w.dX), ni, prec=self.precision)
+            embed_grad()
             _wgrad(lib, s, 4 * H, ni, T * B, P(w.dG), 4 * H, P(w.X), ni, P(gv["lstm.weight_ih_l0"]), ni, self.precision)
             _wgrad(lib, s, 4 * H, H, T * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H, self.precision)
         lib.lv_colsum_f32(P(w.dGsum), 4 * H, B, 4 * H, P(gv["lstm.bias_ih_l0"]), P(gv["lstm.bias_hh_l0"]), s)
-        gv["embed.weight"].zero_()
-        self._aux.join(x.device)                       # token sort queued by forward()
-        lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(w.srows), P(w.stok), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
 
 
 class LSTMDecoderEngine(object):

@@ -92,3 +92,66 @@ def calc_au(model, test_data_batch, delta=0.01):
         cnt += mean.size(0)
     au_var = var / (cnt - 1)
     return int((au_var >= delta).sum().item()), au_var
+
+
+# ---- image side (reference image.py:96-187): the loaders yield (batch, label) pairs like DataLoader(TensorDataset(x, y)) --------
+def image_test(model, test_loader, mode, args=None, verbose=True):
+    """image.py:96-128: loss / KL / reconstruction over one pass of the loader (eval mode is the caller's), then calc_mi over a
+    second pass.  Returns (test_loss, nll, kl)."""
+    kls, recs = [], []
+    report_num_examples = 0
+    nsamples = getattr(args, "nsamples", 1) if args is not None else 1
+    for batch_data, _ in test_loader:
+        report_num_examples += batch_data.size(0)
+        loss, loss_rc, loss_kl = model.loss(batch_data, 1.0, nsamples=nsamples)
+        recs.append(loss_rc.sum())
+        kls.append(loss_kl.sum())
+    report_rec_loss = float(torch.stack(recs).sum().item())
+    report_kl_loss = float(torch.stack(kls).sum().item())
+    mutual_info = image_calc_mi(model, test_loader)
+    test_loss = (report_rec_loss + report_kl_loss) / report_num_examples
+    nll = (report_kl_loss + report_rec_loss) / report_num_examples
+    kl = report_kl_loss / report_num_examples
+    if verbose:
+        print("%s --- avg_loss: %.4f, kl: %.4f, mi: %.4f, recon: %.4f, nll: %.4f" %
+              (mode, test_loss, kl, mutual_info, report_rec_loss / report_num_examples, nll))
+    return test_loss, nll, kl
+
+
+def image_calc_mi(model, test_loader):
+    """image.py:130-140."""
+    mi = 0.0
+    num_examples = 0
+    for batch_data, _ in test_loader:
+        batch_size = batch_data.size(0)
+        num_examples += batch_size
+        mi += model.calc_mi_q(batch_data) * batch_size
+    return mi / num_examples
+
+
+def image_calc_au(model, test_loader, delta=0.01):
+    """image.py:142-162: ONE pass over the loader (the posterior means are collected, then their variance over the data is
+    taken), active = variance >= delta.  Returns (count, au_var)."""
+    means = [model.encode_stats(batch_data)[0].detach() for batch_data, _ in test_loader]
+    means = torch.cat(means, dim=0).contiguous()
+    ns = means.size(0)
+    acc = torch.zeros(means.shape[1], dtype=torch.float32, device=means.device)
+    _eng.au_accumulate(means, None, acc)
+    mean_mean = (acc / ns).contiguous()
+    var = torch.zeros_like(acc)
+    _eng.au_accumulate(means, mean_mean, var)
+    au_var = var / (ns - 1)
+    return int((au_var >= delta).sum().item()), au_var
+
+
+def image_calc_iwnll(model, test_loader, args, verbose=False):
+    """image.py:164-187: importance-weighted NLL per example."""
+    tot = []
+    report_num_examples = 0
+    for batch_data, _ in test_loader:
+        report_num_examples += batch_data.size(0)
+        tot.append(model.nll_iw(batch_data, nsamples=args.iw_nsamples).sum())
+    nll = float(torch.stack(tot).sum().item()) / report_num_examples
+    if verbose:
+        print("iw nll: %.4f" % nll)
+    return nll

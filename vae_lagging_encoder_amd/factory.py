@@ -37,13 +37,14 @@ class UniformInit(object):
 
 
 def build_text_vae(V, ni, H, nz, device, seed=0, model_scale=0.01, emb_scale=0.1, params=None,
-                   dropout_in=0.5, dropout_out=0.5):
+                   dropout_in=0.5, dropout_out=0.5, vocab=None):
+    """vocab: a data.VocabEntry (what text.py:251,277 hands the decoder); default a sized stand-in with the same special ids."""
     from .modules import VAE, LSTMDecoder, LSTMEncoder
     args = argparse.Namespace(ni=ni, enc_nh=H, dec_nh=H, nz=nz, dec_dropout_in=dropout_in, dec_dropout_out=dropout_out,
                               device=torch.device(device))
     torch.manual_seed(seed)
     enc = LSTMEncoder(args, V, UniformInit(model_scale), UniformInit(emb_scale))
-    dec = LSTMDecoder(args, SizedVocab(V), UniformInit(model_scale), UniformInit(emb_scale))
+    dec = LSTMDecoder(args, vocab if vocab is not None else SizedVocab(V), UniformInit(model_scale), UniformInit(emb_scale))
     vae = VAE(enc, dec, args)
     if params is not None:
         missing, unexpected = vae.load_state_dict(params, strict=False)

@@ -33,6 +33,10 @@ def _rank_seed(seed, grad_sync):
 
 
 class AggressiveTextTrainer(object):
+    # data parallel: the embedding gradient goes out as its own all-reduce bucket when it has at least this many elements
+    # (below ~4 MB a second collective costs more in latency than its overlap buys)
+    BUCKET_MIN_ELEMS = 1 << 20
+
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
                  precision="f32"):
         self.vae = vae
@@ -43,6 +47,8 @@ class AggressiveTextTrainer(object):
         self.dec.ensure(self.device)
         assert precision in ("f32", "bf16")
         self.enc.precision = self.dec.precision = precision   # large GEMMs: exact f32 (parity) or bf16 pipe (throughput)
+        if grad_sync is not None:
+            grad_sync.resolve_payload(precision)              # "auto": bf16 wire for the bf16 configuration, exact fp32 otherwise
         self.enc.flat.attach_grads()
         self.dec.flat.attach_grads()
         self.lib = _eng.backend_for(self.device)
@@ -137,7 +143,16 @@ class AggressiveTextTrainer(object):
         lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
                                  self._s(5), T - 1, B, s)
         dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
-        hook = None
+        hook = bucket = None
+        if self.grad_sync is not None and not self._capturing and self.grad_sync.world > 1:
+            ef = self.enc.flat
+            align = 1024 if self.grad_sync.payload == "bf16" else 4      # bf16 wire rows are 1024 elements wide
+            n_emb = ef.offsets[ef.names[1]] // align * align             # the embedding table leads the flat buffer
+            if n_emb >= self.BUCKET_MIN_ELEMS and n_emb > 0:
+                # first bucket of the encoder exchange: the embedding gradient (41 of 66 MB at the Yahoo shape) goes out as
+                # soon as the scatter is queued and runs under the LSTM weight-gradient GEMMs; sync() sends the rest
+                def bucket():
+                    self.grad_sync.start_encoder_bucket(ef, 0, n_emb)
         if self.grad_sync is not None and not self._capturing:
             def start():
                 # data parallel: the decoder-gradient exchange (149 MB all-reduce, or 75 MB reduce-scatter when only its norm
@@ -150,7 +165,7 @@ class AggressiveTextTrainer(object):
                 hook = start
             else:
                 start()                   # step kernels: the collective runs under the whole encoder backward
-        self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl), after_bptt=hook)
+        self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl), after_bptt=hook, after_embed=bucket)
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
 
     def _collective_after_bptt(self):
@@ -345,6 +360,18 @@ class AggressiveImageTrainer(object):
 
     def reset_stats(self):
         self.scal[5:8] = 0
+
+    def set_lr(self, lr):
+        self.scal[1] = lr
+
+    def reset_optimizer(self, lr):
+        """image.py:419-420: a learning-rate decay builds NEW Adam optimizers -- first and second moments and the step counts
+        start from zero again, for the encoder's and the decoder's optimizer alike."""
+        self.scal[1] = lr
+        self.scal[8:10] = 0
+        for k in ("enc", "dec"):
+            self.m[k].zero_()
+            self.v[k].zero_()
 
     def binarize(self, probs):
         """torch.bernoulli(batch) (image.py:287,318) on device."""
