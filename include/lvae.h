@@ -144,6 +144,21 @@ int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const
                              const float* wpk, const float* gates, const float* hs, const float* cs,
                              float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                              int tanh_init, int T, int B, int H, void* stream);
+/* The persistent recurrences for up to 16 batch rows per XCD group (lv_lstm_persist16.hip; nn.LSTM of enc_lstm.py:55 /
+ * dec_lstm.py:104, forward and BPTT): R rows per group (1 <= R <= 16, 8 R >= B), groups [0, ceil(B / R)) carry the batch and the
+ * workgroups of the remaining groups return at once -- B = 128 runs 16 rows on each of the 8 groups (BASELINE.json configs[4]),
+ * and R = 8 at B = 32 runs a recurrence on FOUR XCDs, leaving the other four to concurrent kernels.  Contraction on the
+ * 16 x 16 x 32 MFMA with the weights as the A operand.  Weight images: lv_lstm_persist16_pack(whh, wpk, backward, H)
+ * (lv_lstm_persist_wpk_floats() floats); exchange buffer: lv_lstm_persist16_xch_floats() floats; *status as above.  No in-kernel
+ * dropout (the caller applies dropout_out on the bf16 images of h and once on dO).  LV_ERR_UNSUPPORTED unless H == 1024 and the
+ * device has >= 256 CUs. */
+long lv_lstm_persist16_xch_floats(void);
+int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
+int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch, int* status,
+                               int T, int B, int R, int H, void* stream);
+int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates, const float* hs,
+                               const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
+                               int tanh_init, int T, int B, int R, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
@@ -344,6 +359,10 @@ int lv_conv1x1_wgrad_f32(const float* x, const float* dy, float* dw, float* ws, 
 /* nn.BatchNorm2d in train mode (batch statistics, running stats momentum update with unbiased variance) fused with the
  * residual add and nn.ELU that follow it in ResNetBlock / PixelCNNBlock; backward with ELU' from the saved output */
 int lv_bn_workspace_floats(int C);
+/* the same module in eval mode (running statistics; image.py:96-187 evaluation passes, dec_pixelcnn_v2.py:201-232 sampling):
+ * y = act((x - run_mean) / sqrt(run_var + eps) * gamma + beta (+ res)); mean_out / invstd_out (may be NULL) = what was applied */
+int lv_bn_eval_f32(const float* x, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
+                   const float* res, int act_elu, float* y, float* mean_out, float* invstd_out, long P, int C, void* stream);
 int lv_bn_fwd_f32(const float* x, const float* gamma, const float* beta, const float* res, int act_elu,
                   float* y, float* mean, float* invstd, float* run_mean, float* run_var,
                   float eps, float momentum, float* ws, long P, int C, void* stream);

@@ -193,6 +193,19 @@ def test_conv_bnstat(emu_backend, cfg):
     K.test_conv_bnstat_feeds_batchnorm(emu_backend, CPU, *cfg)
 
 
+@pytest.mark.parametrize("T,B,R", [(3, 8, 1), (2, 20, 3), (2, 18, 6), (2, 27, 14)])
+def test_lstm_fwd_persistent16_emulated(emu_backend, T, B, R):
+    """lv_lstm_persist16.hip (R rows per XCD group, 16x16x32 MFMA with the weights as the A operand), all three instantiations
+    (R <= 4 / 8 / 16), ragged last groups, groups left empty."""
+    K.test_lstm_fwd_persistent16(emu_backend, CPU, T, B, R)
+
+
+@pytest.mark.parametrize("cfg", [(3, 8, 1, True, True, False), (2, 20, 3, False, True, True), (2, 18, 6, True, True, True),
+                                 (2, 27, 14, True, True, False)])
+def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
+    K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg)
+
+
 def test_lstm_fwd_persistent_emulated(emu_backend):
     """The persistent forward recurrence with every workgroup of its grid live at once (fibers; hand-off polls yield)."""
     K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True)
@@ -223,3 +236,8 @@ def test_wgrad_reduce_batched(emu_backend):
 def test_bf16_payload_unpack(emu_backend):
     for n in (1, 7, 4099):
         K.test_bf16_payload_unpack(emu_backend, CPU, n)
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 7, True, True), (3, 33, 5, True, False), (1, 1, 3, False, False)])
+def test_batchnorm_eval(emu_backend, cfg):
+    K.test_batchnorm_eval(emu_backend, CPU, *cfg)

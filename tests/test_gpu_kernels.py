@@ -328,9 +328,10 @@ def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ex
 
 
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
-def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks"):
+def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=None):
     """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
-    and against the launch-per-step kernel fed the same unit-major gx."""
+    and against the launch-per-step kernel fed the same unit-major gx.  variant "k16" = lv_lstm_persist16.hip with R batch rows
+    per XCD group (no in-kernel dropout there: use_mask must be off)."""
     dev, H = hip_device, 1024
     g = torch.Generator().manual_seed(T * 100 + B)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
@@ -349,7 +350,17 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks"):
         hs[0], cs[0] = h0, c0
         gates = torch.empty(T, B, 4 * H, device=dev)
         hdrop = torch.empty(T, B, H, device=dev)
-        if persistent:
+        if persistent and variant == "k16":
+            assert not use_mask
+            wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
+            ws = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
+            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(ws), P(status), T, B,
+                                           R if R is not None else (B + 7) // 8, H, _s(dev))
+            assert int(status.item()) == 0
+            hdrop = hs[1:].clone()
+        elif persistent:
             wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
             ws = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -375,10 +386,10 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks"):
     (6, 32, True, True, True, False), (1, 5, False, False, True, True), (9, 32, True, False, True, True),
     (40, 32, False, True, True, False), (3, 13, True, True, True, True), (17, 8, False, False, False, True),
 ])
-def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs"):
-    """The one-launch persistent BPTT (H = 1024; variant "rs" = reduce-scatter hand-off, "ag" = all-gather hand-off) against
-    the float64 autograd of the same recurrence (bf16-recurrence tolerance) and against the two-launch-per-step kernels on
-    the same saved activations."""
+def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs", R=None):
+    """The one-launch persistent BPTT (H = 1024; variant "rs" = reduce-scatter hand-off, "ag" = all-gather hand-off, "rs16" =
+    lv_lstm_persist16.hip with R batch rows per XCD group, no in-kernel dropout mask) against the float64 autograd of the same
+    recurrence (bf16-recurrence tolerance) and against the two-launch-per-step kernels on the same saved activations."""
     dev, H = hip_device, 1024
     g = torch.Generator().manual_seed(T * 100 + B + 7)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
@@ -406,7 +417,11 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
     lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
     wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
-    lib.lv_lstm_persist_pack(P(whh), P(wpk), 2 if variant == "rs" else 1, H, _s(dev))
+    if variant == "rs16":
+        assert not use_mask
+        lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
+    else:
+        lib.lv_lstm_persist_pack(P(whh), P(wpk), 2 if variant == "rs" else 1, H, _s(dev))
     persist_bwd = lib.lv_lstm_bwd_bf16_persist_rs if variant == "rs" else lib.lv_lstm_bwd_bf16_persist
 
     def common(weights):
@@ -419,7 +434,15 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         dGsum = torch.full((B, 4 * H), 7.0, device=dev)
         dh0 = torch.empty(B, H, device=dev)
         dc0 = torch.empty(B, H, device=dev)
-        if persistent:
+        if persistent and variant == "rs16":
+            wsp = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.lv_lstm_bwd_bf16_persist16(P(wext) if use_ext else None, P(wlast) if use_last else None, P(wpk), P(gates), P(hs), P(cs),
+                                           P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B,
+                                           R if R is not None else (B + 7) // 8, H, _s(dev))
+            assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
+            dG = torch.cat([dG16.view(torch.bfloat16).float()])
+        elif persistent:
             wsp = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             persist_bwd(*common(wpk), None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
@@ -503,6 +526,24 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
         rms = float((a - b).pow(2).mean().sqrt()) / float(b.pow(2).mean().sqrt())
         # dG is compared through its bf16 image: one flipped rounding of an element is 2^-8 of THAT element
         assert rms < 1e-3 and err < (2 ** -7 if what == "dG" else 1e-3) * sc, (what, err / sc, rms)
+
+
+@pytest.mark.parametrize("T,B,R", [(6, 32, 4), (9, 32, 8), (5, 64, 8), (7, 128, 16), (40, 32, 8), (3, 13, 2), (4, 100, 13), (12, 32, 16),
+                                   (1, 5, 5)])
+def test_lstm_fwd_persistent16(lib, hip_device, T, B, R):
+    """lv_lstm_persist16.hip forward: R rows per XCD group -- 8 groups x 4 (the default shape), 4 groups x 8 and 2 groups x 16
+    (a B = 32 recurrence on half / a quarter of the chip), 8 x 8 and 8 x 16 (B = 64 / the stress configuration's B = 128), ragged
+    slices."""
+    test_lstm_fwd_persistent(lib, hip_device, T, B, False, variant="k16", R=R)
+
+
+@pytest.mark.parametrize("T,B,R,tanh_init,use_ext,use_last", [
+    (6, 32, 4, True, True, False), (9, 32, 8, False, True, True), (5, 64, 8, True, True, False), (7, 128, 16, True, True, False),
+    (40, 32, 8, True, True, False), (3, 13, 2, True, True, True), (4, 100, 13, False, True, True), (17, 8, 1, False, False, True),
+    (12, 32, 16, True, True, False),
+])
+def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use_last):
+    test_lstm_bwd_persistent(lib, hip_device, T, B, False, tanh_init, use_ext, use_last, variant="rs16", R=R)
 
 
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (9, 64, True), (3, 13, False)])
@@ -753,6 +794,34 @@ def test_conv_im2col_gemm_fwd_bwd(lib, hip_device, N, Cin, Cout, H, k, stride, p
     dx = torch.empty(N * H * W, Cin, device=dev)
     lib.lv_col2im_f32(P(dcol), K, P(dx), N, H, W, Cin, Ho, Wo, k, k, pad, stride, nt, 0, _s(dev))
     assert float((_nchw(dx.cpu(), N, H, W).double() - x64.grad).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("N,C,H,act,use_res", [(4, 64, 7, True, True), (3, 33, 5, True, False), (2, 16, 28, False, True), (50, 32, 28, True, True),
+                                                (1, 1, 3, False, False)])
+def test_batchnorm_eval(lib, hip_device, N, C, H, act, use_res):
+    """nn.BatchNorm2d in eval mode (+ residual) (+ ELU): the running statistics are applied and left untouched."""
+    import torch.nn.functional as F
+    dev = hip_device
+    g = torch.Generator().manual_seed(C * 3 + H)
+    x = torch.randn(N, C, H, H, generator=g) * 2 + 0.5
+    res = torch.randn(N, C, H, H, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    y_ref = F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    if use_res:
+        y_ref = y_ref + res.double()
+    if act:
+        y_ref = F.elu(y_ref)
+    Pn = N * H * H
+    xd, resd = _nhwc(x).to(dev), _nhwc(res).to(dev)
+    rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
+    y = torch.full((Pn, C), float("nan"), device=dev)
+    mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    lib.lv_bn_eval_f32(P(xd), P(gamma.to(dev)), P(beta.to(dev)), P(rmd), P(rvd), 1e-5, P(resd) if use_res else None, int(act), P(y),
+                       P(mean), P(invstd), Pn, C, _s(dev))
+    assert float((_nchw(y.cpu(), N, H, H).double() - y_ref).abs().max()) < 2e-5
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv) and torch.equal(mean.cpu(), rm)
+    assert float((invstd.cpu().double() - (rv.double() + 1e-5).rsqrt()).abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize("N,C,H,act,use_res", [(3, 8, 5, True, True), (4, 32, 7, True, False), (2, 64, 6, False, False),

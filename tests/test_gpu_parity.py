@@ -67,10 +67,12 @@ def test_bf16_throughput_path_tracks_oracle(hip_device):
     assert out["grads"] < 5e-2, out
 
 
-@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("persistent", [True, False, "rows4", "rows8", "rows16"])
 def test_bf16_throughput_path_h1024(hip_device, persistent):
     """H = 1024, B = 32: the shape class on which the bf16 path runs its LSTM recurrences as persistent XCD-group launches
-    (when the device has >= 256 CUs).  Both realisations must track the f32 oracle to the bf16 path's documented delta."""
+    (when the device has >= 256 CUs).  Every realisation must track the f32 oracle to the bf16 path's documented delta: the
+    4-row kernels on 8 groups, the launch-per-step kernels, and the kernels of lv_lstm_persist16.hip with 4 / 8 / 16 rows per
+    group (8 groups; 4 groups = half the chip; 2 groups)."""
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
     V, ni, H, nz, B, T, klw = 3000, 64, 1024, 16, 32, 14, 0.5
     P = O.random_params(V, ni, H, nz, seed=11, scale=0.03, head_scale=0.2)
@@ -79,7 +81,9 @@ def test_bf16_throughput_path_h1024(hip_device, persistent):
     r = O.inner_step(P, x, klw, eps, m_in, m_out)
     vae = build_vae(V, ni, H, nz, hip_device, params=P)
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
-    tr.enc.persistent = tr.dec.persistent = persistent
+    tr.enc.persistent = tr.dec.persistent = bool(persistent)
+    if isinstance(persistent, str):
+        tr.enc.persist_rows = tr.dec.persist_rows = int(persistent[4:])
     tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
     st = tr.read_stats()          # also checks the persistent launches' status words
     assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
@@ -412,9 +416,9 @@ def test_update_both_and_fixed_k(hip_device):
 
 
 def test_stress_batch_at_h1024(hip_device):
-    """BASELINE.json configs[4] shape class: H = 1024 with B = 128 sequences per GPU, bf16 configuration.  The persistent
-    BPTT launch covers B <= 32 and the persistent forward B <= 64, so this batch runs on the launch-per-step kernels
-    (engine._persistent_ok declines); one fused step against the f32 oracle to the bf16 path's documented delta, then a
+    """BASELINE.json configs[4] shape class: H = 1024 with B = 128 sequences per GPU, bf16 configuration: 16 batch rows on each
+    of the 8 XCD groups of the persistent launches (lv_lstm_persist16.hip); one fused step against the f32 oracle to the bf16
+    path's documented delta -- with the persistent launches and, for comparison, on the launch-per-step kernels -- then a
     fixed-K loop (K = 3) on a pool of such batches stays finite and moves only the encoder."""
     import numpy as np
     from vae_lagging_encoder_amd import engine
@@ -424,16 +428,21 @@ def test_stress_batch_at_h1024(hip_device):
     x = O.synthetic_batch(B, T, V, seed=62)
     eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=63)
     r = O.inner_step(P, x, klw, eps, m_in, m_out)
-    vae = build_vae(V, ni, H, nz, hip_device, params=P)
-    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
-    img = tr.enc._b16(B, T)
-    assert img is not None and not engine._persistent_ok(tr.enc, img, B, H, hip_device, engine._PERSIST_MAX_B)
-    tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
-    st = tr.read_stats()
-    assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
-    assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
-    named = dict(vae.named_parameters())
-    assert max(rel_err(named[k].grad, r["grads"][k] * r["coef"]) for k in ALL_KEYS) < 5e-2
+    full_chip = torch.cuda.get_device_properties(hip_device).multi_processor_count >= 256
+    for persistent in ((True, False) if full_chip else (False,)):
+        vae = build_vae(V, ni, H, nz, hip_device, params=P)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+        tr.enc.persistent = tr.dec.persistent = persistent
+        img = tr.enc._b16(B, T)
+        assert img is not None and engine._persistent_ok(tr.enc, img, B, H, hip_device, engine._PERSIST_BWD_MAX_B) == persistent
+        assert engine._persist_rows(tr.enc, B) == (True, 16)
+        tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+        st = tr.read_stats()                                    # raises on a hand-off timeout
+        assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
+        assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
+        named = dict(vae.named_parameters())
+        assert max(rel_err(named[k].grad, r["grads"][k] * r["coef"]) for k in ALL_KEYS) < 5e-2
+    tr.enc.persistent = tr.dec.persistent = full_chip
     dec0 = {k: vae.state_dict()[k].clone() for k in DEC_KEYS}
     pool = [O.synthetic_batch(B, T, V, seed=70 + i).to(hip_device) for i in range(4)]
     steps = tr.inner_loop(pool, pool[0], klw, np_rng=np.random.RandomState(3), fixed_k=3)
@@ -489,6 +498,33 @@ def test_image_inner_loop_with_data_dependent_exit(hip_device):
     """image.py:295-327 end to end: same random picks, same binarisation draws, same windowed exit, same encoder."""
     steps = pc.check_image_inner_loop(hip_device)
     assert 1 <= steps < 7
+
+
+def test_image_lr_decay_recreates_the_adam_optimizers(hip_device):
+    """image.py:411-420: a learning-rate decay builds NEW Adam optimizers.  AggressiveImageTrainer.reset_optimizer must leave
+    the trainer where a freshly built one at that learning rate is: after two warm-up steps and a reset, the next step (both
+    networks stepped) moves the weights exactly as the first step of a new trainer from the same weights and BatchNorm
+    statistics does."""
+    from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
+    fx = load("image_b6")
+    x = torch.from_numpy(fx["x"]).float().to(hip_device)
+    eps = torch.from_numpy(fx["eps"]).to(hip_device)
+    vae = pc.build_image_vae(hip_device, int(fx["model_seed"]))
+    tr = AggressiveImageTrainer(vae)
+    tr.step(x, 0.5, eps=eps, update="both")
+    tr.step(x, 0.5, eps=eps, update="both")
+    snap = {k: v.clone() for k, v in vae.state_dict().items()}
+    tr.reset_optimizer(0.0005)
+    tr.step(x, 0.5, eps=eps, update="both")
+    after_reset = {k: v.clone() for k, v in vae.state_dict().items()}
+    vae2 = pc.build_image_vae(hip_device, int(fx["model_seed"]))
+    vae2.load_state_dict(snap)
+    tr2 = AggressiveImageTrainer(vae2, lr=0.0005)
+    tr2.step(x, 0.5, eps=eps, update="both")
+    for k, v in vae2.state_dict().items():
+        assert torch.equal(v, after_reset[k]), k
+    moved = max(float((after_reset[k] - snap[k]).abs().max()) for k in snap if k.endswith(".weight"))
+    assert 1e-4 < moved <= 0.0005 * 1.001            # Adam's first step is lr * sign(g) where the gradient is non-zero
 
 
 def test_image_eval_forward_after_decoder_update(hip_device):

@@ -50,6 +50,10 @@ SIGNATURES = {
     "lv_lstm_fwd_bf16_persist_ks": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist_rs": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_lstm_persist16_xch_floats": [],
+    "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
+    "lv_lstm_fwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_lstm_bwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],
     "lv_transpose_ld_f32": [_vp, _l, _vp, _l, _i, _i, _vp],
     "lv_lstm_bwd_ksplit": [_i],
@@ -115,6 +119,7 @@ SIGNATURES = {
     "lv_conv1x1_wgrad_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],
     "lv_bn_workspace_floats": [_i],
+    "lv_bn_eval_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
     "lv_bn_fwd_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _vp],
     "lv_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
     "lv_bn_bwd2_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
@@ -126,7 +131,7 @@ SIGNATURES = {
 }
 
 
-_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_conv32_wpack_floats",
+_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_conv32_wpack_floats",
              "lv_conv32_wgrad_ws_floats")
 
 
@@ -155,7 +160,7 @@ class Lib(object):
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
-                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats"}
+                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

@@ -547,6 +547,46 @@ static inline unsigned conv_grid(long n) {
     return (unsigned)b;
 }
 
+// nn.BatchNorm2d in EVAL mode (+ residual add) (+ nn.ELU): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta (+ res)),
+// one streaming pass; four channels per thread when C % 4 == 0 and the buffers are 16-byte aligned.  mean_out / invstd_out (may be
+// NULL) receive the statistics that were applied, in the layout the backward kernels read.
+template <bool V4>
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                      const float* __restrict__ rvar, float eps, const float* __restrict__ res, int act,
+                                                      float* __restrict__ y, float* __restrict__ mean_out,
+                                                      float* __restrict__ invstd_out, long n, int C) {
+    const long gs = (long)gridDim.x * 256;
+    if (blockIdx.x == 0 && mean_out && invstd_out)
+        for (int c = (int)threadIdx.x; c < C; c += 256) { mean_out[c] = rmean[c]; invstd_out[c] = 1.0f / sqrtf(rvar[c] + eps); }
+    if (V4) {
+        const int C4 = C >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += gs) {
+            const int c = 4 * (int)(i % C4);
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            float v[4] = {xv.x, xv.y, xv.z, xv.w};
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (res) { const float4 rv = reinterpret_cast<const float4*>(res)[i]; r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float o = (v[e] - rmean[c + e]) * (1.0f / sqrtf(rvar[c + e] + eps)) * gamma[c + e] + beta[c + e];
+                if (res) o += r[e];
+                if (act) o = o > 0.f ? o : expm1f(o);
+                v[e] = o;
+            }
+            reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+            const int c = (int)(i % C);
+            float o = (x[i] - rmean[c]) * (1.0f / sqrtf(rvar[c] + eps)) * gamma[c] + beta[c];
+            if (res) o += res[i];
+            if (act) o = o > 0.f ? o : expm1f(o);
+            y[i] = o;
+        }
+    }
+}
+
 }  // namespace
 
 // col[N*Ho*Wo][ldcol] <- the first `ntaps` raster-order taps of a kh x kw window (stride, pad) of NHWC x
@@ -600,6 +640,23 @@ extern "C" int lv_mul_inplace_f32(float* w, const float* m, long n, void* stream
 }
 
 extern "C" int lv_bn_workspace_floats(int C) { return BN_BLOCKS * 2 * (C > 0 ? C : 1); }
+
+// nn.BatchNorm2d with the module in eval mode (the evaluation passes of image.py:96-187 and PixelCNN sampling,
+// dec_pixelcnn_v2.py:201-232): running statistics, nothing is updated.
+extern "C" int lv_bn_eval_f32(const float* x, const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                              float eps, const float* res, int act_elu, float* y, float* mean_out, float* invstd_out, long P, int C,
+                              void* stream) {
+    if (!x || !gamma || !beta || !run_mean || !run_var || !y) return LV_ERR_ARG;
+    if (P <= 0 || C <= 0) return LV_ERR_SHAPE;
+    const long n = P * C;
+    const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
+    if (v4) LV_LAUNCH(bn_eval_kernel<true>, dim3(conv_grid(n >> 2)), dim3(256), 0, stream, x, gamma, beta, run_mean, run_var, eps, res,
+                      act_elu, y, mean_out, invstd_out, n, C);
+    else LV_LAUNCH(bn_eval_kernel<false>, dim3(conv_grid(n)), dim3(256), 0, stream, x, gamma, beta, run_mean, run_var, eps, res, act_elu,
+                   y, mean_out, invstd_out, n, C);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
 
 // BatchNorm2d (train) forward over x [P][C]: batch stats -> mean/invstd (saved), running stats (momentum, unbiased var),
 // y = act(xhat*gamma + beta (+ res)).  ws: lv_bn_workspace_floats(C).

@@ -29,23 +29,18 @@
 // calls (the decoder during the aggressive inner loop) packs once.  The same sources run on the CPU emulator with every
 // workgroup live as fibers (tests/emu): LV_LAUNCH_RESIDENT / LV_BLOCK_SHARED / lv_agent_* in lv_device.h.
 #include "lv_device.h"
+#include "lv_persist_common.h"
 
 namespace {
 
-constexpr int PH = 1024;            // hidden size this kernel is built for
+using namespace lvp;
+
 constexpr int PKS = PH / 32;        // MFMA k-steps per product
-constexpr int PGROUPS = 8;
-constexpr int PMEMBERS = 32;        // workgroups per group
 constexpr int PUW = 8;              // hidden units per wave
 constexpr int HPITCH = PH / 2 + 16; // LDS row pitch of the gathered h image in dwords: rows 16 banks apart, so the A-fragment
                                     // reads of 4 rows x 4 k-quads hit 16 distinct bank groups
 constexpr int PRMAX = 8;            // batch rows per group this build supports (LDS: 2 x PRMAX x HPITCH dwords)
-constexpr int SPIN_LIMIT = LV_SPIN_LIMIT;
-
-typedef unsigned long long gran_t;  // (tag << 32) | two bf16
-
-__device__ __forceinline__ gran_t gran_load(const gran_t* p) { return lv_agent_load_u64(p); }
-__device__ __forceinline__ void gran_store(gran_t* p, gran_t v) { lv_agent_store_u64(p, v); }
+// forward granules: (tag << 32) | two bf16
 
 // Wpk[wave_id (128)][ks (32)][nb (2)][lane (64)] : lane (c = l&15, kq = l>>4) holds W_hh[gate*H + unit][32ks + 8kq .. +7]
 // with unit = 8*wave_id + 4*nb + (c>>2), gate = c&3 -- the B operand of v_mfma_f32_16x16x32_bf16 for that column.
@@ -710,26 +705,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(PersistBwdP p) {
 constexpr int RS_KG = 32;                        // 4-wide k groups over the workgroup's 128 gate rows
 constexpr int RS_SG = 4;                         // 64-column super groups per wave (16 blocks x 4 columns per MFMA)
 constexpr int DPITCH = 64 + 4;                   // dwords per row of the dG image (128 bf16 + pad: rows 4 bank groups apart)
-
-__device__ __forceinline__ uint32_t rs_tag(int k) { return 1u + (uint32_t)(k - 1) % 255u; }      // phase k >= 1 -> 1..255
-__device__ __forceinline__ gran_t rs_pack(float a, float b, uint32_t tag) {
-    uint32_t ua, ub;
-    memcpy(&ua, &a, 4);
-    memcpy(&ub, &b, 4);
-    return (gran_t)((ua + 8u) >> 4) | ((gran_t)((ub + 8u) >> 4) << 28) | ((gran_t)tag << 56);
-}
-__device__ __forceinline__ float rs_lo(gran_t g) {
-    const uint32_t u = ((uint32_t)g & 0x0FFFFFFFu) << 4;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-__device__ __forceinline__ float rs_hi(gran_t g) {
-    const uint32_t u = ((uint32_t)(g >> 28) & 0x0FFFFFFFu) << 4;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
 
 // Wrs[wave_id (128) = 4m + w][kg (32)][sgp (2)][lane (64)] uint4: lane l holds, for output columns j = 256w + 64(2 sgp + h) + l
 // (h = 0, 1: .xy / .zw), the 4 weights W_hh[gate*H + unit][j] of the local gate rows n'' = 4kg + e (unit = 32m + kg, gate = e)

@@ -1,0 +1,595 @@
+// lv_lstm_persist16.hip -- the persistent LSTM recurrences for UP TO 16 BATCH ROWS PER XCD GROUP (bf16 recurrent operands, H = 1024).
+//
+// lv_lstm_persist.hip carries 4 rows per group (B <= 32 on 8 groups) and contracts them on the 4x4x4 MFMA.  Two things need
+// more rows per group: the stress configuration (B = 128 per GPU: 16 rows on each of the 8 groups; until now the
+// launch-per-step kernels at 11 us per timestep) and running a B = 32 recurrence on HALF the chip (4 groups x 8 rows), so that
+// the other four XCDs are free for the GEMMs that do not depend on it.  Same decomposition and hand-off as lv_lstm_persist.hip
+// (a group = the 32 workgroups with the same blockIdx % 8, W_hh register-resident, tagged 8-byte granules, bulk I/O in blocks of
+// timesteps, bounded spins); what changes is the contraction:
+//
+//   * v_mfma_f32_16x16x32_bf16 with the operands SWAPPED: the weights are the A operand (16 gate columns / output units as the
+//     tile's rows), the batch rows are the B operand's 16 columns.  The matrix-pipe time is the one the 4-row kernels already pay
+//     (64 MFMAs x 16 cycles per wave and timestep) for up to 16 rows, and the D tile comes out as [gate column][batch row]: a
+//     lane holds FOUR CONSECUTIVE gate columns of ONE batch row -- in the forward's unit-major column order exactly the
+//     (i, f, g, o) of one unit, so the K-split partial products cross the workgroup as float4 records, and in the BPTT four
+//     consecutive hidden units of one row, i.e. two ready-made partial-sum granules.
+//   * forward (K-split, as lstm_fwd_persist_ks_kernel): wave w gathers K-quarter w of h_{t-1} (rows x 128 granules), 8 fragment
+//     reads + 64 MFMAs, 8 float4 LDS writes, ONE barrier, every (row, unit) thread adds the four quarters and runs the cell.
+//   * BPTT (reduce-scatter, as lstm_bwd_persist_rs_kernel): a workgroup receives 32 senders x rows x 16 granules of partial dh
+//     for its 32 units, sums them in registers + two shuffles, runs the gate-gradient math, publishes its dG image through LDS
+//     (ONE barrier), multiplies it with its 128 gate rows of W_hh (4 fragment reads + 64 MFMAs) and sends the partial sums.
+//   rows per group R <= 16; instantiated for RP = 4 / 8 / 16 (polls per lane, pairs per thread and the I/O block length follow).
+// LDS row pitches are = 2 (mod 16) 16-byte slots: ds_read_b128 serves lanes in groups {0-3,12-15,20-27}, ..., i.e. the 16 rows
+// of one 8-k chunk and a neighbouring chunk, which a pitch of 2 slots spreads over all 16 slot classes.
+#include "lv_device.h"
+#include "lv_persist_common.h"
+
+namespace {
+
+using namespace lvp;
+
+constexpr int HP16 = PH / 2 + 8;        // dwords per row of the gathered h image (130 slots: = 2 mod 16)
+constexpr int DP16 = 64 + 8;            // dwords per row of the dG image (18 slots)
+constexpr int RED_SLOTS = 33;           // float4 slots per row of a quarter product (32 units + 1: 8 consecutive rows = 8 slot classes)
+constexpr int RS16_SLOTS = 256;         // granule slots of one (receiver, sender) pair in the exchange buffer (16 rows x 16)
+template <int V> struct lv_const { static constexpr int value = V; };
+
+// ---- weight images ------------------------------------------------------------------------------------------------------------
+// forward:  Wk16[wave_id (128) = 4m + w][ks (8)][nb (8)][lane (64)] uint4.  Lane (c = l & 15, kq = l >> 4) holds, for gate column
+//           16 nb + c of workgroup m (unit 32m + ((16 nb + c) >> 2), gate c & 3), the 8 weights of k = 256w + 32ks + 8kq + e.
+__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * 8 * 8 * 64) return;
+    const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 7), ks = (int)((idx >> 9) & 7);
+    const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
+    const int c = l & 15, kq = l >> 4, col = 16 * nb + c;
+    const float* row = whh + ((long)(col & 3) * PH + 32 * m + (col >> 2)) * PH + 256 * w + 32 * ks + 8 * kq;
+    wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
+                          lv_pack_bf16x2(row[6], row[7]));
+}
+// BPTT:     Wrs16[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)] uint4.  Lane (c, kq) holds, for output unit
+//           j = 256w + 16 nb + c, the 8 weights W_hh[gate * H + unit][j] of the workgroup's local gate rows n'' = 32ks + 8kq + e
+//           (unit = 32m + (n'' >> 2), gate = n'' & 3).
+__global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128L * 4 * 16 * 64) return;
+    const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 15), ks = (int)((idx >> 10) & 3);
+    const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
+    const int c = l & 15, kq = l >> 4, j = 256 * w + 16 * nb + c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int n2 = 32 * ks + 8 * kq + e;
+        v[e] = whh[((long)(n2 & 3) * PH + 32 * m + (n2 >> 2)) * PH + j];
+    }
+    wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+
+struct Fwd16P {
+    const float* gx; const uint4* wpk;
+    float* hs; float* cs; float* gates;
+    gran_t* hx;                 // exchange: [2 parity][8 groups][16 rows][H/2] granules, zeroed before the launch
+    int* status;
+    int T, B, R;
+};
+
+// =====================================================================================================================
+// forward.  RP: rows per group this instantiation carries (4 / 8 / 16); NP = pairs (row, unit) per thread; SBK = timesteps per
+// I/O block; GJ = granules per lane in flight per polling round.
+template <int RP> struct Cfg16 {
+    static constexpr int NP = RP > 8 ? 2 : 1;
+    static constexpr int SBK = RP > 8 ? 4 : 8;
+    static constexpr int SBB = RP > 8 ? 2 : 8;       // BPTT: two pairs per thread at 16 rows leave room for 2-step blocks only
+    static constexpr int GJ = RP > 4 ? 16 : 8;
+};
+
+template <int RP>
+struct __attribute__((aligned(16))) Fwd16Lds {
+    uint32_t hl[RP * HP16];                   // gathered h_{t-1}: [row][k/2]; wave w owns dwords [128w, 128w + 128) of every row
+    f32x4 red[2][4][RP][RED_SLOTS];           // [step parity][wave]: quarter product, (i, f, g, o) of [row][unit of the workgroup]
+    int abort;
+};
+
+template <int RP>
+__global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
+    constexpr int NP = Cfg16<RP>::NP, SBK = Cfg16<RP>::SBK, GJ = Cfg16<RP>::GJ;
+    LV_BLOCK_SHARED(Fwd16Lds<RP>, sm);
+    int& s_abort = sm.abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    if (rows == 0) return;                                    // a group without rows leaves its XCD to whoever else wants it
+    if (tid == 0) s_abort = 0;
+
+    uint4 wreg[8][8];                                         // [ks][nb]: 256 VGPRs, resident for the whole call
+    {
+        const uint4* wp = p.wpk + (long)wave_id * 8 * 8 * 64 + l;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) wreg[ks][nb] = wp[(ks * 8 + nb) * 64];
+    }
+
+    // this thread's (row, unit) pairs: rows tid >> 5 (+ 8 for the second pair), unit tid & 31 of the workgroup
+    const int uw = tid & 31, punit = 32 * member + uw;
+    const long BH = (long)B * PH;
+    int prow[NP]; bool own[NP]; long pidx[NP]; float c_state[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        prow[q] = (tid >> 5) + 8 * q;
+        own[q] = prow[q] < rows;
+        pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
+        c_state[q] = own[q] ? p.cs[pidx[q]] : 0.f;
+    }
+    gran_t* const hx_g = p.hx + (long)group * 16 * (PH / 2);
+    const long hx_par = (long)PGROUPS * 16 * (PH / 2);
+    const bool even = !(uw & 1);
+
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {      // publish the initial state hs[0] as state 0 (tag 1)
+        const uint32_t mine = lv_f32_to_bf16_bits(own[q] ? p.hs[pidx[q]] : 0.f);
+        const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+        if (own[q] && even) gran_store(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
+    }
+
+    float4 gxb[NP][SBK], recb[NP][SBK];
+    float cb[NP][SBK], hb[NP][SBK];
+    auto load_block = [&](int tb) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < SBK; ++s2) {
+                const int t = tb + s2;
+                gxb[q][s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (own[q] && t < T) gxb[q][s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx[q]) * 4);
+            }
+    };
+    auto store_block = [&](int tb) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < SBK; ++s2) {
+                const int t = tb + s2;
+                if (own[q] && t < T) {
+                    lv_store_nt(f32x4{recb[q][s2].x, recb[q][s2].y, recb[q][s2].z, recb[q][s2].w},
+                                reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx[q]) * 4));
+                    lv_store_nt(cb[q][s2], p.cs + (long)(t + 1) * BH + pidx[q]);
+                    lv_store_nt(hb[q][s2], p.hs + (long)(t + 1) * BH + pidx[q]);
+                }
+            }
+    };
+    load_block(0);
+    __syncthreads();
+
+    const int nq = rows * 128;                                 // granules of this wave's K quarter
+    const int brow = (l & 15) < rows ? (l & 15) : 0;           // batch row of this lane's B fragments (rows beyond the slice re-read row 0)
+    const int kq = l >> 4;
+    for (int tb = 0; tb < T; tb += SBK) {
+#pragma unroll
+        for (int s2 = 0; s2 < SBK; ++s2) {
+            const int t = tb + s2;
+            if (t >= T) break;
+            // ---- gather K-quarter w of state t (tag t + 1) into this wave's part of the LDS image ---------------------------
+            const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
+            const uint32_t want = (uint32_t)(t + 1);
+            for (int base = 0; base < nq; base += 64 * GJ) {
+                gran_t v[GJ];
+                uint32_t pending = 0;
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) pending |= (base + j * 64 + l < nq) ? (1u << j) : 0u;
+                int spins = 0;
+                while (true) {
+#pragma unroll
+                    for (int j = 0; j < GJ; ++j) {
+                        if (pending & (1u << j)) {
+                            const int q = base + j * 64 + l;
+                            v[j] = gran_load(src + (q >> 7) * (PH / 2) + (q & 127));
+                            if ((uint32_t)(v[j] >> 32) == want) pending &= ~(1u << j);
+                        }
+                    }
+                    if (__all(pending == 0)) break;
+                    if (++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                }
+#pragma unroll
+                for (int j = 0; j < GJ; ++j) {
+                    const int q = base + j * 64 + l;
+                    if (q < nq) sm.hl[(q >> 7) * HP16 + 128 * w + (q & 127)] = (uint32_t)v[j];
+                }
+            }
+            LV_WAIT_LDS();                                     // the wave reads back only what its own lanes wrote
+
+            // ---- this wave's K quarter of the product: A = weights (16 gate columns), B = h (16 batch rows) ------------------
+            f32x4 acc[8];
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint4* bp = reinterpret_cast<const uint4*>(sm.hl + brow * HP16 + 128 * w) + kq;
+            uint4 bfr[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) bfr[ks] = bp[ks * 4];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) acc[nb] = lv_mfma_16x16x32_bf16(wreg[ks][nb], bfr[ks], acc[nb]);
+            // D: lane (c = l & 15: batch row, rq = l >> 4) holds gate columns 16 nb + 4 rq + r = the (i, f, g, o) of unit 4 nb + rq
+            if ((l & 15) < RP) {
+                f32x4* rd = sm.red[t & 1][w][l & 15];
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) rd[4 * nb + kq] = acc[nb];
+            }
+            __syncthreads();                                   // the four quarter products (double-buffered by step parity)
+            if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
+
+            // ---- cell update and hand-off of h_t ----------------------------------------------------------------------------------
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float h = 0.f;
+                if (own[q]) {
+                    const f32x4 q0 = sm.red[t & 1][0][prow[q]][uw], q1 = sm.red[t & 1][1][prow[q]][uw];
+                    const f32x4 q2 = sm.red[t & 1][2][prow[q]][uw], q3 = sm.red[t & 1][3][prow[q]][uw];
+                    const float4 gxv = gxb[q][s2];
+                    const float ig = lv_sigmoid_fast(gxv.x + ((q0[0] + q1[0]) + (q2[0] + q3[0])));
+                    const float fg = lv_sigmoid_fast(gxv.y + ((q0[1] + q1[1]) + (q2[1] + q3[1])));
+                    const float gg = lv_tanh_fast(gxv.z + ((q0[2] + q1[2]) + (q2[2] + q3[2])));
+                    const float og = lv_sigmoid_fast(gxv.w + ((q0[3] + q1[3]) + (q2[3] + q3[3])));
+                    const float c = fg * c_state[q] + ig * gg;
+                    h = og * lv_tanh_fast(c);
+                    c_state[q] = c;
+                    recb[q][s2] = make_float4(ig, fg, gg, og);
+                    cb[q][s2] = c; hb[q][s2] = h;
+                }
+                const uint32_t mine = lv_f32_to_bf16_bits(h);
+                const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+                if (own[q] && even)
+                    gran_store(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
+                               ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
+            }
+        }
+        store_block(tb);
+        load_block(tb + SBK);
+    }
+}
+
+// =====================================================================================================================
+// BPTT, reduce-scatter hand-off.  Exchange buffer: [parity][group][receiver (32)][sender (32)][RS16_SLOTS granules]; slot
+// s = 16 row + p of a (receiver, sender) pair carries the sender's partial dh of batch row `row` for the receiver's units
+// u = 16 b + 4 rq + 2 h2 + {0, 1} with p = rq + 4 h2 + 8 b (so that one store instruction writes 32 contiguous bytes per row).
+// A receiver wave sums 16 slots per "batch" (batch beta of wave w = slots [4 RP w + 16 beta, + 16) = one batch row): lane
+// (l & 15) = p, lane group l >> 4 = eight of the 32 senders, two shuffles add the four groups.  Owners: lanes 0..31 take batch
+// 2q, lanes 32..63 batch 2q + 1 (q = pair index), low / high half of the granule by (l >> 4) & 1.
+struct Bwd16P {
+    const float* dh_ext; const float* dh_last;
+    const uint4* wpk;
+    const float* gates; const float* cs; const float* hs;
+    uint16_t* dG16; float* dGsum;
+    float* dh0; float* dc0; int tanh_init;
+    gran_t* gxch;
+    int* status;
+    int T, B, R;
+};
+
+template <int RP>
+struct __attribute__((aligned(16))) Bwd16Lds {
+    uint32_t dgl[2][16 * DP16];                         // [step parity] dG of this workgroup's 128 gate rows (B operand image), rows < R valid
+    uint16_t og[Cfg16<RP>::SBB][RP][4][32];             // dG of one I/O block: [step][row][gate][unit in WG]
+    int abort;
+};
+
+template <int RP>
+__global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
+    constexpr int NP = Cfg16<RP>::NP, SBK = Cfg16<RP>::SBB;
+    constexpr int NB = RP / 4;                          // slot batches (= batch rows) a wave receives
+    LV_BLOCK_SHARED(Bwd16Lds<RP>, sm);
+    int& s_abort = sm.abort;
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int group = (int)blockIdx.x % PGROUPS, member = (int)blockIdx.x / PGROUPS;
+    const int wave_id = member * 4 + w;
+    const int B = p.B, R = p.R, T = p.T;
+    const int b0 = group * R;
+    const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    if (rows == 0) return;
+    if (tid == 0) s_abort = 0;
+    for (int i = tid; i < 2 * 16 * DP16; i += 256) sm.dgl[0][i] = 0u;      // rows the slice does not have multiply as zeros
+
+    uint4 wreg[4][16];                                  // [ks][nb]
+    {
+        const uint4* wp = p.wpk + (long)wave_id * 4 * 16 * 64 + l;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 16; ++nb) wreg[ks][nb] = wp[(ks * 16 + nb) * 64];
+    }
+
+    // owner pairs of this lane: batch beta = 2q + (l >> 5) of wave w -> batch row NB w + beta; unit from the slot position
+    const int pp = l & 15;
+    const int uw = 16 * (pp >> 3) + 4 * (pp & 3) + 2 * ((pp >> 2) & 1) + ((l >> 4) & 1);
+    const int punit = 32 * member + uw;
+    const long BH = (long)B * PH;
+    int prow[NP]; bool own[NP]; long pidx[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int beta = 2 * q + (l >> 5);
+        prow[q] = NB * w + beta;
+        own[q] = beta < NB && prow[q] < rows;
+        pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
+    }
+    const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * RS16_SLOTS;
+    gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * RS16_SLOTS;
+    // receive: sender 8 (l >> 4) + j, slot 4 RP w + 16 beta + (l & 15)
+    const gran_t* const rx = px_g + ((long)member * PMEMBERS + 8 * (l >> 4)) * RS16_SLOTS + 4 * RP * w + pp;
+    // send: lane (c = l & 15: batch row, rq = l >> 4), column block nb -> receiver 8w + (nb >> 1), slot 16 c + rq + 4 h2 + 8 (nb & 1)
+    gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * RS16_SLOTS + 16 * (l & 15) + (l >> 4);
+
+    float dc_rec[NP], gsum[NP][4];
+    float dhb[NP][SBK], ctb[NP][SBK + 1];
+    float4 recb[NP][SBK];
+    uint32_t outb[NP][SBK][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { dc_rec[q] = 0.f; gsum[q][0] = gsum[q][1] = gsum[q][2] = gsum[q][3] = 0.f; }
+    auto load_block = [&](int t_hi) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int s2 = 0; s2 < SBK; ++s2) {
+                const int t = t_hi - s2;
+                dhb[q][s2] = 0.f; recb[q][s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (own[q] && t >= 0) {
+                    if (p.dh_ext) dhb[q][s2] = p.dh_ext[(long)t * BH + pidx[q]];
+                    recb[q][s2] = *reinterpret_cast<const float4*>(p.gates + ((long)t * BH + pidx[q]) * 4);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 <= SBK; ++s2) {
+                const int t = t_hi - s2;
+                ctb[q][s2] = (own[q] && t + 1 >= 0) ? p.cs[(long)(t + 1) * BH + pidx[q]] : 0.f;
+            }
+        }
+    };
+    auto store_block = [&](int t_hi) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (own[q]) {
+#pragma unroll
+                for (int s2 = 0; s2 < SBK; ++s2) {
+                    sm.og[s2][prow[q]][0][uw] = (uint16_t)(outb[q][s2][0] & 0xFFFFu);
+                    sm.og[s2][prow[q]][1][uw] = (uint16_t)(outb[q][s2][0] >> 16);
+                    sm.og[s2][prow[q]][2][uw] = (uint16_t)(outb[q][s2][1] & 0xFFFFu);
+                    sm.og[s2][prow[q]][3][uw] = (uint16_t)(outb[q][s2][1] >> 16);
+                }
+            }
+        __syncthreads();
+        for (int c = tid; c < SBK * RP * 4 * 4; c += 256) {      // 16-byte chunks: [step][row][gate][quarter of 32 units]
+            const int qq = c & 3, g = (c >> 2) & 3, r = (c >> 4) % RP, s2 = (c >> 4) / RP;
+            const int t = t_hi - s2;
+            if (t >= 0 && r < rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&sm.og[s2][r][g][8 * qq]);      // 8 bf16, moved as raw bits
+                uint16_t* dst = p.dG16 + ((long)t * B + (b0 + r)) * 4 * PH + (long)g * PH + 32 * member + 8 * qq;
+                lv_store_nt(v, reinterpret_cast<f32x4*>(dst));
+            }
+        }
+        __syncthreads();
+    };
+    load_block(T - 1);
+    __syncthreads();
+
+    const int brow = l & 15, kq = l >> 4;                // B-fragment row of this lane (rows beyond the slice are zero in the image)
+    const bool closing = p.dh0 || p.tanh_init;
+
+    // receive phase k: the 32 senders' partial sums for this wave's NB batch rows x 32 units; owners get their pairs' totals.
+    // Two batch rows (16 granules per lane) are polled at a time: all 32 granules of the 16-row form in flight at once would
+    // need 64 registers next to the 256 of the weights (the first build spilled 92); the sums over the senders are taken in a
+    // fixed order once a round is complete, so the result does not depend on arrival order.
+    constexpr int HB = NB < 2 ? NB : 2;
+    auto receive_round = [&](auto H0, const gran_t* src, uint32_t want, float (&dh_rec)[NP]) -> bool {
+        constexpr int h0 = decltype(H0)::value;
+        gran_t v[HB][8];
+        uint32_t pending = (1u << (HB * 8)) - 1u;
+        int spins = 0;
+        while (true) {
+#pragma unroll
+            for (int bt = 0; bt < HB; ++bt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t bit = 1u << (bt * 8 + j);
+                    if (pending & bit) {
+                        v[bt][j] = gran_load(src + (long)j * RS16_SLOTS + 16 * (h0 + bt));
+                        if ((uint32_t)(v[bt][j] >> 56) == want) pending &= ~bit;
+                    }
+                }
+            if (__all(pending == 0)) break;
+            if (++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+        }
+#pragma unroll
+        for (int bt = 0; bt < HB; ++bt) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a += rs_lo(v[bt][j]); b += rs_hi(v[bt][j]); }
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            // batch h0 + bt belongs to pair q = (h0 + bt) >> 1 of the lanes with (l >> 5) == ((h0 + bt) & 1)
+            if ((l >> 5) == ((h0 + bt) & 1)) dh_rec[(h0 + bt) >> 1] = (l & 16) ? b : a;
+        }
+        return true;
+    };
+    auto receive = [&](int k, float (&dh_rec)[NP]) -> bool {
+        const gran_t* src = rx + (long)(k & 1) * px_par;
+        const uint32_t want = rs_tag(k);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dh_rec[q] = 0.f;
+        if (!receive_round(lv_const<0>(), src, want, dh_rec)) return false;
+        if constexpr (NB > HB) {
+            if (!receive_round(lv_const<HB>(), src, want, dh_rec)) return false;
+        }
+        return true;
+    };
+    // multiply the dG image of step parity `par` with this wave's 256 output units and send phase k to their owners
+    auto send = [&](int par, int k) {
+        const uint4* bp = reinterpret_cast<const uint4*>(sm.dgl[par] + brow * DP16) + kq;
+        uint4 bfr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bfr[ks] = bp[ks * 4];
+        const uint32_t tag = rs_tag(k);
+        gran_t* dst = tx + (long)(k & 1) * px_par;
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) {                 // four column blocks at a time: their granules go out while the next four multiply
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = lv_mfma_16x16x32_bf16(wreg[ks][4 * n4 + j], bfr[ks], acc[j]);
+            if ((l & 15) < RP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nb = 4 * n4 + j;
+                    gran_t* d = dst + (long)(nb >> 1) * PMEMBERS * RS16_SLOTS + 8 * (nb & 1);
+                    gran_store(d, rs_pack(acc[j][0], acc[j][1], tag));
+                    gran_store(d + 4, rs_pack(acc[j][2], acc[j][3], tag));
+                }
+            }
+        }
+    };
+
+    bool aborted = false;
+    for (int t_hi = T - 1; t_hi >= 0; t_hi -= SBK) {
+#pragma unroll
+        for (int s2 = 0; s2 < SBK; ++s2) {
+            const int t = t_hi - s2;
+            if (t < 0 || aborted) continue;       // (no early exit from the unrolled block: its register arrays must stay registers)
+            float dh_rec[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dh_rec[q] = 0.f;
+            if (t < T - 1) receive(T - 1 - t, dh_rec);        // on a timeout s_abort is set: everybody leaves after the barrier below
+            const int par = (T - t) & 1;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float da[4] = {0.f, 0.f, 0.f, 0.f};
+                if (own[q]) {
+                    float dh = dhb[q][s2] + dh_rec[q];
+                    if (t == T - 1 && p.dh_last) dh += p.dh_last[pidx[q]];
+                    const float ig = recb[q][s2].x, fg = recb[q][s2].y, gg = recb[q][s2].z, og_ = recb[q][s2].w;
+                    const float tc = lv_tanh_fast(ctb[q][s2]);
+                    const float dc = dh * og_ * (1.f - tc * tc) + dc_rec[q];
+                    const float d_o = dh * tc;
+                    const float d_i = dc * gg, d_g = dc * ig, d_f = dc * ctb[q][s2 + 1];
+                    da[0] = d_i * ig * (1.f - ig);
+                    da[1] = d_f * fg * (1.f - fg);
+                    da[2] = d_g * (1.f - gg * gg);
+                    da[3] = d_o * og_ * (1.f - og_);
+                    dc_rec[q] = dc * fg;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gsum[q][g] += da[g];
+                }
+                const uint32_t lo = lv_pack_bf16x2(da[0], da[1]), hi = lv_pack_bf16x2(da[2], da[3]);
+                outb[q][s2][0] = lo; outb[q][s2][1] = hi;
+                if (own[q]) { sm.dgl[par][prow[q] * DP16 + 2 * uw] = lo; sm.dgl[par][prow[q] * DP16 + 2 * uw + 1] = hi; }
+            }
+            __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity)
+            if (s_abort) { aborted = true; continue; }
+            if (t > 0 || closing) send(par, T - t);
+        }
+        if (aborted) { if (tid == 0) atomicExch(p.status, 200 + (t_hi < 0 ? 0 : t_hi)); return; }
+        store_block(t_hi);
+        load_block(t_hi - SBK);
+    }
+
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        if (own[q]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p.dGsum[(long)(b0 + prow[q]) * 4 * PH + (long)g * PH + punit] = gsum[q][g];
+        }
+    if (closing) {
+        float s0[NP];
+        const bool fine = receive(T, s0);
+        __syncthreads();
+        if (!fine || s_abort) { if (tid == 0) atomicExch(p.status, 300); return; }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (own[q]) {
+                if (p.dh0) p.dh0[pidx[q]] = s0[q];
+                float dc = dc_rec[q];
+                if (p.tanh_init) { const float h0 = p.hs[pidx[q]]; dc += s0[q] * (1.f - h0 * h0); }
+                if (p.dc0) p.dc0[pidx[q]] = dc;
+            }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (own[q] && p.dc0) p.dc0[pidx[q]] = dc_rec[q];
+    }
+}
+
+constexpr long XCH_FWD16_BYTES = 2L * PGROUPS * 16 * (PH / 2) * 8;
+constexpr long XCH_RS16_BYTES = 2L * PGROUPS * PMEMBERS * PMEMBERS * RS16_SLOTS * 8;
+
+int check_R(int B, int R) { return R >= 1 && R <= 16 && (long)R * PGROUPS >= B; }
+
+}  // namespace
+
+extern "C" long lv_lstm_persist16_xch_floats(void) { return XCH_RS16_BYTES / 4 + 64; }
+
+// W_hh [4H][H] f32 -> the register image of lv_lstm_fwd_bf16_persist16 (backward = 0) / lv_lstm_bwd_bf16_persist16 (backward = 1):
+// lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
+extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
+    if (!whh || !wpk) return LV_ERR_ARG;
+    if (H != PH) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
+    const dim3 grid((unsigned)lv_cdiv(128L * 64 * 64, 256)), block(256);
+    if (backward) LV_LAUNCH(pack_w_rs16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    else LV_LAUNCH(pack_w_k16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// Forward recurrence in one persistent launch with R batch rows per XCD group (1 <= R <= 16, 8 R >= B): groups
+// [0, ceil(B / R)) carry the batch, the workgroups of the other groups return at once -- R = 8 at B = 32 runs the recurrence on
+// four XCDs and leaves the other four to concurrent kernels.  Arguments as lv_lstm_fwd_bf16_persist_ks without the in-kernel
+// dropout (the engine applies dropout_out while h is converted to its bf16 images); exchange buffer of
+// lv_lstm_persist16_xch_floats() floats.
+extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch,
+                                          int* status, int T, int B, int R, int H, void* stream) {
+    if (!gx || !wpk || !hs || !cs || !gates || !xch || !status) return LV_ERR_ARG;
+    if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // the groups in use must be resident at once
+    if (T == 0) return LV_OK;
+    gran_t* hx = reinterpret_cast<gran_t*>(xch);
+    (void)hipMemsetAsync(hx, 0, (size_t)XCH_FWD16_BYTES, (hipStream_t)stream);
+    Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, hx, status, T, B, R};
+    const dim3 grid(PGROUPS * PMEMBERS), block(256);
+    if (R <= 4) LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<4>, grid, block, 0, stream, p);
+    else if (R <= 8) LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<8>, grid, block, 0, stream, p);
+    else LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<16>, grid, block, 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// BPTT in one persistent launch, R batch rows per XCD group (as above).  Arguments as lv_lstm_bwd_bf16_persist_rs without the
+// in-kernel dropout mask; image-only (dG16).
+extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates,
+                                          const float* hs, const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status,
+                                          float* dh0, float* dc0, int tanh_init, int T, int B, int R, int H, void* stream) {
+    if (!wpk || !gates || !cs || !dG16 || !dGsum || !xch || !status) return LV_ERR_ARG;
+    if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
+    if (tanh_init && !hs) return LV_ERR_ARG;
+    if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
+        return LV_ERR_ALIGN;
+    if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
+    gran_t* gxch = reinterpret_cast<gran_t*>(xch);
+    const int groups = lv_cdiv(B, R);
+    (void)hipMemsetAsync(gxch, 0, (size_t)XCH_RS16_BYTES, (hipStream_t)stream);
+    (void)groups;
+    Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    const dim3 grid(PGROUPS * PMEMBERS), block(256);
+    if (R <= 4) LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<4>, grid, block, 0, stream, p);
+    else if (R <= 8) LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<8>, grid, block, 0, stream, p);
+    else LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<16>, grid, block, 0, stream, p);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}

@@ -1,0 +1,40 @@
+// lv_persist_common.h -- what the persistent LSTM kernels (lv_lstm_persist.hip, lv_lstm_persist16.hip) share: the XCD-group
+// geometry and the tagged 8-byte hand-off granules.
+#pragma once
+#include "lv_device.h"
+
+namespace lvp {
+
+constexpr int PH = 1024;            // hidden size the persistent kernels are built for
+constexpr int PGROUPS = 8;          // XCD-sized groups (blockIdx % 8)
+constexpr int PMEMBERS = 32;        // workgroups per group
+constexpr int SPIN_LIMIT = LV_SPIN_LIMIT;
+
+typedef unsigned long long gran_t;  // a hand-off granule: payload + tag in one 64-bit word, written and read with agent-scope accesses
+
+__device__ __forceinline__ gran_t gran_load(const gran_t* p) { return lv_agent_load_u64(p); }
+__device__ __forceinline__ void gran_store(gran_t* p, gran_t v) { lv_agent_store_u64(p, v); }
+
+// reduce-scatter granule: two partial sums as 28-bit floats (sign, exponent, 19 mantissa bits: 1e-6 relative, three orders below
+// the bf16 rounding of the operands) beside an 8-bit phase tag (phase k >= 1 -> 1..255: a zeroed buffer never matches)
+__device__ __forceinline__ uint32_t rs_tag(int k) { return 1u + (uint32_t)(k - 1) % 255u; }
+__device__ __forceinline__ gran_t rs_pack(float a, float b, uint32_t tag) {
+    uint32_t ua, ub;
+    memcpy(&ua, &a, 4);
+    memcpy(&ub, &b, 4);
+    return (gran_t)((ua + 8u) >> 4) | ((gran_t)((ub + 8u) >> 4) << 28) | ((gran_t)tag << 56);
+}
+__device__ __forceinline__ float rs_lo(gran_t g) {
+    const uint32_t u = ((uint32_t)g & 0x0FFFFFFFu) << 4;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __forceinline__ float rs_hi(gran_t g) {
+    const uint32_t u = ((uint32_t)(g >> 28) & 0x0FFFFFFFu) << 4;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace lvp

@@ -296,7 +296,21 @@ PERSIST_BWD_FORM = "rs"
 # product of the persistent forward: "ks" = contraction split over the workgroup's waves (4x4x4 MFMA, barrier after the product),
 # "cols" = gate columns split over the waves (16x16x32 MFMA, barrier before the product)
 PERSIST_FWD_FORM = "ks"
-_PERSIST_MAX_B = 64
+# Beyond 4 rows per XCD group (B > 32), or when an engine asks for a row count per group (eng.persist_rows: e.g. 8 rows on four
+# groups = a B = 32 recurrence on half the chip), the recurrences run on the kernels of lv_lstm_persist16.hip (<= 16 rows per
+# group: B <= 128, BASELINE.json configs[4]).  PERSIST16_ALWAYS routes every persistent launch there (A/B measurements).
+PERSIST16_ALWAYS = False
+_PERSIST_MAX_B = 128
+
+
+def _persist_rows(eng, B):
+    """(use the 16-row kernels?, rows per group) for a persistent launch of batch B on this engine."""
+    rows = getattr(eng, "persist_rows", None)
+    if rows is not None and 8 * rows >= B and 1 <= rows <= 16:
+        return True, int(rows)
+    if B > 32 or PERSIST16_ALWAYS:
+        return True, (B + 7) // 8
+    return False, (B + 7) // 8
 
 
 def _persistent_ok(eng, img, B, H, device, max_b):
@@ -310,7 +324,7 @@ def weights_version(eng):
     return (sum(p._version for p in eng.flat.params), eng.wgen)
 
 
-def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
+def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, want_persist16=False):
     """Engine-level bf16 images of the module's weights for the throughput path -- W_ih rows in unit-major gate order
     (4u + g: Gx comes out with each unit's (i,f,g,o) side by side), W_ih^T [ni][4H] (contraction index of dX), for the
     decoder also pred_linear.weight / its transpose, and the packed register images of W_hh for the persistent
@@ -347,13 +361,22 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
         if wi.fwd is None:
             n = lib.lv_lstm_persist_wpk_floats()
             wi.fwd, wi.bwd = c.f32(n), c.f32(n)
-            wi.xch = c.f32(lib.lv_lstm_persist_xch_floats())
+            wi.fwd16 = wi.bwd16 = None
+            wi.xch = c.f32(max(lib.lv_lstm_persist_xch_floats(), lib.lv_lstm_persist16_xch_floats()))
             wi.status = torch.zeros(1, dtype=torch.int32, device=device)
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 3 if PERSIST_FWD_FORM == "ks" else 0, H, s)
         wi.fwd_form = PERSIST_FWD_FORM
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 2 if PERSIST_BWD_FORM == "rs" else 1, H, s)
         wi.bwd_form = PERSIST_BWD_FORM
+        wi.packed16 = False
         wi.packed = True
+    if want_persist and want_persist16 and not wi.packed16:
+        if wi.fwd16 is None:
+            n = lib.lv_lstm_persist_wpk_floats()
+            wi.fwd16, wi.bwd16 = c.f32(n), c.f32(n)
+        lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), 0, H, s)
+        lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd16), 1, H, s)
+        wi.packed16 = True
     return wi
 
 
@@ -367,13 +390,19 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
     elif _persistent_ok(eng, img, B, H, device, _PERSIST_MAX_B):
         wi = eng._wimg          # packed by _weight_images(want_persist=True) at the top of the forward
-        fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
-        fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
+        use16, rows = _persist_rows(eng, B)
+        if use16:
+            if mask is not None or hdrop is not None:
+                raise _lib.LvaeError("the 16-row persistent forward has no in-kernel dropout (the engine applies it on the images)")
+            lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, H, s)
+        else:
+            fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
+            fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
 
-_PERSIST_BWD_MAX_B = 32
+_PERSIST_BWD_MAX_B = 128
 
 
 def check_persistent_status(eng):
@@ -395,9 +424,16 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
     dG16 = P(img.dG) if img is not None else None
     if _persistent_ok(eng, img, B, H, device, _PERSIST_BWD_MAX_B):
         wi = eng._wimg
-        fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
-        fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
-           dh0, dc0, tanh_init, T, B, H, s)
+        use16, rows = _persist_rows(eng, B)
+        if use16:
+            if mask is not None:
+                raise _lib.LvaeError("the 16-row persistent BPTT has no in-kernel dropout mask (the engine applies it on dO)")
+            lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
+                                           P(wi.status), dh0, dc0, tanh_init, T, B, rows, H, s)
+        else:
+            fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
+            fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
+               dh0, dc0, tanh_init, T, B, H, s)
     else:
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
                                  P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
@@ -481,6 +517,7 @@ class LSTMEncoderEngine(object):
         self.precision = "f32"    # precision of the large GEMMs: "f32" (parity) or "bf16" (throughput)
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
+        self.persist_rows = None                # rows per XCD group of the persistent launches (None: B / 8; 8 at B = 32 = half the chip)
         self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
         self._wimg = None
@@ -506,7 +543,7 @@ class LSTMEncoderEngine(object):
         self.ensure(device)
         persist = self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and torch.device(device).type == "cuda" and \
             torch.cuda.get_device_properties(device).multi_processor_count >= 256
-        return _weight_images(self, self.lib, stream_ptr(device), device, persist)
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist, want_persist16=_persist_rows(self, B)[0])
 
     def ensure(self, device):
         device = torch.device(device)
@@ -671,6 +708,7 @@ class LSTMDecoderEngine(object):
         self.overlap = None       # None = auto policy (_overlap_on); True / False force it
         self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
+        self.persist_rows = None                # rows per XCD group of the persistent launches (see LSTMEncoderEngine)
         # The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only): its bf16
         # weight images and packed recurrent weights are rebuilt only when weights_version() changes.
         self.cache_weight_images = True
@@ -821,7 +859,8 @@ class LSTMDecoderEngine(object):
         self.ensure(device)
         persist = use_lstm and self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and \
             torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256
-        return _weight_images(self, self.lib, stream_ptr(device), device, persist, lstm=use_lstm, pred=use_pred)
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist, lstm=use_lstm, pred=use_pred,
+                              want_persist16=_persist_rows(self, B)[0])
 
     def _lstm_images(self, Bd, Td):
         V, ni, H, nz = self.dims()

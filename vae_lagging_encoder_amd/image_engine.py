@@ -271,13 +271,9 @@ class Tape(object):
                               P(self.bn_ws(C)), Pn, C, s)
             self.bn_seen.append(bn.num_batches_tracked)
         else:
-            # eval mode (evaluation helpers only): normalise with the running statistics (tensor algebra)
-            mean.copy_(bn.running_mean)
-            invstd.copy_(torch.rsqrt(bn.running_var + bn.eps))
-            yy = (x.t - mean) * invstd * bn.weight + bn.bias
-            if res is not None:
-                yy = yy + res.t
-            y.copy_(torch.nn.functional.elu(yy) if act else yy)
+            # eval mode (evaluation passes, sampling: SURVEY.md 8f): the running statistics, one streaming launch
+            lib.lv_bn_eval_f32(P(x.t), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), bn.eps,
+                               P(res.t) if res is not None else None, int(act), P(y), P(mean), P(invstd), Pn, C, s)
         out = Act(y, x.N, x.H, x.W, C)
 
         def bwd():
