@@ -150,15 +150,17 @@ int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const
  * and R = 8 at B = 32 runs a recurrence on FOUR XCDs, leaving the other four to concurrent kernels.  Contraction on the
  * 16 x 16 x 32 MFMA with the weights as the A operand.  Weight images: lv_lstm_persist16_pack(whh, wpk, backward, H)
  * (lv_lstm_persist_wpk_floats() floats); exchange buffer: lv_lstm_persist16_xch_floats() floats; *status as above.  No in-kernel
- * dropout (the caller applies dropout_out on the bf16 images of h and once on dO).  LV_ERR_UNSUPPORTED unless H == 1024 and the
- * device has >= 256 CUs. */
+ * dropout (the caller applies dropout_out on the bf16 images of h and once on dO).  flags bit 0: the hand-off granules are stored
+ * without the agent-scope write-through, i.e. they stay in the XCD's L2 instead of travelling to memory (valid while every group is
+ * XCD-local, which the round-robin workgroup placement of a 256-CU device gives; a violated assumption shows up as a hand-off
+ * timeout in *status).  LV_ERR_UNSUPPORTED unless H == 1024 and the device has >= 256 CUs. */
 long lv_lstm_persist16_xch_floats(void);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
 int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch, int* status,
-                               int T, int B, int R, int H, void* stream);
+                               int T, int B, int R, int flags, int H, void* stream);
 int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates, const float* hs,
                                const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
-                               int tanh_init, int T, int B, int R, int H, void* stream);
+                               int tanh_init, int T, int B, int R, int flags, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,

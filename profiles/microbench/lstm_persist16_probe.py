@@ -40,19 +40,22 @@ def bufs(B):
 
 
 print("forward / BPTT, us per timestep (T = %d)" % T)
-for B, R in ((32, 4), (32, 8), (32, 16), (64, 8), (128, 16), (16, 4), (16, 8)):
+for B, R in ((32, 4), (32, 8), (32, 16), (64, 8), (128, 16)):
     gx, hs, cs, gates, dO, dG16, dGsum, dc0 = bufs(B)
     line = "B=%3d R=%2d (%d groups): " % (B, R, (B + R - 1) // R)
     if R == 4 and B <= 32:
         a = t(lambda: lib.lv_lstm_fwd_bf16_persist_ks(P(gx), P(wf4), P(hs), P(cs), P(gates), None, 1.0, None, P(xch), P(st), T, B, H, s))
         line += "fwd ks(4x4x4) %.2f | " % (a / T)
-    a = t(lambda: lib.lv_lstm_fwd_bf16_persist16(P(gx), P(wf16), P(hs), P(cs), P(gates), P(xch), P(st), T, B, R, H, s))
-    line += "fwd k16 %.2f | " % (a / T)
+    for fl in (0, 1):
+        a = t(lambda: lib.lv_lstm_fwd_bf16_persist16(P(gx), P(wf16), P(hs), P(cs), P(gates), P(xch), P(st), T, B, R, fl, H, s))
+        line += "fwd k16%s %.2f | " % ("/L2" if fl else "", a / T)
     if R == 4 and B <= 32:
         a = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(P(dO), None, None, 1.0, P(wb4), P(gates), P(hs), P(cs), None, P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, H, s))
         line += "bwd rs(4x4x4) %.2f | " % (a / T)
-    a = t(lambda: lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb16), P(gates), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, R, H, s))
-    line += "bwd rs16 %.2f | status %d" % (a / T, int(st.item()))
+    for fl in (0, 1):
+        a = t(lambda: lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb16), P(gates), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, R, fl, H, s))
+        line += "bwd rs16%s %.2f | " % ("/L2" if fl else "", a / T)
+    line += "status %d" % int(st.item())
     print(line)
 
 # ---- experiment A: half-chip recurrence with a GEMM beside it -------------------------------------------------------------------------
@@ -85,7 +88,7 @@ g_alone = wall(lambda: gemm(s))
 print("dW_pred GEMM alone (full chip): %.1f us" % g_alone)
 for R in (4, 8):
     def bptt():
-        lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb16), P(gates), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, R, H, s)
+        lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb16), P(gates), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, R, 0, H, s)
     alone = wall(bptt)
 
     def both():
@@ -96,5 +99,15 @@ for R in (4, 8):
             gemm(side.cuda_stream)
         torch.cuda.current_stream().wait_stream(side)
     tot = wall(both)
+
+    def both_gemm_first():
+        ev = torch.cuda.Event(); ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            gemm(side.cuda_stream)                          # the GEMM first: the recurrence's workgroups take CUs as its tiles retire
+        bptt()
+        torch.cuda.current_stream().wait_stream(side)
+    tot2 = wall(both_gemm_first)
+    print("  (GEMM queued first: %.1f us)" % tot2)
     print("BPTT R=%d alone %.1f us (%.2f us/step); BPTT + dW_pred on a second stream: %.1f us  (serial would be %.1f)  status %d" % (
         R, alone, alone / T, tot, alone + g_alone, int(st.item())))

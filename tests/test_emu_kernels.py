@@ -197,13 +197,13 @@ def test_conv_bnstat(emu_backend, cfg):
 def test_lstm_fwd_persistent16_emulated(emu_backend, T, B, R):
     """lv_lstm_persist16.hip (R rows per XCD group, 16x16x32 MFMA with the weights as the A operand), all three instantiations
     (R <= 4 / 8 / 16), ragged last groups, groups left empty."""
-    K.test_lstm_fwd_persistent16(emu_backend, CPU, T, B, R)
+    K.test_lstm_fwd_persistent16(emu_backend, CPU, T, B, R, 0)
 
 
 @pytest.mark.parametrize("cfg", [(3, 8, 1, True, True, False), (2, 20, 3, False, True, True), (2, 18, 6, True, True, True),
                                  (2, 27, 14, True, True, False)])
 def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
-    K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg)
+    K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg, 0)
 
 
 def test_lstm_fwd_persistent_emulated(emu_backend):

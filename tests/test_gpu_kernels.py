@@ -328,7 +328,7 @@ def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ex
 
 
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
-def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=None):
+def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=None, flags=0):
     """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
     and against the launch-per-step kernel fed the same unit-major gx.  variant "k16" = lv_lstm_persist16.hip with R batch rows
     per XCD group (no in-kernel dropout there: use_mask must be off)."""
@@ -357,7 +357,7 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=No
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
             lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(ws), P(status), T, B,
-                                           R if R is not None else (B + 7) // 8, H, _s(dev))
+                                           R if R is not None else (B + 7) // 8, flags, H, _s(dev))
             assert int(status.item()) == 0
             hdrop = hs[1:].clone()
         elif persistent:
@@ -386,7 +386,7 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=No
     (6, 32, True, True, True, False), (1, 5, False, False, True, True), (9, 32, True, False, True, True),
     (40, 32, False, True, True, False), (3, 13, True, True, True, True), (17, 8, False, False, False, True),
 ])
-def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs", R=None):
+def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs", R=None, flags=0):
     """The one-launch persistent BPTT (H = 1024; variant "rs" = reduce-scatter hand-off, "ag" = all-gather hand-off, "rs16" =
     lv_lstm_persist16.hip with R batch rows per XCD group, no in-kernel dropout mask) against the float64 autograd of the same
     recurrence (bf16-recurrence tolerance) and against the two-launch-per-step kernels on the same saved activations."""
@@ -439,7 +439,7 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_bwd_bf16_persist16(P(wext) if use_ext else None, P(wlast) if use_last else None, P(wpk), P(gates), P(hs), P(cs),
                                            P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B,
-                                           R if R is not None else (B + 7) // 8, H, _s(dev))
+                                           R if R is not None else (B + 7) // 8, flags, H, _s(dev))
             assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
             dG = torch.cat([dG16.view(torch.bfloat16).float()])
         elif persistent:
@@ -530,11 +530,12 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
 
 @pytest.mark.parametrize("T,B,R", [(6, 32, 4), (9, 32, 8), (5, 64, 8), (7, 128, 16), (40, 32, 8), (3, 13, 2), (4, 100, 13), (12, 32, 16),
                                    (1, 5, 5)])
-def test_lstm_fwd_persistent16(lib, hip_device, T, B, R):
+@pytest.mark.parametrize("flags", [0, 1])
+def test_lstm_fwd_persistent16(lib, hip_device, T, B, R, flags):
     """lv_lstm_persist16.hip forward: R rows per XCD group -- 8 groups x 4 (the default shape), 4 groups x 8 and 2 groups x 16
     (a B = 32 recurrence on half / a quarter of the chip), 8 x 8 and 8 x 16 (B = 64 / the stress configuration's B = 128), ragged
     slices."""
-    test_lstm_fwd_persistent(lib, hip_device, T, B, False, variant="k16", R=R)
+    test_lstm_fwd_persistent(lib, hip_device, T, B, False, variant="k16", R=R, flags=flags)
 
 
 @pytest.mark.parametrize("T,B,R,tanh_init,use_ext,use_last", [
@@ -542,8 +543,9 @@ def test_lstm_fwd_persistent16(lib, hip_device, T, B, R):
     (40, 32, 8, True, True, False), (3, 13, 2, True, True, True), (4, 100, 13, False, True, True), (17, 8, 1, False, False, True),
     (12, 32, 16, True, True, False),
 ])
-def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use_last):
-    test_lstm_bwd_persistent(lib, hip_device, T, B, False, tanh_init, use_ext, use_last, variant="rs16", R=R)
+@pytest.mark.parametrize("flags", [0, 1])
+def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use_last, flags):
+    test_lstm_bwd_persistent(lib, hip_device, T, B, False, tanh_init, use_ext, use_last, variant="rs16", R=R, flags=flags)
 
 
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (9, 64, True), (3, 13, False)])
@@ -814,10 +816,10 @@ def test_batchnorm_eval(lib, hip_device, N, C, H, act, use_res):
         y_ref = F.elu(y_ref)
     Pn = N * H * H
     xd, resd = _nhwc(x).to(dev), _nhwc(res).to(dev)
-    rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
+    rmd, rvd, gd, bd = rm.clone().to(dev), rv.clone().to(dev), gamma.to(dev), beta.to(dev)     # (named: P() of a temporary dangles)
     y = torch.full((Pn, C), float("nan"), device=dev)
     mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    lib.lv_bn_eval_f32(P(xd), P(gamma.to(dev)), P(beta.to(dev)), P(rmd), P(rvd), 1e-5, P(resd) if use_res else None, int(act), P(y),
+    lib.lv_bn_eval_f32(P(xd), P(gd), P(bd), P(rmd), P(rvd), 1e-5, P(resd) if use_res else None, int(act), P(y),
                        P(mean), P(invstd), Pn, C, _s(dev))
     assert float((_nchw(y.cpu(), N, H, H).double() - y_ref).abs().max()) < 2e-5
     assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv) and torch.equal(mean.cpu(), rm)

@@ -67,7 +67,7 @@ def test_bf16_throughput_path_tracks_oracle(hip_device):
     assert out["grads"] < 5e-2, out
 
 
-@pytest.mark.parametrize("persistent", [True, False, "rows4", "rows8", "rows16"])
+@pytest.mark.parametrize("persistent", [True, False, "rows4", "rows8", "rows16", "four_row_kernels", "write_through"])
 def test_bf16_throughput_path_h1024(hip_device, persistent):
     """H = 1024, B = 32: the shape class on which the bf16 path runs its LSTM recurrences as persistent XCD-group launches
     (when the device has >= 256 CUs).  Every realisation must track the f32 oracle to the bf16 path's documented delta: the
@@ -81,11 +81,20 @@ def test_bf16_throughput_path_h1024(hip_device, persistent):
     r = O.inner_step(P, x, klw, eps, m_in, m_out)
     vae = build_vae(V, ni, H, nz, hip_device, params=P)
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
+    from vae_lagging_encoder_amd import engine
     tr.enc.persistent = tr.dec.persistent = bool(persistent)
-    if isinstance(persistent, str):
+    if isinstance(persistent, str) and persistent.startswith("rows"):
         tr.enc.persist_rows = tr.dec.persist_rows = int(persistent[4:])
-    tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
-    st = tr.read_stats()          # also checks the persistent launches' status words
+    saved = (engine.PERSIST16_ALWAYS, engine.PERSIST16_FLAGS)
+    try:
+        if persistent == "four_row_kernels":          # lv_lstm_persist.hip (4x4x4 MFMA forms), the round-2 default
+            engine.PERSIST16_ALWAYS = False
+        if persistent == "write_through":             # hand-off granules written through to memory (agent scope)
+            engine.PERSIST16_FLAGS = 0
+        tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+        st = tr.read_stats()          # also checks the persistent launches' status words
+    finally:
+        engine.PERSIST16_ALWAYS, engine.PERSIST16_FLAGS = saved
     assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
     assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
     named = dict(vae.named_parameters())
@@ -523,8 +532,11 @@ def test_image_lr_decay_recreates_the_adam_optimizers(hip_device):
     tr2.step(x, 0.5, eps=eps, update="both")
     for k, v in vae2.state_dict().items():
         assert torch.equal(v, after_reset[k]), k
-    moved = max(float((after_reset[k] - snap[k]).abs().max()) for k in snap if k.endswith(".weight"))
-    assert 1e-4 < moved <= 0.0005 * 1.001            # Adam's first step is lr * sign(g) where the gradient is non-zero
+    # Adam's first step is lr * sign(g) where the gradient is non-zero (unmasked weights: the masked taps of MaskedConv2d also
+    # collect Adam updates -- the reference keeps their gradients, G5 -- and are re-zeroed by the next forward)
+    lin = "decoder.z_transform.0.weight"
+    moved = float((after_reset[lin] - snap[lin]).abs().max())
+    assert 1e-4 < moved <= 0.0005 * 1.001, moved
 
 
 def test_image_eval_forward_after_decoder_update(hip_device):

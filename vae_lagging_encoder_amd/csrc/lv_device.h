@@ -23,6 +23,7 @@ static inline unsigned long long lv_agent_load_u64(const unsigned long long* p) 
     return __atomic_load_n(p, __ATOMIC_RELAXED);
 }
 static inline void lv_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+static inline void lv_xcd_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 #define LV_WAIT_LDS() lv_emu::wave_sync()      // lanes are fibers here: 'the wave's own LDS writes are visible' needs a rendezvous
 template <class T> static inline void lv_store_nt(T v, T* p) { *p = v; }
 static inline int lv_device_cus() { return 1 << 20; }
@@ -113,6 +114,13 @@ __device__ __forceinline__ unsigned long long lv_agent_load_u64(const unsigned l
 }
 __device__ __forceinline__ void lv_agent_store_u64(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The same 64-bit store WITHOUT the agent-scope write-through (no sc1): it reaches the XCD's L2 through the write-through vector
+// L1 and stays there, visible to sc1 loads of the CUs of THAT XCD only.  For hand-offs inside an XCD-local group: the granules
+// then never travel to the fabric (the agent-scope form writes every granule through to memory).  A reader on another XCD would
+// never see it -- callers must be able to detect that (bounded spins) and fall back.
+__device__ __forceinline__ void lv_xcd_store_u64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 #define LV_SPIN_LIMIT (1 << 22)             // polls per wait before a hand-off is reported lost (~1 s)
 // lgkmcnt(0): a wave's own LDS accesses are ordered; enough when the data is wave-private

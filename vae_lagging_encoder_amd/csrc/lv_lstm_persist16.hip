@@ -31,7 +31,7 @@ using namespace lvp;
 constexpr int HP16 = PH / 2 + 8;        // dwords per row of the gathered h image (130 slots: = 2 mod 16)
 constexpr int DP16 = 64 + 8;            // dwords per row of the dG image (18 slots)
 constexpr int RED_SLOTS = 33;           // float4 slots per row of a quarter product (32 units + 1: 8 consecutive rows = 8 slot classes)
-constexpr int RS16_SLOTS = 256;         // granule slots of one (receiver, sender) pair in the exchange buffer (16 rows x 16)
+constexpr int RS16_SLOTS_MAX = 256;     // granule slots of one (receiver, sender) pair at 16 rows (16 RP in general: the pairs are dense)
 template <int V> struct lv_const { static constexpr int value = V; };
 
 // ---- weight images ------------------------------------------------------------------------------------------------------------
@@ -87,11 +87,14 @@ template <int RP>
 struct __attribute__((aligned(16))) Fwd16Lds {
     uint32_t hl[RP * HP16];                   // gathered h_{t-1}: [row][k/2]; wave w owns dwords [128w, 128w + 128) of every row
     f32x4 red[2][4][RP][RED_SLOTS];           // [step parity][wave]: quarter product, (i, f, g, o) of [row][unit of the workgroup]
+    uint32_t dump[256];                       // where the lanes of a ragged gather round put what they did not need (no branch per granule)
     int abort;
 };
 
-template <int RP>
+template <int RP, bool LOCAL>
 __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
+    // LOCAL: hand-off stores without the agent-scope write-through (lv_xcd_store_u64): valid while a group's 32 workgroups share an XCD
+    auto put = [](gran_t* q, gran_t v) { if (LOCAL) lv_xcd_store_u64(q, v); else gran_store(q, v); };
     constexpr int NP = Cfg16<RP>::NP, SBK = Cfg16<RP>::SBK, GJ = Cfg16<RP>::GJ;
     LV_BLOCK_SHARED(Fwd16Lds<RP>, sm);
     int& s_abort = sm.abort;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     for (int q = 0; q < NP; ++q) {      // publish the initial state hs[0] as state 0 (tag 1)
         const uint32_t mine = lv_f32_to_bf16_bits(own[q] ? p.hs[pidx[q]] : 0.f);
         const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
-        if (own[q] && even) gran_store(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
+        if (own[q] && even) put(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
     }
 
     float4 gxb[NP][SBK], recb[NP][SBK];
@@ -176,27 +179,28 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
             const uint32_t want = (uint32_t)(t + 1);
             for (int base = 0; base < nq; base += 64 * GJ) {
+                // every poll round issues ALL its loads before it looks at a tag (first build: a load and its tag test per granule
+                // inside one predicated block compiled to load -> wait -> compare, GJ dependent round trips: 6.8 us per step at 8 rows)
                 gran_t v[GJ];
-                uint32_t pending = 0;
-#pragma unroll
-                for (int j = 0; j < GJ; ++j) pending |= (base + j * 64 + l < nq) ? (1u << j) : 0u;
                 int spins = 0;
-                while (true) {
+                bool ok;
+                do {
+                    ok = true;
 #pragma unroll
                     for (int j = 0; j < GJ; ++j) {
-                        if (pending & (1u << j)) {
-                            const int q = base + j * 64 + l;
-                            v[j] = gran_load(src + (q >> 7) * (PH / 2) + (q & 127));
-                            if ((uint32_t)(v[j] >> 32) == want) pending &= ~(1u << j);
-                        }
+                        const int q = base + j * 64 + l;
+                        const bool in = q < nq;
+                        v[j] = gran_load(src + (in ? (q >> 7) * (PH / 2) + (q & 127) : 0));      // out-of-range lanes re-read granule 0: no branch
+                        ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
                     }
-                    if (__all(pending == 0)) break;
-                    if (++spins > SPIN_LIMIT) { s_abort = 1; break; }
-                }
+                    ok = __all(ok);
+                    if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                } while (!ok);
 #pragma unroll
                 for (int j = 0; j < GJ; ++j) {
                     const int q = base + j * 64 + l;
-                    if (q < nq) sm.hl[(q >> 7) * HP16 + 128 * w + (q & 127)] = (uint32_t)v[j];
+                    uint32_t* dstw = q < nq ? &sm.hl[(q >> 7) * HP16 + 128 * w + (q & 127)] : &sm.dump[tid];
+                    *dstw = (uint32_t)v[j];
                 }
             }
             LV_WAIT_LDS();                                     // the wave reads back only what its own lanes wrote
@@ -209,6 +213,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             uint4 bfr[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) bfr[ks] = bp[ks * 4];
+            LV_SCHED_BARRIER();                                // all eight fragment reads in flight before the first MFMA (left alone the
+                                                               // compiler reads each one right before its eight MFMAs, behind lgkmcnt(0))
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -243,8 +249,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 const uint32_t mine = lv_f32_to_bf16_bits(h);
                 const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
                 if (own[q] && even)
-                    gran_store(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
-                               ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
+                    put(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
+                        ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
             }
         }
         store_block(tb);
@@ -253,12 +259,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 }
 
 // =====================================================================================================================
-// BPTT, reduce-scatter hand-off.  Exchange buffer: [parity][group][receiver (32)][sender (32)][RS16_SLOTS granules]; slot
-// s = 16 row + p of a (receiver, sender) pair carries the sender's partial dh of batch row `row` for the receiver's units
-// u = 16 b + 4 rq + 2 h2 + {0, 1} with p = rq + 4 h2 + 8 b (so that one store instruction writes 32 contiguous bytes per row).
-// A receiver wave sums 16 slots per "batch" (batch beta of wave w = slots [4 RP w + 16 beta, + 16) = one batch row): lane
-// (l & 15) = p, lane group l >> 4 = eight of the 32 senders, two shuffles add the four groups.  Owners: lanes 0..31 take batch
-// 2q, lanes 32..63 batch 2q + 1 (q = pair index), low / high half of the granule by (l >> 4) & 1.
+// BPTT, reduce-scatter hand-off.  Exchange buffer: [parity][group][receiver (32)][sender (32)][16 RP granules], DENSE for the
+// instantiation (a first layout with a fixed 2 KB stride per pair used 512 B of every 2 KB at 4 rows and 7 us per timestep: a
+// quarter of the L2 channels carried all the traffic).  A sender lane holds, for batch row c and column block nb, the partial dh of
+// units u = 16 b + 4 rq + 2 h2 + {0, 1} of receiver 8w + (nb >> 1) (b = nb & 1; rq = l >> 4; h2 = the register pair): slot
+// s = (2 b + h2) 4 RP + 4 c + rq, so that ONE store instruction (fixed b, h2) writes one contiguous run of 32 RP bytes -- whole
+// 128-byte lines, not four partial writes per line.  A receiver wave w sums the slots [4 RP w, 4 RP w + 4 RP) (b = w >> 1,
+// h2 = w & 1) in batches of 16 (batch beta: rows 4 beta + (p >> 2), rq = p & 3 for lane position p = l & 15): lane group l >> 4 =
+// eight of the 32 senders, two shuffles add the four groups.  Owners: lanes 0..31 take batch 2q, lanes 32..63 batch 2q + 1
+// (q = pair index), low / high half of the granule by (l >> 4) & 1.
 struct Bwd16P {
     const float* dh_ext; const float* dh_last;
     const uint4* wpk;
@@ -277,10 +286,12 @@ struct __attribute__((aligned(16))) Bwd16Lds {
     int abort;
 };
 
-template <int RP>
+template <int RP, bool LOCAL>
 __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
+    auto put = [](gran_t* q, gran_t v) { if (LOCAL) lv_xcd_store_u64(q, v); else gran_store(q, v); };
     constexpr int NP = Cfg16<RP>::NP, SBK = Cfg16<RP>::SBB;
-    constexpr int NB = RP / 4;                          // slot batches (= batch rows) a wave receives
+    constexpr int NB = RP / 4;                          // slot batches of 16 a wave receives
+    constexpr int SLOTS = 16 * RP;                      // granules of one (receiver, sender) pair
     LV_BLOCK_SHARED(Bwd16Lds<RP>, sm);
     int& s_abort = sm.abort;
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -302,25 +313,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             for (int nb = 0; nb < 16; ++nb) wreg[ks][nb] = wp[(ks * 16 + nb) * 64];
     }
 
-    // owner pairs of this lane: batch beta = 2q + (l >> 5) of wave w -> batch row NB w + beta; unit from the slot position
+    // owner pairs of this lane: batch beta = 2q + (l >> 5) -> batch row 4 beta + (p >> 2); unit from (w, p, granule half)
     const int pp = l & 15;
-    const int uw = 16 * (pp >> 3) + 4 * (pp & 3) + 2 * ((pp >> 2) & 1) + ((l >> 4) & 1);
+    const int uw = 16 * (w >> 1) + 4 * (pp & 3) + 2 * (w & 1) + ((l >> 4) & 1);
     const int punit = 32 * member + uw;
     const long BH = (long)B * PH;
     int prow[NP]; bool own[NP]; long pidx[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int beta = 2 * q + (l >> 5);
-        prow[q] = NB * w + beta;
+        prow[q] = 4 * beta + (pp >> 2);
         own[q] = beta < NB && prow[q] < rows;
         pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
     }
-    const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * RS16_SLOTS;
-    gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * RS16_SLOTS;
-    // receive: sender 8 (l >> 4) + j, slot 4 RP w + 16 beta + (l & 15)
-    const gran_t* const rx = px_g + ((long)member * PMEMBERS + 8 * (l >> 4)) * RS16_SLOTS + 4 * RP * w + pp;
-    // send: lane (c = l & 15: batch row, rq = l >> 4), column block nb -> receiver 8w + (nb >> 1), slot 16 c + rq + 4 h2 + 8 (nb & 1)
-    gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * RS16_SLOTS + 16 * (l & 15) + (l >> 4);
+    const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * SLOTS;
+    gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * SLOTS;
+    // receive: sender 8 (l >> 4) + j, slot 4 RP w + 16 beta + p
+    const gran_t* const rx = px_g + ((long)member * PMEMBERS + 8 * (l >> 4)) * SLOTS + 4 * RP * w + pp;
+    // send: lane (c = l & 15: batch row, rq = l >> 4), column block nb, register pair h2 -> receiver 8w + (nb >> 1),
+    // slot (2 (nb & 1) + h2) 4 RP + 4 c + rq
+    gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * SLOTS + 4 * (l & 15) + (l >> 4);
 
     float dc_rec[NP], gsum[NP][4];
     float dhb[NP][SBK], ctb[NP][SBK + 1];
@@ -385,22 +397,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     auto receive_round = [&](auto H0, const gran_t* src, uint32_t want, float (&dh_rec)[NP]) -> bool {
         constexpr int h0 = decltype(H0)::value;
         gran_t v[HB][8];
-        uint32_t pending = (1u << (HB * 8)) - 1u;
         int spins = 0;
-        while (true) {
+        bool ok;
+        do {                                          // all loads of the round in flight, then the tags
+            ok = true;
 #pragma unroll
             for (int bt = 0; bt < HB; ++bt)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const uint32_t bit = 1u << (bt * 8 + j);
-                    if (pending & bit) {
-                        v[bt][j] = gran_load(src + (long)j * RS16_SLOTS + 16 * (h0 + bt));
-                        if ((uint32_t)(v[bt][j] >> 56) == want) pending &= ~bit;
-                    }
+                    v[bt][j] = gran_load(src + (long)j * SLOTS + 16 * (h0 + bt));
+                    ok = ok && (uint32_t)(v[bt][j] >> 56) == want;
                 }
-            if (__all(pending == 0)) break;
-            if (++spins > SPIN_LIMIT) { s_abort = 1; return false; }
-        }
+            ok = __all(ok);
+            if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+        } while (!ok);
 #pragma unroll
         for (int bt = 0; bt < HB; ++bt) {
             float a = 0.f, b = 0.f;
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         uint4 bfr[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bfr[ks] = bp[ks * 4];
+        LV_SCHED_BARRIER();
         const uint32_t tag = rs_tag(k);
         gran_t* dst = tx + (long)(k & 1) * px_par;
 #pragma unroll
@@ -445,9 +456,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nb = 4 * n4 + j;
-                    gran_t* d = dst + (long)(nb >> 1) * PMEMBERS * RS16_SLOTS + 8 * (nb & 1);
-                    gran_store(d, rs_pack(acc[j][0], acc[j][1], tag));
-                    gran_store(d + 4, rs_pack(acc[j][2], acc[j][3], tag));
+                    gran_t* d = dst + (long)(nb >> 1) * PMEMBERS * SLOTS + (nb & 1) * 8 * RP;
+                    put(d, rs_pack(acc[j][0], acc[j][1], tag));
+                    put(d + 4 * RP, rs_pack(acc[j][2], acc[j][3], tag));
                 }
             }
         }
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
 }
 
 constexpr long XCH_FWD16_BYTES = 2L * PGROUPS * 16 * (PH / 2) * 8;
-constexpr long XCH_RS16_BYTES = 2L * PGROUPS * PMEMBERS * PMEMBERS * RS16_SLOTS * 8;
+constexpr long XCH_RS16_BYTES = 2L * PGROUPS * PMEMBERS * PMEMBERS * RS16_SLOTS_MAX * 8;
 
 int check_R(int B, int R) { return R >= 1 && R <= 16 && (long)R * PGROUPS >= B; }
 
@@ -548,9 +559,11 @@ extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward
 // [0, ceil(B / R)) carry the batch, the workgroups of the other groups return at once -- R = 8 at B = 32 runs the recurrence on
 // four XCDs and leaves the other four to concurrent kernels.  Arguments as lv_lstm_fwd_bf16_persist_ks without the in-kernel
 // dropout (the engine applies dropout_out while h is converted to its bf16 images); exchange buffer of
-// lv_lstm_persist16_xch_floats() floats.
+// lv_lstm_persist16_xch_floats() floats.  flags bit 0: hand-off stores without the agent-scope write-through (they stay in the
+// XCD's L2; correct while every group is XCD-local -- the round-robin placement of a 256-CU device -- and reported through
+// *status as a hand-off timeout otherwise).
 extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch,
-                                          int* status, int T, int B, int R, int H, void* stream) {
+                                          int* status, int T, int B, int R, int flags, int H, void* stream) {
     if (!gx || !wpk || !hs || !cs || !gates || !xch || !status) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
@@ -562,9 +575,15 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
     (void)hipMemsetAsync(hx, 0, (size_t)XCH_FWD16_BYTES, (hipStream_t)stream);
     Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, hx, status, T, B, R};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
-    if (R <= 4) LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<4>, grid, block, 0, stream, p);
-    else if (R <= 8) LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<8>, grid, block, 0, stream, p);
-    else LV_LAUNCH_RESIDENT(lstm_fwd_persist_k16_kernel<16>, grid, block, 0, stream, p);
+    if (flags & 1) {
+        if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, true>), grid, block, 0, stream, p);
+        else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<8, true>), grid, block, 0, stream, p);
+        else LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<16, true>), grid, block, 0, stream, p);
+    } else {
+        if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, false>), grid, block, 0, stream, p);
+        else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<8, false>), grid, block, 0, stream, p);
+        else LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<16, false>), grid, block, 0, stream, p);
+    }
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -573,7 +592,7 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
 // in-kernel dropout mask; image-only (dG16).
 extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates,
                                           const float* hs, const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status,
-                                          float* dh0, float* dc0, int tanh_init, int T, int B, int R, int H, void* stream) {
+                                          float* dh0, float* dc0, int tanh_init, int T, int B, int R, int flags, int H, void* stream) {
     if (!wpk || !gates || !cs || !dG16 || !dGsum || !xch || !status) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
@@ -582,14 +601,19 @@ extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_l
         return LV_ERR_ALIGN;
     if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
     gran_t* gxch = reinterpret_cast<gran_t*>(xch);
-    const int groups = lv_cdiv(B, R);
-    (void)hipMemsetAsync(gxch, 0, (size_t)XCH_RS16_BYTES, (hipStream_t)stream);
-    (void)groups;
+    const int RPi = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
+    (void)hipMemsetAsync(gxch, 0, (size_t)(XCH_RS16_BYTES / RS16_SLOTS_MAX * 16 * RPi), (hipStream_t)stream);      // the instantiation's dense extent
     Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
-    if (R <= 4) LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<4>, grid, block, 0, stream, p);
-    else if (R <= 8) LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<8>, grid, block, 0, stream, p);
-    else LV_LAUNCH_RESIDENT(lstm_bwd_persist_rs16_kernel<16>, grid, block, 0, stream, p);
+    if (flags & 1) {
+        if (R <= 4) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<4, true>), grid, block, 0, stream, p);
+        else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<8, true>), grid, block, 0, stream, p);
+        else LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<16, true>), grid, block, 0, stream, p);
+    } else {
+        if (R <= 4) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<4, false>), grid, block, 0, stream, p);
+        else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<8, false>), grid, block, 0, stream, p);
+        else LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<16, false>), grid, block, 0, stream, p);
+    }
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

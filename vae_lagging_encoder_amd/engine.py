@@ -296,10 +296,13 @@ PERSIST_BWD_FORM = "rs"
 # product of the persistent forward: "ks" = contraction split over the workgroup's waves (4x4x4 MFMA, barrier after the product),
 # "cols" = gate columns split over the waves (16x16x32 MFMA, barrier before the product)
 PERSIST_FWD_FORM = "ks"
-# Beyond 4 rows per XCD group (B > 32), or when an engine asks for a row count per group (eng.persist_rows: e.g. 8 rows on four
-# groups = a B = 32 recurrence on half the chip), the recurrences run on the kernels of lv_lstm_persist16.hip (<= 16 rows per
-# group: B <= 128, BASELINE.json configs[4]).  PERSIST16_ALWAYS routes every persistent launch there (A/B measurements).
-PERSIST16_ALWAYS = False
+# The persistent launches run on the kernels of lv_lstm_persist16.hip (<= 16 rows per XCD group: B <= 128, BASELINE.json
+# configs[4]; eng.persist_rows asks for a row count per group, e.g. 8 rows on four groups = a B = 32 recurrence on half the chip)
+# with their hand-off granules kept in the XCD's L2 (PERSIST16_FLAGS bit 0: no agent-scope write-through; measured 3.2 -> 2.2 us
+# per forward timestep, 3.1 -> 2.7 us per BPTT timestep at B = 32).  PERSIST16_ALWAYS = False sends B <= 32 to the 4-row kernels
+# of lv_lstm_persist.hip instead (A/B measurements, tests).
+PERSIST16_ALWAYS = True
+PERSIST16_FLAGS = 1
 _PERSIST_MAX_B = 128
 
 
@@ -394,7 +397,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         if use16:
             if mask is not None or hdrop is not None:
                 raise _lib.LvaeError("the 16-row persistent forward has no in-kernel dropout (the engine applies it on the images)")
-            lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, H, s)
+            lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, PERSIST16_FLAGS, H, s)
         else:
             fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
             fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
@@ -410,8 +413,9 @@ def check_persistent_status(eng):
     read -- call it where the host synchronises anyway)."""
     st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
     if st is not None and int(st.item()) != 0:
-        raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups "
-                             "were resident, e.g. another kernel held compute units for seconds" % int(st.item()))
+        raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups were resident "
+                             "(e.g. another kernel held compute units for seconds), or -- with engine.PERSIST16_FLAGS bit 0 set -- a "
+                             "group's workgroups were not placed on one XCD (set it to 0 to write the granules through)" % int(st.item()))
 
 
 def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, dc0, tanh_init, T, B, H, device):
@@ -429,7 +433,7 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
             if mask is not None:
                 raise _lib.LvaeError("the 16-row persistent BPTT has no in-kernel dropout mask (the engine applies it on dO)")
             lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
-                                           P(wi.status), dh0, dc0, tanh_init, T, B, rows, H, s)
+                                           P(wi.status), dh0, dc0, tanh_init, T, B, rows, PERSIST16_FLAGS, H, s)
         else:
             fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
             fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
