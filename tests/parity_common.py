@@ -257,6 +257,40 @@ def check_bf16_native_operands_equal_on_the_fly(device, V=333, ni=24, H=64, nz=8
         assert rel_err(g1[k], g0[k]) < 5e-3, (k, rel_err(g1[k], g0[k]))
 
 
+def check_token_sort_cache_follows_the_batch(device, V=97, ni=12, H=20, nz=4, B=6, T=7):
+    """The sorted token lists of the embedding backward are cached per batch TENSOR (engine._TokenSortCache).  The cache must hit
+    for a batch that comes back unchanged, and must not for a tensor whose contents were overwritten in place (version counter)
+    or for a different tensor that happens to reuse its address."""
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    P = O.random_params(V, ni, H, nz, seed=71, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    xa, xb = O.synthetic_batch(B, T, V, seed=72).to(device), O.synthetic_batch(B, T, V, seed=73).to(device)
+    eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=74)
+    noise = (eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device))
+
+    def grads_after(seq):
+        vae = build_vae(V, ni, H, nz, device, params=P)
+        tr = AggressiveTextTrainer(vae, lr=0.0, clip=5.0)            # lr 0: the weights stay put, every step sees the same model
+        out = []
+        for x in seq:
+            tr.step(x() if callable(x) else x, 0.5, noise=noise)
+            out.append({k: p.grad.detach().cpu().clone() for k, p in vae.named_parameters() if "embed" in k})
+        return tr, out
+    _, ref = grads_after([xa, xb])
+    x = xa.clone()
+
+    def overwrite():
+        x.copy_(xb)                 # same tensor object, new contents
+        return x
+    tr, got = grads_after([x, x, overwrite, lambda: xb.clone()])
+    hits = tr.enc._sorts.get(x, (T, B))
+    assert hits is not None                                     # the unchanged tensor is served from the cache ...
+    for k in ref[0]:
+        assert torch.equal(got[0][k], ref[0][k]) and torch.equal(got[1][k], ref[0][k]), k
+        assert torch.equal(got[2][k], ref[1][k]), k            # ... the overwritten one is sorted again
+        assert torch.equal(got[3][k], ref[1][k]), k            # and so is a new tensor
+
+
 def check_weight_images_follow_rebound_parameters(device, V=333, ni=24, H=64, nz=8, B=7, T=11):
     """The decoder caches its bf16 weight images across calls (it is frozen for the whole inner loop).  `p.data = X` (what
     `module._apply`, a `.half().float()` round trip or a hand-written load do) keeps the parameters' version counters, so the

@@ -60,3 +60,7 @@ def test_image_step_fused_emulated(emu_backend):
 
 def test_weight_images_follow_rebound_parameters_emulated(emu_backend):
     pc.check_weight_images_follow_rebound_parameters("cpu")
+
+
+def test_token_sort_cache_follows_the_batch_emulated(emu_backend):
+    pc.check_token_sort_cache_follows_the_batch("cpu")

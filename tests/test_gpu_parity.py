@@ -109,6 +109,11 @@ def test_bf16_native_operands_equal_on_the_fly(hip_device):
     pc.check_bf16_native_operands_equal_on_the_fly(hip_device, V=5000, ni=128, H=256, nz=32, B=32, T=30)
 
 
+def test_token_sort_cache_follows_the_batch(hip_device):
+    pc.check_token_sort_cache_follows_the_batch(hip_device)
+    pc.check_token_sort_cache_follows_the_batch(hip_device, V=2003, ni=64, H=64, nz=8, B=32, T=40)
+
+
 @pytest.mark.gpu
 def test_weight_images_follow_rebound_parameters(hip_device):
     pc.check_weight_images_follow_rebound_parameters(hip_device)

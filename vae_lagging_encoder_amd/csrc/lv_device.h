@@ -51,6 +51,20 @@ static inline uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {            // lan
     memcpy(&r, o, 8);
     return r;
 }
+// DPP row_shr with a bank mask: lanes of bank BANK (lanes 4 BANK .. 4 BANK + 3 of every 16-lane row) take src from the lane SHIFT
+// positions lower in their row, every other lane keeps old
+template <int SHIFT, int BANK> static inline float lv_row_shr_into(float old, float src) {
+    auto& w = lv_emu::my_wave();
+    const int l = lv_emu::lane();
+    uint32_t b;
+    memcpy(&b, &src, 4);
+    w.u[l] = b;
+    lv_emu::wave_sync();
+    float out = old;
+    if (((l & 15) >> 2) == BANK && (l & 15) >= SHIFT) { const uint32_t v = (uint32_t)w.u[l - SHIFT]; memcpy(&out, &v, 4); }
+    lv_emu::wave_sync();
+    return out;
+}
 // IEEE binary16 <-> f32 in software (round-to-nearest-even, as v_cvt_f16_f32 does): g++ 11 has no _Float16
 static inline uint16_t lv_f32_to_f16_bits(float x) {
     uint32_t u;
@@ -198,6 +212,13 @@ __device__ __forceinline__ float lv_f16_bits_to_f32(uint16_t b) {
 // the value held by lane (l ^ 1): DPP quad_perm [1,0,3,2], no LDS crossbar
 __device__ __forceinline__ float lv_lane_xor1(float v) {
     const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, r);
+}
+// DPP row_shr with a bank mask (v_mov_b32_dpp row_shr:SHIFT bank_mask:1 << BANK): lanes of bank BANK (lanes 4 BANK .. 4 BANK + 3 of
+// every 16-lane row) take src from the lane SHIFT positions lower in their row, every other lane keeps old.  Merges the valid
+// quarter-rows of four MFMA result registers into one fully populated register (one store instruction instead of four).
+template <int SHIFT, int BANK> __device__ __forceinline__ float lv_row_shr_into(float old, float src) {
+    const int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x110 + SHIFT, 0xF, 1 << BANK, false);
     return __builtin_bit_cast(float, r);
 }
 typedef _Float16 lv_h2 __attribute__((ext_vector_type(2)));

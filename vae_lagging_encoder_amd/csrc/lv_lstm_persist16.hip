@@ -333,6 +333,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     // send: lane (c = l & 15: batch row, rq = l >> 4), column block nb, register pair h2 -> receiver 8w + (nb >> 1),
     // slot (2 (nb & 1) + h2) 4 RP + 4 c + rq
     gran_t* const tx = px_g + ((long)(8 * w) * PMEMBERS + member) * SLOTS + 4 * (l & 15) + (l >> 4);
+    // RP = 4, merged stores: lane position (l & 15) = c + 4 j carries batch row c of column block 4 n4 + j -> receiver
+    // 8w + 2 n4 + (j >> 1), slot (2 (j & 1) + h2) 16 + 4 c + rq
+    gran_t* const tx4 = px_g + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS + 2 * (((l & 15) >> 2) & 1) * 4 * RP +
+                        4 * (l & 3) + (l >> 4);
 
     float dc_rec[NP], gsum[NP][4];
     float dhb[NP][SBK], ctb[NP][SBK + 1];
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         LV_SCHED_BARRIER();
         const uint32_t tag = rs_tag(k);
         gran_t* dst = tx + (long)(k & 1) * px_par;
+        gran_t* dst4 = tx4 + (long)(k & 1) * px_par;
 #pragma unroll
         for (int n4 = 0; n4 < 4; ++n4) {                 // four column blocks at a time: their granules go out while the next four multiply
             f32x4 acc[4];
@@ -452,7 +457,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = lv_mfma_16x16x32_bf16(wreg[ks][4 * n4 + j], bfr[ks], acc[j]);
-            if ((l & 15) < RP) {
+            if constexpr (RP == 4) {
+                // Only lanes 0..3 of every 16-lane row hold batch rows at RP = 4: the four column blocks' quarter-rows are merged
+                // into ONE fully populated register set (DPP row_shr into banks 1..3), so that this chunk goes out as 2 full-wave
+                // stores instead of 8 quarter-wave ones -- the sends are bound by store INSTRUCTIONS, not bytes.
+                float m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[r] = acc[0][r];
+                    m[r] = lv_row_shr_into<4, 1>(m[r], acc[1][r]);
+                    m[r] = lv_row_shr_into<8, 2>(m[r], acc[2][r]);
+                    m[r] = lv_row_shr_into<12, 3>(m[r], acc[3][r]);
+                }
+                gran_t* d = dst4 + (long)(2 * n4) * PMEMBERS * SLOTS;
+                put(d, rs_pack(m[0], m[1], tag));
+                put(d + 4 * RP, rs_pack(m[2], m[3], tag));
+            } else if ((l & 15) < RP) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nb = 4 * n4 + j;

@@ -282,6 +282,40 @@ class _AuxStream(object):
             self.done = None
 
 
+class _TokenSortCache(object):
+    """The stable (token, row) sort of the embedding backward depends on the token ids alone, and the aggressive loop keeps
+    meeting the same batch tensors (text.py:389 draws from the fixed list train_data_batch): the sorted (rows, tokens) pair is
+    kept per batch TENSOR -- weakly (it dies with the tensor) and only while the tensor's version counter is unchanged -- so that
+    in steady state the two single-workgroup sort launches of a step (75 us each, and nothing can run beside the persistent
+    recurrences they used to hide behind) disappear.  Not used under hipGraph capture (a captured step owns fixed buffers)."""
+    LIMIT = 8192
+
+    def __init__(self):
+        self.map = {}          # id(tensor) -> (weak reference to the tensor, {tag: (version, rows, tokens)})
+
+    def _entries(self, key_tensor, create):
+        i = id(key_tensor)
+        ent = self.map.get(i)
+        if ent is not None and ent[0]() is key_tensor:
+            return ent[1]
+        if not create:
+            return None
+        import weakref
+        if len(self.map) >= self.LIMIT:
+            self.map.clear()
+        # (tensors compare element-wise, so they cannot key a WeakKeyDictionary: identity + a weak reference that retires the id)
+        self.map[i] = (weakref.ref(key_tensor, lambda _r, i=i, m=self.map: m.pop(i, None)), {})
+        return self.map[i][1]
+
+    def get(self, key_tensor, tag):
+        ent = self._entries(key_tensor, False)
+        hit = ent.get(tag) if ent is not None else None
+        return hit[1:] if hit is not None and hit[0] == key_tensor._version else None
+
+    def put(self, key_tensor, tag, srows, stok):
+        self._entries(key_tensor, True)[tag] = (key_tensor._version, srows, stok)
+
+
 def reset_persistent_status(eng):
     """Clear the status word (after the caller has handled a reported timeout, e.g. by turning `persistent` off)."""
     st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
@@ -509,6 +543,27 @@ def _wgrad(lib, s, M, N, K, A, lda, Bm, ldb, C, ldc, prec, ws=None):
     _gemm(lib, s, 1, 0, M, N, K, A, lda, Bm, ldb, C, ldc, prec=prec, ws=ws)
 
 
+def _sorted_tokens(eng, lib, s, x, x_key, ids_stride, T_used, B, V, w):
+    """(rows, tokens) of the embedding backward's stable token sort for batch x: from the engine's per-batch cache when this
+    batch tensor has been seen (and not modified) before, else sorted now -- into cache-owned buffers in eager mode, into the
+    workspace under hipGraph capture or when the batch has no stable identity."""
+    key = x_key if x_key is not None else x
+    capturing = x.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    use_cache = eng.ws_evictable and not capturing           # hipGraph trainers pin the workspaces (ws_evictable False): fixed buffers
+    if use_cache:
+        hit = eng._sorts.get(key, (T_used, B))
+        if hit is not None:
+            return hit
+        srows, stok = eng.wsc.i32(T_used * B), eng.wsc.i32(T_used * B)
+    else:
+        srows, stok = w.srows, w.stok
+    eng._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), ids_stride, T_used, B, V, P(srows), P(stok), P(w.stmp), sa if sa is not None else s),
+                 keep=(x, srows, stok))
+    if use_cache:
+        eng._sorts.put(key, (T_used, B), srows, stok)
+    return srows, stok
+
+
 class LSTMEncoderEngine(object):
     """Forward/backward of LSTMEncoder.forward (reference modules/encoders/enc_lstm.py:47-64)."""
 
@@ -526,6 +581,7 @@ class LSTMEncoderEngine(object):
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
         self._wimg = None
         self._aux = _AuxStream()
+        self._sorts = _TokenSortCache()
 
     def _quiesce_side_streams(self):
         dev = self.flat.device if self.flat is not None else None
@@ -596,10 +652,12 @@ class LSTMEncoderEngine(object):
             return w
         return c.get((B, T), build)
 
-    def forward(self, x, head=None):
+    def forward(self, x, head=None, x_key=None):
         """x int64 [B][T] on device -> mulv [B][2nz] (mu | logvar).  Keeps activations for backward().
 
-        head = (eps [B][ns][nz], z, kl): also reparameterise and compute the KL in the head's launch (fused driver)."""
+        head = (eps [B][ns][nz], z, kl): also reparameterise and compute the KL in the head's launch (fused driver).
+        x_key: the batch tensor x was copied from (fused driver: x is its per-shape static buffer), whose identity keys the
+        cache of sorted token lists; default x itself."""
         assert x.dtype == torch.int64 and x.dim() == 2
         x = x.contiguous()
         B, T = x.shape
@@ -611,9 +669,8 @@ class LSTMEncoderEngine(object):
         img = self._b16(B, T)
         if img is None:
             lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
-        # the backward's token sort depends on x only: queue it now, beside the forward chain
-        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, T, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
-                      keep=(x,))
+        # the backward's token sort depends on x only: taken from the per-batch cache, or queued now (auxiliary stream)
+        self._sort = _sorted_tokens(self, lib, s, x, x_key, T, T, B, V, w)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         if img is not None:
             wi = self.refresh_weight_images(B, x.device)
@@ -681,7 +738,7 @@ class LSTMEncoderEngine(object):
             # dX -> embedding rows (the embedding table leads the flat buffer: its gradient is the first, and largest, bucket)
             gv["embed.weight"].zero_()
             self._aux.join(x.device)                   # token sort queued by forward()
-            lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(w.srows), P(w.stok), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
+            lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
             if after_embed is not None:
                 after_embed()
         # input-side grads: dX first, then the embedding scatter, then the two weight-gradient products
@@ -724,6 +781,7 @@ class LSTMDecoderEngine(object):
         self._side_ws = None
         self._pending = None
         self._aux = _AuxStream()
+        self._sorts = _TokenSortCache()
 
     def _quiesce_side_streams(self):
         dev = self.flat.device if self.flat is not None else None
@@ -872,9 +930,9 @@ class LSTMDecoderEngine(object):
             return None
         return self.wsc.get(("b16lstm", Bd, Td), lambda: _LstmImages(self.wsc, Td * Bd, ni, H, key=("b16lstm", Bd, Td)))
 
-    def forward(self, x, z, mask_in, mask_out, p_in, p_out, want_rec=True):
+    def forward(self, x, z, mask_in, mask_out, p_in, p_out, want_rec=True, x_key=None):
         """x int64 [B][T]; z [B][1][nz] (ns = 1 on the HIP path); masks uint8 keep-masks in the reference's
-        batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B]."""
+        batch-first layout ([B][T-1][ni], [B][T-1][H]) or None (eval mode).  Returns rec [B].  x_key: see LSTMEncoderEngine.forward."""
         assert x.dtype == torch.int64 and x.dim() == 2
         x = x.contiguous()
         B, T = x.shape
@@ -896,8 +954,7 @@ class LSTMDecoderEngine(object):
         gather = (P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, Td, B, V)
         if self._lstm_images(B, Td) is None:
             lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, P(mask_in), sc_in, P(w.X), Td, B, ni, V, s)
-        self._aux.run(x.device, lambda sa: lib.lv_token_sort(P(x), T, Td, B, V, P(w.srows), P(w.stok), P(w.stmp), sa if sa is not None else s),
-                      keep=(x,))
+        self._sort = _sorted_tokens(self, lib, s, x, x_key, T, Td, B, V, w)
         # c0 = z W_trans^T ; h0 = tanh(c0) (dec_lstm.py:99-101) ; Zp = z W_ih[:, ni:]^T + b_ih + b_hh, so that
         # Gx = X W_ih[:, :ni]^T + Zp[b]   (cat((word_embed, z_)) never materialised) -- one launch
         wih = v["lstm.weight_ih_l0"]
@@ -1011,7 +1068,7 @@ class LSTMDecoderEngine(object):
                        self.precision, ws=sws)
             gv["embed.weight"].zero_()
             self._aux.join(dev)                        # token sort queued by forward()
-            lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(w.srows), P(w.stok), Td, B, P(gv["embed.weight"]), ni,
+            lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B, P(gv["embed.weight"]), ni,
                                      V - 1, 0, s2)
         self._mark_pending(dev)
         if not fused_ends_ok(B, nz):

@@ -61,6 +61,7 @@ class AggressiveTextTrainer(object):
         # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum]
         self.scal = torch.zeros(8, dtype=torch.float32, device=d)
         self.scal[1] = lr
+        self._klw_host = 0.0                  # host copy of scal[0]
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
         # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
@@ -114,6 +115,8 @@ class AggressiveTextTrainer(object):
             st.dkl = torch.empty(B, dtype=torch.float32, device=d)
             st.dmulv = torch.empty(B, 2 * nz, dtype=torch.float32, device=d)
             st.graphs = {}
+            st.x_key = None
+            st.xin = st.x
             self.static[(B, T)] = st
             if not self.use_graph:
                 while len(self.static) > STATIC_SHAPES:
@@ -136,8 +139,8 @@ class AggressiveTextTrainer(object):
         m_in = st.m_in if use_in else None
         m_out = st.m_out if use_out else None
         # encoder: ... LSTM, then head + reparameterise + KL in one launch
-        mulv = self.enc.forward(st.x, head=(st.eps, st.z, st.kl))
-        self.dec.forward(st.x, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p, want_rec=False)
+        mulv = self.enc.forward(st.xin, head=(st.eps, st.z, st.kl), x_key=st.x_key)
+        self.dec.forward(st.xin, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p, want_rec=False, x_key=st.x_key)
         w = self.dec._ws(B, T - 1)
         # rec, loss, the running report sums and the seeds of mean_b(loss_b).backward(), one launch
         lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
@@ -209,8 +212,15 @@ class AggressiveTextTrainer(object):
         or 'both' (joint step after aggressive mode ends)."""
         B, T = x.shape
         st = self._static_for(B, T)
-        st.x.copy_(x)
-        self.scal[0] = float(kl_weight)
+        if self.use_graph or not (x.is_contiguous() and x.device == self.device):
+            st.x.copy_(x)                 # captured graphs read the per-shape static buffer
+            st.xin = st.x
+        else:
+            st.xin = x                    # eager: the kernels read the caller's batch in place (no copy launch)
+        st.x_key = x                      # the caller's batch tensor: its identity keys the engines' sorted-token cache
+        if self._klw_host != float(kl_weight):
+            self.scal[0] = float(kl_weight)       # one H2D fill per change of the weight, not per step (text.py anneals it per outer iteration)
+            self._klw_host = float(kl_weight)
         draw = noise is None
         if not draw:
             eps, m_in, m_out = noise
