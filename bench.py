@@ -198,6 +198,10 @@ def main():
     pool = [synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
     rs = np.random.RandomState(783435)
     kl_weight = 0.1                                         # text.py default kl_start
+    # batch construction: the per-batch sorted token lists of the embedding backward are built with the batches (a function of
+    # the token ids alone, computed once per batch as train_data_batch itself is; trainer.prepare_batches) -- the aggressive loop
+    # then meets each batch many times (text.py:389)
+    tr.prepare_batches(pool)
 
     def one_step():
         tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
@@ -305,7 +309,9 @@ def main():
                                                           ", fixed K=%d inner steps per loop (stress)" % args.steps if stress else ""),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                    "dp_exchange": ((args.dp_mode + ("/bf16-payload" if args.dp_payload == "bf16" else "")) if world > 1 else None),
-                   "hipgraph": bool(args.graph)},
+                   "hipgraph": bool(args.graph),
+                   "batch_preparation": ("sorted token lists of the embedding backward built once per pool batch, with the batches"
+                                         if not args.graph else "none (the captured step sorts inside the graph)")},
     }
     if not stress:
         out["mean_loss_per_seq"] = round(stats["loss_sum"] / (B * args.steps), 4)

@@ -401,12 +401,15 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, wan
             wi.fwd16 = wi.bwd16 = None
             wi.xch = c.f32(max(lib.lv_lstm_persist_xch_floats(), lib.lv_lstm_persist16_xch_floats()))
             wi.status = torch.zeros(1, dtype=torch.int32, device=device)
+        wi.packed4 = wi.packed16 = False
+        wi.packed = True
+    if want_persist and not want_persist16 and not wi.packed4:
+        # the 4-row forms of lv_lstm_persist.hip (PERSIST16_ALWAYS off, B <= 32)
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 3 if PERSIST_FWD_FORM == "ks" else 0, H, s)
         wi.fwd_form = PERSIST_FWD_FORM
         lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 2 if PERSIST_BWD_FORM == "rs" else 1, H, s)
         wi.bwd_form = PERSIST_BWD_FORM
-        wi.packed16 = False
-        wi.packed = True
+        wi.packed4 = True
     if want_persist and want_persist16 and not wi.packed16:
         if wi.fwd16 is None:
             n = lib.lv_lstm_persist_wpk_floats()

@@ -93,6 +93,29 @@ class AggressiveTextTrainer(object):
     def reset_stats(self):
         self.scal[5:8] = 0
 
+    def prepare_batches(self, batches):
+        """Batch construction for the fused driver: the (token, row) sort the embedding backward needs depends on the token ids
+        alone, so it is computed ONCE per batch tensor, when the batch list is built (as data/text_data.py builds the id tensors
+        themselves once), and kept with the tensor (engine._TokenSortCache) instead of being redone in every step that meets
+        the batch.  Optional: a batch that was not prepared is sorted on first use.  Eager mode only (a captured hipGraph owns
+        fixed buffers and sorts inside the graph)."""
+        if self.use_graph:
+            return
+        lib = self.lib
+        for x in batches:
+            if not (x.is_contiguous() and x.device == self.device and x.dtype == torch.int64 and x.dim() == 2):
+                continue
+            B, T = x.shape
+            s = _eng.stream_ptr(self.device)
+            for eng, Tu in ((self.enc, T), (self.dec, T - 1)):
+                if Tu <= 0 or eng._sorts.get(x, (Tu, B)) is not None:
+                    continue
+                V = eng.dims()[0]
+                srows, stok = eng.wsc.i32(Tu * B), eng.wsc.i32(Tu * B)
+                tmp = eng.wsc.i32(2 * Tu * B)
+                lib.lv_token_sort(P(x), T, Tu, B, V, P(srows), P(stok), P(tmp), s)
+                eng._sorts.put(x, (Tu, B), srows, stok)
+
     # -- per-(B,T) static state ----------------------------------------------------------------------
     def _static_for(self, B, T):
         st = self.static.get((B, T))

@@ -43,6 +43,8 @@ class TextTrainingLoop(object):
         if getattr(args, "momentum", 0) != 0:
             raise ValueError("the fused driver implements optim.SGD(momentum=0), the reference's default (text.py:325-326)")
         self.trainer = trainer if trainer is not None else AggressiveTextTrainer(vae, lr=1.0, clip=CLIP_GRAD, seed=seed)
+        if hasattr(self.trainer, "prepare_batches"):
+            self.trainer.prepare_batches(train_batches)          # per-batch index structures, built once with the batch list
         self.rng = np_rng if np_rng is not None else np.random
         n = n_train_sentences if n_train_sentences is not None else sum(int(b.shape[0]) for b in train_batches)
         self.n_train = n
