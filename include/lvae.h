@@ -346,6 +346,16 @@ long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
 int lv_conv32_wgrad_parts(int N, int k);
 int lv_conv1x1_wgrad_parts(long P);
 int lv_wgrad_reduce_batched(const long long* desc, int ndesc, void* stream);
+/* PixelCNN ancestral sampling one pixel at a time (dec_pixelcnn_v2.py:201-232; lv_pixelcnn_sample.hip): every layer of
+ * PixelCNNDecoderV2.forward at ONE position (i, j) for all B images, from the cached input maps of the masked convolutions at the
+ * earlier positions -- bit-equal to the eval-mode full forward (same fma chains in the same order as lv_gemm_f32 /
+ * lv_conv1x1_f32 / lv_conv32_f32 / lv_bn_eval_f32).  net: HOST array of lv_pixelcnn_net_words() 64-bit words (device pointers,
+ * int64 / double fields of the network table; the per-block tables of lv_pixelcnn_block_words() words each live in device
+ * memory); image_engine.PixelCNNSampler builds both.  lv_conv32_tap_split(N): the summation form lv_conv32_f32 uses at batch N. */
+int lv_pixelcnn_net_words(void);
+int lv_pixelcnn_block_words(void);
+int lv_pixelcnn_pixel_step_f32(const long long* net, int B, int i, int j, void* stream);
+int lv_conv32_tap_split(int N);
 /* Forward convolutions that also leave the stage-1 partials (per-workgroup per-channel sum and sum of squares of their
  * outputs, [blocks][2][Cout]) of the nn.BatchNorm2d that follows them in PixelCNNBlock (dec_pixelcnn_v2.py:41-52), consumed
  * by lv_bn_fwd_partials_f32: the normalisation's statistics pass over the activation is saved. */

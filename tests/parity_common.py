@@ -604,6 +604,49 @@ def check_pixelcnn_ancestral_sampling(device, B=2):
     vae.train()
 
 
+def check_pixelcnn_incremental_sampling(device, B=2, compare_full_path=True, seed=36):
+    """Pixel-at-a-time sampling (image_engine.PixelCNNSampler / lv_pixelcnn_sample.hip) against the full forward, BIT FOR BIT:
+    (i) every pixel's logit, computed at its own step from the cached maps, equals the logit a full eval-mode forward over the
+    finished image gives at that position (causality + identical fma chains); (ii) with `compare_full_path`, decode() draws the
+    same image and returns the same probabilities as the reference's literal procedure of one full decoder pass per pixel
+    (decode(incremental=False)), for the deterministic rule and for Bernoulli draws from the same generator state."""
+    from vae_lagging_encoder_amd import image_engine as IE
+    vae = build_image_vae(device, seed)
+    with torch.no_grad():                      # BatchNorm statistics and affine parameters away from their initial values
+        for m in vae.decoder.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                g = torch.Generator().manual_seed(m.num_features + int(m.weight.sum().item() * 0))
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g).to(device) * 0.1)
+                m.running_var.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(device))
+                m.weight.copy_((torch.rand(m.num_features, generator=g) + 0.5).to(device))
+                m.bias.copy_((torch.randn(m.num_features, generator=g) * 0.1).to(device))
+    vae.eval()
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(B, 32, generator=g).to(device)
+    dec = vae.decoder
+    with torch.no_grad():
+        smp = IE.PixelCNNSampler(dec).start(z)
+        for i in range(28):
+            for j in range(28):
+                p = torch.sigmoid(smp.step(i, j))
+                smp.set_pixel(i, j, (p >= 0.5).float())
+        img = smp.img.clone()
+        inc_logits = smp.logit.clone().cpu()
+        dec._hip.forward(img, z.contiguous().float())
+        full_logits = dec._hip.logit.t.view(B, 784).cpu()
+    nbad = int((inc_logits != full_logits).sum())
+    assert nbad == 0, (nbad, float((inc_logits - full_logits).abs().max()))
+    assert 0 < float(img.mean()) < 1                     # a non-trivial image
+    if compare_full_path:
+        for deterministic in (True, False):
+            outs = []
+            for incremental in (True, False):
+                gen = torch.Generator(device=device).manual_seed(9) if torch.device(device).type == "cuda" else torch.Generator().manual_seed(9)
+                outs.append(dec.decode(z, deterministic=deterministic, generator=gen, incremental=incremental))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), deterministic
+    vae.train()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # a K-step trajectory of the throughput configuration at H = 1024 (persistent recurrences), step by step against the oracle
 def check_bf16_trajectory_h1024(device, K=4, B=32, T=60, V=2003, ni=64, nz=32):

@@ -64,3 +64,9 @@ def test_weight_images_follow_rebound_parameters_emulated(emu_backend):
 
 def test_token_sort_cache_follows_the_batch_emulated(emu_backend):
     pc.check_token_sort_cache_follows_the_batch("cpu")
+
+
+def test_pixelcnn_incremental_sampling_emulated(emu_backend):
+    """Pixel-at-a-time sampling == full forward, bit for bit, on the emulator build (one image; the 784-full-pass comparison is the
+    GPU test)."""
+    pc.check_pixelcnn_incremental_sampling("cpu", B=1, compare_full_path=False)

@@ -558,6 +558,27 @@ def test_generation_against_reference_fixture(hip_device):
     pc.check_generation_against_fixture(hip_device)
 
 
+def test_pixelcnn_incremental_sampling(hip_device):
+    """one launch per pixel instead of one 82-convolution forward per pixel, bit-equal (logits of every pixel,
+    sampled images, final probabilities), at a batch size where the MaskA GEMM is cut along K (B = 2) and one where it is not and
+    the masked convolutions use their tap-split form (B = 50); and fast: 784 pixels of 50 images in well under half a second."""
+    import time
+    pc.check_pixelcnn_incremental_sampling(hip_device, B=2)
+    pc.check_pixelcnn_incremental_sampling(hip_device, B=50, compare_full_path=False)
+    pc.check_pixelcnn_incremental_sampling(hip_device, B=36, compare_full_path=False)          # tap-split off (conv32_ks(36) == 1)
+    vae = pc.build_image_vae(hip_device, 35)
+    vae.eval()
+    z = torch.randn(50, 32, device=hip_device)
+    vae.decoder.decode(z, deterministic=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vae.decoder.decode(z, deterministic=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("incremental PixelCNN sampling, B = 50: %.3f s" % dt)
+    assert dt < 0.5, dt
+
+
 def test_pixelcnn_ancestral_sampling(hip_device):
     """SURVEY.md 8f row 4 (image half): PixelCNNDecoderV2.decode, 784 decoder passes."""
     pc.check_pixelcnn_ancestral_sampling(hip_device)

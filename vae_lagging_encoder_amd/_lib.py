@@ -119,6 +119,10 @@ SIGNATURES = {
     "lv_conv1x1_wgrad_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp],
     "lv_mul_inplace_f32": [_vp, _vp, _l, _vp],
     "lv_bn_workspace_floats": [_i],
+    "lv_pixelcnn_net_words": [],
+    "lv_pixelcnn_block_words": [],
+    "lv_pixelcnn_pixel_step_f32": [_vp, _i, _i, _i, _vp],
+    "lv_conv32_tap_split": [_i],
     "lv_bn_eval_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
     "lv_bn_fwd_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _l, _i, _vp],
     "lv_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
@@ -160,7 +164,8 @@ class Lib(object):
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
-                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats"}
+                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats",
+                           "lv_pixelcnn_net_words", "lv_pixelcnn_block_words", "lv_conv32_tap_split"}
 
     def __getattr__(self, name):
         if name.startswith("lv_"):

@@ -360,6 +360,8 @@ extern "C" int lv_conv32_f32(const float* in, const float* wp, float* out, int N
 
 // forward convolution that also leaves the following BatchNorm's stage-1 partials: bn_partial [lv_conv32_blocks(N)][2][32]
 extern "C" int lv_conv32_blocks(int N) { return N * (IH / (TR / conv32_ks(N))); }
+// the tap-split form (1 or 2) lv_conv32_f32 uses at batch size N: lv_pixelcnn_pixel_step_f32 follows the same summation order
+extern "C" int lv_conv32_tap_split(int N) { return conv32_ks(N); }
 extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, void* stream) {
     if (!in || !wp || !out || !bn_partial) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;

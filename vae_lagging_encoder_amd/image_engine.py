@@ -204,22 +204,25 @@ class Tape(object):
         wp, wpt = ent["wp"], ent["wpt"]
         y = self.f32(x.P, 32)
         out = Act(y, x.N, 28, 28, 32)
-        if bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS:
-            lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(self.bn_ws(32)), x.N, k, nt, s)
-            out.bn_nblk = lib.lv_conv32_blocks(x.N)
-        else:
-            lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
+        with _eng._prof("conv_direct", 2.0 * x.P * 1024 * nt):            # flops over the taps the mask keeps
+            if bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS:
+                lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(self.bn_ws(32)), x.N, k, nt, s)
+                out.bn_nblk = lib.lv_conv32_blocks(x.N)
+            else:
+                lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
 
         def bwd():
             dy = self.grad_of(out)
             if dy is None:
                 return
             ws = self.f32(lib.lv_conv32_wgrad_ws_floats(x.N, k))
-            lib.lv_conv32_wgrad_f32(P(x.t), P(dy), None, P(ws), x.N, k, 0, s)          # stage 1: partials; reduced in flush_wgrads()
+            with _eng._prof("conv_direct", 2.0 * x.P * 1024 * k * k):     # the weight gradient spans all k*k taps (G5)
+                lib.lv_conv32_wgrad_f32(P(x.t), P(dy), None, P(ws), x.N, k, 0, s)      # stage 1: partials; reduced in flush_wgrads()
             self.wgrad_pending.append((ws, gview, k * k * 1024, lib.lv_conv32_wgrad_parts(x.N, k), k * k))
             if x.needs_grad:
                 dx = self.f32(x.P, 32)
-                lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
+                with _eng._prof("conv_direct", 2.0 * x.P * 1024 * nt):
+                    lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
         return out
@@ -230,24 +233,27 @@ class Tape(object):
         Cout, Cin = weight.shape[0], weight.shape[1]
         y = self.f32(x.P, Cout)
         out = Act(y, x.N, x.H, x.W, Cout)
-        if bn_stats and lib.lv_conv1x1_blocks(x.P) <= _BN_MAX_BLOCKS:
-            lib.lv_conv1x1_bnstat_f32(P(x.t), P(weight), P(y), P(self.bn_ws(Cout)), x.P, Cin, Cout, s)
-            out.bn_nblk = int(lib.lv_conv1x1_blocks(x.P))
-        else:
-            lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
+        with _eng._prof("conv_pointwise", 4.0 * x.P * (Cin + Cout)):       # HBM-bound: bytes of the activation in and out
+            if bn_stats and lib.lv_conv1x1_blocks(x.P) <= _BN_MAX_BLOCKS:
+                lib.lv_conv1x1_bnstat_f32(P(x.t), P(weight), P(y), P(self.bn_ws(Cout)), x.P, Cin, Cout, s)
+                out.bn_nblk = int(lib.lv_conv1x1_blocks(x.P))
+            else:
+                lib.lv_conv1x1_f32(P(x.t), P(weight), P(y), x.P, Cin, Cout, 0, 0, s)
 
         def bwd():
             dy = self.grad_of(out)
             if dy is None:
                 return
             ws = self.f32(lib.lv_conv1x1_wgrad_ws_floats(Cin, Cout))
-            lib.lv_conv1x1_wgrad_f32(P(x.t), P(dy), None, P(ws), x.P, Cin, Cout, 0, s)  # stage 1: partials; reduced in flush_wgrads()
+            with _eng._prof("conv_pointwise", 4.0 * x.P * (Cin + Cout)):
+                lib.lv_conv1x1_wgrad_f32(P(x.t), P(dy), None, P(ws), x.P, Cin, Cout, 0, s)  # stage 1: partials; reduced in flush_wgrads()
             self.wgrad_pending.append((ws, gview, Cin * Cout, lib.lv_conv1x1_wgrad_parts(x.P), 0))
             if x.needs_grad:
                 # (accumulating into an existing gradient in the kernel's epilogue was measured slower than a separate vectorised add:
                 # the read-modify-write of 4-byte pieces costs the pointwise kernel 4 us, the add kernel 3)
                 dx = self.f32(x.P, Cin)
-                lib.lv_conv1x1_f32(P(dy), P(weight), P(dx), x.P, Cout, Cin, 1, 0, s)
+                with _eng._prof("conv_pointwise", 4.0 * x.P * (Cin + Cout)):
+                    lib.lv_conv1x1_f32(P(dy), P(weight), P(dx), x.P, Cout, Cin, 1, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
         return out
@@ -259,6 +265,9 @@ class Tape(object):
         y = self.f32(Pn, C)
         mean = self.f32(C)
         invstd = self.f32(C)
+        nres = 1 if res is not None else 0
+        self._bn_prof = _eng._prof("batchnorm", 4.0 * Pn * C * (2 + nres + (0 if (self.train and x.bn_nblk) else 1 if self.train else 0)))
+        self._bn_prof.__enter__()
         if self.train and x.bn_nblk:
             # the producing convolution left the per-channel partial sums in the workspace
             lib.lv_bn_fwd_partials_f32(P(x.t), P(bn.weight), P(bn.bias), P(res.t) if res is not None else None, int(act), P(y),
@@ -274,6 +283,7 @@ class Tape(object):
             # eval mode (evaluation passes, sampling: SURVEY.md 8f): the running statistics, one streaming launch
             lib.lv_bn_eval_f32(P(x.t), P(bn.weight), P(bn.bias), P(bn.running_mean), P(bn.running_var), bn.eps,
                                P(res.t) if res is not None else None, int(act), P(y), P(mean), P(invstd), Pn, C, s)
+        self._bn_prof.__exit__()
         out = Act(y, x.N, x.H, x.W, C)
 
         def bwd():
@@ -283,8 +293,10 @@ class Tape(object):
             dys = [P(t_) for t_ in terms] + [None] * (4 - len(terms))
             dv = self.f32(Pn, C)
             dx = self.f32(Pn, C)
-            lib.lv_bn_bwd4_f32(P(x.t), dys[0], dys[1], dys[2], dys[3], P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx),
-                               P(g_gamma), P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
+            # reduce pass: x, y, the summands in, dv out; apply pass: x, dv in, dx out
+            with _eng._prof("batchnorm", 4.0 * Pn * C * (6 + len(terms))):
+                lib.lv_bn_bwd4_f32(P(x.t), dys[0], dys[1], dys[2], dys[3], P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx),
+                                   P(g_gamma), P(g_beta), 0, P(self.bn_ws(C)), Pn, C, s)
             if res is not None and res.needs_grad:
                 self.add_grad(res, dv)
             if x.needs_grad:
@@ -390,6 +402,7 @@ def decoder_forward(tp, flat, dec, x_img, z2d, zact):
     zt = tp.linear(z2d, zact, lin.weight, lin.bias, _gv(flat, lin.weight), _gv(flat, lin.bias))      # [B, fm*784]
     in5_t = tp.f32(B * npix, 1 + fm)
     lib.lv_dec_input_fwd_f32(P(xflat), P(zt.t), P(in5_t), B, npix, fm, s)
+    tp.in5 = in5_t                      # (PixelCNNSampler reads the latent maps from here)
     in5 = Act(in5_t, B, 28, 28, 1 + fm)
 
     def bwd_in():
@@ -507,3 +520,109 @@ class ImageDecoderEngine(object):
         tp.add_grad(self.logit, dlogit)
         tp.backward()
         return tp.grad_of(self.zact)
+
+
+def _gemm_f32_split(M, N, K, ws_floats):
+    """(splits, k tiles per split) lv_gemm_f32 uses for this product (the host logic of lv_gemm_f32.hip restated: the
+    pixel-at-a-time sampler sums its fma chain in the same pieces)."""
+    BK = 16
+    cdiv = lambda a, b: (a + b - 1) // b
+    nk = cdiv(K, BK)
+    t128 = cdiv(M, 128) * cdiv(N, 128)
+    splits = 1
+    big = t128 >= 1024
+    if not big and ws_floats and t128 >= 48 and nk >= 128:
+        s_ = min(cdiv(1024, t128), nk // 32, ws_floats // (M * N))
+        if s_ >= 2:
+            big, splits = True, s_
+    BT = 128 if big else 64
+    tiles = cdiv(M, BT) * cdiv(N, BT)
+    if not big and ws_floats and tiles < 256 and nk >= 16:
+        s_ = min(cdiv(512, tiles), nk // 8, 64, ws_floats // (M * N))
+        if s_ > 1:
+            splits = s_
+    kt = cdiv(max(nk, 1), splits)
+    return cdiv(max(nk, 1), kt), kt
+
+
+class PixelCNNSampler(object):
+    """Pixel-at-a-time evaluation of PixelCNNDecoderV2.forward for ancestral sampling (reference
+    modules/decoders/dec_pixelcnn_v2.py:201-232; lv_pixelcnn_sample.hip): after `start(z2d)` the image is all zeros and
+    `step(i, j)` returns the logits of pixel (i, j) for every image -- the same bits the eval-mode full forward gives at that
+    position -- from one launch that extends the cached input maps of the 23 masked convolutions by that position;
+    `set_pixel(i, j, values)` then records the drawn pixel.  ~0.1 ms per pixel instead of one 82-convolution forward."""
+
+    def __init__(self, dec_module):
+        self.m = dec_module
+        self.eng = dec_module._hip
+
+    def _bn_words(self, bn):
+        return [bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps)]
+
+    def start(self, z2d):
+        import ctypes
+        import struct
+        dec, eng = self.m, self.eng
+        dev = z2d.device
+        B = z2d.shape[0]
+        self.B, self.device = B, dev
+        lib = self.lib = _eng.backend_for(dev)
+        if dec.training:
+            raise _lib.LvaeError("PixelCNNSampler evaluates the decoder in eval mode (running BatchNorm statistics)")
+        # one full forward on the empty image: builds the latent maps (in5), brings the packed / masked weight images of the
+        # direct convolutions up to date, and re-applies MaskedConv2d's weight.data.mul_(mask) exactly as every forward does
+        self.img = torch.zeros(B, 1, 28, 28, dtype=torch.float32, device=dev)
+        eng.forward(self.img, z2d.contiguous().float())
+        self.in5 = eng.tape.in5
+        pcnn = dec.main[0]
+        keep = self._keep = []
+
+        def t_(w):            # [Cout][Cin](x1x1) -> ci-major copy
+            t = w.detach().reshape(w.shape[0], w.shape[1]).t().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        nblk = len(pcnn.main) - 1 + len(pcnn.direct_connects)
+        self.a1 = torch.zeros(nblk, B, 28 * 28, 32, dtype=torch.float32, device=dev)
+        bw = lib.lv_pixelcnn_block_words()
+
+        def block_words(blk, idx):
+            m = blk.main
+            ent = eng._wcache[id(m[3].weight)]
+            k = m[3].kernel_size[0]
+            words = [t_(m[0].weight)] + self._bn_words(m[1]) + [ent["wp"].data_ptr(), k, int(ent["nt"])] + self._bn_words(m[4]) + \
+                [t_(m[6].weight)] + self._bn_words(m[7]) + [self.a1[idx].data_ptr()]
+            assert len(words) == bw
+            return words
+
+        def pack(words):
+            return b"".join(struct.pack("<d", w) if isinstance(w, float) else struct.pack("<q", int(w)) for w in words)
+        mains = [block_words(b_, i) for i, b_ in enumerate(pcnn.main[1:])]
+        dcs = [block_words(b_, len(mains) + i) for i, b_ in enumerate(pcnn.direct_connects)]
+        raw = b"".join(pack(w) for w in mains + dcs)
+        self.tables = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        mA = pcnn.main[0].main
+        wA = (mA[0].weight.detach() * mA[0].mask)                                      # [64][5][7][7], the mask applied as the forward does
+        self.wAt = wA.reshape(64, 5, 49).permute(2, 1, 0).reshape(245, 64).contiguous()
+        splits, kt = _gemm_f32_split(B * 784, 64, 245, _eng._gemm_ws(lib, stream_ptr(dev)).numel())
+        c1, bnH, c2 = dec.main[1], dec.main[2], dec.main[4]
+        self.logit = torch.zeros(B, 28 * 28, dtype=torch.float32, device=dev)
+        self.c2 = c2.weight.detach().reshape(64).contiguous()
+        words = [self.in5.data_ptr(), self.wAt.data_ptr()] + self._bn_words(mA[1]) + [kt * 16 if splits > 1 else 0,
+                 self.tables.data_ptr(), self.tables.data_ptr() + 8 * bw * len(mains), t_(c1.weight)] + self._bn_words(bnH) + \
+            [self.c2.data_ptr(), self.logit.data_ptr(), int(lib.lv_conv32_tap_split(B)), len(mains), len(dcs)]
+        assert len(words) == lib.lv_pixelcnn_net_words()
+        assert splits <= 2
+        self.net = (ctypes.c_char * (8 * len(words))).from_buffer_copy(pack(words))
+        return self
+
+    def step(self, i, j):
+        """-> logits [B] of pixel (i, j) (a view into the sampler's logit map)."""
+        import ctypes
+        self.lib.lv_pixelcnn_pixel_step_f32(ctypes.cast(self.net, ctypes.c_void_p), self.B, i, j, stream_ptr(self.device))
+        return self.logit[:, i * 28 + j]
+
+    def set_pixel(self, i, j, values):
+        """values [B] (or [B, 1]) in {0, 1}: the drawn pixel."""
+        v = values.reshape(self.B).float()
+        self.img[:, 0, i, j] = v
+        self.in5.view(self.B, 28 * 28, -1)[:, i * 28 + j, 0] = v

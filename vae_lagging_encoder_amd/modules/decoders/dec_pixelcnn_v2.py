@@ -206,18 +206,34 @@ class PixelCNNDecoderV2(DecoderBase):
             B = x_img.shape[0]
             return torch.sigmoid(self._hip.logit.t.view(B, 1, _SIDE, _SIDE))
 
-    def decode(self, z, deterministic=False, generator=None):
+    def decode(self, z, deterministic=False, generator=None, incremental=True):
         """Ancestral sampling (reference dec_pixelcnn_v2.py:201-232): the image is filled pixel by pixel in
-        raster order, each from one full decoder pass over the image so far (784 passes) -- thresholded at 0.5 when
-        `deterministic`, else a Bernoulli draw; a last pass gives the probabilities.  -> (img (batch, 1, 28, 28), probs)."""
+        raster order -- thresholded at 0.5 when `deterministic`, else a Bernoulli draw -- and a last full pass gives the
+        probabilities.  -> (img (batch, 1, 28, 28), probs).
+
+        incremental (default): each pixel's probability comes from ONE launch that evaluates every layer at that position
+        only (image_engine.PixelCNNSampler, lv_pixelcnn_sample.hip), bit-equal to the full forward; incremental=False runs
+        the reference's literal procedure, one full decoder pass per pixel (784 passes)."""
         batch_size = z.size(0)
         z2d = z.reshape(batch_size, -1)
-        img = torch.zeros(batch_size, self.nc, _SIDE, _SIDE, device=z.device)
-        for i in range(_SIDE):
-            for j in range(_SIDE):
-                p = self.forward_probs(img, z2d)[:, :, i, j]
-                if deterministic:
-                    img[:, :, i, j] = (p >= 0.5).float()
-                else:
-                    img[:, :, i, j] = (torch.rand(p.shape, device=p.device, generator=generator) < p).float()
+        if not incremental or self.training:
+            img = torch.zeros(batch_size, self.nc, _SIDE, _SIDE, device=z.device)
+            for i in range(_SIDE):
+                for j in range(_SIDE):
+                    p = self.forward_probs(img, z2d)[:, :, i, j]
+                    if deterministic:
+                        img[:, :, i, j] = (p >= 0.5).float()
+                    else:
+                        img[:, :, i, j] = (torch.rand(p.shape, device=p.device, generator=generator) < p).float()
+            return img, self.forward_probs(img, z2d)
+        with torch.no_grad():
+            smp = _ie.PixelCNNSampler(self).start(z2d)
+            for i in range(_SIDE):
+                for j in range(_SIDE):
+                    p = torch.sigmoid(smp.step(i, j)).view(batch_size, 1)
+                    if deterministic:
+                        smp.set_pixel(i, j, (p >= 0.5).float())
+                    else:
+                        smp.set_pixel(i, j, (torch.rand(p.shape, device=p.device, generator=generator) < p).float())
+            img = smp.img.clone()
         return img, self.forward_probs(img, z2d)
