@@ -13,9 +13,16 @@ python bench.py --graph 1 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_hip
 python bench.py --workload yelp --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yelp.json 2>/dev/null
 python bench.py --workload stress --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_stress.json 2>/dev/null
 python bench.py --dtype f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yahoo_f32.json 2>/dev/null
+# Omniglot (BASELINE.json configs[3]): the dtype is named explicitly (the decoder's convolutions are exact f32 in both modes;
+# --dtype only moves the encoder's im2col GEMMs) so that file names and the "dtype" field cannot disagree
+python bench.py --workload omniglot --dtype f32 --steps 30 --warmup 5 > $O/${TAG}_bench_omniglot_f32.json 2>/dev/null
+python bench.py --workload omniglot --dtype f32 --graph 1 --steps 30 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_omniglot_f32_hipgraph.json 2>/dev/null
+python bench.py --workload omniglot --dtype bf16 --graph 1 --steps 30 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_omniglot_bf16_hipgraph.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py $O/prof_${TAG}/${TAG}_results.db > $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt
+rocprofv3 --kernel-trace -d $O/prof_omni_${TAG} -o ${TAG}o -- python $R/bench.py --workload omniglot --dtype f32 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python $R/profiles/summarize_rocpd.py $O/prof_omni_${TAG}/${TAG}o_results.db > $O/${TAG}_omniglot_kernel_stats.txt
 for W in yahoo yelp; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${C}_${W}_${TAG} -o p -- \
@@ -32,6 +39,8 @@ python $R/profiles/summarize_sq.py $O/pmc_sq_${TAG}/p_counter_collection.csv > $
 cd $R
 cut -c1-400 $O/${TAG}_bench_default.json
 cut -c1-200 $O/${TAG}_bench_hipgraph.json $O/${TAG}_bench_yelp.json $O/${TAG}_bench_stress.json $O/${TAG}_bench_yahoo_f32.json
+cut -c1-200 $O/${TAG}_bench_omniglot_f32.json $O/${TAG}_bench_omniglot_f32_hipgraph.json $O/${TAG}_bench_omniglot_bf16_hipgraph.json
+head -8 $O/${TAG}_omniglot_kernel_stats.txt | cut -c1-170
 head -14 $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt | cut -c1-170
 head -8 $O/${TAG}_pmc_hbm_traffic_yahoo_bf16.txt | cut -c1-170
 cat $O/${TAG}_pmc_groups_yahoo.json | tr -d '\n' | cut -c1-600; echo
