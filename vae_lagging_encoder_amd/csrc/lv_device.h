@@ -234,6 +234,19 @@ __device__ __forceinline__ uint32_t lv_pack_f16x2(float lo, float hi) {
 #include <stdint.h>
 #include <string.h>
 
+// Measurement tooling (profiles/microbench/build_trace.sh builds a SEPARATE library with -DLV_TRACE; the product build has no
+// trace code): LV_TRACE_MARK(step, i) stores the shader clock of one chosen lane into a caller-provided buffer, for phase
+// breakdowns inside the persistent kernels.
+#if defined(LV_TRACE) && !defined(LV_EMU)
+extern __device__ unsigned long long* lv_trace_buf;
+#define LV_TRACE_MARK(step, i)                                                                                              \
+    do {                                                                                                                    \
+        if (lv_trace_buf && blockIdx.x == 8 && threadIdx.x == 0) lv_trace_buf[(long)(step) * 8 + (i)] = clock64();         \
+    } while (0)
+#else
+#define LV_TRACE_MARK(step, i) do { } while (0)
+#endif
+
 #define LV_WAVE 64
 
 // (q0 + ro) mod m for 0 <= q0 < m, 0 <= ro < 32, without a division per element: the GEMM epilogue addends are indexed by

@@ -24,6 +24,11 @@
 #include "lv_device.h"
 #include "lv_persist_common.h"
 
+#if defined(LV_TRACE) && !defined(LV_EMU)
+__device__ unsigned long long* lv_trace_buf = nullptr;
+extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lv_trace_buf), &p, sizeof(p)); }
+#endif
+
 namespace {
 
 using namespace lvp;
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
         for (int s2 = 0; s2 < SBK; ++s2) {
             const int t = tb + s2;
             if (t >= T) break;
+            LV_TRACE_MARK(t, 0);
             // ---- gather K-quarter w of state t (tag t + 1) into this wave's part of the LDS image ---------------------------
             const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
             const uint32_t want = (uint32_t)(t + 1);
@@ -203,7 +209,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     *dstw = (uint32_t)v[j];
                 }
             }
+            LV_TRACE_MARK(t, 1);
             LV_WAIT_LDS();                                     // the wave reads back only what its own lanes wrote
+            LV_TRACE_MARK(t, 2);
 
             // ---- this wave's K quarter of the product: A = weights (16 gate columns), B = h (16 batch rows) ------------------
             f32x4 acc[8];
@@ -225,7 +233,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb) rd[4 * nb + kq] = acc[nb];
             }
+            LV_TRACE_MARK(t, 3);
             __syncthreads();                                   // the four quarter products (double-buffered by step parity)
+            LV_TRACE_MARK(t, 4);
             if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
 
             // ---- cell update and hand-off of h_t ----------------------------------------------------------------------------------
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     put(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
                         ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
             }
+            LV_TRACE_MARK(t, 5);
         }
         store_block(tb);
         load_block(tb + SBK);
@@ -493,7 +504,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             float dh_rec[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) dh_rec[q] = 0.f;
+            LV_TRACE_MARK(t, 0);
             if (t < T - 1) receive(T - 1 - t, dh_rec);        // on a timeout s_abort is set: everybody leaves after the barrier below
+            LV_TRACE_MARK(t, 1);
             const int par = (T - t) & 1;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -518,9 +531,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                 outb[q][s2][0] = lo; outb[q][s2][1] = hi;
                 if (own[q]) { sm.dgl[par][prow[q] * DP16 + 2 * uw] = lo; sm.dgl[par][prow[q] * DP16 + 2 * uw + 1] = hi; }
             }
+            LV_TRACE_MARK(t, 2);
             __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity)
+            LV_TRACE_MARK(t, 3);
             if (s_abort) { aborted = true; continue; }
             if (t > 0 || closing) send(par, T - t);
+            LV_TRACE_MARK(t, 4);
         }
         if (aborted) { if (tid == 0) atomicExch(p.status, 200 + (t_hi < 0 ? 0 : t_hi)); return; }
         store_block(t_hi);
