@@ -153,12 +153,19 @@ int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const
  * dropout (the caller applies dropout_out on the bf16 images of h and once on dO).  flags bit 0: the hand-off granules are stored
  * without the agent-scope write-through, i.e. they stay in the XCD's L2 instead of travelling to memory (valid while every group is
  * XCD-local, which the round-robin workgroup placement of a 256-CU device gives; a violated assumption shows up as a hand-off
- * timeout in *status).  LV_ERR_UNSUPPORTED unless H == 1024 and the device has >= 256 CUs. */
+ * timeout in *status).  LV_ERR_UNSUPPORTED unless H == 1024 and the device has >= 256 CUs.
+ * saved: what the forward keeps for the BPTT (the gates i, f, g, o and the cell states c_0 .. c_{T-1}), in the kernels' own
+ * WORKGROUP-MAJOR order -- saved[group][member][t]{ gates [R][32 units][4], c [R][32 units] }: lv_lstm_persist16_saved_floats(T, R)
+ * floats, opaque to the caller, and the BPTT call must be given the T, B, R of the forward that wrote it.  (In [t][b][...] order
+ * every timestep of every array is a different page at B = 128, and the address translations of a block of loads serialise in
+ * front of the next hand-off poll: 1.5 us of a 7.9 us BPTT timestep.)  hs: [T + 1][B][H] as everywhere; cs: [T + 1][B][H], of which
+ * these kernels read slot 0 (the initial state) and write slot T (the final one) only. */
 long lv_lstm_persist16_xch_floats(void);
+long lv_lstm_persist16_saved_floats(int T, int R);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
-int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch, int* status,
+int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* saved, float* xch, int* status,
                                int T, int B, int R, int flags, int H, void* stream);
-int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates, const float* hs,
+int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved, const float* hs,
                                const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                                int tanh_init, int T, int B, int R, int flags, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */

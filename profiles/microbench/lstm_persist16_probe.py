@@ -6,7 +6,12 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vae_lagging_encoder_amd import _lib
 from vae_lagging_encoder_amd.engine import P, stream_ptr
-dev = torch.device("cuda:0"); lib = _lib.load(); s = stream_ptr(dev)
+dev = torch.device("cuda:0"); s = stream_ptr(dev)
+if os.environ.get("LVAE_PROBE_LIB"):            # an alternative build of the kernel library (a measurement knob compiled in)
+    import ctypes
+    lib = _lib.bind(ctypes.CDLL(os.environ["LVAE_PROBE_LIB"]), os.environ["LVAE_PROBE_LIB"])
+else:
+    lib = _lib.load()
 T, H = 200, 1024
 whh = (torch.rand(4 * H, H, device=dev) * 2 - 1) * 0.03
 n = lib.lv_lstm_persist_wpk_floats()
@@ -32,7 +37,7 @@ def bufs(B):
     g = torch.Generator(device="cpu").manual_seed(B)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     hs = torch.zeros(T + 1, B, H, device=dev); cs = torch.zeros(T + 1, B, H, device=dev)
-    gates = torch.empty(T, B, 4 * H, device=dev)
+    gates = torch.empty(max(T * B * 4 * H, lib.lv_lstm_persist16_saved_floats(T, 16)), device=dev)      # also the 16-row kernels' saved-activation buffer
     dO = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
     dG16 = torch.empty(T, B, 4 * H, dtype=torch.int16, device=dev)
     dGsum = torch.empty(B, 4 * H, device=dev); dc0 = torch.empty(B, H, device=dev)

@@ -23,11 +23,11 @@ xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
 st = torch.zeros(1, dtype=torch.int32, device=dev)
 trace = torch.zeros(T, 8, dtype=torch.int64, device=dev)
 cdll.lv_trace_set.argtypes = [ctypes.c_void_p]
-for B, R in ((32, 4), (64, 8)):
+for B, R in ((32, 4), (64, 8), (128, 16)):
     g = torch.Generator().manual_seed(B)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     hs = torch.zeros(T + 1, B, H, device=dev); cs = torch.zeros(T + 1, B, H, device=dev)
-    gates = torch.empty(T, B, 4 * H, device=dev)
+    gates = torch.empty(max(T * B * 4 * H, lib.lv_lstm_persist16_saved_floats(T, 16)), device=dev)      # also the 16-row kernels' saved-activation buffer
     dO = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
     dG16 = torch.empty(T, B, 4 * H, dtype=torch.int16, device=dev)
     dGsum = torch.empty(B, 4 * H, device=dev); dc0 = torch.empty(B, H, device=dev)

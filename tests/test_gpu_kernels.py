@@ -327,6 +327,27 @@ def test_lstm_bwd_bf16_img(lib, hip_device, T, B, H, use_mask, tanh_init, use_ex
     test_lstm_fwd_bwd(lib, hip_device, T, B, H, use_mask, tanh_init, use_ext, use_last, prec="bf16_img")
 
 
+def _saved16_pack(lib, gates, cs, R):
+    """gates [T][B][4H] (unit-major: (i, f, g, o) per unit) and cs [T + 1][B][H] -> the workgroup-major saved-activation buffer of
+    lv_lstm_persist16.hip: saved[group][member][t]{ gates [R][32][4], c [R][32] }, R rows per group (c_t = cs[t + 1])."""
+    T, B, H = gates.shape[0], gates.shape[1], gates.shape[2] // 4
+    g = torch.zeros(T, 8 * R, H, 4, device=gates.device); g[:, :B] = gates.view(T, B, H, 4)
+    c = torch.zeros(T, 8 * R, H, device=gates.device); c[:, :B] = cs[1:]
+    g = g.view(T, 8, R, 32, 32 * 4).permute(1, 3, 0, 2, 4).reshape(8, 32, T, R * 128)
+    c = c.view(T, 8, R, 32, 32).permute(1, 3, 0, 2, 4).reshape(8, 32, T, R * 32)
+    out = torch.cat([g, c], dim=3).contiguous().view(-1)
+    assert out.numel() == lib.lv_lstm_persist16_saved_floats(T, R)
+    return out
+
+
+def _saved16_unpack(saved, T, B, R, H=1024):
+    """The inverse: (gates [T][B][4H], c_0 .. c_{T-1} as [T][B][H])."""
+    sv = saved.view(8, 32, T, R * 160)
+    g = sv[..., :R * 128].reshape(8, 32, T, R, 32 * 4).permute(2, 0, 3, 1, 4).reshape(T, 8 * R, 4 * H)
+    c = sv[..., R * 128:].reshape(8, 32, T, R, 32).permute(2, 0, 3, 1, 4).reshape(T, 8 * R, H)
+    return g[:, :B].contiguous(), c[:, :B].contiguous()
+
+
 @pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
 def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=None, flags=0):
     """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
@@ -356,10 +377,16 @@ def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=No
             ws = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
-            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(ws), P(status), T, B,
-                                           R if R is not None else (B + 7) // 8, flags, H, _s(dev))
+            R16 = R if R is not None else (B + 7) // 8
+            saved = torch.full((lib.lv_lstm_persist16_saved_floats(T, R16),), float("nan"), device=dev)
+            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(ws), P(status), T, B, R16, flags, H, _s(dev))
             assert int(status.item()) == 0
             hdrop = hs[1:].clone()
+            # gates and cell states come back in the kernels' workgroup-major buffer; canonical cs holds the final state only
+            gates, c_t = _saved16_unpack(saved, T, B, R16)
+            assert torch.equal(cs[T], c_t[T - 1]) and float(cs[1:T].abs().max() if T > 1 else 0.0) == 0.0
+            cs[1:] = c_t
+            gates = gates.view(T, B, 4 * H)
         elif persistent:
             wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
             ws = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
@@ -437,9 +464,12 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         if persistent and variant == "rs16":
             wsp = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_bwd_bf16_persist16(P(wext) if use_ext else None, P(wlast) if use_last else None, P(wpk), P(gates), P(hs), P(cs),
+            R16 = R if R is not None else (B + 7) // 8
+            saved = _saved16_pack(lib, gates.view(T, B, 4 * H), cs, R16)
+            cs0 = torch.full_like(cs, float("nan")); cs0[0] = cs[0]          # the kernel may read the initial state only
+            lib.lv_lstm_bwd_bf16_persist16(P(wext) if use_ext else None, P(wlast) if use_last else None, P(wpk), P(saved), P(hs), P(cs0),
                                            P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B,
-                                           R if R is not None else (B + 7) // 8, flags, H, _s(dev))
+                                           R16, flags, H, _s(dev))
             assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
             dG = torch.cat([dG16.view(torch.bfloat16).float()])
         elif persistent:
@@ -465,8 +495,10 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
 
 
-def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
-    """Both persistent recurrences at the length the metric is quoted on (T = 200, B = 32, H = 1024) against the
+@pytest.mark.parametrize("kernels", ["16row", "4row"])
+def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels):
+    """Both persistent recurrences (the default kernels of lv_lstm_persist16.hip with their hand-off in the XCD's L2, and the
+    4-row kernels of lv_lstm_persist.hip) at the length the metric is quoted on (T = 200, B = 32, H = 1024) against the
     launch-per-step bf16 kernels on the SAME inputs: the two realisations see the same bf16-rounded operands and differ only
     in f32 summation order (and in what a flipped bf16 rounding moves downstream), so they must stay within 1e-3 of each other
     over all 200 steps -- a per-kernel check that localises a regression the end-to-end Yahoo fixture test would only see as a
@@ -486,7 +518,17 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
         cs = torch.zeros(T + 1, B, H, device=dev)
         hs[0], cs[0] = h0, c0
         gates = torch.empty(T, B, 4 * H, device=dev)
-        if persistent:
+        if persistent and kernels == "16row":
+            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+            xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, 4), device=dev)
+            lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
+            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(xch), P(status), T, B, 4, 1, H, _s(dev))
+            assert int(status.item()) == 0
+            gates, c_t = _saved16_unpack(saved, T, B, 4)
+            cs[1:] = c_t
+        elif persistent:
             wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
             xch = torch.empty(lib.lv_lstm_persist_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -496,7 +538,7 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
         else:
             ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
             lib.lv_lstm_fwd_bf16_ug(P(gxu), P(whh), P(hs), P(cs), P(gates), None, 1.0, None, P(ws), T, B, H, _s(dev))
-        fw[persistent] = (hs, cs, gates)
+        fw[persistent] = (hs, cs, gates.view(T, B, 4 * H))
     for a, b, what in zip(fw[True], fw[False], ("h", "c", "gates")):
         err = float((a - b).abs().max())
         assert err < 1e-3, (what, err)
@@ -507,7 +549,15 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device):
         dG16 = torch.zeros(T, B, 4 * H, dtype=torch.int16, device=dev)
         dGsum = torch.empty(B, 4 * H, device=dev)
         dc0 = torch.empty(B, H, device=dev)
-        if persistent:
+        if persistent and kernels == "16row":
+            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+            xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
+            lib.lv_lstm_bwd_bf16_persist16(P(wext), None, P(wpk), P(_saved16_pack(lib, gates.view(T, B, 4 * H), cs, 4)), P(hs), P(cs), P(dG16),
+                                           P(dGsum), P(xch), P(status), None, P(dc0), 1, T, B, 4, 1, H, _s(dev))
+            assert int(status.item()) == 0
+        elif persistent:
             wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
             xch = torch.empty(lib.lv_lstm_persist_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "lv_lstm_bwd_bf16_persist": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist_rs": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_persist16_xch_floats": [],
+    "lv_lstm_persist16_saved_floats": [_i, _i],
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
     "lv_lstm_fwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -135,7 +136,7 @@ SIGNATURES = {
 }
 
 
-_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_conv32_wpack_floats",
+_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats", "lv_conv32_wpack_floats",
              "lv_conv32_wgrad_ws_floats")
 
 
@@ -164,7 +165,7 @@ class Lib(object):
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
-                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats",
+                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats",
                            "lv_pixelcnn_net_words", "lv_pixelcnn_block_words", "lv_conv32_tap_split"}
 
     def __getattr__(self, name):

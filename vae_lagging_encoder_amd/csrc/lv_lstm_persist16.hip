@@ -19,6 +19,11 @@
 //     for its 32 units, sums them in registers + two shuffles, runs the gate-gradient math, publishes its dG image through LDS
 //     (ONE barrier), multiplies it with its 128 gate rows of W_hh (4 fragment reads + 64 MFMAs) and sends the partial sums.
 //   rows per group R <= 16; instantiated for RP = 4 / 8 / 16 (polls per lane, pairs per thread and the I/O block length follow).
+//   * the activations the forward saves for the BPTT (gates i, f, g, o and the cell state) live in a WORKGROUP-MAJOR buffer:
+//     saved[group][member][t]{ gates [R][32 units][4], c [R][32 units] } -- 640 R bytes per workgroup and timestep, consecutive
+//     timesteps adjacent.  In the canonical [t][b][...] order every timestep of every array is its own page at B = 128 (2 MB apart),
+//     and the address translations of a block's loads serialise IN FRONT of whatever the wave issues next: 3.8 us per 2-step
+//     block in the 16-row BPTT (trace: profiles/r03k_*), 1.5 us per timestep of 7.9 (what-if build reading the same pages).
 // LDS row pitches are = 2 (mod 16) 16-byte slots: ds_read_b128 serves lanes in groups {0-3,12-15,20-27}, ..., i.e. the 16 rows
 // of one 8-k chunk and a neighbouring chunk, which a pitch of 2 slots spreads over all 16 slot classes.
 #include "lv_device.h"
@@ -29,6 +34,10 @@ __device__ unsigned long long* lv_trace_buf = nullptr;
 extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lv_trace_buf), &p, sizeof(p)); }
 #endif
 
+#ifndef LV_SBB16
+#define LV_SBB16 2                      // (measurement knob of profiles/microbench: input block length of the 16-row BPTT)
+#endif
+
 namespace {
 
 using namespace lvp;
@@ -36,6 +45,7 @@ using namespace lvp;
 constexpr int HP16 = PH / 2 + 8;        // dwords per row of the gathered h image (130 slots: = 2 mod 16)
 constexpr int DP16 = 64 + 8;            // dwords per row of the dG image (18 slots)
 constexpr int RED_SLOTS = 33;           // float4 slots per row of a quarter product (32 units + 1: 8 consecutive rows = 8 slot classes)
+constexpr int SAVED_PER_ROW = 160;     // floats per batch row in a (workgroup, timestep) record of the saved activations: 32 units x (4 gates + c)
 constexpr int RS16_SLOTS_MAX = 256;     // granule slots of one (receiver, sender) pair at 16 rows (16 RP in general: the pairs are dense)
 template <int V> struct lv_const { static constexpr int value = V; };
 
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restric
 
 struct Fwd16P {
     const float* gx; const uint4* wpk;
-    float* hs; float* cs; float* gates;
+    float* hs; float* cs; float* saved;
     gran_t* hx;                 // exchange: [2 parity][8 groups][16 rows][H/2] granules, zeroed before the launch
     int* status;
     int T, B, R;
@@ -84,7 +94,7 @@ struct Fwd16P {
 template <int RP> struct Cfg16 {
     static constexpr int NP = RP > 8 ? 2 : 1;
     static constexpr int SBK = RP > 8 ? 4 : 8;
-    static constexpr int SBB = RP > 8 ? 2 : 8;       // BPTT: two pairs per thread at 16 rows leave room for 2-step blocks only
+    static constexpr int SBB = RP > 8 ? LV_SBB16 : 8; // BPTT: timesteps per input block
     static constexpr int GJ = RP > 4 ? 16 : 8;
 };
 
@@ -124,13 +134,17 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     // this thread's (row, unit) pairs: rows tid >> 5 (+ 8 for the second pair), unit tid & 31 of the workgroup
     const int uw = tid & 31, punit = 32 * member + uw;
     const long BH = (long)B * PH;
-    int prow[NP]; bool own[NP]; long pidx[NP]; float c_state[NP];
+    const long rec = (long)R * SAVED_PER_ROW;                  // floats of one (workgroup, timestep) record of the saved activations
+    float* const sv = p.saved + (long)(group * PMEMBERS + member) * T * rec;
+    int prow[NP]; bool own[NP]; long pidx[NP]; float c_state[NP]; int sg[NP], sc[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         prow[q] = (tid >> 5) + 8 * q;
         own[q] = prow[q] < rows;
         pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
         c_state[q] = own[q] ? p.cs[pidx[q]] : 0.f;
+        sg[q] = (prow[q] * 32 + uw) * 4;                       // gates record of the pair, and its cell state behind the R rows of gates
+        sc[q] = R * 128 + prow[q] * 32 + uw;
     }
     gran_t* const hx_g = p.hx + (long)group * 16 * (PH / 2);
     const long hx_par = (long)PGROUPS * 16 * (PH / 2);
@@ -145,14 +159,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 
     float4 gxb[NP][SBK], recb[NP][SBK];
     float cb[NP][SBK], hb[NP][SBK];
-    auto load_block = [&](int tb) {
+    auto load_slots = [&](int tb, int lo, int hi) {          // gx of steps tb + [lo, hi) into their slots
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int s2 = 0; s2 < SBK; ++s2) {
-                const int t = tb + s2;
-                gxb[q][s2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (own[q] && t < T) gxb[q][s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx[q]) * 4);
+                if (s2 < lo || s2 >= hi) continue;
+                // UNCONDITIONAL, from a clamped address (steps >= T never run, pairs nobody owns read row 0 of the slice and are
+                // never used): behind an `if` the loaded value meets a zero in a phi, the four components stop being one register
+                // tuple, and the compiler copies them out right behind the load -- s_waitcnt vmcnt(0) after EVERY block load, a
+                // full HBM round trip each (16-row BPTT: 3.8 us per 2-step block).
+                const int t = tb + s2 < T ? tb + s2 : T - 1;
+                gxb[q][s2] = *reinterpret_cast<const float4*>(p.gx + ((long)t * BH + pidx[q]) * 4);
             }
     };
     auto store_block = [&](int tb) {
@@ -163,13 +181,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 const int t = tb + s2;
                 if (own[q] && t < T) {
                     lv_store_nt(f32x4{recb[q][s2].x, recb[q][s2].y, recb[q][s2].z, recb[q][s2].w},
-                                reinterpret_cast<f32x4*>(p.gates + ((long)t * BH + pidx[q]) * 4));
-                    lv_store_nt(cb[q][s2], p.cs + (long)(t + 1) * BH + pidx[q]);
+                                reinterpret_cast<f32x4*>(sv + (long)t * rec + sg[q]));
+                    lv_store_nt(cb[q][s2], sv + (long)t * rec + sc[q]);
                     lv_store_nt(hb[q][s2], p.hs + (long)(t + 1) * BH + pidx[q]);
+                    if (t == T - 1) p.cs[(long)T * BH + pidx[q]] = cb[q][s2];      // the final cell state in the canonical place
                 }
             }
     };
-    load_block(0);
+    load_slots(0, 0, SBK);
     __syncthreads();
 
     const int nq = rows * 128;                                 // granules of this wave's K quarter
@@ -209,6 +228,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     *dstw = (uint32_t)v[j];
                 }
             }
+            // Bulk I/O goes out right BEHIND a completed gather: a wave's loads and stores retire in order, so whatever is issued in
+            // front of a poll is waited for by that poll with its full memory latency (first build: everything at the block
+            // boundary).  First step of a block: the previous block's results and the one gx slot that was still in use; last
+            // step: the next block's other slots.
+            if (s2 == 0 && tb > 0) { store_block(tb - SBK); load_slots(tb, SBK - 1, SBK); }
+            if (s2 == SBK - 1) load_slots(tb + SBK, 0, SBK - 1);
             LV_TRACE_MARK(t, 1);
             LV_WAIT_LDS();                                     // the wave reads back only what its own lanes wrote
             LV_TRACE_MARK(t, 2);
@@ -234,7 +259,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 for (int nb = 0; nb < 8; ++nb) rd[4 * nb + kq] = acc[nb];
             }
             LV_TRACE_MARK(t, 3);
-            __syncthreads();                                   // the four quarter products (double-buffered by step parity)
+            LV_BARRIER_LDS();                                  // the four quarter products (double-buffered by step parity); LDS-only:
+                                                               // the block loads issued behind the gather stay in flight
             LV_TRACE_MARK(t, 4);
             if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
 
@@ -264,9 +290,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             }
             LV_TRACE_MARK(t, 5);
         }
-        store_block(tb);
-        load_block(tb + SBK);
     }
+    store_block((T - 1) / SBK * SBK);
 }
 
 // =====================================================================================================================
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 struct Bwd16P {
     const float* dh_ext; const float* dh_last;
     const uint4* wpk;
-    const float* gates; const float* cs; const float* hs;
+    const float* saved; const float* cs; const float* hs;
     uint16_t* dG16; float* dGsum;
     float* dh0; float* dc0; int tanh_init;
     gran_t* gxch;
@@ -293,7 +318,7 @@ struct Bwd16P {
 template <int RP>
 struct __attribute__((aligned(16))) Bwd16Lds {
     uint32_t dgl[2][16 * DP16];                         // [step parity] dG of this workgroup's 128 gate rows (B operand image), rows < R valid
-    uint16_t og[Cfg16<RP>::SBB][RP][4][32];             // dG of one I/O block: [step][row][gate][unit in WG]
+    uint16_t og[2][RP][4][32];                          // [step parity] the same dG as it goes to memory: [row][gate][unit in WG]
     int abort;
 };
 
@@ -329,13 +354,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     const int uw = 16 * (w >> 1) + 4 * (pp & 3) + 2 * (w & 1) + ((l >> 4) & 1);
     const int punit = 32 * member + uw;
     const long BH = (long)B * PH;
-    int prow[NP]; bool own[NP]; long pidx[NP];
+    const long rec = (long)R * SAVED_PER_ROW;
+    const float* const sv = p.saved + (long)(group * PMEMBERS + member) * T * rec;
+    int prow[NP]; bool own[NP]; long pidx[NP]; int sg[NP], sc[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int beta = 2 * q + (l >> 5);
         prow[q] = 4 * beta + (pp >> 2);
         own[q] = beta < NB && prow[q] < rows;
         pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
+        sg[q] = ((own[q] ? prow[q] : 0) * 32 + uw) * 4;
+        sc[q] = R * 128 + (own[q] ? prow[q] : 0) * 32 + uw;
     }
     const long px_par = (long)PGROUPS * PMEMBERS * PMEMBERS * SLOTS;
     gran_t* const px_g = p.gxch + (long)group * PMEMBERS * PMEMBERS * SLOTS;
@@ -352,51 +381,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     float dc_rec[NP], gsum[NP][4];
     float dhb[NP][SBK], ctb[NP][SBK + 1];
     float4 recb[NP][SBK];
-    uint32_t outb[NP][SBK][2];
 #pragma unroll
     for (int q = 0; q < NP; ++q) { dc_rec[q] = 0.f; gsum[q][0] = gsum[q][1] = gsum[q][2] = gsum[q][3] = 0.f; }
+    const bool has_ext = p.dh_ext != nullptr;
+    const float* const dh_src = has_ext ? p.dh_ext : p.cs;      // (without dh_ext the loads still run, on any mapped [T][B][H]-sized array)
     auto load_block = [&](int t_hi) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
             for (int s2 = 0; s2 < SBK; ++s2) {
-                const int t = t_hi - s2;
-                dhb[q][s2] = 0.f; recb[q][s2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (own[q] && t >= 0) {
-                    if (p.dh_ext) dhb[q][s2] = p.dh_ext[(long)t * BH + pidx[q]];
-                    recb[q][s2] = *reinterpret_cast<const float4*>(p.gates + ((long)t * BH + pidx[q]) * 4);
-                }
+                const int t = t_hi - s2 < 0 ? 0 : t_hi - s2;      // unconditional loads from clamped addresses: see the forward's load_slots
+                dhb[q][s2] = dh_src[(long)t * BH + pidx[q]];
+                recb[q][s2] = *reinterpret_cast<const float4*>(sv + (long)t * rec + sg[q]);
             }
 #pragma unroll
             for (int s2 = 0; s2 <= SBK; ++s2) {
                 const int t = t_hi - s2;
-                ctb[q][s2] = (own[q] && t + 1 >= 0) ? p.cs[(long)(t + 1) * BH + pidx[q]] : 0.f;
+                const float* src = t >= 0 ? sv + (long)t * rec + sc[q] : p.cs + pidx[q];      // c_t; c_{-1} = the initial state
+                ctb[q][s2] = *src;
             }
         }
     };
-    auto store_block = [&](int t_hi) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-            if (own[q]) {
-#pragma unroll
-                for (int s2 = 0; s2 < SBK; ++s2) {
-                    sm.og[s2][prow[q]][0][uw] = (uint16_t)(outb[q][s2][0] & 0xFFFFu);
-                    sm.og[s2][prow[q]][1][uw] = (uint16_t)(outb[q][s2][0] >> 16);
-                    sm.og[s2][prow[q]][2][uw] = (uint16_t)(outb[q][s2][1] & 0xFFFFu);
-                    sm.og[s2][prow[q]][3][uw] = (uint16_t)(outb[q][s2][1] >> 16);
-                }
-            }
-        __syncthreads();
-        for (int c = tid; c < SBK * RP * 4 * 4; c += 256) {      // 16-byte chunks: [step][row][gate][quarter of 32 units]
-            const int qq = c & 3, g = (c >> 2) & 3, r = (c >> 4) % RP, s2 = (c >> 4) / RP;
-            const int t = t_hi - s2;
-            if (t >= 0 && r < rows) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&sm.og[s2][r][g][8 * qq]);      // 8 bf16, moved as raw bits
+    // dG16 of one step, after that step's barrier: 16-byte chunks [row][gate][quarter of the 32 units] of the og image
+    auto store_step = [&](int par, int t) {
+        for (int c = tid; c < RP * 16; c += 256) {
+            const int qq = c & 3, g = (c >> 2) & 3, r = c >> 4;
+            if (r < rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&sm.og[par][r][g][8 * qq]);      // 8 bf16, moved as raw bits
                 uint16_t* dst = p.dG16 + ((long)t * B + (b0 + r)) * 4 * PH + (long)g * PH + 32 * member + 8 * qq;
                 lv_store_nt(v, reinterpret_cast<f32x4*>(dst));
             }
         }
-        __syncthreads();
     };
     load_block(T - 1);
     __syncthreads();
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             for (int q = 0; q < NP; ++q) {
                 float da[4] = {0.f, 0.f, 0.f, 0.f};
                 if (own[q]) {
-                    float dh = dhb[q][s2] + dh_rec[q];
+                    float dh = (has_ext ? dhb[q][s2] : 0.f) + dh_rec[q];
                     if (t == T - 1 && p.dh_last) dh += p.dh_last[pidx[q]];
                     const float ig = recb[q][s2].x, fg = recb[q][s2].y, gg = recb[q][s2].z, og_ = recb[q][s2].w;
                     const float tc = lv_tanh_fast(ctb[q][s2]);
@@ -528,19 +543,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                     for (int g = 0; g < 4; ++g) gsum[q][g] += da[g];
                 }
                 const uint32_t lo = lv_pack_bf16x2(da[0], da[1]), hi = lv_pack_bf16x2(da[2], da[3]);
-                outb[q][s2][0] = lo; outb[q][s2][1] = hi;
-                if (own[q]) { sm.dgl[par][prow[q] * DP16 + 2 * uw] = lo; sm.dgl[par][prow[q] * DP16 + 2 * uw + 1] = hi; }
+                if (own[q]) {
+                    sm.dgl[par][prow[q] * DP16 + 2 * uw] = lo; sm.dgl[par][prow[q] * DP16 + 2 * uw + 1] = hi;
+                    sm.og[par][prow[q]][0][uw] = (uint16_t)(lo & 0xFFFFu); sm.og[par][prow[q]][1][uw] = (uint16_t)(lo >> 16);
+                    sm.og[par][prow[q]][2][uw] = (uint16_t)(hi & 0xFFFFu); sm.og[par][prow[q]][3][uw] = (uint16_t)(hi >> 16);
+                }
             }
+            // Bulk input of the NEXT block right behind a completed receive (and the last use of this block's registers): a wave's
+            // loads retire in order, so anything issued just before a poll is waited for by that poll with its full HBM latency
+            // (the first build loaded at the block boundary, i.e. in front of the next receive: 3.8 us per boundary at 16 rows).
+            if (s2 == SBK - 1) load_block(t_hi - SBK);
             LV_TRACE_MARK(t, 2);
-            __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity)
+            LV_BARRIER_LDS();                   // the workgroup's dG image of this step (double-buffered by step parity); LDS-only:
+                                                // the next block's loads stay in flight across it
             LV_TRACE_MARK(t, 3);
             if (s_abort) { aborted = true; continue; }
             if (t > 0 || closing) send(par, T - t);
+            store_step(par, t);
             LV_TRACE_MARK(t, 4);
         }
         if (aborted) { if (tid == 0) atomicExch(p.status, 200 + (t_hi < 0 ? 0 : t_hi)); return; }
-        store_block(t_hi);
-        load_block(t_hi - SBK);
     }
 
 #pragma unroll
@@ -578,6 +600,12 @@ int check_R(int B, int R) { return R >= 1 && R <= 16 && (long)R * PGROUPS >= B; 
 
 extern "C" long lv_lstm_persist16_xch_floats(void) { return XCH_RS16_BYTES / 4 + 64; }
 
+// floats of the saved-activation buffer the 16-row forward writes and the 16-row BPTT reads (workgroup-major, see the top of the
+// file): T timesteps at R rows per XCD group.  Both calls must be given the same T, B and R.
+extern "C" long lv_lstm_persist16_saved_floats(int T, int R) {
+    return T < 0 || R < 1 || R > 16 ? 0 : (long)PGROUPS * PMEMBERS * T * R * SAVED_PER_ROW;
+}
+
 // W_hh [4H][H] f32 -> the register image of lv_lstm_fwd_bf16_persist16 (backward = 0) / lv_lstm_bwd_bf16_persist16 (backward = 1):
 // lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
 extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
@@ -594,22 +622,23 @@ extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward
 // Forward recurrence in one persistent launch with R batch rows per XCD group (1 <= R <= 16, 8 R >= B): groups
 // [0, ceil(B / R)) carry the batch, the workgroups of the other groups return at once -- R = 8 at B = 32 runs the recurrence on
 // four XCDs and leaves the other four to concurrent kernels.  Arguments as lv_lstm_fwd_bf16_persist_ks without the in-kernel
-// dropout (the engine applies dropout_out while h is converted to its bf16 images); exchange buffer of
-// lv_lstm_persist16_xch_floats() floats.  flags bit 0: hand-off stores without the agent-scope write-through (they stay in the
+// dropout (the engine applies dropout_out while h is converted to its bf16 images) and with the saved activations in the
+// workgroup-major buffer of lv_lstm_persist16_saved_floats(T, R) floats instead of gates / cs[1 .. T - 1] (cs: slot 0 is read,
+// slot T written); exchange buffer of lv_lstm_persist16_xch_floats() floats.  flags bit 0: hand-off stores without the agent-scope write-through (they stay in the
 // XCD's L2; correct while every group is XCD-local -- the round-robin placement of a 256-CU device -- and reported through
 // *status as a hand-off timeout otherwise).
-extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* gates, float* xch,
+extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* saved, float* xch,
                                           int* status, int T, int B, int R, int flags, int H, void* stream) {
-    if (!gx || !wpk || !hs || !cs || !gates || !xch || !status) return LV_ERR_ARG;
+    if (!gx || !wpk || !hs || !cs || !saved || !xch || !status) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
-    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)saved) & 15) != 0 || (((uintptr_t)gx) & 15) != 0 || (((uintptr_t)xch) & 15) != 0)
         return LV_ERR_ALIGN;
     if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // the groups in use must be resident at once
     if (T == 0) return LV_OK;
     gran_t* hx = reinterpret_cast<gran_t*>(xch);
     (void)hipMemsetAsync(hx, 0, (size_t)XCH_FWD16_BYTES, (hipStream_t)stream);
-    Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, gates, hx, status, T, B, R};
+    Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, saved, hx, status, T, B, R};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
     if (flags & 1) {
         if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, true>), grid, block, 0, stream, p);
@@ -625,21 +654,21 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
 }
 
 // BPTT in one persistent launch, R batch rows per XCD group (as above).  Arguments as lv_lstm_bwd_bf16_persist_rs without the
-// in-kernel dropout mask; image-only (dG16).
-extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* gates,
+// in-kernel dropout mask; image-only (dG16).  saved: as the forward with the same T, B, R wrote it; cs: slot 0 only.
+extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved,
                                           const float* hs, const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status,
                                           float* dh0, float* dc0, int tanh_init, int T, int B, int R, int flags, int H, void* stream) {
-    if (!wpk || !gates || !cs || !dG16 || !dGsum || !xch || !status) return LV_ERR_ARG;
+    if (!wpk || !saved || !cs || !dG16 || !dGsum || !xch || !status) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || H <= 0) return LV_ERR_SHAPE;
     if (tanh_init && !hs) return LV_ERR_ARG;
     if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
-    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)gates) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
+    if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)saved) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
         return LV_ERR_ALIGN;
     if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
     gran_t* gxch = reinterpret_cast<gran_t*>(xch);
     const int RPi = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
     (void)hipMemsetAsync(gxch, 0, (size_t)(XCH_RS16_BYTES / RS16_SLOTS_MAX * 16 * RPi), (hipStream_t)stream);      // the instantiation's dense extent
-    Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), gates, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), saved, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
     if (flags & 1) {
         if (R <= 4) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<4, true>), grid, block, 0, stream, p);

@@ -350,6 +350,16 @@ def _persist_rows(eng, B):
     return False, (B + 7) // 8
 
 
+def _saved_floats(eng, T, B, H):
+    """Floats of one LSTM layer's saved-activation buffer: gates [T][B][4H] for the step kernels and the 4-row persistent ones;
+    the kernels of lv_lstm_persist16.hip keep gates AND cell states in a workgroup-major record buffer of their own size."""
+    n = T * B * 4 * H
+    use16, rows = _persist_rows(eng, B)
+    if use16 and H == _PERSIST_H and eng.precision == "bf16" and eng.persistent:
+        n = max(n, eng.lib.lv_lstm_persist16_saved_floats(T, rows))
+    return n
+
+
 def _persistent_ok(eng, img, B, H, device, max_b):
     return (eng.precision == "bf16" and img is not None and eng.persistent and H == _PERSIST_H and B <= max_b
             and torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
@@ -434,6 +444,9 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         if use16:
             if mask is not None or hdrop is not None:
                 raise _lib.LvaeError("the 16-row persistent forward has no in-kernel dropout (the engine applies it on the images)")
+            need = lib.lv_lstm_persist16_saved_floats(T, rows)
+            if w.gates.numel() < need:              # eng.persist_rows changed after the workspace was built
+                w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
             lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, PERSIST16_FLAGS, H, s)
         else:
             fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
@@ -641,7 +654,7 @@ class LSTMEncoderEngine(object):
             # index 0 = the initial state: zero for the encoder (enc_lstm.py:60), and no kernel ever writes slot 0
             w.hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=c.device)
             w.cs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=c.device)
-            w.gates = c.f32(T * B, 4 * H)
+            w.gates = c.f32(_saved_floats(self, T, B, H))
             w.mulv = c.f32(B, nz2)
             w.dmulv = c.f32(B, nz2)
             w.dG = c.f32(T * B, 4 * H)
@@ -866,7 +879,7 @@ class LSTMDecoderEngine(object):
             w.Gx = c.f32(Td * Bd, 4 * H)
             w.hs = c.f32(Td + 1, Bd, H)
             w.cs = c.f32(Td + 1, Bd, H)
-            w.gates = c.f32(Td * Bd, 4 * H)
+            w.gates = c.f32(_saved_floats(self, Td, Bd, H))
             w.O = c.f32(Td * Bd, H)
             w._logits = None                 # f32 logits image: allocated on first use (the fused bf16 route never needs it)
             w.lse = c.f32(Td * Bd)
