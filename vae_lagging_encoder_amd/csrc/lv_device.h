@@ -24,7 +24,6 @@ static inline unsigned long long lv_agent_load_u64(const unsigned long long* p) 
 }
 static inline void lv_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 static inline void lv_xcd_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
-#define LV_BARRIER_LDS() __syncthreads()
 #define LV_WAIT_LDS() lv_emu::wave_sync()      // lanes are fibers here: 'the wave's own LDS writes are visible' needs a rendezvous
 template <class T> static inline void lv_store_nt(T v, T* p) { *p = v; }
 static inline int lv_device_cus() { return 1 << 20; }
@@ -140,11 +139,6 @@ __device__ __forceinline__ void lv_xcd_store_u64(unsigned long long* p, unsigned
 #define LV_SPIN_LIMIT (1 << 22)             // polls per wait before a hand-off is reported lost (~1 s)
 // lgkmcnt(0): a wave's own LDS accesses are ordered; enough when the data is wave-private
 #define LV_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xc07f)
-// Workgroup barrier for data that crosses the workgroup through LDS ONLY: waits for this wave's LDS accesses and meets the
-// others, WITHOUT the vmcnt(0) that __syncthreads() puts in front of s_barrier -- a wave with bulk loads or stores in flight
-// would sit at the barrier for their whole memory latency (persistent LSTM kernels: the saved-activation loads of the next
-// block, 2 us per block at 16 rows).  Global data must not rely on this barrier for ordering.
-#define LV_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // streaming store: consumed by later kernels only (no write-allocate fetch of a partially written line)
 template <class T> __device__ __forceinline__ void lv_store_nt(T v, T* p) { __builtin_nontemporal_store(v, p); }
 // compute units of the current device (cached per ordinal; the persistent launches need their whole grid resident)

@@ -35,7 +35,13 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #endif
 
 #ifndef LV_SBB16
-#define LV_SBB16 2                      // (measurement knob of profiles/microbench: input block length of the 16-row BPTT)
+#define LV_SBB16 2                      // (measurement knobs of profiles/microbench: input block length of the 16-row BPTT,
+#endif                                  //  I/O block length and granules per lane and polling round of the 16-row forward)
+#ifndef LV_SBK16
+#define LV_SBK16 4
+#endif
+#ifndef LV_GJ16
+#define LV_GJ16 16
 #endif
 
 namespace {
@@ -93,9 +99,9 @@ struct Fwd16P {
 // I/O block; GJ = granules per lane in flight per polling round.
 template <int RP> struct Cfg16 {
     static constexpr int NP = RP > 8 ? 2 : 1;
-    static constexpr int SBK = RP > 8 ? 4 : 8;
+    static constexpr int SBK = RP > 8 ? LV_SBK16 : 8;
     static constexpr int SBB = RP > 8 ? LV_SBB16 : 8; // BPTT: timesteps per input block
-    static constexpr int GJ = RP > 4 ? 16 : 8;
+    static constexpr int GJ = RP > 8 ? LV_GJ16 : (RP > 4 ? 16 : 8);
 };
 
 template <int RP>
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 for (int nb = 0; nb < 8; ++nb) rd[4 * nb + kq] = acc[nb];
             }
             LV_TRACE_MARK(t, 3);
-            LV_BARRIER_LDS();                                  // the four quarter products (double-buffered by step parity); LDS-only:
-                                                               // the block loads issued behind the gather stay in flight
+            __syncthreads();                                   // the four quarter products (double-buffered by step parity); compiles to
+                                                               // lgkmcnt(0) + s_barrier: the block loads issued above stay in flight
             LV_TRACE_MARK(t, 4);
             if (s_abort) { if (tid == 0) atomicExch(p.status, 100 + t); return; }
 
@@ -554,8 +560,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             // (the first build loaded at the block boundary, i.e. in front of the next receive: 3.8 us per boundary at 16 rows).
             if (s2 == SBK - 1) load_block(t_hi - SBK);
             LV_TRACE_MARK(t, 2);
-            LV_BARRIER_LDS();                   // the workgroup's dG image of this step (double-buffered by step parity); LDS-only:
-                                                // the next block's loads stay in flight across it
+            __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity); compiles to
+                                                // lgkmcnt(0) + s_barrier: the next block's loads stay in flight across it
             LV_TRACE_MARK(t, 3);
             if (s_abort) { aborted = true; continue; }
             if (t > 0 || closing) send(par, T - t);
