@@ -42,7 +42,9 @@ for B, R in ((32, 4), (64, 8), (128, 16)):
         trace.zero_()
         e0.record(); fn(); e1.record(); torch.cuda.synchronize()
         us_traced = e0.elapsed_time(e1) * 1e3 / T
-        tr = trace.cpu().numpy().astype(np.float64)[:, :nm]
+        full = trace.cpu().numpy().astype(np.float64)
+        spins = full[:, 6:8]
+        tr = full[:, :nm]
         order = np.argsort(tr[:, 0])                       # BPTT walks t downwards
         tr = tr[order]
         period = np.diff(tr[:, 0])
@@ -50,6 +52,8 @@ for B, R in ((32, 4), (64, 8), (128, 16)):
         ticks_per_us = np.median(period[inner - 1]) / us_traced
         ph = np.diff(tr, axis=1)[inner]
         tail = (tr[inner + 1, 0] - tr[inner, nm - 1])
-        print("B=%d R=%d %s: %.2f us/step untraced, %.2f traced; median phase times (us): %s | to next step start %.2f  (clock %.0f ticks/us)" % (
-            B, R, name, us_plain, us_traced, " ".join("%.2f" % (v / ticks_per_us) for v in np.median(ph, axis=0)), np.median(tail) / ticks_per_us, ticks_per_us))
+        print("B=%d R=%d %s: %.2f us/step untraced, %.2f traced; median phase times (us): %s | to next step start %.2f  (clock %.0f ticks/us); "
+              "failed poll rounds per step of the last polling round(s): mean %s" % (
+            B, R, name, us_plain, us_traced, " ".join("%.2f" % (v / ticks_per_us) for v in np.median(ph, axis=0)), np.median(tail) / ticks_per_us, ticks_per_us,
+            " ".join("%.2f" % v for v in spins[5:-5].mean(axis=0))))
 cdll.lv_trace_set(None)

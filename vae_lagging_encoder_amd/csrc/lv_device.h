@@ -243,8 +243,15 @@ extern __device__ unsigned long long* lv_trace_buf;
     do {                                                                                                                    \
         if (lv_trace_buf && blockIdx.x == 8 && threadIdx.x == 0) lv_trace_buf[(long)(step) * 8 + (i)] = clock64();         \
     } while (0)
+#define LV_TRACE_VAL(step, i, v)                                                                                           \
+    do {                                                                                                                    \
+        if (lv_trace_buf && blockIdx.x == 8 && threadIdx.x == 0) lv_trace_buf[(long)(step) * 8 + (i)] = (unsigned long long)(v); \
+    } while (0)
+#define LV_TRACE_ONLY(...) __VA_ARGS__
 #else
 #define LV_TRACE_MARK(step, i) do { } while (0)
+#define LV_TRACE_VAL(step, i, v) do { } while (0)
+#define LV_TRACE_ONLY(...)
 #endif
 
 #define LV_WAVE 64

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     ok = __all(ok);
                     if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
                 } while (!ok);
+                LV_TRACE_VAL(t, 6, spins);
 #pragma unroll
                 for (int j = 0; j < GJ; ++j) {
                     const int q = base + j * 64 + l;
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     // need 64 registers next to the 256 of the weights (the first build spilled 92); the sums over the senders are taken in a
     // fixed order once a round is complete, so the result does not depend on arrival order.
     constexpr int HB = NB < 2 ? NB : 2;
+    LV_TRACE_ONLY(int tr_spins[2] = {0, 0};)
     auto receive_round = [&](auto H0, const gran_t* src, uint32_t want, float (&dh_rec)[NP]) -> bool {
         constexpr int h0 = decltype(H0)::value;
         gran_t v[HB][8];
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             ok = __all(ok);
             if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
         } while (!ok);
+        LV_TRACE_ONLY(tr_spins[h0 ? 1 : 0] = spins;)
 #pragma unroll
         for (int bt = 0; bt < HB; ++bt) {
             float a = 0.f, b = 0.f;
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             LV_TRACE_MARK(t, 0);
             if (t < T - 1) receive(T - 1 - t, dh_rec);        // on a timeout s_abort is set: everybody leaves after the barrier below
             LV_TRACE_MARK(t, 1);
+            LV_TRACE_ONLY(LV_TRACE_VAL(t, 6, tr_spins[0]); LV_TRACE_VAL(t, 7, tr_spins[1]);)
             const int par = (T - t) & 1;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
