@@ -208,6 +208,10 @@ int lv_token_sort(const int64_t* ids, long ids_stride, int T, int B, int V,
 int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
                          const int* sorted_tok, int T, int B, float* dE, int ni, int pad_idx, int accumulate,
                          void* stream);
+/* the same sums with dE [V][ni] COMPLETE: the rows of tokens that do not occur in the batch (and pad_idx) are written as zeros
+ * by the same launch -- the embedding gradient of nn.Embedding (enc_lstm.py:33, dec_lstm.py:34) without a fill of the table */
+int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
+                              const int* sorted_tok, int T, int B, float* dE, int ni, int V, int pad_idx, void* stream);
 
 /* ---- reparameterise + analytic KL: GaussianEncoderBase.encode / reparameterize (modules/encoders/encoder.py:40-79)
  * mulv [B][2nz] = mu | logvar; eps [B][ns][nz] is an input (host RNG in parity mode, lv_rng_* otherwise). */

@@ -656,6 +656,13 @@ def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):
     dE2 = torch.zeros(V, ni, device=dev)
     lib.lv_embed_scatter_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE2), ni, V - 1, 0, _s(dev))
     assert torch.equal(dE, dE2)                            # deterministic (sorted segments, no atomics)
+    # the complete form: the same sums, and every other row (and the padding row) zeroed by the same launch
+    dE3 = torch.full((V, ni), float("nan"), device=dev)
+    lib.lv_embed_scatter_full_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE3), ni, V, V - 1, _s(dev))
+    assert torch.equal(dE3, dE)
+    dE4 = torch.full((V, ni), float("nan"), device=dev)
+    lib.lv_embed_scatter_full_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE4), ni, V, -1, _s(dev))
+    assert torch.equal(dE4[:V - 1], dE[:V - 1]) and float(dE4[V - 1].abs().max()) > 0.0      # no padding row: token V - 1 counts
 
 
 @pytest.mark.parametrize("B,ns,nz", [(32, 1, 32), (16, 1, 1), (5, 3, 40), (128, 2, 7)])

@@ -161,12 +161,26 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
                                                             float scale, const int* __restrict__ rows,
                                                             const int* __restrict__ toks, int N, int B, int T,
                                                             float* __restrict__ dE, int ni, int pad_idx, int accumulate,
-                                                            int vec) {
+                                                            int vec, int V) {
     const int p = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    if (V > 0) {
+        // complete form: every row of dE is written exactly once by this launch -- the rows of tokens that occur by their segment
+        // heads below, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
+        // binary search of the sorted token list per row).  Replaces a separate fill of the whole table (41 MB at V = 20001).
+        const int v0 = (int)((long)p * V / N), v1 = (int)((long)(p + 1) * V / N);
+        for (int v = v0; v < v1; ++v) {
+            int lo = 0, hi = N;                  // first position with toks[pos] >= v
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < v) lo = mid + 1; else hi = mid; }
+            if (lo < N && toks[lo] == v && v != pad_idx) continue;
+            float* z = dE + (long)v * ni;
+            if (vec) for (int k = tid * 4; k < ni; k += 512) *reinterpret_cast<float4*>(z + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int k = tid; k < ni; k += 128) z[k] = 0.f;
+        }
+    }
     const int tok = toks[p];
     if (p > 0 && toks[p - 1] == tok) return;   // not a segment head
     if (tok == pad_idx) return;
-    const int tid = (int)threadIdx.x;
     float* dst = dE + (long)tok * ni;
     if (vec) {
         for (int k = tid * 4; k < ni; k += 512) {
@@ -244,7 +258,22 @@ extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float 
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0;
     const int N = T * B;
     LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
-              N, B, T, dE, ni, pad_idx, accumulate, vec);
+              N, B, T, dE, ni, pad_idx, accumulate, vec, 0);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// The same sums, and dE COMPLETE: rows [0, V) of tokens that do not occur (and pad_idx) are written as zeros by the same launch,
+// so the caller needs no fill of the table in front of it.  Every token id must lie in [0, V).
+extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale,
+                                         const int* sorted_rows, const int* sorted_tok, int T, int B,
+                                         float* dE, int ni, int V, int pad_idx, void* stream) {
+    if (!dX || !sorted_rows || !sorted_tok || !dE) return LV_ERR_ARG;
+    if (T <= 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
+    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0;
+    const int N = T * B;
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+              N, B, T, dE, ni, pad_idx, 0, vec, V);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

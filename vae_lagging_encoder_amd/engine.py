@@ -752,9 +752,9 @@ class LSTMEncoderEngine(object):
             after_bptt()
         def embed_grad():
             # dX -> embedding rows (the embedding table leads the flat buffer: its gradient is the first, and largest, bucket)
-            gv["embed.weight"].zero_()
             self._aux.join(x.device)                   # token sort queued by forward()
-            lib.lv_embed_scatter_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni, -1, 0, s)
+            # every row of the table's gradient is written by this launch (zeros where a token does not occur): no fill in front
+            lib.lv_embed_scatter_full_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni, V, -1, s)
             if after_embed is not None:
                 after_embed()
         # input-side grads: dX first, then the embedding scatter, then the two weight-gradient products
@@ -1082,10 +1082,9 @@ class LSTMDecoderEngine(object):
                 _wgrad(lib, s2, 4 * H, ni, Td * B, P(w.dG), 4 * H, P(w.X), ni, P(gwih), ni + nz, self.precision, ws=sws)
                 _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
                        self.precision, ws=sws)
-            gv["embed.weight"].zero_()
             self._aux.join(dev)                        # token sort queued by forward()
-            lib.lv_embed_scatter_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B, P(gv["embed.weight"]), ni,
-                                     V - 1, 0, s2)
+            lib.lv_embed_scatter_full_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B, P(gv["embed.weight"]), ni,
+                                          V, V - 1, s2)
         self._mark_pending(dev)
         if not fused_ends_ok(B, nz):
             _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)
