@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restri
         float acc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        for (int h = l; h < H; h += 64) {
+#pragma unroll 4
+        for (int h = l; h < H; h += 64) {                 // (4 x 16 independent loads in flight: the loop is a chain of L2 round trips)
             const float x = sh[h];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -82,28 +83,42 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
     const int tid = (int)threadIdx.x;
     const int h0 = (int)blockIdx.x * HB_COLS;
     const long pstride = (long)B * ns * nz;
+    // staging loads are UNCONDITIONAL (clamped column, the value dropped by a select afterwards): a load behind a condition is
+    // waited for right behind its issue, which turns a staging loop into a chain of memory round trips
     for (int i = tid; i < nz2 * HB_COLS; i += 256) {
         const int j = i / HB_COLS, c = i % HB_COLS;
-        sw[i] = h0 + c < H ? wlin[(long)j * H + h0 + c] : 0.f;
+        const float v = wlin[(long)j * H + (h0 + c < H ? h0 + c : H - 1)];
+        sw[i] = h0 + c < H ? v : 0.f;
     }
     for (int i = tid; i < B * HB_COLS; i += 256) {
         const int bb = i / HB_COLS, c = i % HB_COLS;
-        shh[i] = h0 + c < H ? hT[(long)bb * H + h0 + c] : 0.f;
+        const float v = hT[(long)bb * H + (h0 + c < H ? h0 + c : H - 1)];
+        shh[i] = h0 + c < H ? v : 0.f;
     }
-    // dz = sum of the partial sums (in order), staged in LDS first: (element, part) pairs are spread over all threads, 8
-    // loads in flight each, so the pass costs a few memory round trips whatever the part count
+    // dz = sum of the partial sums (in order), staged in LDS first
     float* sg = shh + B * HB_COLS;                         // [B*ns*nz] summed dz
     const int ne = B * ns * nz;
-    for (int e = tid; e < ne; e += 256) {
-        float g = 0.f;
-        for (int q0 = 0; q0 < parts; q0 += 8) {
-            float pv[8];
+    // (two elements x 32 parts = 64 independent loads per thread and round trip: with 8 in flight the 80 parts of the decoder tail
+    //  were 40 dependent round trips per thread, 20 of this kernel's 30 us)
+    for (int e = tid; e < ne; e += 512) {
+        const int e1 = e + 256 < ne ? e + 256 : e;
+        float g0 = 0.f, g1 = 0.f;
+        for (int q0 = 0; q0 < parts; q0 += 32) {
+            float pa[32], pb[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = dz[(long)(q0 + u < parts ? q0 + u : 0) * pstride + e];
+            for (int u = 0; u < 32; ++u) {
+                const long off = (long)(q0 + u < parts ? q0 + u : 0) * pstride;
+                pa[u] = dz[off + e];
+                pb[u] = dz[off + e1];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g += q0 + u < parts ? pv[u] : 0.f;
+            for (int u = 0; u < 32; ++u) {
+                g0 += q0 + u < parts ? pa[u] : 0.f;
+                g1 += q0 + u < parts ? pb[u] : 0.f;
+            }
         }
-        sg[e] = g;
+        sg[e] = g0;
+        if (e + 256 < ne) sg[e + 256] = g1;
     }
     __syncthreads();
     for (int i = tid; i < B * nz; i += 256) {
@@ -169,9 +184,10 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
     for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
     for (int i = tid; i < DI_ROWS * nz; i += 256) {
         const int rr = i / nz, k = i % nz, n = n0 + rr;
-        float v = 0.f;
-        if (n < 5 * H) v = n < H ? wtr[(long)n * nz + k] : wih[(long)(n - H) * ld_wih + col0 + k];
-        swt[rr * pw + k] = v;
+        const int nc = n < 5 * H ? n : 5 * H - 1;          // unconditional load from a clamped row (see enc_head_bwd_kernel)
+        const float* src = nc < H ? wtr + (long)nc * nz + k : wih + (long)(nc - H) * ld_wih + col0 + k;
+        const float v = *src;
+        swt[rr * pw + k] = n < 5 * H ? v : 0.f;
     }
     __syncthreads();
     const int rr = tid & 63, bq = tid >> 6;
@@ -220,16 +236,18 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
     const int nrows = 5 * H - row0 < DZ_ROWS ? 5 * H - row0 : DZ_ROWS;
     for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
     for (int i = tid; i < B * DZ_ROWS; i += 256) {
-        const int b = i / DZ_ROWS, rr = i % DZ_ROWS, row = row0 + rr;
-        float v = 0.f;
-        if (rr < nrows) v = row < 4 * H ? dGsum[(long)b * 4 * H + row] : dc0[(long)b * H + (row - 4 * H)];
-        sdv[b * pd + rr] = v;
+        const int b = i / DZ_ROWS, rr = i % DZ_ROWS;
+        const int row = rr < nrows ? row0 + rr : row0;     // unconditional loads from clamped rows (see enc_head_bwd_kernel)
+        const float* src = row < 4 * H ? dGsum + (long)b * 4 * H + row : dc0 + (long)b * H + (row - 4 * H);
+        const float v = *src;
+        sdv[b * pd + rr] = rr < nrows ? v : 0.f;
     }
     for (int i = tid; i < DZ_ROWS * nz; i += 256) {
-        const int rr = i / nz, k = i % nz, row = row0 + rr;
-        float v = 0.f;
-        if (rr < nrows) v = row < 4 * H ? wih[(long)row * ld_wih + col0 + k] : wtr[(long)(row - 4 * H) * nz + k];
-        swt[i] = v;
+        const int rr = i / nz, k = i % nz;
+        const int row = rr < nrows ? row0 + rr : row0;
+        const float* src = row < 4 * H ? wih + (long)row * ld_wih + col0 + k : wtr + (long)(row - 4 * H) * nz + k;
+        const float v = *src;
+        swt[i] = rr < nrows ? v : 0.f;
     }
     __syncthreads();
     // weight gradients: (row, k) pairs dealt to the threads with k fastest

@@ -309,7 +309,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += in[(long)r * ld + c];
+    for (int r0 = 0; r0 < R; r0 += 16) {                 // 16 independent loads per round trip, added in row order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = in[(long)(r0 + u < R ? r0 + u : 0) * ld + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += r0 + u < R ? v[u] : 0.f;
+    }
     out[c] = s;
     if (out2) out2[c] = s;
 }
