@@ -263,27 +263,46 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
     // 4 rows per trip, their loads issued together (the trip count is data-dependent: the compiler will not batch on its own)
     const long stride = (long)nblk * RPB;
     for (long r = (long)blockIdx.x * RPB + rsub; r < P; r += 4 * stride) {
-        float4 xv[4], gv[4], yv[4];
+        float4 xv[4], gv[4], yv[4], g2[4], g3[4], g4[4];
+        long idx[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long rr = r + u * stride;
-            const long i = (rr < P ? rr : r) * C + 4 * c4;
-            xv[u] = *reinterpret_cast<const float4*>(x + i);
-            if (MODE == 1) {
-                gv[u] = *reinterpret_cast<const float4*>(dy + i);
-                if (dy2) {                    // the incoming gradient arrives as up to four summands (an activation with several
-                    const float4 g2 = *reinterpret_cast<const float4*>(dy2 + i);        // consumers), added in the order given
-                    gv[u].x += g2.x; gv[u].y += g2.y; gv[u].z += g2.z; gv[u].w += g2.w;
-                }
-                if (dy3) {
-                    const float4 g3 = *reinterpret_cast<const float4*>(dy3 + i);
-                    gv[u].x += g3.x; gv[u].y += g3.y; gv[u].z += g3.z; gv[u].w += g3.w;
-                }
-                if (dy4) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(dy4 + i);
-                    gv[u].x += g4.x; gv[u].y += g4.y; gv[u].z += g4.z; gv[u].w += g4.w;
-                }
-                if (act) yv[u] = *reinterpret_cast<const float4*>(y + i);
+            idx[u] = (rr < P ? rr : r) * C + 4 * c4;
+            xv[u] = *reinterpret_cast<const float4*>(x + idx[u]);
+            if (MODE == 1) gv[u] = *reinterpret_cast<const float4*>(dy + idx[u]);
+        }
+        if (MODE == 1) {
+            // The incoming gradient arrives as up to four summands (an activation with several consumers), added in the order
+            // given.  ALL loads of the trip are issued before the first addition: one uniform branch per summand around its four
+            // loads (a load and its `+=` inside a per-row `if (dy2)` made every summand of every row its own memory round trip).
+            if (dy2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g2[u] = *reinterpret_cast<const float4*>(dy2 + idx[u]);
+            }
+            if (dy3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g3[u] = *reinterpret_cast<const float4*>(dy3 + idx[u]);
+            }
+            if (dy4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g4[u] = *reinterpret_cast<const float4*>(dy4 + idx[u]);
+            }
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yv[u] = *reinterpret_cast<const float4*>(y + idx[u]);
+            }
+            if (dy2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { gv[u].x += g2[u].x; gv[u].y += g2[u].y; gv[u].z += g2[u].z; gv[u].w += g2[u].w; }
+            }
+            if (dy3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { gv[u].x += g3[u].x; gv[u].y += g3[u].y; gv[u].z += g3[u].z; gv[u].w += g3[u].w; }
+            }
+            if (dy4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { gv[u].x += g4[u].x; gv[u].y += g4[u].y; gv[u].z += g4[u].z; gv[u].w += g4[u].w; }
             }
         }
 #pragma unroll
@@ -349,12 +368,14 @@ __device__ __forceinline__ void bn_block_totals(const float* __restrict__ partia
     {
         float4 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int bb = b + u * nsub;
-            v[u] = bb < nblk ? p4[(long)bb * NF4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 16; ++u) {                 // unconditional loads from clamped indices (a load behind a condition is
+            const int bb = b + u * nsub;                // waited for right behind its issue: 16 round trips instead of one)
+            v[u] = p4[(long)(bb < nblk ? bb : 0) * NF4];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+        for (int u = 0; u < 16; ++u) {
+            if (b + u * nsub < nblk) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+        }
     }
     double* sc = scratch + (long)bsub * npair + 4 * pg;
     sc[0] = s0; sc[1] = s1; sc[2] = s2; sc[3] = s3;

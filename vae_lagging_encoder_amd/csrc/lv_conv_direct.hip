@@ -58,22 +58,28 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     const int n = (int)blockIdx.x / (IH / TRW), r0 = ((int)blockIdx.x % (IH / TRW)) * TRW;
     const int p = k / 2, HW = IW + 2 * p, HR = TRW + 2 * p;
     // stage rows r0-p .. r0+TRW-1+p, columns -p .. IW-1+p (zero outside the image): all of a thread's loads first (in flight
-    // together), then the LDS writes -- a load -> store loop would pay one memory round trip per iteration
+    // together), then the LDS writes -- a load -> store loop would pay one memory round trip per iteration.  The loads are
+    // UNCONDITIONAL, from coordinates clamped into the image, and what lies outside is zeroed by a select at the LDS write: a
+    // float4 loaded behind an `if` meets the zero in a phi, stops being one register tuple and is copied out right behind the
+    // load, i.e. `s_waitcnt vmcnt(0)` after every load (the first form of this loop: 17 such waits per workgroup).
     {
         float4 hv[HALO_F4];
+        uint32_t inside = 0u;
 #pragma unroll
         for (int u = 0; u < HALO_F4; ++u) {
             const int i = tid + 256 * u;
             const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
             const int gy = r0 - p + hy, gx = hx - p;
-            hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW)
-                hv[u] = *reinterpret_cast<const float4*>(in + (((long)n * IH + gy) * IW + gx) * CC + 4 * c4);
+            if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW) inside |= 1u << u;
+            const int cy = gy < 0 ? 0 : (gy < IH ? gy : IH - 1), cx = gx < 0 ? 0 : (gx < IW ? gx : IW - 1);
+            hv[u] = *reinterpret_cast<const float4*>(in + (((long)n * IH + cy) * IW + cx) * CC + 4 * c4);
         }
 #pragma unroll
         for (int u = 0; u < HALO_F4; ++u) {
             const int i = tid + 256 * u;
-            if (i < HR * HW * (CC / 4)) *reinterpret_cast<float4*>(&halo[(i / (CC / 4)) * PP + 4 * (i % (CC / 4))]) = hv[u];
+            const bool ok = (inside >> u) & 1u;
+            const float4 v = make_float4(ok ? hv[u].x : 0.f, ok ? hv[u].y : 0.f, ok ? hv[u].z : 0.f, ok ? hv[u].w : 0.f);
+            if (i < HR * HW * (CC / 4)) *reinterpret_cast<float4*>(&halo[(i / (CC / 4)) * PP + 4 * (i % (CC / 4))]) = v;
         }
     }
     __syncthreads();
@@ -423,16 +429,17 @@ __global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ 
     {
         float4 v[NF4];
 #pragma unroll
-        for (int u = 0; u < NF4; ++u) {
+        for (int u = 0; u < NF4; ++u) {                   // unconditional loads from a clamped pixel (see conv32_direct_kernel)
             const int i = tid + PWT * u;
             const int c4 = i % (CIN / 4), pp = i / (CIN / 4);
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + pp < P) v[u] = *reinterpret_cast<const float4*>(in + (p0 + pp) * CIN + 4 * c4);
+            v[u] = *reinterpret_cast<const float4*>(in + (p0 + pp < P ? p0 + pp : P - 1) * CIN + 4 * c4);
         }
 #pragma unroll
         for (int u = 0; u < NF4; ++u) {
             const int i = tid + PWT * u;
-            *reinterpret_cast<float4*>(&sa[(i / (CIN / 4)) * PA + 4 * (i % (CIN / 4))]) = v[u];
+            const bool ok = p0 + i / (CIN / 4) < P;
+            *reinterpret_cast<float4*>(&sa[(i / (CIN / 4)) * PA + 4 * (i % (CIN / 4))]) =
+                make_float4(ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, ok ? v[u].z : 0.f, ok ? v[u].w : 0.f);
         }
     }
     // sw[co][ci] = W[co][ci]  (w stored [COUT][CIN]), or W^T when the caller hands the [CIN][COUT] matrix of the forward
@@ -517,11 +524,22 @@ __global__ __launch_bounds__(512) void conv1x1_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < PW_U; ++u) {
             const long pp = p + 2 * u + kp;
-            const bool ok = pp < p1;
+            const long pc = pp < p1 ? pp : p1 - 1;         // unconditional loads from a clamped pixel; the tail is zeroed below
 #pragma unroll
-            for (int i = 0; i < NA; ++i) a[u][i] = ok ? dy[pp * COUT + 32 * i + cl] : 0.f;
+            for (int i = 0; i < NA; ++i) a[u][i] = dy[pc * COUT + 32 * i + cl];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) b[u][j] = ok ? x[pp * CIN + 32 * j + cl] : 0.f;
+            for (int j = 0; j < NB; ++j) b[u][j] = x[pc * CIN + 32 * j + cl];
+        }
+        if (p + 2 * PW_U > p1) {                           // ragged last batch only (uniform): pixels beyond the run count as zero
+#pragma unroll
+            for (int u = 0; u < PW_U; ++u) {
+                if (p + 2 * u + kp >= p1) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) a[u][i] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) b[u][j] = 0.f;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < PW_U; ++u)
@@ -574,11 +592,12 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
 #pragma unroll
     for (int u = 0; u < PW_PARTS_MAX / 32; ++u) {
         const int part = sub + 32 * u;
-        v[u] = part < parts ? *reinterpret_cast<const float4*>(dwp + (long)part * n + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = *reinterpret_cast<const float4*>(dwp + (long)(part < parts ? part : 0) * n + base);
     }
-    float4 s = v[0];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 1; u < PW_PARTS_MAX / 32; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    for (int u = 0; u < PW_PARTS_MAX / 32; ++u)
+        if (sub + 32 * u < parts) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     *reinterpret_cast<float4*>(&sred[sub][4 * f4]) = s;
     __syncthreads();
     if (tid < 32) {
@@ -679,11 +698,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WgradBatch bt
 #pragma unroll
     for (int u = 0; u < PW_PARTS_MAX / 32; ++u) {
         const int part = sub + 32 * u;
-        v[u] = part < d.parts ? *reinterpret_cast<const float4*>(d.part + (long)part * d.n + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = *reinterpret_cast<const float4*>(d.part + (long)(part < d.parts ? part : 0) * d.n + base);
     }
-    float4 s = v[0];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 1; u < PW_PARTS_MAX / 32; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    for (int u = 0; u < PW_PARTS_MAX / 32; ++u)
+        if (sub + 32 * u < d.parts) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     *reinterpret_cast<float4*>(&sred[sub][4 * f4]) = s;
     __syncthreads();
     if (tid < 32) {

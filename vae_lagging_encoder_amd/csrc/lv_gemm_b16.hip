@@ -374,7 +374,18 @@ __device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, 
             for (int e = 0; e < 16; ++e) ad[e] = p.add1[(long)lv_wrap_row(q1, (e & 3) + 8 * (e >> 2), p.mod1) * p.ld1 + col];
         }
     }
-    const int q2 = p.add2 ? rbase % p.mod2 : 0;
+    // The second addend (the decoder's z projection: every Gx of the decoder) is gathered like the first one -- 16 loads issued
+    // together -- and INTO the same registers (ad = add1 + add2): loaded in place behind `if (rbase + ro < M)` each one was its own
+    // memory round trip (Gx with the z addend: 61 us against 43 us plain), while 16 more live registers cost the 128 x 128 kernel
+    // its occupancy (all of its GEMMs 40-55 % slower: measured).
+    if (p.add2) {
+        const int q2 = rbase % p.mod2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t2 = p.add2[(long)lv_wrap_row(q2, (e & 3) + 8 * (e >> 2), p.mod2) * p.ld2 + col];
+            ad[e] = p.add1 ? ad[e] + t2 : t2;
+        }
+    }
     float* cb = p.C + (long)rbase * p.ldc + col;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -382,8 +393,7 @@ __device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, 
         if (rbase + ro >= p.M) continue;
         float* c = cb + (long)ro * p.ldc;
         float v = p.alpha * a[e];
-        if (p.add1) v += ad[e];
-        if (p.add2) v += p.add2[(long)lv_wrap_row(q2, ro, p.mod2) * p.ld2 + col];     // second addend: rare, loaded in place
+        if (p.add1 || p.add2) v += ad[e];
         if (p.accumulate) v += *c;
         *c = v;
     }
@@ -1011,13 +1021,31 @@ __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 
     }
 }
 
+template <int NF>
+__device__ __forceinline__ float sum_pieces(const float* first, long stride, int n) {
+    float s = 0.f;
+    for (int k0 = 0; k0 < n; k0 += NF) {
+        float pv[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) pv[u] = first[(long)(k0 + u < n ? k0 + u : 0) * stride];      // clamped: the surplus is never added
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+            if (k0 + u < n) s += pv[u];
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long MN = (long)p.M * p.N;
     if (idx >= MN) return;
     const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+    // the pieces in flight together (2, 4 or 8 at a time by the split count), added in piece order: one load -> add per iteration
+    // was one memory round trip per piece
     float s = 0.f;
-    for (int k = 0; k < p.splits; ++k) s += p.ws[(long)k * MN + idx];
+    if (p.splits <= 2) s = sum_pieces<2>(p.ws + idx, MN, p.splits);
+    else if (p.splits <= 4) s = sum_pieces<4>(p.ws + idx, MN, p.splits);
+    else s = sum_pieces<8>(p.ws + idx, MN, p.splits);
     float v = p.alpha * s;
     if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
     if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];

@@ -194,6 +194,24 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
             if (col >= p.N) continue;
             const int rbase = m0 + wm * 32 * WT + i * 32 + 4 * (l >> 5);
             const int q1 = p.add1 ? rbase % p.mod1 : 0, q2 = p.add2 ? rbase % p.mod2 : 0;
+            // addends and the old C of an accumulating call: the 16 loads of each kind issued together (rows clamped into the
+            // matrix), then the arithmetic -- loaded in place behind `if (row < M)` every one of them was its own memory round trip
+            float a1[16], a2[16], co[16];
+            if (!split && p.add1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a1[e] = p.add1[(long)lv_wrap_row(q1, (e & 3) + 8 * (e >> 2), p.mod1) * p.ld1 + col];
+            }
+            if (!split && p.add2) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a2[e] = p.add2[(long)lv_wrap_row(q2, (e & 3) + 8 * (e >> 2), p.mod2) * p.ld2 + col];
+            }
+            if (!split && p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rbase + (e & 3) + 8 * (e >> 2);
+                    co[e] = p.C[(long)(row < p.M ? row : p.M - 1) * p.ldc + col];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ro = (e & 3) + 8 * (e >> 2);
@@ -202,12 +220,26 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
                 float* c = out + (long)row * ldo + col;
                 if (split) { *c = acc[i][j][e]; continue; }
                 float v = p.alpha * acc[i][j][e];
-                if (p.add1) v += p.add1[(long)lv_wrap_row(q1, ro, p.mod1) * p.ld1 + col];
-                if (p.add2) v += p.add2[(long)lv_wrap_row(q2, ro, p.mod2) * p.ld2 + col];
-                if (p.accumulate) v += *c;
+                if (p.add1) v += a1[e];
+                if (p.add2) v += a2[e];
+                if (p.accumulate) v += co[e];
                 *c = v;
             }
         }
+}
+
+template <int NF>
+__device__ __forceinline__ float sum_pieces(const float* first, long stride, int n) {
+    float s = 0.f;
+    for (int k0 = 0; k0 < n; k0 += NF) {
+        float pv[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) pv[u] = first[(long)(k0 + u < n ? k0 + u : 0) * stride];      // clamped: the surplus is never added
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+            if (k0 + u < n) s += pv[u];
+    }
+    return s;
 }
 
 // C = alpha * sum_s ws[s] (+ addends) (+ C): fixed summation order -> deterministic
@@ -216,8 +248,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p) {
     const long MN = (long)p.M * p.N;
     if (idx >= MN) return;
     const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+    // the pieces in flight together (2, 4 or 8 at a time by the split count), added in piece order
     float s = 0.f;
-    for (int k = 0; k < p.splits; ++k) s += p.ws[(long)k * MN + idx];
+    if (p.splits <= 2) s = sum_pieces<2>(p.ws + idx, MN, p.splits);
+    else if (p.splits <= 4) s = sum_pieces<4>(p.ws + idx, MN, p.splits);
+    else s = sum_pieces<8>(p.ws + idx, MN, p.splits);
     float v = p.alpha * s;
     if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
     if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
