@@ -181,22 +181,56 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
     const int tok = toks[p];
     if (p > 0 && toks[p - 1] == tok) return;   // not a segment head
     if (tok == pad_idx) return;
+    // end of the segment [p, e): the next eight positions in one batch of loads (most tokens occur once or twice); a longer run is
+    // finished by a binary search of the sorted list.  The segment used to be walked as `for (q = p; toks[q] == tok; ++q)` with the
+    // row id and the gradient row loaded inside: three dependent memory round trips per occurrence -- 2 us each for a token that
+    // occurs a few hundred times in a batch of natural text (a Zipf head), with the whole launch waiting for that one workgroup.
+    int e = p + 1;
+    {
+        int nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nx[u] = toks[p + 1 + u < N ? p + 1 + u : N - 1];
+        bool run = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            run = run && p + 1 + u < N && nx[u] == tok;
+            if (run) e = p + 2 + u;
+        }
+        if (run && e < N) {                      // all eight equal: e = first position past p + 8 whose token differs
+            int lo = e, hi = N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] == tok) lo = mid + 1; else hi = mid; }
+            e = lo;
+        }
+    }
     float* dst = dE + (long)tok * ni;
     if (vec) {
         for (int k = tid * 4; k < ni; k += 512) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q = p; q < N && toks[q] == tok; ++q) {
-                const int r = rows[q];
-                float4 v = *reinterpret_cast<const float4*>(dX + (long)r * ni + k);
+            for (int q0 = p; q0 < e; q0 += 8) {  // eight occurrences at a time: row ids, gradient rows, mask bytes -- each stage in one batch
+                int r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = rows[q0 + u < e ? q0 + u : e - 1];
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dX + (long)r[u] * ni + k);
                 if (mask) {
-                    const int t = r / B, b = r % B;
-                    const uint8_t* m = mask + ((long)b * T + t) * ni + k;
-                    v.x = m[0] ? v.x * scale : 0.f;
-                    v.y = m[1] ? v.y * scale : 0.f;
-                    v.z = m[2] ? v.z * scale : 0.f;
-                    v.w = m[3] ? v.w * scale : 0.f;
+                    uint32_t mk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = r[u] / B, b = r[u] % B;
+                        mk[u] = *reinterpret_cast<const uint32_t*>(mask + ((long)b * T + t) * ni + k);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[u].x = (mk[u] & 0xFFu) ? v[u].x * scale : 0.f;
+                        v[u].y = (mk[u] & 0xFF00u) ? v[u].y * scale : 0.f;
+                        v[u].z = (mk[u] & 0xFF0000u) ? v[u].z * scale : 0.f;
+                        v[u].w = (mk[u] & 0xFF000000u) ? v[u].w * scale : 0.f;
+                    }
                 }
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (q0 + u < e) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
             }
             float4* d4 = reinterpret_cast<float4*>(dst + k);
             if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
@@ -205,7 +239,7 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
     } else {
         for (int k = tid; k < ni; k += 128) {
             float acc = 0.f;
-            for (int q = p; q < N && toks[q] == tok; ++q) {
+            for (int q = p; q < e; ++q) {
                 const int r = rows[q];
                 float v = dX[(long)r * ni + k];
                 if (mask) {
@@ -255,7 +289,7 @@ extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float 
     if (!dX || !sorted_rows || !sorted_tok || !dE) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || ni <= 0) return LV_ERR_SHAPE;
     if (T == 0) return LV_OK;
-    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0;
+    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
     LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
               N, B, T, dE, ni, pad_idx, accumulate, vec, 0);
@@ -270,7 +304,7 @@ extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, f
                                          float* dE, int ni, int V, int pad_idx, void* stream) {
     if (!dX || !sorted_rows || !sorted_tok || !dE) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
-    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0;
+    const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
     LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
               N, B, T, dE, ni, pad_idx, 0, vec, V);

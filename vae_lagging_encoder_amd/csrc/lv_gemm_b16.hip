@@ -1076,34 +1076,57 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
     const bool tb = keep || gids;
     const int Tt = tb ? R / Bsz : 1;
     int bb = tb ? (r0 + q) % Bsz : 0, tt = tb ? (r0 + q) / Bsz : 0;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int r = q + 4 * i;
-        const int gr = r0 + r, gc = c0 + lane;
-        uint16_t b = 0;
-        if (gr < R && gc < C) {
-            long sr = gr;
-            if (gids) {
-                sr = gids[(long)bb * gstride + tt];
-                sr = sr < 0 ? 0 : (sr >= gV ? gV - 1 : sr);
+    // Eight rows at a time, every stage of their loads issued together (row index of a gathered source, the source element, the
+    // keep byte), from addresses CLAMPED into the matrix; the stores are predicated afterwards.  The first form loaded inside
+    // `if (gr < R && gc < C)`: a thread's 16 rows were 16 (gathered: 32) dependent memory round trips, and with one round of
+    // workgroups on the chip that chain WAS the kernel's duration (17 us for 52 MB).
+    const int gc = c0 + lane, gcc = gc < C ? gc : C - 1;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+        int grs[8], bbs[8], tts[8];
+        long sr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            grs[u] = r0 + q + 4 * (i0 + u);
+            bbs[u] = bb; tts[u] = tt;
+            if (tb) {
+                bb += 4;
+                while (bb >= Bsz) { bb -= Bsz; ++tt; }
             }
-            float v = src[sr * lds_ + gc];
-            if (keep) {
-                const bool kp = keep[((long)bb * Tt + tt) * C + gc] != 0;
-                if (gids) v = kp ? v * kscale : 0.f;        // as lv_embed_gather_f32 writes it (+0 for a dropped element)
-                else v *= kp ? kscale : 0.f;                // as h * (keep * scale) rounds (a dropped negative element is -0)
-            }
-            b = (uint16_t)lv_f32_to_bf16_bits(v);
-            if (dst) {
-                const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
-                dst[dr * ldd + gc] = b;
-            }
+            sr[u] = grs[u] < R ? grs[u] : R - 1;
         }
-        if (tb) {
-            bb += 4;
-            while (bb >= Bsz) { bb -= Bsz; ++tt; }
+        if (gids) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sr[u] = gids[(long)bbs[u] * gstride + (grs[u] < R ? tts[u] : 0)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sr[u] = sr[u] < 0 ? 0 : (sr[u] >= gV ? gV - 1 : sr[u]);
         }
-        tile[r][lane] = b;
+        float v[8];
+        uint8_t kp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[sr[u] * lds_ + gcc];
+        if (keep) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kp[u] = keep[((long)bbs[u] * Tt + (grs[u] < R ? tts[u] : 0)) * C + gcc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int gr = grs[u];
+            uint16_t b = 0;
+            if (gr < R && gc < C) {
+                float x = v[u];
+                if (keep) {
+                    if (gids) x = kp[u] ? x * kscale : 0.f;      // as lv_embed_gather_f32 writes it (+0 for a dropped element)
+                    else x *= kp[u] ? kscale : 0.f;              // as h * (keep * scale) rounds (a dropped negative element is -0)
+                }
+                b = (uint16_t)lv_f32_to_bf16_bits(x);
+                if (dst) {
+                    const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
+                    dst[dr * ldd + gc] = b;
+                }
+            }
+            tile[q + 4 * (i0 + u)][lane] = b;
+        }
     }
     if (!dstT) return;
     __syncthreads();

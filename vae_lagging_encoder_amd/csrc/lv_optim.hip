@@ -188,6 +188,23 @@ __global__ __launch_bounds__(256) void keep_scale_kernel(float* __restrict__ x, 
     x[i] *= keep[((r % Bsz) * (long)T + r / Bsz) * C + c] ? kscale : 0.f;
 }
 
+// four consecutive columns per thread (C % 4 == 0, 16-byte aligned x, 4-byte aligned keep): one float4, four keep bytes in one
+// load, one row division per four elements -- the scalar form above spends its time on a 64-bit division per element
+__global__ __launch_bounds__(256) void keep_scale_v4_kernel(float* __restrict__ x, const uint8_t* __restrict__ keep, float kscale, int T,
+                                                            int Bsz, int C4, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int r = (int)(i / C4), c4 = (int)(i - (long)r * C4);
+    const int t = r / Bsz, b = r - t * Bsz;
+    const uint32_t k = *reinterpret_cast<const uint32_t*>(keep + ((long)b * T + t) * (4L * C4) + 4 * c4);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x *= (k & 0xFFu) ? kscale : 0.f;
+    v.y *= (k & 0xFF00u) ? kscale : 0.f;
+    v.z *= (k & 0xFF0000u) ? kscale : 0.f;
+    v.w *= (k & 0xFF000000u) ? kscale : 0.f;
+    reinterpret_cast<float4*>(x)[i] = v;
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef) {
     const float c = coef[0];
     if (c == 1.0f) return;            // clip inactive (coef is exactly 1): x * 1 is x bit for bit, skip the pass
@@ -282,7 +299,10 @@ extern "C" int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, in
     if (T < 0 || Bsz <= 0 || C <= 0) return LV_ERR_SHAPE;
     const long n = (long)T * Bsz * C;
     if (n == 0) return LV_OK;
-    LV_LAUNCH(keep_scale_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, x, keep, kscale, T, Bsz, C, n);
+    if (C % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)keep) & 3) == 0 && (long)T * Bsz < (1L << 31))
+        LV_LAUNCH(keep_scale_v4_kernel, dim3((unsigned)lv_cdiv(n / 4, 256)), dim3(256), 0, stream, x, keep, kscale, T, Bsz, C / 4, n / 4);
+    else
+        LV_LAUNCH(keep_scale_kernel, dim3((unsigned)lv_cdiv(n, 256)), dim3(256), 0, stream, x, keep, kscale, T, Bsz, C, n);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
