@@ -620,7 +620,7 @@ def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):
 
 
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),
-                                              (200, 128, 64, 300, True)])
+                                              (200, 128, 64, 300, True), (50, 32, 512, 40, True), (9, 8, 512, 3, False)])
 def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):
     dev = hip_device
     g = torch.Generator().manual_seed(T + B + ni)

@@ -157,14 +157,21 @@ __global__ __launch_bounds__(SORT_THREADS) void token_sort_kernel(const int64_t*
     }
 }
 
-__global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
+#ifndef LV_SC_PARTS
+#define LV_SC_PARTS 2
+#endif
+// (profiles/microbench/embed_scatter_zipf.py, us per scatter at the Yahoo shape, uniform ids / Zipf(1) ids whose most frequent token
+//  occurs 628 times: 1 group 24.9 / 72.3, 2 groups 30.9 / 44.0, 4 groups 43.5 / 35.7 -- every position's workgroup carries the groups)
+constexpr int SC_PARTS = LV_SC_PARTS;       // thread groups of a workgroup that share one token's occurrences (8 at a time each)
+__global__ __launch_bounds__(128 * SC_PARTS) void embed_scatter_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
                                                             float scale, const int* __restrict__ rows,
                                                             const int* __restrict__ toks, int N, int B, int T,
                                                             float* __restrict__ dE, int ni, int pad_idx, int accumulate,
                                                             int vec, int V) {
+    __shared__ __attribute__((aligned(16))) float part_sum[SC_PARTS > 1 ? SC_PARTS - 1 : 1][512];
     const int p = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x;
-    if (V > 0) {
+    const int tid = (int)threadIdx.x & 127, grp = (int)threadIdx.x >> 7;      // column thread, occurrence group
+    if (V > 0 && grp == 0) {
         // complete form: every row of dE is written exactly once by this launch -- the rows of tokens that occur by their segment
         // heads below, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
         // binary search of the sorted token list per row).  Replaces a separate fill of the whole table (41 MB at V = 20001).
@@ -203,10 +210,16 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
         }
     }
     float* dst = dE + (long)tok * ni;
+    // ni == 512 (one float4 column group per thread): the occurrences are dealt to the SC_PARTS thread groups in batches of eight
+    // (group g takes batches g, g + SC_PARTS, ...), and the groups' sums are added in group order through LDS -- a fixed order, so the
+    // result is deterministic; a token that occurs a few hundred times (the head of a Zipf distribution) no longer makes the
+    // launch wait for one 128-thread walk over all of its occurrences.  Other widths: group 0 alone, in occurrence order.
+    const bool split = vec && ni == 512;
+    if (!split && grp != 0) return;
     if (vec) {
         for (int k = tid * 4; k < ni; k += 512) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q0 = p; q0 < e; q0 += 8) {  // eight occurrences at a time: row ids, gradient rows, mask bytes -- each stage in one batch
+            for (int q0 = p + (split ? 8 * grp : 0); q0 < e; q0 += (split ? 8 * SC_PARTS : 8)) {  // eight occurrences at a time: row ids, gradient rows, mask bytes -- each stage in one batch
                 int r[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) r[u] = rows[q0 + u < e ? q0 + u : e - 1];
@@ -231,6 +244,20 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (q0 + u < e) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            if (split) {
+                if (e - p > 8) {                  // (a token with at most eight occurrences is group 0's alone: nothing to add)
+                    if (grp > 0) *reinterpret_cast<float4*>(&part_sum[grp - 1][k]) = acc;
+                    __syncthreads();
+                    if (grp == 0) {
+#pragma unroll
+                        for (int g = 0; g < SC_PARTS - 1; ++g) {
+                            const float4 o = *reinterpret_cast<const float4*>(&part_sum[g][k]);
+                            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                        }
+                    }
+                }
+                if (grp != 0) return;
             }
             float4* d4 = reinterpret_cast<float4*>(dst + k);
             if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
@@ -291,7 +318,7 @@ extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float 
     if (T == 0) return LV_OK;
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
-    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128 * SC_PARTS), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
               N, B, T, dE, ni, pad_idx, accumulate, vec, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -306,7 +333,7 @@ extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, f
     if (T <= 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
-    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128 * SC_PARTS), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
               N, B, T, dE, ni, pad_idx, 0, vec, V);
     LV_CHECK_LAUNCH();
     return LV_OK;
