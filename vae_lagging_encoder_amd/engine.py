@@ -434,6 +434,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
     """The forward recurrence of one LSTM layer: exact f32, bf16 launch-per-step, or (bf16 image path on a >= 256-CU
     device, H = 1024, B <= 64) the single persistent launch of lv_lstm_persist.hip."""
     args = (Gx, whh, P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop)
+    w.saved_layout = ("canonical", T, B, 0)
     if eng.precision != "bf16":
         lib.lv_lstm_fwd_f32(*args, P(w.lstm_ws), T, B, H, s)
     elif img is None:
@@ -448,6 +449,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
             if w.gates.numel() < need:              # eng.persist_rows changed after the workspace was built
                 w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
             lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, PERSIST16_FLAGS, H, s)
+            w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
         else:
             fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
             fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
@@ -468,6 +470,14 @@ def check_persistent_status(eng):
                              "group's workgroups were not placed on one XCD (set it to 0 to write the granules through)" % int(st.item()))
 
 
+def _need_canonical_saved(w):
+    lay = getattr(w, "saved_layout", None)
+    if lay is not None and lay[0] != "canonical":
+        raise _lib.LvaeError("the saved activations are in the 16-row persistent kernels' own order %r, but the backward was routed to a "
+                             "kernel that reads gates [T][B][4H] / cs: eng.persistent / eng.persist_rows changed between forward and "
+                             "backward" % (lay,))
+
+
 def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, dc0, tanh_init, T, B, H, device):
     """BPTT of one LSTM layer: exact f32, bf16 two launches per step, or the single persistent launch where supported."""
     if eng.precision != "bf16":
@@ -482,13 +492,18 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
         if use16:
             if mask is not None:
                 raise _lib.LvaeError("the 16-row persistent BPTT has no in-kernel dropout mask (the engine applies it on dO)")
+            if getattr(w, "saved_layout", None) != ("persist16", T, B, rows):
+                raise _lib.LvaeError("the saved activations were not written by a 16-row persistent forward with the same T, B and rows per "
+                                     "group (%r): eng.persist_rows / eng.persistent changed between forward and backward" % (getattr(w, "saved_layout", None),))
             lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
                                            P(wi.status), dh0, dc0, tanh_init, T, B, rows, PERSIST16_FLAGS, H, s)
         else:
+            _need_canonical_saved(w)
             fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
             fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
                dh0, dc0, tanh_init, T, B, H, s)
     else:
+        _need_canonical_saved(w)
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
                                  P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
 
