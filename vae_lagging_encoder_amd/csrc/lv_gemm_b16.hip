@@ -18,7 +18,14 @@
 // loads 16 B (eight adjacent rows at one k) for 4 consecutive k and transposes the 8x4 block in registers (16 integer
 // ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
 // consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
+#if defined(LV_TRACE)
+#define lv_trace_buf lv_trace_buf_gemm      // (one trace pointer per translation unit: device code is not relocatable)
+#endif
 #include "lv_device.h"
+#if defined(LV_TRACE) && !defined(LV_EMU)
+__device__ unsigned long long* lv_trace_buf = nullptr;
+extern "C" int lv_trace_set_gemm(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lv_trace_buf), &p, sizeof(p)); }
+#endif
 #include <type_traits>
 
 namespace {
@@ -825,8 +832,10 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     // k-step ks + 1 are requested BEFORE the 8 MFMAs of k-step ks (left alone the compiler reads each fragment group right before
     // its MFMAs and waits out the LDS latency eight times per tile), and the tile's 8 DMA instructions go out two per k-step BETWEEN
     // the MFMAs (an LDS-DMA instruction costs 60-180 issue cycles; at the top of the tile they would all run with the pipe empty).
+    LV_TRACE_ONLY(int tr_kt = 0;)
     auto mma_tile = [&](auto staging, LdsTile2& Ac, LdsTile2& Bc, int kt_next, LdsTile2& Ad, LdsTile2& Bd) {
         constexpr bool STAGE = decltype(staging)::value;
+        LV_TRACE_MARK(tr_kt, 0);
         uint4 fa[2][4], fb[2][2];
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) fa[0][i2] = a_frag(Ac, 0, i2);
@@ -864,8 +873,12 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
                 for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
             LV_SCHED_BARRIER();
         }
+        LV_TRACE_MARK(tr_kt, 1);
         if constexpr (STAGE) LV_WAIT_VMEM();
+        LV_TRACE_MARK(tr_kt, 2);
         __syncthreads();
+        LV_TRACE_MARK(tr_kt, 3);
+        LV_TRACE_ONLY(++tr_kt;)
     };
 
     // The ragged tile at the end of a K that is not a multiple of 64 goes FIRST (masked loads through registers while the
