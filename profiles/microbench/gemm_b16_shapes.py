@@ -5,7 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from vae_lagging_encoder_amd import _lib
 from vae_lagging_encoder_amd.engine import P, stream_ptr
 dev = torch.device("cuda:0")
-lib = _lib.load()
+if os.environ.get("LVAE_PROBE_LIB"):            # an alternative build of the kernel library (a measurement knob compiled in)
+    import ctypes
+    lib = _lib.bind(ctypes.CDLL(os.environ["LVAE_PROBE_LIB"]), os.environ["LVAE_PROBE_LIB"])
+else:
+    lib = _lib.load()
 B, T, V, H = 32, 200, 20001, 1024
 Td = T - 1
 R = Td * B

@@ -18,6 +18,9 @@
 // loads 16 B (eight adjacent rows at one k) for 4 consecutive k and transposes the 8x4 block in registers (16 integer
 // ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
 // consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
+#ifndef LV_B16_T256_DMA
+#define LV_B16_T256_DMA 1
+#endif
 #if defined(LV_TRACE)
 #define lv_trace_buf lv_trace_buf_gemm      // (one trace pointer per translation unit: device code is not relocatable)
 #endif
@@ -865,7 +868,21 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
                 for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
             }
 #endif
+            // the next tile's 8 DMA instructions: two UNITS (4 instructions) behind each of the first two k-steps' first MFMA groups, so
+            // that the last of them has half a tile of MFMAs to land under (one unit per k-step left the last pair ~600 cycles short
+            // at the end-of-tile vmcnt(0): 8192^3 1090 -> 1185 TF, dW_pred 290 -> 276 us, dO 307 -> 300; all four units at the top, or
+            // 1-2-1, measured worse: profiles/microbench/gemm_b16_shapes.py with -DLV_B16_T256_DMA=0/2/3/4)
+#if LV_B16_T256_DMA == 1
+            if constexpr (STAGE) { if (ks < 2) { stage_unit(kt_next, 2 * ks, Ad, Bd); stage_unit(kt_next, 2 * ks + 1, Ad, Bd); } }
+#elif LV_B16_T256_DMA == 2
+            if constexpr (STAGE) { if (ks == 0) { stage_unit(kt_next, 0, Ad, Bd); stage_unit(kt_next, 1, Ad, Bd); } else if (ks < 3) stage_unit(kt_next, ks + 1, Ad, Bd); }
+#elif LV_B16_T256_DMA == 3
+            if constexpr (STAGE) { if (ks == 0) { stage_unit(kt_next, 0, Ad, Bd); stage_unit(kt_next, 1, Ad, Bd); stage_unit(kt_next, 2, Ad, Bd); } else if (ks == 1) stage_unit(kt_next, 3, Ad, Bd); }
+#elif LV_B16_T256_DMA == 4
+            if constexpr (STAGE) { if (ks == 0) stage_unit(kt_next, 0, Ad, Bd); else if (ks == 1) { stage_unit(kt_next, 1, Ad, Bd); stage_unit(kt_next, 2, Ad, Bd); } else if (ks == 2) stage_unit(kt_next, 3, Ad, Bd); }
+#else
             if constexpr (STAGE) stage_unit(kt_next, ks, Ad, Bd);
+#endif
             LV_SCHED_BARRIER();
 #pragma unroll
             for (int i = 2; i < 4; ++i)
