@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
 }
 
 #ifndef LV_B16_T256_ORDER
-#define LV_B16_T256_ORDER 0   // 256 x 256 kernel: fragments of k-step ks+1 requested before (0) / in the middle of (1) the MFMAs of k-step ks
+#define LV_B16_T256_ORDER 1   // 256 x 256 kernel: fragments of k-step ks+1 requested before (0) / in the middle of (1) the MFMAs of k-step ks
+                              // (1 since the DMA moved into the first half of the tile: logits 310 -> 298 us, dO 304 -> 295, fused NLL 325 -> 317;
+                              //  DMA ahead of the fragment reads, or one unit behind each MFMA group, measured the same)
 #endif
 #ifndef LV_B16_SINGLE_WAVES
 #define LV_B16_SINGLE_WAVES 4   // single-buffer 128 x 128 kernel: waves per SIMD its register budget is cut to (0 = unconstrained: 161 registers, 3 workgroups per CU; 4: 123-128 registers, 4 per CU -- the 1600-tile input projection then needs two rounds instead of three: 47-53 -> 43 us)
