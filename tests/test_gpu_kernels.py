@@ -495,7 +495,7 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
 
 
-@pytest.mark.parametrize("kernels", ["16row", "4row"])
+@pytest.mark.parametrize("kernels", ["16row", "16row_B64_R8", "16row_B128_R16", "4row"])
 def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels):
     """Both persistent recurrences (the default kernels of lv_lstm_persist16.hip with their hand-off in the XCD's L2, and the
     4-row kernels of lv_lstm_persist.hip) at the length the metric is quoted on (T = 200, B = 32, H = 1024) against the
@@ -503,7 +503,10 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
     in f32 summation order (and in what a flipped bf16 rounding moves downstream), so they must stay within 1e-3 of each other
     over all 200 steps -- a per-kernel check that localises a regression the end-to-end Yahoo fixture test would only see as a
     loss delta.  Weights at 3x the reference's init scale (U(-0.03, 0.03): a contractive recurrence, like the fixtures)."""
-    dev, H, T, B = hip_device, 1024, 200, 32
+    dev, H, T, B, R16 = hip_device, 1024, 200, 32, 4
+    if kernels.startswith("16row_"):             # the 8- and 16-row instantiations at their own batch sizes (B = 128: the stress shape)
+        B, R16 = int(kernels.split("_")[1][1:]), int(kernels.split("_")[2][1:])
+        T, kernels = 120, "16row"
     g = torch.Generator().manual_seed(20001)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) * 0.03).to(dev)
@@ -522,11 +525,11 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
             wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
             xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, 4), device=dev)
+            saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, R16), device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
-            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(xch), P(status), T, B, 4, 1, H, _s(dev))
+            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(xch), P(status), T, B, R16, 1, H, _s(dev))
             assert int(status.item()) == 0
-            gates, c_t = _saved16_unpack(saved, T, B, 4)
+            gates, c_t = _saved16_unpack(saved, T, B, R16)
             cs[1:] = c_t
         elif persistent:
             wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
@@ -554,8 +557,8 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
             xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
-            lib.lv_lstm_bwd_bf16_persist16(P(wext), None, P(wpk), P(_saved16_pack(lib, gates.view(T, B, 4 * H), cs, 4)), P(hs), P(cs), P(dG16),
-                                           P(dGsum), P(xch), P(status), None, P(dc0), 1, T, B, 4, 1, H, _s(dev))
+            lib.lv_lstm_bwd_bf16_persist16(P(wext), None, P(wpk), P(_saved16_pack(lib, gates.view(T, B, 4 * H), cs, R16)), P(hs), P(cs), P(dG16),
+                                           P(dGsum), P(xch), P(status), None, P(dc0), 1, T, B, R16, 1, H, _s(dev))
             assert int(status.item()) == 0
         elif persistent:
             wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)

@@ -30,6 +30,10 @@ static inline int lv_device_cus() { return 1 << 20; }
 #define LV_SPIN_LIMIT (1 << 15)             // polls per wait before a hand-off is reported lost (a poll = one scheduling round here)
 static inline f32x16 lv_mfma_32x32x16_bf16(uint4 a, uint4 b, f32x16 c) { return lv_emu_mfma_32x32x16_bf16(a, b, c); }
 static inline f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
+static inline f32x4 lv_mfma_16x16x32_bf16_areg(uint4 a, uint4 b, f32x4 c) { return lv_emu_mfma_16x16x32_bf16(a, b, c); }
+static inline f32x4 lv_mfma_16x16x32_bf16_areg_first(uint4 a, uint4 b) { return lv_emu_mfma_16x16x32_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f}); }
+#define LV_MFMA_DRAIN() do { } while (0)
+static inline void LV_MFMA_RESULT(f32x4&) { }
 static inline f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) { return lv_emu_mfma_4x4x4_16b_bf16(a, b, c); }
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
@@ -173,6 +177,32 @@ __device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<lv_bf16x8*>(&a), *reinterpret_cast<lv_bf16x8*>(&b),
                                                    c, 0, 0, 0);
 }
+// The same instruction with its A operand READ FROM THE ACCUMULATION REGISTERS (gfx90a+: srcA / srcB of an MFMA may be AGPRs).  For
+// operands that stay resident for a whole kernel and fill half of the 512 registers (W_hh of the persistent LSTM kernels): the
+// register allocator otherwise keeps such values in AGPRs as SPILL slots and copies them back (4 x v_accvgpr_read per MFMA, as
+// many VALU cycles as the MFMA's own pipe time).  Inline assembly, so the compiler's MFMA hazard handling does not see it: the
+// caller puts LV_MFMA_DRAIN() between the last of these and the first instruction that reads an accumulator (an 8-pass XDL
+// write needs 11 wait states before a VALU / LDS / VMEM read of its destination).
+typedef unsigned int lv_u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16_areg(uint4 a, uint4 b, f32x4 c) {
+    const lv_u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(av), "v"(bv));
+    return c;
+}
+// first product of an accumulation chain: C = 0 as an inline constant (no zeroing v_mov in front of an instruction the compiler
+// does not know to be an MFMA)
+__device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16_areg_first(uint4 a, uint4 b) {
+    const lv_u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    f32x4 c;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "a"(av), "v"(bv));
+    return c;
+}
+#define LV_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+// ... and passes every accumulator it is about to read through LV_MFMA_RESULT() BEHIND that point in program order: volatile asm
+// statements keep their order, ordinary instructions that merely depend on an asm's output do not -- without this the scheduler is
+// free to hoist a read of acc right behind the MFMA that writes it (no interlock: the read returns a half-written accumulator;
+// the first build of the BPTT did exactly that, 2 % rms error after 200 timesteps).
+__device__ __forceinline__ void LV_MFMA_RESULT(f32x4& c) { asm volatile("" : "+v"(c)); }
 // v_mfma_f32_4x4x4_16b_bf16: 16 independent 4 x 4 x 4 products.  Lane l belongs to block l >> 2; a = 4 bf16 (k = 0..3) of A row
 // (l & 3), b = 4 bf16 of B column (l & 3); D[row r][col l & 3] of the block in register r.  2 passes: for a 4-row A it does the
 // useful work of a 16x16x32 MFMA (whose other 12 rows would be padding) in half the matrix-pipe time.
@@ -298,7 +328,9 @@ __device__ __forceinline__ float lv_sigmoid(float x) { return 1.0f / (1.0f + exp
 __device__ __forceinline__ float lv_sigmoid_fast(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float lv_exp_fast(float x) { return expf(x); }
 #else
-__device__ __forceinline__ float lv_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// (v_rcp_f32 through the builtin: __frcp_rn is the correctly rounded reciprocal and expands to the full division sequence --
+//  v_div_scale / v_rcp / 4 x fma / v_div_fmas / v_div_fixup, ~10 VALU instructions per activation in the recurrences' epilogue)
+__device__ __forceinline__ float lv_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // hardware exp2 (v_exp_f32), ~2 ulp: for values that are rounded to bf16 right afterwards
 __device__ __forceinline__ float lv_exp_fast(float x) { return __expf(x); }
 #endif

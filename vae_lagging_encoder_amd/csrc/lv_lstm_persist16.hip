@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
         if (own[q] && even) put(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
     }
 
-    float4 gxb[NP][SBK], recb[NP][SBK];
+    float4 gxb[NP][SBK];
+    f32x4 recb[NP][SBK];
     float cb[NP][SBK], hb[NP][SBK];
     auto load_slots = [&](int tb, int lo, int hi) {          // gx of steps tb + [lo, hi) into their slots
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             for (int s2 = 0; s2 < SBK; ++s2) {
                 const int t = tb + s2;
                 if (own[q] && t < T) {
-                    lv_store_nt(f32x4{recb[q][s2].x, recb[q][s2].y, recb[q][s2].z, recb[q][s2].w},
+                    lv_store_nt(recb[q][s2],
                                 reinterpret_cast<f32x4*>(sv + (long)t * rec + sg[q]));
                     lv_store_nt(cb[q][s2], sv + (long)t * rec + sc[q]);
                     lv_store_nt(hb[q][s2], p.hs + (long)(t + 1) * BH + pidx[q]);
@@ -247,8 +248,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 
             // ---- this wave's K quarter of the product: A = weights (16 gate columns), B = h (16 batch rows) ------------------
             f32x4 acc[8];
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
             const uint4* bp = reinterpret_cast<const uint4*>(sm.hl + brow * HP16 + 128 * w) + kq;
             uint4 bfr[8];
 #pragma unroll
@@ -258,7 +257,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb) acc[nb] = lv_mfma_16x16x32_bf16(wreg[ks][nb], bfr[ks], acc[nb]);
+                for (int nb = 0; nb < 8; ++nb)
+                    acc[nb] = ks == 0 ? lv_mfma_16x16x32_bf16_areg_first(wreg[0][nb], bfr[0]) : lv_mfma_16x16x32_bf16_areg(wreg[ks][nb], bfr[ks], acc[nb]);
+            LV_MFMA_DRAIN();
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) LV_MFMA_RESULT(acc[nb]);
             // D: lane (c = l & 15: batch row, rq = l >> 4) holds gate columns 16 nb + 4 rq + r = the (i, f, g, o) of unit 4 nb + rq
             if ((l & 15) < RP) {
                 f32x4* rd = sm.red[t & 1][w][l & 15];
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     const float c = fg * c_state[q] + ig * gg;
                     h = og * lv_tanh_fast(c);
                     c_state[q] = c;
-                    recb[q][s2] = make_float4(ig, fg, gg, og);
+                    recb[q][s2] = f32x4{ig, fg, gg, og};
                     cb[q][s2] = c; hb[q][s2] = h;
                 }
                 const uint32_t mine = lv_f32_to_bf16_bits(h);
@@ -483,15 +486,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         const uint32_t tag = rs_tag(k);
         gran_t* dst = tx + (long)(k & 1) * px_par;
         gran_t* dst4 = tx4 + (long)(k & 1) * px_par;
-#pragma unroll
-        for (int n4 = 0; n4 < 4; ++n4) {                 // four column blocks at a time: their granules go out while the next four multiply
-            f32x4 acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Four column blocks at a time, software-pipelined by hand: the 16 MFMAs of chunk n4 + 1 are issued BEFORE the granules
+        // of chunk n4 are merged, packed and stored (the weights are read from AGPRs by inline-assembly MFMAs, which the compiler
+        // neither reorders nor guards: two accumulator sets, and one drain in front of the last chunk's reads).
+        auto chunk_mfma = [&](int n4, f32x4 (&acc)[4]) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = lv_mfma_16x16x32_bf16(wreg[ks][4 * n4 + j], bfr[ks], acc[j]);
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = ks == 0 ? lv_mfma_16x16x32_bf16_areg_first(wreg[0][4 * n4 + j], bfr[0])
+                                     : lv_mfma_16x16x32_bf16_areg(wreg[ks][4 * n4 + j], bfr[ks], acc[j]);
+        };
+        auto chunk_send = [&](int n4, const f32x4 (&acc)[4]) {
             if constexpr (RP == 4) {
                 // Only lanes 0..3 of every 16-lane row hold batch rows at RP = 4: the four column blocks' quarter-rows are merged
                 // into ONE fully populated register set (DPP row_shr into banks 1..3), so that this chunk goes out as 2 full-wave
@@ -516,7 +522,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                     put(d + 4 * RP, rs_pack(acc[j][2], acc[j][3], tag));
                 }
             }
-        }
+        };
+        auto results = [&](f32x4 (&acc)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) LV_MFMA_RESULT(acc[j]);
+        };
+        f32x4 acc_a[4], acc_b[4], acc_c[4], acc_d[4];
+        chunk_mfma(0, acc_a);
+        chunk_mfma(1, acc_b);
+        results(acc_a);                 // 16 MFMAs behind its last write
+        chunk_send(0, acc_a);
+        chunk_mfma(2, acc_c);
+        results(acc_b);
+        chunk_send(1, acc_b);
+        chunk_mfma(3, acc_d);
+        results(acc_c);
+        chunk_send(2, acc_c);
+        LV_MFMA_DRAIN();
+        results(acc_d);
+        chunk_send(3, acc_d);
     };
 
     bool aborted = false;
