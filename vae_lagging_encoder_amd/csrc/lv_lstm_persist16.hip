@@ -37,6 +37,9 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_SBB16
 #define LV_SBB16 2                      // (measurement knobs of profiles/microbench: input block length of the 16-row BPTT,
 #endif                                  //  I/O block length and granules per lane and polling round of the 16-row forward)
+#ifndef LV_HB16
+#define LV_HB16 2                       // slot batches of the BPTT receive polled together (2: two rounds at 16 rows; 4: one)
+#endif
 #ifndef LV_SBK16
 #define LV_SBK16 4
 #endif
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     // Two batch rows (16 granules per lane) are polled at a time: all 32 granules of the 16-row form in flight at once would
     // need 64 registers next to the 256 of the weights (the first build spilled 92); the sums over the senders are taken in a
     // fixed order once a round is complete, so the result does not depend on arrival order.
-    constexpr int HB = NB < 2 ? NB : 2;
+    constexpr int HB = NB < LV_HB16 ? NB : LV_HB16;
     LV_TRACE_ONLY(int tr_spins[2] = {0, 0};)
     auto receive_round = [&](auto H0, const gran_t* src, uint32_t want, float (&dh_rec)[NP]) -> bool {
         constexpr int h0 = decltype(H0)::value;
