@@ -495,7 +495,7 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
 
 
-@pytest.mark.parametrize("kernels", ["16row", "16row_B64_R8", "16row_B128_R16", "4row"])
+@pytest.mark.parametrize("kernels", ["16row", "16row_B64_R8", "16row_B128_R16", "16row_B100_R13", "16row_B13_R2", "4row"])
 def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels):
     """Both persistent recurrences (the default kernels of lv_lstm_persist16.hip with their hand-off in the XCD's L2, and the
     4-row kernels of lv_lstm_persist.hip) at the length the metric is quoted on (T = 200, B = 32, H = 1024) against the
