@@ -18,6 +18,9 @@
 // loads 16 B (eight adjacent rows at one k) for 4 consecutive k and transposes the 8x4 block in registers (16 integer
 // ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
 // consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
+#ifndef LV_B16_T256_W4
+#define LV_B16_T256_W4 0
+#endif
 #ifndef LV_B16_T256_DMA
 #define LV_B16_T256_DMA 1
 #endif
@@ -716,8 +719,14 @@ __device__ __forceinline__ void t256_tile_of(const GemmQ& p, int s, int& tm, int
     tn = (s % nig) / gsz;
 }
 
-template <bool NLL, bool TN>
-__global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
+// WN = waves along N: 4 (8 waves, wave tile 128 x 64: acc 128 registers, two waves per SIMD) or 2 (4 waves, wave tile 128 x 128: acc
+// 256 registers -- AGPRs --, ONE wave per SIMD, 8 fragment reads per 16 MFMAs instead of 6 per 8: a third less LDS read traffic,
+// which at 8 waves equals the MFMA pipe time).  The NLL epilogue exists for WN = 4 only.
+template <bool NLL, bool TN, int WN = 4>
+__global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
+    static_assert(WN == 4 || (WN == 2 && !NLL), "4 waves: plain epilogue only");
+    constexpr int NJ = 8 / WN;                          // 32-column fragments per wave along N
+    constexpr int UN = 16 / WN;                         // 1 KB staging units per wave and image
     __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
     __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
 
@@ -749,14 +758,14 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 
     const int t = (int)threadIdx.x;
     const int l = t & 63, w = lv_wave_uniform(t >> 6);   // wave id in SGPRs: the LDS-DMA destinations below are scalar (M0)
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = w / WN, wn = w % WN;
     const int li = l & 31, lh = l >> 5;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -764,11 +773,11 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 
     // staging units of this thread: wave w fills the 1 KB pieces u = 4w + i of each image (8 rows of 128 B; TN A image: 2 k rows
     // of 512 B)
-    uint32_t oa[4], ob[4];                             // element offsets from p.A / p.B (the launcher checks they fit 32 bits)
-    int kch[4];
+    uint32_t oa[UN], ob[UN];                           // element offsets from p.A / p.B (the launcher checks they fit 32 bits)
+    int kch[UN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = 4 * w + i;
+    for (int i = 0; i < UN; ++i) {
+        const int u = UN * w + i;
         const int row = 8 * u + (l >> 3);
         const int c = (l & 7) ^ ((row >> 1) & 7);
         kch[i] = 8 * c;
@@ -788,18 +797,18 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     auto stage_unit = [&](int kt, int i, LdsTile2& Ad, LdsTile2& Bd) {     // 2 of the 8 DMA instructions of a K tile
         const uint32_t k0 = (uint32_t)(kt * BK);
         const uint32_t ka = TN ? k0 * (uint32_t)p.lda : k0;
-        lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (4 * w + i));
-        lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (4 * w + i));
+        lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (UN * w + i));
+        lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (UN * w + i));
     };
     auto stage_dma = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage_unit(kt, i, Ad, Bd);
+        for (int i = 0; i < UN; ++i) stage_unit(kt, i, Ad, Bd);
     };
     auto stage_ragged = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int u = 4 * w + i;
+        for (int i = 0; i < UN; ++i) {
+            const int u = UN * w + i;
             const int k = k0 + kch[i];
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
             if constexpr (TN) {
@@ -813,7 +822,7 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
         }
     };
 
-    const int arow = wm * 128 + li, brow = wn * 64 + li;
+    const int arow = wm * 128 + li, brow = wn * (32 * NJ) + li;
     const int sx = (li >> 1) & 7;                      // swizzle key of this lane's fragment rows (rows differ by multiples of 32)
     int atr[4] = {0, 0, 0, 0};
     if constexpr (TN) {
@@ -841,17 +850,19 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     auto mma_tile = [&](auto staging, LdsTile2& Ac, LdsTile2& Bc, int kt_next, LdsTile2& Ad, LdsTile2& Bd) {
         constexpr bool STAGE = decltype(staging)::value;
         LV_TRACE_MARK(tr_kt, 0);
-        uint4 fa[2][4], fb[2][2];
+        uint4 fa[2][4], fb[2][NJ];
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) fa[0][i2] = a_frag(Ac, 0, i2);
-        fb[0][0] = Bc[brow][lh ^ sx]; fb[0][1] = Bc[brow + 32][lh ^ sx];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[0][j] = Bc[brow + 32 * j][lh ^ sx];
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
 #if LV_B16_T256_ORDER == 0
             if (ks + 1 < BK / 16) {
                 const int c = 2 * (ks + 1) + lh;
-                fb[nxt][0] = Bc[brow][c ^ sx]; fb[nxt][1] = Bc[brow + 32][c ^ sx];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[nxt][j] = Bc[brow + 32 * j][c ^ sx];
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
             }
@@ -860,12 +871,13 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
             LV_SCHED_BARRIER();
 #if LV_B16_T256_ORDER == 1
             if (ks + 1 < BK / 16) {
                 const int c = 2 * (ks + 1) + lh;
-                fb[nxt][0] = Bc[brow][c ^ sx]; fb[nxt][1] = Bc[brow + 32][c ^ sx];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[nxt][j] = Bc[brow + 32 * j][c ^ sx];
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2) fa[nxt][i2] = a_frag(Ac, ks + 1, i2);
             }
@@ -875,7 +887,12 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
             // at the end-of-tile vmcnt(0): 8192^3 1090 -> 1185 TF, dW_pred 290 -> 276 us, dO 307 -> 300; all four units at the top, or
             // 1-2-1, measured worse: profiles/microbench/gemm_b16_shapes.py with -DLV_B16_T256_DMA=0/2/3/4)
 #if LV_B16_T256_DMA == 1
-            if constexpr (STAGE) { if (ks < 2) { stage_unit(kt_next, 2 * ks, Ad, Bd); stage_unit(kt_next, 2 * ks + 1, Ad, Bd); } }
+            if constexpr (STAGE) {
+                if (ks < 2) {
+#pragma unroll
+                    for (int i = 0; i < UN / 2; ++i) stage_unit(kt_next, (UN / 2) * ks + i, Ad, Bd);
+                }
+            }
 #elif LV_B16_T256_DMA == 2
             if constexpr (STAGE) { if (ks == 0) { stage_unit(kt_next, 0, Ad, Bd); stage_unit(kt_next, 1, Ad, Bd); } else if (ks < 3) stage_unit(kt_next, ks + 1, Ad, Bd); }
 #elif LV_B16_T256_DMA == 3
@@ -889,7 +906,7 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 #pragma unroll
             for (int i = 2; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
             LV_SCHED_BARRIER();
         }
         LV_TRACE_MARK(tr_kt, 1);
@@ -1003,8 +1020,8 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + (l & 31);
+            for (int j = 0; j < NJ; ++j) {
+                const int col = wn * (32 * NJ) + j * 32 + (l & 31);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
@@ -1016,8 +1033,8 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 #pragma unroll
     for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            store_frag_f32(p, acc[i2][j], m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), n0 + wn * 64 + j * 32 + (l & 31));
+        for (int j = 0; j < NJ; ++j)
+            store_frag_f32(p, acc[i2][j], m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), n0 + wn * (32 * NJ) + j * 32 + (l & 31));
 }
 
 // the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)
@@ -1233,8 +1250,13 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
         const Tail256 q = t256_plan((long)p.tilesM * p.tilesN, nk, ws ? ws_floats : 0);
         const long tail = (long)p.tilesM * p.tilesN - q.full;
         dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
+#if LV_B16_T256_W4                                         // (measurement knob: the 4-wave form of the kernel, wave tile 128 x 128)
+        if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, 2>), grid, dim3(256), 0, stream, p, q);
+        else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, 2>), grid, dim3(256), 0, stream, p, q);
+#else
         if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
+#endif
         if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
