@@ -157,6 +157,88 @@ __global__ __launch_bounds__(SORT_THREADS) void token_sort_kernel(const int64_t*
     }
 }
 
+// The same sort with the intermediate passes in LDS (N <= SORT_LDS_MAX elements: 32-bit keys + 16-bit row ids in two ping-pong
+// images).  A radix pass scatters every element to its own address; from one workgroup that is ~13 000 four-byte global stores per
+// pass, and those -- not the loads -- were the 55 us of token_sort_kernel at the Yahoo shape.  Here only the last pass writes to
+// memory.  Same digit order, same stable placement: the output is identical.
+constexpr int SORT_LDS_MAX = 8192;
+__global__ __launch_bounds__(SORT_THREADS) void token_sort_lds_kernel(const int64_t* __restrict__ ids, long ids_stride, int T, int B,
+                                                                      int V, int* out_rows, int* out_tok) {
+    __shared__ int counts[16 * SORT_THREADS];
+    __shared__ int wave_tot[SORT_WAVES];
+    __shared__ int kimg[2][SORT_LDS_MAX];
+    __shared__ uint16_t vimg[2][SORT_LDS_MAX];
+    const int tid = (int)threadIdx.x;
+    const int N = T * B;
+    const int per = (N + SORT_THREADS - 1) / SORT_THREADS;
+    const int e0 = tid * per;
+    const int e1 = (e0 + per) < N ? (e0 + per) : N;
+    int bits = 1;
+    while ((1L << bits) < (long)V) ++bits;
+    const int npass = (bits + 3) / 4;
+    // the tokens of this thread's elements into image 1 (what "pass -1" would have written), 16 loads in flight at a time
+    for (int c0 = e0; c0 < e1; c0 += 16) {
+        long tk[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = c0 + u < e1 ? c0 + u : e1 - 1;
+            const int t = e / B, b = e % B;
+            tk[u] = ids[(long)b * ids_stride + t];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (c0 + u < e1) {
+                kimg[1][c0 + u] = (int)(tk[u] < 0 ? 0 : (tk[u] >= V ? V - 1 : tk[u]));
+                vimg[1][c0 + u] = (uint16_t)(c0 + u);
+            }
+    }
+    __syncthreads();
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 4 * pass;
+        const int* kin = kimg[(pass + 1) & 1];           // pass p reads image (p + 1) & 1 (written by pass p - 1), writes image p & 1
+        const uint16_t* vin = vimg[(pass + 1) & 1];
+        int* kout = kimg[pass & 1];
+        uint16_t* vout = vimg[pass & 1];
+        const bool last = pass == npass - 1;
+        auto key_of = [&](int e) -> int { return kin[e]; };
+        int hist[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) hist[d] = 0;
+        for (int e = e0; e < e1; ++e) {
+            const int dgt = (key_of(e) >> shift) & 15;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) hist[d] += (d == dgt) ? 1 : 0;
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) counts[d * SORT_THREADS + tid] = hist[d];
+        __syncthreads();
+        int loc[16];
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { loc[i] = counts[tid * 16 + i]; s += loc[i]; }
+        int total;
+        int base = block_exclusive_scan(s, wave_tot, &total);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { counts[tid * 16 + i] = base; base += loc[i]; }
+        __syncthreads();
+        int off[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) off[d] = counts[d * SORT_THREADS + tid];
+        for (int e = e0; e < e1; ++e) {
+            const int key = key_of(e);
+            const int val = (int)vin[e];
+            const int dgt = (key >> shift) & 15;
+            int pos = 0;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d == dgt) { pos = off[d]; off[d] = pos + 1; }
+            if (last) { out_tok[pos] = key; out_rows[pos] = val; }
+            else { kout[pos] = key; vout[pos] = (uint16_t)val; }
+        }
+        __syncthreads();
+    }
+}
+
 #ifndef LV_SC_PARTS
 #define LV_SC_PARTS 2
 #endif
@@ -303,7 +385,10 @@ extern "C" int lv_token_sort(const int64_t* ids, long ids_stride, int T, int B, 
     if (!ids || !out_rows || !out_tok || !tmp) return LV_ERR_ARG;
     if (T < 0 || B <= 0 || V <= 0) return LV_ERR_SHAPE;
     if (T == 0) return LV_OK;
-    LV_LAUNCH(token_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, ids, ids_stride, T, B, V, out_rows, out_tok, tmp);
+    if ((long)T * B <= SORT_LDS_MAX)
+        LV_LAUNCH(token_sort_lds_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, ids, ids_stride, T, B, V, out_rows, out_tok);
+    else
+        LV_LAUNCH(token_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, ids, ids_stride, T, B, V, out_rows, out_tok, tmp);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
