@@ -194,24 +194,6 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
             if (col >= p.N) continue;
             const int rbase = m0 + wm * 32 * WT + i * 32 + 4 * (l >> 5);
             const int q1 = p.add1 ? rbase % p.mod1 : 0, q2 = p.add2 ? rbase % p.mod2 : 0;
-            // addends and the old C of an accumulating call: the 16 loads of each kind issued together (rows clamped into the
-            // matrix), then the arithmetic -- loaded in place behind `if (row < M)` every one of them was its own memory round trip
-            float a1[16], a2[16], co[16];
-            if (!split && p.add1) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a1[e] = p.add1[(long)lv_wrap_row(q1, (e & 3) + 8 * (e >> 2), p.mod1) * p.ld1 + col];
-            }
-            if (!split && p.add2) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a2[e] = p.add2[(long)lv_wrap_row(q2, (e & 3) + 8 * (e >> 2), p.mod2) * p.ld2 + col];
-            }
-            if (!split && p.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = rbase + (e & 3) + 8 * (e >> 2);
-                    co[e] = p.C[(long)(row < p.M ? row : p.M - 1) * p.ldc + col];
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ro = (e & 3) + 8 * (e >> 2);
@@ -220,9 +202,11 @@ __global__ __launch_bounds__(256) void lv_gemm_f32_kernel(GemmP p) {
                 float* c = out + (long)row * ldo + col;
                 if (split) { *c = acc[i][j][e]; continue; }
                 float v = p.alpha * acc[i][j][e];
-                if (p.add1) v += a1[e];
-                if (p.add2) v += a2[e];
-                if (p.accumulate) v += co[e];
+                // (addends loaded in place: gathering them first, as lv_gemm_b16's epilogue does, costs this kernel 27-48 more live
+                //  registers and a third to a half of its occupancy)
+                if (p.add1) v += p.add1[(long)lv_wrap_row(q1, ro, p.mod1) * p.ld1 + col];
+                if (p.add2) v += p.add2[(long)lv_wrap_row(q2, ro, p.mod2) * p.ld2 + col];
+                if (p.accumulate) v += *c;
                 *c = v;
             }
         }
