@@ -709,8 +709,13 @@ struct Tail256 {
     int kt_per_piece;  // K tiles per piece
 };
 
+#ifndef LV_T256_G
+#define LV_T256_G 4                      // M tiles per group of the 256-tile kernel's tile order: the 32 workgroups an XCD runs at a time
+                                         // then cover 4 x 8 tiles, whose operand slices fit its 4 MB L2 better than 8 x 4 (8: plain
+                                         // logits 312 us, dO 300, 8192^3 930; 4: 284 / 290 / 890-915; 2, 3, 6, 16 in between or worse)
+#endif
 __device__ __forceinline__ void t256_tile_of(const GemmQ& p, int s, int& tm, int& tn) {
-    const int G = 8;
+    const int G = LV_T256_G;
     const int nig = G * p.tilesN;
     const int group = s / nig;
     const int first_m = group * G;
