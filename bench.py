@@ -200,6 +200,9 @@ def main():
                     help="wire format of the data-parallel gradient exchange (auto = bf16 for --dtype bf16, exact f32 mean for --dtype "
                          "f32; bf16 halves the bytes)")
     ap.add_argument("--pool", type=int, default=None)
+    ap.add_argument("--tokens", default="uniform", choices=["uniform", "zipf"],
+                    help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
+                         "tokens repeat hundreds of times per batch, which the embedding backward's sort / scatter feel)")
     args = ap.parse_args()
     stress = args.workload == "stress"
     if args.steps is None:
@@ -234,7 +237,7 @@ def main():
     tr.enc.persistent = tr.dec.persistent = bool(args.persistent)
     if sync is not None:
         args.dp_payload = sync.payload                      # "auto" resolved by the trainer
-    pool = [synthetic_batch(B, T, V, seed=1000 * rank + i).to(dev) for i in range(args.pool)]
+    pool = [synthetic_batch(B, T, V, seed=1000 * rank + i, dist=args.tokens).to(dev) for i in range(args.pool)]
     rs = np.random.RandomState(783435)
     kl_weight = 0.1                                         # text.py default kl_start
     # batch construction: the per-batch sorted token lists of the embedding backward are built with the batches (a function of
@@ -342,7 +345,7 @@ def main():
     out = {
         "metric": "aggressive-loop seqs/sec", "value": round(value, 2), "unit": "seq/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.tokens == "uniform" else "synthetic (Zipf-distributed token ids)",
         "config": {"workload": "%s LSTM-VAE aggressive inner step (fwd+bwd+clip+encoder SGD), B=%d/GPU, T=%d, V=%d, "
                                "ni=%d, H=%d, nz=%d%s" % ("yahoo" if stress else args.workload, B, T, V, ni, H, nz,
                                                           ", fixed K=%d inner steps per loop (stress)" % args.steps if stress else ""),

@@ -239,23 +239,64 @@ __global__ __launch_bounds__(SORT_THREADS) void token_sort_lds_kernel(const int6
     }
 }
 
-#ifndef LV_SC_PARTS
-#define LV_SC_PARTS 2
-#endif
+// ---- embedding backward: dE[tok] = sum over the occurrences of tok of dX[row] (masked / scaled), tokens sorted ---------------------
+// One workgroup per sorted position; the segment heads do the sums.  A head reads its occurrences eight at a time (row ids,
+// gradient rows, mask words: each stage one batch of loads -- walked one by one, each occurrence was three dependent memory round
+// trips, 2 us apiece for a token that occurs a few hundred times in a batch of natural text, with the whole launch waiting for that
+// one workgroup).  LONG runs (ni = 512 only) are left to embed_scatter_long_kernel, whose 1024-thread workgroups split a run over 8
+// thread groups: run [h, e) is long iff q0 + SC_LONG < e for q0 = the first multiple of SC_LONG at or behind h -- a rule both kernels
+// can evaluate (this one knows h and e, the other one looks at toks[q - SC_LONG] and toks[q + SC_LONG]).  Sums are added in a fixed
+// order everywhere: deterministic.
 // (profiles/microbench/embed_scatter_zipf.py, us per scatter at the Yahoo shape, uniform ids / Zipf(1) ids whose most frequent token
-//  occurs 628 times: 1 group 24.9 / 72.3, 2 groups 30.9 / 44.0, 4 groups 43.5 / 35.7 -- every position's workgroup carries the groups)
-constexpr int SC_PARTS = LV_SC_PARTS;       // thread groups of a workgroup that share one token's occurrences (8 at a time each)
-__global__ __launch_bounds__(128 * SC_PARTS) void embed_scatter_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
+//  occurs 628 times: one 128-thread group for everything 24.9 / 72.3; every position's workgroup with 2 groups 30.9 / 44.0, with 4
+//  groups 43.5 / 35.7 -- the wider workgroups are paid for at every position; this two-kernel form 27.7 / 43.6, and in the Yahoo step
+//  with Zipf ids (masked decoder scatter included) 72 -> 47 us per scatter on average)
+constexpr int SC_LONG = 32;
+constexpr int SC_GROUPS = 8;
+
+// sum of the occurrences [q_lo, e) taken in batches of 8 with stride `stride` (one float4 column group, column k)
+__device__ __forceinline__ float4 scatter_batches(const float* __restrict__ dX, const uint8_t* __restrict__ mask, float scale,
+                                                  const int* __restrict__ rows, int q_lo, int e, int stride, int ni, int k, int B, int T) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = q_lo; q0 < e; q0 += stride) {
+        int r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = rows[q0 + u < e ? q0 + u : e - 1];
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dX + (long)r[u] * ni + k);
+        if (mask) {
+            uint32_t mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = r[u] / B, b = r[u] % B;
+                mk[u] = *reinterpret_cast<const uint32_t*>(mask + ((long)b * T + t) * ni + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u].x = (mk[u] & 0xFFu) ? v[u].x * scale : 0.f;
+                v[u].y = (mk[u] & 0xFF00u) ? v[u].y * scale : 0.f;
+                v[u].z = (mk[u] & 0xFF0000u) ? v[u].z * scale : 0.f;
+                v[u].w = (mk[u] & 0xFF000000u) ? v[u].w * scale : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q0 + u < e) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
                                                             float scale, const int* __restrict__ rows,
                                                             const int* __restrict__ toks, int N, int B, int T,
                                                             float* __restrict__ dE, int ni, int pad_idx, int accumulate,
-                                                            int vec, int V) {
-    __shared__ __attribute__((aligned(16))) float part_sum[SC_PARTS > 1 ? SC_PARTS - 1 : 1][512];
+                                                            int vec, int V, int long_runs_elsewhere) {
     const int p = (int)blockIdx.x;
-    const int tid = (int)threadIdx.x & 127, grp = (int)threadIdx.x >> 7;      // column thread, occurrence group
-    if (V > 0 && grp == 0) {
-        // complete form: every row of dE is written exactly once by this launch -- the rows of tokens that occur by their segment
-        // heads below, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
+    const int tid = (int)threadIdx.x;
+    if (V > 0) {
+        // complete form: every row of dE is written exactly once by this launch (pair) -- the rows of tokens that occur by their
+        // segment heads, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
         // binary search of the sorted token list per row).  Replaces a separate fill of the whole table (41 MB at V = 20001).
         const int v0 = (int)((long)p * V / N), v1 = (int)((long)(p + 1) * V / N);
         for (int v = v0; v < v1; ++v) {
@@ -270,10 +311,8 @@ __global__ __launch_bounds__(128 * SC_PARTS) void embed_scatter_kernel(const flo
     const int tok = toks[p];
     if (p > 0 && toks[p - 1] == tok) return;   // not a segment head
     if (tok == pad_idx) return;
-    // end of the segment [p, e): the next eight positions in one batch of loads (most tokens occur once or twice); a longer run is
-    // finished by a binary search of the sorted list.  The segment used to be walked as `for (q = p; toks[q] == tok; ++q)` with the
-    // row id and the gradient row loaded inside: three dependent memory round trips per occurrence -- 2 us each for a token that
-    // occurs a few hundred times in a batch of natural text (a Zipf head), with the whole launch waiting for that one workgroup.
+    // end of the run [p, e): the next eight positions in one batch of loads (most tokens occur once or twice); a longer run is
+    // finished by a binary search of the sorted list
     int e = p + 1;
     {
         int nx[8];
@@ -292,55 +331,10 @@ __global__ __launch_bounds__(128 * SC_PARTS) void embed_scatter_kernel(const flo
         }
     }
     float* dst = dE + (long)tok * ni;
-    // ni == 512 (one float4 column group per thread): the occurrences are dealt to the SC_PARTS thread groups in batches of eight
-    // (group g takes batches g, g + SC_PARTS, ...), and the groups' sums are added in group order through LDS -- a fixed order, so the
-    // result is deterministic; a token that occurs a few hundred times (the head of a Zipf distribution) no longer makes the
-    // launch wait for one 128-thread walk over all of its occurrences.  Other widths: group 0 alone, in occurrence order.
-    const bool split = vec && ni == 512;
-    if (!split && grp != 0) return;
     if (vec) {
+        if (long_runs_elsewhere && (p + SC_LONG - 1) / SC_LONG * SC_LONG + SC_LONG < e) return;      // a long run: embed_scatter_long_kernel's
         for (int k = tid * 4; k < ni; k += 512) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q0 = p + (split ? 8 * grp : 0); q0 < e; q0 += (split ? 8 * SC_PARTS : 8)) {  // eight occurrences at a time: row ids, gradient rows, mask bytes -- each stage in one batch
-                int r[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) r[u] = rows[q0 + u < e ? q0 + u : e - 1];
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(dX + (long)r[u] * ni + k);
-                if (mask) {
-                    uint32_t mk[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int t = r[u] / B, b = r[u] % B;
-                        mk[u] = *reinterpret_cast<const uint32_t*>(mask + ((long)b * T + t) * ni + k);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        v[u].x = (mk[u] & 0xFFu) ? v[u].x * scale : 0.f;
-                        v[u].y = (mk[u] & 0xFF00u) ? v[u].y * scale : 0.f;
-                        v[u].z = (mk[u] & 0xFF0000u) ? v[u].z * scale : 0.f;
-                        v[u].w = (mk[u] & 0xFF000000u) ? v[u].w * scale : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (q0 + u < e) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-            }
-            if (split) {
-                if (e - p > 8) {                  // (a token with at most eight occurrences is group 0's alone: nothing to add)
-                    if (grp > 0) *reinterpret_cast<float4*>(&part_sum[grp - 1][k]) = acc;
-                    __syncthreads();
-                    if (grp == 0) {
-#pragma unroll
-                        for (int g = 0; g < SC_PARTS - 1; ++g) {
-                            const float4 o = *reinterpret_cast<const float4*>(&part_sum[g][k]);
-                            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-                        }
-                    }
-                }
-                if (grp != 0) return;
-            }
+            float4 acc = scatter_batches(dX, mask, scale, rows, p, e, 8, ni, k, B, T);
             float4* d4 = reinterpret_cast<float4*>(dst + k);
             if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
             *d4 = acc;
@@ -361,6 +355,41 @@ __global__ __launch_bounds__(128 * SC_PARTS) void embed_scatter_kernel(const flo
             dst[k] = acc;
         }
     }
+}
+
+// the long runs (ni = 512, 16-byte aligned): workgroup j looks at position q = SC_LONG j and takes the run that contains it iff q is
+// the run's first multiple of SC_LONG and the run reaches beyond q + SC_LONG; 8 groups of 128 threads take the run's batches of
+// eight occurrences round-robin and their sums meet in LDS in group order
+__global__ __launch_bounds__(128 * SC_GROUPS) void embed_scatter_long_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
+                                                                             float scale, const int* __restrict__ rows,
+                                                                             const int* __restrict__ toks, int N, int B, int T,
+                                                                             float* __restrict__ dE, int pad_idx, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float part_sum[SC_GROUPS - 1][512];
+    const int q = (int)blockIdx.x * SC_LONG;
+    const int tid = (int)threadIdx.x & 127, grp = (int)threadIdx.x >> 7;
+    if (q + SC_LONG >= N) return;
+    const int tok = toks[q];
+    if (toks[q + SC_LONG] != tok || tok == pad_idx) return;
+    if (q >= SC_LONG && toks[q - SC_LONG] == tok) return;          // an earlier workgroup's
+    int lo = q - SC_LONG + 1 < 0 ? 0 : q - SC_LONG + 1, hi = q;     // head: first position in (q - SC_LONG, q] with this token
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < tok) lo = mid + 1; else hi = mid; }
+    const int h = lo;
+    lo = q + SC_LONG + 1; hi = N;                                   // end: first position behind q + SC_LONG with another token
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] == tok) lo = mid + 1; else hi = mid; }
+    const int e = lo;
+    const int k = tid * 4;
+    float4 acc = scatter_batches(dX, mask, scale, rows, h + 8 * grp, e, 8 * SC_GROUPS, 512, k, B, T);
+    if (grp > 0) *reinterpret_cast<float4*>(&part_sum[grp - 1][k]) = acc;
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int g = 0; g < SC_GROUPS - 1; ++g) {
+        const float4 o = *reinterpret_cast<const float4*>(&part_sum[g][k]);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    float4* d4 = reinterpret_cast<float4*>(dE + (long)tok * 512 + k);
+    if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    *d4 = acc;
 }
 
 }  // namespace
@@ -403,8 +432,12 @@ extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float 
     if (T == 0) return LV_OK;
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
-    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128 * SC_PARTS), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
-              N, B, T, dE, ni, pad_idx, accumulate, vec, 0);
+    const int two = vec && ni == 512 && N > 2 * SC_LONG;
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+              N, B, T, dE, ni, pad_idx, accumulate, vec, 0, two);
+    if (two)
+        LV_LAUNCH(embed_scatter_long_kernel, dim3((unsigned)lv_cdiv(N, SC_LONG)), dim3(128 * SC_GROUPS), 0, stream, dX, mask, scale, sorted_rows,
+                  sorted_tok, N, B, T, dE, pad_idx, accumulate);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -418,8 +451,12 @@ extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, f
     if (T <= 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
-    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128 * SC_PARTS), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
-              N, B, T, dE, ni, pad_idx, 0, vec, V);
+    const int two = vec && ni == 512 && N > 2 * SC_LONG;
+    LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
+              N, B, T, dE, ni, pad_idx, 0, vec, V, two);
+    if (two)
+        LV_LAUNCH(embed_scatter_long_kernel, dim3((unsigned)lv_cdiv(N, SC_LONG)), dim3(128 * SC_GROUPS), 0, stream, dX, mask, scale, sorted_rows,
+                  sorted_tok, N, B, T, dE, pad_idx, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -64,10 +64,15 @@ def build_image_vae(device, seed, nz=32, latent_feature_map=4):
     return vae
 
 
-def synthetic_batch(B, T, V, seed=0):
-    """ids ~ U{4..V-1}, column 0 = <s> (1), last column = </s> (2); int64 [B][T] on the CPU."""
+def synthetic_batch(B, T, V, seed=0, dist="uniform"):
+    """ids ~ U{4..V-1} (dist="zipf": rank-frequency 1/r over the same range, like natural text -- the most frequent
+    token then occurs a few hundred times in a 6000-token batch), column 0 = <s> (1), last column = </s> (2); int64 [B][T] on the CPU."""
     g = torch.Generator().manual_seed(seed)
-    x = torch.randint(4, V, (B, T), generator=g, dtype=torch.int64)
+    if dist == "zipf":
+        w = 1.0 / torch.arange(1, V - 3, dtype=torch.float64)
+        x = (torch.multinomial(w, B * T, replacement=True, generator=g) + 4).view(B, T).to(torch.int64)
+    else:
+        x = torch.randint(4, V, (B, T), generator=g, dtype=torch.int64)
     x[:, 0] = 1
     x[:, -1] = 2
     return x
