@@ -320,6 +320,40 @@ def check_weight_images_follow_rebound_parameters(device, V=333, ni=24, H=64, nz
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
+def check_saved_activation_layout_is_checked(device, V=333, ni=24, H=1024, nz=8, B=16, T=9):
+    """The persistent recurrences keep what the forward saves for the BPTT in a buffer of their own layout, whose record size
+    depends on the rows per XCD group.  A backward that would read it differently (rows per group or the persistent route changed
+    between forward and backward) must fail loudly instead of computing garbage."""
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd import _lib, engine
+    P0 = O.random_params(V, ni, H, nz, seed=41, scale=0.05, emb_scale=0.5, head_scale=0.5)
+    x = O.synthetic_batch(B, T, V, seed=43).to(device)
+    vae = build_vae(V, ni, H, nz, device, params=P0)
+    vae.encoder._hip.precision = vae.decoder._hip.precision = "bf16"
+    enc = vae.encoder._hip
+    if not engine._persistent_ok(enc, object(), B, H, device, engine._PERSIST_MAX_B):
+        return False                                            # no persistent route on this device: nothing to check
+    for change in ("rows", "route"):
+        mu, logvar = vae.encoder(x)
+        if change == "rows":
+            enc.persist_rows = 8                                # forward ran with ceil(16 / 8) = 2 rows per group
+        else:
+            enc.persistent = False                              # backward routed to the step kernels
+        try:
+            raised = False
+            try:
+                (mu.sum() + logvar.sum()).backward()
+            except _lib.LvaeError as e:
+                raised = "saved activations" in str(e)
+            assert raised, "backward accepted saved activations of another layout (%s changed)" % change
+        finally:
+            enc.persist_rows = None
+            enc.persistent = True
+    mu, logvar = vae.encoder(x)                                 # and the unchanged pair still works
+    (mu.sum() + logvar.sum()).backward()
+    return True
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # joint step after aggressive mode ends (text.py:418-421: encoder AND decoder stepped) and the fixed-K loop of the stress config
 def check_update_both_and_fixed_k(device, V=97, ni=12, H=20, nz=4, B=6, K=4, precision="f32", tol=5e-4):

@@ -115,6 +115,11 @@ def test_token_sort_cache_follows_the_batch(hip_device):
 
 
 @pytest.mark.gpu
+def test_saved_activation_layout_is_checked(hip_device):
+    assert pc.check_saved_activation_layout_is_checked(hip_device)
+
+
+@pytest.mark.gpu
 def test_weight_images_follow_rebound_parameters(hip_device):
     pc.check_weight_images_follow_rebound_parameters(hip_device)
     pc.check_weight_images_follow_rebound_parameters(hip_device, V=2003, ni=64, H=1024, nz=32, B=32, T=12)   # persistent route: packed W_hh too
