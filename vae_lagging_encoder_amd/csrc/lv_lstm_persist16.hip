@@ -35,7 +35,7 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #endif
 
 #ifndef LV_SBB16
-#define LV_SBB16 2                      // (measurement knobs of profiles/microbench: input block length of the 16-row BPTT,
+#define LV_SBB16 8                      // (measurement knobs of profiles/microbench: input block length of the 16-row BPTT,
 #endif                                  //  I/O block length and granules per lane and polling round of the 16-row forward)
 #ifndef LV_HB16
 #define LV_HB16 2                       // slot batches of the BPTT receive polled together (2: two rounds at 16 rows; 4: one)
