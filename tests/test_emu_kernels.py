@@ -73,7 +73,7 @@ def test_lstm_bf16_img(emu_backend, cfg):
     K.test_lstm_fwd_bwd(emu_backend, CPU, *cfg, prec="bf16_img")
 
 
-@pytest.mark.parametrize("cfg", [(7, 4, 8, 53, True), (12, 16, 50, 1004, False), (9, 8, 512, 3, True)])
+@pytest.mark.parametrize("cfg", [(7, 4, 8, 53, True), (12, 16, 50, 1004, False), (9, 8, 512, 3, True), (24, 8, 512, 3, True)])
 def test_embed(emu_backend, cfg):
     K.test_embed_gather_sort_scatter(emu_backend, CPU, *cfg)
 

@@ -623,7 +623,8 @@ def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):
 
 
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),
-                                              (200, 128, 64, 300, True), (50, 32, 512, 40, True), (9, 8, 512, 3, False)])
+                                              (200, 128, 64, 300, True), (50, 32, 512, 40, True), (9, 8, 512, 3, False),
+                                              (40, 8, 512, 3, True), (130, 16, 512, 7, False)])      # long runs: the 8-group kernel
 def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):
     dev = hip_device
     g = torch.Generator().manual_seed(T + B + ni)
