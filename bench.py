@@ -56,8 +56,15 @@ def fwd_flops(V, ni, H, nz, B, T):
 
 
 def bench_omniglot(args, dev, rank, world):
+    out = measure_omniglot(args, dev, rank, world, cpu_baseline=(rank == 0 and not args.no_cpu_baseline))
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def measure_omniglot(args, dev, rank, world, cpu_baseline=False, profile_eager=False):
     """images/sec through the aggressive inner step of the Omniglot VAE (image.py:300-314), B=50 per GPU, replicas only
-    (BatchNorm batch statistics make naive data parallelism non-equivalent: SURVEY.md 8e)."""
+    (BatchNorm batch statistics make naive data parallelism non-equivalent: SURVEY.md 8e).  profile_eager: take the per-group
+    kernel times from an eager pass even when the timed steps were hipGraph replays (a second trainer on the same model)."""
     from vae_lagging_encoder_amd import engine
     from vae_lagging_encoder_amd.factory import build_image_vae
     from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
@@ -84,7 +91,11 @@ def bench_omniglot(args, dev, rank, world):
     # the host runs ahead, and the kernels (and the event records between them) execute back to back.
     prof = {}
     prof_steps = 0
-    if not args.graph:
+    stats = tr.read_stats()
+    if not args.graph or profile_eager:
+        if args.graph:
+            tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, seed=783435 + rank, precision=args.dtype, use_graph=False)
+            one_step()                                      # allocate the eager path's buffers outside the profiled steps
         engine.PROFILE = prof
         prof_steps = 4
         for _ in range(prof_steps):
@@ -92,7 +103,6 @@ def bench_omniglot(args, dev, rank, world):
             one_step()
         torch.cuda.synchronize(dev)
         engine.PROFILE = None
-    stats = tr.read_stats()
     value = world * B * args.steps / dt
     out = {"metric": "aggressive-loop images/sec", "value": round(value, 2), "unit": "img/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -145,7 +155,7 @@ def bench_omniglot(args, dev, rank, world):
     else:
         out["roofline"] = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                            "note": "graph replay: no per-kernel events; see the eager run / profiles/ for the kernel breakdown"}
-    if rank == 0 and not args.no_cpu_baseline:
+    if cpu_baseline:
         from oracle import image_vae_oracle as IO          # the checker, used here only as the timed CPU baseline
         nthreads = min(64, os.cpu_count() or 1)
         torch.set_num_threads(nthreads)
@@ -163,8 +173,7 @@ def bench_omniglot(args, dev, rank, world):
                                "sample": "%d timed inner steps at B=%d after 1 warm-up, torch CPU ATen ops (the reference's CPU path "
                                          "restated in oracle/image_vae_oracle.py)" % (n, B)}
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-    if rank == 0:
-        print(json.dumps(out))
+    return out
 
 
 def lstm_algorithmic_bytes(kind, T, B, H, wb, per_step_weights):
@@ -179,6 +188,120 @@ def lstm_algorithmic_bytes(kind, T, B, H, wb, per_step_weights):
     return per_t * T + w * (T if per_step_weights else 1)
 
 
+def text_rooflines(prof, steps, workload, dtype, B, T, H, peak_mfma):
+    """(gemm_roof, lstm_roof, pmc whole-step GB or None) from the HIP-event records engine.PROFILE collected over `steps` steps."""
+    args = argparse.Namespace(steps=steps, workload=workload, dtype=dtype)
+    whole_step_pmc = None
+    # live HIP-event timing of the kernel groups that make up the step, on their launch stream
+    groups = {}
+    for name, recs in prof.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+        groups[name] = dict(ms=ms, work=sum(w for _, _, w, _ in recs), launches=sum(n for _, _, _, n in recs))
+    gname = "gemm_" + args.dtype
+    gemm = groups.get(gname, dict(ms=0.0, work=0.0, launches=0))
+    gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
+    gemm_roof = {
+        "bound": "mfma", "kernel": "lv_gemm_b16_t256_kernel (256x256x64, the three vocabulary-sized products) / lv_gemm_b16_nt_glds_kernel (128x128x64, the LSTM-sized ones)" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2),
+        "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(gemm_tf / peak_mfma, 4), "traffic": None,
+        "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
+        "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
+    wb = 2.0 if args.dtype == "bf16" else 4.0
+    kinds = ("fwd_enc", "fwd_dec", "bwd_dec", "bwd_enc")
+    lstm_ms = lstm_bytes = 0.0
+    lstm_launches = steps_total = 0
+    per_kind = {}
+    persistent = False
+    for k in kinds:
+        gk = groups.get("lstm_" + k)
+        if not gk:
+            continue
+        Tk = T if k.endswith("enc") else T - 1
+        calls = int(round(gk["work"] / Tk))
+        per_step_w = gk["launches"] > calls                 # launch-per-step kernels re-read W_hh every timestep
+        persistent = persistent or not per_step_w
+        by = lstm_algorithmic_bytes(k, Tk, B, H, wb, per_step_w) * calls
+        per_kind[k] = {"us_per_timestep": round(1e3 * gk["ms"] / gk["work"], 3), "ms_per_step": round(gk["ms"] / args.steps, 4),
+                       "algorithmic_MB_per_call": round(by / calls / 1e6, 1),
+                       "GBs": round(by / (gk["ms"] * 1e-3) / 1e9, 1)}
+        lstm_ms += gk["ms"]; lstm_bytes += by; lstm_launches += gk["launches"]; steps_total += gk["work"]
+    lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
+    lstm_roof = {
+        "bound": "hbm",
+        "kernel": ("lstm_fwd_persist_k16_kernel / lstm_bwd_persist_rs16_kernel (one launch per recurrence, W_hh register-resident, 16x16x32 MFMA with the weights as the A operand, tagged-granule hand-off per timestep kept in the XCD's L2: all-gather of h forward, reduce-scatter of partial dh sums in BPTT)"
+                   if persistent else "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)"),
+        "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
+        "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
+        "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3),
+        "timesteps_per_step": int(steps_total // args.steps),
+        "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
+        "algorithmic_bytes_per_launch": round(lstm_bytes / max(1, lstm_launches)),
+        "per_recurrence": per_kind,
+        "note": "latency-bound chain of dependent timesteps (persistent launches, per timestep at 4 rows per XCD group: one L2 round "
+                "trip for the hand-off ~0.7 us + fragments and 64 MFMAs ~0.75 us + cell update / sends 0.5-1.3 us, "
+                "profiles/r03o_lstm_phase_trace.txt): us_per_timestep is the actionable number, the HBM fraction is what a perfectly "
+                "overlapped version would be bound by"}
+    # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        tr_ = pmc.get(args.workload, {}).get(args.dtype)
+        if tr_:
+            lstm_roof["traffic"] = round(tr_["lstm_persist_MB_per_launch" if persistent else "lstm_MB_per_launch"] * 1e6)
+            gemm_roof["traffic"] = round(tr_["gemm_MB_per_launch"] * 1e6)
+            lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = pmc.get("source_short", "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)")
+            if "whole_step_GB" in tr_:
+                whole_step_pmc = tr_["whole_step_GB"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return gemm_roof, lstm_roof, gemm["ms"], lstm_ms, whole_step_pmc
+
+
+def side_run_text(workload, dev, steps, warmup, dtype="bf16"):
+    """A compact record of one of the other BASELINE.json text configurations, measured in the same process after the headline
+    (same trainer, same kernels, its own model / pool): {value, unit, ms_per_step, dtype, workload, dominant kernel group + its
+    roofline fraction}.  stress = one fixed-K inner loop of `steps` steps (BASELINE.json configs[4])."""
+    from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.factory import build_text_vae, synthetic_batch
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    cfg = WORKLOADS[workload]
+    V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
+    stress = workload == "stress"
+    vae = build_text_vae(V, ni, H, nz, dev, seed=783435)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, precision=dtype)
+    pool = [synthetic_batch(B, T, V, seed=7000 + i).to(dev) for i in range(8 if stress else 16)]
+    tr.prepare_batches(pool)
+    rs = np.random.RandomState(783435)
+    for _ in range(warmup):
+        tr.step(pool[int(rs.randint(0, len(pool)))], 0.1)
+    tr.commit()
+    prof = {}
+    engine.PROFILE = prof
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if stress:
+        n = tr.inner_loop(pool, pool[0], 0.1, np_rng=rs, max_iter=10 ** 9, fixed_k=steps)
+        assert n == steps
+    else:
+        for _ in range(steps):
+            tr.step(pool[int(rs.randint(0, len(pool)))], 0.1)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    engine.PROFILE = None
+    peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    gemm_roof, lstm_roof, gemm_ms, lstm_ms, _ = text_rooflines(prof, steps, workload, dtype, B, T, H, peak)
+    dom = gemm_roof if gemm_ms >= lstm_ms else lstm_roof
+    rec = {"value": round(B * steps / dt, 2), "unit": "seq/s", "ms_per_step": round(1e3 * dt / steps, 4), "dtype": dtype, "steps": steps,
+           "workload": "%s LSTM-VAE aggressive inner step, B=%d, T=%d, V=%d, ni=%d, H=%d, nz=%d%s" % (
+               "yahoo" if stress else workload, B, T, V, ni, H, nz, ", one fixed-K=%d loop (stress)" % steps if stress else ""),
+           "dominant_group": {"bound": dom["bound"], "frac": dom["frac"], "achieved": dom["achieved"], "unit": dom["unit"],
+                              "ms_per_step": dom["ms_per_step"]},
+           "gemm_tflops": gemm_roof["achieved"], "lstm_us_per_timestep": lstm_roof.get("us_per_timestep"),
+           "lstm_ladder_rung": max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))}
+    del tr, vae, pool
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +312,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                     help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side-runs", action="store_true", help="skip the f32 parity side run (profiling passes: only the timed arithmetic runs)")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the f32 parity run and the side runs of the other BASELINE.json configurations (profiling passes: only the timed arithmetic runs)")
     ap.add_argument("--persistent", type=int, default=1, help="forward LSTM recurrences as one persistent launch (bf16 path)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="decoder weight-gradient GEMMs on a side stream under the BPTT chains (auto: on for f32, off for bf16)")
@@ -263,41 +386,15 @@ def main():
         torch.cuda.synchronize(dev)
 
     warm_up()
-    # The persistent LSTM launches need the whole GPU resident at once; if one of them reported a hand-off timeout during
-    # warm-up (something else holds compute units on this box), every rank falls back to the launch-per-step kernels.
-    healthy = 1
-    try:
-        engine.check_persistent_status(tr.enc)
-        engine.check_persistent_status(tr.dec)
-    except Exception as e:      # noqa
-        healthy = 0
-        print("bench: persistent LSTM launch unhealthy (%s); using the launch-per-step kernels" % e, file=sys.stderr)
-    if world > 1:
-        flag = torch.tensor([healthy], dtype=torch.int32, device=dev)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        healthy = int(flag.item())
-    if not healthy and engine.PERSIST16_FLAGS:
-        # first suspect: the hand-off granules kept in the XCD's L2 assume XCD-local groups; write them through instead
-        print("bench: retrying the persistent launches with write-through hand-off stores", file=sys.stderr)
-        engine.PERSIST16_FLAGS = 0
-        engine.reset_persistent_status(tr.enc)
-        engine.reset_persistent_status(tr.dec)
+    # The persistent LSTM launches assume that the whole GPU is resident at once and (rung 0) that a group's workgroups share an
+    # XCD.  A hand-off timeout voids the step on the device; the trainer notices it at this host read, moves down its fallback
+    # ladder (write-through hand-off, then the launch-per-timestep kernels) and replays -- data parallel on all ranks alike.
+    rung = tr.commit()
+    if rung > 0:
+        print("bench: persistent LSTM launches timed out during warm-up; running on ladder rung %d (%s)"
+              % (rung, engine.PERSIST_RUNGS[rung]), file=sys.stderr)
         warm_up()
-        healthy = 1
-        try:
-            engine.check_persistent_status(tr.enc)
-            engine.check_persistent_status(tr.dec)
-        except Exception:      # noqa
-            healthy = 0
-        if world > 1:
-            flag = torch.tensor([healthy], dtype=torch.int32, device=dev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            healthy = int(flag.item())
-    if not healthy:
-        tr.enc.persistent = tr.dec.persistent = False
-        engine.reset_persistent_status(tr.enc)
-        engine.reset_persistent_status(tr.dec)
-        warm_up()
+        tr.commit()
     if world > 1:
         torch.distributed.barrier()
     prof = None
@@ -352,6 +449,7 @@ def main():
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                    "dp_exchange": ((args.dp_mode + ("/bf16-payload" if args.dp_payload == "bf16" else "")) if world > 1 else None),
                    "hipgraph": bool(args.graph),
+                   "lstm_ladder_rung": engine.PERSIST_RUNGS[max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))] if args.dtype == "bf16" else None,
                    "batch_preparation": ("sorted token lists of the embedding backward built once per pool batch, with the batches"
                                          if not args.graph else "none (the captured step sorts inside the graph)")},
     }
@@ -384,72 +482,14 @@ def main():
         "chain_floor_ms": round((4 * T - 2) * 1.45e-3, 3),
         "note": "neither roofline binds at B=32: the floor is the serial chain of 4T-2 dependent LSTM timesteps"}
     if prof:
-        # live HIP-event timing of the kernel groups that make up the step, on their launch stream
-        groups = {}
-        for name, recs in prof.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
-            groups[name] = dict(ms=ms, work=sum(w for _, _, w, _ in recs), launches=sum(n for _, _, _, n in recs))
-        gname = "gemm_" + args.dtype
-        gemm = groups.get(gname, dict(ms=0.0, work=0.0, launches=0))
-        gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
-        gemm_roof = {
-            "bound": "mfma", "kernel": "lv_gemm_b16_t256_kernel (256x256x64, the three vocabulary-sized products) / lv_gemm_b16_nt_glds_kernel (128x128x64, the LSTM-sized ones)" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2),
-            "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(gemm_tf / peak_mfma, 4), "traffic": None,
-            "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
-            "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
-        wb = 2.0 if args.dtype == "bf16" else 4.0
-        kinds = ("fwd_enc", "fwd_dec", "bwd_dec", "bwd_enc")
-        lstm_ms = lstm_bytes = 0.0
-        lstm_launches = steps_total = 0
-        per_kind = {}
-        persistent = False
-        for k in kinds:
-            gk = groups.get("lstm_" + k)
-            if not gk:
-                continue
-            Tk = T if k.endswith("enc") else T - 1
-            calls = int(round(gk["work"] / Tk))
-            per_step_w = gk["launches"] > calls                 # launch-per-step kernels re-read W_hh every timestep
-            persistent = persistent or not per_step_w
-            by = lstm_algorithmic_bytes(k, Tk, B, H, wb, per_step_w) * calls
-            per_kind[k] = {"us_per_timestep": round(1e3 * gk["ms"] / gk["work"], 3), "ms_per_step": round(gk["ms"] / args.steps, 4),
-                           "algorithmic_MB_per_call": round(by / calls / 1e6, 1),
-                           "GBs": round(by / (gk["ms"] * 1e-3) / 1e9, 1)}
-            lstm_ms += gk["ms"]; lstm_bytes += by; lstm_launches += gk["launches"]; steps_total += gk["work"]
-        lstm_gbs = lstm_bytes / (lstm_ms * 1e-3) / 1e9 if lstm_ms > 0 else 0.0
-        lstm_roof = {
-            "bound": "hbm",
-            "kernel": ("lstm_fwd_persist_k16_kernel / lstm_bwd_persist_rs16_kernel (one launch per recurrence, W_hh register-resident, 16x16x32 MFMA with the weights as the A operand, tagged-granule hand-off per timestep kept in the XCD's L2: all-gather of h forward, reduce-scatter of partial dh sums in BPTT)"
-                       if persistent else "lstm_step_{fwd,bwd_elem,bwd_mm}_kernel (one launch per timestep and stage)"),
-            "achieved": round(lstm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(lstm_gbs / PEAK_HBM_GBS, 4),
-            "traffic": None, "launches_per_step": lstm_launches // args.steps, "ms_per_step": round(lstm_ms / args.steps, 4),
-            "avg_launch_us": round(1e3 * lstm_ms / max(1, lstm_launches), 3),
-            "timesteps_per_step": int(steps_total // args.steps),
-            "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
-            "algorithmic_bytes_per_launch": round(lstm_bytes / max(1, lstm_launches)),
-            "per_recurrence": per_kind,
-            "note": "latency-bound chain of dependent timesteps (persistent launches, per timestep at 4 rows per XCD group: one L2 round "
-                    "trip for the hand-off ~0.7 us + fragments and 64 MFMAs ~0.75 us + cell update / sends 0.5-1.3 us, "
-                    "profiles/r03o_lstm_phase_trace.txt): us_per_timestep is the actionable number, the HBM fraction is what a perfectly "
-                    "overlapped version would be bound by"}
-        # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            tr_ = pmc.get(args.workload, {}).get(args.dtype)
-            if tr_:
-                lstm_roof["traffic"] = round(tr_["lstm_persist_MB_per_launch" if persistent else "lstm_MB_per_launch"] * 1e6)
-                gemm_roof["traffic"] = round(tr_["gemm_MB_per_launch"] * 1e6)
-                lstm_roof["traffic_source"] = gemm_roof["traffic_source"] = pmc.get("source_short", "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)")
-                if "whole_step_GB" in tr_:
-                    out["whole_step"]["hbm_GB_per_step_pmc"] = tr_["whole_step_GB"]
-        except (OSError, ValueError, KeyError):
-            pass
-        if gemm["ms"] >= lstm_ms:
+        gemm_roof, lstm_roof, gemm_ms, lstm_ms, pmc_gb = text_rooflines(prof, args.steps, args.workload, args.dtype, B, T, H, peak_mfma)
+        if pmc_gb is not None:
+            out["whole_step"]["hbm_GB_per_step_pmc"] = pmc_gb
+        if gemm_ms >= lstm_ms:
             out["roofline"], out["roofline_secondary"] = gemm_roof, lstm_roof
         else:
             out["roofline"], out["roofline_secondary"] = lstm_roof, gemm_roof
-        out["rest_ms_per_step"] = round(1e3 * step_s - (gemm["ms"] + lstm_ms) / args.steps, 4)
+        out["rest_ms_per_step"] = round(1e3 * step_s - (gemm_ms + lstm_ms) / args.steps, 4)
     else:
         out["roofline"] = {"bound": "mfma", "achieved": round(step_flops / step_s / 1e12, 2),
                            "peak": peak_mfma, "unit": "TFLOP/s",
@@ -471,6 +511,23 @@ def main():
         tr.enc.precision = tr.dec.precision = args.dtype
         out["f32_parity_path"] = {"value": round(B * n32 / d32, 2), "unit": "seq/s", "ms_per_step": round(1e3 * d32 / n32, 4),
                                   "steps": n32, "note": "exact-f32 MFMA GEMMs; ELBO parity <= 1e-4 vs the reference CPU path"}
+    if world == 1 and args.workload == "yahoo" and args.dtype == "bf16" and not args.graph and not args.no_side_runs:
+        # the other BASELINE.json GPU configurations, in front of the driver: configs[1] Yelp, configs[4] stress (one fixed-K = 50
+        # loop), configs[3] Omniglot (hipGraph replay; kernel groups from an eager pass) -- compact records, ~10 s together
+        side = {}
+        try:
+            side["yelp"] = side_run_text("yelp", dev, steps=10, warmup=3)
+            side["stress"] = side_run_text("stress", dev, steps=50, warmup=2)
+            oa = argparse.Namespace(**vars(args))
+            oa.graph, oa.dtype, oa.steps, oa.warmup, oa.pool = 1, "f32", 20, 5, 16
+            om = measure_omniglot(oa, dev, 0, 1, cpu_baseline=False, profile_eager=True)
+            side["omniglot"] = {"value": om["value"], "unit": om["unit"], "ms_per_step": om["ms_per_step"], "dtype": om["dtype"],
+                                "steps": om["steps"], "workload": om["config"]["workload"] + ", hipGraph replay",
+                                "dominant_group": {k: om["roofline"].get(k) for k in ("bound", "frac", "achieved", "unit", "ms_per_step", "kernel")},
+                                "other_groups": [{k: g.get(k) for k in ("bound", "frac", "ms_per_step")} for g in om.get("roofline_other_groups", [])]}
+        except Exception as e:      # noqa  (a side run must never cost the headline line)
+            side["error"] = repr(e)[:300]
+        out["side_runs"] = side
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline_and_elbo(out, args, vae, pool, kl_weight, V, ni, H, nz, B, T, dev, value)
     print(json.dumps(out))

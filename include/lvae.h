@@ -109,47 +109,17 @@ int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, fl
  * lv_cvt_bf16_gates_f32 image of W_ih and lv_gate_interleave_f32-ed epilogue addends. */
 int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                         const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
-/* The same forward recurrence as ONE persistent launch: 256 workgroups in 8 XCD-sized groups, each group carries a
- * slice of the batch through all T steps with its slice of W_hh held in registers and hands h_t around inside the
- * group through tagged 8-byte granules (lv_lstm_persist.hip).  gx unit-major as for lv_lstm_fwd_bf16_ug; wpk = the
- * packed register image of W_hh built by lv_lstm_persist_pack(whh, wpk, 0, H) (lv_lstm_persist_wpk_floats() floats; a
- * caller whose weights do not change between calls -- the decoder during the aggressive inner loop, text.py:371-400 --
- * packs once); xch = exchange buffer of lv_lstm_persist_xch_floats() floats; *status (device int, zeroed by the caller)
- * becomes non-zero if a hand-off timed out.  LV_ERR_UNSUPPORTED unless H == 1024, B <= 64 and the device has >= 256
- * CUs: use lv_lstm_fwd_bf16_ug then. */
-long lv_lstm_persist_wpk_floats(void);
-long lv_lstm_persist_xch_floats(void);
-int lv_lstm_persist_pack(const float* whh, float* wpk, int backward, int H, void* stream);
-int lv_lstm_fwd_bf16_persist(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
-                             const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
-                             int T, int B, int H, void* stream);
-/* the same recurrence with the contraction split over the workgroup's waves (weights packed with backward = 3): each wave
- * gathers and multiplies its own K quarter, the quarter products meet in LDS after ONE barrier; same arguments and outputs (up
- * to f32 summation order). */
-int lv_lstm_fwd_bf16_persist_ks(const float* gx, const float* wpk, float* hs, float* cs, float* gates,
-                             const uint8_t* dmask, float dscale, float* hdrop, float* xch, int* status,
-                             int T, int B, int H, void* stream);
-/* BPTT as one persistent launch (same decomposition; dG[t] is what travels between steps and the gate-gradient math of
- * a step runs where its dh is completed, so a timestep is one phase instead of two launches).  Arguments as
- * lv_lstm_bwd_bf16_img with wpk = lv_lstm_persist_pack(whh, wpk, 1, H), xch / status as above; dG16 16-byte aligned.
- * LV_ERR_UNSUPPORTED unless H == 1024, B <= 32, >= 256 CUs. */
-int lv_lstm_bwd_bf16_persist(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                             const float* wpk, const float* gates, const float* hs, const float* cs,
-                             float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
-                             int tanh_init, int T, int B, int H, void* stream);
-/* the same recurrence in its reduce-scatter form (weights packed with lv_lstm_persist_pack(..., backward = 2)): every
- * workgroup sends partial sums of dh to the owners of the units instead of gathering all of dG -- a quarter of the hand-off
- * granules per timestep; same arguments and outputs (up to f32 summation order). */
-int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,
-                             const float* wpk, const float* gates, const float* hs, const float* cs,
-                             float* dG, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
-                             int tanh_init, int T, int B, int H, void* stream);
-/* The persistent recurrences for up to 16 batch rows per XCD group (lv_lstm_persist16.hip; nn.LSTM of enc_lstm.py:55 /
- * dec_lstm.py:104, forward and BPTT): R rows per group (1 <= R <= 16, 8 R >= B), groups [0, ceil(B / R)) carry the batch and the
- * workgroups of the remaining groups return at once -- B = 128 runs 16 rows on each of the 8 groups (BASELINE.json configs[4]),
- * and R = 8 at B = 32 runs a recurrence on FOUR XCDs, leaving the other four to concurrent kernels.  Contraction on the
- * 16 x 16 x 32 MFMA with the weights as the A operand.  Weight images: lv_lstm_persist16_pack(whh, wpk, backward, H)
- * (lv_lstm_persist_wpk_floats() floats); exchange buffer: lv_lstm_persist16_xch_floats() floats; *status as above.  No in-kernel
+/* The same recurrences as ONE persistent launch each (lv_lstm_persist16.hip; nn.LSTM of enc_lstm.py:55 / dec_lstm.py:104, forward
+ * and BPTT): 256 workgroups in 8 XCD-sized groups (blockIdx % 8), each group carries a slice of the batch through all T steps with
+ * its slice of W_hh held in registers and hands h_t (forward: all-gather) or partial dh sums (BPTT: reduce-scatter) around inside
+ * the group through tagged 8-byte granules.  R rows per group (1 <= R <= 16, 8 R >= B), groups [0, ceil(B / R)) carry the batch and
+ * the workgroups of the remaining groups return at once -- B = 32 runs 4 rows on each of the 8 groups, B = 128 sixteen (BASELINE.json
+ * configs[4]), and R = 8 at B = 32 runs a recurrence on FOUR XCDs.  Contraction on the 16 x 16 x 32 MFMA with the weights as the A
+ * operand.  gx unit-major as for lv_lstm_fwd_bf16_ug.  Weight images: lv_lstm_persist16_pack(whh, wpk, backward, H)
+ * (lv_lstm_persist16_wpk_floats() floats each; a caller whose weights do not change between calls -- the decoder during the
+ * aggressive inner loop, text.py:371-400 -- packs once); exchange buffer: lv_lstm_persist16_xch_floats() floats; *status (device
+ * int, zeroed by the caller) becomes non-zero if a bounded hand-off spin ran out (see lv_clip_norm2_txn_f32 for what the fused
+ * driver does about it).  No in-kernel
  * dropout (the caller applies dropout_out on the bf16 images of h and once on dO).  flags bit 0: the hand-off granules are stored
  * without the agent-scope write-through, i.e. they stay in the XCD's L2 instead of travelling to memory (valid while every group is
  * XCD-local, which the round-robin workgroup placement of a 256-CU device gives; a violated assumption shows up as a hand-off
@@ -160,6 +130,7 @@ int lv_lstm_bwd_bf16_persist_rs(const float* dh_ext, const float* dh_last, const
  * every timestep of every array is a different page at B = 128, and the address translations of a block of loads serialise in
  * front of the next hand-off poll: 1.5 us of a 7.9 us BPTT timestep.)  hs: [T + 1][B][H] as everywhere; cs: [T + 1][B][H], of which
  * these kernels read slot 0 (the initial state) and write slot T (the final one) only. */
+long lv_lstm_persist16_wpk_floats(void);
 long lv_lstm_persist16_xch_floats(void);
 long lv_lstm_persist16_saved_floats(int T, int R);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
@@ -283,6 +254,22 @@ int lv_clip_norm2_f32(const float* g1, long n1, const float* g2, long n2, float*
 int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
                     void* stream);
 int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream);
+/* The same clip + update with a device-side TRANSACTION GATE (round 4).  The fused driver keeps the reference's per-iteration
+ * host read (text.py:381 loss.sum().item()) off the step, so nothing on the host looks at a step before its update is applied
+ * (text.py:385-387); a persistent LSTM launch that hit its bounded hand-off spin must therefore be caught on the DEVICE: the gate
+ * runs in the clip coefficient's single thread, reads the engines' status words (and, data parallel, a guard element of the
+ * exchanged gradient buffer that lv_txn_guard_f32 set), and either commits the step -- txn[1] += 1, acc[0..2] += the pending
+ * (loss, rec, kl) sums txn[2..4] that lv_loss_assemble_f32 left -- or raises the sticky void flag txn[0], under which
+ * lv_sgd_step_txn_f32 / lv_scale_txn_f32 are no-ops.  txn: device float[5]; acc: device float[3] or NULL; status / guard may be NULL. */
+int lv_clip_norm2_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
+                          float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
+                          const float* guard, float* txn, float* acc, void* stream);
+int lv_clip_coef_txn_f32(const float* sumsq_dev, float max_norm, float* coef_dev, float* norm_out_dev, const int* status1,
+                         const int* status2, const float* guard, float* txn, float* acc, void* stream);
+int lv_txn_guard_f32(const int* status1, const int* status2, float* guard, void* stream);
+int lv_sgd_step_txn_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
+                        const float* void_flag_dev, void* stream);
+int lv_scale_txn_f32(float* x, long n, const float* coef_dev, const float* void_flag_dev, void* stream);
 int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float* lr_dev, const float* coef_dev,
                      const float* step_dev, float beta1, float beta2, float eps, int write_back_clipped, void* stream);
 

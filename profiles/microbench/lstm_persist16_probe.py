@@ -1,4 +1,4 @@
-"""Microbenchmark (measurement tooling): the persistent recurrences of lv_lstm_persist16.hip against the 4-row kernels, by rows per
+"""Microbenchmark (measurement tooling): the persistent recurrences of lv_lstm_persist16.hip by rows per
 XCD group -- us per timestep of the forward and the BPTT at T = 200 -- and experiment A of the round-2 review: a B = 32
 recurrence on FOUR XCD groups (8 rows each) with a large GEMM queued beside it on a second stream (does the GEMM get the four
 idle XCDs, and what does the recurrence pay?)."""
@@ -14,13 +14,11 @@ else:
     lib = _lib.load()
 T, H = 200, 1024
 whh = (torch.rand(4 * H, H, device=dev) * 2 - 1) * 0.03
-n = lib.lv_lstm_persist_wpk_floats()
-wf4, wb4, wf16, wb16 = (torch.empty(n, device=dev) for _ in range(4))
-lib.lv_lstm_persist_pack(P(whh), P(wf4), 3, H, s)
-lib.lv_lstm_persist_pack(P(whh), P(wb4), 2, H, s)
+n = lib.lv_lstm_persist16_wpk_floats()
+wf16, wb16 = (torch.empty(n, device=dev) for _ in range(2))
 lib.lv_lstm_persist16_pack(P(whh), P(wf16), 0, H, s)
 lib.lv_lstm_persist16_pack(P(whh), P(wb16), 1, H, s)
-xch = torch.empty(max(lib.lv_lstm_persist_xch_floats(), lib.lv_lstm_persist16_xch_floats()), device=dev)
+xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
 st = torch.zeros(1, dtype=torch.int32, device=dev)
 
 
@@ -48,15 +46,9 @@ print("forward / BPTT, us per timestep (T = %d)" % T)
 for B, R in ((32, 4), (32, 8), (32, 16), (64, 8), (128, 16)):
     gx, hs, cs, gates, dO, dG16, dGsum, dc0 = bufs(B)
     line = "B=%3d R=%2d (%d groups): " % (B, R, (B + R - 1) // R)
-    if R == 4 and B <= 32:
-        a = t(lambda: lib.lv_lstm_fwd_bf16_persist_ks(P(gx), P(wf4), P(hs), P(cs), P(gates), None, 1.0, None, P(xch), P(st), T, B, H, s))
-        line += "fwd ks(4x4x4) %.2f | " % (a / T)
     for fl in (0, 1):
         a = t(lambda: lib.lv_lstm_fwd_bf16_persist16(P(gx), P(wf16), P(hs), P(cs), P(gates), P(xch), P(st), T, B, R, fl, H, s))
         line += "fwd k16%s %.2f | " % ("/L2" if fl else "", a / T)
-    if R == 4 and B <= 32:
-        a = t(lambda: lib.lv_lstm_bwd_bf16_persist_rs(P(dO), None, None, 1.0, P(wb4), P(gates), P(hs), P(cs), None, P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, H, s))
-        line += "bwd rs(4x4x4) %.2f | " % (a / T)
     for fl in (0, 1):
         a = t(lambda: lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb16), P(gates), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(st), None, P(dc0), 1, T, B, R, fl, H, s))
         line += "bwd rs16%s %.2f | " % ("/L2" if fl else "", a / T)

@@ -15,7 +15,7 @@ lib = _lib.bind(cdll, "liblvae_trace.so")
 dev = torch.device("cuda:0"); s = stream_ptr(dev)
 T, H = 200, 1024
 whh = (torch.rand(4 * H, H, device=dev) * 2 - 1) * 0.03
-n = lib.lv_lstm_persist_wpk_floats()
+n = lib.lv_lstm_persist16_wpk_floats()
 wf, wb = torch.empty(n, device=dev), torch.empty(n, device=dev)
 lib.lv_lstm_persist16_pack(P(whh), P(wf), 0, H, s)
 lib.lv_lstm_persist16_pack(P(whh), P(wb), 1, H, s)

@@ -282,13 +282,45 @@ def check_token_sort_cache_follows_the_batch(device, V=97, ni=12, H=20, nz=4, B=
     def overwrite():
         x.copy_(xb)                 # same tensor object, new contents
         return x
-    tr, got = grads_after([x, x, overwrite, lambda: xb.clone()])
+    y = xa.clone()
+
+    def behind_the_counter():
+        y.data.copy_(xb)            # a write torch's version counter does not see: the documented contract asks for invalidate_batch()
+        holder["tr"].invalidate_batch(y)
+        return y
+    holder = {}
+
+    def first():
+        return y
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    tr = AggressiveTextTrainer(vae, lr=0.0, clip=5.0)
+    holder["tr"] = tr
+    got = []
+    for xx in [x, x, overwrite, lambda: xb.clone(), first, behind_the_counter]:
+        tr.step(xx() if callable(xx) else xx, 0.5, noise=noise)
+        got.append({k: p.grad.detach().cpu().clone() for k, p in vae.named_parameters() if "embed" in k})
     hits = tr.enc._sorts.get(x, (T, B))
     assert hits is not None                                     # the unchanged tensor is served from the cache ...
     for k in ref[0]:
         assert torch.equal(got[0][k], ref[0][k]) and torch.equal(got[1][k], ref[0][k]), k
         assert torch.equal(got[2][k], ref[1][k]), k            # ... the overwritten one is sorted again
         assert torch.equal(got[3][k], ref[1][k]), k            # and so is a new tensor
+        assert torch.equal(got[4][k], ref[0][k]) and torch.equal(got[5][k], ref[1][k]), k      # invalidate_batch() after a hidden write
+    # an int32 id batch is converted (the in-place fast path takes int64 only)
+    tr.step(xa.to(torch.int32), 0.5, noise=noise)
+    g32 = {k: p.grad.detach().cpu().clone() for k, p in vae.named_parameters() if "embed" in k}
+    for k in ref[0]:
+        assert torch.equal(g32[k], ref[0][k]), k
+    # least-recently-used eviction instead of dropping everything
+    c = tr.enc._sorts
+    old_limit, type(c).LIMIT = type(c).LIMIT, 3
+    try:
+        keep = [O.synthetic_batch(B, T, V, seed=80 + i).to(device) for i in range(5)]
+        for t_ in keep:
+            tr.step(t_, 0.5, noise=noise)
+        assert len(c.map) == 3 and c.get(keep[4], (T, B)) is not None and c.get(keep[2], (T, B)) is not None and c.get(keep[0], (T, B)) is None
+    finally:
+        type(c).LIMIT = old_limit
 
 
 def check_weight_images_follow_rebound_parameters(device, V=333, ni=24, H=64, nz=8, B=7, T=11):
@@ -404,6 +436,76 @@ def check_update_both_and_fixed_k(device, V=97, ni=12, H=20, nz=4, B=6, K=4, pre
     sd = vae.state_dict()
     for k in ALL_KEYS:
         assert rel_err(sd[k], Pr[k]) < tol, (k, rel_err(sd[k], Pr[k]))
+
+
+def check_transactional_recovery(device, V=97, ni=12, H=20, nz=4, B=6, K=5, precision="f32", fault_at=(2,), rungs_down=1,
+                                 use_graph=False):
+    """A persistent-launch hand-off timeout must never reach the weights (text.py:385-387: an update is computed from complete
+    recurrences or not at all).  K inner steps + the joint decoder step with injected noise; before the steps listed in
+    `fault_at` an engine's status word is set -- what a timed-out recurrence leaves behind.  The device-side gate then voids that
+    step and every step queued behind it; the next host read moves both engines `rungs_down` rungs down the fallback ladder
+    (the fault is re-raised through on_demote until then) and replays the voided steps.  Weights, committed report sums and the
+    step count must equal a run that never saw a fault and ran on the final rung from the first voided step on -- bit for bit
+    when the rung's arithmetic is the same (the test backend; persistent rung 0 -> 1 on the GPU), else to `tol`."""
+    import numpy as np
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd import engine
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    P = O.random_params(V, ni, H, nz, seed=51, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    Ts = [5, 8, 6] if H < 1024 else [12, 9, 14]
+    batches = [O.synthetic_batch(B, T, V, seed=60 + i).to(device) for i, T in enumerate(Ts)]
+    klw = 0.7
+    picks = [0] + [int(i) for i in np.random.RandomState(9).randint(0, len(batches), size=K)]
+
+    def noise_for(step, x):
+        e, a, b = O.draw_noise(x.shape[0], x.shape[1], ni, H, nz, seed=700 + step)
+        return e.to(device), a.to(torch.uint8).to(device), b.to(torch.uint8).to(device)
+
+    def run(faulty):
+        vae = build_vae(V, ni, H, nz, device, params=P)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision, use_graph=use_graph)
+        log = {"demotions": []}
+        if not faulty:
+            # the clean comparison run: on the rung the faulty run ends on, from the first step on
+            for _ in range(rungs_down):
+                for e in (tr.enc, tr.dec):
+                    engine.demote_persistent(e)
+        else:
+            def on_demote(rung):
+                log["demotions"].append(rung)
+                if len(log["demotions"]) < rungs_down:
+                    tr.dec.status.fill_(300)            # the next rung "times out" as well
+            tr.on_demote = on_demote
+        sums = []
+        tr.reset_stats()
+        for step in range(K):
+            x = batches[picks[step]]
+            if faulty and step in fault_at:
+                (tr.enc if step % 2 == 0 else tr.dec).status.fill_(100 + step)
+            tr.step(x, klw, noise=noise_for(step, x))
+            if step == K - 2:
+                sums.append(tr.read_stats())            # a host read in the middle: settles what is queued so far
+        tr.step(batches[1], klw, noise=noise_for(K, batches[1]), update="decoder")
+        sums.append(tr.read_stats())
+        return vae.state_dict(), sums, tr, log
+
+    sd_f, sums_f, tr_f, log = run(True)
+    sd_c, sums_c, tr_c, _ = run(False)
+    assert log["demotions"] == list(range(1, rungs_down + 1)), log
+    assert tr_f.recoveries == rungs_down and tr_c.recoveries == 0
+    assert engine.persist_rung(tr_f.enc) == engine.persist_rung(tr_c.enc) == rungs_down
+    assert int(tr_f.enc.status.item()) == 0 and int(tr_f.dec.status.item()) == 0
+    first_fault = min(fault_at)
+    exact = first_fault == 0 or torch.device(device).type != "cuda" or precision == "f32" or rungs_down == 1
+    for k in ALL_KEYS:
+        if exact:
+            assert torch.equal(sd_f[k], sd_c[k]), k
+        else:
+            assert rel_err(sd_f[k], sd_c[k]) < 2e-3, (k, rel_err(sd_f[k], sd_c[k]))
+    for a, b in zip(sums_f, sums_c):
+        for key in ("loss_sum", "rec_sum", "kl_sum"):
+            assert abs(a[key] - b[key]) <= (0.0 if exact else 2e-3 * abs(b[key])), (key, a[key], b[key])
+    return tr_f
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -70,3 +70,10 @@ def test_pixelcnn_incremental_sampling_emulated(emu_backend):
     """Pixel-at-a-time sampling == full forward, bit for bit, on the emulator build (one image; the 784-full-pass comparison is the
     GPU test)."""
     pc.check_pixelcnn_incremental_sampling("cpu", B=1, compare_full_path=False)
+
+
+@pytest.mark.parametrize("fault_at,rungs_down", [((2,), 1), ((0,), 2), ((1, 3), 2)])
+def test_voided_steps_are_replayed_down_the_ladder_emulated(emu_backend, fault_at, rungs_down):
+    """The transaction gate of the fused step (lv_clip_norm2_txn_f32 + lv_sgd_step_txn_f32) and the trainer's replay, with the
+    status words a timed-out persistent launch would leave set by hand: the weights equal a run that never saw the fault."""
+    pc.check_transactional_recovery("cpu", fault_at=fault_at, rungs_down=rungs_down)

@@ -28,8 +28,9 @@ def test_gemm_b16(emu_backend, cfg):
 
 @pytest.mark.parametrize("cfg", [(0, 130, 140, 37, False), (1, 70, 130, 50, False), (1, 300, 260, 200, False), (0, 258, 100, 1100, True),
                                  (1, 131, 270, 1100, True), (0, 520, 30, 128, False)])
-def test_gemm_b16_tile256(emu_backend, cfg):
-    K.test_gemm_b16_tile256(emu_backend, CPU, *cfg)
+@pytest.mark.parametrize("tile", [256, 257])
+def test_gemm_b16_tile256(emu_backend, cfg, tile):
+    K.test_gemm_b16_tile256(emu_backend, CPU, *cfg, tile)
 
 
 @pytest.mark.parametrize("R,C", [(1, 1), (64, 64), (70, 130), (200, 33)])
@@ -174,8 +175,9 @@ def test_gemm_b16_nll_fused(emu_backend, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 600, 64)])
-def test_gemm_b16_nll_fused_tile256(emu_backend, cfg):
-    K.test_gemm_b16_nll_fused_tile256(emu_backend, CPU, *cfg)
+@pytest.mark.parametrize("tile", [256, 257])
+def test_gemm_b16_nll_fused_tile256(emu_backend, cfg, tile):
+    K.test_gemm_b16_nll_fused_tile256(emu_backend, CPU, *cfg, tile)
 
 
 @pytest.mark.parametrize("cfg", [(2, 7, True), (1, 5, True), (1, 3, False), (20, 7, True), (40, 3, True)])
@@ -196,7 +198,8 @@ def test_conv_bnstat(emu_backend, cfg):
 @pytest.mark.parametrize("T,B,R", [(3, 8, 1), (2, 20, 3), (2, 18, 6), (2, 27, 14)])
 def test_lstm_fwd_persistent16_emulated(emu_backend, T, B, R):
     """lv_lstm_persist16.hip (R rows per XCD group, 16x16x32 MFMA with the weights as the A operand), all three instantiations
-    (R <= 4 / 8 / 16), ragged last groups, groups left empty."""
+    (R <= 4 / 8 / 16), ragged last groups, groups left empty -- every workgroup of the grid live at once (fibers; hand-off polls
+    yield)."""
     K.test_lstm_fwd_persistent16(emu_backend, CPU, T, B, R, 0)
 
 
@@ -204,20 +207,6 @@ def test_lstm_fwd_persistent16_emulated(emu_backend, T, B, R):
                                  (2, 27, 14, True, True, False)])
 def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg, 0)
-
-
-def test_lstm_fwd_persistent_emulated(emu_backend):
-    """The persistent forward recurrence with every workgroup of its grid live at once (fibers; hand-off polls yield)."""
-    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True)
-    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 20, True)              # 3 batch rows per group (ragged last group)
-    K.test_lstm_fwd_persistent(emu_backend, CPU, 2, 45, False)             # 6 rows per group: two 4-row passes
-    K.test_lstm_fwd_persistent(emu_backend, CPU, 3, 3, True, variant="cols")
-
-
-@pytest.mark.parametrize("cfg", [(3, 3, True, True, True, False, "rs"), (2, 2, False, False, True, True, "rs"),
-                                 (10, 5, True, False, True, True, "rs"), (4, 3, True, True, True, False, "ag")])
-def test_lstm_bwd_persistent_emulated(emu_backend, cfg):
-    K.test_lstm_bwd_persistent(emu_backend, CPU, *cfg)
 
 
 @pytest.mark.parametrize("cfg", [(5, 3, 70, 50, True), (3, 33, 128, 90, False)])

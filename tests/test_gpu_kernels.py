@@ -190,11 +190,12 @@ def test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=None, tile=0):
     (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False), (0, 3000, 2100, 512, False),
     (1, 1100, 1200, 2304, True), (0, 4200, 4100, 320, True),
 ])
-def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split):
-    """The 256 x 256 x 64 kernel (forced): same checks; with a workspace the tail tiles (tiles % 256) are cut along K and reduced in
-    piece order.  Bit-identical to the 128 x 128 chain when K is a multiple of 64 and nothing is cut (the ragged K tile is
-    accumulated first here, last there)."""
-    test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=(not split) and K % 64 == 0, tile=256)
+@pytest.mark.parametrize("tile", [256, 257])
+def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split, tile):
+    """The 256 x 256 x 64 kernel (forced; 256 = lockstep K loop, 257 = the two wave groups half a k-step apart): same checks; with a
+    workspace the tail tiles (tiles % 256) are cut along K and reduced in piece order.  Bit-identical to the 128 x 128 chain when K
+    is a multiple of 64 and nothing is cut (the ragged K tile is accumulated first here, last there)."""
+    test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=(not split) and K % 64 == 0, tile=tile)
 
 
 def test_gemm_b16_alignment_errors(lib, hip_device):
@@ -348,87 +349,101 @@ def _saved16_unpack(saved, T, B, R, H=1024):
     return g[:, :B].contiguous(), c[:, :B].contiguous()
 
 
-@pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (1, 5, False), (9, 64, True), (40, 32, False), (3, 13, True)])
-def test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="ks", R=None, flags=0):
-    """The one-launch persistent forward (H = 1024) against the float64 restatement, at the bf16-recurrence tolerance,
-    and against the launch-per-step kernel fed the same unit-major gx.  variant "k16" = lv_lstm_persist16.hip with R batch rows
-    per XCD group (no in-kernel dropout there: use_mask must be off)."""
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def _lstm_ref_bf16_recurrent(gx, whh, h0, c0):
+    """float64 LSTM whose recurrent product sees what the bf16 kernels feed the matrix pipe: W_hh and h_{t-1} rounded to bf16
+    (RNE), everything else exact.  A kernel then differs from it by f32 accumulation order, the hardware exp / reciprocal of the
+    activations (~1e-6) and by what an h element that rounds the other way moves downstream -- not by the 2^-9 operand rounding
+    itself, so the comparison can be held to 1e-3 instead of the bf16 noise floor."""
+    T = gx.shape[0]
+    w = _bf16_round(whh.float()).double()
+    h, c = h0, c0
+    hs, cs = [h0], [c0]
+    for t in range(T):
+        a = gx[t] + _bf16_round(h.float()).double() @ w.t()
+        i, f, g, o = a.chunk(4, -1)
+        i, f, o, g = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(g)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        hs.append(h)
+        cs.append(c)
+    return torch.stack(hs), torch.stack(cs)
+
+
+@pytest.mark.parametrize("T,B,R", [(6, 32, 4), (9, 32, 8), (5, 64, 8), (7, 128, 16), (40, 32, 8), (3, 13, 2), (4, 100, 13), (12, 32, 16),
+                                   (1, 5, 5)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_lstm_fwd_persistent16(lib, hip_device, T, B, R, flags):
+    """The one-launch persistent forward (lv_lstm_persist16.hip, H = 1024): R rows per XCD group -- 8 groups x 4 (the default
+    shape), 4 groups x 8 and 2 groups x 16 (a B = 32 recurrence on half / a quarter of the chip), 8 x 8 and 8 x 16 (B = 64 / the
+    stress configuration's B = 128), ragged slices; flags 1 = hand-off granules kept in the XCD's L2.  Held to 1e-3 twice: against
+    the float64 recurrence on bf16-rounded recurrent operands, and against the launch-per-step kernel fed the same unit-major gx
+    (same operands, different f32 summation order) -- the bound the T = 200 test below uses, which is what a half-written
+    accumulator or a stale granule fails (the former `tol = 300` admitted a 2 % error)."""
     dev, H = hip_device, 1024
     g = torch.Generator().manual_seed(T * 100 + B)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
     c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
     h0 = torch.tanh(c0)
-    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(dev)
-    hs_r, cs_r, out_r = _lstm_ref(gx.double(), whh.double(), h0.double(), c0.double(), mask if use_mask else None, 2.0)
+    hs_r, cs_r = _lstm_ref_bf16_recurrent(gx.double(), whh.double(), h0.double(), c0.double())
     perm = torch.arange(4 * H).view(4, H).t().reshape(-1).to(dev)
     gxu = gx[:, :, perm].contiguous()
-    m8 = mask.to(torch.uint8).contiguous()
     res = []
     for persistent in (True, False):
         hs = torch.zeros(T + 1, B, H, device=dev)
         cs = torch.zeros(T + 1, B, H, device=dev)
         hs[0], cs[0] = h0, c0
         gates = torch.empty(T, B, 4 * H, device=dev)
-        hdrop = torch.empty(T, B, H, device=dev)
-        if persistent and variant == "k16":
-            assert not use_mask
-            wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
+        if persistent:
+            wpk = torch.full((lib.lv_lstm_persist16_wpk_floats(),), float("nan"), device=dev)
             ws = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 0, H, _s(dev))
-            R16 = R if R is not None else (B + 7) // 8
-            saved = torch.full((lib.lv_lstm_persist16_saved_floats(T, R16),), float("nan"), device=dev)
-            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(ws), P(status), T, B, R16, flags, H, _s(dev))
+            saved = torch.full((lib.lv_lstm_persist16_saved_floats(T, R),), float("nan"), device=dev)
+            lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(ws), P(status), T, B, R, flags, H, _s(dev))
             assert int(status.item()) == 0
-            hdrop = hs[1:].clone()
             # gates and cell states come back in the kernels' workgroup-major buffer; canonical cs holds the final state only
-            gates, c_t = _saved16_unpack(saved, T, B, R16)
+            gates, c_t = _saved16_unpack(saved, T, B, R)
             assert torch.equal(cs[T], c_t[T - 1]) and float(cs[1:T].abs().max() if T > 1 else 0.0) == 0.0
             cs[1:] = c_t
             gates = gates.view(T, B, 4 * H)
-        elif persistent:
-            wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
-            ws = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_persist_pack(P(whh), P(wpk), 3 if variant == "ks" else 0, H, _s(dev))
-            (lib.lv_lstm_fwd_bf16_persist_ks if variant == "ks" else lib.lv_lstm_fwd_bf16_persist)(P(gxu), P(wpk), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
-                                         P(ws), P(status), T, B, H, _s(dev))
-            assert int(status.item()) == 0
         else:
             ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
-            lib.lv_lstm_fwd_bf16_ug(P(gxu), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop),
-                                    P(ws), T, B, H, _s(dev))
-        tol = 300.0
-        assert float((hs.double() - hs_r).abs().max()) < 2e-5 * tol
-        assert float((cs.double() - cs_r).abs().max()) < 2e-5 * tol
-        assert float((hdrop.double() - out_r).abs().max()) < 4e-5 * tol
+            hdrop = torch.empty(T, B, H, device=dev)
+            lib.lv_lstm_fwd_bf16_ug(P(gxu), P(whh), P(hs), P(cs), P(gates), None, 1.0, P(hdrop), P(ws), T, B, H, _s(dev))
+        assert float((hs.double() - hs_r).abs().max()) < 1e-3
+        assert float((cs.double() - cs_r).abs().max()) < 1e-3 * max(1.0, float(cs_r.abs().max()))
         res.append((hs.clone(), cs.clone(), gates.clone()))
-    # the two realisations differ only in f32 summation order of the recurrent product (and what that flips downstream)
-    for a, b in zip(*res):
-        assert float((a - b).abs().max()) < 6e-3
+    for a, b, what in zip(*res, ("h", "c", "gates")):
+        assert float((a - b).abs().max()) < 1e-3, what
 
 
-@pytest.mark.parametrize("T,B,use_mask,tanh_init,use_ext,use_last", [
-    (6, 32, True, True, True, False), (1, 5, False, False, True, True), (9, 32, True, False, True, True),
-    (40, 32, False, True, True, False), (3, 13, True, True, True, True), (17, 8, False, False, False, True),
+@pytest.mark.parametrize("T,B,R,tanh_init,use_ext,use_last", [
+    (6, 32, 4, True, True, False), (9, 32, 8, False, True, True), (5, 64, 8, True, True, False), (7, 128, 16, True, True, False),
+    (40, 32, 8, True, True, False), (3, 13, 2, True, True, True), (4, 100, 13, False, True, True), (17, 8, 1, False, False, True),
+    (12, 32, 16, True, True, False),
 ])
-def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="rs", R=None, flags=0):
-    """The one-launch persistent BPTT (H = 1024; variant "rs" = reduce-scatter hand-off, "ag" = all-gather hand-off, "rs16" =
-    lv_lstm_persist16.hip with R batch rows per XCD group, no in-kernel dropout mask) against the float64 autograd of the same
-    recurrence (bf16-recurrence tolerance) and against the two-launch-per-step kernels on the same saved activations."""
+@pytest.mark.parametrize("flags", [0, 1])
+def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use_last, flags):
+    """The one-launch persistent BPTT (lv_lstm_persist16.hip: reduce-scatter hand-off, R batch rows per XCD group) on the saved
+    activations of the step kernels' forward: against the two-launch-per-step kernels on the same inputs at the T = 200 test's
+    bounds (rms 1e-3; a flipped bf16 rounding of one dG element is 2^-8 of that element), and against the float64 autograd of the
+    exact recurrence at the bf16 noise floor (the operands of dh = dG . W_hh are rounded to bf16: ~2^-9 relative per product)."""
     dev, H = hip_device, 1024
     g = torch.Generator().manual_seed(T * 100 + B + 7)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
     c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
-    mask = (torch.rand(B, T, H, generator=g) < 0.5).to(dev)
     wext = torch.randn(T, B, H, generator=g).to(dev)
     wlast = torch.randn(B, H, generator=g).to(dev)
     gx64 = gx.double().requires_grad_(True)
     c064 = c0.double().requires_grad_(True)
     h064 = torch.tanh(c064) if tanh_init else torch.zeros_like(c064)
-    hs_r, cs_r, out_r = _lstm_ref(gx64, whh.double(), h064, c064, mask if use_mask else None, 2.0)
+    hs_r, cs_r, out_r = _lstm_ref(gx64, whh.double(), h064, c064, None, 1.0)
     loss = 0
     if use_ext:
         loss = loss + (out_r * wext.double()).sum()
@@ -440,20 +455,10 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
     hs[0], cs[0] = h064.detach().float(), c0
     gates = torch.empty(T, B, 4 * H, device=dev)
     hdrop = torch.empty(T, B, H, device=dev)
-    m8 = mask.to(torch.uint8).contiguous()
     ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
-    lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), P(m8) if use_mask else None, 2.0, P(hdrop), P(ws), T, B, H, _s(dev))
-    wpk = torch.full((lib.lv_lstm_persist_wpk_floats(),), float("nan"), device=dev)
-    if variant == "rs16":
-        assert not use_mask
-        lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
-    else:
-        lib.lv_lstm_persist_pack(P(whh), P(wpk), 2 if variant == "rs" else 1, H, _s(dev))
-    persist_bwd = lib.lv_lstm_bwd_bf16_persist_rs if variant == "rs" else lib.lv_lstm_bwd_bf16_persist
-
-    def common(weights):
-        return (P(wext) if use_ext else None, P(wlast) if use_last else None, P(m8) if use_mask else None, 2.0,
-                P(weights), P(gates), P(hs), P(cs))
+    lib.lv_lstm_fwd_bf16(P(gx), P(whh), P(hs), P(cs), P(gates), None, 1.0, P(hdrop), P(ws), T, B, H, _s(dev))
+    wpk = torch.full((lib.lv_lstm_persist16_wpk_floats(),), float("nan"), device=dev)
+    lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
     outs = []
     for persistent in (True, False):
         dG = torch.empty(T, B, 4 * H, device=dev)
@@ -461,52 +466,47 @@ def test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext
         dGsum = torch.full((B, 4 * H), 7.0, device=dev)
         dh0 = torch.empty(B, H, device=dev)
         dc0 = torch.empty(B, H, device=dev)
-        if persistent and variant == "rs16":
+        if persistent:
             wsp = torch.full((lib.lv_lstm_persist16_xch_floats(),), float("nan"), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-            R16 = R if R is not None else (B + 7) // 8
-            saved = _saved16_pack(lib, gates.view(T, B, 4 * H), cs, R16)
+            saved = _saved16_pack(lib, gates.view(T, B, 4 * H), cs, R)
             cs0 = torch.full_like(cs, float("nan")); cs0[0] = cs[0]          # the kernel may read the initial state only
             lib.lv_lstm_bwd_bf16_persist16(P(wext) if use_ext else None, P(wlast) if use_last else None, P(wpk), P(saved), P(hs), P(cs0),
                                            P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B,
-                                           R16, flags, H, _s(dev))
+                                           R, flags, H, _s(dev))
             assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
-            dG = torch.cat([dG16.view(torch.bfloat16).float()])
-        elif persistent:
-            wsp = torch.full((lib.lv_lstm_persist_xch_floats(),), float("nan"), device=dev)
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
-            persist_bwd(*common(wpk), None, P(dG16), P(dGsum), P(wsp), P(status), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
-            assert int(status.item()) == 0, "hand-off timeout, status %d" % int(status.item())
-            dG = torch.cat([dG16.view(torch.bfloat16).float()])      # image-only kernel: compare through the bf16 image
+            dG = dG16.view(torch.bfloat16).float()                           # image-only kernel: compare through the bf16 image
         else:
             ws.fill_(float("nan"))
-            lib.lv_lstm_bwd_bf16_img(*common(whh), P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
-        if not persistent:
+            lib.lv_lstm_bwd_bf16_img(P(wext) if use_ext else None, P(wlast) if use_last else None, None, 1.0, P(whh), P(gates), P(hs),
+                                     P(cs), P(dG), P(dG16), P(dGsum), P(ws), P(dh0), P(dc0), int(tanh_init), T, B, H, _s(dev))
             assert torch.equal(dG16.cpu(), dG.cpu().to(torch.bfloat16).view(torch.int16))
-        sc, tol = float(gx64.grad.abs().max()), 300.0
-        assert float((dG.double() - gx64.grad).abs().max()) < 1e-4 * sc * tol
-        assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < 1e-4 * sc * T * tol
-        assert float((dc0.double() - c064.grad).abs().max()) < 1e-4 * float(c064.grad.abs().max()) * tol
+        sc, noise = float(gx64.grad.abs().max()), 3e-2                       # bf16 noise floor against the exact recurrence
+        assert float((dG.double() - gx64.grad).abs().max()) < noise * sc
+        assert float((dGsum.double() - gx64.grad.sum(0)).abs().max()) < noise * sc * T
+        assert float((dc0.double() - c064.grad).abs().max()) < noise * float(c064.grad.abs().max())
         if not tanh_init:
             ref_dh0 = gx64.grad[0] @ whh.double()
-            assert float((dh0.double() - ref_dh0).abs().max()) < 1e-4 * float(ref_dh0.abs().max()) * tol
-        outs.append((dG.clone(), dGsum.clone(), dc0.clone()))
-    sc = float(outs[1][0].abs().max())
-    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-2 * sc      # same math, different f32 summation order + bf16 re-rounding
+            assert float((dh0.double() - ref_dh0).abs().max()) < noise * float(ref_dh0.abs().max())
+        outs.append((dG16.view(torch.bfloat16).float(), dGsum.clone(), dc0.clone()))
+    for a, b, what in zip(outs[0], outs[1], ("dG", "dGsum", "dc0")):
+        sc = float(b.abs().max())
+        err = float((a - b).abs().max())
+        rms = float((a - b).pow(2).mean().sqrt()) / float(b.pow(2).mean().sqrt())
+        assert rms < 1e-3 and err < (2 ** -7 if what == "dG" else 1e-3) * sc, (what, err / sc, rms)
 
 
-@pytest.mark.parametrize("kernels", ["16row", "16row_B64_R8", "16row_B128_R16", "16row_B100_R13", "16row_B13_R2", "4row"])
+@pytest.mark.parametrize("kernels", ["B32_R4", "B64_R8", "B128_R16", "B100_R13", "B13_R2"])
 def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels):
-    """Both persistent recurrences (the default kernels of lv_lstm_persist16.hip with their hand-off in the XCD's L2, and the
-    4-row kernels of lv_lstm_persist.hip) at the length the metric is quoted on (T = 200, B = 32, H = 1024) against the
+    """Both persistent recurrences (lv_lstm_persist16.hip, hand-off in the XCD's L2) at the length the metric is quoted on
+    (T = 200, B = 32, H = 1024; the 8- and 16-row instantiations at their own batch sizes and T = 120) against the
     launch-per-step bf16 kernels on the SAME inputs: the two realisations see the same bf16-rounded operands and differ only
     in f32 summation order (and in what a flipped bf16 rounding moves downstream), so they must stay within 1e-3 of each other
     over all 200 steps -- a per-kernel check that localises a regression the end-to-end Yahoo fixture test would only see as a
     loss delta.  Weights at 3x the reference's init scale (U(-0.03, 0.03): a contractive recurrence, like the fixtures)."""
-    dev, H, T, B, R16 = hip_device, 1024, 200, 32, 4
-    if kernels.startswith("16row_"):             # the 8- and 16-row instantiations at their own batch sizes (B = 128: the stress shape)
-        B, R16 = int(kernels.split("_")[1][1:]), int(kernels.split("_")[2][1:])
-        T, kernels = 120, "16row"
+    dev, H = hip_device, 1024
+    B, R16 = int(kernels.split("_")[0][1:]), int(kernels.split("_")[1][1:])
+    T = 200 if kernels == "B32_R4" else 120
     g = torch.Generator().manual_seed(20001)
     gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
     whh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) * 0.03).to(dev)
@@ -521,8 +521,8 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
         cs = torch.zeros(T + 1, B, H, device=dev)
         hs[0], cs[0] = h0, c0
         gates = torch.empty(T, B, 4 * H, device=dev)
-        if persistent and kernels == "16row":
-            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+        if persistent:
+            wpk = torch.empty(lib.lv_lstm_persist16_wpk_floats(), device=dev)
             xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, R16), device=dev)
@@ -531,13 +531,6 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
             assert int(status.item()) == 0
             gates, c_t = _saved16_unpack(saved, T, B, R16)
             cs[1:] = c_t
-        elif persistent:
-            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
-            xch = torch.empty(lib.lv_lstm_persist_xch_floats(), device=dev)
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_persist_pack(P(whh), P(wpk), 3, H, _s(dev))
-            lib.lv_lstm_fwd_bf16_persist_ks(P(gxu), P(wpk), P(hs), P(cs), P(gates), None, 1.0, None, P(xch), P(status), T, B, H, _s(dev))
-            assert int(status.item()) == 0
         else:
             ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
             lib.lv_lstm_fwd_bf16_ug(P(gxu), P(whh), P(hs), P(cs), P(gates), None, 1.0, None, P(ws), T, B, H, _s(dev))
@@ -552,21 +545,13 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
         dG16 = torch.zeros(T, B, 4 * H, dtype=torch.int16, device=dev)
         dGsum = torch.empty(B, 4 * H, device=dev)
         dc0 = torch.empty(B, H, device=dev)
-        if persistent and kernels == "16row":
-            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
+        if persistent:
+            wpk = torch.empty(lib.lv_lstm_persist16_wpk_floats(), device=dev)
             xch = torch.empty(lib.lv_lstm_persist16_xch_floats(), device=dev)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
             lib.lv_lstm_persist16_pack(P(whh), P(wpk), 1, H, _s(dev))
             lib.lv_lstm_bwd_bf16_persist16(P(wext), None, P(wpk), P(_saved16_pack(lib, gates.view(T, B, 4 * H), cs, R16)), P(hs), P(cs), P(dG16),
                                            P(dGsum), P(xch), P(status), None, P(dc0), 1, T, B, R16, 1, H, _s(dev))
-            assert int(status.item()) == 0
-        elif persistent:
-            wpk = torch.empty(lib.lv_lstm_persist_wpk_floats(), device=dev)
-            xch = torch.empty(lib.lv_lstm_persist_xch_floats(), device=dev)
-            status = torch.zeros(1, dtype=torch.int32, device=dev)
-            lib.lv_lstm_persist_pack(P(whh), P(wpk), 2, H, _s(dev))
-            lib.lv_lstm_bwd_bf16_persist_rs(P(wext), None, None, 1.0, P(wpk), P(gates), P(hs), P(cs), None, P(dG16), P(dGsum), P(xch),
-                                            P(status), None, P(dc0), 1, T, B, H, _s(dev))
             assert int(status.item()) == 0
         else:
             ws = torch.empty(lib.lv_lstm_ws_floats(B, H), device=dev)
@@ -581,45 +566,15 @@ def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels
         assert rms < 1e-3 and err < (2 ** -7 if what == "dG" else 1e-3) * sc, (what, err / sc, rms)
 
 
-@pytest.mark.parametrize("T,B,R", [(6, 32, 4), (9, 32, 8), (5, 64, 8), (7, 128, 16), (40, 32, 8), (3, 13, 2), (4, 100, 13), (12, 32, 16),
-                                   (1, 5, 5)])
-@pytest.mark.parametrize("flags", [0, 1])
-def test_lstm_fwd_persistent16(lib, hip_device, T, B, R, flags):
-    """lv_lstm_persist16.hip forward: R rows per XCD group -- 8 groups x 4 (the default shape), 4 groups x 8 and 2 groups x 16
-    (a B = 32 recurrence on half / a quarter of the chip), 8 x 8 and 8 x 16 (B = 64 / the stress configuration's B = 128), ragged
-    slices."""
-    test_lstm_fwd_persistent(lib, hip_device, T, B, False, variant="k16", R=R, flags=flags)
-
-
-@pytest.mark.parametrize("T,B,R,tanh_init,use_ext,use_last", [
-    (6, 32, 4, True, True, False), (9, 32, 8, False, True, True), (5, 64, 8, True, True, False), (7, 128, 16, True, True, False),
-    (40, 32, 8, True, True, False), (3, 13, 2, True, True, True), (4, 100, 13, False, True, True), (17, 8, 1, False, False, True),
-    (12, 32, 16, True, True, False),
-])
-@pytest.mark.parametrize("flags", [0, 1])
-def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use_last, flags):
-    test_lstm_bwd_persistent(lib, hip_device, T, B, False, tanh_init, use_ext, use_last, variant="rs16", R=R, flags=flags)
-
-
-@pytest.mark.parametrize("T,B,use_mask", [(6, 32, True), (9, 64, True), (3, 13, False)])
-def test_lstm_fwd_persistent_column_split_form(lib, hip_device, T, B, use_mask):
-    test_lstm_fwd_persistent(lib, hip_device, T, B, use_mask, variant="cols")
-
-
-@pytest.mark.parametrize("T,B,use_mask,tanh_init,use_ext,use_last", [(6, 32, True, True, True, False), (40, 30, False, False, True, True)])
-def test_lstm_bwd_persistent_allgather_form(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last):
-    test_lstm_bwd_persistent(lib, hip_device, T, B, use_mask, tanh_init, use_ext, use_last, variant="ag")
-
-
-def test_lstm_fwd_persistent_unsupported_shapes(lib, hip_device):
+def test_lstm_persistent16_unsupported_shapes(lib, hip_device):
     if hip_device.type != "cuda":
         pytest.skip("GPU only")
     z = torch.zeros(1 << 16, device=hip_device)
     st = torch.zeros(1, dtype=torch.int32, device=hip_device)
     with pytest.raises(_lib.LvaeError):      # H != 1024
-        lib.lv_lstm_fwd_bf16_persist(P(z), P(z), P(z), P(z), P(z), None, 1.0, None, P(z), P(st), 1, 4, 64, _s(hip_device))
-    with pytest.raises(_lib.LvaeError):      # B > 64
-        lib.lv_lstm_fwd_bf16_persist(P(z), P(z), P(z), P(z), P(z), None, 1.0, None, P(z), P(st), 1, 65, 1024, _s(hip_device))
+        lib.lv_lstm_fwd_bf16_persist16(P(z), P(z), P(z), P(z), P(z), P(z), P(st), 1, 4, 1, 0, 64, _s(hip_device))
+    with pytest.raises(_lib.LvaeError):      # more than 16 rows per group
+        lib.lv_lstm_fwd_bf16_persist16(P(z), P(z), P(z), P(z), P(z), P(z), P(st), 1, 136, 17, 0, 1024, _s(hip_device))
 
 
 @pytest.mark.parametrize("T,B,ni,V,masked", [(7, 4, 8, 53, True), (199, 32, 512, 20001, True), (12, 16, 50, 1004, False),
@@ -1139,7 +1094,7 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=0):
         l16b = torch.full((R, ldv), 0x7E00, dtype=torch.int16, device=dev)
         partb = torch.full((R, 2 * nparts), float("nan"), device=dev)
         tgtb = torch.full((R,), float("nan"), device=dev)
-        lib.lv_gemm_b16_nll_tile(384 - tile, R, V, H, P(O16), H, P(W16), H, P(l16b), ldv, P(xd), T + 1, 1, B, P(partb), P(tgtb), _s(dev))
+        lib.lv_gemm_b16_nll_tile(128 if tile >= 256 else 256, R, V, H, P(O16), H, P(W16), H, P(l16b), ldv, P(xd), T + 1, 1, B, P(partb), P(tgtb), _s(dev))
         assert torch.equal(l16[:, :V].cpu(), l16b[:, :V].cpu()) and torch.equal(part.cpu(), partb.cpu()) and torch.equal(tgt.cpu(), tgtb.cpu())
     got16 = l16[:, :V].cpu().view(torch.float16)
     # binary16 RNE of an f32 accumulation of exact bf16 products: within 1 ulp of the float64 result's rounding
@@ -1165,7 +1120,8 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=0):
 
 
 @pytest.mark.parametrize("tA,M,N,K", [(0, 2100, 2304, 4100), (1, 4500, 1024, 3000), (0, 6368, 1024, 20001)])
-def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K):
+@pytest.mark.parametrize("tile", [256, 257])
+def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K, tile):
     """Race screen of the 256 x 256 kernel's LDS-DMA hand-over and of the K-split tail: the same launch twelve times, on operands
     that are refilled in between (so the caches hold something else), must give the same bits every time -- a fragment read that
     overtook its DMA, or a reduce that read a slab early, shows up as a sporadic difference."""
@@ -1182,7 +1138,7 @@ def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K):
         C = torch.full((M, N), float("nan"), device=dev)
         ws.fill_(float(it))                      # stale slabs must never be read
         scratch.fill_(it)                        # evict the operands from L2
-        lib.lv_gemm_b16_tile(256, tA, M, N, K, 1.0, P(A16), lda, P(B16), ldb, P(C), N, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
+        lib.lv_gemm_b16_tile(tile, tA, M, N, K, 1.0, P(A16), lda, P(B16), ldb, P(C), N, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
         out = C.cpu()
         assert bool(torch.isfinite(out).all())
         if first is None:
@@ -1192,8 +1148,9 @@ def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K):
 
 
 @pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 1000, 128), (40, 32, 20001, 1024)])
-def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H):
-    test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=256)
+@pytest.mark.parametrize("tile", [256, 257])
+def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H, tile):
+    test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=tile)
 
 
 @pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (1, 7, False), (50, 7, True), (50, 5, True),

@@ -67,12 +67,12 @@ def test_bf16_throughput_path_tracks_oracle(hip_device):
     assert out["grads"] < 5e-2, out
 
 
-@pytest.mark.parametrize("persistent", [True, False, "rows4", "rows8", "rows16", "four_row_kernels", "write_through"])
+@pytest.mark.parametrize("persistent", [True, False, "rows4", "rows8", "rows16", "write_through"])
 def test_bf16_throughput_path_h1024(hip_device, persistent):
     """H = 1024, B = 32: the shape class on which the bf16 path runs its LSTM recurrences as persistent XCD-group launches
     (when the device has >= 256 CUs).  Every realisation must track the f32 oracle to the bf16 path's documented delta: the
-    4-row kernels on 8 groups, the launch-per-step kernels, and the kernels of lv_lstm_persist16.hip with 4 / 8 / 16 rows per
-    group (8 groups; 4 groups = half the chip; 2 groups)."""
+    launch-per-step kernels and the kernels of lv_lstm_persist16.hip with 4 / 8 / 16 rows per group (8 groups; 4 groups = half the
+    chip; 2 groups), hand-off granules in the XCD's L2 or written through."""
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
     V, ni, H, nz, B, T, klw = 3000, 64, 1024, 16, 32, 14, 0.5
     P = O.random_params(V, ni, H, nz, seed=11, scale=0.03, head_scale=0.2)
@@ -85,16 +85,12 @@ def test_bf16_throughput_path_h1024(hip_device, persistent):
     tr.enc.persistent = tr.dec.persistent = bool(persistent)
     if isinstance(persistent, str) and persistent.startswith("rows"):
         tr.enc.persist_rows = tr.dec.persist_rows = int(persistent[4:])
-    saved = (engine.PERSIST16_ALWAYS, engine.PERSIST16_FLAGS)
-    try:
-        if persistent == "four_row_kernels":          # lv_lstm_persist.hip (4x4x4 MFMA forms), the round-2 default
-            engine.PERSIST16_ALWAYS = False
-        if persistent == "write_through":             # hand-off granules written through to memory (agent scope)
-            engine.PERSIST16_FLAGS = 0
-        tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
-        st = tr.read_stats()          # also checks the persistent launches' status words
-    finally:
-        engine.PERSIST16_ALWAYS, engine.PERSIST16_FLAGS = saved
+    if persistent == "write_through":                 # ladder rung 1: hand-off granules written through to memory (agent scope)
+        tr.enc.persist_flags = tr.dec.persist_flags = 0
+    rung = max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))
+    tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
+    st = tr.read_stats()              # also settles the transaction gate: a timed-out launch would have moved the engines down the ladder
+    assert max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec)) == rung and tr.recoveries == 0
     assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3
     assert abs(st["norm"] - r["total_norm"]) / r["total_norm"] < 3e-2
     named = dict(vae.named_parameters())
@@ -102,6 +98,21 @@ def test_bf16_throughput_path_h1024(hip_device, persistent):
     assert worst < 5e-2, worst
     sd = vae.state_dict()
     assert max(rel_err(sd[k], r["new_params"][k]) for k in ENC_KEYS) < 5e-2
+
+
+@pytest.mark.parametrize("fault_at,rungs_down,use_graph", [((0,), 2, False), ((2,), 1, False), ((1, 3), 2, False), ((0,), 2, True),
+                                                           ((2,), 1, True)])
+def test_timed_out_persistent_launch_never_reaches_the_weights(hip_device, fault_at, rungs_down, use_graph):
+    """The bf16 configuration at H = 1024, B = 32 (persistent recurrences): a status word as a timed-out launch leaves it, set
+    before the listed steps.  The device-side gate voids the step and everything queued behind it, the next host read moves the
+    engines down the fallback ladder (rungs_down = 2: write-through hand-off, then the launch-per-timestep kernels) and replays.
+    fault_at = (0,), rungs_down = 2: the weights EQUAL a run on the step kernels, bit for bit; rung 0 -> 1 is the same
+    arithmetic, so there too.  Also through captured hipGraphs (graphs of the failed rung are dropped)."""
+    tr = pc.check_transactional_recovery(hip_device, V=2003, ni=64, H=1024, nz=32, B=32, K=5, precision="bf16", fault_at=fault_at,
+                                         rungs_down=rungs_down, use_graph=use_graph)
+    from vae_lagging_encoder_amd import engine
+    if torch.cuda.get_device_properties(hip_device).multi_processor_count >= 256:
+        assert engine._persistent_ok(tr.enc, object(), 32, 1024, hip_device, 128) == (rungs_down < 2)
 
 
 def test_bf16_native_operands_equal_on_the_fly(hip_device):
@@ -454,7 +465,7 @@ def test_stress_batch_at_h1024(hip_device):
         tr.enc.persistent = tr.dec.persistent = persistent
         img = tr.enc._b16(B, T)
         assert img is not None and engine._persistent_ok(tr.enc, img, B, H, hip_device, engine._PERSIST_BWD_MAX_B) == persistent
-        assert engine._persist_rows(tr.enc, B) == (True, 16)
+        assert engine._persist_rows(tr.enc, B) == 16
         tr.step(x.to(hip_device), klw, noise=(eps.to(hip_device), m_in.to(torch.uint8).to(hip_device), m_out.to(torch.uint8).to(hip_device)))
         st = tr.read_stats()                                    # raises on a hand-off timeout
         assert abs(st["loss_sum"] - float(r["loss"].sum())) / abs(float(r["loss"].sum())) < 2e-3

@@ -248,3 +248,23 @@ def test_image_outer_loop_policy():
     assert stop == [False, False, False, False, False, False, False, True] and loop.decay_cnt == 5
     assert loop.trainer.resets == [0.001 * 0.5 ** k for k in range(1, 6)]
     del w0
+
+
+def test_sampler_order_equals_a_shuffled_dataloader_pass():
+    """data.sampler_order must consume torch's global generator exactly as `for datum in DataLoader(..., shuffle=True)` does
+    (image.py:219-221,281): the iterator's _base_seed draw first, then RandomSampler's seed -- same orders pass after pass, and
+    the same generator state afterwards (so that whatever the training loop draws next matches the reference's stream)."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from vae_lagging_encoder_amd.data import ShuffledLoader, sampler_order
+    n = 37
+    torch.manual_seed(5)
+    dl = DataLoader(TensorDataset(torch.arange(n)), batch_size=5, shuffle=True)
+    ref = [[int(v) for b in dl for v in b[0]] for _ in range(3)]
+    state = torch.get_rng_state().clone()
+    torch.manual_seed(5)
+    assert [sampler_order(n) for _ in range(3)] == ref
+    assert torch.equal(torch.get_rng_state(), state)
+    torch.manual_seed(5)
+    sl = ShuffledLoader(torch.arange(n).float().view(n, 1), 5)
+    assert [[int(v) for b, _ in sl for v in b.view(-1)] for _ in range(3)] == ref

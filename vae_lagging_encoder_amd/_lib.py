@@ -35,9 +35,6 @@ SIGNATURES = {
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
-    "lv_lstm_persist_wpk_floats": [],
-    "lv_lstm_persist_xch_floats": [],
-    "lv_lstm_persist_pack": [_vp, _vp, _i, _i, _vp],
     "lv_loss_assemble_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "lv_enc_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_enc_head_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -45,11 +42,13 @@ SIGNATURES = {
     "lv_dec_init_f32": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_dec_tail_bwd_f32": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_clip_norm2_f32": [_vp, _l, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp],
+    "lv_clip_norm2_txn_f32": [_vp, _l, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "lv_clip_coef_txn_f32": [_vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "lv_txn_guard_f32": [_vp, _vp, _vp, _vp],
+    "lv_sgd_step_txn_f32": [_vp, _vp, _l, _vp, _vp, _i, _vp, _vp],
+    "lv_scale_txn_f32": [_vp, _l, _vp, _vp, _vp],
     "lv_rng_noise_step": [_vp, _l, _vp, _l, _f, _vp, _l, _f, _vp, _u64, _vp],
-    "lv_lstm_fwd_bf16_persist": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "lv_lstm_fwd_bf16_persist_ks": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "lv_lstm_bwd_bf16_persist": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "lv_lstm_bwd_bf16_persist_rs": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lv_lstm_persist16_wpk_floats": [],
     "lv_lstm_persist16_xch_floats": [],
     "lv_lstm_persist16_saved_floats": [_i, _i],
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
@@ -137,7 +136,7 @@ SIGNATURES = {
 }
 
 
-_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats", "lv_conv32_wpack_floats",
+_LONG_FNS = ("lv_lstm_ws_floats", "lv_conv1x1_wgrad_ws_floats", "lv_conv1x1_blocks", "lv_lstm_persist16_wpk_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats", "lv_conv32_wpack_floats",
              "lv_conv32_wgrad_ws_floats")
 
 
@@ -166,7 +165,7 @@ class Lib(object):
         # functions that return a value rather than a status
         self._value_fns = {"lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
-                           "lv_lstm_persist_wpk_floats", "lv_lstm_persist_xch_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats",
+                           "lv_lstm_persist16_wpk_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats",
                            "lv_pixelcnn_net_words", "lv_pixelcnn_block_words", "lv_conv32_tap_split"}
 
     def __getattr__(self, name):

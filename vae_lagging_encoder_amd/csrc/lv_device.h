@@ -38,6 +38,8 @@ static inline f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) { return l
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
 #define LV_WAIT_VMEM() do { } while (0)
+#define LV_S_BARRIER() __syncthreads()      // a bare workgroup barrier (no counter waits attached); fibers: the same rendezvous
+#define LV_SETPRIO(n) do { } while (0)
 static inline uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {            // lane map: see the HIP definition below
     auto& w = lv_emu::my_wave();
     const int l = lv_emu::lane();
@@ -218,6 +220,11 @@ __device__ __forceinline__ void lv_glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// s_barrier alone: __syncthreads() puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of it whenever anything is in flight -- for
+// schedules that keep LDS-DMA in flight across a barrier and order it by counted waits of their own
+#define LV_S_BARRIER() __builtin_amdgcn_s_barrier()
+// issue priority of this wave against the other waves of its SIMD (0..3): the wave that multiplies goes first
+#define LV_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // ds_read_b64_tr_b16 (LDS transpose read), lane map measured with profiles/microbench/ds_read_tr_probe.hip: inside each group
 // of 16 lanes every lane r supplies the address of FOUR consecutive 16-bit elements, a 16 x 4 matrix Mx[r][c]; lane i receives
 // out[j] = Mx[4j + (i >> 2)][i & 3].  Pointing lane r at T[k0 + (r >> 2)][m0 + 4 (r & 3)] of a row-major [k][m] tile therefore

@@ -304,6 +304,18 @@ __global__ __launch_bounds__(256) void lv_gemm_b16_kernel(GemmQ p) {
         }
 }
 
+#ifndef LV_B16_PP_DMA
+#define LV_B16_PP_DMA 0        // ping-pong schedule: units of the next tile's DMA per LOAD segment of k-steps 0..3: 0 = 2,2,0,0; 1 = 2,1,1,0; 2 = 1,1,1,1
+#endif
+#ifndef LV_B16_PP_ABL
+#define LV_B16_PP_ABL 0        // ablation switches for profiles/microbench only (results are wrong): 1 = no DMA in the loop, 2 = no MFMA, 4 = no fragment reads, 8 = no barriers, 16 = a second tile's DMA stays in flight (vmcnt(8)), 32 = only the A tile is staged, 64 = every workgroup stages tile (0, 0), 128 = no source-side swizzle
+#endif
+#ifndef LV_B16_PP_WAIT
+#define LV_B16_PP_WAIT 1       // ping-pong schedule: group 0 waits for its DMA at the end of the MFMA segment of k-step 3 (0: both groups at the end of the LOAD segment)
+#endif
+#ifndef LV_B16_PP_PRIO
+#define LV_B16_PP_PRIO 1       // ping-pong schedule: s_setprio 1 around the MFMA segment
+#endif
 #ifndef LV_B16_T256_ORDER
 #define LV_B16_T256_ORDER 1   // 256 x 256 kernel: fragments of k-step ks+1 requested before (0) / in the middle of (1) the MFMAs of k-step ks
                               // (1 since the DMA moved into the first half of the tile: logits 310 -> 298 us, dO 304 -> 295, fused NLL 325 -> 317;
@@ -727,9 +739,20 @@ __device__ __forceinline__ void t256_tile_of(const GemmQ& p, int s, int& tm, int
 // WN = waves along N: 4 (8 waves, wave tile 128 x 64: acc 128 registers, two waves per SIMD) or 2 (4 waves, wave tile 128 x 128: acc
 // 256 registers -- AGPRs --, ONE wave per SIMD, 8 fragment reads per 16 MFMAs instead of 6 per 8: a third less LDS read traffic,
 // which at 8 waves equals the MFMA pipe time).  The NLL epilogue exists for WN = 4 only.
-template <bool NLL, bool TN, int WN = 4>
+// PP ("ping-pong", round 4): the K loop runs as two wave groups half a k-step apart.  Waves w and w + 4 share SIMD w & 3 and belong
+// to different groups (wm = 0 / 1); a k-step of a wave is a LOAD segment (its 6 fragment reads of that k-step + its share of the
+// next tile's LDS-DMA) and an MFMA segment (8 MFMAs = 256 cycles of the SIMD's matrix pipe), each closed by a bare s_barrier, and
+// group 1 enters the loop one barrier late: whenever one wave of a SIMD multiplies, its partner reads / stages, so the matrix pipe
+// of every SIMD sees ONE instruction stream of back-to-back MFMAs while only four waves at a time compete for the LDS port.
+// Ordering of the LDS-DMA: a tile's 8 DMA instructions go out in the LOAD segments of k-steps 0 and 1 of the tile before it, every
+// wave waits for its own (vmcnt(0): nothing newer is in flight then) at the end of the LOAD segment of k-step 3, i.e. before the
+// barrier that closes that segment, and the first read of the new tile by EITHER group lies behind that barrier; a LOAD segment
+// ends with lgkmcnt(0) BEFORE its barrier, so the buffer a DMA overwrites (the tile before the current one) has been read
+// completely by both groups when the first DMA instruction of the tile after the current one is issued.
+template <bool NLL, bool TN, int WN = 4, bool PP = false>
 __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
     static_assert(WN == 4 || (WN == 2 && !NLL), "4 waves: plain epilogue only");
+    static_assert(!PP || WN == 4, "ping-pong schedule: 8 waves");
     constexpr int NJ = 8 / WN;                          // 32-column fragments per wave along N
     constexpr int UN = 16 / WN;                         // 1 KB staging units per wave and image
     __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
@@ -784,9 +807,17 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
     for (int i = 0; i < UN; ++i) {
         const int u = UN * w + i;
         const int row = 8 * u + (l >> 3);
+#if LV_B16_PP_ABL & 128
+        const int c = (l & 7);
+#else
         const int c = (l & 7) ^ ((row >> 1) & 7);
+#endif
         kch[i] = 8 * c;
+#if LV_B16_PP_ABL & 64
+        int ra = row, rb = row;
+#else
         int ra = m0 + row, rb = n0 + row;
+#endif
         if (ra > p.M - 1) ra = p.M - 1;                // clamped, not predicated (see the 128 x 128 kernel)
         if (rb > p.N - 1) rb = p.N - 1;
         oa[i] = (uint32_t)((long)ra * p.lda + kch[i]);
@@ -803,7 +834,9 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
         const uint32_t k0 = (uint32_t)(kt * BK);
         const uint32_t ka = TN ? k0 * (uint32_t)p.lda : k0;
         lv_glds16(p.A + (size_t)(oa[i] + ka), reinterpret_cast<char*>(&Ad[0][0]) + 1024 * (UN * w + i));
+#if !(LV_B16_PP_ABL & 32)
         lv_glds16(p.B + (size_t)(ob[i] + k0), reinterpret_cast<char*>(&Bd[0][0]) + 1024 * (UN * w + i));
+#endif
     };
     auto stage_dma = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {
 #pragma unroll
@@ -936,10 +969,80 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
     // branch-free staging: the tile after the last one is the last one again (a harmless reload into the idle buffer), so the
     // loop body is the only copy of the K-tile code besides the ragged prologue
     const int klast = kt0 + nmain - 1;
+    if constexpr (PP) {
+        auto pp_tile = [&](LdsTile2& Ac, LdsTile2& Bc, int kt_next, LdsTile2& Ad, LdsTile2& Bd) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                // LOAD segment
+                uint4 fa[4], fb[NJ];
+#if LV_B16_PP_ABL & 4
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = make_uint4(oa[j], ob[j], oa[j] + ks, 0x3f803f80u);
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) fa[i2] = make_uint4(ob[i2], oa[i2], 0x3f803f80u, ob[i2] + ks);
+#else
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = Bc[brow + 32 * j][(2 * ks + lh) ^ sx];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) fa[i2] = a_frag(Ac, ks, i2);
+#endif
+                LV_SCHED_BARRIER();
+#if LV_B16_PP_ABL & 1
+#elif LV_B16_PP_DMA == 0
+                if (ks < 2) {
+#pragma unroll
+                    for (int i = 0; i < UN / 2; ++i) stage_unit(kt_next, (UN / 2) * ks + i, Ad, Bd);
+                }
+#elif LV_B16_PP_DMA == 1
+                if (ks == 0) { stage_unit(kt_next, 0, Ad, Bd); stage_unit(kt_next, 1, Ad, Bd); }
+                else if (ks < 3) stage_unit(kt_next, ks + 1, Ad, Bd);
+#else
+                stage_unit(kt_next, ks, Ad, Bd);
+#endif
+                LV_SCHED_BARRIER();
+#if LV_B16_PP_ABL & 16
+                if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+                // the DMA wait: every wave before the SAME barrier -- the one behind which group 0 starts reading the next tile --, i.e.
+                // group 1 at the end of this LOAD segment, group 0 one segment later, at the end of its MFMA segment (LV_B16_PP_WAIT 1)
+                if (ks == BK / 16 - 1 && (!LV_B16_PP_WAIT || wm == 1)) LV_WAIT_VMEM();
+#endif
+                LV_WAIT_LDS();
+                if (!(LV_B16_PP_ABL & 8)) LV_S_BARRIER();
+                LV_SCHED_BARRIER();
+                // MFMA segment
+                if (LV_B16_PP_PRIO) LV_SETPRIO(1);
+#if LV_B16_PP_ABL & 2
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j][0] += (float)((fa[i].x ^ fb[j].y) & 0xFFu);
+#else
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[i], fb[j], acc[i][j]);
+#endif
+                if (LV_B16_PP_PRIO) LV_SETPRIO(0);
+                LV_SCHED_BARRIER();
+                if (LV_B16_PP_WAIT && ks == BK / 16 - 1 && wm == 0) LV_WAIT_VMEM();
+                if (!(LV_B16_PP_ABL & 8)) LV_S_BARRIER();
+                LV_SCHED_BARRIER();
+            }
+        };
+        if (wm == 1) LV_S_BARRIER();                 // group 1 runs one segment behind group 0
+        for (int i = 0; i < nmain; i += 2) {
+            pp_tile(As0, Bs0, kt0 + i + 1 < klast ? kt0 + i + 1 : klast, As1, Bs1);
+            if (i + 1 >= nmain) break;
+            pp_tile(As1, Bs1, kt0 + i + 2 < klast ? kt0 + i + 2 : klast, As0, Bs0);
+        }
+        if (wm == 0) LV_S_BARRIER();                 // ... and is met again here: behind this barrier nobody reads the K tiles any more
+    } else {
     for (int i = 0; i < nmain; i += 2) {
         mma_tile(std::true_type{}, As0, Bs0, kt0 + i + 1 < klast ? kt0 + i + 1 : klast, As1, Bs1);
         if (i + 1 >= nmain) break;
         mma_tile(std::true_type{}, As1, Bs1, kt0 + i + 2 < klast ? kt0 + i + 2 : klast, As0, Bs0);
+    }
     }
 
     if constexpr (NLL) {
@@ -1199,9 +1302,14 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
 // finer grid and shorter prologue win (measured: profiles/microbench/gemm_b16_shapes.py).  tile: 0 = by shape, 128 / 256 = the
 // caller names the tile edge (lv_gemm_b16_tile / lv_gemm_b16_nll_tile: tests and microbenchmarks; no process-wide state).
 static bool t256_wanted(int tile, int M, int N, int K) {
-    if (tile) return tile == 256;
+    if (tile) return tile >= 256;
     return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
 }
+#ifndef LV_B16_PP_DEFAULT
+#define LV_B16_PP_DEFAULT 1       // schedule of the 256 x 256 kernel when the caller does not name it: 0 = lockstep, 1 = ping-pong
+#endif
+// tile argument of the *_tile entries: 0 = by shape, 128, 256 = 256 x 256 lockstep schedule, 257 = 256 x 256 ping-pong schedule
+static bool t256_pp(int tile) { return tile == 257 || (tile == 0 && LV_B16_PP_DEFAULT); }
 
 // How the tail (tiles % 256) of a 256 x 256 launch is cut along K: estimated microseconds for s pieces per tail tile =
 // rounds x K tiles per piece x ~2 us per tile step + the slab traffic of the reduce ((s + 1) passes over tail x 256 KB at ~4.5 TB/s)
@@ -1234,7 +1342,7 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
                                 const float* add1, long ld1, int mod1,
                                 const float* add2, long ld2, int mod2,
                                 float* ws, long ws_floats, void* stream) {
-    if (tile != 0 && tile != 128 && tile != 256) return LV_ERR_ARG;
+    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return LV_ERR_ARG;
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
@@ -1259,7 +1367,10 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
         if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, 2>), grid, dim3(256), 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, 2>), grid, dim3(256), 0, stream, p, q);
 #else
-        if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
+        if (t256_pp(tile)) {
+            if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, 4, true>), grid, block, 0, stream, p, q);
+            else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, 4, true>), grid, block, 0, stream, p, q);
+        } else if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
 #endif
         if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
@@ -1373,7 +1484,7 @@ extern "C" int lv_gemm_b16_nll_parts(int N) { return 4 * lv_cdiv(N, BT2); }
 extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                     uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
                                     float* part, float* tgt_logit, void* stream) {
-    if (tile != 0 && tile != 128 && tile != 256) return LV_ERR_ARG;
+    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return LV_ERR_ARG;
     if (M < 0 || N <= 0 || K <= 0 || Bsz <= 0) return LV_ERR_SHAPE;
     if (M == 0) return LV_OK;
     if (!A || !B || !logits16 || !ids || !part || !tgt_logit) return LV_ERR_ARG;
@@ -1393,7 +1504,8 @@ extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
         q.full = (int)(tiles / 256 * 256); q.tail = (int)(tiles - q.full); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
-        LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        if (t256_pp(tile)) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, 4, true>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }

@@ -1,11 +1,12 @@
 // lv_lstm_persist16.hip -- the persistent LSTM recurrences for UP TO 16 BATCH ROWS PER XCD GROUP (bf16 recurrent operands, H = 1024).
 //
-// lv_lstm_persist.hip carries 4 rows per group (B <= 32 on 8 groups) and contracts them on the 4x4x4 MFMA.  Two things need
-// more rows per group: the stress configuration (B = 128 per GPU: 16 rows on each of the 8 groups; until now the
-// launch-per-step kernels at 11 us per timestep) and running a B = 32 recurrence on HALF the chip (4 groups x 8 rows), so that
-// the other four XCDs are free for the GEMMs that do not depend on it.  Same decomposition and hand-off as lv_lstm_persist.hip
-// (a group = the 32 workgroups with the same blockIdx % 8, W_hh register-resident, tagged 8-byte granules, bulk I/O in blocks of
-// timesteps, bounded spins); what changes is the contraction:
+// The rounds 1-2 kernels (lv_lstm_persist.hip, retired in round 4: these are faster at every row count, profiles/r03z_persist16_probe.txt)
+// carried 4 rows per group (B <= 32 on 8 groups) on the 4x4x4 MFMA.  Two things need more rows per group: the stress
+// configuration (B = 128 per GPU: 16 rows on each of the 8 groups) and running a B = 32 recurrence on HALF the chip (4 groups x 8
+// rows).  Decomposition and hand-off: a group = the 32 workgroups with the same blockIdx % 8; a group owns a slice of the batch
+// and carries it through all T steps, groups never talk; W_hh stays register-resident for the whole call (a wave's 64 KB slice
+// in 256 AGPRs); per timestep the only exchange is h_t (forward, all-gather) or partial dh sums (BPTT, reduce-scatter) inside
+// the group, as tagged 8-byte granules gathered by polling; bulk I/O in blocks of timesteps; all spins bounded.  The contraction:
 //
 //   * v_mfma_f32_16x16x32_bf16 with the operands SWAPPED: the weights are the A operand (16 gate columns / output units as the
 //     tile's rows), the batch rows are the B operand's 16 columns.  The matrix-pipe time is the one the 4-row kernels already pay
@@ -13,9 +14,9 @@
 //     lane holds FOUR CONSECUTIVE gate columns of ONE batch row -- in the forward's unit-major column order exactly the
 //     (i, f, g, o) of one unit, so the K-split partial products cross the workgroup as float4 records, and in the BPTT four
 //     consecutive hidden units of one row, i.e. two ready-made partial-sum granules.
-//   * forward (K-split, as lstm_fwd_persist_ks_kernel): wave w gathers K-quarter w of h_{t-1} (rows x 128 granules), 8 fragment
+//   * forward (K-split): wave w gathers K-quarter w of h_{t-1} (rows x 128 granules), 8 fragment
 //     reads + 64 MFMAs, 8 float4 LDS writes, ONE barrier, every (row, unit) thread adds the four quarters and runs the cell.
-//   * BPTT (reduce-scatter, as lstm_bwd_persist_rs_kernel): a workgroup receives 32 senders x rows x 16 granules of partial dh
+//   * BPTT (reduce-scatter): a workgroup receives 32 senders x rows x 16 granules of partial dh
 //     for its 32 units, sums them in registers + two shuffles, runs the gate-gradient math, publishes its dG image through LDS
 //     (ONE barrier), multiplies it with its 128 gate rows of W_hh (4 fragment reads + 64 MFMAs) and sends the partial sums.
 //   rows per group R <= 16; instantiated for RP = 4 / 8 / 16 (polls per lane, pairs per thread and the I/O block length follow).
@@ -636,6 +637,8 @@ int check_R(int B, int R) { return R >= 1 && R <= 16 && (long)R * PGROUPS >= B; 
 }  // namespace
 
 extern "C" long lv_lstm_persist16_xch_floats(void) { return XCH_RS16_BYTES / 4 + 64; }
+// floats of ONE packed bf16 image of W_hh (forward or BPTT form: 128 waves x 64 fragments x 64 lanes x 16 bytes = 8 MB)
+extern "C" long lv_lstm_persist16_wpk_floats(void) { return 128L * 64 * 64 * 16 / 4; }
 
 // floats of the saved-activation buffer the 16-row forward writes and the 16-row BPTT reads (workgroup-major, see the top of the
 // file): T timesteps at R rows per XCD group.  Both calls must be given the same T, B and R.
@@ -644,7 +647,7 @@ extern "C" long lv_lstm_persist16_saved_floats(int T, int R) {
 }
 
 // W_hh [4H][H] f32 -> the register image of lv_lstm_fwd_bf16_persist16 (backward = 0) / lv_lstm_bwd_bf16_persist16 (backward = 1):
-// lv_lstm_persist_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
+// lv_lstm_persist16_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
 extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream) {
     if (!whh || !wpk) return LV_ERR_ARG;
     if (H != PH) return LV_ERR_UNSUPPORTED;
@@ -658,8 +661,9 @@ extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward
 
 // Forward recurrence in one persistent launch with R batch rows per XCD group (1 <= R <= 16, 8 R >= B): groups
 // [0, ceil(B / R)) carry the batch, the workgroups of the other groups return at once -- R = 8 at B = 32 runs the recurrence on
-// four XCDs and leaves the other four to concurrent kernels.  Arguments as lv_lstm_fwd_bf16_persist_ks without the in-kernel
-// dropout (the engine applies dropout_out while h is converted to its bf16 images) and with the saved activations in the
+// four XCDs and leaves the other four to concurrent kernels.  gx: unit-major input projections [T][B][4H]; wpk: forward image of
+// lv_lstm_persist16_pack; hs [T+1][B][H] (slot 0 = initial state, read); no in-kernel dropout (the engine applies dropout_out while h
+// is converted to its bf16 images); the saved activations go to the
 // workgroup-major buffer of lv_lstm_persist16_saved_floats(T, R) floats instead of gates / cs[1 .. T - 1] (cs: slot 0 is read,
 // slot T written); exchange buffer of lv_lstm_persist16_xch_floats() floats.  flags bit 0: hand-off stores without the agent-scope write-through (they stay in the
 // XCD's L2; correct while every group is XCD-local -- the round-robin placement of a 256-CU device -- and reported through
@@ -690,8 +694,8 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
     return LV_OK;
 }
 
-// BPTT in one persistent launch, R batch rows per XCD group (as above).  Arguments as lv_lstm_bwd_bf16_persist_rs without the
-// in-kernel dropout mask; image-only (dG16).  saved: as the forward with the same T, B, R wrote it; cs: slot 0 only.
+// BPTT in one persistent launch, R batch rows per XCD group (as above).  dh_ext [T][B][H] (external gradient of every h_t, or
+// NULL) / dh_last [B][H] (of h_T, or NULL); no in-kernel dropout mask; image-only (dG16 = bf16 gate gradients [T][B][4H], gate-major).  saved: as the forward with the same T, B, R wrote it; cs: slot 0 only.
 extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved,
                                           const float* hs, const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status,
                                           float* dh0, float* dc0, int tanh_init, int T, int B, int R, int flags, int H, void* stream) {

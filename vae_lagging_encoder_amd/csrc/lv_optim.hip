@@ -92,9 +92,38 @@ __global__ __launch_bounds__(256) void sumsq2_stage1_kernel(const float* __restr
     if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The transaction gate of a fused training step (lv_clip_*_txn_f32).  A persistent LSTM recurrence that ran into its bounded
+// hand-off spin returns early and leaves a non-zero status word; everything queued behind it then works on a half-finished
+// recurrence.  The gate sits in the one single-thread spot every step passes before anything is applied -- the clip coefficient --
+// and decides on the DEVICE whether the step counts: status words zero (and, data parallel, the exchanged guard element zero: no
+// rank saw a timeout) -> the step's pending report sums are committed and the step counter advances; otherwise the sticky void
+// flag goes up, and the update kernels (lv_sgd_step_txn_f32 / lv_scale_txn_f32) leave weights and gradients alone for this and
+// every later step until the host has noticed (one read per loss window), moved the engines down the fallback ladder and replayed
+// the voided steps.  txn = {void flag, steps committed, pending loss / rec / kl sums}; acc = the three running report sums.
+struct TxnGate {
+    const int* status1; const int* status2;      // the two engines' persistent-launch status words (either may be null)
+    const float* guard;                          // data parallel: element of the exchanged gradient buffer that is non-zero iff a rank was void
+    float* txn;                                  // null: no gate (the plain entries)
+    float* acc;
+};
+
+__device__ __forceinline__ bool txn_gate(const TxnGate& g) {
+    if (!g.txn) return true;
+    const bool bad = (g.status1 && g.status1[0] != 0) || (g.status2 && g.status2[0] != 0) || (g.guard && g.guard[0] != 0.f) ||
+                     g.txn[0] != 0.f;
+    if (bad) {
+        g.txn[0] = 1.f;
+    } else {
+        if (g.acc) { g.acc[0] += g.txn[2]; g.acc[1] += g.txn[3]; g.acc[2] += g.txn[4]; }
+        g.txn[1] += 1.f;
+    }
+    g.txn[2] = 0.f; g.txn[3] = 0.f; g.txn[4] = 0.f;
+    return !bad;
+}
+
 // stage 2 + clip coefficient: sumsq = sum(partial) in double; norm = sqrt; coef = min(1, max_norm / (norm + 1e-6))
 __global__ __launch_bounds__(256) void clip_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
-                                                          float* sumsq, float* coef, float* norm_out) {
+                                                          float* sumsq, float* coef, float* norm_out, TxnGate gate) {
     __shared__ double red[4];
     const int tid = (int)threadIdx.x;
     double s = 0.0;
@@ -110,24 +139,35 @@ __global__ __launch_bounds__(256) void clip_finish_kernel(const float* __restric
         if (sumsq) sumsq[0] = ss;
         coef[0] = c;
         if (norm_out) norm_out[0] = nrm;
+        txn_gate(gate);
     }
 }
 
 // norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out, TxnGate gate) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float nrm = sqrtf(sumsq[0]);
         float c = max_norm / (nrm + 1e-6f);
         if (c > 1.f) c = 1.f;
         coef[0] = c;
         if (norm_out) norm_out[0] = nrm;
+        txn_gate(gate);
     }
+}
+
+// data parallel: guard[0] = 1 when one of this rank's persistent launches reported a timeout, else 0 -- written into the tail
+// padding of the gradient buffer that is about to be mean-all-reduced, so that afterwards it is non-zero on EVERY rank iff any
+// rank was void (all ranks then void the same step and replay it together)
+__global__ void txn_guard_kernel(const int* status1, const int* status2, float* guard) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        guard[0] = ((status1 && status1[0] != 0) || (status2 && status2[0] != 0)) ? 1.f : 0.f;
 }
 
 // g <- g*coef (optional write-back); p <- p - lr * g
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, long n,
                                                   const float* __restrict__ lr, const float* __restrict__ coef,
-                                                  int write_back) {
+                                                  int write_back, const float* __restrict__ void_flag) {
+    if (void_flag && void_flag[0] != 0.f) return;      // the step was voided by the transaction gate: nothing is applied
     const float c = coef ? coef[0] : 1.f;
     const float a = lr[0];
     const bool wb = write_back && c != 1.0f;      // g * 1 is g: the clipped-gradient write-back is skipped when the clip is inactive
@@ -205,7 +245,9 @@ __global__ __launch_bounds__(256) void keep_scale_v4_kernel(float* __restrict__ 
     reinterpret_cast<float4*>(x)[i] = v;
 }
 
-__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef) {
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, const float* __restrict__ coef,
+                                                    const float* __restrict__ void_flag) {
+    if (void_flag && void_flag[0] != 0.f) return;
     const float c = coef[0];
     if (c == 1.0f) return;            // clip inactive (coef is exactly 1): x * 1 is x bit for bit, skip the pass
     const long stride = (long)gridDim.x * 256;
@@ -271,7 +313,24 @@ extern "C" int lv_sumsq_f32(const float* x, long n, float* ws, float* out, int a
 
 extern "C" int lv_clip_coef_f32(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
     if (!sumsq || !coef) return LV_ERR_ARG;
-    LV_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, stream, sumsq, max_norm, coef, norm_out);
+    LV_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, stream, sumsq, max_norm, coef, norm_out, TxnGate{nullptr, nullptr, nullptr, nullptr, nullptr});
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// lv_clip_coef_f32 + the transaction gate (see TxnGate): status1 / status2 / guard may be null; txn = device float[5] {void flag,
+// steps committed, pending loss, rec, kl sums}; acc = device float[3] the committed running sums (may be null)
+extern "C" int lv_clip_coef_txn_f32(const float* sumsq, float max_norm, float* coef, float* norm_out, const int* status1,
+                                    const int* status2, const float* guard, float* txn, float* acc, void* stream) {
+    if (!sumsq || !coef || !txn) return LV_ERR_ARG;
+    LV_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, stream, sumsq, max_norm, coef, norm_out, TxnGate{status1, status2, guard, txn, acc});
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_txn_guard_f32(const int* status1, const int* status2, float* guard, void* stream) {
+    if (!guard) return LV_ERR_ARG;
+    LV_LAUNCH(txn_guard_kernel, dim3(1), dim3(64), 0, stream, status1, status2, guard);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -287,7 +346,17 @@ extern "C" int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, 
                                int write_back_clipped, void* stream) {
     if (!p || !g || !lr_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
-    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped);
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, (const float*)nullptr);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// lv_sgd_step_f32 behind the transaction gate: a no-op while void_flag_dev[0] != 0 (txn[0] of lv_clip_*_txn_f32)
+extern "C" int lv_sgd_step_txn_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev,
+                                   int write_back_clipped, const float* void_flag_dev, void* stream) {
+    if (!p || !g || !lr_dev || !void_flag_dev || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, void_flag_dev);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -320,7 +389,15 @@ extern "C" int lv_cvt_f32_bf16_scaled(const uint16_t* src, long n, float scale, 
 extern "C" int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream) {
     if (!x || !coef_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
-    LV_LAUNCH(scale_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, x, n, coef_dev);
+    LV_LAUNCH(scale_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, x, n, coef_dev, (const float*)nullptr);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_scale_txn_f32(float* x, long n, const float* coef_dev, const float* void_flag_dev, void* stream) {
+    if (!x || !coef_dev || !void_flag_dev || n < 0) return LV_ERR_ARG;
+    if (n == 0) return LV_OK;
+    LV_LAUNCH(scale_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, x, n, coef_dev, void_flag_dev);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -362,7 +439,24 @@ extern "C" int lv_clip_norm2_f32(const float* g1, long n1, const float* g2, long
     if (nb2 > NORM_BLOCKS) nb2 = NORM_BLOCKS;
     LV_LAUNCH(sumsq2_stage1_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, stream, g1, n1, (int)nb1, g2, n2, (int)nb2, ws);
     LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), max_norm, sumsq_dev, coef_dev,
-              norm_dev);
+              norm_dev, TxnGate{nullptr, nullptr, nullptr, nullptr, nullptr});
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// lv_clip_norm2_f32 + the transaction gate (see TxnGate / lv_clip_coef_txn_f32)
+extern "C" int lv_clip_norm2_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
+                                     float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
+                                     const float* guard, float* txn, float* acc, void* stream) {
+    if (!g1 || !g2 || !ws || !coef_dev || !txn || n1 < 0 || n2 < 0) return LV_ERR_ARG;
+    long nb1 = (n1 + 8191) / 8192, nb2 = (n2 + 8191) / 8192;
+    if (nb1 < 1) nb1 = 1;
+    if (nb1 > NORM_BLOCKS) nb1 = NORM_BLOCKS;
+    if (nb2 < 1) nb2 = 1;
+    if (nb2 > NORM_BLOCKS) nb2 = NORM_BLOCKS;
+    LV_LAUNCH(sumsq2_stage1_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, stream, g1, n1, (int)nb1, g2, n2, (int)nb2, ws);
+    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), max_norm, sumsq_dev, coef_dev,
+              norm_dev, TxnGate{status1, status2, guard, txn, acc});
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

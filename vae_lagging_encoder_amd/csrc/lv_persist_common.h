@@ -1,5 +1,5 @@
-// lv_persist_common.h -- what the persistent LSTM kernels (lv_lstm_persist.hip, lv_lstm_persist16.hip) share: the XCD-group
-// geometry and the tagged 8-byte hand-off granules.
+// lv_persist_common.h -- the XCD-group geometry and the tagged 8-byte hand-off granules of the persistent LSTM kernels
+// (lv_lstm_persist16.hip).
 #pragma once
 #include "lv_device.h"
 

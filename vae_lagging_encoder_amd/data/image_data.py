@@ -19,8 +19,12 @@ def load_image_triple(path, device=None):
 
 
 def sampler_order(n):
-    """The order torch.utils.data.RandomSampler gives a shuffled DataLoader pass (what image.py:219-221's loaders draw on every
-    `for datum in loader`): one int64 seed from torch's global generator, then randperm(n) from a private generator."""
+    """The order a shuffled DataLoader pass yields (what image.py:219-221's loaders draw on every `for datum in loader`), with
+    the same consumption of torch's global generator: the DataLoader iterator first draws its `_base_seed` (one int64 from the
+    global generator, used only for worker seeding -- torch >= 2.0's _BaseDataLoaderIter), THEN RandomSampler draws its own
+    int64 seed and takes randperm(n) from a private generator seeded with it.  (tests/test_host_logic.py compares this against a
+    real DataLoader under the same seed, orders and the state the global generator is left in.)"""
+    torch.empty((), dtype=torch.int64).random_()          # _BaseDataLoaderIter._base_seed: drawn and not used in-process
     seed = int(torch.empty((), dtype=torch.int64).random_().item())
     g = torch.Generator()
     g.manual_seed(seed)

@@ -93,8 +93,20 @@ class GradSync(object):
         lib = _eng.backend_for(flat.device)
         if self._inv is None or self._inv.device != flat.device:
             self._inv = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.device)
-        hi = flat.numel if hi is None else hi
-        lib.lv_scale_f32(P(flat.grad, lo), hi - lo, P(self._inv), _eng.stream_ptr(flat.device))
+        hi = flat.grad_padded.numel() if hi is None else min(hi, flat.grad_padded.numel())
+        if hi <= lo:
+            return
+        # over the padded buffer: the guard element in the tail padding (trainer's transaction gate) only has to stay non-zero
+        lib.lv_scale_f32(P(flat.grad_padded, lo), hi - lo, P(self._inv), _eng.stream_ptr(flat.device))
+
+    def begin_step(self):
+        """Called by the trainer before a step queues anything: collectives a previous step left in flight -- an exception between
+        the encoder backward and sync() -- are waited for and dropped, so that this step's buckets start from a clean slate on
+        every rank (a stale handle would otherwise trip the overlap check of start_encoder_bucket for good)."""
+        stale = [b[0] for b in self._buckets] + [h[0] for h in (self._h_dec,) if h is not None] + [h for h in (self._h_rs,) if h is not None]
+        self._buckets, self._h_dec, self._h_rs = [], None, None
+        for h in stale:
+            h.wait()
 
     # ---- measurement ------------------------------------------------------------------------------------------------
     class _Phase(object):
@@ -145,8 +157,12 @@ class GradSync(object):
 
     def _unwire(self, flat, t16, scale, lo=0, hi=None):
         lib = _eng.backend_for(t16.device)
-        hi = flat.numel if hi is None else min(hi, flat.numel)
-        lib.lv_cvt_f32_bf16_scaled(P(t16), hi - lo, scale, P(flat.grad, lo), _eng.stream_ptr(t16.device))
+        pad = flat.grad_padded.numel()
+        hi = pad if hi is None else min(hi, pad)
+        if hi <= lo:
+            return
+        # into the padded buffer (the tail padding carries the transaction guard element)
+        lib.lv_cvt_f32_bf16_scaled(P(t16), hi - lo, scale, P(flat.grad_padded, lo), _eng.stream_ptr(t16.device))
 
     def _all_reduce_mean_start(self, flat, lo=0, hi=None):
         """Start the mean all-reduce of (a 1024-aligned range of) a flat gradient buffer; returns what
@@ -163,7 +179,7 @@ class GradSync(object):
         if t16 is not None:
             self._unwire(flat, t16, 1.0 / self.world, lo, hi)
         else:
-            self._scale(flat, lo, min(hi, flat.numel))
+            self._scale(flat, lo, hi)
 
     def start_encoder_bucket(self, enc_flat, lo, hi):
         """Issue the mean all-reduce of encoder-gradient elements [lo, hi) now (lo, hi multiples of 1024 elements, or hi = the

@@ -62,8 +62,11 @@ class FlatBuffer(object):
         self.device = torch.device(device)
         self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
         # gradients: zero tail padding to a multiple of 1024 elements, so the buffer splits evenly across any power-of-two
-        # world size (reduce-scatter of dist.GradSync); kernels only ever touch [0, numel)
-        self.grad_padded = torch.zeros(_round_up(off, 1024), dtype=torch.float32, device=self.device)
+        # world size (reduce-scatter of dist.GradSync); kernels only ever touch [0, numel).  There is always at least one
+        # padding element: the LAST one is the data-parallel transaction guard (lv_txn_guard_f32 writes 1 there when this rank's
+        # persistent launches reported a timeout; after the mean all-reduce it is non-zero on every rank iff any rank did)
+        self.grad_padded = torch.zeros(_round_up(off + 1, 1024), dtype=torch.float32, device=self.device)
+        self.guard_index = self.grad_padded.numel() - 1
         self.grad = self.grad_padded[:off]
         self.views, self.gviews = {}, {}
         for n, p in named_params:
@@ -287,22 +290,30 @@ class _TokenSortCache(object):
     meeting the same batch tensors (text.py:389 draws from the fixed list train_data_batch): the sorted (rows, tokens) pair is
     kept per batch TENSOR -- weakly (it dies with the tensor) and only while the tensor's version counter is unchanged -- so that
     in steady state the two single-workgroup sort launches of a step (75 us each, and nothing can run beside the persistent
-    recurrences they used to hide behind) disappear.  Not used under hipGraph capture (a captured step owns fixed buffers)."""
+    recurrences they used to hide behind) disappear.  Not used under hipGraph capture (a captured step owns fixed buffers).
+
+    CONTRACT: a batch tensor handed to step() is immutable, as the reference's train_data_batch entries are.  In-place torch ops
+    bump the version counter and are noticed; writes that bypass it are NOT -- `x.data.copy_(...)`, a numpy view of a CPU tensor,
+    DLPack / custom-kernel writes into a reused device buffer: after those call `invalidate(x)` (or pass a fresh tensor), else the
+    embedding gradients of both networks are scattered with the old batch's token lists.  At most LIMIT batches are kept, the least
+    recently used ones go first."""
     LIMIT = 8192
 
     def __init__(self):
-        self.map = {}          # id(tensor) -> (weak reference to the tensor, {tag: (version, rows, tokens)})
+        import collections
+        self.map = collections.OrderedDict()   # id(tensor) -> (weak reference to the tensor, {tag: (version, rows, tokens)})
 
     def _entries(self, key_tensor, create):
         i = id(key_tensor)
         ent = self.map.get(i)
         if ent is not None and ent[0]() is key_tensor:
+            self.map.move_to_end(i)
             return ent[1]
         if not create:
             return None
         import weakref
-        if len(self.map) >= self.LIMIT:
-            self.map.clear()
+        while len(self.map) >= self.LIMIT:
+            self.map.popitem(last=False)       # least recently used batch (its buffers go back to the caching allocator)
         # (tensors compare element-wise, so they cannot key a WeakKeyDictionary: identity + a weak reference that retires the id)
         self.map[i] = (weakref.ref(key_tensor, lambda _r, i=i, m=self.map: m.pop(i, None)), {})
         return self.map[i][1]
@@ -315,48 +326,78 @@ class _TokenSortCache(object):
     def put(self, key_tensor, tag, srows, stok):
         self._entries(key_tensor, True)[tag] = (key_tensor._version, srows, stok)
 
+    def invalidate(self, key_tensor=None):
+        """Forget the sorted lists of one batch tensor (None: of all) -- for callers that rewrote a batch behind the version counter."""
+        if key_tensor is None:
+            self.map.clear()
+        else:
+            self.map.pop(id(key_tensor), None)
+
 
 def reset_persistent_status(eng):
-    """Clear the status word (after the caller has handled a reported timeout, e.g. by turning `persistent` off)."""
-    st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
-    if st is not None:
-        st.zero_()
+    """Clear the status word (after the caller has handled a reported timeout, e.g. by moving down the fallback ladder)."""
+    if eng.status is not None:
+        eng.status.zero_()
 
 
-_PERSIST_H = 1024        # lv_lstm_persist.hip is built for this hidden size
-# hand-off of the persistent BPTT: "rs" = reduce-scatter of partial dh sums (2048 granules per workgroup and timestep),
-# "ag" = all-gather of dG (8192); read when the weight images are packed
-PERSIST_BWD_FORM = "rs"
-# product of the persistent forward: "ks" = contraction split over the workgroup's waves (4x4x4 MFMA, barrier after the product),
-# "cols" = gate columns split over the waves (16x16x32 MFMA, barrier before the product)
-PERSIST_FWD_FORM = "ks"
-# The persistent launches run on the kernels of lv_lstm_persist16.hip (<= 16 rows per XCD group: B <= 128, BASELINE.json
-# configs[4]; eng.persist_rows asks for a row count per group, e.g. 8 rows on four groups = a B = 32 recurrence on half the chip)
-# with their hand-off granules kept in the XCD's L2 (PERSIST16_FLAGS bit 0: no agent-scope write-through; measured 3.2 -> 2.2 us
-# per forward timestep, 3.1 -> 2.7 us per BPTT timestep at B = 32).  PERSIST16_ALWAYS = False sends B <= 32 to the 4-row kernels
-# of lv_lstm_persist.hip instead (A/B measurements, tests).
-PERSIST16_ALWAYS = True
-PERSIST16_FLAGS = 1
+# ---- the fallback ladder of the persistent recurrences -----------------------------------------------------------------------
+# rung 0: persistent launches, hand-off granules kept in the XCD's L2 (persist_flags bit 0) -- the fast form, which ASSUMES that
+#         the 32 workgroups of a group (blockIdx % 8) share an XCD: checked by the bounded spins, never proven;
+# rung 1: persistent launches with agent-scope (write-through) granules: any placement works as long as all 256 workgroups are
+#         resident together (they are not when something else holds compute units, e.g. a collective's kernels);
+# rung 2: the launch-per-timestep kernels: no co-residency assumption at all.
+# A timeout is reported through the engine's device status word; the fused trainers gate every update on it ON THE DEVICE
+# (lv_clip_*_txn_f32), notice it at their next host read, call demote_persistent() and replay the voided steps.
+PERSIST_RUNGS = ("persistent, XCD-local hand-off", "persistent, write-through hand-off", "launch-per-timestep kernels")
+
+
+def persist_rung(eng):
+    if not eng.persistent:
+        return 2
+    return 0 if (eng.persist_flags & 1) else 1
+
+
+def demote_persistent(eng):
+    """Move `eng` one rung down the ladder and clear its status word; returns the new rung.  Raises when there is nothing left
+    (the launch-per-timestep kernels have no hand-off that could time out)."""
+    r = persist_rung(eng)
+    if r == 0:
+        eng.persist_flags &= ~1
+    elif r == 1:
+        eng.persistent = False
+    else:
+        raise _lib.LvaeError("a persistent-launch timeout was reported although the engine runs the launch-per-timestep kernels")
+    reset_persistent_status(eng)
+    return r + 1
+
+
+def status_ptr(eng):
+    """Device pointer of the engine's persistent-launch status word (None before ensure())."""
+    return P(eng.status) if eng.status is not None else None
+
+
+_PERSIST_H = 1024        # lv_lstm_persist16.hip is built for this hidden size
+# The persistent launches (lv_lstm_persist16.hip): <= 16 rows per XCD group, so B <= 128 (BASELINE.json configs[4] runs 16 rows on
+# each of the 8 groups); eng.persist_rows asks for a row count per group (e.g. 8 rows on four groups = a B = 32 recurrence on
+# half the chip); eng.persist_flags bit 0 keeps the hand-off granules in the XCD's L2 (no agent-scope write-through; measured
+# 3.2 -> 2.2 us per forward timestep, 3.1 -> 2.7 us per BPTT timestep at B = 32) -- rung 0 of the ladder above.
 _PERSIST_MAX_B = 128
 
 
 def _persist_rows(eng, B):
-    """(use the 16-row kernels?, rows per group) for a persistent launch of batch B on this engine."""
+    """Rows per XCD group for a persistent launch of batch B on this engine."""
     rows = getattr(eng, "persist_rows", None)
     if rows is not None and 8 * rows >= B and 1 <= rows <= 16:
-        return True, int(rows)
-    if B > 32 or PERSIST16_ALWAYS:
-        return True, (B + 7) // 8
-    return False, (B + 7) // 8
+        return int(rows)
+    return (B + 7) // 8
 
 
 def _saved_floats(eng, T, B, H):
-    """Floats of one LSTM layer's saved-activation buffer: gates [T][B][4H] for the step kernels and the 4-row persistent ones;
-    the kernels of lv_lstm_persist16.hip keep gates AND cell states in a workgroup-major record buffer of their own size."""
+    """Floats of one LSTM layer's saved-activation buffer: gates [T][B][4H] for the step kernels; the persistent kernels keep
+    gates AND cell states in a workgroup-major record buffer of their own size."""
     n = T * B * 4 * H
-    use16, rows = _persist_rows(eng, B)
-    if use16 and H == _PERSIST_H and eng.precision == "bf16" and eng.persistent:
-        n = max(n, eng.lib.lv_lstm_persist16_saved_floats(T, rows))
+    if H == _PERSIST_H and eng.precision == "bf16" and eng.persistent and B <= _PERSIST_MAX_B:
+        n = max(n, eng.lib.lv_lstm_persist16_saved_floats(T, _persist_rows(eng, B)))
     return n
 
 
@@ -371,7 +412,7 @@ def weights_version(eng):
     return (sum(p._version for p in eng.flat.params), eng.wgen)
 
 
-def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, want_persist16=False):
+def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
     """Engine-level bf16 images of the module's weights for the throughput path -- W_ih rows in unit-major gate order
     (4u + g: Gx comes out with each unit's (i,f,g,o) side by side), W_ih^T [ni][4H] (contraction index of dX), for the
     decoder also pred_linear.weight / its transpose, and the packed register images of W_hh for the persistent
@@ -385,7 +426,7 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, wan
     if wi is None:
         wi = eng._wimg = _NS()
         wi.ver = object()
-        wi.W = wi.WT = wi.pred = wi.predT = wi.fwd = wi.bwd = None
+        wi.W = wi.WT = wi.pred = wi.predT = wi.fwd16 = wi.bwd16 = wi.xch = None
         if lstm:
             wi.W = c.i16(4 * H, ni)
             wi.WT = c.i16(ni, 4 * H)
@@ -393,7 +434,7 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, wan
         if pred:
             wi.pred = c.i16(V, H)
             wi.predT = c.i16(H, wi.ldv)
-        wi.packed = False
+        wi.packed16 = False
     ver = weights_version(eng) if eng.cache_weight_images else object()
     stale = wi.ver != ver
     if stale:
@@ -403,27 +444,12 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, wan
         if wi.pred is not None:
             lib.lv_cvt_bf16_f32(P(v["pred_linear.weight"]), H, V, H, P(wi.pred), H, P(wi.predT), wi.ldv, s)
         wi.ver = ver
-        wi.packed = False
-    if want_persist and not wi.packed:
-        if wi.fwd is None:
-            n = lib.lv_lstm_persist_wpk_floats()
-            wi.fwd, wi.bwd = c.f32(n), c.f32(n)
-            wi.fwd16 = wi.bwd16 = None
-            wi.xch = c.f32(max(lib.lv_lstm_persist_xch_floats(), lib.lv_lstm_persist16_xch_floats()))
-            wi.status = torch.zeros(1, dtype=torch.int32, device=device)
-        wi.packed4 = wi.packed16 = False
-        wi.packed = True
-    if want_persist and not want_persist16 and not wi.packed4:
-        # the 4-row forms of lv_lstm_persist.hip (PERSIST16_ALWAYS off, B <= 32)
-        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd), 3 if PERSIST_FWD_FORM == "ks" else 0, H, s)
-        wi.fwd_form = PERSIST_FWD_FORM
-        lib.lv_lstm_persist_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd), 2 if PERSIST_BWD_FORM == "rs" else 1, H, s)
-        wi.bwd_form = PERSIST_BWD_FORM
-        wi.packed4 = True
-    if want_persist and want_persist16 and not wi.packed16:
+        wi.packed16 = False
+    if want_persist and not wi.packed16:
         if wi.fwd16 is None:
-            n = lib.lv_lstm_persist_wpk_floats()
+            n = lib.lv_lstm_persist16_wpk_floats()
             wi.fwd16, wi.bwd16 = c.f32(n), c.f32(n)
+            wi.xch = c.f32(lib.lv_lstm_persist16_xch_floats())
         lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), 0, H, s)
         lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd16), 1, H, s)
         wi.packed16 = True
@@ -432,7 +458,7 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False, wan
 
 def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, device):
     """The forward recurrence of one LSTM layer: exact f32, bf16 launch-per-step, or (bf16 image path on a >= 256-CU
-    device, H = 1024, B <= 64) the single persistent launch of lv_lstm_persist.hip."""
+    device, H = 1024, B <= 128) the single persistent launch of lv_lstm_persist16.hip."""
     args = (Gx, whh, P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop)
     w.saved_layout = ("canonical", T, B, 0)
     if eng.precision != "bf16":
@@ -441,18 +467,14 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         lib.lv_lstm_fwd_bf16(*args, P(w.lstm_ws), T, B, H, s)
     elif _persistent_ok(eng, img, B, H, device, _PERSIST_MAX_B):
         wi = eng._wimg          # packed by _weight_images(want_persist=True) at the top of the forward
-        use16, rows = _persist_rows(eng, B)
-        if use16:
-            if mask is not None or hdrop is not None:
-                raise _lib.LvaeError("the 16-row persistent forward has no in-kernel dropout (the engine applies it on the images)")
-            need = lib.lv_lstm_persist16_saved_floats(T, rows)
-            if w.gates.numel() < need:              # eng.persist_rows changed after the workspace was built
-                w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
-            lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(wi.status), T, B, rows, PERSIST16_FLAGS, H, s)
-            w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
-        else:
-            fn = lib.lv_lstm_fwd_bf16_persist_ks if wi.fwd_form == "ks" else lib.lv_lstm_fwd_bf16_persist
-            fn(Gx, P(wi.fwd), P(w.hs), P(w.cs), P(w.gates), mask, scale, hdrop, P(wi.xch), P(wi.status), T, B, H, s)
+        rows = _persist_rows(eng, B)
+        if mask is not None or hdrop is not None:
+            raise _lib.LvaeError("the persistent forward has no in-kernel dropout (the engine applies it on the images)")
+        need = lib.lv_lstm_persist16_saved_floats(T, rows)
+        if w.gates.numel() < need:              # eng.persist_rows / eng.persistent changed after the workspace was built
+            w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
+        lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(eng.status), T, B, rows, eng.persist_flags, H, s)
+        w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
 
@@ -463,11 +485,13 @@ _PERSIST_BWD_MAX_B = 128
 def check_persistent_status(eng):
     """Raise if a persistent LSTM launch of this engine ever reported a hand-off timeout (device status word; one host
     read -- call it where the host synchronises anyway)."""
-    st = getattr(eng._wimg, "status", None) if eng._wimg is not None else None
+    st = eng.status
     if st is not None and int(st.item()) != 0:
-        raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d): not all 256 workgroups were resident "
-                             "(e.g. another kernel held compute units for seconds), or -- with engine.PERSIST16_FLAGS bit 0 set -- a "
-                             "group's workgroups were not placed on one XCD (set it to 0 to write the granules through)" % int(st.item()))
+        raise _lib.LvaeError("persistent LSTM kernel reported hand-off timeout (status %d) on ladder rung %d (%s): not all 256 "
+                             "workgroups were resident (e.g. another kernel held compute units for seconds), or -- with "
+                             "eng.persist_flags bit 0 set -- a group's workgroups were not placed on one XCD.  The fused trainers "
+                             "recover from this by themselves (engine.demote_persistent); on the drop-in autograd path call it and "
+                             "redo the step" % (int(st.item()), persist_rung(eng), PERSIST_RUNGS[persist_rung(eng)]))
 
 
 def _need_canonical_saved(w):
@@ -488,20 +512,14 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
     dG16 = P(img.dG) if img is not None else None
     if _persistent_ok(eng, img, B, H, device, _PERSIST_BWD_MAX_B):
         wi = eng._wimg
-        use16, rows = _persist_rows(eng, B)
-        if use16:
-            if mask is not None:
-                raise _lib.LvaeError("the 16-row persistent BPTT has no in-kernel dropout mask (the engine applies it on dO)")
-            if getattr(w, "saved_layout", None) != ("persist16", T, B, rows):
-                raise _lib.LvaeError("the saved activations were not written by a 16-row persistent forward with the same T, B and rows per "
-                                     "group (%r): eng.persist_rows / eng.persistent changed between forward and backward" % (getattr(w, "saved_layout", None),))
-            lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
-                                           P(wi.status), dh0, dc0, tanh_init, T, B, rows, PERSIST16_FLAGS, H, s)
-        else:
-            _need_canonical_saved(w)
-            fn = lib.lv_lstm_bwd_bf16_persist_rs if wi.bwd_form == "rs" else lib.lv_lstm_bwd_bf16_persist
-            fn(dh_ext, dh_last, mask, scale, P(wi.bwd), P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum), P(wi.xch), P(wi.status),
-               dh0, dc0, tanh_init, T, B, H, s)
+        rows = _persist_rows(eng, B)
+        if mask is not None:
+            raise _lib.LvaeError("the persistent BPTT has no in-kernel dropout mask (the engine applies it on dO)")
+        if getattr(w, "saved_layout", None) != ("persist16", T, B, rows):
+            raise _lib.LvaeError("the saved activations were not written by a persistent forward with the same T, B and rows per "
+                                 "group (%r): eng.persist_rows / eng.persistent changed between forward and backward" % (getattr(w, "saved_layout", None),))
+        lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
+                                       P(eng.status), dh0, dc0, tanh_init, T, B, rows, eng.persist_flags, H, s)
     else:
         _need_canonical_saved(w)
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
@@ -608,6 +626,8 @@ class LSTMEncoderEngine(object):
         self.native16 = True      # bf16 path: pre-rounded bf16 operand images (lv_gemm_b16) where the shapes allow
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
         self.persist_rows = None                # rows per XCD group of the persistent launches (None: B / 8; 8 at B = 32 = half the chip)
+        self.persist_flags = 1                  # bit 0: hand-off granules stay in the XCD's L2 (ladder rung 0; see demote_persistent)
+        self.status = None                      # device int32: a persistent launch's hand-off timeout is reported here
         self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
         self._wimg = None
@@ -634,7 +654,7 @@ class LSTMEncoderEngine(object):
         self.ensure(device)
         persist = self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and torch.device(device).type == "cuda" and \
             torch.cuda.get_device_properties(device).multi_processor_count >= 256
-        return _weight_images(self, self.lib, stream_ptr(device), device, persist, want_persist16=_persist_rows(self, B)[0])
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist)
 
     def ensure(self, device):
         device = torch.device(device)
@@ -650,6 +670,8 @@ class LSTMEncoderEngine(object):
             # the parameters' version counters, so weights_version() alone would not notice)
             self._wimg = None
         self.lib = backend_for(device)
+        if self.status is None or self.status.device != device:
+            self.status = torch.zeros(1, dtype=torch.int32, device=device)
         return self.flat
 
     def dims(self):
@@ -801,6 +823,8 @@ class LSTMDecoderEngine(object):
         self.native16 = True      # bf16 path: feed the vocabulary-sized GEMMs pre-rounded bf16 operand images (lv_gemm_b16)
         self.persistent = _PERSISTENT_DEFAULT   # bf16 image path: forward recurrence as one persistent launch where supported
         self.persist_rows = None                # rows per XCD group of the persistent launches (see LSTMEncoderEngine)
+        self.persist_flags = 1
+        self.status = None
         # The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only): its bf16
         # weight images and packed recurrent weights are rebuilt only when weights_version() changes.
         self.cache_weight_images = True
@@ -871,6 +895,8 @@ class LSTMDecoderEngine(object):
             # the parameters' version counters, so weights_version() alone would not notice)
             self._wimg = None
         self.lib = backend_for(device)
+        if self.status is None or self.status.device != device:
+            self.status = torch.zeros(1, dtype=torch.int32, device=device)
         return self.flat
 
     def dims(self):
@@ -952,8 +978,7 @@ class LSTMDecoderEngine(object):
         self.ensure(device)
         persist = use_lstm and self.persistent and H == _PERSIST_H and B <= _PERSIST_MAX_B and \
             torch.device(device).type == "cuda" and torch.cuda.get_device_properties(device).multi_processor_count >= 256
-        return _weight_images(self, self.lib, stream_ptr(device), device, persist, lstm=use_lstm, pred=use_pred,
-                              want_persist16=_persist_rows(self, B)[0])
+        return _weight_images(self, self.lib, stream_ptr(device), device, persist, lstm=use_lstm, pred=use_pred)
 
     def _lstm_images(self, Bd, Td):
         V, ni, H, nz = self.dims()

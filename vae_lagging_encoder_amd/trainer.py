@@ -58,10 +58,16 @@ class AggressiveTextTrainer(object):
         self._capturing = False
         self._update = "encoder"
         d = self.device
-        # device scalars: [kl_weight, lr, sumsq, coef, norm, loss_sum, rec_sum, kl_sum]
-        self.scal = torch.zeros(8, dtype=torch.float32, device=d)
+        # device scalars: [0 kl_weight, 1 lr, 2 sumsq, 3 coef, 4 norm, 5 loss_sum, 6 rec_sum, 7 kl_sum,
+        #                  8 void flag, 9 steps committed, 10..12 (loss, rec, kl) sums of the step in flight]  -- 8..12 = the
+        # transaction block of lv_clip_*_txn_f32: a step whose persistent recurrences timed out is voided on the device
+        self.scal = torch.zeros(16, dtype=torch.float32, device=d)
         self.scal[1] = lr
         self._klw_host = 0.0                  # host copy of scal[0]
+        self._journal = []                    # steps queued since the last host check: (x, kl_weight, noise, update)
+        self._committed_base = 0.0            # scal[9] at the last host check
+        self.on_demote = None                 # optional callback(rung) after a move down the persistent-launch ladder (logging)
+        self.recoveries = 0                   # how many times a voided run of steps was replayed
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
         # into the key), otherwise row i of every rank's batch would see the same eps / dropout masks.
@@ -83,12 +89,54 @@ class AggressiveTextTrainer(object):
     def set_lr(self, lr):
         self.scal[1] = lr
 
+    # how many steps may be queued before the driver looks at the transaction block on its own (one host read)
+    JOURNAL_MAX = 64
+
     def read_stats(self):
-        """One host read: dict(loss_sum, rec_sum, kl_sum, norm, coef) accumulated since reset_stats()."""
-        v = self.scal.cpu().tolist()
-        _eng.check_persistent_status(self.enc)
-        _eng.check_persistent_status(self.dec)
+        """One host read: dict(loss_sum, rec_sum, kl_sum, norm, coef) accumulated since reset_stats() -- over COMMITTED steps:
+        the same read settles the transaction block (a run of steps voided by a persistent-launch timeout is replayed first)."""
+        v = self._settle(self.scal.cpu().tolist())
         return dict(loss_sum=v[5], rec_sum=v[6], kl_sum=v[7], norm=v[4], coef=v[3])
+
+    def commit(self):
+        """One host read that makes sure every step queued so far has been applied (text.py:385-387 semantics: an update is
+        computed from complete recurrences or not at all).  Returns the ladder rung the engines run on afterwards."""
+        self._settle(self.scal.cpu().tolist())
+        return max(_eng.persist_rung(self.enc), _eng.persist_rung(self.dec))
+
+    def _settle(self, v):
+        """v: host copy of the device scalars.  While the void flag is up: the first (steps committed) entries of the journal were
+        applied, the rest was voided ON THE DEVICE (no weight, no report sum moved) -- move both engines one rung down the
+        fallback ladder (engine.demote_persistent: write-through hand-off, then the launch-per-timestep kernels), clear the
+        gate and queue the voided steps again.  Data parallel: the guard element makes every rank void the same step, so all
+        ranks take these decisions identically.  The random draws of a replayed step are new ones (the Philox offset is not
+        rewound); injected noise is replayed as given."""
+        while v[8] != 0.0:
+            done = int(round(v[9] - self._committed_base))
+            redo = self._journal[done:]
+            if all(_eng.persist_rung(e) == 2 for e in (self.enc, self.dec)):
+                raise _eng._lib.LvaeError("a step was voided although both engines run the launch-per-timestep kernels (status words "
+                                          "%s / %s)" % (self.enc.status.tolist(), self.dec.status.tolist()))
+            for e in (self.enc, self.dec):
+                if _eng.persist_rung(e) < 2:
+                    _eng.demote_persistent(e)
+                else:
+                    _eng.reset_persistent_status(e)
+            self.recoveries += 1
+            for st in self.static.values():
+                st.graphs = {}                 # captured graphs hold the launches of the rung that failed
+            self.scal[8:13] = 0
+            self._committed_base = 0.0
+            self._journal = []
+            if self.on_demote is not None:
+                self.on_demote(max(_eng.persist_rung(self.enc), _eng.persist_rung(self.dec)))
+            for x, klw, noise, update in redo:
+                self._queue_step(x, klw, noise, update)
+                self._journal.append((x, klw, noise, update))
+            v = self.scal.cpu().tolist()
+        self._committed_base = v[9]
+        self._journal = []
+        return v
 
     def reset_stats(self):
         self.scal[5:8] = 0
@@ -115,6 +163,12 @@ class AggressiveTextTrainer(object):
                 tmp = eng.wsc.i32(2 * Tu * B)
                 lib.lv_token_sort(P(x), T, Tu, B, V, P(srows), P(stok), P(tmp), s)
                 eng._sorts.put(x, (Tu, B), srows, stok)
+
+    def invalidate_batch(self, x=None):
+        """A batch tensor was rewritten behind torch's version counter (x.data.copy_, a numpy view, a DLPack / custom-kernel
+        write): drop its cached sorted token lists (None: all of them).  See engine._TokenSortCache."""
+        self.enc._sorts.invalidate(x)
+        self.dec._sorts.invalidate(x)
 
     # -- per-(B,T) static state ----------------------------------------------------------------------
     def _static_for(self, B, T):
@@ -167,7 +221,7 @@ class AggressiveTextTrainer(object):
         w = self.dec._ws(B, T - 1)
         # rec, loss, the running report sums and the seeds of mean_b(loss_b).backward(), one launch
         lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
-                                 self._s(5), T - 1, B, s)
+                                 self._s(10), T - 1, B, s)      # pending sums: committed by the transaction gate
         dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
         hook = bucket = None
         if self.grad_sync is not None and not self._capturing and self.grad_sync.world > 1:
@@ -193,6 +247,10 @@ class AggressiveTextTrainer(object):
                 start()                   # step kernels: the collective runs under the whole encoder backward
         self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl), after_bptt=hook, after_embed=bucket)
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
+        if self.grad_sync is not None and self.grad_sync.world > 1:
+            # data parallel: this rank's timeout flag rides in the tail padding of the encoder gradient (exchanged by sync())
+            ef = self.enc.flat
+            lib.lv_txn_guard_f32(_eng.status_ptr(self.enc), _eng.status_ptr(self.dec), P(ef.grad_padded, ef.guard_index), s)
 
     def _collective_after_bptt(self):
         """True when the encoder's BPTT may be a persistent launch: a collective must then not be in flight beside it."""
@@ -201,26 +259,33 @@ class AggressiveTextTrainer(object):
     def _clip_and_step(self, update, dec_ss=None):
         lib, s = self.lib, _eng.stream_ptr(self.device)
         ef, df = self.enc.flat, self.dec.flat
+        # the transaction gate rides in the clip coefficient's launch: status words of both engines, data parallel also the
+        # exchanged guard element; it commits the step's report sums (scal[10..12] -> scal[5..7]) or raises the void flag scal[8]
+        dp = self.grad_sync is not None and self.grad_sync.world > 1
+        gate = (_eng.status_ptr(self.enc), _eng.status_ptr(self.dec), P(ef.grad_padded, ef.guard_index) if dp else None,
+                self._s(8), self._s(5))
         if dec_ss is None:
-            lib.lv_clip_norm2_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
-                                  self._s(4), s)
+            lib.lv_clip_norm2_txn_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
+                                      self._s(4), *gate, s)
         else:
             # data parallel, encoder-only step: the decoder gradient was exchanged as its sum of squares only (GradSync)
             lib.lv_sumsq_f32(P(ef.grad), ef.numel, P(self.norm_ws), self._s(2), 0, s)
             lib.lv_sum_accum_f32(P(dec_ss), 1, self._s(2), s)
-            lib.lv_clip_coef_f32(self._s(2), self.clip, self._s(3), self._s(4), s)
-        # clip_grad_norm_ scales every grad in place; the update only touches the stepped side
+            lib.lv_clip_coef_txn_f32(self._s(2), self.clip, self._s(3), self._s(4), *gate, s)
+        # clip_grad_norm_ scales every grad in place; the update only touches the stepped side; both are no-ops under the void flag
         if update in ("encoder", "both"):
-            lib.lv_sgd_step_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, s)
+            lib.lv_sgd_step_txn_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, self._s(8), s)
         else:
-            lib.lv_scale_f32(P(ef.grad), ef.numel, self._s(3), s)
+            lib.lv_scale_txn_f32(P(ef.grad), ef.numel, self._s(3), self._s(8), s)
         if update in ("decoder", "both"):
-            lib.lv_sgd_step_f32(P(df.data), P(df.grad), df.numel, self._s(1), self._s(3), 1, s)
+            lib.lv_sgd_step_txn_f32(P(df.data), P(df.grad), df.numel, self._s(1), self._s(3), 1, self._s(8), s)
         else:
-            lib.lv_scale_f32(P(df.grad), df.numel, self._s(3), s)
+            lib.lv_scale_txn_f32(P(df.grad), df.numel, self._s(3), self._s(8), s)
 
     def _run(self, st, update, draw):
         self._update = update
+        if self.grad_sync is not None:
+            self.grad_sync.begin_step()
         self._fwd_bwd(st, draw)
         dec_ss = None
         if self.grad_sync is not None:
@@ -232,10 +297,21 @@ class AggressiveTextTrainer(object):
 
         noise=(eps, mask_in, mask_out) injects the random draws (parity mode); None draws them on device.
         update: 'encoder' (inner loop, text.py:387), 'decoder' (joint step while aggressive, text.py:419-424)
-        or 'both' (joint step after aggressive mode ends)."""
+        or 'both' (joint step after aggressive mode ends).
+
+        The step is queued, not awaited.  It is also journalled until the next host read (read_stats / commit / every JOURNAL_MAX
+        steps): should a persistent recurrence of it time out, the device voids it -- and everything queued behind it -- and the
+        read replays the voided steps one rung down the fallback ladder (_settle).  x (and injected noise) must therefore stay
+        unmodified until then, as they must for the sorted-token cache."""
+        self._queue_step(x, kl_weight, noise, update)
+        self._journal.append((x, float(kl_weight), noise, update))
+        if len(self._journal) >= self.JOURNAL_MAX:
+            self.commit()
+
+    def _queue_step(self, x, kl_weight, noise, update):
         B, T = x.shape
         st = self._static_for(B, T)
-        if self.use_graph or not (x.is_contiguous() and x.device == self.device):
+        if self.use_graph or not (x.is_contiguous() and x.device == self.device and x.dtype == torch.int64):
             st.x.copy_(x)                 # captured graphs read the per-shape static buffer
             st.xin = st.x
         else:
@@ -346,9 +422,8 @@ class AggressiveTextTrainer(object):
                 burn_num_words = 0
                 self.reset_stats()
             sub_iter += 1
-        # a persistent-launch hand-off timeout must not go unnoticed in the modes that never read the statistics
-        _eng.check_persistent_status(self.enc)
-        _eng.check_persistent_status(self.dec)
+        # every step of the loop has been applied when it returns (one host read; a voided tail is replayed here)
+        self.commit()
         self.reset_stats()
         return steps
 
