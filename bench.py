@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--dp-payload", default="auto", choices=["auto", "f32", "bf16"],
                     help="wire format of the data-parallel gradient exchange (auto = bf16 for --dtype bf16, exact f32 mean for --dtype "
                          "f32; bf16 halves the bytes)")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="gradient accumulation: the step's batch as m row slices, slice i's gradient exchange under slice i+1's "
+                         "computation (costs m times the recurrences at B=32: they are latency-bound; see DESIGN.md section 6)")
     ap.add_argument("--pool", type=int, default=None)
     ap.add_argument("--tokens", default="uniform", choices=["uniform", "zipf"],
                     help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
@@ -354,7 +357,7 @@ def main():
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
     sync = lvdist.GradSync(mode=args.dp_mode, payload=args.dp_payload) if world > 1 else None
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, grad_sync=sync, use_graph=bool(args.graph),
-                               precision=args.dtype)
+                               precision=args.dtype, micro_batches=args.micro_batches)
     if args.overlap != "auto":
         tr.dec.overlap = (args.overlap == "on")
     tr.enc.persistent = tr.dec.persistent = bool(args.persistent)
@@ -431,7 +434,10 @@ def main():
             "unit": "ms per step on the compute stream (HIP events): time the step WAITED in each phase; hidden communication does not show",
             "phases": names + ["rank_ms_per_step"], "per_rank": rows, "exposed_ms_per_step_per_rank": exposed,
             "exposed_ms_per_step_max": max(exposed), "payload": sync.payload, "mode": args.dp_mode,
-            "bytes_sent_per_rank_per_step": int(sync.bytes_per_step(tr.enc.flat, tr.dec.flat)),
+            "bytes_sent_per_rank_per_step": int(sync.bytes_per_step(tr.enc.flat, tr.dec.flat)) * args.micro_batches,
+            "bytes_on_wire": sync.bytes_on_wire(tr.enc.flat, tr.dec.flat, "encoder", micro_batches=args.micro_batches,
+                                                n_emb=(tr.enc.flat.offsets[tr.enc.flat.names[1]] // 1024 * 1024) if not args.graph else 0),
+            "micro_batches": args.micro_batches,
             "encoder_bucket": "embedding gradient issued from inside the encoder backward (under dW_ih / dW_hh)" if not args.graph else "none (hipGraph split)"}
     stats = tr.read_stats()
 

@@ -38,7 +38,8 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
         vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
         mode, decoder = mode.split("/")[:2]
         gs = GradSync(mode=mode, decoder=decoder, payload="bf16" if name_suffix.endswith("16") else "f32")
-        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, grad_sync=gs)
+        # "micro": gradient accumulation over two row slices per rank, slice 0's exchange in flight under slice 1's computation
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, grad_sync=gs, micro_batches=2 if name_suffix.startswith("micro") else 1)
         if name_suffix.startswith("bucket"):   # the embedding gradient as its own all-reduce, issued from inside the encoder backward
             tr.BUCKET_MIN_ELEMS = 1
             seen = []
@@ -65,6 +66,8 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
         errs["_recoveries"] = (tr.recoveries, engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))
         if name_suffix.startswith("bucket"):
             assert len(seen) == 1 and seen[0][0] == 0 and 0 < seen[0][1] < tr.enc.flat.numel, seen
+        if name_suffix.startswith("micro"):
+            errs["_bytes"] = gs.bytes_on_wire(tr.enc.flat, tr.dec.flat, micro_batches=2)["total"] / 2.0     # per slice: as one unsliced step
         q.put((rank, st["norm"], st["loss_sum"], errs, None))
         dist.destroy_process_group()
     except Exception as e:  # noqa
@@ -74,7 +77,8 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
 
 @pytest.mark.parametrize("name,decoder", [("text_small_wide", d) for d in ("norm", "allreduce", "norm/hook", "allreduce/hook", "norm/bf16",
                                                                             "allreduce/bf16", "norm/bucket", "norm/fault", "allreduce/fault", "norm/fault16")]
-                         + [("text_mid", "norm/bucket16"), ("text_mid", "allreduce/bucket")])
+                         + [("text_mid", "norm/bucket16"), ("text_mid", "allreduce/bucket"), ("text_mid", "norm/micro"),
+                            ("text_mid", "allreduce/micro"), ("text_mid", "norm/micro16"), ("text_small_wide", "norm/micro")])
 def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, device="cpu"):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     if device == "cpu":

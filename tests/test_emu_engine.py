@@ -77,3 +77,8 @@ def test_voided_steps_are_replayed_down_the_ladder_emulated(emu_backend, fault_a
     """The transaction gate of the fused step (lv_clip_norm2_txn_f32 + lv_sgd_step_txn_f32) and the trainer's replay, with the
     status words a timed-out persistent launch would leave set by hand: the weights equal a run that never saw the fault."""
     pc.check_transactional_recovery("cpu", fault_at=fault_at, rungs_down=rungs_down)
+
+
+@pytest.mark.parametrize("name,m", [("text_small_wide", 2), ("text_mid", 4), ("text_small_wide", 4)])
+def test_micro_batches_give_the_whole_batch_gradient_emulated(emu_backend, name, m):
+    pc.check_micro_batches_against_fixture(name, "cpu", m)

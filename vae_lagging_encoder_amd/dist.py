@@ -67,21 +67,41 @@ class GradSync(object):
         assert decoder in ("auto", "norm", "allreduce")
         assert payload in ("auto", "f32", "bf16")
         self.payload = payload
-        self._buckets = []        # encoder buckets already in flight: (lo, hi, handle, wire tensor or None)
         self.profile = False
         self._prof = []           # per step: list of (name, start event, end event)
-        self._b16 = {}            # bf16 wire images of the flat gradient buffers (payload "bf16")
         self.group = group
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.decoder = decoder
         self._inv = None
-        self._h_dec = None
-        self._h_rs = None         # reduce-scatter issued early by start_decoder()
-        self._shard16 = None
-        self._shard = None
+        # per-slot state (slot = micro-batch slice of a step, trainer.micro_batches; slot 0 alone without gradient accumulation):
+        # encoder buckets in flight, the decoder handles, the wire images and the reduce-scatter shard of that slice
+        self._slots = {}
+        self._slot = 0
         self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
+        self._shard_sum = None
+
+    class _Slot(object):
+        def __init__(self):
+            self.buckets = []     # encoder buckets already in flight: (handle, wire tensor or None, lo, hi)
+            self.h_dec = None
+            self.h_rs = None      # reduce-scatter issued early by start_decoder()
+            self.enc_rest = []
+            self.b16 = {}         # bf16 wire images of the flat gradient buffers (payload "bf16")
+            self.shard16 = None
+            self.shard = None
+
+    @property
+    def _cur(self):
+        st = self._slots.get(self._slot)
+        if st is None:
+            st = self._slots[self._slot] = GradSync._Slot()
+        return st
+
+    def set_slot(self, i):
+        """Select the micro-batch slice the next calls belong to (the trainer also switches the flat buffers' gradient slot)."""
+        self._slot = int(i)
 
     def resolve_payload(self, precision):
         """payload "auto" -> the wire format that matches the trainer's arithmetic (called once by the trainer)."""
@@ -103,8 +123,11 @@ class GradSync(object):
         """Called by the trainer before a step queues anything: collectives a previous step left in flight -- an exception between
         the encoder backward and sync() -- are waited for and dropped, so that this step's buckets start from a clean slate on
         every rank (a stale handle would otherwise trip the overlap check of start_encoder_bucket for good)."""
-        stale = [b[0] for b in self._buckets] + [h[0] for h in (self._h_dec,) if h is not None] + [h for h in (self._h_rs,) if h is not None]
-        self._buckets, self._h_dec, self._h_rs = [], None, None
+        stale = []
+        for st in self._slots.values():
+            stale += [b[0] for b in st.buckets + st.enc_rest] + [h[0] for h in (st.h_dec,) if h is not None] + [h for h in (st.h_rs,) if h is not None]
+            st.buckets, st.enc_rest, st.h_dec, st.h_rs = [], [], None, None
+        self._slot = 0
         for h in stale:
             h.wait()
 
@@ -147,10 +170,11 @@ class GradSync(object):
         src = flat.grad_padded
         n = src.numel()
         hi = n if hi is None else hi
-        t = self._b16.get(id(flat))
+        b16 = self._cur.b16
+        t = b16.get(id(flat))
         if t is None or t.numel() != n or t.device != src.device:
             t = torch.empty(n, dtype=torch.int16, device=src.device)
-            self._b16[id(flat)] = t
+            b16[id(flat)] = t
         lib = _eng.backend_for(src.device)
         lib.lv_cvt_bf16_f32(P(src, lo), 1024, (hi - lo) // 1024, 1024, P(t, lo), 1024, None, 0, _eng.stream_ptr(src.device))
         return t[lo:hi]
@@ -192,8 +216,8 @@ class GradSync(object):
         assert lo < hi
         if self.payload == "bf16":          # the wire conversion works on rows of 1024 elements
             assert lo % 1024 == 0 and (hi % 1024 == 0 or hi == pad), (lo, hi)
-        assert all(hi <= b[2] or lo >= b[3] for b in self._buckets), "encoder buckets must not overlap"
-        self._buckets.append(self._all_reduce_mean_start(enc_flat, lo, hi))
+        assert all(hi <= b[2] or lo >= b[3] for b in self._cur.buckets), "encoder buckets must not overlap"
+        self._cur.buckets.append(self._all_reduce_mean_start(enc_flat, lo, hi))
 
     def _norm_only(self, dec_flat, update):
         return (self.mode == "strict" and update == "encoder" and self.decoder in ("auto", "norm")
@@ -206,23 +230,26 @@ class GradSync(object):
         if self.world == 1 or self.mode != "strict":
             return
         if self._norm_only(dec_flat, update):
-            self._h_rs = self._reduce_scatter(dec_flat, update, async_op=True)
+            self._cur.h_rs = self._reduce_scatter(dec_flat, update, async_op=True)
             return
-        self._h_dec = self._all_reduce_mean_start(dec_flat)
+        self._cur.h_dec = self._all_reduce_mean_start(dec_flat)
 
     def _reduce_scatter(self, dec_flat, update, async_op):
         """Reduce-scatter of the (padded) decoder gradient into this rank's shard; returns a waitable handle or None."""
         src = dec_flat.grad_padded
         n = src.numel() // self.world
         self.ss_handle(dec_flat, update)
+        st = self._cur
+        if st.shard is None or st.shard.numel() != n or st.shard.device != src.device:
+            st.shard = torch.empty(n, dtype=torch.float32, device=src.device)
         bf = self.payload == "bf16"
         if bf:
             src = self._wire(dec_flat).view(torch.bfloat16)
-            if self._shard16 is None or self._shard16.numel() != n or self._shard16.device != src.device:
-                self._shard16 = torch.empty(n, dtype=torch.int16, device=src.device)
+            if st.shard16 is None or st.shard16.numel() != n or st.shard16.device != src.device:
+                st.shard16 = torch.empty(n, dtype=torch.int16, device=src.device)
         # the same call on RCCL and on gloo (torch >= 2.10's gloo has reduce_scatter_tensor, bf16 included): the CPU tests
         # exercise the product's collective, not a substitute
-        dst = self._shard16.view(torch.bfloat16) if bf else self._shard
+        dst = st.shard16.view(torch.bfloat16) if bf else st.shard
         return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def sync(self, enc_flat, dec_flat, update="encoder"):
@@ -231,43 +258,81 @@ class GradSync(object):
         it to the encoder's sum of squares for the clip coefficient)."""
         if self.world == 1:
             return None
-        h_dec, self._h_dec = self._h_dec, None
-        lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
-        ss = None
+        self.sync_issue(enc_flat, dec_flat, update)
+        self.sync_collect(enc_flat, dec_flat, update)
+        return self.sync_norm(dec_flat, update, (self._slot,))
+
+    def sync_issue(self, enc_flat, dec_flat, update="encoder"):
+        """First half of sync() for the current slot: every collective of this slice's gradients that is not in flight yet is
+        issued (asynchronously); nothing is waited for.  With micro-batches the trainer calls this after each slice's backward
+        and goes on to the next slice -- the exchange runs underneath it (weights are frozen within a step)."""
+        if self.world == 1:
+            return
+        st = self._cur
         dev = enc_flat.device
         if self._norm_only(dec_flat, update):
+            if st.h_rs is None:
+                st.h_rs = self._reduce_scatter(dec_flat, update, async_op=True)      # not started early (hipGraph split, direct callers)
+        elif self.mode == "strict" and st.h_dec is None:
+            st.h_dec = self._all_reduce_mean_start(dec_flat)
+        with self._Phase(self, "encoder_allreduce_issue", dev):
+            st.enc_rest = self._start_encoder_rest(enc_flat)
+
+    def sync_collect(self, enc_flat, dec_flat, update="encoder"):
+        """Second half for the current slot (the flat buffers must have the same gradient slot selected): wait for this slice's
+        collectives and unpack them -- the encoder (and, where it was all-reduced, the decoder) buffer then holds the mean over
+        ranks of this slice's gradient, the reduce-scatter shard the SUM over ranks of this rank's share of the decoder's."""
+        if self.world == 1:
+            return
+        st = self._cur
+        lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
+        dev = enc_flat.device
+        h_rs, st.h_rs = st.h_rs, None
+        h_dec, st.h_dec = st.h_dec, None
+        if h_rs is not None:
             n = dec_flat.grad_padded.numel() // self.world
-            h_rs, self._h_rs = self._h_rs, None
-            if h_rs is None:
-                h_rs = self._reduce_scatter(dec_flat, update, async_op=True)      # not started early (hipGraph split, direct callers)
-            with self._Phase(self, "encoder_allreduce_issue", dev):
-                enc_rest = self._start_encoder_rest(enc_flat)
             with self._Phase(self, "decoder_reduce_scatter_wait", dev):
                 h_rs.wait()
                 if self.payload == "bf16":
-                    lib.lv_cvt_f32_bf16_scaled(P(self._shard16), n, 1.0, P(self._shard), s)
-                lib.lv_sumsq_f32(P(self._shard), n, P(self._ws), P(self._ss), 0, s)
-                lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
-            with self._Phase(self, "scalar_allreduce", dev):
-                dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
-            ss = self._ss
-        else:
-            if self.mode == "strict" and h_dec is None:
-                h_dec = self._all_reduce_mean_start(dec_flat)
-            with self._Phase(self, "encoder_allreduce_issue", dev):
-                enc_rest = self._start_encoder_rest(enc_flat)
-            if h_dec is not None:
-                with self._Phase(self, "decoder_allreduce_wait", dev):
-                    self._all_reduce_mean_finish(dec_flat, h_dec)
+                    lib.lv_cvt_f32_bf16_scaled(P(st.shard16), n, 1.0, P(st.shard), s)
+        if h_dec is not None:
+            with self._Phase(self, "decoder_allreduce_wait", dev):
+                self._all_reduce_mean_finish(dec_flat, h_dec)
+        rest, st.enc_rest = st.enc_rest, []
         with self._Phase(self, "encoder_allreduce_wait", dev):
-            for st in enc_rest:
-                self._all_reduce_mean_finish(enc_flat, st)
-        return ss
+            for h in rest:
+                self._all_reduce_mean_finish(enc_flat, h)
+
+    def sync_norm(self, dec_flat, update, slots):
+        """Norm-only decoder exchange: sum of squares of the MEAN decoder gradient from the reduce-scatter shards of the listed
+        slots (their sum = this rank's share of the gradient summed over ranks and micro-batches) + one scalar all-reduce.
+        Returns the device scalar, or None when the decoder gradient was all-reduced in full (or not exchanged)."""
+        if self.world == 1 or not self._norm_only(dec_flat, update):
+            return None
+        lib, s = _eng.backend_for(dec_flat.device), _eng.stream_ptr(dec_flat.device)
+        dev = dec_flat.device
+        n = dec_flat.grad_padded.numel() // self.world
+        shards = [self._slots[i].shard for i in slots]
+        with self._Phase(self, "decoder_reduce_scatter_wait", dev):
+            total = shards[0]
+            if len(shards) > 1:
+                if self._shard_sum is None or self._shard_sum.numel() != n or self._shard_sum.device != dev:
+                    self._shard_sum = torch.empty(n, dtype=torch.float32, device=dev)
+                total = self._shard_sum
+                lib.lv_add_f32(P(shards[0]), P(shards[1]), P(total), n, s)
+                for sh in shards[2:]:
+                    lib.lv_add_f32(P(total), P(sh), P(total), n, s)
+            lib.lv_sumsq_f32(P(total), n, P(self._ws), P(self._ss), 0, s)
+            lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
+        with self._Phase(self, "scalar_allreduce", dev):
+            dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
+        return self._ss
 
     def _start_encoder_rest(self, enc_flat):
         """Issue the all-reduce of every encoder range no bucket has covered; returns all encoder handles in flight, lowest
         range first (finished by sync in that order)."""
-        started, self._buckets = sorted(self._buckets, key=lambda b: b[2]), []
+        st = self._cur
+        started, st.buckets = sorted(st.buckets, key=lambda b: b[2]), []
         pad = enc_flat.grad_padded.numel()
         gaps, pos = [], 0
         for b in started:
@@ -283,10 +348,8 @@ class GradSync(object):
         if self.world == 1 or not self._norm_only(dec_flat, update):
             return None
         src = dec_flat.grad_padded
-        n = src.numel() // self.world
-        if self._shard is None or self._shard.numel() != n or self._shard.device != src.device:
+        if self._ss is None or self._ss.device != src.device:
             lib = _eng.backend_for(src.device)
-            self._shard = torch.empty(n, dtype=torch.float32, device=src.device)
             self._ss = torch.zeros(1, dtype=torch.float32, device=src.device)
             self._ws = torch.empty(lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=src.device)
             self._inv2 = torch.full((1,), 1.0 / (self.world * self.world), dtype=torch.float32, device=src.device)
@@ -300,6 +363,25 @@ class GradSync(object):
         if self.mode != "strict":
             return enc
         return enc + (f if self._norm_only(dec_flat, update) else 2 * f) * 4 * dec_flat.numel
+
+    def bytes_on_wire(self, enc_flat, dec_flat, update="encoder", n_emb=0, micro_batches=1):
+        """Bytes this rank SENDS per step, per phase of the exchange (ring algorithms, as bytes_per_step), for the bench's
+        dp_breakdown: the embedding bucket issued from inside the encoder backward (n_emb elements, 0 = no bucket), the rest of the
+        encoder buffer, the decoder's reduce-scatter or all-reduce, the scalar all-reduce; times the micro-batch count."""
+        f = (self.world - 1) / max(1, self.world)
+        b = 2 if self.payload == "bf16" else 4
+        pad_e, pad_d = enc_flat.grad_padded.numel(), dec_flat.grad_padded.numel()
+        out = {"encoder_bucket_embedding": int(2 * f * b * n_emb) * micro_batches,
+               "encoder_rest": int(2 * f * b * (pad_e - n_emb)) * micro_batches,
+               "decoder_reduce_scatter": 0, "decoder_allreduce": 0, "scalar_allreduce": 0}
+        if self.mode == "strict":
+            if self._norm_only(dec_flat, update):
+                out["decoder_reduce_scatter"] = int(f * b * pad_d) * micro_batches
+                out["scalar_allreduce"] = int(2 * f * 4)
+            else:
+                out["decoder_allreduce"] = int(2 * f * b * pad_d) * micro_batches
+        out["total"] = sum(out.values())
+        return out
 
     def window_mean(self, loss_sum, num_words):
         """Global mean loss per word of one exit window (text.py:393-396): sum of the ranks' loss sums over the sum of

@@ -77,13 +77,26 @@ class FlatBuffer(object):
             self.views[n] = v
             self.gviews[n] = self.grad[o:o + p.numel()].view(p.shape)
 
+        self._slots = [(self.grad_padded, self.grad, self.gviews)]
+
+    def use_slot(self, i):
+        """Gradient accumulation over micro-batches (trainer.micro_batches): slice i of a step writes its gradients into slot i --
+        a second, third, ... flat gradient buffer of the same layout, created on first use -- so that slice i's exchange can be in
+        flight while slice i + 1 is computed; slot 0 is the buffer param.grad aliases and the one the update reads."""
+        while len(self._slots) <= i:
+            gp = torch.zeros_like(self._slots[0][0])
+            g = gp[:self.numel]
+            gv = {n: g[self.offsets[n]:self.offsets[n] + p.numel()].view(p.shape) for n, p in zip(self.names, self.params)}
+            self._slots.append((gp, g, gv))
+        self.grad_padded, self.grad, self.gviews = self._slots[i]
+
     def bound(self):
         return all(p.data_ptr() == self.views[n].data_ptr() for n, p in zip(self.names, self.params))
 
     def attach_grads(self):
         """Make param.grad alias the flat gradient segments (fused driver path)."""
         for n, p in zip(self.names, self.params):
-            p.grad = self.gviews[n]
+            p.grad = self._slots[0][2][n]
 
 
 def _tensor_bytes(obj, depth=0):

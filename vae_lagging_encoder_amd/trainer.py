@@ -38,8 +38,17 @@ class AggressiveTextTrainer(object):
     BUCKET_MIN_ELEMS = 1 << 20
 
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
-                 precision="f32"):
+                 precision="f32", micro_batches=1):
+        """micro_batches = m > 1: gradient accumulation -- every step's batch is cut into m row slices that run one after the
+        other on the frozen weights, slice i's gradient exchange (data parallel) is issued when its backward has been queued and
+        runs under slice i + 1's forward and backward, the m slice gradients are summed and ONE clip + update follows: the same
+        mean gradient as the whole batch in one piece (text.py:382-387; SURVEY.md 8e's overlap window).  Eager mode only."""
         self.vae = vae
+        self.micro_batches = int(micro_batches)
+        assert self.micro_batches >= 1
+        if self.micro_batches > 1 and use_graph:
+            raise ValueError("micro_batches > 1 runs in eager mode (every slice writes its own gradient slot)")
+        self._slice_views = {}
         self.enc = vae.encoder._hip
         self.dec = vae.decoder._hip
         self.device = torch.device(device) if device is not None else next(vae.parameters()).device
@@ -171,10 +180,12 @@ class AggressiveTextTrainer(object):
         self.dec._sorts.invalidate(x)
 
     # -- per-(B,T) static state ----------------------------------------------------------------------
-    def _static_for(self, B, T):
-        st = self.static.get((B, T))
+    def _static_for(self, B, T, parts=1):
+        """parts: the step's batch is B * parts rows of which this static state serves one slice (mean over ALL rows)."""
+        key = (B, T) if parts == 1 else (B, T, parts)
+        st = self.static.get(key)
         if st is not None:
-            self.static.move_to_end((B, T))
+            self.static.move_to_end(key)
         else:
             d = self.device
             V, ni, H, nz = self.dec.dims()
@@ -187,14 +198,14 @@ class AggressiveTextTrainer(object):
             st.kl = torch.empty(B, dtype=torch.float32, device=d)
             st.loss = torch.empty(B, dtype=torch.float32, device=d)
             st.rec = torch.empty(B, dtype=torch.float32, device=d)
-            st.gl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=d)   # d(mean_b loss_b)/d loss_b
+            st.gl = torch.full((B,), 1.0 / (B * parts), dtype=torch.float32, device=d)   # d(mean_b loss_b)/d loss_b
             st.rowscale = torch.empty(B, dtype=torch.float32, device=d)
             st.dkl = torch.empty(B, dtype=torch.float32, device=d)
             st.dmulv = torch.empty(B, 2 * nz, dtype=torch.float32, device=d)
             st.graphs = {}
             st.x_key = None
             st.xin = st.x
-            self.static[(B, T)] = st
+            self.static[key] = st
             if not self.use_graph:
                 while len(self.static) > STATIC_SHAPES:
                     self.static.popitem(last=False)
@@ -308,7 +319,84 @@ class AggressiveTextTrainer(object):
         if len(self._journal) >= self.JOURNAL_MAX:
             self.commit()
 
+    def _slices(self, x, m):
+        """The m row slices of batch tensor x as stable view objects (kept per batch tensor, weakly: the sorted-token cache is
+        keyed by tensor identity, and a fresh view per step would re-sort every slice every time)."""
+        import weakref
+        ent = self._slice_views.get(id(x))
+        if ent is not None and ent[0]() is x and ent[1] == (x._version, m):
+            return ent[2]
+        Bs = x.shape[0] // m
+        views = [x[i * Bs:(i + 1) * Bs] for i in range(m)]
+        if len(self._slice_views) > 4096:
+            self._slice_views.clear()
+        self._slice_views[id(x)] = (weakref.ref(x, lambda _r, i=id(x), d=self._slice_views: d.pop(i, None)), (x._version, m), views)
+        return views
+
+    def _queue_micro(self, x, kl_weight, noise, update, m):
+        """One step as m micro-batches (see __init__)."""
+        lib, s = self.lib, _eng.stream_ptr(self.device)
+        B, T = x.shape
+        if B % m != 0:
+            raise ValueError("micro_batches = %d does not divide the batch of %d sequences" % (m, B))
+        if not (x.is_contiguous() and x.device == self.device and x.dtype == torch.int64):
+            x = x.to(self.device, torch.int64).contiguous()
+        Bs = B // m
+        if self._klw_host != float(kl_weight):
+            self.scal[0] = float(kl_weight)
+            self._klw_host = float(kl_weight)
+        draw = noise is None
+        ef, df = self.enc.flat, self.dec.flat
+        gs = self.grad_sync
+        dp = gs is not None and gs.world > 1
+        self._update = update
+        if gs is not None:
+            gs.begin_step()
+        try:
+            for i, xs in enumerate(self._slices(x, m)):
+                st = self._static_for(Bs, T, m)
+                st.xin, st.x_key = xs, xs
+                if not draw:
+                    eps, m_in, m_out = noise
+                    rows = slice(i * Bs, (i + 1) * Bs)
+                    st.eps.copy_(eps.reshape(B, 1, -1)[rows])
+                    if m_in is not None:
+                        st.m_in.copy_(m_in[rows])
+                    if m_out is not None:
+                        st.m_out.copy_(m_out[rows])
+                ef.use_slot(i)
+                df.use_slot(i)
+                if gs is not None:
+                    gs.set_slot(i)
+                self._fwd_bwd(st, draw)
+                if dp:
+                    gs.sync_issue(ef, df, update)       # slice i's exchange: in flight underneath slice i + 1
+            dec_ss = None
+            if dp:
+                for i in range(m):
+                    ef.use_slot(i)
+                    df.use_slot(i)
+                    gs.set_slot(i)
+                    gs.sync_collect(ef, df, update)
+                dec_ss = gs.sync_norm(df, update, tuple(range(m)))
+        finally:
+            ef.use_slot(0)
+            df.use_slot(0)
+            if gs is not None:
+                gs.set_slot(0)
+        # sum of the slice gradients (each carries the 1 / B of the whole batch), over the padded buffers: the guard elements add up too
+        for f in (ef, df):
+            for i in range(1, m):
+                lib.lv_add_f32(P(f._slots[0][0]), P(f._slots[i][0]), P(f._slots[0][0]), f._slots[0][0].numel(), s)
+        self._clip_and_step(update, dec_ss)
+        if update in ("encoder", "both"):
+            self.enc.wgen += 1
+        if update in ("decoder", "both"):
+            self.dec.wgen += 1
+
     def _queue_step(self, x, kl_weight, noise, update):
+        if self.micro_batches > 1:
+            return self._queue_micro(x, kl_weight, noise, update, self.micro_batches)
         B, T = x.shape
         st = self._static_for(B, T)
         if self.use_graph or not (x.is_contiguous() and x.device == self.device and x.dtype == torch.int64):
