@@ -28,7 +28,7 @@ def test_gemm_b16(emu_backend, cfg):
 
 @pytest.mark.parametrize("cfg", [(0, 130, 140, 37, False), (1, 70, 130, 50, False), (1, 300, 260, 200, False), (0, 258, 100, 1100, True),
                                  (1, 131, 270, 1100, True), (0, 520, 30, 128, False)])
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_tile256(emu_backend, cfg, tile):
     K.test_gemm_b16_tile256(emu_backend, CPU, *cfg, tile)
 
@@ -175,7 +175,7 @@ def test_gemm_b16_nll_fused(emu_backend, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 600, 64)])
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_nll_fused_tile256(emu_backend, cfg, tile):
     K.test_gemm_b16_nll_fused_tile256(emu_backend, CPU, *cfg, tile)
 

@@ -190,7 +190,7 @@ def test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=None, tile=0):
     (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False), (0, 3000, 2100, 512, False),
     (1, 1100, 1200, 2304, True), (0, 4200, 4100, 320, True),
 ])
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split, tile):
     """The 256 x 256 x 64 kernel (forced; 256 = lockstep K loop, 257 = the two wave groups half a k-step apart): same checks; with a
     workspace the tail tiles (tiles % 256) are cut along K and reduced in piece order.  Bit-identical to the 128 x 128 chain when K
@@ -1120,7 +1120,7 @@ def test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=0):
 
 
 @pytest.mark.parametrize("tA,M,N,K", [(0, 2100, 2304, 4100), (1, 4500, 1024, 3000), (0, 6368, 1024, 20001)])
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K, tile):
     """Race screen of the 256 x 256 kernel's LDS-DMA hand-over and of the K-split tail: the same launch twelve times, on operands
     that are refilled in between (so the caches hold something else), must give the same bits every time -- a fragment read that
@@ -1148,7 +1148,7 @@ def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K, tile):
 
 
 @pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 1000, 128), (40, 32, 20001, 1024)])
-@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H, tile):
     test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=tile)
 

@@ -37,7 +37,9 @@ static inline void LV_MFMA_RESULT(f32x4&) { }
 static inline f32x4 lv_mfma_4x4x4_16b_bf16(uint2 a, uint2 b, f32x4 c) { return lv_emu_mfma_4x4x4_16b_bf16(a, b, c); }
 // LDS-DMA: lane l's 16 bytes at g land at lds_wave_base + 16*l (the base is wave-uniform)
 static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * lv_emu::lane(), g, 16); }
+static inline void lv_glds16_uncounted(const void* g, void* lds_wave_base) { lv_glds16(g, lds_wave_base); }
 #define LV_WAIT_VMEM() do { } while (0)
+#define LV_WAIT_VMEM_N(n) do { } while (0)
 #define LV_S_BARRIER() __syncthreads()      // a bare workgroup barrier (no counter waits attached); fibers: the same rendezvous
 #define LV_SETPRIO(n) do { } while (0)
 static inline uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {            // lane map: see the HIP definition below
@@ -219,7 +221,24 @@ __device__ __forceinline__ void lv_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same transfer as an asm statement, i.e. OUTSIDE hipcc's bookkeeping: the compiler neither counts it for its s_waitcnt
+// insertion nor sees an LDS write it would have to order its own ds_reads of the same array behind (it puts s_waitcnt vmcnt(0) in
+// front of every read of an LDS object that has a counted LDS-DMA in flight -- which is exactly what a schedule that keeps the DMA
+// stream running while it reads OTHER parts of the same buffer must not have).  The caller owns the ordering: a counted
+// s_waitcnt vmcnt(N) of its own, then a barrier, then the reads.  M0 is compiler-reserved: saved and restored inside the statement
+// (cdna_hip_programming.md 5.7).
+#ifndef LV_GLDS_POLICY
+#define LV_GLDS_POLICY ""          // cache-policy bits of the uncounted LDS-DMA (" nt", " sc0", " sc1", ...: A/B knob of profiles/microbench)
+#endif
+__device__ __forceinline__ void lv_glds16_uncounted(const void* g, void* lds_wave_base) {
+    unsigned keep;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" LV_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
 #define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// counted form: all but the newest n vector-memory operations of this wave have completed (n a literal)
+#define LV_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // s_barrier alone: __syncthreads() puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of it whenever anything is in flight -- for
 // schedules that keep LDS-DMA in flight across a barrier and order it by counted waits of their own
 #define LV_S_BARRIER() __builtin_amdgcn_s_barrier()

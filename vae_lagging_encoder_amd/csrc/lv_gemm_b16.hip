@@ -18,9 +18,6 @@
 // loads 16 B (eight adjacent rows at one k) for 4 consecutive k and transposes the 8x4 block in registers (16 integer
 // ops) into the eight rows' k-quads; row e of octet m8 is kept in LDS row 16*e + m8 so that the lanes of one store hit
 // consecutive LDS rows, and the epilogue undoes that permutation for free in its row index.
-#ifndef LV_B16_T256_W4
-#define LV_B16_T256_W4 0
-#endif
 #ifndef LV_B16_T256_DMA
 #define LV_B16_T256_DMA 1
 #endif
@@ -736,36 +733,17 @@ __device__ __forceinline__ void t256_tile_of(const GemmQ& p, int s, int& tm, int
     tn = (s % nig) / gsz;
 }
 
-// WN = waves along N: 4 (8 waves, wave tile 128 x 64: acc 128 registers, two waves per SIMD) or 2 (4 waves, wave tile 128 x 128: acc
-// 256 registers -- AGPRs --, ONE wave per SIMD, 8 fragment reads per 16 MFMAs instead of 6 per 8: a third less LDS read traffic,
-// which at 8 waves equals the MFMA pipe time).  The NLL epilogue exists for WN = 4 only.
-// PP ("ping-pong", round 4): the K loop runs as two wave groups half a k-step apart.  Waves w and w + 4 share SIMD w & 3 and belong
-// to different groups (wm = 0 / 1); a k-step of a wave is a LOAD segment (its 6 fragment reads of that k-step + its share of the
-// next tile's LDS-DMA) and an MFMA segment (8 MFMAs = 256 cycles of the SIMD's matrix pipe), each closed by a bare s_barrier, and
-// group 1 enters the loop one barrier late: whenever one wave of a SIMD multiplies, its partner reads / stages, so the matrix pipe
-// of every SIMD sees ONE instruction stream of back-to-back MFMAs while only four waves at a time compete for the LDS port.
-// Ordering of the LDS-DMA: a tile's 8 DMA instructions go out in the LOAD segments of k-steps 0 and 1 of the tile before it, every
-// wave waits for its own (vmcnt(0): nothing newer is in flight then) at the end of the LOAD segment of k-step 3, i.e. before the
-// barrier that closes that segment, and the first read of the new tile by EITHER group lies behind that barrier; a LOAD segment
-// ends with lgkmcnt(0) BEFORE its barrier, so the buffer a DMA overwrites (the tile before the current one) has been read
-// completely by both groups when the first DMA instruction of the tile after the current one is issued.
-template <bool NLL, bool TN, int WN = 4, bool PP = false>
-__global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
-    static_assert(WN == 4 || (WN == 2 && !NLL), "4 waves: plain epilogue only");
-    static_assert(!PP || WN == 4, "ping-pong schedule: 8 waves");
-    constexpr int NJ = 8 / WN;                          // 32-column fragments per wave along N
-    constexpr int UN = 16 / WN;                         // 1 KB staging units per wave and image
-    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
-    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
-
-    const int bid = (int)blockIdx.x;
+// Which tile (and which K piece of it) workgroup `bid` of a 256 x 256 launch computes.
+struct T256Pick { int tile, kt0, kt1, piece, tm, tn; };
+__device__ __forceinline__ T256Pick t256_pick(const GemmQ& p, const Tail256& q, int bid) {
+    T256Pick k;
     const int nk_all = (p.K + BK - 1) / BK;
-    int tile, kt0, kt1, piece = -1;
+    k.piece = -1;
     if (bid < q.full) {
         // whole rounds: consecutive workgroup ids land on different XCDs; give each XCD (own L2) a contiguous range of tiles
         const int xcd = bid % 8, per = q.full / 8;
-        tile = xcd * per + bid / 8;
-        kt0 = 0; kt1 = nk_all;
+        k.tile = xcd * per + bid / 8;
+        k.kt0 = 0; k.kt1 = nk_all;
     } else {
         // tail workgroups: XCD x (= workgroup id % 8, own L2) gets a contiguous range of (piece, tile) pairs in piece-major order,
         // i.e. neighbouring tiles over the SAME K range, so that its 32 co-resident workgroups share A and B tiles in L2 (with the
@@ -773,16 +751,150 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
         const int r = bid - q.full, nw = q.tail * q.tail_s;
         const int xcd = r % 8, qq = nw / 8, rem = nw % 8;
         const int idx = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + r / 8;
-        tile = q.full + idx % q.tail;
-        piece = idx / q.tail;
-        kt0 = piece * q.kt_per_piece;
-        kt1 = kt0 + q.kt_per_piece;
-        if (kt1 > nk_all) kt1 = nk_all;
-        if (q.tail_s == 1) piece = -1;
+        k.tile = q.full + idx % q.tail;
+        k.piece = idx / q.tail;
+        k.kt0 = k.piece * q.kt_per_piece;
+        k.kt1 = k.kt0 + q.kt_per_piece;
+        if (k.kt1 > nk_all) k.kt1 = nk_all;
+        if (q.tail_s == 1) k.piece = -1;
     }
-    int tm, tn;
-    t256_tile_of(p, tile, tm, tn);
-    const int m0 = tm * BT2, n0 = tn * BT2;
+    t256_tile_of(p, k.tile, k.tm, k.tn);
+    return k;
+}
+
+// What a workgroup of the 256 x 256 kernels does with its finished accumulators (wave (wm, wn) of 2 x 4 holds the 128 x 64 block
+// at (128 wm, 64 wn) as 4 x 2 fragments): the fused NLL epilogue, a K piece's slab, or C.  Every wave of the workgroup has passed
+// a barrier behind its last read of the K tiles, and no LDS-DMA is in flight.
+template <bool NLL>
+__device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, f32x16 (&acc)[4][2], LdsTile2& As0, LdsTile2& Bs0,
+                                              LdsTile2& As1, LdsTile2& Bs1, int tile, int piece, int tn, int m0, int n0, int t, int l,
+                                              int wm, int wn, int lh) {
+    constexpr int NJ = 2;
+    if constexpr (NLL) {
+        // fused epilogue of the vocabulary projection (see the 128 x 128 kernel): the 256 x 256 tile goes through the 128 KB of
+        // LDS as binary16 (64 rows of 512 B per buffer, 16-byte chunks permuted by chunk ^ (row & 15) so that the row-per-lane
+        // reads below are conflict-free), thread (row rr = t & 255, half = t >> 8) owns 128 consecutive logits = two 64-column
+        // pieces of the statistics
+        auto rowptr = [&](int rr) -> char* {            // 64 tile rows of 512 B per buffer
+            const int b = rr >> 6;
+            char* base = b == 0 ? reinterpret_cast<char*>(&As0[0][0]) : b == 1 ? reinterpret_cast<char*>(&Bs0[0][0])
+                       : b == 2 ? reinterpret_cast<char*>(&As1[0][0]) : reinterpret_cast<char*>(&Bs1[0][0]);
+            return base + (rr & 63) * 512;
+        };
+        // Write phase: a lane holds ONE column of 16 rows per fragment, its neighbour (lane ^ 1) the next column.  Rows are taken
+        // in pairs (e, e + 1): the even lane sends its row e + 1 and keeps row e, the odd lane the other way round (one DPP move),
+        // so every lane stores one packed pair (two adjacent columns of one row) -- 64 ds_write_b32 per thread instead of 128
+        // ds_write_b16, one conversion instruction per pair.  Address = buffer + row * 512 + (chunk ^ (row & 15)) * 16 + ...; with
+        // row & 15 = (e & 3 | odd) | 4 lh | 8 (e >> 2 & 1) the lane part and the per-e part of the XOR separate.
+        const int odd = l & 1;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            char* const bufp = rowptr(wm * 128 + i2 * 32);                  // row (i2 & 1) * 32 of its buffer
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int clp = (wn * 64 + j * 32 + (l & 31)) & ~1;          // first column of this lane's pair
+                const int lane_off = (4 * lh + odd) * 512 + ((((clp >> 3) ^ (4 * lh) ^ odd) << 4) | ((clp & 7) << 1));
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float mine0 = acc[i2][j][e], mine1 = acc[i2][j][e + 1];
+                    const float got = lv_lane_xor1(odd ? mine0 : mine1);
+                    const uint32_t pk = odd ? lv_pack_f16x2(got, mine1) : lv_pack_f16x2(mine0, got);
+                    const int key = (e & 3) | (8 * ((e >> 2) & 1));          // compile-time part of row & 15
+                    const int roff = ((e & 3) + 8 * (e >> 2)) * 512;
+                    *reinterpret_cast<uint32_t*>(bufp + roff + (lane_off ^ (key << 4))) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        const int rr = t & 255, half = t >> 8;
+        const int row = m0 + rr;
+        if (row < p.M) {
+            const char* rowp = rowptr(rr);
+            const int tt = row / p.Bsz, bb = row % p.Bsz;
+            long tg = p.ids[(long)bb * p.ids_stride + tt + p.tgt_off];
+            if (tg < 0) tg = 0;
+            if (tg >= p.N) tg = p.N - 1;
+#pragma unroll 1
+            for (int pc = 0; pc < 2; ++pc) {
+                const int cb = 128 * half + 64 * pc;       // first column of this piece inside the tile
+                const int c0 = n0 + cb;
+                uint4 qv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qv[k] = *reinterpret_cast<const uint4*>(rowp + ((((cb >> 3) + k) ^ (rr & 15)) << 4));
+                uint16_t* dst = p.C16 + (long)row * p.ldc16 + c0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + 8 * k + 8 <= p.ldc16) reinterpret_cast<uint4*>(dst)[k] = qv[k];
+                float v[64];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t wv[4] = {qv[k].x, qv[k].y, qv[k].z, qv[k].w};
+#pragma unroll
+                    for (int h2 = 0; h2 < 4; ++h2) {
+                        v[8 * k + 2 * h2] = lv_f16_bits_to_f32((uint16_t)(wv[h2] & 0xFFFFu));
+                        v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
+                    }
+                }
+                float mx, sm;
+                nll_piece_stats(v, p.N - c0, mx, sm);
+                p.part[(long)row * p.nparts + 4 * tn + 2 * half + pc] = make_float2(mx, sm);
+                const int tl = (int)tg - c0;
+                if (tl >= 0 && tl < 64) {
+                    const int cl = cb + tl;
+                    p.tgt[row] = lv_f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(rowp + ((((cl >> 3) ^ (rr & 15)) << 4) | ((cl & 7) << 1))));
+                }
+            }
+        }
+        return;
+    }
+    if (piece >= 0) {
+        // a K piece of a tail tile: dense 256 x 256 slab (no bounds: the reduce reads only what is inside C)
+        float* slab = p.ws + ((long)(tile - q.full) * q.tail_s + piece) * (BT2 * BT2);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = wn * (32 * NJ) + j * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                    slab[rr * BT2 + col] = acc[i2][j][e];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            store_frag_f32(p, acc[i2][j], m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), n0 + wn * (32 * NJ) + j * 32 + (l & 31));
+}
+
+// PP ("ping-pong", round 4): the K loop runs as two wave groups half a k-step apart.  Waves w and w + 4 share SIMD w & 3 and belong
+// to different groups (wm = 0 / 1); a k-step of a wave is a LOAD segment (its 6 fragment reads of that k-step + its share of the
+// next tile's LDS-DMA) and an MFMA segment (8 MFMAs = 256 cycles of the SIMD's matrix pipe), each closed by a bare s_barrier, and
+// group 1 enters the loop one barrier late: whenever one wave of a SIMD multiplies, its partner reads / stages, so the matrix pipe
+// of every SIMD sees ONE instruction stream of back-to-back MFMAs while only four waves at a time compete for the LDS port.
+// Ordering of the LDS-DMA: a tile's 8 DMA instructions go out in the LOAD segments of k-steps 0 and 1 of the tile before it, every
+// wave waits for its own (vmcnt(0): nothing newer is in flight then) before the barrier behind which group 0 starts to read the new
+// tile (group 1 at the end of its LOAD segment of k-step 3, group 0 one segment later), and a LOAD segment ends with lgkmcnt(0)
+// BEFORE its barrier, so the buffer a DMA overwrites (the tile before the current one) has been read completely by both groups
+// when the first DMA instruction of the tile after the current one is issued.  Measured (profiles/r04a_gemm_pingpong_probe.txt):
+// 8192^3 1204 -> 1241 TF, dO 290 -> 280 us, logits 282 -> 272 us, dW_pred unchanged -- the ablations of
+// profiles/r04b_gemm_pingpong_ablation.txt say why it is not more: without the DMA the same loop runs at 2100 TF, the DMA alone
+// (no MFMA, no fragment reads) takes 87 % of the full kernel's time: a CU gets ~45 GB/s out of L2 into LDS, i.e. 64 KB per 1.4 us
+// against 0.85 us of matrix-pipe time per K tile.
+template <bool NLL, bool TN, bool PP = false>
+__global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 q) {
+    constexpr int WN = 4;                               // 8 waves as 2 (M) x 4 (N), wave tile 128 x 64
+    constexpr int NJ = 2;                               // 32-column fragments per wave along N
+    constexpr int UN = 4;                               // 1 KB staging units per wave and image
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
+
+    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
+    const int kt0 = pk.kt0, kt1 = pk.kt1;
+    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
 
     const int t = (int)threadIdx.x;
     const int l = t & 63, w = lv_wave_uniform(t >> 6);   // wave id in SGPRs: the LDS-DMA destinations below are scalar (M0)
@@ -1001,7 +1113,7 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
 #endif
                 LV_SCHED_BARRIER();
 #if LV_B16_PP_ABL & 16
-                if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (ks == BK / 16 - 1) LV_WAIT_VMEM_N(8);
 #else
                 // the DMA wait: every wave before the SAME barrier -- the one behind which group 0 starts reading the next tile --, i.e.
                 // group 1 at the end of this LOAD segment, group 0 one segment later, at the end of its MFMA segment (LV_B16_PP_WAIT 1)
@@ -1045,104 +1157,244 @@ __global__ __launch_bounds__(128 * WN) void lv_gemm_b16_t256_kernel(GemmQ p, Tai
     }
     }
 
-    if constexpr (NLL) {
-        // fused epilogue of the vocabulary projection (see the 128 x 128 kernel): the 256 x 256 tile goes through the 128 KB of
-        // LDS as binary16 (64 rows of 512 B per buffer, 16-byte chunks permuted by chunk ^ (row & 15) so that the row-per-lane
-        // reads below are conflict-free), thread (row rr = t & 255, half = t >> 8) owns 128 consecutive logits = two 64-column
-        // pieces of the statistics
-        auto rowptr = [&](int rr) -> char* {            // 64 tile rows of 512 B per buffer
-            const int b = rr >> 6;
-            char* base = b == 0 ? reinterpret_cast<char*>(&As0[0][0]) : b == 1 ? reinterpret_cast<char*>(&Bs0[0][0])
-                       : b == 2 ? reinterpret_cast<char*>(&As1[0][0]) : reinterpret_cast<char*>(&Bs1[0][0]);
-            return base + (rr & 63) * 512;
-        };
-        // Write phase: a lane holds ONE column of 16 rows per fragment, its neighbour (lane ^ 1) the next column.  Rows are taken
-        // in pairs (e, e + 1): the even lane sends its row e + 1 and keeps row e, the odd lane the other way round (one DPP move),
-        // so every lane stores one packed pair (two adjacent columns of one row) -- 64 ds_write_b32 per thread instead of 128
-        // ds_write_b16, one conversion instruction per pair.  Address = buffer + row * 512 + (chunk ^ (row & 15)) * 16 + ...; with
-        // row & 15 = (e & 3 | odd) | 4 lh | 8 (e >> 2 & 1) the lane part and the per-e part of the XOR separate.
-        const int odd = l & 1;
+    t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, wm, wn, lh);
+}
+
+// ---- the same tile with a QUADRANT-ordered ping-pong schedule and a continuous LDS-DMA stream (round 4) -----------------------
+// The k-step schedules above stage a K tile as two bursts of 32 KB and then leave the memory pipeline empty until the next tile may
+// be fetched (its buffer is read until the last k-step): a CU holds ~32 KB of DMA in flight and a burst takes one L2 round trip, so
+// the tile period is two round trips + the gap.  Here a wave's 128 x 64 block is walked as four QUADRANTS (64 x 32: 2 fragments x 1
+// fragment x all four k-steps = 8 MFMAs), in the order (a, b) = (0,0) (0,1) (1,1) (1,0): quadrant rows a / columns b are exactly one
+// HALF of the A / B tile (A-half a = rows 128 wm + 64 a + [0, 64) for both wm, B-half b = rows 64 wn + 32 b + [0, 32) for all four
+// wn), so a half-tile is read in ONE phase -- A0 and B0 in phase 0, B1 in phase 1, A1 in phase 2, nothing in phase 3 -- and its LDS
+// can be refilled right behind that phase, 1.25 to 1.75 tiles ahead.  Every LOAD segment therefore issues one half-tile (2 DMA
+// instructions per wave, 16 KB per workgroup): in the phases 1, 2, 3, 0 (of the next tile) the halves A0, B0, B1, A1 of the tile
+// after next, into the buffer the current tile is being read from.  The stream never pauses: the DMA statements are inline assembly
+// (lv_glds16_uncounted: hipcc would otherwise drain the stream in front of every read of a buffer that has DMA in flight), the
+// waits are counted by hand (vmcnt(10): the five half-tiles issued behind the one about to be read stay in flight) and every wave places its wait before the barrier behind which
+// group 0 starts reading that half (group 1: end of its LOAD segment, group 0: end of its MFMA segment).  Fragment registers: A
+// half 8 x 4, both B halves 2 x 4 x 4 = 64 (the k-step schedules: 24 / 48).  The LDS images of B and of a K-contiguous A are the
+// ones above (a half-tile is a set of whole 8-row DMA units); the M-contiguous A of the weight-gradient form is kept per half as
+// [64 k][16 slots of 16 B] (slot = (8 wm + m / 8) ^ 4 (k & 3): the swizzle stays inside the half).
+template <bool NLL, bool TN>
+__global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256 q) {
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
+
+    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
+    const int kt0 = pk.kt0, kt1 = pk.kt1;
+    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
+
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = lv_wave_uniform(t >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int li = l & 31, lh = l >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nfull = p.K / BK;
+
+    // This wave's DMA items: for each half-tile two 1 KB units.  item h in {A0, A1, B0, B1} x u in {0, 1}: source element offset
+    // (per lane), LDS byte offset inside the operand's tile buffer (wave-uniform), and what the ragged tile needs (the lane's k).
+    uint32_t osrc[4][2];
+    int odst[4][2], okk[4][2];                  // okk: NT = k offset of the lane's chunk inside the tile, TN A = the lane's k row
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // B-half a (b = a): 8-row unit 8 (w >> 1) + 4 b + 2 (w & 1) + u
+            {
+                const int ub = 8 * (w >> 1) + 4 * a + 2 * (w & 1) + u;
+                const int row = 8 * ub + (l >> 3);
+                const int c = (l & 7) ^ ((row >> 1) & 7);
+                int rb = n0 + row;
+                if (rb > p.N - 1) rb = p.N - 1;                  // clamped, not predicated
+                osrc[2 + a][u] = (uint32_t)((long)rb * p.ldb + 8 * c);
+                odst[2 + a][u] = 1024 * ub;
+                okk[2 + a][u] = 8 * c;
+            }
+            if constexpr (TN) {
+                // A stored [K][M]: unit 2 w + u of half a = k rows 4 (2w + u) + (l >> 4), 16-byte slot l & 15 of the half's 256-byte row
+                const int krow = 4 * (2 * w + u) + (l >> 4);
+                const int s16 = (l & 15) ^ (4 * (krow & 3));
+                long mc = m0 / 8 + 16 * (s16 >> 3) + 8 * a + (s16 & 7);      // 8-element chunk index along M
+                if (mc > p.lda / 8 - 1) mc = p.lda / 8 - 1;
+                osrc[a][u] = (uint32_t)((long)krow * p.lda + 8 * mc);
+                odst[a][u] = 16384 * a + 1024 * (2 * w + u);
+                okk[a][u] = krow;
+            } else {
+                const int ub = 16 * (w >> 2) + 8 * a + 2 * (w & 3) + u;
+                const int row = 8 * ub + (l >> 3);
+                const int c = (l & 7) ^ ((row >> 1) & 7);
+                int ra = m0 + row;
+                if (ra > p.M - 1) ra = p.M - 1;
+                osrc[a][u] = (uint32_t)((long)ra * p.lda + 8 * c);
+                odst[a][u] = 1024 * ub;
+                okk[a][u] = 8 * c;
+            }
+        }
+    // one half-tile (h: 0 = A0, 1 = A1, 2 = B0, 3 = B1) of K tile kt into the buffer pair (Ad, Bd): 2 DMA instructions
+    auto stage_half = [&](int kt, int h, LdsTile2& Ad, LdsTile2& Bd) {
+        const uint32_t k0 = (uint32_t)(kt * BK);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (h < 2) {
+                const uint32_t ka = TN ? k0 * (uint32_t)p.lda : k0;
+                lv_glds16_uncounted(p.A + (size_t)(osrc[h][u] + ka), reinterpret_cast<char*>(&Ad[0][0]) + odst[h][u]);
+            } else {
+                lv_glds16_uncounted(p.B + (size_t)(osrc[h][u] + k0), reinterpret_cast<char*>(&Bd[0][0]) + odst[h][u]);
+            }
+        }
+    };
+    auto stage_ragged = [&](int kt, LdsTile2& Ad, LdsTile2& Bd) {      // the ragged last K tile: masked loads through registers
+        const int k0 = kt * BK;
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                char* dst = reinterpret_cast<char*>(h < 2 ? &Ad[0][0] : &Bd[0][0]) + odst[h][u] + 16 * l;
+                if (h < 2 && TN) {
+                    *reinterpret_cast<uint4*>(dst) = k0 + okk[h][u] < p.K
+                        ? *reinterpret_cast<const uint4*>(p.A + (size_t)(osrc[h][u] + (uint32_t)k0 * (uint32_t)p.lda)) : z4;
+                } else {
+                    const uint16_t* src = (h < 2 ? p.A : p.B) + (size_t)(osrc[h][u] + (uint32_t)k0);
+                    const int k = k0 + okk[h][u];
+                    *reinterpret_cast<uint4*>(dst) = k < p.K ? load_chunk_masked(src, p.K - k) : z4;
+                }
+            }
+    };
+
+    const int arow = wm * 128 + li, brow = wn * 64 + li;
+    const int sx = (li >> 1) & 7;
+    int atr[4] = {0, 0, 0, 0};
+    if constexpr (TN) {
+        const int r = l & 15, kr = r >> 2;
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) {
-            char* const bufp = rowptr(wm * 128 + i2 * 32);                  // row (i2 & 1) * 32 of its buffer
+            const int mh = 32 * (i2 & 1) + 16 * ((l >> 4) & 1) + 4 * (r & 3);          // m inside the (wm, half) block of 64
+            const int s16 = 8 * wm + (mh >> 3);
+            atr[i2] = 16384 * (i2 >> 1) + (8 * lh + kr) * 256 + ((s16 ^ (4 * kr)) * 16) + (mh & 7) * 2;
+        }
+    }
+    auto a_frag = [&](LdsTile2& Ac, int ks, int i2) -> uint4 {
+        if constexpr (TN) {
+            const char* base = reinterpret_cast<const char*>(&Ac[0][0]) + atr[i2] + ks * 16 * 256;
+            const uint2 lo = lv_ds_read_tr16_b64(base), hi = lv_ds_read_tr16_b64(base + 4 * 256);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            return Ac[arow + 32 * i2][(2 * ks + lh) ^ sx];
+        }
+    };
+    auto b_frag = [&](LdsTile2& Bc, int ks, int j) -> uint4 { return Bc[brow + 32 * j][(2 * ks + lh) ^ sx]; };
+    // 8 MFMAs of one quadrant: accumulators (2a, b) and (2a + 1, b) alternate, all four k-steps
+    auto mma_quadrant = [&](const uint4 (&fa)[4][2], const uint4 (&fb)[4], int a, int b) {
+        LV_SETPRIO(1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int clp = (wn * 64 + j * 32 + (l & 31)) & ~1;          // first column of this lane's pair
-                const int lane_off = (4 * lh + odd) * 512 + ((((clp >> 3) ^ (4 * lh) ^ odd) << 4) | ((clp & 7) << 1));
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const float mine0 = acc[i2][j][e], mine1 = acc[i2][j][e + 1];
-                    const float got = lv_lane_xor1(odd ? mine0 : mine1);
-                    const uint32_t pk = odd ? lv_pack_f16x2(got, mine1) : lv_pack_f16x2(mine0, got);
-                    const int key = (e & 3) | (8 * ((e >> 2) & 1));          // compile-time part of row & 15
-                    const int roff = ((e & 3) + 8 * (e >> 2)) * 512;
-                    *reinterpret_cast<uint32_t*>(bufp + roff + (lane_off ^ (key << 4))) = pk;
-                }
-            }
+            for (int i = 0; i < 2; ++i) acc[2 * a + i][b] = lv_mfma_32x32x16_bf16(fa[ks][i], fb[ks], acc[2 * a + i][b]);
+        LV_SETPRIO(0);
+    };
+    // the DMA wait of a phase: before the barrier behind which group 0 reads what it covers -- group 1 at the end of its LOAD
+    // segment, group 0 at the end of its MFMA segment; 10 = the DMA instructions of the five half-tiles issued behind the needed one
+#define LV_Q_WAIT() LV_WAIT_VMEM_N(10)
+    auto seg_close = [&](bool wait) {           // end of a LOAD segment
+        LV_SCHED_BARRIER();
+        if (wait && wm == 1) LV_Q_WAIT();
+        LV_WAIT_LDS();
+        LV_S_BARRIER();
+        LV_SCHED_BARRIER();
+    };
+    auto mfma_close = [&](bool wait) {          // end of an MFMA segment
+        LV_SCHED_BARRIER();
+        if (wait && wm == 0) LV_Q_WAIT();
+        LV_S_BARRIER();
+        LV_SCHED_BARRIER();
+    };
+    // One K tile out of (Ac, Bc); kn1 = the tile after it (its half A1 is still to be issued: into (Ao, Bo), the OTHER pair), kn2 =
+    // the tile after that (halves A0, B0, B1: into (Ac, Bc) itself, behind the phases that read them).
+    auto q_tile = [&](LdsTile2& Ac, LdsTile2& Bc, LdsTile2& Ao, LdsTile2& Bo, int kn1, int kn2) {
+        uint4 fa[4][2], fb0[4], fb1[4];
+        // phase 0: quadrant (0, 0) -- reads A0 and B0, issues A1 of the next tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb0[ks] = b_frag(Bc, ks, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fa[ks][0] = a_frag(Ac, ks, 0); fa[ks][1] = a_frag(Ac, ks, 1); }
+        LV_SCHED_BARRIER();
+        stage_half(kn1, 1, Ao, Bo);
+        seg_close(true);                        // ... and the wait that covers B1 of this tile (read in phase 1)
+        mma_quadrant(fa, fb0, 0, 0);
+        mfma_close(true);
+        // phase 1: quadrant (0, 1) -- reads B1, issues A0 of the tile after next (A0 of this pair was read in phase 0 by everybody)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb1[ks] = b_frag(Bc, ks, 1);
+        LV_SCHED_BARRIER();
+        stage_half(kn2, 0, Ac, Bc);
+        seg_close(true);                        // covers A1 of this tile (phase 2)
+        mma_quadrant(fa, fb1, 0, 1);
+        mfma_close(true);
+        // phase 2: quadrant (1, 1) -- reads A1, issues B0 of the tile after next
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fa[ks][0] = a_frag(Ac, ks, 2); fa[ks][1] = a_frag(Ac, ks, 3); }
+        LV_SCHED_BARRIER();
+        stage_half(kn2, 2, Ac, Bc);
+        seg_close(false);
+        mma_quadrant(fa, fb1, 1, 1);
+        mfma_close(false);
+        // phase 3: quadrant (1, 0) -- reads nothing, issues B1 of the tile after next
+        stage_half(kn2, 3, Ac, Bc);
+        seg_close(true);                        // covers A0 and B0 of the next tile (its phase 0)
+        mma_quadrant(fa, fb0, 1, 0);
+        mfma_close(true);
+    };
+
+    // The ragged tile at the end of a K that is not a multiple of 64 goes FIRST (masked loads through registers, lockstep)
+    const int nmain = (kt1 < nfull ? kt1 : nfull) - kt0;
+    if (kt1 > kt0 + nmain) {
+        stage_ragged(kt1 - 1, As0, Bs0);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 ra[4], rb[2];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) ra[i2] = a_frag(As0, ks, i2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rb[j] = b_frag(Bs0, ks, j);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i2][j] = lv_mfma_32x32x16_bf16(ra[i2], rb[j], acc[i2][j]);
         }
         __syncthreads();
-        const int rr = t & 255, half = t >> 8;
-        const int row = m0 + rr;
-        if (row < p.M) {
-            const char* rowp = rowptr(rr);
-            const int tt = row / p.Bsz, bb = row % p.Bsz;
-            long tg = p.ids[(long)bb * p.ids_stride + tt + p.tgt_off];
-            if (tg < 0) tg = 0;
-            if (tg >= p.N) tg = p.N - 1;
-#pragma unroll 1
-            for (int pc = 0; pc < 2; ++pc) {
-                const int cb = 128 * half + 64 * pc;       // first column of this piece inside the tile
-                const int c0 = n0 + cb;
-                uint4 qv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) qv[k] = *reinterpret_cast<const uint4*>(rowp + ((((cb >> 3) + k) ^ (rr & 15)) << 4));
-                uint16_t* dst = p.C16 + (long)row * p.ldc16 + c0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (c0 + 8 * k + 8 <= p.ldc16) reinterpret_cast<uint4*>(dst)[k] = qv[k];
-                float v[64];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t wv[4] = {qv[k].x, qv[k].y, qv[k].z, qv[k].w};
-#pragma unroll
-                    for (int h2 = 0; h2 < 4; ++h2) {
-                        v[8 * k + 2 * h2] = lv_f16_bits_to_f32((uint16_t)(wv[h2] & 0xFFFFu));
-                        v[8 * k + 2 * h2 + 1] = lv_f16_bits_to_f32((uint16_t)(wv[h2] >> 16));
-                    }
-                }
-                float mx, sm;
-                nll_piece_stats(v, p.N - c0, mx, sm);
-                p.part[(long)row * p.nparts + 4 * tn + 2 * half + pc] = make_float2(mx, sm);
-                const int tl = (int)tg - c0;
-                if (tl >= 0 && tl < 64) {
-                    const int cl = cb + tl;
-                    p.tgt[row] = lv_f16_bits_to_f32(*reinterpret_cast<const uint16_t*>(rowp + ((((cl >> 3) ^ (rr & 15)) << 4) | ((cl & 7) << 1))));
-                }
-            }
+    }
+    if (nmain > 0) {
+        const int klast = kt0 + nmain - 1;
+        auto tile_at = [&](int i) { return kt0 + i < klast ? kt0 + i : klast; };      // beyond the end: the last tile again (a harmless reload)
+        // prologue: the issue order of the steady state up to the first phase -- all of tile 0, then A0, B0, B1 of tile 1
+        stage_half(tile_at(0), 0, As0, Bs0); stage_half(tile_at(0), 2, As0, Bs0); stage_half(tile_at(0), 3, As0, Bs0);
+        stage_half(tile_at(0), 1, As0, Bs0);
+        stage_half(tile_at(1), 0, As1, Bs1); stage_half(tile_at(1), 2, As1, Bs1); stage_half(tile_at(1), 3, As1, Bs1);
+        LV_Q_WAIT();                            // A0, B0 of tile 0 (10 newer instructions behind them)
+        __syncthreads();
+        if (wm == 1) LV_S_BARRIER();            // group 1 runs one segment behind group 0
+        for (int i = 0; i < nmain; i += 2) {
+            q_tile(As0, Bs0, As1, Bs1, tile_at(i + 1), tile_at(i + 2));
+            if (i + 1 >= nmain) break;
+            q_tile(As1, Bs1, As0, Bs0, tile_at(i + 2), tile_at(i + 3));
         }
-        return;
+        if (wm == 0) LV_S_BARRIER();            // ... and is met again here
+        LV_WAIT_VMEM();                         // the reloads issued in the last two tiles: nothing may still land in LDS
+        __syncthreads();
     }
-    if (piece >= 0) {
-        // a K piece of a tail tile: dense 256 x 256 slab (no bounds: the reduce reads only what is inside C)
-        float* slab = p.ws + ((long)(tile - q.full) * q.tail_s + piece) * (BT2 * BT2);
-#pragma unroll
-        for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = wn * (32 * NJ) + j * 32 + (l & 31);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = wm * 128 + i2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-                    slab[rr * BT2 + col] = acc[i2][j][e];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            store_frag_f32(p, acc[i2][j], m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), n0 + wn * (32 * NJ) + j * 32 + (l & 31));
+#undef LV_Q_WAIT
+    t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, wm, wn, lh);
 }
 
 // the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)
@@ -1305,11 +1557,17 @@ static bool t256_wanted(int tile, int M, int N, int K) {
     if (tile) return tile >= 256;
     return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
 }
-#ifndef LV_B16_PP_DEFAULT
-#define LV_B16_PP_DEFAULT 1       // schedule of the 256 x 256 kernel when the caller does not name it: 0 = lockstep, 1 = ping-pong
+#ifndef LV_B16_SCHED_DEFAULT
+#define LV_B16_SCHED_DEFAULT -1   // schedule of the 256 x 256 kernel when the caller does not name it: -1 = by K tiles per workgroup, 0 = lockstep, 1 = ping-pong by k-steps, 2 = ping-pong by quadrants with a continuous DMA stream
 #endif
-// tile argument of the *_tile entries: 0 = by shape, 128, 256 = 256 x 256 lockstep schedule, 257 = 256 x 256 ping-pong schedule
-static bool t256_pp(int tile) { return tile == 257 || (tile == 0 && LV_B16_PP_DEFAULT); }
+// tile argument of the *_tile entries: 0 = by shape, 128, 256 / 257 / 258 = the 256 x 256 tile on schedule 0 / 1 / 2
+// By shape (measured, profiles/r04f_gemm_schedules.txt): the quadrant schedule wins where a workgroup walks many K tiles (dO: 63 per
+// piece, 278 -> 270 us; dW_pred: 100 / 25, 274 -> 258 us; 8192^3 1234 -> 1264 TF), the k-step ping-pong where it walks few and the
+// prologue (seven half-tiles before the first MFMA) shows (logits, K = 1024: 271 vs 280 us; fused NLL 308 vs 322; 4096^3).
+static int t256_sched(int tile, int kt_per_wg) {
+    if (tile >= 256) return tile - 256;
+    return LV_B16_SCHED_DEFAULT >= 0 ? LV_B16_SCHED_DEFAULT : (kt_per_wg >= 24 ? 2 : 1);
+}
 
 // How the tail (tiles % 256) of a 256 x 256 launch is cut along K: estimated microseconds for s pieces per tail tile =
 // rounds x K tiles per piece x ~2 us per tile step + the slab traffic of the reduce ((s + 1) passes over tail x 256 KB at ~4.5 TB/s)
@@ -1342,7 +1600,7 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
                                 const float* add1, long ld1, int mod1,
                                 const float* add2, long ld2, int mod2,
                                 float* ws, long ws_floats, void* stream) {
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return LV_ERR_ARG;
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
@@ -1363,16 +1621,15 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
         const Tail256 q = t256_plan((long)p.tilesM * p.tilesN, nk, ws ? ws_floats : 0);
         const long tail = (long)p.tilesM * p.tilesN - q.full;
         dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
-#if LV_B16_T256_W4                                         // (measurement knob: the 4-wave form of the kernel, wave tile 128 x 128)
-        if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, 2>), grid, dim3(256), 0, stream, p, q);
-        else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, 2>), grid, dim3(256), 0, stream, p, q);
-#else
-        if (t256_pp(tile)) {
-            if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, 4, true>), grid, block, 0, stream, p, q);
-            else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, 4, true>), grid, block, 0, stream, p, q);
+        const int sched = t256_sched(tile, q.tail_s > 1 && q.full == 0 ? q.kt_per_piece : nk);
+        if (sched == 2) {
+            if (transA) LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, true>), grid, block, 0, stream, p, q);
+            else LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, false>), grid, block, 0, stream, p, q);
+        } else if (sched == 1) {
+            if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true, true>), grid, block, 0, stream, p, q);
+            else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, true>), grid, block, 0, stream, p, q);
         } else if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
-#endif
         if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
@@ -1484,7 +1741,7 @@ extern "C" int lv_gemm_b16_nll_parts(int N) { return 4 * lv_cdiv(N, BT2); }
 extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                     uint16_t* logits16, long ldl16, const int64_t* ids, long ids_stride, int tgt_off, int Bsz,
                                     float* part, float* tgt_logit, void* stream) {
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return LV_ERR_ARG;
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
     if (M < 0 || N <= 0 || K <= 0 || Bsz <= 0) return LV_ERR_SHAPE;
     if (M == 0) return LV_OK;
     if (!A || !B || !logits16 || !ids || !part || !tgt_logit) return LV_ERR_ARG;
@@ -1504,7 +1761,9 @@ extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
         q.full = (int)(tiles / 256 * 256); q.tail = (int)(tiles - q.full); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
-        if (t256_pp(tile)) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, 4, true>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        const int sched = t256_sched(tile, p.kt_per_split);
+        if (sched == 2) LV_LAUNCH((lv_gemm_b16_t256q_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        else if (sched == 1) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, true>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;

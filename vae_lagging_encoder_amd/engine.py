@@ -207,20 +207,25 @@ class _DecWS(_NS):
 # stream and (start, end, work, launches) is appended under the group name (measurement only; None normally).
 # work = flops for the GEMM groups, timesteps for the LSTM groups.
 PROFILE = None
+# ... and only the groups whose name starts with this prefix (None: all).  A HIP event record costs ~5 us of an otherwise gap-free
+# queue (kernel trace: profiles/r04d_timeline.txt -- 28 records = 150 us of a 3.5 ms step), so the bench brackets only the
+# dominant group inside its timed region and takes the other group's times from a separate, untimed pass.
+PROFILE_PREFIX = None
 
 
 class _prof(object):
     def __init__(self, name, work, launches=1):
         self.name, self.work, self.launches = name, work, launches
+        self.on = PROFILE is not None and (PROFILE_PREFIX is None or name.startswith(PROFILE_PREFIX))
 
     def __enter__(self):
-        if PROFILE is not None:
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *a):
-        if PROFILE is not None:
+        if self.on:
             self.e1.record()
             PROFILE.setdefault(self.name, []).append((self.e0, self.e1, self.work, self.launches))
 
