@@ -56,6 +56,11 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
  * sum exp(x - max)) with parts = lv_gemm_b16_nll_parts(N), + tgt_logit [M] = the logit of row r's target token
  * ids[(r % Bsz) * ids_stride + r / Bsz + tgt_off].  lv_softmax_nll_merge_f32 finishes lse / nll; lv_softmax_nll_bwd_h16 is the
  * backward over the binary16 image.  ldl16 % 8 == 0. */
+/* C [M][N] = (A . B^T) * (keep ? kscale : 0): lv_gemm_b16 (transA = 0, plain output, ldc = N) with the backward of nn.Dropout on the
+ * LSTM output (dec_lstm.py:106; dO = dlogits . W_pred then masked) applied in the product's reduction stage instead of by a pass of
+ * its own; rows time-major (r = t * Bsz + b), keep = the reference-layout mask [Bsz][M / Bsz][N], uint8. */
+int lv_gemm_b16_keep(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C,
+                     const uint8_t* keep, float kscale, int Bsz, float* ws, long ws_floats, void* stream);
 int lv_gemm_b16_nll_parts(int N);
 /* The same two entries with the tile edge named by the caller instead of chosen by shape: tile = 0 (by shape: the 256 x 256 x 64
  * kernel, one workgroup per CU, for products of >= 1e11 flop -- the three vocabulary-sized GEMMs of dec_lstm.py:117,140-146 --
@@ -134,6 +139,7 @@ long lv_lstm_persist16_wpk_floats(void);
 long lv_lstm_persist16_xch_floats(void);
 long lv_lstm_persist16_saved_floats(int T, int R);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
+int lv_lstm_persist16_pack2(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream);   /* both images, one launch */
 int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* saved, float* xch, int* status,
                                int T, int B, int R, int flags, int H, void* stream);
 int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved, const float* hs,
@@ -211,6 +217,10 @@ int lv_loss_bwd_scales_f32(const float* g_loss, const float* g_rec, const float*
  * dkl[b] = w*g_loss[b] (the seeds of loss.mean().backward(), text.py:382-384) */
 int lv_loss_assemble_f32(const float* nll, const float* kl, const float* kl_weight_dev, const float* g_loss,
                          float* loss, float* rec, float* rowscale, float* dkl, float* acc_dev, int T, int B, void* stream);
+/* the same + rng_state[1] += rng_inc (the {seed, offset} state of lv_rng_noise_step, which the fused step then calls with inc = 0) */
+int lv_loss_assemble_rng_f32(const float* nll, const float* kl, const float* kl_weight_dev, const float* g_loss,
+                             float* loss, float* rec, float* rowscale, float* dkl, float* acc, int T, int B,
+                             uint64_t* rng_state, uint64_t rng_inc, void* stream);
 
 /* ---- the batch-sized ends of the two LSTM networks, one launch each (lv_head.hip) --------------------------------------
  * LSTMEncoder's head + GaussianEncoderBase.encode (enc_lstm.py:62-64, encoder.py:40-57): mulv = hT . W_lin^T,
@@ -270,6 +280,10 @@ int lv_txn_guard_f32(const int* status1, const int* status2, float* guard, void*
 int lv_sgd_step_txn_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
                         const float* void_flag_dev, void* stream);
 int lv_scale_txn_f32(float* x, long n, const float* coef_dev, const float* void_flag_dev, void* stream);
+/* lv_sgd_step_txn_f32 on (p, g) and lv_scale_txn_f32 on x2 -- the gradient buffer of the side that is NOT stepped, which
+ * clip_grad_norm_ (text.py:385) scales all the same -- in one launch */
+int lv_sgd_step_scale_txn_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev, int write_back_clipped,
+                              float* x2, long n2, const float* void_flag_dev, void* stream);
 int lv_adam_step_f32(float* p, float* g, float* m, float* v, long n, const float* lr_dev, const float* coef_dev,
                      const float* step_dev, float beta1, float beta2, float eps, int write_back_clipped, void* stream);
 

@@ -230,3 +230,8 @@ def test_bf16_payload_unpack(emu_backend):
 @pytest.mark.parametrize("cfg", [(4, 64, 7, True, True), (3, 33, 5, True, False), (1, 1, 3, False, False)])
 def test_batchnorm_eval(emu_backend, cfg):
     K.test_batchnorm_eval(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(5, 4, 70, 100, False), (4, 8, 64, 1100, False), (3, 7, 300, 64, False)])
+def test_gemm_b16_keep(emu_backend, cfg):
+    K.test_gemm_b16_keep(emu_backend, CPU, *cfg)

@@ -198,6 +198,30 @@ def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split, tile):
     test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=(not split) and K % 64 == 0, tile=tile)
 
 
+@pytest.mark.parametrize("T,B,N,K,big", [(5, 4, 70, 100, False), (9, 32, 64, 1100, False), (40, 32, 1024, 4200, True), (3, 7, 300, 64, False)])
+def test_gemm_b16_keep(lib, hip_device, T, B, N, K, big):
+    """lv_gemm_b16_keep: C = (A . B^T) * (keep ? kscale : 0), the dropout backward applied in the product's reduction stage (split-K
+    reduce of the 128 x 128 kernel, tail reduce of the 256 x 256 one) or, where there is none, by a pass of its own -- bit-identical
+    to lv_gemm_b16 followed by lv_keep_scale_f32."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(T * 31 + N)
+    M = T * B
+    lda = ldb = ((K + 7) // 8) * 8
+    A16 = _bf16_bits(torch.randn(M, lda, generator=g)).to(dev)
+    B16 = _bf16_bits(torch.randn(N, ldb, generator=g)).to(dev)
+    keep = (torch.rand(B, T, N, generator=g) < 0.5).to(torch.uint8).to(dev)
+    ws = torch.empty(1 << 24, device=dev)
+    C1 = torch.full((M, N), float("nan"), device=dev)
+    C2 = torch.full((M, N), float("nan"), device=dev)
+    lib.lv_gemm_b16_keep(M, N, K, P(A16), lda, P(B16), ldb, P(C1), P(keep), 2.0, B, P(ws), ws.numel(), _s(dev))
+    lib.lv_gemm_b16(0, M, N, K, 1.0, P(A16), lda, P(B16), ldb, P(C2), N, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
+    lib.lv_keep_scale_f32(P(C2), P(keep), 2.0, T, B, N, _s(dev))
+    assert torch.equal(C1.cpu(), C2.cpu())
+    ref = (A16.cpu().view(torch.bfloat16).double()[:, :K] @ B16.cpu().view(torch.bfloat16).double()[:, :K].t())
+    ref = ref.view(T, B, N) * keep.cpu().double().permute(1, 0, 2) * 2.0
+    assert float((C1.cpu().double().view(T, B, N) - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 16
+
+
 def test_gemm_b16_alignment_errors(lib, hip_device):
     z = torch.zeros(64, 64, dtype=torch.int16, device=hip_device)
     c = torch.zeros(8, 8, device=hip_device)

@@ -22,6 +22,7 @@ SIGNATURES = {
     "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_b16_keep": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _vp, _l, _vp],
     "lv_gemm_b16_nll_parts": [_i],
     "lv_gemm_b16_tile": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16_nll_tile": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp],
@@ -36,6 +37,7 @@ SIGNATURES = {
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "lv_loss_assemble_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lv_loss_assemble_rng_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp],
     "lv_enc_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_enc_head_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_dec_tail_parts": [_i],
@@ -47,11 +49,13 @@ SIGNATURES = {
     "lv_txn_guard_f32": [_vp, _vp, _vp, _vp],
     "lv_sgd_step_txn_f32": [_vp, _vp, _l, _vp, _vp, _i, _vp, _vp],
     "lv_scale_txn_f32": [_vp, _l, _vp, _vp, _vp],
+    "lv_sgd_step_scale_txn_f32": [_vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _vp],
     "lv_rng_noise_step": [_vp, _l, _vp, _l, _f, _vp, _l, _f, _vp, _u64, _vp],
     "lv_lstm_persist16_wpk_floats": [],
     "lv_lstm_persist16_xch_floats": [],
     "lv_lstm_persist16_saved_floats": [_i, _i],
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
+    "lv_lstm_persist16_pack2": [_vp, _vp, _vp, _i, _vp],
     "lv_lstm_fwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],

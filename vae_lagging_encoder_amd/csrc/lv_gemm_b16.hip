@@ -60,6 +60,8 @@ struct GemmQ {
     const int64_t* ids; long ids_stride; int tgt_off; int Bsz;
     float2* part; int nparts;          // [M][nparts] (max, sum exp(x - max)) of each 64-column piece of a row
     float* tgt;                        // [M] the target token's logit
+    // nn.Dropout backward folded into the reduction stage (lv_gemm_b16_keep): C *= keep[(row % Bsz) * keepT + row / Bsz][col] ? kscale : 0
+    const uint8_t* keep; float kscale; int keepT;
 };
 
 __device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int valid) {
@@ -1425,6 +1427,7 @@ __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 
             if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
             float* c = p.C + (long)row * p.ldc + col;
             if (p.accumulate) v += *c;
+            if (p.keep) v *= p.keep[((long)(row % p.Bsz) * p.keepT + row / p.Bsz) * p.N + col] ? p.kscale : 0.f;
             *c = v;
         }
     }
@@ -1460,6 +1463,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
     if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
     float* c = p.C + (long)row * p.ldc + col;
     if (p.accumulate) v += *c;
+    if (p.keep) v *= p.keep[((long)(row % p.Bsz) * p.keepT + row / p.Bsz) * p.N + col] ? p.kscale : 0.f;
     *c = v;
 }
 
@@ -1594,12 +1598,14 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
 // A: transA == 0 -> stored [M][K] (lda >= K); transA == 1 -> stored [K][M] (lda >= M).  B: stored [N][K] (ldb >= K).
 // All leading dimensions % 8 == 0 and bases 16 B-aligned (else LV_ERR_ALIGN).  Rows may be read up to the next
 // multiple of 8 elements past their logical end (never past ld); what lies there never reaches C.
-extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float alpha,
-                                const uint16_t* A, long lda, const uint16_t* B, long ldb,
-                                float* C, long ldc, int accumulate,
-                                const float* add1, long ld1, int mod1,
-                                const float* add2, long ld2, int mod2,
-                                float* ws, long ws_floats, void* stream) {
+extern "C" int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, int T, int Bsz, int C, void* stream);
+
+static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alpha,
+                           const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                           float* C, long ldc, int accumulate,
+                           const float* add1, long ld1, int mod1,
+                           const float* add2, long ld2, int mod2,
+                           float* ws, long ws_floats, void* stream, const uint8_t* keep, float kscale, int Bsz) {
     if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
@@ -1608,18 +1614,22 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
     if (lda < (transA ? M : K) || ldb < K || ldc < N) return LV_ERR_SHAPE;
     if (ldb % 8 != 0 || (((uintptr_t)B) & 15) != 0) return LV_ERR_ALIGN;
     if (lda % 8 != 0 || (((uintptr_t)A) & 15) != 0) return LV_ERR_ALIGN;
-    GemmQ p;
+    GemmQ p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.accumulate = accumulate;
     p.add1 = add1; p.ld1 = ld1; p.mod1 = mod1 > 0 ? mod1 : 1;
     p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
     p.ws = ws;
+    p.keep = nullptr; p.kscale = 1.f; p.keepT = 1; p.Bsz = Bsz > 0 ? Bsz : 1;
+    // a keep-mask rides in the reduction kernel when every output element passes through one; else a pass of its own follows
+    bool keep_pending = keep != nullptr;
     const int nk = lv_cdiv(K > 0 ? K : 1, BK);
     if (t256_wanted(tile, M, N, K)) {
         p.tilesM = lv_cdiv(M, BT2); p.tilesN = lv_cdiv(N, BT2);
         p.splits = 1; p.kt_per_split = nk;
         const Tail256 q = t256_plan((long)p.tilesM * p.tilesN, nk, ws ? ws_floats : 0);
         const long tail = (long)p.tilesM * p.tilesN - q.full;
+        if (keep && q.full == 0 && q.tail_s > 1) { p.keep = keep; p.kscale = kscale; p.keepT = M / p.Bsz; keep_pending = false; }
         dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
         const int sched = t256_sched(tile, q.tail_s > 1 && q.full == 0 ? q.kt_per_piece : nk);
         if (sched == 2) {
@@ -1632,6 +1642,7 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
         if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
         LV_CHECK_LAUNCH();
+        if (keep_pending) return lv_keep_scale_f32(C, keep, kscale, M / p.Bsz, p.Bsz, N, stream);
         return LV_OK;
     }
     p.tilesM = lv_cdiv(M, BT); p.tilesN = lv_cdiv(N, BT);
@@ -1649,6 +1660,7 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
     p.kt_per_split = lv_cdiv(nk, splits);
     splits = lv_cdiv(nk, p.kt_per_split);
     p.splits = splits;
+    if (keep && splits > 1) { p.keep = keep; p.kscale = kscale; p.keepT = M / p.Bsz; keep_pending = false; }
     dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
     if (transA && LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<false, false, true>), grid, block, 0, stream, p);
     else if (transA && LV_B16_GLDS) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, false, true>), grid, block, 0, stream, p);
@@ -1659,7 +1671,28 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
     if (splits > 1)
         LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);
     LV_CHECK_LAUNCH();
+    if (keep_pending) return lv_keep_scale_f32(C, keep, kscale, M / p.Bsz, p.Bsz, N, stream);
     return LV_OK;
+}
+
+extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float alpha,
+                                const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                float* C, long ldc, int accumulate,
+                                const float* add1, long ld1, int mod1,
+                                const float* add2, long ld2, int mod2,
+                                float* ws, long ws_floats, void* stream) {
+    return gemm_b16_launch(tile, transA, M, N, K, alpha, A, lda, B, ldb, C, ldc, accumulate, add1, ld1, mod1, add2, ld2, mod2, ws, ws_floats,
+                           stream, nullptr, 1.f, 1);
+}
+
+// C [M][N] (ldc = N) = (A . B^T) * (keep ? kscale : 0): the product of lv_gemm_b16 (transA = 0) with the backward of nn.Dropout
+// (dec_lstm.py:106 on the LSTM output: dO = dlogits . W_pred, masked) folded into the reduction stage of the product -- rows are
+// time-major (r = t * Bsz + b), keep is the reference-layout mask [Bsz][M / Bsz][N] (uint8).  Where the product has no reduction
+// stage (it fits whole tiles) the mask is applied by a pass of its own (lv_keep_scale_f32): same result either way.
+extern "C" int lv_gemm_b16_keep(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C,
+                                const uint8_t* keep, float kscale, int Bsz, float* ws, long ws_floats, void* stream) {
+    if (!keep || Bsz <= 0 || M % Bsz != 0) return LV_ERR_ARG;
+    return gemm_b16_launch(0, 0, M, N, K, 1.f, A, lda, B, ldb, C, N, 0, nullptr, 0, 1, nullptr, 0, 1, ws, ws_floats, stream, keep, kscale, Bsz);
 }
 
 // The same with the tile edge chosen by shape (the product's entry).

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64 * LA_WAVES) void loss_assemble_kernel(const floa
                                                             const float* __restrict__ klw, const float* __restrict__ g_loss,
                                                             float* __restrict__ loss, float* __restrict__ rec,
                                                             float* __restrict__ rowscale, float* __restrict__ dkl,
-                                                            float* __restrict__ acc, int T, int B) {
+                                                            float* __restrict__ acc, int T, int B,
+                                                            unsigned long long* rng_state, unsigned long long rng_inc) {
     __shared__ float red[3][LA_WAVES];
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const float kw = klw[0];
@@ -286,6 +287,9 @@ __global__ __launch_bounds__(64 * LA_WAVES) void loss_assemble_kernel(const floa
         for (int i = 0; i < LA_WAVES; ++i) t += red[tid][i];
         acc[tid] += t;
     }
+    // the Philox offset of the step's noise (lv_rng_noise_step with inc = 0 drew from it at the head of the step): advanced here, in
+    // a launch the step has anyway, instead of by a launch of its own
+    if (tid == 0 && rng_state) rng_state[1] += rng_inc;
 }
 
 // upstream grads (each may be null) -> per-row scales used by the backward kernels
@@ -450,7 +454,20 @@ extern "C" int lv_loss_assemble_f32(const float* nll, const float* kl, const flo
     if (!nll || !kl || !kl_weight_dev || !g_loss || !loss || !rec || !rowscale || !dkl || !acc) return LV_ERR_ARG;
     if (T < 0 || B <= 0) return LV_ERR_SHAPE;
     LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(64 * LA_WAVES), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale,
-              dkl, acc, T, B);
+              dkl, acc, T, B, (unsigned long long*)nullptr, 0ULL);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// The same, and rng_state[1] += rng_inc (the {seed, offset} state of lv_rng_*): the fused step draws its noise with
+// lv_rng_noise_step(..., inc = 0) and advances the offset here -- one launch less per step.
+extern "C" int lv_loss_assemble_rng_f32(const float* nll, const float* kl, const float* kl_weight_dev, const float* g_loss,
+                                        float* loss, float* rec, float* rowscale, float* dkl, float* acc, int T, int B,
+                                        uint64_t* rng_state, uint64_t rng_inc, void* stream) {
+    if (!nll || !kl || !kl_weight_dev || !g_loss || !loss || !rec || !rowscale || !dkl || !acc || !rng_state) return LV_ERR_ARG;
+    if (T < 0 || B <= 0) return LV_ERR_SHAPE;
+    LV_LAUNCH(loss_assemble_kernel, dim3(1), dim3(64 * LA_WAVES), 0, stream, nll, kl, kl_weight_dev, g_loss, loss, rec, rowscale,
+              dkl, acc, T, B, reinterpret_cast<unsigned long long*>(rng_state), (unsigned long long)rng_inc);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

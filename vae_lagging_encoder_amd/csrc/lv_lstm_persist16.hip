@@ -62,9 +62,14 @@ template <int V> struct lv_const { static constexpr int value = V; };
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // forward:  Wk16[wave_id (128) = 4m + w][ks (8)][nb (8)][lane (64)] uint4.  Lane (c = l & 15, kq = l >> 4) holds, for gate column
 //           16 nb + c of workgroup m (unit 32m + ((16 nb + c) >> 2), gate c & 3), the 8 weights of k = 256w + 32ks + 8kq + e.
-__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 128L * 8 * 8 * 64) return;
+__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk);
+// BPTT:     Wrs16[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)] uint4.  Lane (c, kq) holds, for output unit
+//           j = 256w + 16 nb + c, the 8 weights W_hh[gate * H + unit][j] of the workgroup's local gate rows n'' = 32ks + 8kq + e
+//           (unit = 32m + (n'' >> 2), gate = n'' & 3).
+__global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk);
+
+// both images in one launch (the encoder's W_hh changes every inner step: blocks [0, n) pack the forward image, [n, 2n) the BPTT one)
+__device__ __forceinline__ void pack_w_k16_one(const float* __restrict__ whh, uint4* __restrict__ wpk, long idx) {
     const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 7), ks = (int)((idx >> 9) & 7);
     const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
     const int c = l & 15, kq = l >> 4, col = 16 * nb + c;
@@ -72,12 +77,7 @@ __global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict
     wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
                           lv_pack_bf16x2(row[6], row[7]));
 }
-// BPTT:     Wrs16[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)] uint4.  Lane (c, kq) holds, for output unit
-//           j = 256w + 16 nb + c, the 8 weights W_hh[gate * H + unit][j] of the workgroup's local gate rows n'' = 32ks + 8kq + e
-//           (unit = 32m + (n'' >> 2), gate = n'' & 3).
-__global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 128L * 4 * 16 * 64) return;
+__device__ __forceinline__ void pack_w_rs16_one(const float* __restrict__ whh, uint4* __restrict__ wpk, long idx) {
     const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 15), ks = (int)((idx >> 10) & 3);
     const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
     const int c = l & 15, kq = l >> 4, j = 256 * w + 16 * nb + c;
@@ -88,6 +88,21 @@ __global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restric
         v[e] = whh[((long)(n2 & 3) * PH + 32 * m + (n2 >> 2)) * PH + j];
     }
     wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
+}
+__global__ __launch_bounds__(256) void pack_w_both16_kernel(const float* __restrict__ whh, uint4* __restrict__ wfwd, uint4* __restrict__ wbwd) {
+    const long n = 128L * 64 * 64;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) pack_w_k16_one(whh, wfwd, idx);
+    else if (idx < 2 * n) pack_w_rs16_one(whh, wbwd, idx - n);
+}
+
+__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < 128L * 8 * 8 * 64) pack_w_k16_one(whh, wpk, idx);
+}
+__global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < 128L * 4 * 16 * 64) pack_w_rs16_one(whh, wpk, idx);
 }
 
 struct Fwd16P {
@@ -655,6 +670,17 @@ extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward
     const dim3 grid((unsigned)lv_cdiv(128L * 64 * 64, 256)), block(256);
     if (backward) LV_LAUNCH(pack_w_rs16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
     else LV_LAUNCH(pack_w_k16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// Both register images in one launch (forward -> wpk_fwd, BPTT -> wpk_bwd; each lv_lstm_persist16_wpk_floats() floats).
+extern "C" int lv_lstm_persist16_pack2(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream) {
+    if (!whh || !wpk_fwd || !wpk_bwd) return LV_ERR_ARG;
+    if (H != PH) return LV_ERR_UNSUPPORTED;
+    if (((((uintptr_t)wpk_fwd) | ((uintptr_t)wpk_bwd)) & 15) != 0) return LV_ERR_ALIGN;
+    LV_LAUNCH(pack_w_both16_kernel, dim3((unsigned)lv_cdiv(2 * 128L * 64 * 64, 256)), dim3(256), 0, stream, whh,
+              reinterpret_cast<uint4*>(wpk_fwd), reinterpret_cast<uint4*>(wpk_bwd));
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

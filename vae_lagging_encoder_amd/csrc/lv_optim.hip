@@ -166,9 +166,15 @@ __global__ void txn_guard_kernel(const int* status1, const int* status2, float* 
 // g <- g*coef (optional write-back); p <- p - lr * g
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, long n,
                                                   const float* __restrict__ lr, const float* __restrict__ coef,
-                                                  int write_back, const float* __restrict__ void_flag) {
+                                                  int write_back, const float* __restrict__ void_flag,
+                                                  float* __restrict__ x2, long n2) {
     if (void_flag && void_flag[0] != 0.f) return;      // the step was voided by the transaction gate: nothing is applied
     const float c = coef ? coef[0] : 1.f;
+    if (x2 && c != 1.0f) {
+        // clip_grad_norm_ scales EVERY gradient, the buffer that is not stepped too: in this launch instead of one of its own
+        const long stride2 = (long)gridDim.x * 256;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride2) x2[i] *= c;
+    }
     const float a = lr[0];
     const bool wb = write_back && c != 1.0f;      // g * 1 is g: the clipped-gradient write-back is skipped when the clip is inactive
     const long stride = (long)gridDim.x * 256;
@@ -346,7 +352,7 @@ extern "C" int lv_sgd_step_f32(float* p, float* g, long n, const float* lr_dev, 
                                int write_back_clipped, void* stream) {
     if (!p || !g || !lr_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
-    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, (const float*)nullptr);
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, (const float*)nullptr, (float*)nullptr, 0L);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -356,7 +362,7 @@ extern "C" int lv_sgd_step_txn_f32(float* p, float* g, long n, const float* lr_d
                                    int write_back_clipped, const float* void_flag_dev, void* stream) {
     if (!p || !g || !lr_dev || !void_flag_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
-    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, void_flag_dev);
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped, void_flag_dev, (float*)nullptr, 0L);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -390,6 +396,17 @@ extern "C" int lv_scale_f32(float* x, long n, const float* coef_dev, void* strea
     if (!x || !coef_dev || n < 0) return LV_ERR_ARG;
     if (n == 0) return LV_OK;
     LV_LAUNCH(scale_kernel, dim3(lv_stream_grid(n)), dim3(256), 0, stream, x, n, coef_dev, (const float*)nullptr);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// lv_sgd_step_txn_f32 on (p, g) + lv_scale_txn_f32 on a second gradient buffer x2 (the one that is not stepped) in one launch
+extern "C" int lv_sgd_step_scale_txn_f32(float* p, float* g, long n, const float* lr_dev, const float* coef_dev,
+                                         int write_back_clipped, float* x2, long n2, const float* void_flag_dev, void* stream) {
+    if (!p || !g || !lr_dev || !coef_dev || !void_flag_dev || !x2 || n < 0 || n2 < 0) return LV_ERR_ARG;
+    if (n == 0 && n2 == 0) return LV_OK;
+    LV_LAUNCH(sgd_kernel, dim3(lv_stream_grid(n > n2 ? n : n2)), dim3(256), 0, stream, p, g, n, lr_dev, coef_dev, write_back_clipped,
+              void_flag_dev, x2, n2);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

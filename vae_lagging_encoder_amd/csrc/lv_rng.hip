@@ -189,7 +189,7 @@ extern "C" int lv_rng_noise_step(float* eps, long n_eps, uint8_t* mask_in, long 
              (unsigned)lv_cdiv((n_eps + 3) / 4, 256), (unsigned)lv_cdiv((n_in + 7) / 8, 256)};
     const unsigned nb = p.nb0 + p.nb1 + (unsigned)lv_cdiv((n_out + 7) / 8, 256);
     if (nb > 0) LV_LAUNCH(rng_noise_step_kernel, dim3(nb), dim3(256), 0, stream, p);
-    LV_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, stream, state, inc);
+    if (inc != 0) LV_LAUNCH(rng_advance_kernel, dim3(1), dim3(64), 0, stream, state, inc);      // inc = 0: the caller advances (lv_loss_assemble_rng_f32)
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -468,8 +468,7 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
             n = lib.lv_lstm_persist16_wpk_floats()
             wi.fwd16, wi.bwd16 = c.f32(n), c.f32(n)
             wi.xch = c.f32(lib.lv_lstm_persist16_xch_floats())
-        lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), 0, H, s)
-        lib.lv_lstm_persist16_pack(P(v["lstm.weight_hh_l0"]), P(wi.bwd16), 1, H, s)
+        lib.lv_lstm_persist16_pack2(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), P(wi.bwd16), H, s)
         wi.packed16 = True
     return wi
 
@@ -1119,14 +1118,21 @@ class LSTMDecoderEngine(object):
             else:
                 _wgrad(lib, stream_ptr(dev), V, H, Td * B, P(w.logits), w.ldl, P(w.O), H, P(gv["pred_linear.weight"]), H,
                        self.precision, ws=sws)
-        if b16 is not None:
-            _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(self._wimg.predT), b16.ldv, P(w.dO), H)
-        else:
-            _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
         img = self._lstm_images(B, Td)
         late_mask = _persistent_ok(self, img, B, H, dev, _PERSIST_BWD_MAX_B)
-        if late_mask and mask_out is not None:
-            lib.lv_keep_scale_f32(P(w.dO), P(mask_out), sc_out, Td, B, H, s)      # dropout_out backward, once, loads along H
+        if b16 is not None and late_mask and mask_out is not None:
+            # dO = dlogits . W_pred with the dropout_out backward applied where the product's K pieces are summed (no pass of its own)
+            gws = _gemm_ws(lib, s)
+            with _prof("gemm_bf16", 2.0 * Td * B * H * V):
+                lib.lv_gemm_b16_keep(Td * B, H, V, P(b16.dl), b16.ldv, P(self._wimg.predT), b16.ldv, P(w.dO), P(mask_out), sc_out, B,
+                                     P(gws), gws.numel(), s)
+        else:
+            if b16 is not None:
+                _gemm16(lib, s, 0, Td * B, H, V, P(b16.dl), b16.ldv, P(self._wimg.predT), b16.ldv, P(w.dO), H)
+            else:
+                _gemm(lib, s, 0, 0, Td * B, H, V, P(w.logits), w.ldl, P(v["pred_linear.weight"]), H, P(w.dO), H, prec=self.precision)
+            if late_mask and mask_out is not None:
+                lib.lv_keep_scale_f32(P(w.dO), P(mask_out), sc_out, Td, B, H, s)      # dropout_out backward, once, loads along H
         with _prof("lstm_bwd_dec", float(Td), 1 if late_mask else 2 * Td):
             _lstm_backward(self, lib, s, img, w, P(w.dO), None, None if late_mask else P(mask_out), 1.0 if late_mask else sc_out,
                            P(v["lstm.weight_hh_l0"]), None, P(w.dc0), 1, Td, B, H, dev)

@@ -221,9 +221,10 @@ class AggressiveTextTrainer(object):
         use_out = train and dec.dropout_out.p > 0
         if draw:
             # throughput mode: eps and both dropout keep-masks from the on-device Philox stream, one launch
+            # (offset advanced by the loss assembly's launch below: inc = 0 here)
             lib.lv_rng_noise_step(P(st.eps), st.eps.numel(), P(st.m_in) if use_in else None, st.m_in.numel(),
                                   1.0 - dec.dropout_in.p, P(st.m_out) if use_out else None, st.m_out.numel(),
-                                  1.0 - dec.dropout_out.p, P(self.rng_state), 1, s)
+                                  1.0 - dec.dropout_out.p, P(self.rng_state), 0, s)
         m_in = st.m_in if use_in else None
         m_out = st.m_out if use_out else None
         # encoder: ... LSTM, then head + reparameterise + KL in one launch
@@ -231,8 +232,13 @@ class AggressiveTextTrainer(object):
         self.dec.forward(st.xin, st.z, m_in, m_out, dec.dropout_in.p, dec.dropout_out.p, want_rec=False, x_key=st.x_key)
         w = self.dec._ws(B, T - 1)
         # rec, loss, the running report sums and the seeds of mean_b(loss_b).backward(), one launch
-        lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
-                                 self._s(10), T - 1, B, s)      # pending sums: committed by the transaction gate
+        # (report sums into the pending slots: committed by the transaction gate; the Philox offset moves on here when drawn)
+        if draw:
+            lib.lv_loss_assemble_rng_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
+                                         self._s(10), T - 1, B, P(self.rng_state), 1, s)
+        else:
+            lib.lv_loss_assemble_f32(P(w.nll), P(st.kl), self._s(0), P(st.gl), P(st.loss), P(st.rec), P(st.rowscale), P(st.dkl),
+                                     self._s(10), T - 1, B, s)
         dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
         hook = bucket = None
         if self.grad_sync is not None and not self._capturing and self.grad_sync.world > 1:
@@ -284,14 +290,12 @@ class AggressiveTextTrainer(object):
             lib.lv_sum_accum_f32(P(dec_ss), 1, self._s(2), s)
             lib.lv_clip_coef_txn_f32(self._s(2), self.clip, self._s(3), self._s(4), *gate, s)
         # clip_grad_norm_ scales every grad in place; the update only touches the stepped side; both are no-ops under the void flag
-        if update in ("encoder", "both"):
+        if update == "both":
             lib.lv_sgd_step_txn_f32(P(ef.data), P(ef.grad), ef.numel, self._s(1), self._s(3), 1, self._s(8), s)
-        else:
-            lib.lv_scale_txn_f32(P(ef.grad), ef.numel, self._s(3), self._s(8), s)
-        if update in ("decoder", "both"):
             lib.lv_sgd_step_txn_f32(P(df.data), P(df.grad), df.numel, self._s(1), self._s(3), 1, self._s(8), s)
         else:
-            lib.lv_scale_txn_f32(P(df.grad), df.numel, self._s(3), self._s(8), s)
+            a, b = (ef, df) if update == "encoder" else (df, ef)      # a is stepped, b's gradient is only scaled: one launch
+            lib.lv_sgd_step_scale_txn_f32(P(a.data), P(a.grad), a.numel, self._s(1), self._s(3), 1, P(b.grad), b.numel, self._s(8), s)
 
     def _run(self, st, update, draw):
         self._update = update
