@@ -189,6 +189,12 @@ int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale, cons
  * by the same launch -- the embedding gradient of nn.Embedding (enc_lstm.py:33, dec_lstm.py:34) without a fill of the table */
 int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
                               const int* sorted_tok, int T, int B, float* dE, int ni, int V, int pad_idx, void* stream);
+/* Data parallel, row-list exchange of the embedding gradient (new design; the reference has no distributed code): the
+ * dense MEAN gradient dE [V][ni] rebuilt from every rank's (sorted token ids, gradient rows) list -- ids_all int64 [world][cap]
+ * (ascending, -1 padded), rows_all [world][cap][ni] f32 (b16 = 0) or bf16 (b16 = 1) --, rows added in rank order (deterministic),
+ * times scale (1 / world); rows no rank touched are written as zeros. */
+int lv_rows_merge_f32(const int64_t* ids_all, const void* rows_all, int b16, int world, int cap, int ni, int V, float scale,
+                      float* dE, void* stream);
 
 /* ---- reparameterise + analytic KL: GaussianEncoderBase.encode / reparameterize (modules/encoders/encoder.py:40-79)
  * mulv [B][2nz] = mu | logvar; eps [B][ns][nz] is an input (host RNG in parity mode, lv_rng_* otherwise). */

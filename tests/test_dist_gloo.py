@@ -50,6 +50,10 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
         x = torch.from_numpy(fx["x"])[sl].contiguous().to(device)
         noise = (torch.from_numpy(fx["eps"])[sl].contiguous().to(device), torch.from_numpy(fx["mask_in"])[sl].contiguous().to(device),
                  torch.from_numpy(fx["mask_out"])[sl].contiguous().to(device))
+        if name_suffix.startswith("rows"):
+            # the embedding gradient as a row list (all-gather of the touched rows) instead of inside the dense all-reduce
+            assert tr.enable_row_exchange([x], mode="rows")
+            tr.BUCKET_MIN_ELEMS = 1
         if name_suffix.startswith("fault") and rank == 1:
             # what a timed-out persistent launch leaves behind, on ONE rank: the guard element of the encoder exchange must void
             # the step on BOTH ranks, and both must replay it one rung down the ladder (else the replicas diverge)
@@ -78,7 +82,8 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
 @pytest.mark.parametrize("name,decoder", [("text_small_wide", d) for d in ("norm", "allreduce", "norm/hook", "allreduce/hook", "norm/bf16",
                                                                             "allreduce/bf16", "norm/bucket", "norm/fault", "allreduce/fault", "norm/fault16")]
                          + [("text_mid", "norm/bucket16"), ("text_mid", "allreduce/bucket"), ("text_mid", "norm/micro"),
-                            ("text_mid", "allreduce/micro"), ("text_mid", "norm/micro16"), ("text_small_wide", "norm/micro")])
+                            ("text_mid", "allreduce/micro"), ("text_mid", "norm/micro16"), ("text_small_wide", "norm/micro"),
+                            ("text_mid", "norm/rows"), ("text_mid", "allreduce/rows16"), ("text_small_wide", "norm/rows")])
 def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, device="cpu"):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     if device == "cpu":

@@ -235,3 +235,8 @@ def test_batchnorm_eval(emu_backend, cfg):
 @pytest.mark.parametrize("cfg", [(5, 4, 70, 100, False), (4, 8, 64, 1100, False), (3, 7, 300, 64, False)])
 def test_gemm_b16_keep(emu_backend, cfg):
     K.test_gemm_b16_keep(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(2, 53, 8, (5, 9), 0), (3, 200, 64, (40, 1, 17), 1), (2, 37, 12, (37, 37), 1)])
+def test_rows_merge(emu_backend, cfg):
+    K.test_rows_merge(emu_backend, CPU, *cfg)

@@ -222,6 +222,36 @@ def test_gemm_b16_keep(lib, hip_device, T, B, N, K, big):
     assert float((C1.cpu().double().view(T, B, N) - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 16
 
 
+@pytest.mark.parametrize("world,V,ni,counts,b16", [(2, 53, 8, (5, 9), 0), (3, 200, 64, (40, 1, 17), 1), (8, 1000, 512, (120,) * 8, 0),
+                                                    (2, 37, 12, (37, 37), 1)])
+def test_rows_merge(lib, hip_device, world, V, ni, counts, b16):
+    """lv_rows_merge_f32: the dense mean embedding gradient rebuilt from every rank's (sorted ids, rows) list -- overlapping and
+    disjoint token sets, an absent rank list entry (-1 padding), every row of the table written (zeros where nobody has it), rows
+    added in rank order."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(V + world)
+    cap = (max(counts) + 7) // 8 * 8
+    ids = torch.full((world, cap), -1, dtype=torch.int64)
+    rows = torch.zeros(world, cap, ni)
+    ref = torch.zeros(V, ni, dtype=torch.float64)
+    for r, n in enumerate(counts):
+        pick = torch.randperm(V, generator=g)[:n].sort().values
+        ids[r, :n] = pick
+        vals = torch.randn(n, ni, generator=g)
+        if b16:
+            vals = vals.to(torch.bfloat16).float()
+        rows[r, :n] = vals
+        rows[r, n:] = float("nan")                        # padding slots must never be read into the result
+    acc = torch.zeros(V, ni)
+    for r, n in enumerate(counts):                         # rank order, f32: the kernel's summation order
+        acc[ids[r, :n]] += rows[r, :n]
+    acc = acc * (1.0 / world)
+    wire = rows.to(torch.bfloat16).view(torch.int16) if b16 else rows
+    dE = torch.full((V, ni), float("nan"), device=dev)
+    lib.lv_rows_merge_f32(P(ids.to(dev)), P(wire.to(dev)), b16, world, cap, ni, V, 1.0 / world, P(dE), _s(dev))
+    assert torch.equal(dE.cpu(), acc)
+
+
 def test_gemm_b16_alignment_errors(lib, hip_device):
     z = torch.zeros(64, 64, dtype=torch.int16, device=hip_device)
     c = torch.zeros(8, 8, device=hip_device)

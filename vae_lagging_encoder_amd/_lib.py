@@ -72,6 +72,7 @@ SIGNATURES = {
     "lv_token_sort": [_vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp],
     "lv_embed_scatter_f32": [_vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "lv_embed_scatter_full_f32": [_vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "lv_rows_merge_f32": [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "lv_reparam_kl_fwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_reparam_kl_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_softmax_nll_fwd_f32": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _i, _vp],

@@ -392,7 +392,65 @@ __global__ __launch_bounds__(128 * SC_GROUPS) void embed_scatter_long_kernel(con
     *d4 = acc;
 }
 
+// Row-list exchange of an embedding gradient under data parallelism (of the V rows of the table's gradient at most
+// B * T are non-zero on a rank): every rank contributes the sorted list of token ids that occur in its batch (ids_all[r][0 .. cap),
+// ascending, padded with -1) and the gradient rows of those tokens (rows_all[r][i][:], f32 or bf16); the dense MEAN gradient is
+// rebuilt by ONE workgroup per table row v: a binary search of v in every rank's list, the rows found are added in RANK ORDER
+// (deterministic, the same bits on every rank), scaled, and written -- rows nobody touched are written as zeros, so dE is complete.
+template <bool B16>
+__global__ __launch_bounds__(128) void rows_merge_kernel(const int64_t* __restrict__ ids_all, const void* __restrict__ rows_all, int world,
+                                                        int cap, int ni, int V, float scale, float* __restrict__ dE) {
+    const int v = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    __shared__ int pos[64];
+    if (tid < world) {
+        const int64_t* ids = ids_all + (long)tid * cap;
+        int lo = 0, hi = cap;                                   // first index with ids[i] >= v among the valid (non-negative) prefix
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const int64_t x = ids[mid];
+            if (x >= 0 && x < v) lo = mid + 1; else hi = mid;
+        }
+        pos[tid] = (lo < cap && ids[lo] == v) ? lo : -1;
+    }
+    __syncthreads();
+    for (int c = tid * 4; c < ni; c += 512) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = 0; r < world; ++r) {
+            const int q = pos[r];
+            if (q < 0) continue;
+            const long off = ((long)r * cap + q) * ni + c;
+            if (B16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(rows_all) + off);
+                const uint32_t w4[4] = {u.x << 16, u.x & 0xFFFF0000u, u.y << 16, u.y & 0xFFFF0000u};      // bf16 = the high half of an f32
+                float f4[4];
+                memcpy(f4, w4, 16);
+                a0 += f4[0]; a1 += f4[1]; a2 += f4[2]; a3 += f4[3];
+            } else {
+                const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rows_all) + off);
+                a0 += f.x; a1 += f.y; a2 += f.z; a3 += f.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dE + (long)v * ni + c) = make_float4(a0 * scale, a1 * scale, a2 * scale, a3 * scale);
+    }
+}
+
 }  // namespace
+
+// dE [V][ni] = scale * sum over ranks r (in rank order) of the row of token v in rank r's list, zero where no rank has it.
+// ids_all int64 [world][cap] (each list ascending, -1 padded), rows_all [world][cap][ni] f32 (b16 = 0) or bf16 (b16 = 1);
+// ni % 4 == 0, world <= 64, 16-byte aligned buffers.  The data-parallel replacement for a dense all-reduce of the embedding
+// gradient (reference: the gradient of nn.Embedding, enc_lstm.py:18, averaged over ranks as loss.mean() implies, text.py:382).
+extern "C" int lv_rows_merge_f32(const int64_t* ids_all, const void* rows_all, int b16, int world, int cap, int ni, int V, float scale,
+                                 float* dE, void* stream) {
+    if (!ids_all || !rows_all || !dE) return LV_ERR_ARG;
+    if (world <= 0 || world > 64 || cap <= 0 || ni <= 0 || ni % 4 != 0 || V <= 0) return LV_ERR_SHAPE;
+    if ((((uintptr_t)rows_all) | ((uintptr_t)dE)) & 15) return LV_ERR_ALIGN;
+    if (b16) LV_LAUNCH(rows_merge_kernel<true>, dim3((unsigned)V), dim3(128), 0, stream, ids_all, rows_all, world, cap, ni, V, scale, dE);
+    else LV_LAUNCH(rows_merge_kernel<false>, dim3((unsigned)V), dim3(128), 0, stream, ids_all, rows_all, world, cap, ni, V, scale, dE);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
 
 // X[t*B + b][:] = emb[ids[b*ids_stride + t]][:] * (mask ? mask[b][t][:] * scale : 1)
 extern "C" int lv_embed_gather_f32(const float* emb, const int64_t* ids, long ids_stride,

@@ -81,6 +81,8 @@ class GradSync(object):
         self._slot = 0
         self._ss = None           # device scalar: sum of squares of the mean decoder gradient (decoder="norm")
         self._shard_sum = None
+        # row-list exchange of the encoder's embedding gradient (prepare_rows): per-batch sorted token ids of EVERY rank, padded
+        self.rows = None          # dict(cap, ni, V, n_emb, ids_all [n_batches][world][cap] int64, mine [n_batches][1][cap] int64)
 
     class _Slot(object):
         def __init__(self):
@@ -200,6 +202,13 @@ class GradSync(object):
     def _all_reduce_mean_finish(self, flat, started):
         h, t16, lo, hi = started
         h.wait()
+        if isinstance(t16, tuple):            # the row-list bucket: rebuild the dense mean of the embedding gradient
+            _, j, recv = t16
+            R = self.rows
+            lib = _eng.backend_for(flat.device)
+            lib.lv_rows_merge_f32(P(R["ids_all"][j]), P(recv), 1 if self.payload == "bf16" else 0, self.world, R["cap"], R["ni"], R["V"],
+                                  1.0 / self.world, P(flat.grad), _eng.stream_ptr(flat.device))
+            return
         if t16 is not None:
             self._unwire(flat, t16, 1.0 / self.world, lo, hi)
         else:
@@ -218,6 +227,66 @@ class GradSync(object):
             assert lo % 1024 == 0 and (hi % 1024 == 0 or hi == pad), (lo, hi)
         assert all(hi <= b[2] or lo >= b[3] for b in self._cur.buckets), "encoder buckets must not overlap"
         self._cur.buckets.append(self._all_reduce_mean_start(enc_flat, lo, hi))
+
+    # ---- row-list exchange of the embedding gradient ---------------------------------------------------------------------
+    def prepare_rows(self, unique_ids, V, ni, n_emb, mode="auto"):
+        """unique_ids: for every batch of THIS rank's pool, in pool order, the sorted token ids that occur in it (1-D int64 device
+        tensors).  One-time exchange (all ranks call it with pools of the same length, and later step on the same pool index --
+        the aggressive loop replicates its host draws, text.py:389): the longest list of any rank fixes the capacity, every
+        rank's id lists are all-gathered and kept.  From then on start_encoder_rows(flat, j) replaces the dense all-reduce of
+        the first n_emb elements of the encoder gradient (the embedding table leads the flat buffer) by an all-gather of
+        `cap` gradient rows per rank (lv_rows_merge_f32 rebuilds the dense mean).  mode "auto": only when that is fewer bytes
+        than the ring all-reduce (cap * world < 2 V: Zipf-distributed natural text, small worlds), else dense; "rows" forces it.
+        Returns True when the row-list exchange is in use."""
+        if self.world == 1:
+            return False
+        dev = unique_ids[0].device
+        cap = torch.tensor([max(int(u.numel()) for u in unique_ids), len(unique_ids)], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            cap = cap.to(dev)
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
+        cap, nb = int(cap[0]), int(cap[1])
+        if nb != len(unique_ids):
+            raise _eng._lib.LvaeError("prepare_rows: the ranks' pools differ in length (%d here, %d elsewhere)" % (len(unique_ids), nb))
+        cap = (cap + 7) // 8 * 8
+        use = mode == "rows" or (mode == "auto" and cap * self.world < 2 * V)
+        if not use:
+            self.rows = None
+            return False
+        mine = torch.full((nb, 1, cap), -1, dtype=torch.int64, device=dev)
+        for j, u in enumerate(unique_ids):
+            mine[j, 0, :u.numel()] = u
+        ids_all = torch.empty(self.world, nb, cap, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(ids_all.view(-1), mine.view(-1), group=self.group)
+        self.rows = dict(cap=cap, ni=int(ni), V=int(V), n_emb=int(n_emb), mine=mine,
+                         ids_all=ids_all.permute(1, 0, 2).contiguous())      # [batch][rank][cap]
+        return True
+
+    def start_encoder_rows(self, enc_flat, j):
+        """Issue the row-list exchange of the embedding gradient of pool batch j (the dense gradient is complete in enc_flat.grad[0 :
+        n_emb]): gather this rank's `cap` rows into the wire buffer (f32, or bf16 under the bf16 payload), all-gather them.
+        sync_collect() rebuilds the dense mean in place."""
+        R = self.rows
+        lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
+        st = self._cur
+        cap, ni, V = R["cap"], R["ni"], R["V"]
+        bf = self.payload == "bf16"
+        key = ("rows", bf)
+        buf = st.b16.get(key)
+        if buf is None:
+            dt = torch.int16 if bf else torch.float32
+            buf = (torch.empty(cap, ni, dtype=dt, device=enc_flat.device), torch.empty(self.world, cap, ni, dtype=dt, device=enc_flat.device))
+            st.b16[key] = buf
+        send, recv = buf
+        ids = R["mine"][j]                                   # [1][cap]: batch-first ids of the gather kernels (B = 1, T = cap)
+        if bf:
+            lib.lv_embed_gather_b16(P(enc_flat.grad), P(ids), cap, None, 1.0, cap, 1, ni, V, P(send), ni, None, 0, s)
+            h = dist.all_gather_into_tensor(recv.view(torch.bfloat16).view(-1), send.view(torch.bfloat16).view(-1), group=self.group, async_op=True)
+        else:
+            lib.lv_embed_gather_f32(P(enc_flat.grad), P(ids), cap, None, 1.0, P(send), cap, 1, ni, V, s)
+            h = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group, async_op=True)
+        align = 1024 if bf else 4
+        st.buckets.append((h, ("rows", j, recv), 0, R["n_emb"] // align * align))
 
     def _norm_only(self, dec_flat, update):
         return (self.mode == "strict" and update == "encoder" and self.decoder in ("auto", "norm")
@@ -371,7 +440,8 @@ class GradSync(object):
         f = (self.world - 1) / max(1, self.world)
         b = 2 if self.payload == "bf16" else 4
         pad_e, pad_d = enc_flat.grad_padded.numel(), dec_flat.grad_padded.numel()
-        out = {"encoder_bucket_embedding": int(2 * f * b * n_emb) * micro_batches,
+        out = {"encoder_bucket_embedding": (int(2 * f * b * n_emb) if self.rows is None else int(f * self.world * b * self.rows["cap"] * self.rows["ni"])) * micro_batches,
+               "embedding_exchange": "dense all-reduce" if self.rows is None else "row list (all-gather of %d rows per rank)" % self.rows["cap"],
                "encoder_rest": int(2 * f * b * (pad_e - n_emb)) * micro_batches,
                "decoder_reduce_scatter": 0, "decoder_allreduce": 0, "scalar_allreduce": 0}
         if self.mode == "strict":
@@ -380,7 +450,7 @@ class GradSync(object):
                 out["scalar_allreduce"] = int(2 * f * 4)
             else:
                 out["decoder_allreduce"] = int(2 * f * b * pad_d) * micro_batches
-        out["total"] = sum(out.values())
+        out["total"] = sum(v for v in out.values() if not isinstance(v, str))
         return out
 
     def window_mean(self, loss_sum, num_words):

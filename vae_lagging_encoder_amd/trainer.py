@@ -49,6 +49,7 @@ class AggressiveTextTrainer(object):
         if self.micro_batches > 1 and use_graph:
             raise ValueError("micro_batches > 1 runs in eager mode (every slice writes its own gradient slot)")
         self._slice_views = {}
+        self._row_index = {}
         self.enc = vae.encoder._hip
         self.dec = vae.decoder._hip
         self.device = torch.device(device) if device is not None else next(vae.parameters()).device
@@ -173,6 +174,32 @@ class AggressiveTextTrainer(object):
                 lib.lv_token_sort(P(x), T, Tu, B, V, P(srows), P(stok), P(tmp), s)
                 eng._sorts.put(x, (Tu, B), srows, stok)
 
+    def enable_row_exchange(self, batches, mode="auto"):
+        """Data parallel: exchange the encoder's embedding gradient as a ROW LIST -- an all-gather of the gradient rows of the tokens
+        that occur in each rank's batch -- instead of inside the dense all-reduce (41 of the 66 MB encoder payload at the Yahoo
+        shape, of which at most B * T of V rows are non-zero per rank).  `batches`: this rank's whole pool, in the
+        order every rank uses (later steps must be on these tensors, and all ranks on the same pool index at a time: the
+        aggressive loop's replicated host draws).  mode "auto" switches it on only where it is fewer bytes on the wire than the
+        ring all-reduce (capacity * world < 2 V: natural, Zipf-distributed text; small worlds); "rows" forces it.  Collective:
+        every rank must call it.  Returns True when the row-list exchange is in use afterwards."""
+        gs = self.grad_sync
+        if gs is None or gs.world == 1:
+            return False
+        if self.micro_batches != 1 or self.use_graph:
+            raise ValueError("the row-list exchange runs with micro_batches = 1 in eager mode")
+        self.prepare_batches(batches)
+        V, ni = self.enc.dims()[:2]
+        uniq = []
+        self._row_index = {}
+        for j, x in enumerate(batches):
+            B, T = x.shape
+            _, stok = self.enc._sorts.get(x, (T, B))
+            uniq.append(torch.unique_consecutive(stok).to(torch.int64))      # batch preparation, once: sorted ids of the tokens that occur
+            self._row_index[id(x)] = j
+        self._row_keep = list(batches)                       # the ids in _row_index must stay valid
+        ef = self.enc.flat
+        return gs.prepare_rows(uniq, V, ni, ef.offsets[ef.names[1]], mode=mode)
+
     def invalidate_batch(self, x=None):
         """A batch tensor was rewritten behind torch's version counter (x.data.copy_, a numpy view, a DLPack / custom-kernel
         write): drop its cached sorted token lists (None: all of them).  See engine._TokenSortCache."""
@@ -245,7 +272,15 @@ class AggressiveTextTrainer(object):
             ef = self.enc.flat
             align = 1024 if self.grad_sync.payload == "bf16" else 4      # bf16 wire rows are 1024 elements wide
             n_emb = ef.offsets[ef.names[1]] // align * align             # the embedding table leads the flat buffer
-            if n_emb >= self.BUCKET_MIN_ELEMS and n_emb > 0:
+            if self.grad_sync.rows is not None:
+                # ... as a ROW LIST (enable_row_exchange): this rank's touched rows are all-gathered instead of the dense table
+                j = self._row_index.get(id(st.x_key))
+                if j is None:
+                    raise _eng._lib.LvaeError("row-list exchange is on, but this batch tensor was not among those given to "
+                                              "enable_row_exchange()")
+                def bucket():
+                    self.grad_sync.start_encoder_rows(ef, j)
+            elif n_emb >= self.BUCKET_MIN_ELEMS and n_emb > 0:
                 # first bucket of the encoder exchange: the embedding gradient (41 of 66 MB at the Yahoo shape) goes out as
                 # soon as the scatter is queued and runs under the LSTM weight-gradient GEMMs; sync() sends the rest
                 def bucket():
