@@ -283,8 +283,6 @@ def side_run_text(workload, dev, steps, warmup, dtype="bf16"):
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, precision=dtype)
     pool = [synthetic_batch(B, T, V, seed=7000 + i).to(dev) for i in range(8 if stress else 16)]
     tr.prepare_batches(pool)
-    if sync is not None and args.dp_embedding != "dense" and args.micro_batches == 1 and not args.graph:
-        tr.enable_row_exchange(pool, mode=args.dp_embedding)
     rs = np.random.RandomState(783435)
     for _ in range(warmup):
         tr.step(pool[int(rs.randint(0, len(pool)))], 0.1)
@@ -337,9 +335,10 @@ def main():
     ap.add_argument("--dp-payload", default="auto", choices=["auto", "f32", "bf16"],
                     help="wire format of the data-parallel gradient exchange (auto = bf16 for --dtype bf16, exact f32 mean for --dtype "
                          "f32; bf16 halves the bytes)")
-    ap.add_argument("--dp-embedding", default="auto", choices=["auto", "rows", "dense"],
-                    help="data parallel: the encoder's embedding gradient as a row list (all-gather of the touched rows) or inside the "
-                         "dense all-reduce; auto = rows only where that is fewer bytes (capacity * world < 2 V)")
+    ap.add_argument("--dp-embedding", default="dense", choices=["auto", "rows", "dense"],
+                    help="data parallel: the encoder's embedding gradient inside the dense all-reduce (default: the form the scaling "
+                         "runs have always used) or as a row list (all-gather of the touched rows); auto = rows only where that is "
+                         "fewer bytes on the wire (capacity * world < 2 V)")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="gradient accumulation: the step's batch as m row slices, slice i's gradient exchange under slice i+1's "
                          "computation (costs m times the recurrences at B=32: they are latency-bound; see DESIGN.md section 6)")
@@ -388,6 +387,8 @@ def main():
     # the token ids alone, computed once per batch as train_data_batch itself is; trainer.prepare_batches) -- the aggressive loop
     # then meets each batch many times (text.py:389)
     tr.prepare_batches(pool)
+    if sync is not None and args.dp_embedding != "dense" and args.micro_batches == 1 and not args.graph:
+        tr.enable_row_exchange(pool, mode=args.dp_embedding)
 
     def one_step():
         tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
