@@ -44,6 +44,7 @@ WORKLOADS = {
     # BASELINE.json configs[3]: Omniglot ResNet-enc + PixelCNN-dec, 28x28 binary (parity-test case; bench line on request)
     "omniglot": dict(B=50),
 }
+EVENT_EVERY = 4                   # timed region: steps between two event-bracketed ones (text workloads, eager mode)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (same table)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured copy)
@@ -393,14 +394,21 @@ def main():
     def one_step():
         tr.step(pool[int(rs.randint(0, len(pool)))], kl_weight)
 
+    prof = None
+
     def timed_region():
         if stress:
             # BASELINE.json configs[4]: fixed K inner steps, no data-dependent exit (text.py:371-400 with the break removed)
             n = tr.inner_loop(pool, pool[0], kl_weight, np_rng=rs, max_iter=10 ** 9, fixed_k=args.steps)
             assert n == args.steps
         else:
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                # the live HIP events of the dominant group on every EVENT_EVERY-th step only: an event record is ~5 us of queue
+                # idle (8 records per step around the four recurrences), and a quarter of the launches estimates their average
+                if prof is not None:
+                    engine.PROFILE = prof if i % EVENT_EVERY == 0 else None
                 one_step()
+            engine.PROFILE = prof
 
     def warm_up():
         for _ in range(args.warmup):
@@ -419,7 +427,6 @@ def main():
         tr.commit()
     if world > 1:
         torch.distributed.barrier()
-    prof = None
     if not args.graph:
         # the dominant kernel group (the four LSTM recurrences) is bracketed live inside the timed region; the GEMM group's events
         # (22 records per step, ~5 us of queue idle each) are taken in a separate untimed pass right after it
@@ -440,7 +447,7 @@ def main():
     engine.PROFILE_PREFIX = None
     prof_gemm, gemm_steps = None, 0
     if prof is not None:
-        prof_gemm, gemm_steps = {}, (5 if not stress else 3)
+        prof_gemm, gemm_steps = {}, min(args.steps, 5 if not stress else 3)
         engine.PROFILE, engine.PROFILE_PREFIX = prof_gemm, "gemm_"
         for _ in range(gemm_steps):
             one_step()
@@ -520,8 +527,12 @@ def main():
         "chain_floor_ms": round((4 * T - 2) * 1.45e-3, 3),
         "note": "neither roofline binds at B=32: the floor is the serial chain of 4T-2 dependent LSTM timesteps"}
     if prof:
-        lstm_roof, gemm_roof, gemm_ms, lstm_ms, pmc_gb = text_rooflines_split(prof, args.steps, prof_gemm, gemm_steps, args.workload, args.dtype,
+        ev_steps = args.steps if stress else len(range(0, args.steps, EVENT_EVERY))      # steps of the timed region that carried events
+        lstm_roof, gemm_roof, gemm_ms, lstm_ms, pmc_gb = text_rooflines_split(prof, ev_steps, prof_gemm, gemm_steps, args.workload, args.dtype,
                                                                              B, T, H, peak_mfma)
+        lstm_ms *= args.steps / ev_steps                     # per-step arithmetic below: scaled to the whole timed region
+        gemm_ms *= args.steps / ev_steps
+        lstm_roof["measured"] += ", on %d of its %d steps" % (ev_steps, args.steps)
         if pmc_gb is not None:
             out["whole_step"]["hbm_GB_per_step_pmc"] = pmc_gb
         if gemm_ms >= lstm_ms:

@@ -21,6 +21,8 @@ python bench.py --workload omniglot --dtype bf16 --graph 1 --steps 30 --warmup 5
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py $O/prof_${TAG}/${TAG}_results.db > $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt
+# one step of the TIMED region in dispatch order (the last 5 steps of the process are the bench's untimed GEMM-event pass)
+python $R/profiles/timeline_rocpd.py $O/prof_${TAG}/${TAG}_results.db 8 > $O/${TAG}_bench_yahoo_bf16_timeline.txt
 rocprofv3 --kernel-trace -d $O/prof_omni_${TAG} -o ${TAG}o -- python $R/bench.py --workload omniglot --dtype f32 --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python $R/profiles/summarize_rocpd.py $O/prof_omni_${TAG}/${TAG}o_results.db > $O/${TAG}_omniglot_kernel_stats.txt
 for W in yahoo yelp; do
@@ -31,12 +33,15 @@ for W in yahoo yelp; do
   python $R/profiles/summarize_pmc.py $O/pmc_FETCH_SIZE_${W}_${TAG}/p_counter_collection.csv $O/pmc_WRITE_SIZE_${W}_${TAG}/p_counter_collection.csv \
       > $O/${TAG}_pmc_hbm_traffic_${W}_bf16.txt
   python $R/profiles/summarize_pmc.py $O/pmc_FETCH_SIZE_${W}_${TAG}/p_counter_collection.csv $O/pmc_WRITE_SIZE_${W}_${TAG}/p_counter_collection.csv \
-      --json 3 > $O/${TAG}_pmc_groups_${W}.json
+      --json 5 > $O/${TAG}_pmc_groups_${W}.json
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq_${TAG} -o p -- \
   python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-runs > /dev/null 2>&1
 python $R/profiles/summarize_sq.py $O/pmc_sq_${TAG}/p_counter_collection.csv > $O/${TAG}_pmc_sq_mfma_busy_yahoo_bf16.txt 2>&1
 cd $R
+timeout 200 python profiles/microbench/lstm_persist16_probe.py > $O/${TAG}_persist16_probe.txt 2>&1
+timeout 100 python profiles/microbench/lstm_fixed_cost_probe.py > $O/${TAG}_lstm_fixed_cost.txt 2>&1
+rm -rf $O/prof_${TAG} $O/prof_omni_${TAG} $O/pmc_*_${TAG}
 cut -c1-400 $O/${TAG}_bench_default.json
 cut -c1-200 $O/${TAG}_bench_hipgraph.json $O/${TAG}_bench_yelp.json $O/${TAG}_bench_stress.json $O/${TAG}_bench_yahoo_f32.json
 cut -c1-200 $O/${TAG}_bench_omniglot_f32.json $O/${TAG}_bench_omniglot_f32_hipgraph.json $O/${TAG}_bench_omniglot_bf16_hipgraph.json
