@@ -237,10 +237,10 @@ def text_rooflines(prof, steps, workload, dtype, B, T, H, peak_mfma):
         "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
         "algorithmic_bytes_per_launch": round(lstm_bytes / max(1, lstm_launches)),
         "per_recurrence": per_kind,
-        "note": "latency-bound chain of dependent timesteps (persistent launches, per timestep at 4 rows per XCD group: one L2 round "
-                "trip for the hand-off ~0.7 us + fragments and 64 MFMAs ~0.75 us + cell update / sends 0.5-1.3 us, "
-                "profiles/r03o_lstm_phase_trace.txt): us_per_timestep is the actionable number, the HBM fraction is what a perfectly "
-                "overlapped version would be bound by"}
+        "note": "latency-bound chain of dependent timesteps: a persistent launch costs 15 us (forward) / 20 us (BPTT) fixed + 1.89 / "
+                "1.80 us per timestep at 4 rows per XCD group (profiles/microbench/lstm_fixed_cost_probe.py; per timestep one L2 round "
+                "trip for the hand-off, 64 MFMAs with their fragments, the cell update and the publishing stores): us_per_timestep is the "
+                "actionable number, the HBM fraction is what a perfectly overlapped version would be bound by"}
     # HBM traffic per launch from the PMC passes committed under profiles/ (a profiler cannot wrap this process)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
