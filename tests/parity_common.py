@@ -888,14 +888,41 @@ class _EpsQueue(object):
         return e.to(self.device)
 
 
-def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3):
+class _MaskQueue(object):
+    """The decoder dropout keep-masks of the recorded free-running run (policy_text_free.npz), one (mask_in, mask_out) pair
+    per training-mode loss call in program order."""
+
+    def __init__(self, fx, ni, H, device):
+        import numpy as np
+        self.shapes = [(int(b), int(t)) for b, t in fx["mask_shapes"]]
+        self.bits_in, self.bits_out = np.unpackbits(fx["mask_in_bits"]), np.unpackbits(fx["mask_out_bits"])
+        self.off_in = np.concatenate([[0], np.cumsum([b * t * ni for b, t in self.shapes])])
+        self.off_out = np.concatenate([[0], np.cumsum([b * t * H for b, t in self.shapes])])
+        self.ni, self.H, self.pos, self.device = ni, H, 0, device
+
+    def pop(self, x):
+        b, t = self.shapes[self.pos]
+        assert (b, t) == (x.shape[0], x.shape[1] - 1), (self.pos, (b, t), tuple(x.shape))
+        i = self.pos
+        self.pos += 1
+        mi = torch.from_numpy(self.bits_in[self.off_in[i]:self.off_in[i + 1]].copy()).reshape(b, t, self.ni)
+        mo = torch.from_numpy(self.bits_out[self.off_out[i]:self.off_out[i + 1]].copy()).reshape(b, t, self.H)
+        return mi.to(self.device), mo.to(self.device)
+
+
+def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3, free_running=False):
     """The reference's text.main() (text.py:229-522) was run on a tiny corpus with every decision recorded
     (tests/golden/make_golden_policy.py -> policy_text.npz).  Here the SAME corpus goes through our input pipeline
     (MonoTextData -> create_data_batch on `device`), the same initial weights, the same Gaussian draws and the same host seed
     through TextTrainingLoop on the HIP path, and the run must take the same decisions: batch order, KL weight, number of
     inner encoder steps of every iteration (the windowed exit test, text.py:393-396), the batch picks inside the inner loop,
     the iteration at which aggressive training stops (MI check, text.py:447-455), which epochs update the best checkpoint, the
-    learning-rate decay (text.py:469-479); and report the same statistics within `rtol`."""
+    learning-rate decay (text.py:469-479); and report the same statistics within `rtol`.
+
+    free_running: the second recorded run (policy_text_free.npz: `--free`, 3 epochs with the reference's decoder dropout 0.5,
+    every keep-mask recorded).  The replay is fed the masks and the Gaussian draws and is NEVER re-synchronised: 39 outer
+    iterations and 1080 inner encoder steps, each on the weights the previous one left, through the aggressive phase, the MI
+    check that ends it and the joint steps after it."""
     import argparse
     import os
     import numpy as np
@@ -903,7 +930,7 @@ def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3):
     from vae_lagging_encoder_amd.factory import build_text_vae
     from vae_lagging_encoder_amd.modules.encoders.encoder import GaussianEncoderBase
     from vae_lagging_encoder_amd.training import TextTrainingLoop
-    fx = load("policy_text")
+    fx = load("policy_text_free" if free_running else "policy_text")
     paths = {}
     for k in ("train", "val", "test"):
         paths[k] = os.path.join(str(tmp_dir), k + ".txt")
@@ -920,7 +947,8 @@ def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3):
     V = len(train.vocab)
     init = {k[5:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("init/")}
     assert init["encoder.embed.weight"].shape[0] == V
-    vae = build_text_vae(V, ni, H, nz, device, seed=int(fx["seed"]), params=init, dropout_in=0.0, dropout_out=0.0, vocab=train.vocab)
+    p_drop = float(fx["dropout"]) if free_running else 0.0
+    vae = build_text_vae(V, ni, H, nz, device, seed=int(fx["seed"]), params=init, dropout_in=p_drop, dropout_out=p_drop, vocab=train.vocab)
     epochs = int(fx["epochs"]) if max_epochs is None else max_epochs
     args = argparse.Namespace(kl_start=float(fx["kl_start"]), warm_up=int(fx["warm_up"]), batch_size=bs, epochs=epochs, aggressive=1,
                               nsamples=1, test_nepoch=int(fx["test_nepoch"]), iw_nsamples=100, momentum=0)
@@ -939,10 +967,14 @@ def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3):
             drift.append(max(rel_err(sd[k], st[k]) for k in ALL_KEYS))
         vae.load_state_dict(st, strict=False)
     drift = []
+    masks = _MaskQueue(fx, ni, H, device) if free_running else None
+
+    def noise_fn(x):
+        eps = queue.pop(x.shape[0], 1, nz)
+        return (eps,) + (masks.pop(x) if free_running else (None, None))
     try:
         loop = TextTrainingLoop(vae, tb, vb, sb, args, n_train_sentences=len(train), log=logs.append, np_rng=rng,
-                                seed=int(fx["seed"]), noise_fn=lambda x: (queue.pop(x.shape[0], 1, nz), None, None),
-                                epoch_hook=resync)
+                                seed=int(fx["seed"]), noise_fn=noise_fn, epoch_hook=None if free_running else resync)
         out = loop.run()
     finally:
         GaussianEncoderBase._draw_eps = saved
@@ -987,6 +1019,8 @@ def check_policy_replay_text(device, tmp_dir, max_epochs=None, rtol=2e-3):
         assert worst < 50 * rtol, worst                 # run() ends on the best checkpoint, as text.py:506 does
     # what one epoch of the replay drifts from the reference's weights before it is re-synchronised
     assert max(drift + [0.0]) < 5e-3, drift
+    if free_running:
+        assert masks.pos == len(masks.shapes) or max_epochs is not None, (masks.pos, len(masks.shapes))
     return dict(iterations=n_it, inner_steps=int(sum(r["inner_steps"] for r in it)), eps_used=queue.pos, out=out, drift=drift)
 
 

@@ -24,3 +24,19 @@ def test_image_policy_replay(hip_device):
     minute on the CI box)."""
     r = pc.check_policy_replay_image(hip_device)
     assert r["inner_steps"] > 0
+
+
+def test_text_policy_replay_free_running_first_epoch_emulated(emu_backend, tmp_path):
+    """The first epoch of the free-running replay (decoder dropout 0.5 fed from the recorded keep-masks, no re-synchronisation)
+    on the CI emulator; all three epochs are the GPU test below."""
+    r = pc.check_policy_replay_text("cpu", tmp_path, max_epochs=1, free_running=True)
+    assert r["iterations"] == 13
+
+
+@pytest.mark.gpu
+def test_text_policy_replay_free_running(hip_device, tmp_path):
+    """Three epochs of the reference's text.main() with dec_dropout 0.5, never re-synchronised: every one of the 1080 inner encoder
+    steps runs on the weights our own previous steps left, and the windowed exits, the batch picks, the end of the aggressive
+    phase and the best-checkpoint updates still equal the recorded run's."""
+    r = pc.check_policy_replay_text(hip_device, tmp_path, free_running=True)
+    assert r["iterations"] == 39 and r["inner_steps"] == 1080
