@@ -270,7 +270,7 @@ def text_rooflines_split(prof_lstm, steps, prof_gemm, gemm_steps, workload, dtyp
     return lstm_roof, gemm_roof, gemm_ms * steps / max(1, gemm_steps), lstm_ms, pmc_gb
 
 
-def side_run_text(workload, dev, steps, warmup, dtype="bf16"):
+def side_run_text(workload, dev, steps, warmup, dtype="bf16", decoder_grads="full"):
     """A compact record of one of the other BASELINE.json text configurations, measured in the same process after the headline
     (same trainer, same kernels, its own model / pool): {value, unit, ms_per_step, dtype, workload, dominant kernel group + its
     roofline fraction}.  stress = one fixed-K inner loop of `steps` steps (BASELINE.json configs[4])."""
@@ -281,7 +281,7 @@ def side_run_text(workload, dev, steps, warmup, dtype="bf16"):
     V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
     stress = workload == "stress"
     vae = build_text_vae(V, ni, H, nz, dev, seed=783435)
-    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, precision=dtype)
+    tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, precision=dtype, decoder_grads=decoder_grads)
     pool = [synthetic_batch(B, T, V, seed=7000 + i).to(dev) for i in range(8 if stress else 16)]
     tr.prepare_batches(pool)
     rs = np.random.RandomState(783435)
@@ -311,6 +311,8 @@ def side_run_text(workload, dev, steps, warmup, dtype="bf16"):
                               "ms_per_step": dom["ms_per_step"]},
            "gemm_tflops": gemm_roof["achieved"], "lstm_us_per_timestep": lstm_roof.get("us_per_timestep"),
            "lstm_ladder_rung": max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))}
+    if decoder_grads != "full":
+        rec["decoder_grads"] = decoder_grads
     del tr, vae, pool
     torch.cuda.empty_cache()
     return rec
@@ -343,6 +345,10 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="gradient accumulation: the step's batch as m row slices, slice i's gradient exchange under slice i+1's "
                          "computation (costs m times the recurrences at B=32: they are latency-bound; see DESIGN.md section 6)")
+    ap.add_argument("--decoder-grads", default="full", choices=["full", "norm"],
+                    help="full (default): every .grad left as clip_grad_norm_ leaves it; norm: in the encoder-only inner step the "
+                         "decoder's two vocabulary-sized gradient tensors are reduced to their sums of squares in their producers and "
+                         "never written (text.py:383-387 uses them for the clip norm alone); single GPU")
     ap.add_argument("--pool", type=int, default=None)
     ap.add_argument("--tokens", default="uniform", choices=["uniform", "zipf"],
                     help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
@@ -375,7 +381,7 @@ def main():
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
     sync = lvdist.GradSync(mode=args.dp_mode, payload=args.dp_payload) if world > 1 else None
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, grad_sync=sync, use_graph=bool(args.graph),
-                               precision=args.dtype, micro_batches=args.micro_batches)
+                               precision=args.dtype, micro_batches=args.micro_batches, decoder_grads=args.decoder_grads)
     if args.overlap != "auto":
         tr.dec.overlap = (args.overlap == "on")
     tr.enc.persistent = tr.dec.persistent = bool(args.persistent)
@@ -494,6 +500,9 @@ def main():
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                    "dp_exchange": ((args.dp_mode + ("/bf16-payload" if args.dp_payload == "bf16" else "")) if world > 1 else None),
                    "hipgraph": bool(args.graph),
+                   "clip_norm": ("vocabulary-sized tensors' sums of squares emitted by their producers + one pass over the rest"
+                                 if tr._fold is not None else "one streaming pass over both flat gradients"),
+                   "decoder_grads": args.decoder_grads,
                    "lstm_ladder_rung": engine.PERSIST_RUNGS[max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))] if args.dtype == "bf16" else None,
                    "batch_preparation": ("sorted token lists of the embedding backward built once per pool batch, with the batches"
                                          if not args.graph else "none (the captured step sorts inside the graph)")},
@@ -568,6 +577,9 @@ def main():
         try:
             side["yelp"] = side_run_text("yelp", dev, steps=10, warmup=3)
             side["stress"] = side_run_text("stress", dev, steps=50, warmup=2)
+            # the headline configuration with --decoder-grads norm (the decoder's vocabulary-sized gradients reduced to their sums of
+            # squares in their producers, never written: an option, not the headline -- .grad of those two tensors is then unspecified)
+            side["yahoo_decoder_grads_norm"] = side_run_text("yahoo", dev, steps=20, warmup=3, decoder_grads="norm")
             oa = argparse.Namespace(**vars(args))
             oa.graph, oa.dtype, oa.steps, oa.warmup, oa.pool = 1, "f32", 20, 5, 16
             om = measure_omniglot(oa, dev, 0, 1, cpu_baseline=False, profile_eager=True)

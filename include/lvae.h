@@ -61,6 +61,14 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
  * its own; rows time-major (r = t * Bsz + b), keep = the reference-layout mask [Bsz][M / Bsz][N], uint8. */
 int lv_gemm_b16_keep(int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C,
                      const uint8_t* keep, float kscale, int Bsz, float* ws, long ws_floats, void* stream);
+/* C = op(A) . B^T as lv_gemm_b16 computes it (alpha 1, no addends) and, in the same pass, the product's sum of squares:
+ * sq[0 .. parts) receives one partial per wave of the kernels that hold C's final values (fixed slots: deterministic), parts =
+ * lv_gemm_b16_sumsq_parts(M, N, K, ws_floats); 0 parts = the shape does not take the 256 x 256 tile and lv_gemm_b16_sumsq refuses it
+ * (LV_ERR_ARG).  sq_only != 0: C is NOT written -- a weight gradient that only enters the norm of clip_grad_norm_ (text.py:383-387:
+ * the inner loop clips over all parameters and steps the encoder alone; dW_pred is such a gradient). */
+int lv_gemm_b16_sumsq_parts(int M, int N, int K, long ws_floats);
+int lv_gemm_b16_sumsq(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C, long ldc,
+                      float* ws, long ws_floats, float* sq, int sq_only, void* stream);
 int lv_gemm_b16_nll_parts(int N);
 /* The same two entries with the tile edge named by the caller instead of chosen by shape: tile = 0 (by shape: the 256 x 256 x 64
  * kernel, one workgroup per CU, for products of >= 1e11 flop -- the three vocabulary-sized GEMMs of dec_lstm.py:117,140-146 --
@@ -189,6 +197,12 @@ int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float scale, cons
  * by the same launch -- the embedding gradient of nn.Embedding (enc_lstm.py:33, dec_lstm.py:34) without a fill of the table */
 int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
                               const int* sorted_tok, int T, int B, float* dE, int ni, int V, int pad_idx, void* stream);
+/* lv_embed_scatter_full_f32 and, in the same pass, the sum of squares of the table gradient it completes: sq[0 .. parts) receives
+ * one partial per wave (parts = lv_embed_scatter_sumsq_parts(T, B)); sq_only != 0: dE is NOT written (see lv_gemm_b16_sumsq). */
+int lv_embed_scatter_sumsq_parts(int T, int B);
+int lv_embed_scatter_full_sumsq_f32(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows,
+                                    const int* sorted_tok, int T, int B, float* dE, int ni, int V, int pad_idx, float* sq, int sq_only,
+                                    void* stream);
 /* Data parallel, row-list exchange of the embedding gradient (new design; the reference has no distributed code): the
  * dense MEAN gradient dE [V][ni] rebuilt from every rank's (sorted token ids, gradient rows) list -- ids_all int64 [world][cap]
  * (ascending, -1 padded), rows_all [world][cap][ni] f32 (b16 = 0) or bf16 (b16 = 1) --, rows added in rank order (deterministic),
@@ -280,6 +294,11 @@ int lv_scale_f32(float* x, long n, const float* coef_dev, void* stream);
 int lv_clip_norm2_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
                           float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
                           const float* guard, float* txn, float* acc, void* stream);
+/* lv_clip_norm2_txn_f32 where part of the gradient arrives as the partial sums of squares its producers emitted (extra[0 .. n_extra):
+ * lv_gemm_b16_sumsq, lv_embed_scatter_full_sumsq_f32): g1 / g2 are then the REST of the two flat gradients. */
+int lv_clip_norm2_fold_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, const float* extra, int n_extra,
+                               float max_norm, float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1,
+                               const int* status2, const float* guard, float* txn, float* acc, void* stream);
 int lv_clip_coef_txn_f32(const float* sumsq_dev, float max_norm, float* coef_dev, float* norm_out_dev, const int* status1,
                          const int* status2, const float* guard, float* txn, float* acc, void* stream);
 int lv_txn_guard_f32(const int* status1, const int* status2, float* guard, void* stream);

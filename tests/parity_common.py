@@ -462,6 +462,51 @@ def check_micro_batches_against_fixture(name, device, m, precision="f32", tol=RT
     assert rel_err(g, fx["grad/decoder.pred_linear.weight"] * float(fx["coef"])) < 2 * tol
 
 
+def check_fold_norm(device, V, ni, H, nz, B, T, precision="f32", use_graph=False, steps=3, decoder_grads="full"):
+    """Norm folding (trainer._plan_fold): the clip norm assembled from the producers' partial sums of squares + a streaming pass over
+    the rest must be the norm of the same gradients -- against a trainer with folding off, on the same weights, batches and noise:
+    per-step norm and clip coefficient to f32 summation-order accuracy, gradients bit for bit, the encoder after `steps` updates to
+    what those coefficient differences allow.  decoder_grads = "norm": the decoder's two big tensors are never written in these
+    (encoder-only) steps; everything else must still agree.  (The fixture parity tests run with folding on: they compare the folded norm with
+    the reference's total_norm.)"""
+    from oracle import text_vae_oracle as O
+    from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
+    P = O.random_params(V, ni, H, nz, seed=91, scale=0.05 if H >= 512 else 0.3, emb_scale=0.5, head_scale=0.3)
+    xs = [O.synthetic_batch(B, T, V, seed=20 + i).to(device) for i in range(steps)]
+    out = {}
+    for fold in (False, True):
+        vae = build_vae(V, ni, H, nz, device, params=P)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision, use_graph=use_graph, fold_norm=fold,
+                                   decoder_grads=decoder_grads if fold else "full")
+        rec = []
+        for i, x in enumerate(xs):
+            e, a, b = O.draw_noise(B, T, ni, H, nz, seed=40 + i)
+            tr.reset_stats()
+            tr.step(x, 0.5, noise=(e.to(device), a.to(torch.uint8).to(device), b.to(torch.uint8).to(device)))
+            st = tr.read_stats()
+            rec.append((st["norm"], st["coef"]))
+            if i == 0:
+                grads = {k: p.grad.detach().clone() for k, p in vae.named_parameters() if p.grad is not None}
+        assert (tr._fold is not None) == fold
+        if fold and precision == "bf16" and 2.0 * V * H * (T - 1) * B >= 1e11 and torch.device(device).type == "cuda":
+            assert "pred" in tr.dec.fold, "dW_pred's squares were expected to come from the product's epilogue at this shape"
+        out[fold] = (rec, grads, {k: v.detach().clone() for k, v in vae.state_dict().items()})
+    for (n0, c0), (n1, c1) in zip(out[False][0], out[True][0]):
+        assert abs(n0 - n1) <= 2e-6 * n0 and abs(c0 - c1) <= 2e-6, ((n0, c0), (n1, c1))
+    c0, c1 = out[False][0][0][1], out[True][0][0][1]
+    for k, g in out[False][1].items():
+        g1 = out[True][1][k]
+        if decoder_grads == "norm" and k in ("decoder.embed.weight", "decoder.pred_linear.weight"):
+            continue                                          # not materialised by an encoder-only step: unspecified
+        if c0 == c1:
+            assert torch.equal(g, g1), k                      # step 0: the same gradients; clipped in place by the same coefficient
+        else:
+            assert rel_err(g1, g) < 1e-5, k
+    for k in ENC_KEYS:
+        assert rel_err(out[True][2][k], out[False][2][k]) < 1e-4, k
+    return out[True][0]
+
+
 def check_transactional_recovery(device, V=97, ni=12, H=20, nz=4, B=6, K=5, precision="f32", fault_at=(2,), rungs_down=1,
                                  use_graph=False):
     """A persistent-launch hand-off timeout must never reach the weights (text.py:385-387: an update is computed from complete

@@ -82,3 +82,12 @@ def test_voided_steps_are_replayed_down_the_ladder_emulated(emu_backend, fault_a
 @pytest.mark.parametrize("name,m", [("text_small_wide", 2), ("text_mid", 4), ("text_small_wide", 4)])
 def test_micro_batches_give_the_whole_batch_gradient_emulated(emu_backend, name, m):
     pc.check_micro_batches_against_fixture(name, "cpu", m)
+
+
+@pytest.mark.parametrize("shape", [(97, 12, 20, 4, 6, 7), (300, 512, 16, 4, 8, 40)])
+def test_norm_folding_is_the_same_norm_emulated(emu_backend, shape):
+    """trainer._plan_fold on the CI emulator: the embedding tables' sums of squares from the scatter's own pass (the second shape
+    has ni = 512 and token runs long enough for the 8-group scatter kernel)."""
+    V, ni, H, nz, B, T = shape
+    pc.check_fold_norm("cpu", V, ni, H, nz, B, T)
+    pc.check_fold_norm("cpu", V, ni, H, nz, B, T, decoder_grads="norm")

@@ -222,6 +222,40 @@ def test_gemm_b16_keep(lib, hip_device, T, B, N, K, big):
     assert float((C1.cpu().double().view(T, B, N) - ref).abs().max()) < 2e-6 * (K ** 0.5 + 1) * 16
 
 
+@pytest.mark.parametrize("tA,M,N,K", [(1, 20001, 1024, 6368), (0, 2048, 2304, 1536), (1, 4100, 1024, 3100), (0, 1024, 1024, 200)])
+def test_gemm_b16_sumsq(lib, hip_device, tA, M, N, K):
+    """lv_gemm_b16_sumsq: the product as lv_gemm_b16 writes it (bit for bit) and partial sums of squares that add up to its
+    squared Frobenius norm -- tiles that hold whole-K results, tail tiles whose K pieces meet in the reduce kernel, ragged edges
+    (rows / columns outside C contribute nothing); sq_only leaves C alone; shapes off the 256 x 256 tile are refused."""
+    if hip_device.type != "cuda":
+        pytest.skip("GPU only")
+    dev = hip_device
+    g = torch.Generator().manual_seed(M + N + K)
+    ld_a = (M + 7) // 8 * 8 if tA else (K + 7) // 8 * 8
+    ld_b = (K + 7) // 8 * 8
+    A = (torch.randn((K, ld_a) if tA else (M, ld_a), generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    Bm = (torch.randn(N, ld_b, generator=g) * 0.1).to(torch.bfloat16).view(torch.int16).to(dev)
+    ws = torch.empty(1 << 26, device=dev)
+    n = lib.lv_gemm_b16_sumsq_parts(M, N, K, ws.numel())
+    C0 = torch.empty(M, N, device=dev)
+    lib.lv_gemm_b16(tA, M, N, K, 1.0, P(A), ld_a, P(Bm), ld_b, P(C0), N, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
+    if n == 0:
+        sq = torch.zeros(8, device=dev)
+        with pytest.raises(_lib.LvaeError):
+            lib.lv_gemm_b16_sumsq(tA, M, N, K, P(A), ld_a, P(Bm), ld_b, P(C0), N, P(ws), ws.numel(), P(sq), 0, _s(dev))
+        return
+    sq = torch.full((n,), float("nan"), device=dev)
+    C1 = torch.full((M, N), float("nan"), device=dev)
+    lib.lv_gemm_b16_sumsq(tA, M, N, K, P(A), ld_a, P(Bm), ld_b, P(C1), N, P(ws), ws.numel(), P(sq), 0, _s(dev))
+    assert torch.equal(C1, C0)
+    want = float(C0.double().pow(2).sum())
+    assert abs(float(sq.double().sum()) - want) <= 1e-5 * want
+    sq2 = torch.full((n,), float("nan"), device=dev)
+    C2 = torch.full((M, N), 3.0, device=dev)
+    lib.lv_gemm_b16_sumsq(tA, M, N, K, P(A), ld_a, P(Bm), ld_b, P(C2), N, P(ws), ws.numel(), P(sq2), 1, _s(dev))
+    assert torch.equal(sq2, sq) and float((C2 - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("world,V,ni,counts,b16", [(2, 53, 8, (5, 9), 0), (3, 200, 64, (40, 1, 17), 1), (8, 1000, 512, (120,) * 8, 0),
                                                     (2, 37, 12, (37, 37), 1)])
 def test_rows_merge(lib, hip_device, world, V, ni, counts, b16):
@@ -676,6 +710,19 @@ def test_embed_gather_sort_scatter(lib, hip_device, T, B, ni, V, masked):
     dE4 = torch.full((V, ni), float("nan"), device=dev)
     lib.lv_embed_scatter_full_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE4), ni, V, -1, _s(dev))
     assert torch.equal(dE4[:V - 1], dE[:V - 1]) and float(dE4[V - 1].abs().max()) > 0.0      # no padding row: token V - 1 counts
+    # ... and with the table gradient's sum of squares emitted by the same pass (norm folding): the same table, partials that add
+    # up to its squared norm, every slot written; sq_only leaves the table alone and reports the same partials
+    n = lib.lv_embed_scatter_sumsq_parts(T, B)
+    sq = torch.full((n,), float("nan"), device=dev)
+    dE5 = torch.full((V, ni), float("nan"), device=dev)
+    lib.lv_embed_scatter_full_sumsq_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE5), ni, V, V - 1, P(sq), 0, _s(dev))
+    assert torch.equal(dE5, dE)
+    want = float(dE.double().pow(2).sum())
+    assert abs(float(sq.double().sum()) - want) <= 1e-5 * want
+    sq2 = torch.full((n,), float("nan"), device=dev)
+    dE6 = torch.full((V, ni), 7.0, device=dev)
+    lib.lv_embed_scatter_full_sumsq_f32(P(dX), P(mask) if masked else None, 2.0, P(rows), P(toks), T, B, P(dE6), ni, V, V - 1, P(sq2), 1, _s(dev))
+    assert torch.equal(sq2, sq) and float((dE6 - 7.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("B,ns,nz", [(32, 1, 32), (16, 1, 1), (5, 3, 40), (128, 2, 7)])

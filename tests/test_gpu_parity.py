@@ -598,3 +598,17 @@ def test_pixelcnn_incremental_sampling(hip_device):
 def test_pixelcnn_ancestral_sampling(hip_device):
     """SURVEY.md 8f row 4 (image half): PixelCNNDecoderV2.decode, 784 decoder passes."""
     pc.check_pixelcnn_ancestral_sampling(hip_device)
+
+
+@pytest.mark.parametrize("shape,precision,use_graph", [((20001, 512, 1024, 32, 32, 200), "bf16", False),
+                                                       ((20001, 512, 1024, 32, 32, 200), "bf16", True),
+                                                       ((8003, 512, 1024, 32, 32, 121), "bf16", False),
+                                                       ((2003, 64, 256, 16, 16, 33), "f32", False)])
+def test_norm_folding_is_the_same_norm(hip_device, shape, precision, use_graph):
+    """trainer._plan_fold: both embedding tables' squares from the scatter, dW_pred's from the 256 x 256 product's epilogue and tail
+    reduce (first three shapes; the Yahoo shape has 256 whole-K tiles + 60 tail tiles), the rest from the streaming pass -- the
+    same clip norm as with folding off, the same gradients, the same encoder after three updates."""
+    V, ni, H, nz, B, T = shape
+    pc.check_fold_norm(hip_device, V, ni, H, nz, B, T, precision=precision, use_graph=use_graph)
+    if not use_graph:
+        pc.check_fold_norm(hip_device, V, ni, H, nz, B, T, precision=precision, decoder_grads="norm")

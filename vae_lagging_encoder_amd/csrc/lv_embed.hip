@@ -291,10 +291,10 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
                                                             float scale, const int* __restrict__ rows,
                                                             const int* __restrict__ toks, int N, int B, int T,
                                                             float* __restrict__ dE, int ni, int pad_idx, int accumulate,
-                                                            int vec, int V, int long_runs_elsewhere) {
+                                                            int vec, int V, int long_runs_elsewhere, float* __restrict__ sq, int sq_only) {
     const int p = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
-    if (V > 0) {
+    if (V > 0 && !sq_only) {
         // complete form: every row of dE is written exactly once by this launch (pair) -- the rows of tokens that occur by their
         // segment heads, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
         // binary search of the sorted token list per row).  Replaces a separate fill of the whole table (41 MB at V = 20001).
@@ -308,51 +308,65 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
             else for (int k = tid; k < ni; k += 128) z[k] = 0.f;
         }
     }
+    // sq: the squares of the row this workgroup completes, one partial per wave in slots [2p, 2p + 2) (zeros from workgroups that
+    // complete none); slots [2N, 2N + 2 ceil(N / SC_LONG)) belong to embed_scatter_long_kernel and are zeroed here when it does not run
+    float ss = 0.f;
     const int tok = toks[p];
-    if (p > 0 && toks[p - 1] == tok) return;   // not a segment head
-    if (tok == pad_idx) return;
-    // end of the run [p, e): the next eight positions in one batch of loads (most tokens occur once or twice); a longer run is
-    // finished by a binary search of the sorted list
-    int e = p + 1;
-    {
-        int nx[8];
+    bool work = !(p > 0 && toks[p - 1] == tok) && tok != pad_idx;      // a segment head of a real token
+    if (work) {
+        // end of the run [p, e): the next eight positions in one batch of loads (most tokens occur once or twice); a longer run is
+        // finished by a binary search of the sorted list
+        int e = p + 1;
+        {
+            int nx[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nx[u] = toks[p + 1 + u < N ? p + 1 + u : N - 1];
-        bool run = true;
+            for (int u = 0; u < 8; ++u) nx[u] = toks[p + 1 + u < N ? p + 1 + u : N - 1];
+            bool run = true;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            run = run && p + 1 + u < N && nx[u] == tok;
-            if (run) e = p + 2 + u;
+            for (int u = 0; u < 8; ++u) {
+                run = run && p + 1 + u < N && nx[u] == tok;
+                if (run) e = p + 2 + u;
+            }
+            if (run && e < N) {                      // all eight equal: e = first position past p + 8 whose token differs
+                int lo = e, hi = N;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] == tok) lo = mid + 1; else hi = mid; }
+                e = lo;
+            }
         }
-        if (run && e < N) {                      // all eight equal: e = first position past p + 8 whose token differs
-            int lo = e, hi = N;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] == tok) lo = mid + 1; else hi = mid; }
-            e = lo;
+        float* dst = dE + (long)tok * ni;
+        if (vec) {
+            if (!(long_runs_elsewhere && (p + SC_LONG - 1) / SC_LONG * SC_LONG + SC_LONG < e)) {      // (a long run is embed_scatter_long_kernel's)
+                for (int k = tid * 4; k < ni; k += 512) {
+                    float4 acc = scatter_batches(dX, mask, scale, rows, p, e, 8, ni, k, B, T);
+                    float4* d4 = reinterpret_cast<float4*>(dst + k);
+                    if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+                    ss += (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+                    if (!sq_only) *d4 = acc;
+                }
+            }
+        } else {
+            for (int k = tid; k < ni; k += 128) {
+                float acc = 0.f;
+                for (int q = p; q < e; ++q) {
+                    const int r = rows[q];
+                    float v = dX[(long)r * ni + k];
+                    if (mask) {
+                        const int t = r / B, b = r % B;
+                        v = mask[((long)b * T + t) * ni + k] ? v * scale : 0.f;
+                    }
+                    acc += v;
+                }
+                if (accumulate) acc += dst[k];
+                ss += acc * acc;
+                if (!sq_only) dst[k] = acc;
+            }
         }
     }
-    float* dst = dE + (long)tok * ni;
-    if (vec) {
-        if (long_runs_elsewhere && (p + SC_LONG - 1) / SC_LONG * SC_LONG + SC_LONG < e) return;      // a long run: embed_scatter_long_kernel's
-        for (int k = tid * 4; k < ni; k += 512) {
-            float4 acc = scatter_batches(dX, mask, scale, rows, p, e, 8, ni, k, B, T);
-            float4* d4 = reinterpret_cast<float4*>(dst + k);
-            if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-            *d4 = acc;
-        }
-    } else {
-        for (int k = tid; k < ni; k += 128) {
-            float acc = 0.f;
-            for (int q = p; q < e; ++q) {
-                const int r = rows[q];
-                float v = dX[(long)r * ni + k];
-                if (mask) {
-                    const int t = r / B, b = r % B;
-                    v = mask[((long)b * T + t) * ni + k] ? v * scale : 0.f;
-                }
-                acc += v;
-            }
-            if (accumulate) acc += dst[k];
-            dst[k] = acc;
+    if (sq) {
+        ss = lv_wave_sum(ss);
+        if ((tid & 63) == 0) {
+            sq[2 * p + (tid >> 6)] = ss;
+            if (!long_runs_elsewhere && p < (N + SC_LONG - 1) / SC_LONG) sq[2 * N + 2 * p + (tid >> 6)] = 0.f;
         }
     }
 }
@@ -363,14 +377,23 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
 __global__ __launch_bounds__(128 * SC_GROUPS) void embed_scatter_long_kernel(const float* __restrict__ dX, const uint8_t* __restrict__ mask,
                                                                              float scale, const int* __restrict__ rows,
                                                                              const int* __restrict__ toks, int N, int B, int T,
-                                                                             float* __restrict__ dE, int pad_idx, int accumulate) {
+                                                                             float* __restrict__ dE, int pad_idx, int accumulate,
+                                                                             float* __restrict__ sq, int sq_only) {
     __shared__ __attribute__((aligned(16))) float part_sum[SC_GROUPS - 1][512];
     const int q = (int)blockIdx.x * SC_LONG;
     const int tid = (int)threadIdx.x & 127, grp = (int)threadIdx.x >> 7;
-    if (q + SC_LONG >= N) return;
-    const int tok = toks[q];
-    if (toks[q + SC_LONG] != tok || tok == pad_idx) return;
-    if (q >= SC_LONG && toks[q - SC_LONG] == tok) return;          // an earlier workgroup's
+    // (sq: slots [2N + 2 blockIdx, + 2), the two waves of group 0; a workgroup that finds no run of its own writes zeros)
+    float* sq_slot = sq && grp == 0 && (tid & 63) == 0 ? sq + 2 * N + 2 * (int)blockIdx.x + (tid >> 6) : nullptr;
+    bool mine = q + SC_LONG < N;
+    int tok = 0;
+    if (mine) {
+        tok = toks[q];
+        mine = toks[q + SC_LONG] == tok && tok != pad_idx && !(q >= SC_LONG && toks[q - SC_LONG] == tok);      // (else an earlier workgroup's)
+    }
+    if (!mine) {
+        if (sq_slot) *sq_slot = 0.f;
+        return;
+    }
     int lo = q - SC_LONG + 1 < 0 ? 0 : q - SC_LONG + 1, hi = q;     // head: first position in (q - SC_LONG, q] with this token
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < tok) lo = mid + 1; else hi = mid; }
     const int h = lo;
@@ -389,7 +412,11 @@ __global__ __launch_bounds__(128 * SC_GROUPS) void embed_scatter_long_kernel(con
     }
     float4* d4 = reinterpret_cast<float4*>(dE + (long)tok * 512 + k);
     if (accumulate) { float4 o = *d4; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-    *d4 = acc;
+    if (!sq_only) *d4 = acc;
+    if (sq) {
+        const float ss = lv_wave_sum((acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w));
+        if (sq_slot) *sq_slot = ss;
+    }
 }
 
 // Row-list exchange of an embedding gradient under data parallelism (of the V rows of the table's gradient at most
@@ -492,29 +519,49 @@ extern "C" int lv_embed_scatter_f32(const float* dX, const uint8_t* mask, float 
     const int N = T * B;
     const int two = vec && ni == 512 && N > 2 * SC_LONG;
     LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
-              N, B, T, dE, ni, pad_idx, accumulate, vec, 0, two);
+              N, B, T, dE, ni, pad_idx, accumulate, vec, 0, two, (float*)nullptr, 0);
     if (two)
         LV_LAUNCH(embed_scatter_long_kernel, dim3((unsigned)lv_cdiv(N, SC_LONG)), dim3(128 * SC_GROUPS), 0, stream, dX, mask, scale, sorted_rows,
-                  sorted_tok, N, B, T, dE, pad_idx, accumulate);
+                  sorted_tok, N, B, T, dE, pad_idx, accumulate, (float*)nullptr, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
 // The same sums, and dE COMPLETE: rows [0, V) of tokens that do not occur (and pad_idx) are written as zeros by the same launch,
 // so the caller needs no fill of the table in front of it.  Every token id must lie in [0, V).
-extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale,
-                                         const int* sorted_rows, const int* sorted_tok, int T, int B,
-                                         float* dE, int ni, int V, int pad_idx, void* stream) {
+static int embed_scatter_full(const float* dX, const uint8_t* mask, float scale, const int* sorted_rows, const int* sorted_tok, int T, int B,
+                              float* dE, int ni, int V, int pad_idx, float* sq, int sq_only, void* stream) {
     if (!dX || !sorted_rows || !sorted_tok || !dE) return LV_ERR_ARG;
     if (T <= 0 || B <= 0 || ni <= 0 || V <= 0) return LV_ERR_SHAPE;
     const int vec = (ni % 4 == 0) && (((uintptr_t)dX | (uintptr_t)dE) & 15) == 0 && (((uintptr_t)mask) & 3) == 0;      // (mask bytes read 4 at a time)
     const int N = T * B;
     const int two = vec && ni == 512 && N > 2 * SC_LONG;
     LV_LAUNCH(embed_scatter_kernel, dim3((unsigned)N), dim3(128), 0, stream, dX, mask, scale, sorted_rows, sorted_tok,
-              N, B, T, dE, ni, pad_idx, 0, vec, V, two);
+              N, B, T, dE, ni, pad_idx, 0, vec, V, two, sq, sq ? sq_only : 0);
     if (two)
         LV_LAUNCH(embed_scatter_long_kernel, dim3((unsigned)lv_cdiv(N, SC_LONG)), dim3(128 * SC_GROUPS), 0, stream, dX, mask, scale, sorted_rows,
-                  sorted_tok, N, B, T, dE, pad_idx, 0);
+                  sorted_tok, N, B, T, dE, pad_idx, 0, sq, sq ? sq_only : 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+extern "C" int lv_embed_scatter_full_f32(const float* dX, const uint8_t* mask, float scale,
+                                         const int* sorted_rows, const int* sorted_tok, int T, int B,
+                                         float* dE, int ni, int V, int pad_idx, void* stream) {
+    return embed_scatter_full(dX, mask, scale, sorted_rows, sorted_tok, T, B, dE, ni, V, pad_idx, nullptr, 0, stream);
+}
+
+// The complete scatter and, in the same pass, the sum of squares of the table gradient it completes: sq[0 .. parts) receives one
+// partial per wave (fixed slots: deterministic; rows no token touches are zero and contribute nothing), parts =
+// lv_embed_scatter_sumsq_parts(T, B).  sq_only != 0: dE is NOT written (a gradient needed for the norm of clip_grad_norm_ alone).
+extern "C" int lv_embed_scatter_sumsq_parts(int T, int B) {
+    const long N = (long)T * B;
+    return N <= 0 ? 0 : (int)(2 * N + 2 * ((N + SC_LONG - 1) / SC_LONG));
+}
+
+extern "C" int lv_embed_scatter_full_sumsq_f32(const float* dX, const uint8_t* mask, float scale,
+                                               const int* sorted_rows, const int* sorted_tok, int T, int B,
+                                               float* dE, int ni, int V, int pad_idx, float* sq, int sq_only, void* stream) {
+    if (!sq) return LV_ERR_ARG;
+    return embed_scatter_full(dX, mask, scale, sorted_rows, sorted_tok, T, B, dE, ni, V, pad_idx, sq, sq_only, stream);
 }

@@ -62,6 +62,9 @@ struct GemmQ {
     float* tgt;                        // [M] the target token's logit
     // nn.Dropout backward folded into the reduction stage (lv_gemm_b16_keep): C *= keep[(row % Bsz) * keepT + row / Bsz][col] ? kscale : 0
     const uint8_t* keep; float kscale; int keepT;
+    // sum of squares of the product emitted by the kernels that hold its final values (lv_gemm_b16_sumsq: the 256 x 256 tile's
+    // epilogue and the tail reduce; one partial per wave, fixed slots: deterministic); sq_only: C itself is not written
+    float* sq; int sq_only;
 };
 
 __device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int valid) {
@@ -851,6 +854,7 @@ __device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, 
     }
     if (piece >= 0) {
         // a K piece of a tail tile: dense 256 x 256 slab (no bounds: the reduce reads only what is inside C)
+        if (p.sq && piece == 0 && l == 0) p.sq[tile * 8 + (t >> 6)] = 0.f;          // this tile's squares come from the reduce
         float* slab = p.ws + ((long)(tile - q.full) * q.tail_s + piece) * (BT2 * BT2);
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2)
@@ -864,6 +868,24 @@ __device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, 
                 }
             }
         return;
+    }
+    if (p.sq) {
+        // the gradient norm's share of this tile (what lies inside C, as stored: alpha * acc), one partial per wave
+        float ss = 0.f;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int rbase = m0 + wm * 128 + i2 * 32 + 4 * (l >> 5), col = n0 + wn * (32 * NJ) + j * 32 + (l & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = p.alpha * acc[i2][j][e];
+                    if (col < p.N && rbase + (e & 3) + 8 * (e >> 2) < p.M) ss += v * v;
+                }
+            }
+        ss = lv_wave_sum(ss);
+        if (l == 0) p.sq[tile * 8 + (t >> 6)] = ss;
+        if (p.sq_only) return;
     }
 #pragma unroll
     for (int i2 = 0; i2 < 4; ++i2)
@@ -1407,6 +1429,7 @@ __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 
     const float* slab = p.ws + (long)(tile - q.full) * q.tail_s * (BT2 * BT2);
     const int t = (int)threadIdx.x;
     const int c4 = (t & 63) * 4;
+    float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rr = ((int)blockIdx.x % 8) * 32 + 4 * it + (t >> 6);
@@ -1428,8 +1451,13 @@ __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 
             float* c = p.C + (long)row * p.ldc + col;
             if (p.accumulate) v += *c;
             if (p.keep) v *= p.keep[((long)(row % p.Bsz) * p.keepT + row / p.Bsz) * p.N + col] ? p.kscale : 0.f;
-            *c = v;
+            ss += v * v;
+            if (!p.sq_only) *c = v;
         }
+    }
+    if (p.sq) {
+        ss = lv_wave_sum(ss);
+        if ((t & 63) == 0) p.sq[(long)p.tilesM * p.tilesN * 8 + (long)blockIdx.x * 4 + (t >> 6)] = ss;
     }
 }
 
@@ -1605,7 +1633,8 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
                            float* C, long ldc, int accumulate,
                            const float* add1, long ld1, int mod1,
                            const float* add2, long ld2, int mod2,
-                           float* ws, long ws_floats, void* stream, const uint8_t* keep, float kscale, int Bsz) {
+                           float* ws, long ws_floats, void* stream, const uint8_t* keep, float kscale, int Bsz,
+                           float* sq = nullptr, int sq_only = 0) {
     if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
@@ -1621,6 +1650,8 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     p.add2 = add2; p.ld2 = ld2; p.mod2 = mod2 > 0 ? mod2 : 1;
     p.ws = ws;
     p.keep = nullptr; p.kscale = 1.f; p.keepT = 1; p.Bsz = Bsz > 0 ? Bsz : 1;
+    p.sq = sq; p.sq_only = sq ? sq_only : 0;
+    if (sq && (!t256_wanted(tile, M, N, K) || accumulate || add1 || add2 || keep)) return LV_ERR_ARG;     // see lv_gemm_b16_sumsq_parts
     // a keep-mask rides in the reduction kernel when every output element passes through one; else a pass of its own follows
     bool keep_pending = keep != nullptr;
     const int nk = lv_cdiv(K > 0 ? K : 1, BK);
@@ -1693,6 +1724,25 @@ extern "C" int lv_gemm_b16_keep(int M, int N, int K, const uint16_t* A, long lda
                                 const uint8_t* keep, float kscale, int Bsz, float* ws, long ws_floats, void* stream) {
     if (!keep || Bsz <= 0 || M % Bsz != 0) return LV_ERR_ARG;
     return gemm_b16_launch(0, 0, M, N, K, 1.f, A, lda, B, ldb, C, N, 0, nullptr, 0, 1, nullptr, 0, 1, ws, ws_floats, stream, keep, kscale, Bsz);
+}
+
+// C = op(A) . B^T as lv_gemm_b16 computes it, and the product's sum of squares in the same pass: sq[0 .. parts) receives one
+// partial per wave of the kernels that hold C's final values (their sum in any fixed order is |C|^2; parts =
+// lv_gemm_b16_sumsq_parts(M, N, K, ws_floats), 0 = this shape does not take the 256 x 256 tile and the entry refuses it).
+// sq_only != 0: C is NOT written (a gradient that is only needed for the norm of clip_grad_norm_: the aggressive inner loop,
+// text.py:383-387, clips over all parameters and steps the encoder alone).
+extern "C" int lv_gemm_b16_sumsq_parts(int M, int N, int K, long ws_floats) {
+    if (M <= 0 || N <= 0 || K <= 0 || !t256_wanted(0, M, N, K)) return 0;
+    const long tiles = (long)lv_cdiv(M, BT2) * lv_cdiv(N, BT2);
+    const Tail256 q = t256_plan(tiles, lv_cdiv(K, BK), ws_floats);
+    return (int)(tiles * 8 + (q.tail_s > 1 ? (long)q.tail * 32 : 0));
+}
+
+extern "C" int lv_gemm_b16_sumsq(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                 float* C, long ldc, float* ws, long ws_floats, float* sq, int sq_only, void* stream) {
+    if (!sq) return LV_ERR_ARG;
+    return gemm_b16_launch(0, transA, M, N, K, 1.f, A, lda, B, ldb, C, ldc, 0, nullptr, 0, 1, nullptr, 0, 1, ws, ws_floats, stream,
+                           nullptr, 1.f, 1, sq, sq_only);
 }
 
 // The same with the tile edge chosen by shape (the product's entry).

@@ -122,17 +122,39 @@ __device__ __forceinline__ bool txn_gate(const TxnGate& g) {
 }
 
 // stage 2 + clip coefficient: sumsq = sum(partial) in double; norm = sqrt; coef = min(1, max_norm / (norm + 1e-6))
-__global__ __launch_bounds__(256) void clip_finish_kernel(const float* __restrict__ partial, int nblk, float max_norm,
-                                                          float* sumsq, float* coef, float* norm_out, TxnGate gate) {
-    __shared__ double red[4];
-    const int tid = (int)threadIdx.x;
+// (extra: partial sums of squares the gradients' PRODUCERS emitted -- lv_gemm_b16_sumsq, lv_embed_scatter_full_sumsq_f32 -- for the
+// tensors stage 1 was not run over; 256 or 1024 threads)
+__global__ __launch_bounds__(1024) void clip_finish_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ extra,
+                                                           int n_extra, float max_norm, float* sumsq, float* coef, float* norm_out,
+                                                           TxnGate gate) {
+    __shared__ double red[16];
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     double s = 0.0;
-    for (int i = tid; i < nblk; i += 256) s += (double)partial[i];
+    for (int i = tid; i < nblk; i += nt) s += (double)partial[i];
+    if (n_extra > 0 && (((uintptr_t)extra) & 15) == 0) {
+        // ~30k producer partials at the Yahoo shape, written on other XCDs (every load is a trip to memory): 16-byte loads, four in
+        // flight per thread -- two round trips instead of thirty
+        const float4* e4 = reinterpret_cast<const float4*>(extra);
+        const int n4 = n_extra / 4;
+        for (int i0 = tid; i0 < n4; i0 += 4 * nt) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = e4[i0 + u * nt < n4 ? i0 + u * nt : i0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * nt < n4) s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+        }
+        for (int i = n4 * 4 + tid; i < n_extra; i += nt) s += (double)extra[i];
+    } else {
+        for (int i = tid; i < n_extra; i += nt) s += (double)extra[i];
+    }
     s = lv_wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     if (tid == 0) {
-        const float ss = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        double tot = 0.0;
+        for (int w = 0; w < nt / 64; ++w) tot += red[w];
+        const float ss = (float)tot;
         const float nrm = sqrtf(ss);
         float c = max_norm / (nrm + 1e-6f);
         if (c > 1.f) c = 1.f;
@@ -455,25 +477,40 @@ extern "C" int lv_clip_norm2_f32(const float* g1, long n1, const float* g2, long
     if (nb2 < 1) nb2 = 1;
     if (nb2 > NORM_BLOCKS) nb2 = NORM_BLOCKS;
     LV_LAUNCH(sumsq2_stage1_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, stream, g1, n1, (int)nb1, g2, n2, (int)nb2, ws);
-    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), max_norm, sumsq_dev, coef_dev,
-              norm_dev, TxnGate{nullptr, nullptr, nullptr, nullptr, nullptr});
+    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), (const float*)nullptr, 0, max_norm,
+              sumsq_dev, coef_dev, norm_dev, TxnGate{nullptr, nullptr, nullptr, nullptr, nullptr});
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
 // lv_clip_norm2_f32 + the transaction gate (see TxnGate / lv_clip_coef_txn_f32)
-extern "C" int lv_clip_norm2_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
-                                     float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
-                                     const float* guard, float* txn, float* acc, void* stream) {
-    if (!g1 || !g2 || !ws || !coef_dev || !txn || n1 < 0 || n2 < 0) return LV_ERR_ARG;
+static int clip_norm2_txn(const float* g1, long n1, const float* g2, long n2, float* ws, const float* extra, int n_extra, float max_norm,
+                          float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
+                          const float* guard, float* txn, float* acc, void* stream) {
+    if (!g1 || !g2 || !ws || !coef_dev || !txn || n1 < 0 || n2 < 0 || n_extra < 0 || (n_extra > 0 && !extra)) return LV_ERR_ARG;
     long nb1 = (n1 + 8191) / 8192, nb2 = (n2 + 8191) / 8192;
     if (nb1 < 1) nb1 = 1;
     if (nb1 > NORM_BLOCKS) nb1 = NORM_BLOCKS;
     if (nb2 < 1) nb2 = 1;
     if (nb2 > NORM_BLOCKS) nb2 = NORM_BLOCKS;
     LV_LAUNCH(sumsq2_stage1_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, stream, g1, n1, (int)nb1, g2, n2, (int)nb2, ws);
-    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, (int)(nb1 + nb2), max_norm, sumsq_dev, coef_dev,
-              norm_dev, TxnGate{status1, status2, guard, txn, acc});
+    LV_LAUNCH(clip_finish_kernel, dim3(1), dim3(n_extra > 0 ? 1024 : 256), 0, stream, (const float*)ws, (int)(nb1 + nb2), extra, n_extra,
+              max_norm, sumsq_dev, coef_dev, norm_dev, TxnGate{status1, status2, guard, txn, acc});
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+extern "C" int lv_clip_norm2_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, float max_norm,
+                                     float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1, const int* status2,
+                                     const float* guard, float* txn, float* acc, void* stream) {
+    return clip_norm2_txn(g1, n1, g2, n2, ws, nullptr, 0, max_norm, sumsq_dev, coef_dev, norm_dev, status1, status2, guard, txn, acc, stream);
+}
+
+// The same where part of the gradient arrives as partial sums of squares its producers emitted (extra[0 .. n_extra): the
+// vocabulary-sized tensors, see lv_gemm_b16_sumsq / lv_embed_scatter_full_sumsq_f32): g1 / g2 are then the REST of the two flat
+// gradients, and the 164 MB of the three big tensors are not read a second time for the norm.
+extern "C" int lv_clip_norm2_fold_txn_f32(const float* g1, long n1, const float* g2, long n2, float* ws, const float* extra, int n_extra,
+                                          float max_norm, float* sumsq_dev, float* coef_dev, float* norm_dev, const int* status1,
+                                          const int* status2, const float* guard, float* txn, float* acc, void* stream) {
+    return clip_norm2_txn(g1, n1, g2, n2, ws, extra, n_extra, max_norm, sumsq_dev, coef_dev, norm_dev, status1, status2, guard, txn, acc, stream);
 }

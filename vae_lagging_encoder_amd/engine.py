@@ -645,6 +645,7 @@ class LSTMEncoderEngine(object):
         self.persist_rows = None                # rows per XCD group of the persistent launches (None: B / 8; 8 at B = 32 = half the chip)
         self.persist_flags = 1                  # bit 0: hand-off granules stay in the XCD's L2 (ladder rung 0; see demote_persistent)
         self.status = None                      # device int32: a persistent launch's hand-off timeout is reported here
+        self.fold = None                        # norm folding (trainer._plan_fold): {"embed": (partials tensor, norm-only flag)}
         self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
         self._wimg = None
@@ -661,6 +662,11 @@ class LSTMEncoderEngine(object):
         if not _LstmImages.usable(self.precision, self.native16, ni, H):
             return None
         return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H, key=("b16", B, T)))
+
+    def fold_parts(self, B, T):
+        """Partial sums of squares this engine's backward can emit from the kernels that complete its big gradient tensors
+        (name -> number of partials): the embedding table's gradient, from the scatter."""
+        return {"embed": self.lib.lv_embed_scatter_sumsq_parts(T, B)}
 
     def refresh_weight_images(self, B, device):
         """Bring the bf16 weight images (and, where the persistent launches apply, the packed recurrent weights) up to
@@ -808,7 +814,12 @@ class LSTMEncoderEngine(object):
             # dX -> embedding rows (the embedding table leads the flat buffer: its gradient is the first, and largest, bucket)
             self._aux.join(x.device)                   # token sort queued by forward()
             # every row of the table's gradient is written by this launch (zeros where a token does not occur): no fill in front
-            lib.lv_embed_scatter_full_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni, V, -1, s)
+            if self.fold and "embed" in self.fold:
+                sq, only = self.fold["embed"]         # the table gradient's squares go to the clip kernel from here (no second read)
+                lib.lv_embed_scatter_full_sumsq_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni,
+                                                    V, -1, P(sq), int(only), s)
+            else:
+                lib.lv_embed_scatter_full_f32(P(w.dX), None, 1.0, P(self._sort[0]), P(self._sort[1]), T, B, P(gv["embed.weight"]), ni, V, -1, s)
             if after_embed is not None:
                 after_embed()
         # input-side grads: dX first, then the embedding scatter, then the two weight-gradient products
@@ -842,6 +853,7 @@ class LSTMDecoderEngine(object):
         self.persist_rows = None                # rows per XCD group of the persistent launches (see LSTMEncoderEngine)
         self.persist_flags = 1
         self.status = None
+        self.fold = None                        # norm folding: {"embed": (partials, only), "pred": (partials, only)}
         # The decoder is frozen for the whole aggressive inner loop (text.py:371-400 steps the encoder only): its bf16
         # weight images and packed recurrent weights are rebuilt only when weights_version() changes.
         self.cache_weight_images = True
@@ -960,6 +972,20 @@ class LSTMDecoderEngine(object):
             w.loss = c.f32(Bd)
             return w
         return c.get((Bd, Td), build)
+
+    def fold_parts(self, B, Td):
+        """As TextEncoderEngine.fold_parts: the embedding table's gradient from the scatter and, where the bf16 product takes the
+        256 x 256 tile, dW_pred from its own epilogue (the ws size enters the tile plan, so it must be the launch's)."""
+        out = {"embed": self.lib.lv_embed_scatter_sumsq_parts(Td, B)}
+        V, ni, H, nz = self.dims()
+        if self._b16(B, Td) is not None:
+            dev = self.flat.device
+            on_side = torch.device(dev).type == "cuda" and self._overlap_on()
+            ws_n = (1 << 26) if on_side else _gemm_ws(self.lib, stream_ptr(dev)).numel()
+            n = self.lib.lv_gemm_b16_sumsq_parts(V, H, Td * B, ws_n)
+            if n > 0:
+                out["pred"] = n
+        return out
 
     def _b16(self, Bd, Td):
         """bf16 images of the vocabulary-sized GEMMs' operands (throughput path), or None when the shapes do not meet
@@ -1112,7 +1138,13 @@ class LSTMDecoderEngine(object):
             lib.lv_softmax_nll_bwd_f32(P(w.logits), w.ldl, P(w.lse), P(x), T, 1, P(drec), Td, B, V, s)
         ctx, sws = self._fork(dev)                    # side: dW_pred = dlogits^T . O (only needs dlogits and O)
         with ctx:
-            if b16 is not None:
+            if b16 is not None and self.fold and "pred" in self.fold:
+                sq, only = self.fold["pred"]          # |dW_pred|^2 leaves the product's own epilogue
+                gws = sws if sws is not None else _gemm_ws(lib, s)
+                with _prof("gemm_bf16", 2.0 * V * H * Td * B):
+                    lib.lv_gemm_b16_sumsq(1, V, H, Td * B, P(b16.dl), b16.ldv, P(b16.OT), b16.ldr, P(gv["pred_linear.weight"]), H,
+                                          P(gws), gws.numel(), P(sq), int(only), stream_ptr(dev))
+            elif b16 is not None:
                 _gemm16(lib, stream_ptr(dev), 1, V, H, Td * B, P(b16.dl), b16.ldv, P(b16.OT), b16.ldr,
                         P(gv["pred_linear.weight"]), H, ws=sws)
             else:
@@ -1147,8 +1179,13 @@ class LSTMDecoderEngine(object):
                 _wgrad(lib, s2, 4 * H, H, Td * B, P(w.dG), 4 * H, P(w.hs), H, P(gv["lstm.weight_hh_l0"]), H,
                        self.precision, ws=sws)
             self._aux.join(dev)                        # token sort queued by forward()
-            lib.lv_embed_scatter_full_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B, P(gv["embed.weight"]), ni,
-                                          V, V - 1, s2)
+            if self.fold and "embed" in self.fold:
+                sq, only = self.fold["embed"]
+                lib.lv_embed_scatter_full_sumsq_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B,
+                                                    P(gv["embed.weight"]), ni, V, V - 1, P(sq), int(only), s2)
+            else:
+                lib.lv_embed_scatter_full_f32(P(w.dX), P(mask_in), sc_in, P(self._sort[0]), P(self._sort[1]), Td, B, P(gv["embed.weight"]), ni,
+                                              V, V - 1, s2)
         self._mark_pending(dev)
         if not fused_ends_ok(B, nz):
             _gemm(lib, s, 1, 0, 4 * H, nz, B, P(w.dGsum), 4 * H, P(z2), nz, P(gwih, ni), ni + nz)

@@ -38,14 +38,24 @@ class AggressiveTextTrainer(object):
     BUCKET_MIN_ELEMS = 1 << 20
 
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
-                 precision="f32", micro_batches=1):
-        """micro_batches = m > 1: gradient accumulation -- every step's batch is cut into m row slices that run one after the
+                 precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full"):
+        """decoder_grads = "norm" (needs fold_norm): in ENCODER-ONLY steps the decoder's two vocabulary-sized gradient tensors
+        (embedding table, dW_pred) are not written to memory at all -- text.py:383-387 needs them for the clip norm alone, the
+        next backward overwrites them -- and their .grad is left unspecified by such a step; "full" (default) keeps every .grad
+        as clip_grad_norm_ would leave it.
+        fold_norm: the vocabulary-sized gradient tensors hand their sums of squares to the clip kernel from their producers'
+        own passes instead of being read again (_plan_fold; the same norm up to summation order).
+        micro_batches = m > 1: gradient accumulation -- every step's batch is cut into m row slices that run one after the
         other on the frozen weights, slice i's gradient exchange (data parallel) is issued when its backward has been queued and
         runs under slice i + 1's forward and backward, the m slice gradients are summed and ONE clip + update follows: the same
         mean gradient as the whole batch in one piece (text.py:382-387; SURVEY.md 8e's overlap window).  Eager mode only."""
         self.vae = vae
         self.micro_batches = int(micro_batches)
         assert self.micro_batches >= 1
+        self.fold_norm = bool(fold_norm)
+        assert decoder_grads in ("full", "norm")
+        self.decoder_grads = decoder_grads
+        self._fold, self._fold_plans = None, {}
         if self.micro_batches > 1 and use_graph:
             raise ValueError("micro_batches > 1 runs in eager mode (every slice writes its own gradient slot)")
         self._slice_views = {}
@@ -316,7 +326,12 @@ class AggressiveTextTrainer(object):
         dp = self.grad_sync is not None and self.grad_sync.world > 1
         gate = (_eng.status_ptr(self.enc), _eng.status_ptr(self.dec), P(ef.grad_padded, ef.guard_index) if dp else None,
                 self._s(8), self._s(5))
-        if dec_ss is None:
+        if dec_ss is None and self._fold is not None:
+            # the vocabulary-sized tensors' squares came out of their producers (_plan_fold): stage 1 reads the rest only
+            f = self._fold
+            lib.lv_clip_norm2_fold_txn_f32(P(ef.grad, f.enc_off), ef.numel - f.enc_off, P(df.grad, f.dec_off), f.dec_end - f.dec_off,
+                                           P(self.norm_ws), P(f.parts), f.n, self.clip, self._s(2), self._s(3), self._s(4), *gate, s)
+        elif dec_ss is None:
             lib.lv_clip_norm2_txn_f32(P(ef.grad), ef.numel, P(df.grad), df.numel, P(self.norm_ws), self.clip, self._s(2), self._s(3),
                                       self._s(4), *gate, s)
         else:
@@ -330,10 +345,49 @@ class AggressiveTextTrainer(object):
             lib.lv_sgd_step_txn_f32(P(df.data), P(df.grad), df.numel, self._s(1), self._s(3), 1, self._s(8), s)
         else:
             a, b = (ef, df) if update == "encoder" else (df, ef)      # a is stepped, b's gradient is only scaled: one launch
-            lib.lv_sgd_step_scale_txn_f32(P(a.data), P(a.grad), a.numel, self._s(1), self._s(3), 1, P(b.grad), b.numel, self._s(8), s)
+            b_off, b_n = 0, b.numel
+            if update == "encoder" and self._fold is not None and self.decoder_grads == "norm":
+                b_off, b_n = self._fold.dec_off, self._fold.dec_end - self._fold.dec_off      # what of the decoder's gradient exists
+            lib.lv_sgd_step_scale_txn_f32(P(a.data), P(a.grad), a.numel, self._s(1), self._s(3), 1, P(b.grad, b_off), b_n, self._s(8), s)
+
+    def _plan_fold(self, st, update):
+        """Norm folding (single GPU, one micro-batch): the three vocabulary-sized gradient tensors -- both embedding tables and
+        dW_pred, 164 of the 215 MB at the Yahoo shape -- hand their sums of squares to the clip kernel from the kernels that
+        complete them, and lv_clip_norm2's streaming pass covers only the rest of the two flat buffers (embedding first in both,
+        pred_linear last in the decoder's: the rest is one contiguous range each).  Off where the norm is not that of this
+        backward's own tensors: data parallel (the norm is the averaged gradient's) and micro-batches (of the slots' sum)."""
+        self._fold = None
+        self.enc.fold = self.dec.fold = None
+        if not self.fold_norm or self.grad_sync is not None or self.micro_batches != 1:
+            return
+        B, T = st.x.shape
+        key = (B, T)
+        f = self._fold_plans.get(key)
+        if f is None:
+            pe, pd = self.enc.fold_parts(B, T), self.dec.fold_parts(B, T - 1)
+            f = _eng._NS()
+            f.n = pe["embed"] + pd["embed"] + pd.get("pred", 0)
+            f.parts = torch.zeros(f.n, dtype=torch.float32, device=self.device)
+            f.enc_embed = f.parts[:pe["embed"]]
+            f.dec_embed = f.parts[pe["embed"]:pe["embed"] + pd["embed"]]
+            f.dec_pred = f.parts[pe["embed"] + pd["embed"]:] if "pred" in pd else None
+            ef, df = self.enc.flat, self.dec.flat
+            f.enc_off = ef.offsets["lstm.weight_ih_l0"]              # behind the encoder's embedding table
+            f.dec_off = df.offsets["trans_linear.weight"]            # behind the decoder's
+            f.dec_end = df.offsets["pred_linear.weight"] if f.dec_pred is not None else df.numel
+            assert ef.offsets["embed.weight"] == 0 and df.offsets["embed.weight"] == 0 and \
+                df.offsets["pred_linear.weight"] + self.vae.decoder.pred_linear.weight.numel() <= df.numel
+            self._fold_plans[key] = f
+        self._fold = f
+        only = self.decoder_grads == "norm" and update == "encoder"
+        self.enc.fold = {"embed": (f.enc_embed, False)}
+        self.dec.fold = {"embed": (f.dec_embed, only)}
+        if f.dec_pred is not None:
+            self.dec.fold["pred"] = (f.dec_pred, only)
 
     def _run(self, st, update, draw):
         self._update = update
+        self._plan_fold(st, update)
         if self.grad_sync is not None:
             self.grad_sync.begin_step()
         self._fwd_bwd(st, draw)
@@ -389,6 +443,8 @@ class AggressiveTextTrainer(object):
         gs = self.grad_sync
         dp = gs is not None and gs.world > 1
         self._update = update
+        self._fold = None                 # (the norm is that of the slots' sum: no folding, _plan_fold)
+        self.enc.fold = self.dec.fold = None
         if gs is not None:
             gs.begin_step()
         try:
@@ -485,6 +541,7 @@ class AggressiveTextTrainer(object):
         """Capture the step as hipGraph(s).  With a gradient all-reduce the step is split around it
         (fwd+bwd graph | RCCL all-reduce | clip+SGD graph): collectives are not captured."""
         parts = []
+        self._plan_fold(st, update)
         stream = torch.cuda.Stream(self.device)
         stream.wait_stream(torch.cuda.current_stream(self.device))
 
