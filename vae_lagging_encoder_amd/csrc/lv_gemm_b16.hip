@@ -44,6 +44,9 @@ constexpr int BK = 64;
 constexpr int BT = 128;
 constexpr int NCH = BK / 8;
 
+#ifndef LV_NLL_ABL
+#define LV_NLL_ABL 0                     // measurement only (profiles/microbench/gemm_pp_probe.py): 1 = no logits store, 2 = no statistics, 4 = no epilogue
+#endif
 struct GemmQ {
     const uint16_t* A; const uint16_t* B; float* C;
     int M, N, K;
@@ -721,6 +724,7 @@ struct Tail256 {
     int tail;          // tiles [full, full + tail): the last, partial round
     int tail_s;        // pieces per tail tile (1: the tail tiles run whole as well)
     int kt_per_piece;  // K tiles per piece
+    int nwork;         // work items of the launch: full + tail * tail_s (lv_gemm_b16_t256_kernel walks them with stride gridDim.x)
 };
 
 #ifndef LV_T256_G
@@ -776,6 +780,9 @@ __device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, 
                                               int wm, int wn, int lh) {
     constexpr int NJ = 2;
     if constexpr (NLL) {
+#if LV_NLL_ABL & 4
+        return;
+#endif
         // fused epilogue of the vocabulary projection (see the 128 x 128 kernel): the 256 x 256 tile goes through the 128 KB of
         // LDS as binary16 (64 rows of 512 B per buffer, 16-byte chunks permuted by chunk ^ (row & 15) so that the row-per-lane
         // reads below are conflict-free), thread (row rr = t & 255, half = t >> 8) owns 128 consecutive logits = two 64-column
@@ -811,6 +818,22 @@ __device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, 
             }
         }
         __syncthreads();
+#if !(LV_NLL_ABL & 1)
+        // the binary16 logits leave in ROW order: half a wave per 512-byte tile row (32 lanes x 16 B = four full lines), 16 rows per
+        // step of the workgroup.  (From the row-per-lane registers of the statistics below every store instruction touched 64
+        // different lines, 16 bytes each -- 8192 line requests per tile instead of 1024 -- and the stores were 57 of the kernel's 302 us.)
+        {
+            const int c = l & 31;
+#pragma unroll 4
+            for (int s16 = 0; s16 < 16; ++s16) {
+                const int r2 = 16 * s16 + 2 * (t >> 6) + (l >> 5);
+                const uint4 qv = *reinterpret_cast<const uint4*>(rowptr(r2) + ((c ^ (r2 & 15)) << 4));
+                const int col0 = n0 + 8 * c;
+                // (non-temporal stores measured the same: 274 vs 278 us for the launch, nothing in the step)
+                if (m0 + r2 < p.M && col0 + 8 <= p.ldc16) *reinterpret_cast<uint4*>(p.C16 + (long)(m0 + r2) * p.ldc16 + col0) = qv;
+            }
+        }
+#endif
         const int rr = t & 255, half = t >> 8;
         const int row = m0 + rr;
         if (row < p.M) {
@@ -826,10 +849,10 @@ __device__ __forceinline__ void t256_epilogue(const GemmQ& p, const Tail256& q, 
                 uint4 qv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) qv[k] = *reinterpret_cast<const uint4*>(rowp + ((((cb >> 3) + k) ^ (rr & 15)) << 4));
-                uint16_t* dst = p.C16 + (long)row * p.ldc16 + c0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (c0 + 8 * k + 8 <= p.ldc16) reinterpret_cast<uint4*>(dst)[k] = qv[k];
+#if LV_NLL_ABL & 2
+                if (qv[0].x == 0x12345678u) p.tgt[row] = 1.f;
+                continue;
+#endif
                 float v[64];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -916,14 +939,21 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
     __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
 
-    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
-    const int kt0 = pk.kt0, kt1 = pk.kt1;
-    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
-
     const int t = (int)threadIdx.x;
     const int l = t & 63, w = lv_wave_uniform(t >> 6);   // wave id in SGPRs: the LDS-DMA destinations below are scalar (M0)
     const int wm = w / WN, wn = w % WN;
     const int li = l & 31, lh = l >> 5;
+    const int nfull = p.K / BK;
+
+    // A workgroup walks work items blockIdx.x, + gridDim.x, ...: one item per workgroup (grid = q.nwork) where a launch is a round or
+    // two, a PERSISTENT grid of 256 where it is many short tiles (the vocabulary projection: K = 1024 is 16 K tiles per tile, 8 to 31
+    // rounds) -- a workgroup then goes from its epilogue straight into the next tile's first loads, and the epilogue's stores drain
+    // underneath them instead of in front of a workgroup launch (a wave's slot is only released when its stores have been
+    // acknowledged).  The stride keeps the XCD (gridDim.x % 8 == 0), so t256_pick's tile ranges per L2 hold either way.
+    for (int bid = (int)blockIdx.x; bid < q.nwork; bid += (int)gridDim.x) {
+    const T256Pick pk = t256_pick(p, q, bid);
+    const int kt0 = pk.kt0, kt1 = pk.kt1;
+    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
 
     f32x16 acc[4][NJ];
 #pragma unroll
@@ -932,8 +962,6 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nfull = p.K / BK;
 
     // staging units of this thread: wave w fills the 1 KB pieces u = 4w + i of each image (8 rows of 128 B; TN A image: 2 k rows
     // of 512 B)
@@ -1182,6 +1210,8 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     }
 
     t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, wm, wn, lh);
+    if (bid + (int)gridDim.x < q.nwork) __syncthreads();      // the fused epilogue staged the tile through the K tiles' LDS
+    }
 }
 
 // ---- the same tile with a QUADRANT-ordered ping-pong schedule and a continuous LDS-DMA stream (round 4) -----------------------
@@ -1589,6 +1619,9 @@ static bool t256_wanted(int tile, int M, int N, int K) {
     if (tile) return tile >= 256;
     return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
 }
+#ifndef LV_T256_PERSIST_MIN
+#define LV_T256_PERSIST_MIN 768          // work items from which the k-step schedules of the 256 x 256 kernel run as a persistent grid of 256
+#endif
 #ifndef LV_B16_SCHED_DEFAULT
 #define LV_B16_SCHED_DEFAULT -1   // schedule of the 256 x 256 kernel when the caller does not name it: -1 = by K tiles per workgroup, 0 = lockstep, 1 = ping-pong by k-steps, 2 = ping-pong by quadrants with a continuous DMA stream
 #endif
@@ -1610,6 +1643,7 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
     q.kt_per_piece = nk;
     const long tail = tiles - q.full;
     q.tail = (int)tail;
+    q.nwork = (int)tiles;
     if (tail == 0) return q;
     double best = (double)nk * 2.0;
     for (int s = 2; s <= 16; ++s) {
@@ -1619,6 +1653,7 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
     }
     q.kt_per_piece = lv_cdiv(nk, q.tail_s);
     q.tail_s = lv_cdiv(nk, q.kt_per_piece);
+    q.nwork = q.full + q.tail * q.tail_s;
     return q;
 }
 
@@ -1663,6 +1698,7 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
         if (keep && q.full == 0 && q.tail_s > 1) { p.keep = keep; p.kscale = kscale; p.keepT = M / p.Bsz; keep_pending = false; }
         dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
         const int sched = t256_sched(tile, q.tail_s > 1 && q.full == 0 ? q.kt_per_piece : nk);
+        if (sched != 2 && q.nwork >= LV_T256_PERSIST_MIN) grid.x = 256;      // many short tiles: a persistent grid (see the kernel)
         if (sched == 2) {
             if (transA) LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, true>), grid, block, 0, stream, p, q);
             else LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, false>), grid, block, 0, stream, p, q);
@@ -1844,10 +1880,12 @@ extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
         q.full = (int)(tiles / 256 * 256); q.tail = (int)(tiles - q.full); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
+        q.nwork = (int)tiles;
         const int sched = t256_sched(tile, p.kt_per_split);
+        const unsigned grid = sched != 2 && tiles >= LV_T256_PERSIST_MIN ? 256u : (unsigned)tiles;      // persistent: see the kernel
         if (sched == 2) LV_LAUNCH((lv_gemm_b16_t256q_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
-        else if (sched == 1) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, true>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
-        else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        else if (sched == 1) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, true>), dim3(grid), dim3(512), 0, stream, p, q);
+        else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3(grid), dim3(512), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
