@@ -189,7 +189,7 @@ def test_gemm_b16(lib, hip_device, tA, M, N, K, split, exact=None, tile=0):
     (0, 130, 140, 37, False), (1, 70, 130, 50, False), (0, 1, 1, 1, False), (1, 300, 260, 200, False), (0, 257, 513, 1000, True),
     (1, 301, 100, 1100, True), (0, 640, 1024, 2001, True), (1, 2001, 1024, 640, False), (0, 3000, 2100, 512, False),
     (1, 1100, 1200, 2304, True), (0, 4200, 4100, 320, True),
-    (0, 7100, 7000, 130, False), (1, 7000, 7100, 200, True),      # 784 tiles: the k-step schedules run as a persistent grid of 256
+    (0, 7100, 7000, 130, False), (1, 7000, 7100, 200, True),      # 784 tiles: three whole rounds of 256 + a tail
 ])
 @pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_tile256(lib, hip_device, tA, M, N, K, split, tile):
@@ -1250,7 +1250,7 @@ def test_gemm_b16_tile256_repeatable(lib, hip_device, tA, M, N, K, tile):
 
 
 @pytest.mark.parametrize("T,B,V,H", [(5, 32, 20001, 64), (3, 7, 333, 40), (2, 5, 128, 72), (9, 33, 1000, 128), (40, 32, 20001, 1024),
-                                     (199, 32, 20001, 128)])      # the last: 1975 tiles, a persistent grid of 256 workgroups
+                                     (199, 32, 20001, 128)])      # the last: the Yahoo step's 1975 tiles
 @pytest.mark.parametrize("tile", [256, 257, 258])
 def test_gemm_b16_nll_fused_tile256(lib, hip_device, T, B, V, H, tile):
     test_gemm_b16_nll_fused(lib, hip_device, T, B, V, H, tile=tile)

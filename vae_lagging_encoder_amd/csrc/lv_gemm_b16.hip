@@ -724,7 +724,6 @@ struct Tail256 {
     int tail;          // tiles [full, full + tail): the last, partial round
     int tail_s;        // pieces per tail tile (1: the tail tiles run whole as well)
     int kt_per_piece;  // K tiles per piece
-    int nwork;         // work items of the launch: full + tail * tail_s (lv_gemm_b16_t256_kernel walks them with stride gridDim.x)
 };
 
 #ifndef LV_T256_G
@@ -945,13 +944,7 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     const int li = l & 31, lh = l >> 5;
     const int nfull = p.K / BK;
 
-    // A workgroup walks work items blockIdx.x, + gridDim.x, ...: one item per workgroup (grid = q.nwork) where a launch is a round or
-    // two, a PERSISTENT grid of 256 where it is many short tiles (the vocabulary projection: K = 1024 is 16 K tiles per tile, 8 to 31
-    // rounds) -- a workgroup then goes from its epilogue straight into the next tile's first loads, and the epilogue's stores drain
-    // underneath them instead of in front of a workgroup launch (a wave's slot is only released when its stores have been
-    // acknowledged).  The stride keeps the XCD (gridDim.x % 8 == 0), so t256_pick's tile ranges per L2 hold either way.
-    for (int bid = (int)blockIdx.x; bid < q.nwork; bid += (int)gridDim.x) {
-    const T256Pick pk = t256_pick(p, q, bid);
+    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
     const int kt0 = pk.kt0, kt1 = pk.kt1;
     const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
 
@@ -1210,8 +1203,6 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
     }
 
     t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, wm, wn, lh);
-    if (bid + (int)gridDim.x < q.nwork) __syncthreads();      // the fused epilogue staged the tile through the K tiles' LDS
-    }
 }
 
 // ---- the same tile with a QUADRANT-ordered ping-pong schedule and a continuous LDS-DMA stream (round 4) -----------------------
@@ -1619,9 +1610,6 @@ static bool t256_wanted(int tile, int M, int N, int K) {
     if (tile) return tile >= 256;
     return 2.0 * M * N * K >= 1.0e11 && M >= 1024 && N >= 1024 && K >= 1024;
 }
-#ifndef LV_T256_PERSIST_MIN
-#define LV_T256_PERSIST_MIN 768          // work items from which the k-step schedules of the 256 x 256 kernel run as a persistent grid of 256
-#endif
 #ifndef LV_B16_SCHED_DEFAULT
 #define LV_B16_SCHED_DEFAULT -1   // schedule of the 256 x 256 kernel when the caller does not name it: -1 = by K tiles per workgroup, 0 = lockstep, 1 = ping-pong by k-steps, 2 = ping-pong by quadrants with a continuous DMA stream
 #endif
@@ -1643,7 +1631,6 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
     q.kt_per_piece = nk;
     const long tail = tiles - q.full;
     q.tail = (int)tail;
-    q.nwork = (int)tiles;
     if (tail == 0) return q;
     double best = (double)nk * 2.0;
     for (int s = 2; s <= 16; ++s) {
@@ -1653,7 +1640,6 @@ static Tail256 t256_plan(long tiles, int nk, long ws_floats) {
     }
     q.kt_per_piece = lv_cdiv(nk, q.tail_s);
     q.tail_s = lv_cdiv(nk, q.kt_per_piece);
-    q.nwork = q.full + q.tail * q.tail_s;
     return q;
 }
 
@@ -1698,7 +1684,6 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
         if (keep && q.full == 0 && q.tail_s > 1) { p.keep = keep; p.kscale = kscale; p.keepT = M / p.Bsz; keep_pending = false; }
         dim3 grid((unsigned)(q.full + tail * q.tail_s)), block(512);
         const int sched = t256_sched(tile, q.tail_s > 1 && q.full == 0 ? q.kt_per_piece : nk);
-        if (sched != 2 && q.nwork >= LV_T256_PERSIST_MIN) grid.x = 256;      // many short tiles: a persistent grid (see the kernel)
         if (sched == 2) {
             if (transA) LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, true>), grid, block, 0, stream, p, q);
             else LV_LAUNCH((lv_gemm_b16_t256q_kernel<false, false>), grid, block, 0, stream, p, q);
@@ -1880,12 +1865,12 @@ extern "C" int lv_gemm_b16_nll_tile(int tile, int M, int N, int K, const uint16_
         Tail256 q;
         const long tiles = (long)p.tilesM * p.tilesN;
         q.full = (int)(tiles / 256 * 256); q.tail = (int)(tiles - q.full); q.tail_s = 1; q.kt_per_piece = p.kt_per_split;
-        q.nwork = (int)tiles;
         const int sched = t256_sched(tile, p.kt_per_split);
-        const unsigned grid = sched != 2 && tiles >= LV_T256_PERSIST_MIN ? 256u : (unsigned)tiles;      // persistent: see the kernel
+        // (a persistent grid of 256 workgroups walking the 1975 tiles -- epilogue stores draining under the next tile's first loads --
+        // measured the same for this launch, 292 vs 293 us, and cost the plain-store variants of the kernel ~1 KB of scratch per lane)
         if (sched == 2) LV_LAUNCH((lv_gemm_b16_t256q_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
-        else if (sched == 1) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, true>), dim3(grid), dim3(512), 0, stream, p, q);
-        else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3(grid), dim3(512), 0, stream, p, q);
+        else if (sched == 1) LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false, true>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
+        else LV_LAUNCH((lv_gemm_b16_t256_kernel<true, false>), dim3((unsigned)tiles), dim3(512), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
