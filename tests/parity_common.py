@@ -488,8 +488,9 @@ def check_fold_norm(device, V, ni, H, nz, B, T, precision="f32", use_graph=False
             if i == 0:
                 grads = {k: p.grad.detach().clone() for k, p in vae.named_parameters() if p.grad is not None}
         assert (tr._fold is not None) == fold
+        assert tr.enc.fold is None and tr.dec.fold is None      # disarmed between steps: the autograd path never sees a trainer's plan
         if fold and precision == "bf16" and 2.0 * V * H * (T - 1) * B >= 1e11 and torch.device(device).type == "cuda":
-            assert "pred" in tr.dec.fold, "dW_pred's squares were expected to come from the product's epilogue at this shape"
+            assert tr._fold.dec_pred is not None, "dW_pred's squares were expected to come from the product's epilogue at this shape"
         out[fold] = (rec, grads, {k: v.detach().clone() for k, v in vae.state_dict().items()})
     for (n0, c0), (n1, c1) in zip(out[False][0], out[True][0]):
         assert abs(n0 - n1) <= 2e-6 * n0 and abs(c0 - c1) <= 2e-6, ((n0, c0), (n1, c1))

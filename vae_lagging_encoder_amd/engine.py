@@ -1141,6 +1141,8 @@ class LSTMDecoderEngine(object):
             if b16 is not None and self.fold and "pred" in self.fold:
                 sq, only = self.fold["pred"]          # |dW_pred|^2 leaves the product's own epilogue
                 gws = sws if sws is not None else _gemm_ws(lib, s)
+                if lib.lv_gemm_b16_sumsq_parts(V, H, Td * B, gws.numel()) != sq.numel():
+                    raise RuntimeError("norm folding: the plan's partial count does not match this launch's tile plan")
                 with _prof("gemm_bf16", 2.0 * V * H * Td * B):
                     lib.lv_gemm_b16_sumsq(1, V, H, Td * B, P(b16.dl), b16.ldv, P(b16.OT), b16.ldr, P(gv["pred_linear.weight"]), H,
                                           P(gws), gws.numel(), P(sq), int(only), stream_ptr(dev))

@@ -250,6 +250,13 @@ class AggressiveTextTrainer(object):
 
     # -- the step ----------------------------------------------------------------------------------------
     def _fwd_bwd(self, st, draw):
+        self._arm_fold()
+        try:
+            self._fwd_bwd_armed(st, draw)
+        finally:
+            self.enc.fold = self.dec.fold = None
+
+    def _fwd_bwd_armed(self, st, draw):
         lib, s = self.lib, _eng.stream_ptr(self.device)
         B, T = st.x.shape
         dec = self.vae.decoder
@@ -357,7 +364,6 @@ class AggressiveTextTrainer(object):
         pred_linear last in the decoder's: the rest is one contiguous range each).  Off where the norm is not that of this
         backward's own tensors: data parallel (the norm is the averaged gradient's) and micro-batches (of the slots' sum)."""
         self._fold = None
-        self.enc.fold = self.dec.fold = None
         if not self.fold_norm or self.grad_sync is not None or self.micro_batches != 1:
             return
         B, T = st.x.shape
@@ -379,7 +385,15 @@ class AggressiveTextTrainer(object):
                 df.offsets["pred_linear.weight"] + self.vae.decoder.pred_linear.weight.numel() <= df.numel
             self._fold_plans[key] = f
         self._fold = f
-        only = self.decoder_grads == "norm" and update == "encoder"
+
+    def _arm_fold(self):
+        """Tell the engines where this backward's partial sums of squares go (and whether the decoder's big tensors are
+        norm-only); _fwd_bwd disarms them again when everything is queued, so that a backward of the drop-in autograd path on
+        the same modules never runs with a trainer's plan."""
+        f = self._fold
+        if f is None:
+            return
+        only = self.decoder_grads == "norm" and self._update == "encoder"
         self.enc.fold = {"embed": (f.enc_embed, False)}
         self.dec.fold = {"embed": (f.dec_embed, only)}
         if f.dec_pred is not None:
@@ -444,7 +458,6 @@ class AggressiveTextTrainer(object):
         dp = gs is not None and gs.world > 1
         self._update = update
         self._fold = None                 # (the norm is that of the slots' sum: no folding, _plan_fold)
-        self.enc.fold = self.dec.fold = None
         if gs is not None:
             gs.begin_step()
         try:
@@ -541,6 +554,7 @@ class AggressiveTextTrainer(object):
         """Capture the step as hipGraph(s).  With a gradient all-reduce the step is split around it
         (fwd+bwd graph | RCCL all-reduce | clip+SGD graph): collectives are not captured."""
         parts = []
+        self._update = update
         self._plan_fold(st, update)
         stream = torch.cuda.Stream(self.device)
         stream.wait_stream(torch.cuda.current_stream(self.device))
