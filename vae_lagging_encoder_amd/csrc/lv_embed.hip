@@ -296,16 +296,29 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
     const int tid = (int)threadIdx.x;
     if (V > 0 && !sq_only) {
         // complete form: every row of dE is written exactly once by this launch (pair) -- the rows of tokens that occur by their
-        // segment heads, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in (a
-        // binary search of the sorted token list per row).  Replaces a separate fill of the whole table (41 MB at V = 20001).
+        // segment heads, all others (and pad_idx) with zeros HERE, by the workgroup whose slice of the vocabulary they fall in
+        // (balanced whatever the token distribution).  Whether a row occurs is a binary search of the sorted list: ONE search per
+        // LANE, all rows of the slice at once -- 13 dependent loads per workgroup; walking the slice row by row it was 13 per row,
+        // 3 rows per workgroup at the Yahoo shape, and most of the launch's 26-32 us.  Replaces a separate fill of the whole
+        // table (41 MB at V = 20001).
+        __shared__ int absent_row[64];
         const int v0 = (int)((long)p * V / N), v1 = (int)((long)(p + 1) * V / N);
-        for (int v = v0; v < v1; ++v) {
-            int lo = 0, hi = N;                  // first position with toks[pos] >= v
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < v) lo = mid + 1; else hi = mid; }
-            if (lo < N && toks[lo] == v && v != pad_idx) continue;
-            float* z = dE + (long)v * ni;
-            if (vec) for (int k = tid * 4; k < ni; k += 512) *reinterpret_cast<float4*>(z + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-            else for (int k = tid; k < ni; k += 128) z[k] = 0.f;
+        for (int vb = v0; vb < v1; vb += 64) {
+            if (tid < 64) {
+                const int v = vb + tid;
+                int lo = 0, hi = N;                  // first position with toks[pos] >= v
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < v) lo = mid + 1; else hi = mid; }
+                absent_row[tid] = (v < v1 && !(lo < N && toks[lo] == v && v != pad_idx)) ? 1 : 0;
+            }
+            __syncthreads();
+            const int nrow = v1 - vb < 64 ? v1 - vb : 64;
+            for (int i = 0; i < nrow; ++i) {
+                if (!absent_row[i]) continue;
+                float* z = dE + (long)(vb + i) * ni;
+                if (vec) for (int k = tid * 4; k < ni; k += 512) *reinterpret_cast<float4*>(z + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else for (int k = tid; k < ni; k += 128) z[k] = 0.f;
+            }
+            if (vb + 64 < v1) __syncthreads();
         }
     }
     // sq: the squares of the row this workgroup completes, one partial per wave in slots [2p, 2p + 2) (zeros from workgroups that
