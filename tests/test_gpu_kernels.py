@@ -283,7 +283,8 @@ def test_rows_merge(lib, hip_device, world, V, ni, counts, b16):
     acc = acc * (1.0 / world)
     wire = rows.to(torch.bfloat16).view(torch.int16) if b16 else rows
     dE = torch.full((V, ni), float("nan"), device=dev)
-    lib.lv_rows_merge_f32(P(ids.to(dev)), P(wire.to(dev)), b16, world, cap, ni, V, 1.0 / world, P(dE), _s(dev))
+    ids_d, wire_d = ids.to(dev), wire.to(dev)                 # (held: a temporary's block may be handed out again at once)
+    lib.lv_rows_merge_f32(P(ids_d), P(wire_d), b16, world, cap, ni, V, 1.0 / world, P(dE), _s(dev))
     assert torch.equal(dE.cpu(), acc)
 
 

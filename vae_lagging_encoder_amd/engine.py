@@ -1233,8 +1233,9 @@ def reparam_kl_backward(mulv, eps, dz, dkl):
     nz = nz2 // 2
     ns = eps.shape[1]
     dmulv = torch.empty_like(mulv)
-    lib.lv_reparam_kl_bwd_f32(P(mulv.contiguous()), P(eps.contiguous()), P(dz.contiguous()), P(dkl.contiguous()),
-                              P(dmulv), B, ns, nz, s)
+    # (contiguous copies are held in locals until the launch is queued: a temporary's block may be handed out again at once)
+    mulv_c, eps_c, dz_c, dkl_c = mulv.contiguous(), eps.contiguous(), dz.contiguous(), dkl.contiguous()
+    lib.lv_reparam_kl_bwd_f32(P(mulv_c), P(eps_c), P(dz_c), P(dkl_c), P(dmulv), B, ns, nz, s)
     return dmulv
 
 

@@ -516,7 +516,8 @@ class ImageDecoderEngine(object):
         tp = self.tape
         B = self.rec.shape[0]
         dlogit = tp.f32(B * 28 * 28, 1)
-        tp.lib.lv_sigmoid_bce_bwd_f32(P(self.logit.t), P(self.xflat), P(drec.contiguous()), P(dlogit), B, 28 * 28, 1e-12, tp.s())
+        drec_c = drec.contiguous()
+        tp.lib.lv_sigmoid_bce_bwd_f32(P(self.logit.t), P(self.xflat), P(drec_c), P(dlogit), B, 28 * 28, 1e-12, tp.s())
         tp.add_grad(self.logit, dlogit)
         tp.backward()
         return tp.grad_of(self.zact)
