@@ -51,7 +51,7 @@ for name, tA, M, N, K, A, lda, Bm, ldb, C, ldc, add in shapes:
             line += " | %s %6.1f us %6.1f TF" % (ln, us, 2.0 * M * N * K / us / 1e6)
             if rep == 1:
                 tot[ln] += us
-    for tile in (256, 257):
+    for tile in (256, 257, 258):
         L = libs[0][1]
         us = med(lambda: L.lv_gemm_b16_tile(tile, tA, M, N, K, 1.0, P(A), lda, P(Bm), ldb, P(C), ldc, 0, P(add) if add is not None else None, 0, 1, None, 0, 1,
                                             P(ws), ws.numel(), s))
