@@ -1816,7 +1816,7 @@ extern "C" int lv_gemm_b16_sumsq_parts(int M, int N, int K, long ws_floats) {
 
 extern "C" int lv_gemm_b16_sumsq(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                                  float* C, long ldc, float* ws, long ws_floats, float* sq, int sq_only, void* stream) {
-    if (!sq) return LV_ERR_ARG;
+    if (!sq || (!ws && ws_floats > 0)) return LV_ERR_ARG;      // (the partial count follows the tile plan, and the plan the workspace size)
     return gemm_b16_launch(0, transA, M, N, K, 1.f, A, lda, B, ldb, C, ldc, 0, nullptr, 0, 1, nullptr, 0, 1, ws, ws_floats, stream,
                            nullptr, 1.f, 1, sq, sq_only);
 }
