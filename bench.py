@@ -116,6 +116,11 @@ def measure_omniglot(args, dev, rank, world, cpu_baseline=False, profile_eager=F
     # convolutions and the im2col GEMMs against the f32 MFMA peak (flops over the taps the mask keeps), BatchNorm (+ residual +
     # ELU) and the pointwise convolutions against HBM (bytes of the activations they stream)
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    gemm_group = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
+    # the direct convolutions' pipe: exact f32, bf16, or bf16 at three instructions per product (a third of its peak is what they can reach)
+    conv_peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)}[args.dtype]
+    conv_label = {"f32": "exact-f32 MFMA", "bf16": "bf16 operands, f32 accumulate",
+                  "bf16x3": "split-bf16 operands: three bf16 MFMAs per product, f32 accumulate; peak = a third of the bf16 pipe's"}[args.dtype]
     groups = {}
     for name, recs in prof.items():
         ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
@@ -126,7 +131,7 @@ def measure_omniglot(args, dev, rank, world, cpu_baseline=False, profile_eager=F
         if not g or g["ms"] <= 0:
             return None
         tf = g["work"] / (g["ms"] * 1e-3) / 1e12
-        pk = PEAK_F32_MFMA_TFLOPS if (name == "conv_direct" or args.dtype == "f32") else peak
+        pk = conv_peak if name == "conv_direct" else peak
         return {"bound": "mfma", "kernel": label, "achieved": round(tf, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(tf / pk, 4),
                 "traffic": None, "launches_per_step": g["launches"] // prof_steps, "ms_per_step": round(g["ms"] / prof_steps, 4),
                 "gflop_per_step": round(g["work"] / prof_steps / 1e9, 1)}
@@ -140,10 +145,10 @@ def measure_omniglot(args, dev, rank, world, cpu_baseline=False, profile_eager=F
                 "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_per_step": g["launches"] // prof_steps,
                 "ms_per_step": round(g["ms"] / prof_steps, 4), "algorithmic_MB_per_step": round(g["work"] / prof_steps / 1e6, 1)}
     views = [v for v in (
-        mfma_view("conv_direct", "conv32_direct_kernel / conv32_wgrad_kernel (masked 32->32 k x k convolutions, exact-f32 MFMA, forward + data gradient over the kept taps, weight gradient over all taps)"),
+        mfma_view("conv_direct", "conv32_direct%s_kernel / conv32_wgrad%s_kernel (masked 32->32 k x k convolutions, %s, forward + data gradient over the kept taps, weight gradient over all taps)" % (("", "", conv_label) if args.dtype == "f32" else ("_b16", "_b16", conv_label))),
         hbm_view("batchnorm", "bn_reduce_v4 / bn_apply_{fwd,bwd}_v4 (BatchNorm + residual + ELU, forward and backward)"),
         hbm_view("conv_pointwise", "conv1x1_kernel / conv1x1_wgrad_kernel (pointwise 32/64-channel convolutions)"),
-        mfma_view("gemm_" + args.dtype, "lv_gemm_%s_kernel (im2col convolutions of the ResNet encoder and the MaskA block, linear layers)" % args.dtype),
+        mfma_view(gemm_group, "lv_%s_kernel (im2col convolutions of the ResNet encoder and the MaskA block, linear layers)" % gemm_group),
     ) if v]
     views.sort(key=lambda v: -v["ms_per_step"])
     if views:
@@ -333,8 +338,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="yahoo", choices=sorted(WORKLOADS))
     ap.add_argument("--graph", type=int, default=0, help="replay the step as captured hipGraphs (no per-kernel events)")
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
-                    help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "bf16x3"],
+                    help="arithmetic of the large GEMMs: f32 = exact-f32 MFMA (parity path), bf16 = bf16 MFMA, f32 accumulate; bf16x3 "
+                         "(--workload omniglot only) = the decoder's direct convolutions with every operand split into two bf16 numbers, "
+                         "three bf16 MFMAs per product, f32 accumulate (f32-like results: holds the f32 fixtures' bounds), the rest exact f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the f32 parity run and the side runs of the other BASELINE.json configurations (profiling passes: only the timed arithmetic runs)")
     ap.add_argument("--persistent", type=int, default=1, help="forward LSTM recurrences as one persistent launch (bf16 path)")
@@ -383,6 +390,8 @@ def main():
     cfg = WORKLOADS[args.workload]
     if args.workload == "omniglot":
         return bench_omniglot(args, dev, rank, world)
+    if args.dtype == "bf16x3":
+        raise SystemExit("--dtype bf16x3 names the split-bf16 direct convolutions of --workload omniglot; the text workloads take f32 or bf16")
     V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
 
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
@@ -598,6 +607,13 @@ def main():
                                 "steps": om["steps"], "workload": om["config"]["workload"] + ", hipGraph replay",
                                 "dominant_group": {k: om["roofline"].get(k) for k in ("bound", "frac", "achieved", "unit", "ms_per_step", "kernel")},
                                 "other_groups": [{k: g.get(k) for k in ("bound", "frac", "ms_per_step")} for g in om.get("roofline_other_groups", [])]}
+            # the same with the decoder's direct convolutions on split-bf16 operands (precision="bf16x3": holds the f32 fixtures' bounds)
+            oa.dtype = "bf16x3"
+            om3 = measure_omniglot(oa, dev, 0, 1, cpu_baseline=False, profile_eager=True)
+            side["omniglot_bf16x3"] = {"value": om3["value"], "unit": om3["unit"], "ms_per_step": om3["ms_per_step"], "dtype": om3["dtype"],
+                                       "steps": om3["steps"], "workload": om3["config"]["workload"] + ", hipGraph replay",
+                                       "dominant_group": {k: om3["roofline"].get(k) for k in ("bound", "frac", "achieved", "unit", "ms_per_step", "kernel")},
+                                       "other_groups": [{k: g.get(k) for k in ("bound", "frac", "ms_per_step")} for g in om3.get("roofline_other_groups", [])]}
         except Exception as e:      # noqa  (a side run must never cost the headline line)
             side["error"] = repr(e)[:300]
         out["side_runs"] = side

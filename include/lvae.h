@@ -376,6 +376,15 @@ int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw /*[32][32][k*
 int lv_conv1x1_f32(const float* in, const float* w, float* out, long P, int Cin, int Cout, int w_transposed, int accumulate,
                    void* stream);
 long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
+/* Split-bf16 forms of lv_conv32_f32 / lv_conv32_bnstat_f32 (round 4): every operand as hi + lo with hi = bf16(x), lo = bf16(x - hi),
+ * products on the bf16 matrix pipe with f32 accumulation.  terms = 3: hi*hi' + hi*lo' + lo*hi' (results agree with the exact-f32 form
+ * to ~1e-5 relative per product term before summation); terms = 1: plain bf16 operands.  wp16: lv_conv32_pack_b16's image (a buffer of
+ * lv_conv32_wpack_floats(ntaps) floats).  bn_partial: NULL, or the BatchNorm stage-1 partials as lv_conv32_bnstat_f32 (forward only). */
+int lv_conv32_pack_b16(const float* w, void* wp16, int k, int ntaps, int transpose, void* stream);
+int lv_conv32_b16(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror, int accumulate,
+                  int terms, void* stream);
+/* ... and of lv_conv32_wgrad_f32 (same scratch and partial layout: lv_wgrad_reduce_batched serves both). */
+int lv_conv32_wgrad_b16(const float* x, const float* dy, float* dw, float* ws, int N, int k, int accumulate, int terms, void* stream);
 /* All weight-gradient reductions of a backward pass in one launch: lv_conv32_wgrad_f32 / lv_conv1x1_wgrad_f32 called with
  * dw = NULL leave their partial blocks in ws (lv_conv32_wgrad_parts / lv_conv1x1_wgrad_parts of them), and
  * lv_wgrad_reduce_batched sums every layer's partials into its gradient.  desc (HOST memory): 4 int64 per layer =

@@ -40,8 +40,16 @@ for N in (36, 50, 73, 100):
         t_s = timeit(lambda: lib.lv_conv32_bnstat_f32(P(x), P(wp), P(y), P(part), N, k, nt, s))
         t_w = timeit(lambda: lib.lv_conv32_wgrad_f32(P(x), P(dy), P(dw), P(ws), N, k, 0, s))
         fl = 2.0 * N * 784 * 32 * 32
-        print("N=%3d k=%d nt=%2d  fwd %6.1f us (%5.1f TF)  fwd+bnstat %6.1f us  wgrad(+reduce) %6.1f us (%5.1f TF)" %
-              (N, k, nt, t_f, fl * nt / t_f / 1e6, t_s, t_w, fl * k * k / t_w / 1e6))
+        wp16 = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+        lib.lv_conv32_pack_b16(P(w), P(wp16), k, nt, 0, s)
+        t_b3 = timeit(lambda: lib.lv_conv32_b16(P(x), P(wp16), P(y), P(part), N, k, nt, 0, 0, 3, s))
+        t_b1 = timeit(lambda: lib.lv_conv32_b16(P(x), P(wp16), P(y), P(part), N, k, nt, 0, 0, 1, s))
+        t_w1 = timeit(lambda: lib.lv_conv32_wgrad_f32(P(x), P(dy), None, P(ws), N, k, 0, s))
+        t_w3 = timeit(lambda: lib.lv_conv32_wgrad_b16(P(x), P(dy), None, P(ws), N, k, 0, 3, s))
+        t_wb = timeit(lambda: lib.lv_conv32_wgrad_b16(P(x), P(dy), None, P(ws), N, k, 0, 1, s))
+        print("N=%3d k=%d nt=%2d  fwd %6.1f us (%5.1f TF)  fwd+bnstat %6.1f us  split-bf16 x3 %6.1f us  bf16 %6.1f us | wgrad(+reduce) %6.1f us (%5.1f TF)"
+              "  stage 1 alone: f32 %6.1f  x3 %6.1f  bf16 %6.1f us" %
+              (N, k, nt, t_f, fl * nt / t_f / 1e6, t_s, t_b3, t_b1, t_w, fl * k * k / t_w / 1e6, t_w1, t_w3, t_wb))
 for N in (50,):
     Pn = N * 784
     for Cin, Cout in ((64, 32), (32, 64)):

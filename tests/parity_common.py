@@ -138,29 +138,34 @@ def check_image_step_dropin(name, device):
     return fx
 
 
-def check_image_step_fused(name, device, use_graph=False):
+def check_image_step_fused(name, device, use_graph=False, precision="f32", rtol=RTOL, norm_tol=5e-4, upd_tol=2e-5):
+    """precision = "bf16x3" (the direct convolutions on split-bf16 operands) is held to the SAME bounds as the exact-f32 path;
+    "bf16" (plain bf16 operands) to the ones its caller states.  Returns the measured errors."""
     from vae_lagging_encoder_amd.trainer import AggressiveImageTrainer
     fx = load(name)
     vae = build_image_vae(device, int(fx["model_seed"]))
-    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, use_graph=use_graph)
+    tr = AggressiveImageTrainer(vae, lr=1e-3, clip=5.0, use_graph=use_graph, precision=precision)
     x = torch.from_numpy(fx["x"]).float().to(device)
     tr.step(x, float(fx["kl_weight"]), eps=torch.from_numpy(fx["eps"]).to(device))
     st = tr.read_stats()
-    assert abs(st["loss_sum"] - float(fx["loss"].sum())) / abs(float(fx["loss"].sum())) < RTOL
-    assert abs(st["kl_sum"] - float(fx["kl"].sum())) / abs(float(fx["kl"].sum())) < RTOL
-    assert abs(st["norm"] - float(fx["total_norm64"])) / float(fx["total_norm64"]) < 5e-4
+    errs = dict(loss=abs(st["loss_sum"] - float(fx["loss"].sum())) / abs(float(fx["loss"].sum())),
+                kl=abs(st["kl_sum"] - float(fx["kl"].sum())) / abs(float(fx["kl"].sum())),
+                norm=abs(st["norm"] - float(fx["total_norm64"])) / float(fx["total_norm64"]), upd=0.0)
+    assert errs["loss"] < rtol and errs["kl"] < rtol and errs["norm"] < norm_tol, errs
     sd = vae.state_dict()
     for k, p in vae.named_parameters():
         if k.startswith("encoder."):
             idx = torch.from_numpy(fx["sample_idx/" + k])
             upd_ref = torch.from_numpy(fx["sample_new/" + k]) - torch.from_numpy(fx["sample_p0/" + k])
             upd_got = sd[k].reshape(-1)[idx].cpu() - torch.from_numpy(fx["sample_p0/" + k])
-            assert float((upd_got - upd_ref).abs().max()) < 2e-5, k
+            errs["upd"] = max(errs["upd"], float((upd_got - upd_ref).abs().max()))
+            assert float((upd_got - upd_ref).abs().max()) < upd_tol, (k, float((upd_got - upd_ref).abs().max()))
         else:   # decoder untouched except MaskedConv2d's in-place weight masking
             idx = torch.from_numpy(fx["sample_idx/" + k])
             got = sd[k].reshape(-1)[idx].cpu()
             ref = torch.from_numpy(fx["sample_p0/" + k])
             assert bool(((got == ref) | (got == 0)).all()), k
+    return errs
 
 
 # ---------------------------------------------------------------------------------------------------------------------

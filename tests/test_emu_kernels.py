@@ -185,6 +185,11 @@ def test_conv32_direct(emu_backend, cfg):
     K.test_conv32_direct_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [(2, 7, True, 3), (1, 5, True, 3), (3, 3, True, 1), (2, 3, False, 3)])
+def test_conv32_direct_split_bf16(emu_backend, cfg):
+    K.test_conv32_direct_split_bf16(emu_backend, CPU, *cfg)
+
+
 @pytest.mark.parametrize("cfg", [(1000, 64, 32), (300, 32, 64), (129, 64, 64), (70, 32, 32)])
 def test_conv1x1(emu_backend, cfg):
     K.test_conv1x1_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)

@@ -1300,6 +1300,55 @@ def test_conv32_direct_fwd_dgrad_wgrad(lib, hip_device, N, k, masked):
     assert float((dw.cpu().double() - wfull.grad).abs().max()) < 2e-5 * float(wfull.grad.abs().max())
 
 
+@pytest.mark.parametrize("N,k,masked", [(2, 7, True), (1, 5, True), (3, 3, True), (2, 3, False), (50, 7, True), (50, 5, True), (37, 5, False)])
+@pytest.mark.parametrize("terms", [3, 1])
+def test_conv32_direct_split_bf16(lib, hip_device, N, k, masked, terms):
+    """lv_conv32_b16: the same convolution with every operand as hi + lo of two bf16 numbers on the bf16 matrix pipe, against torch
+    conv2d in float64 -- terms = 3 (hi*hi' + hi*lo' + lo*hi') to f32-like accuracy, terms = 1 (plain bf16 operands) to bf16's;
+    forward with the BatchNorm partials, data gradient with the transposed image, the accumulate flag."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(N * 10 + k)
+    C, S = 32, 28
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5
+    dy = torch.randn(N, C, S, S, generator=g)
+    nt = (k // 2) * k + k // 2 + 1 if masked else k * k
+    mask = torch.zeros(k * k)
+    mask[:nt] = 1
+    wm = (w.reshape(C, C, k * k) * mask).reshape(C, C, k, k)
+    x64 = x.double().requires_grad_(True)
+    y_r = torch.nn.functional.conv2d(x64, wm.double(), padding=k // 2)
+    y_r.backward(dy.double())
+    tol = 3e-5 if terms == 3 else 2e-2
+    xn, dyn = _nhwc(x).to(dev), _nhwc(dy).to(dev)
+    wd = wm.contiguous().to(dev)
+    wp = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    wpt = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    lib.lv_conv32_pack_b16(P(wd), P(wp), k, nt, 0, _s(dev))
+    lib.lv_conv32_pack_b16(P(wd), P(wpt), k, nt, 1, _s(dev))
+    y = torch.full((N * S * S, C), float("nan"), device=dev)
+    nblk = lib.lv_conv32_blocks(N)
+    part = torch.full((nblk, 2, C), float("nan"), device=dev)
+    lib.lv_conv32_b16(P(xn), P(wp), P(y), P(part), N, k, nt, 0, 0, terms, _s(dev))
+    assert float((_nchw(y.cpu(), N, S, S).double() - y_r.detach()).abs().max()) < tol * float(y_r.abs().max())
+    # the BatchNorm stage-1 partials are those of the values that were stored
+    yd = y.double()
+    assert float((part[:, 0].double().sum(0) - yd.sum(0)).abs().max()) < 1e-4 * float(yd.abs().sum(0).max())
+    assert float((part[:, 1].double().sum(0) - (yd * yd).sum(0)).abs().max()) < 1e-4 * float((yd * yd).sum(0).max())
+    dx = torch.full((N * S * S, C), float("nan"), device=dev)
+    lib.lv_conv32_b16(P(dyn), P(wpt), P(dx), None, N, k, nt, 1, 0, terms, _s(dev))
+    assert float((_nchw(dx.cpu(), N, S, S).double() - x64.grad).abs().max()) < tol * float(x64.grad.abs().max())
+    lib.lv_conv32_b16(P(dyn), P(wpt), P(dx), None, N, k, nt, 1, 1, terms, _s(dev))
+    assert float((_nchw(dx.cpu(), N, S, S).double() - 2 * x64.grad).abs().max()) < 2 * tol * float(x64.grad.abs().max())
+    # weight gradient over ALL taps, K = pixels through the transposing LDS reads
+    wfull = wm.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wfull, padding=k // 2).backward(dy.double())
+    ws = torch.full((lib.lv_conv32_wgrad_ws_floats(N, k),), float("nan"), device=dev)
+    dw = torch.full((C, C, k, k), float("nan"), device=dev)
+    lib.lv_conv32_wgrad_b16(P(xn), P(dyn), P(dw), P(ws), N, k, 0, terms, _s(dev))
+    assert float((dw.cpu().double() - wfull.grad).abs().max()) < tol * float(wfull.grad.abs().max())
+
+
 @pytest.mark.parametrize("P_,Cin,Cout", [(39200, 64, 32), (1000, 32, 64), (300, 64, 64), (129, 32, 32)])
 def test_conv1x1_fwd_dgrad_wgrad(lib, hip_device, P_, Cin, Cout):
     dev = hip_device

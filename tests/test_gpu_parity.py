@@ -388,6 +388,39 @@ def test_image_step_fused_matches_reference_fixture(hip_device, name):
     pc.check_image_step_fused(name, hip_device)
 
 
+@pytest.mark.parametrize("name", ["image_b6", "image_b50"])
+def test_image_step_split_bf16_convolutions_hold_the_f32_bounds(hip_device, name):
+    """precision="bf16x3": the decoder's 23 direct convolutions (forward, data and weight gradients) with every operand as
+    hi + lo of two bf16 numbers on the bf16 matrix pipe -- against the SAME reference fixtures and the SAME bounds as the exact-f32
+    path (loss / KL 1e-4, clip norm 5e-4, Adam updates 2e-5); also through a captured hipGraph."""
+    e = pc.check_image_step_fused(name, hip_device, precision="bf16x3")
+    pc.check_image_step_fused(name, hip_device, precision="bf16x3", use_graph=True)
+    _record_image_parity(name, "bf16x3", e)
+
+
+@pytest.mark.parametrize("name", ["image_b6", "image_b50"])
+def test_image_step_bf16_convolutions_contract(hip_device, name):
+    """precision="bf16": plain bf16 operands in the direct convolutions and the im2col GEMMs, f32 accumulation: the configuration's
+    own contract (as the text path's): loss within 1e-3, KL within 1e-2, clip norm within 2e-2 of the reference."""
+    e = pc.check_image_step_fused(name, hip_device, precision="bf16", rtol=1e-2, norm_tol=2e-2, upd_tol=2.1e-3)
+    assert e["loss"] < 1e-3, e
+    _record_image_parity(name, "bf16", e)
+
+
+def _record_image_parity(name, precision, errs):
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = os.path.join("gpurun_out", "image_parity.json")
+    rec = {}
+    if os.path.exists(path):
+        with open(path) as fh:
+            rec = json.load(fh)
+    rec["%s/%s" % (name, precision)] = {k: float(v) for k, v in errs.items()}
+    with open(path, "w") as fh:
+        json.dump(rec, fh, indent=1)
+
+
 def test_image_hipgraph_replay_equals_eager(hip_device):
     """Two steps through captured-graph replay (first call = eager warm-up + capture, second = replay) land on the
     same weights / statistics as two eager steps."""

@@ -119,6 +119,9 @@ SIGNATURES = {
     "lv_conv32_wgrad_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "lv_conv1x1_f32": [_vp, _vp, _vp, _l, _i, _i, _i, _i, _vp],
     "lv_conv1x1_wgrad_ws_floats": [_i, _i],
+    "lv_conv32_pack_b16": [_vp, _vp, _i, _i, _i, _vp],
+    "lv_conv32_b16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lv_conv32_wgrad_b16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_conv32_wgrad_parts": [_i, _i],
     "lv_conv1x1_wgrad_parts": [_l],
     "lv_wgrad_reduce_batched": [_vp, _i, _vp],

@@ -162,6 +162,176 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     }
 }
 
+// ---- split-bf16 forms of the same convolution (round 4) -------------------------------------------------------------------------
+// The exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32: 64 cycles for 4096 multiply-adds) is what bounds the 5 x 5 and 7 x 7 masked
+// convolutions (~1 us per tap at B = 50, profiles/microbench/conv32_probe.py).  Here every operand is written as the sum of two
+// bf16 numbers, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|), and a product as
+// hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with f32 accumulation (TERMS = 3: the dropped lo*lo' term and the
+// representation error are ~2^-16 relative per product, i.e. f32-like sums; TERMS = 1: plain bf16 operands, hi*hi' only): 6 (2)
+// instructions of 32 cycles per tap instead of 16 of 64.  The split happens ONCE per element -- activations when the halo is staged
+// into LDS (two bf16 images, pixel pitch 80 bytes = 5 sixteen-byte slots: conflict-free ds_read_b128 of a pixel's 8-channel
+// group), weights when they are packed -- so the tap loop is LDS reads, weight-fragment loads and MFMAs only.
+// A operand: lane (m = l & 31: pixel, kh = l >> 5) holds channels 16 ks + 8 kh + [0, 8) of k-step ks; B: lane (n = l & 31: output
+// channel, kh) the same channels of the tap's weight slice; D as in the f32 kernel.
+constexpr int PPB = 80;                // bytes per halo pixel of a bf16 image
+
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = lv_f32_to_bf16_bits(x);
+    const uint32_t hb = hi << 16;                      // bf16 = the high half of an f32
+    float hf;
+    memcpy(&hf, &hb, 4);
+    lo = lv_f32_to_bf16_bits(x - hf);
+}
+
+// wp16[t][ks (2)][part (hi, lo)][lane (64)] uint4: lane (j = l & 31, kh = l >> 5) holds, for output channel j, the weights of the
+// input channels c = 16 ks + 8 kh + e, e < 8, at tap t (transpose: roles of the channel indices swapped, as conv32_pack_kernel)
+__global__ __launch_bounds__(256) void conv32_pack_b16_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int KK, int ntaps,
+                                                              int transpose) {
+    const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (idx >= ntaps * 4 * 64) return;
+    const int l = idx & 63, part = (idx >> 6) & 1, ks = (idx >> 7) & 1, t = idx >> 8;
+    const int j = l & 31, c0 = 16 * ks + 8 * (l >> 5);
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float v = transpose ? w[((long)c * CC + j) * KK + t] : w[((long)j * CC + c) * KK + t];
+        uint32_t hi, lo;
+        split_bf16(v, hi, lo);
+        h[e] = part ? lo : hi;
+    }
+    wp[idx] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+template <int KS, int TERMS>
+__global__ __launch_bounds__(256) void conv32_direct_b16_kernel(const float* __restrict__ in, const uint4* __restrict__ wp,
+                                                                float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
+                                                                int mirror, int accumulate) {
+    constexpr int TRW = TR / KS;         // image rows per workgroup
+    constexpr int HALO_PIX = (TRW + KMAX - 1) * (IW + KMAX - 1);
+    __shared__ __attribute__((aligned(16))) unsigned char halo_hi[HALO_PIX * PPB];
+    __shared__ __attribute__((aligned(16))) unsigned char halo_lo[TERMS == 3 ? HALO_PIX * PPB : 16];
+    __shared__ float sstat[TRW][2][CC];
+    __shared__ float red[KS == 2 ? TRW * 16 * 64 : 1];
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wr = w % TRW, wk = w / TRW;                    // this wave's row of the tile and its share of the taps
+    const int n = (int)blockIdx.x / (IH / TRW), r0 = ((int)blockIdx.x % (IH / TRW)) * TRW;
+    const int p = k / 2, HW = IW + 2 * p, HR = TRW + 2 * p;
+    {
+        // staging as in conv32_direct_kernel (all loads first, unconditional from clamped coordinates, zero outside the image by a
+        // select), each float4 split into four (hi, lo) pairs on its way into LDS
+        float4 hv[HALO_F4];
+        uint32_t inside = 0u;
+#pragma unroll
+        for (int u = 0; u < HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            const int c4 = i % (CC / 4), hx = (i / (CC / 4)) % HW, hy = i / ((CC / 4) * HW);
+            const int gy = r0 - p + hy, gx = hx - p;
+            if (hy < HR && gy >= 0 && gy < IH && gx >= 0 && gx < IW) inside |= 1u << u;
+            const int cy = gy < 0 ? 0 : (gy < IH ? gy : IH - 1), cx = gx < 0 ? 0 : (gx < IW ? gx : IW - 1);
+            hv[u] = *reinterpret_cast<const float4*>(in + (((long)n * IH + cy) * IW + cx) * CC + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            const bool ok = (inside >> u) & 1u;
+            const float v[4] = {ok ? hv[u].x : 0.f, ok ? hv[u].y : 0.f, ok ? hv[u].z : 0.f, ok ? hv[u].w : 0.f};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(v[e], hi[e], lo[e]);
+            if (i < HR * HW * (CC / 4)) {
+                const int off = (i / (CC / 4)) * PPB + 8 * (i % (CC / 4));
+                *reinterpret_cast<uint2*>(&halo_hi[off]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                if constexpr (TERMS == 3) *reinterpret_cast<uint2*>(&halo_lo[off]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int px = (l & 31) < IW ? (l & 31) : IW - 1;        // lanes 28..31 shadow pixel 27: their rows of the result are dropped
+    const int kh = l >> 5;
+    const int t_lo = wk == 0 ? 0 : (ntaps + 1) / 2;          // KS = 1: all taps
+    const int t_hi = (KS == 1 || wk == 1) ? ntaps : (ntaps + 1) / 2;
+    constexpr int NB = TERMS == 3 ? 4 : 2;                   // weight fragments per tap: [ks][part]
+    auto fetch_b = [&](uint4 (&b)[4], int t) {
+        const uint4* bw = wp + (long)(t < ntaps ? t : ntaps - 1) * 4 * 64 + l;
+        b[0] = bw[0];                                        // ks 0, hi
+        b[2] = bw[2 * 64];                                   // ks 1, hi
+        if constexpr (TERMS == 3) { b[1] = bw[64]; b[3] = bw[3 * 64]; }
+    };
+    auto tap = [&](const uint4 (&b)[4], int t) {
+        int dy = t / k - p, dx = t % k - p;
+        if (mirror) { dy = -dy; dx = -dx; }
+        const int off = ((wr + p + dy) * HW + (px + p + dx)) * PPB + 16 * kh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 ah = *reinterpret_cast<const uint4*>(&halo_hi[off + 32 * ks]);
+            if constexpr (TERMS == 3) {
+                const uint4 al = *reinterpret_cast<const uint4*>(&halo_lo[off + 32 * ks]);
+                acc = lv_mfma_32x32x16_bf16(al, b[2 * ks], acc);          // the small terms first
+                acc = lv_mfma_32x32x16_bf16(ah, b[2 * ks + 1], acc);
+            }
+            acc = lv_mfma_32x32x16_bf16(ah, b[2 * ks], acc);
+        }
+    };
+    (void)NB;
+    uint4 b0[4], b1[4];
+    fetch_b(b0, t_lo);
+    int t = t_lo;
+    for (; t + 1 < t_hi; t += 2) {
+        fetch_b(b1, t + 1);
+        LV_SCHED_BARRIER();
+        tap(b0, t);
+        LV_SCHED_BARRIER();
+        fetch_b(b0, t + 2);
+        LV_SCHED_BARRIER();
+        tap(b1, t + 1);
+        LV_SCHED_BARRIER();
+    }
+    if (t < t_hi) tap(b0, t);
+    if constexpr (KS == 2) {             // the two tap halves of a row meet in LDS
+        if (wk == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wr * 16 + e) * 64 + l] = acc[e];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[(wr * 16 + e) * 64 + l];
+        }
+    }
+    const int r = r0 + wr;
+    const int col = l & 31;
+    float st0 = 0.f, st1 = 0.f;
+    if (wk == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            if (x < IW) {
+                float* o = out + (((long)n * IH + r) * IW + x) * CC + col;
+                const float v = accumulate ? *o + acc[e] : acc[e];
+                *o = v;
+                st0 += v; st1 += v * v;
+            }
+        }
+    }
+    if (bn_partial) {
+        st0 += __shfl_xor(st0, 32, 64);
+        st1 += __shfl_xor(st1, 32, 64);
+        if (wk == 0 && l < 32) { sstat[wr][0][l] = st0; sstat[wr][1][l] = st1; }
+        __syncthreads();
+        if (tid < 2 * CC) {
+            const int q = tid / CC, c = tid % CC;
+            float tsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TRW; ++i) tsum += sstat[i][q][c];
+            bn_partial[((long)blockIdx.x * 2 + q) * CC + c] = tsum;
+        }
+    }
+}
+
 // tap split (KS = 2) only where it shortens the schedule: wave-rows on 1024 SIMDs, rounds x time per unit
 static inline int conv32_ks(int N) {
     const long units = (long)N * IH;                         // wave-rows
@@ -305,6 +475,138 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(const float* __restri
     }
 }
 
+// ---- split-bf16 weight gradient (round 4) -------------------------------------------------------------------------------------
+// D_t[ci][co] += sum over the tile's 112 pixels of x[pixel + off_t][ci] dy[pixel][co] on v_mfma_f32_32x32x16_bf16: M = ci, N = co,
+// K = 16 PIXELS per instruction (seven k-steps cover a 4-row tile exactly; a k-step's pixels may straddle an image row: every lane
+// computes the address of its own pixel).  Both operands are K-contiguous fragments of images that are CHANNEL-contiguous in LDS
+// (NHWC), i.e. transposed reads: ds_read_b64_tr_b16 (lv_ds_read_tr16_b64) hands lane (m = l & 31, kh = l >> 5) the four pixels
+// 8 kh + 4 h + [0, 4) of its channel from four pixel rows of the image, two reads per fragment.  x and dy are split into (hi, lo)
+// bf16 images when a tile is staged (pixel pitch 80 bytes); a wave owns whole taps (t = lane + lanes q, q < 4, lanes = 4 waves x
+// gridDim.y) on ALL pixels of the tile: the dy fragments of a k-step are read once and reused by the wave's taps.  Partials go to
+// the same [slab][t][ci][co] scratch as conv32_wgrad_kernel's, so the reduction stage is shared.
+constexpr int WGB_TAPS = 4;
+
+template <int NQ, int TERMS>
+__device__ __forceinline__ void wgrad_b16_tile(const unsigned char* xh, const unsigned char* xl, const unsigned char* gh,
+                                               const unsigned char* gl, const int (&offx)[14], const int (&offg)[14],
+                                               const int (&toff)[WGB_TAPS], f32x16 (&acc)[WGB_TAPS]) {
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const uint2 b0 = lv_ds_read_tr16_b64(gh + offg[2 * ks]), b1 = lv_ds_read_tr16_b64(gh + offg[2 * ks + 1]);
+        const uint4 bh = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        uint4 bl = bh;
+        if constexpr (TERMS == 3) {
+            const uint2 c0 = lv_ds_read_tr16_b64(gl + offg[2 * ks]), c1 = lv_ds_read_tr16_b64(gl + offg[2 * ks + 1]);
+            bl = make_uint4(c0.x, c0.y, c1.x, c1.y);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint2 a0 = lv_ds_read_tr16_b64(xh + offx[2 * ks] + toff[q]), a1 = lv_ds_read_tr16_b64(xh + offx[2 * ks + 1] + toff[q]);
+            const uint4 ah = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            if constexpr (TERMS == 3) {
+                const uint2 d0 = lv_ds_read_tr16_b64(xl + offx[2 * ks] + toff[q]), d1 = lv_ds_read_tr16_b64(xl + offx[2 * ks + 1] + toff[q]);
+                const uint4 al = make_uint4(d0.x, d0.y, d1.x, d1.y);
+                acc[q] = lv_mfma_32x32x16_bf16(al, bh, acc[q]);
+                acc[q] = lv_mfma_32x32x16_bf16(ah, bl, acc[q]);
+            }
+            acc[q] = lv_mfma_32x32x16_bf16(ah, bh, acc[q]);
+        }
+    }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void conv32_wgrad_b16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dwp, int N, int k, int tiles_per_slab) {
+    constexpr int HALO_PIX = (TR + KMAX - 1) * (IW + KMAX - 1), GY_PIX = TR * IW;
+    __shared__ __attribute__((aligned(16))) unsigned char xh[HALO_PIX * PPB];
+    __shared__ __attribute__((aligned(16))) unsigned char xl[TERMS == 3 ? HALO_PIX * PPB : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char gh[GY_PIX * PPB];
+    __shared__ __attribute__((aligned(16))) unsigned char gl[TERMS == 3 ? GY_PIX * PPB : 16];
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int KK = k * k, p = k / 2, HW = IW + 2 * p, HR = TR + 2 * p;
+    const int nw = 4 * (int)gridDim.y, gw = (int)blockIdx.y * 4 + w;      // tap lanes: every wave owns whole taps on all pixels
+    f32x16 acc[WGB_TAPS];
+#pragma unroll
+    for (int q = 0; q < WGB_TAPS; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const int ntiles = N * (IH / TR);
+    const int t0 = (int)blockIdx.x * tiles_per_slab;
+    const int t1 = t0 + tiles_per_slab < ntiles ? t0 + tiles_per_slab : ntiles;
+    // this lane's part in the transposing reads: r = lane within its group of 16 points at pixel row (r >> 2) of the four and at
+    // channels m0 + 4 (r & 3) + [0, 4); the group (l >> 4) fixes m0 = 16 (g & 1) and the k half 8 (g >> 1)
+    const int r = l & 15, g16 = l >> 4;
+    const int chb = (16 * (g16 & 1) + 4 * (r & 3)) * 2, kb = 8 * (g16 >> 1) + (r >> 2);
+    int offx[14], offg[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const int q = 16 * (i >> 1) + kb + 4 * (i & 1);                  // pixel of the tile, row-major over its 4 x 28 pixels
+        offx[i] = ((q / IW) * HW + q % IW) * PPB + chb;
+        offg[i] = q * PPB + chb;
+    }
+    int toff[WGB_TAPS];
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < WGB_TAPS; ++q) {
+        const int t = gw + nw * q;
+        if (t < KK) nq = q + 1;
+        const int tt = t < KK ? t : 0;
+        toff[q] = ((tt / k) * HW + tt % k) * PPB;
+    }
+    nq = lv_wave_uniform(nq);
+    float4 hv[WG_HALO_F4], gv[WG_GY_F4];
+    if (t0 < t1) wgrad_fetch(x, dy, t0, p, HW, HR, tid, hv, gv);
+    for (int tile = t0; tile < t1; ++tile) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < WG_HALO_F4; ++u) {
+            const int i = tid + 256 * u;
+            const float v[4] = {hv[u].x, hv[u].y, hv[u].z, hv[u].w};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(v[e], hi[e], lo[e]);
+            if (i < HR * HW * (CC / 4)) {
+                const int off = (i / (CC / 4)) * PPB + 8 * (i % (CC / 4));
+                *reinterpret_cast<uint2*>(&xh[off]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                if constexpr (TERMS == 3) *reinterpret_cast<uint2*>(&xl[off]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WG_GY_F4; ++u) {
+            const int i = tid + 256 * u;
+            const float v[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(v[e], hi[e], lo[e]);
+            if (i < TR * IW * (CC / 4)) {
+                const int off = (i / (CC / 4)) * PPB + 8 * (i % (CC / 4));
+                *reinterpret_cast<uint2*>(&gh[off]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                if constexpr (TERMS == 3) *reinterpret_cast<uint2*>(&gl[off]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
+        __syncthreads();
+        if (tile + 1 < t1) wgrad_fetch(x, dy, tile + 1, p, HW, HR, tid, hv, gv);
+        switch (nq) {          // wave-uniform: the tap loop is unrolled with no predication
+            case 1: wgrad_b16_tile<1, TERMS>(xh, xl, gh, gl, offx, offg, toff, acc); break;
+            case 2: wgrad_b16_tile<2, TERMS>(xh, xl, gh, gl, offx, offg, toff, acc); break;
+            case 3: wgrad_b16_tile<3, TERMS>(xh, xl, gh, gl, offx, offg, toff, acc); break;
+            case 4: wgrad_b16_tile<4, TERMS>(xh, xl, gh, gl, offx, offg, toff, acc); break;
+            default: break;
+        }
+    }
+    float* outp = dwp + (long)blockIdx.x * KK * CC * CC;
+#pragma unroll
+    for (int q = 0; q < WGB_TAPS; ++q) {
+        const int t = gw + nw * q;
+        if (t >= KK) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);      // ci
+            outp[((long)t * CC + row) * CC + (l & 31)] = acc[q][e];
+        }
+    }
+}
+
 // stage 2: dw[co][ci][t] (=|+=) sum_slab dwp[slab][t][ci][co]   (fixed order; writes the reference's parameter layout)
 __global__ __launch_bounds__(256) void conv32_wgrad_reduce_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int KK,
                                                                   int slabs, int accumulate) {
@@ -380,6 +682,36 @@ extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out
     return LV_OK;
 }
 
+// The split-bf16 forms (see conv32_direct_b16_kernel): wp16 = lv_conv32_pack_b16(w, ., transpose) holds lv_conv32_wpack_floats(ntaps)
+// floats' worth of bytes (the same buffer size as the f32 image).  terms: 3 = hi*hi' + hi*lo' + lo*hi' (f32-like results), 1 = plain
+// bf16 operands.  bn_partial may be NULL (then as lv_conv32_f32), else as lv_conv32_bnstat_f32 (forward only).
+extern "C" int lv_conv32_pack_b16(const float* w, void* wp16, int k, int ntaps, int transpose, void* stream) {
+    if (!w || !wp16) return LV_ERR_ARG;
+    if (k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
+    LV_LAUNCH(conv32_pack_b16_kernel, dim3((unsigned)lv_cdiv((long)ntaps * 4 * 64, 256)), dim3(256), 0, stream, w,
+              reinterpret_cast<uint4*>(wp16), k * k, ntaps, transpose);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_conv32_b16(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror,
+                             int accumulate, int terms, void* stream) {
+    if (!in || !wp16 || !out) return LV_ERR_ARG;
+    if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
+    if (terms != 1 && terms != 3) return LV_ERR_ARG;
+    if (bn_partial && (mirror || accumulate)) return LV_ERR_ARG;
+    if (((((uintptr_t)in) | ((uintptr_t)wp16)) & 15) != 0) return LV_ERR_ALIGN;
+    const uint4* wp = reinterpret_cast<const uint4*>(wp16);
+    const bool two = conv32_ks(N) == 2;
+    const dim3 grid((unsigned)(N * (IH / (two ? 2 : TR))));
+    if (two && terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<2, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
+    else if (two) LV_LAUNCH((conv32_direct_b16_kernel<2, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
+    else if (terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<1, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
+    else LV_LAUNCH((conv32_direct_b16_kernel<1, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
 // weight gradient over ALL k*k taps: dw [32][32][k*k] (=|+=) sum_pixels dy[p][co] x[p + off_t][ci]; ws: lv_conv32_wgrad_ws_floats
 // partial blocks lv_conv32_wgrad_f32 leaves in ws ([parts][k*k][32 ci][32 co]) -- what lv_wgrad_reduce_batched needs to know
 extern "C" int lv_conv32_wgrad_parts(int N, int k) {
@@ -396,6 +728,27 @@ extern "C" int lv_conv32_wgrad_f32(const float* x, const float* dy, float* dw, f
     const int tps = lv_cdiv(ntiles, slabs);
     const int used = lv_cdiv(ntiles, tps);
     LV_LAUNCH(conv32_wgrad_kernel, dim3((unsigned)used, (unsigned)wgrad_groups(k)), dim3(256), 0, stream, x, dy, ws, N, k, tps);
+    if (dw)
+        LV_LAUNCH(conv32_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)k * k * CC * CC, 256)), dim3(256), 0, stream, (const float*)ws,
+                  dw, k * k, used, accumulate);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// the split-bf16 form of lv_conv32_wgrad_f32 (same scratch, same partial layout, same reduction stage; terms as lv_conv32_b16)
+extern "C" int lv_conv32_wgrad_b16(const float* x, const float* dy, float* dw, float* ws, int N, int k, int accumulate, int terms,
+                                   void* stream) {
+    if (!x || !dy || !ws) return LV_ERR_ARG;
+    if (N <= 0 || k <= 0 || k > KMAX || !(k & 1)) return LV_ERR_SHAPE;
+    if (terms != 1 && terms != 3) return LV_ERR_ARG;
+    if (((((uintptr_t)x) | ((uintptr_t)dy)) & 15) != 0) return LV_ERR_ALIGN;
+    const int ntiles = N * (IH / TR);
+    const int slabs = lv_conv32_wgrad_slabs(N, k);
+    const int tps = lv_cdiv(ntiles, slabs);
+    const int used = lv_cdiv(ntiles, tps);
+    const dim3 grid((unsigned)used, (unsigned)wgrad_groups(k));
+    if (terms == 3) LV_LAUNCH(conv32_wgrad_b16_kernel<3>, grid, dim3(256), 0, stream, x, dy, ws, N, k, tps);
+    else LV_LAUNCH(conv32_wgrad_b16_kernel<1>, grid, dim3(256), 0, stream, x, dy, ws, N, k, tps);
     if (dw)
         LV_LAUNCH(conv32_wgrad_reduce_kernel, dim3((unsigned)lv_cdiv((long)k * k * CC * CC, 256)), dim3(256), 0, stream, (const float*)ws,
                   dw, k * k, used, accumulate);

@@ -27,6 +27,7 @@ class Act(object):
 
 
 _BN_MAX_BLOCKS = 1024         # partial blocks a BN workspace holds (lv_bn_workspace_floats)
+CONV_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}      # precision -> terms of lv_conv32_b16 / lv_conv32_wgrad_b16 (0: the exact-f32 entries)
 
 
 def pack_conv32(lib, s, ent):
@@ -34,15 +35,22 @@ def pack_conv32(lib, s, ent):
     weight.data.mul_(mask) (dec_pixelcnn_v2.py:29, G5) happens here, once per weight version."""
     if ent["mask"] is not None:
         lib.lv_mul_inplace_f32(P(ent["weight"]), P(ent["mask"]), ent["weight"].numel(), s)
-    lib.lv_conv32_pack_f32(P(ent["weight"]), P(ent["wp"]), ent["k"], ent["nt"], 0, s)
-    lib.lv_conv32_pack_f32(P(ent["weight"]), P(ent["wpt"]), ent["k"], ent["nt"], 1, s)
+    pack = lib.lv_conv32_pack_b16 if ent.get("terms", 0) else lib.lv_conv32_pack_f32      # (hi, lo) bf16 fragments / f32 fragments
+    pack(P(ent["weight"]), P(ent["wp"]), ent["k"], ent["nt"], 0, s)
+    pack(P(ent["weight"]), P(ent["wpt"]), ent["k"], ent["nt"], 1, s)
 
 
 class Tape(object):
     def __init__(self, device, precision="f32", train=True, wcache=None, wver=None):
         self.device = torch.device(device)
         self.lib = _eng.backend_for(self.device)
+        # "f32": exact-f32 matrix pipe everywhere.  "bf16x3": the direct 32 -> 32 convolutions with every operand split into two
+        # bf16 numbers (three bf16 MFMAs per product, f32 accumulation: f32-like results), the rest exact.  "bf16": plain bf16
+        # operands in the direct convolutions and in the im2col GEMMs.
+        assert precision in CONV_TERMS
         self.precision = precision
+        self.gemm_prec = "bf16" if precision == "bf16" else "f32"
+        self.conv_terms = CONV_TERMS[precision]
         self.train = train
         self.back = []
         self.grads = {}
@@ -164,7 +172,7 @@ class Tape(object):
             wg = self.f32(Cout, ldk)
             lib.lv_conv_pack_w_f32(P(weight), P(wg), Cout, Cin, KK, s)
         K = nt * Cin
-        _gemm(lib, s, 0, 1, Pout, Cout, K, P(col), ldk, P(wg), ldk, P(y), Cout, prec=self.precision)
+        _gemm(lib, s, 0, 1, Pout, Cout, K, P(col), ldk, P(wg), ldk, P(y), Cout, prec=self.gemm_prec)
         out = Act(y, x.N, Ho, Wo, Cout)
 
         def bwd():
@@ -173,18 +181,18 @@ class Tape(object):
                 return
             # weight gradient over ALL taps (masked taps keep non-zero grads in the reference: they enter the clip norm)
             if one_by_one:
-                _gemm(lib, s, 1, 0, Cout, Cin, Pout, P(dy), Cout, P(col), ldk, P(gview), Cin, prec=self.precision)
+                _gemm(lib, s, 1, 0, Cout, Cin, Pout, P(dy), Cout, P(col), ldk, P(gview), Cin, prec=self.gemm_prec)
             else:
                 dwg = self.f32(Cout, ldk)
-                _gemm(lib, s, 1, 0, Cout, ldk, Pout, P(dy), Cout, P(col), ldk, P(dwg), ldk, prec=self.precision)
+                _gemm(lib, s, 1, 0, Cout, ldk, Pout, P(dy), Cout, P(col), ldk, P(dwg), ldk, prec=self.gemm_prec)
                 lib.lv_conv_unpack_dw_f32(P(dwg), P(gview), Cout, Cin, KK, 0, s)
             if x.needs_grad:
                 dx = self.f32(x.P, Cin)
                 if one_by_one:
-                    _gemm(lib, s, 0, 0, Pout, Cin, Cout, P(dy), Cout, P(wg), ldk, P(dx), Cin, prec=self.precision)
+                    _gemm(lib, s, 0, 0, Pout, Cin, Cout, P(dy), Cout, P(wg), ldk, P(dx), Cin, prec=self.gemm_prec)
                 else:
                     dcol = self.f32(Pout, K)
-                    _gemm(lib, s, 0, 0, Pout, K, Cout, P(dy), Cout, P(wg), ldk, P(dcol), K, prec=self.precision)
+                    _gemm(lib, s, 0, 0, Pout, K, Cout, P(dy), Cout, P(wg), ldk, P(dcol), K, prec=self.gemm_prec)
                     lib.lv_col2im_f32(P(dcol), K, P(dx), x.N, x.H, x.W, Cin, Ho, Wo, kh, kw, pad, stride, nt, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
@@ -195,21 +203,28 @@ class Tape(object):
         gradient over the mask's tap prefix, weight gradient over all taps."""
         lib, s = self.lib, self.s()
         ent = self.wcache.get(id(weight))
+        terms = self.conv_terms
         if ent is None:
             n = lib.lv_conv32_wpack_floats(nt)
-            ent = self.wcache[id(weight)] = dict(ver=object(), wp=self.f32(n), wpt=self.f32(n), weight=weight, k=k, nt=nt, mask=mask)
-        if self.wver is None or ent["ver"] != self.wver:
+            ent = self.wcache[id(weight)] = dict(ver=object(), wp=self.f32(n), wpt=self.f32(n), weight=weight, k=k, nt=nt, mask=mask,
+                                                 terms=terms)
+        if self.wver is None or ent["ver"] != self.wver or ent.get("terms", 0) != terms:
+            ent["terms"] = terms                                       # (the images of another precision mode are of another format)
             pack_conv32(lib, s, ent)
             ent["ver"] = self.wver if self.wver is not None else object()
         wp, wpt = ent["wp"], ent["wpt"]
         y = self.f32(x.P, 32)
         out = Act(y, x.N, 28, 28, 32)
         with _eng._prof("conv_direct", 2.0 * x.P * 1024 * nt):            # flops over the taps the mask keeps
-            if bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS:
+            stats = bn_stats and lib.lv_conv32_blocks(x.N) <= _BN_MAX_BLOCKS
+            if terms:
+                lib.lv_conv32_b16(P(x.t), P(wp), P(y), P(self.bn_ws(32)) if stats else None, x.N, k, nt, 0, 0, terms, s)
+            elif stats:
                 lib.lv_conv32_bnstat_f32(P(x.t), P(wp), P(y), P(self.bn_ws(32)), x.N, k, nt, s)
-                out.bn_nblk = lib.lv_conv32_blocks(x.N)
             else:
                 lib.lv_conv32_f32(P(x.t), P(wp), P(y), x.N, k, nt, 0, 0, s)
+            if stats:
+                out.bn_nblk = lib.lv_conv32_blocks(x.N)
 
         def bwd():
             dy = self.grad_of(out)
@@ -217,12 +232,18 @@ class Tape(object):
                 return
             ws = self.f32(lib.lv_conv32_wgrad_ws_floats(x.N, k))
             with _eng._prof("conv_direct", 2.0 * x.P * 1024 * k * k):     # the weight gradient spans all k*k taps (G5)
-                lib.lv_conv32_wgrad_f32(P(x.t), P(dy), None, P(ws), x.N, k, 0, s)      # stage 1: partials; reduced in flush_wgrads()
+                if terms:                                                   # stage 1: partials; reduced in flush_wgrads()
+                    lib.lv_conv32_wgrad_b16(P(x.t), P(dy), None, P(ws), x.N, k, 0, terms, s)
+                else:
+                    lib.lv_conv32_wgrad_f32(P(x.t), P(dy), None, P(ws), x.N, k, 0, s)
             self.wgrad_pending.append((ws, gview, k * k * 1024, lib.lv_conv32_wgrad_parts(x.N, k), k * k))
             if x.needs_grad:
                 dx = self.f32(x.P, 32)
                 with _eng._prof("conv_direct", 2.0 * x.P * 1024 * nt):
-                    lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
+                    if terms:
+                        lib.lv_conv32_b16(P(dy), P(wpt), P(dx), None, x.N, k, nt, 1, 0, terms, s)
+                    else:
+                        lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
         return out

@@ -639,7 +639,9 @@ class AggressiveImageTrainer(object):
         self.device = torch.device(device) if device is not None else next(vae.parameters()).device
         self.enc.ensure(self.device)
         self.dec.ensure(self.device)
-        assert precision in ("f32", "bf16")
+        # "f32": exact; "bf16x3": the decoder's direct convolutions on split-bf16 operands (f32-like results: the f32 fixtures hold),
+        # the rest exact; "bf16": plain bf16 operands there and in the im2col GEMMs (image_engine.CONV_TERMS)
+        assert precision in ("f32", "bf16x3", "bf16")
         self.enc.precision = self.dec.precision = precision
         self.enc.flat.attach_grads()
         self.dec.flat.attach_grads()
