@@ -383,6 +383,19 @@ long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout);
 int lv_conv32_pack_b16(const float* w, void* wp16, int k, int ntaps, int transpose, void* stream);
 int lv_conv32_b16(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror, int accumulate,
                   int terms, void* stream);
+/* Stage 1 of a BatchNorm BACKWARD in the epilogue of the data-gradient convolution that produces its incoming gradient (round 4;
+ * dec_pixelcnn_v2.py:44-62: conv -> BatchNorm -> ELU chains, backward): the data gradient g = dL/d(BN output) leaves the kernel as
+ * dv = g * ELU'(y) and every workgroup writes the per-channel (sum dv, sum dv * xhat), xhat = (x - mean) * invstd, of what it stored to
+ * partial [blocks][2][C] (blocks = lv_conv32_blocks(N) / lv_conv1x1_blocks(P)); lv_bn_bwd_apply_partials_f32 then finishes the
+ * BatchNorm (dx, dgamma, dbeta) with no reduction launch.  y = the BatchNorm's saved output, x = its input.  lv_conv32_bnbwd: terms = 0
+ * (exact f32, wp from lv_conv32_pack_f32(transpose = 1)), 1 / 3 (split-bf16, lv_conv32_pack_b16). */
+int lv_conv32_bnbwd(const float* in, const void* wp, float* dv, float* partial, int N, int k, int ntaps, const float* y, const float* x,
+                    const float* mean, const float* invstd, int act_elu, int terms, void* stream);
+int lv_conv1x1_bnbwd_f32(const float* in, const float* w, float* dv, float* partial, long P, int Cin, int Cout, const float* y,
+                         const float* x, const float* mean, const float* invstd, int act_elu, void* stream);
+int lv_bn_bwd_apply_partials_f32(const float* x, const float* dv, const float* partial, int nblk, const float* mean, const float* invstd,
+                                 const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate_param_grads, long P, int C,
+                                 void* stream);
 /* ... and of lv_conv32_wgrad_f32 (same scratch and partial layout: lv_wgrad_reduce_batched serves both). */
 int lv_conv32_wgrad_b16(const float* x, const float* dy, float* dw, float* ws, int N, int k, int accumulate, int terms, void* stream);
 /* All weight-gradient reductions of a backward pass in one launch: lv_conv32_wgrad_f32 / lv_conv1x1_wgrad_f32 called with

@@ -190,6 +190,16 @@ def test_conv32_direct_split_bf16(emu_backend, cfg):
     K.test_conv32_direct_split_bf16(emu_backend, CPU, *cfg)
 
 
+@pytest.mark.parametrize("cfg", [(2, 7, 0, 1), (3, 5, 3, 1), (2, 3, 1, 0)])
+def test_conv32_fused_bn_backward(emu_backend, cfg):
+    K.test_conv32_data_gradient_with_fused_batchnorm_backward(emu_backend, CPU, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [(1000, 64, 32), (129, 32, 32)])
+def test_conv1x1_fused_bn_backward(emu_backend, cfg):
+    K.test_conv1x1_data_gradient_with_fused_batchnorm_backward(emu_backend, CPU, *cfg)
+
+
 @pytest.mark.parametrize("cfg", [(1000, 64, 32), (300, 32, 64), (129, 64, 64), (70, 32, 32)])
 def test_conv1x1(emu_backend, cfg):
     K.test_conv1x1_fwd_dgrad_wgrad(emu_backend, CPU, *cfg)

@@ -1349,6 +1349,95 @@ def test_conv32_direct_split_bf16(lib, hip_device, N, k, masked, terms):
     assert float((dw.cpu().double() - wfull.grad).abs().max()) < tol * float(wfull.grad.abs().max())
 
 
+def _bn_bwd_reference(g, yv, xin, mean, invstd, gamma, act):
+    """dv, dx, dgamma, dbeta of a train-mode BatchNorm (+ ELU) backward in float64, from the gradient g wrt its output."""
+    dv = g * torch.where(yv > 0, torch.ones_like(yv), yv + 1) if act else g
+    xh = (xin - mean) * invstd
+    n = xin.shape[0]
+    s0, s1 = dv.sum(0), (dv * xh).sum(0)
+    dx = gamma * invstd * (dv - s0 / n - xh * s1 / n)
+    return dv, dx, s1, s0
+
+
+@pytest.mark.parametrize("N,k,terms", [(2, 7, 0), (3, 5, 0), (50, 3, 0), (50, 7, 3), (5, 5, 3), (4, 3, 1)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_conv32_data_gradient_with_fused_batchnorm_backward(lib, hip_device, N, k, terms, act):
+    """lv_conv32_bnbwd + lv_bn_bwd_apply_partials_f32: the data gradient of a masked convolution leaves its kernel as the dv of the
+    BatchNorm in front of the convolution, with the per-workgroup (sum dv, sum dv * xhat) -- against the data gradient (float64) pushed
+    through a BatchNorm (+ ELU) backward in float64."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(N * 7 + k + act)
+    C, S = 32, 28
+    Pn = N * S * S
+    w = torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5
+    nt = (k // 2) * k + k // 2 + 1
+    mask = torch.zeros(k * k)
+    mask[:nt] = 1
+    wm = (w.reshape(C, C, k * k) * mask).reshape(C, C, k, k)
+    dyc = torch.randn(N, C, S, S, generator=g)                       # gradient wrt the convolution's output
+    xin = torch.randn(Pn, C, generator=g)                            # BatchNorm input (NHWC rows)
+    gamma = torch.rand(C, generator=g) + 0.5
+    mean, var = xin.double().mean(0), xin.double().var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    ybn = (xin.double() - mean) * invstd * gamma.double()
+    yv = torch.where(ybn > 0, ybn, ybn.exp() - 1) if act else ybn    # BatchNorm output (+ ELU): the convolution's input
+    x_conv = _nchw(yv.float(), N, S, S).double().requires_grad_(True)
+    torch.nn.functional.conv2d(x_conv, wm.double(), padding=k // 2).backward(dyc.double())
+    gref = _nhwc(x_conv.grad.float()).double()                       # dL/d(BN output), [P][C]
+    dv_r, dx_r, dgam_r, dbeta_r = _bn_bwd_reference(gref, yv, xin.double(), mean, invstd, gamma.double(), act)
+    wd = wm.contiguous().to(dev)
+    wpt = torch.empty(lib.lv_conv32_wpack_floats(nt), device=dev)
+    (lib.lv_conv32_pack_b16 if terms else lib.lv_conv32_pack_f32)(P(wd), P(wpt), k, nt, 1, _s(dev))
+    dyn, xd, yd = _nhwc(dyc).to(dev), xin.to(dev), yv.float().to(dev)
+    md, isd, gd = mean.float().to(dev), invstd.float().to(dev), gamma.to(dev)
+    nblk = lib.lv_conv32_blocks(N)
+    dv = torch.full((Pn, C), float("nan"), device=dev)
+    part = torch.full((nblk, 2, C), float("nan"), device=dev)
+    lib.lv_conv32_bnbwd(P(dyn), P(wpt), P(dv), P(part), N, k, nt, P(yd) if act else None, P(xd), P(md), P(isd), act, terms, _s(dev))
+    tol = 2e-5 if terms == 0 else (6e-5 if terms == 3 else 3e-2)
+    assert float((dv.cpu().double() - dv_r).abs().max()) < tol * float(dv_r.abs().max())
+    dvd = dv.double()
+    xh = ((xd.double() - md.double()) * isd.double())
+    assert float((part[:, 0].double().sum(0) - dvd.sum(0)).abs().max()) < 1e-4 * float(dvd.abs().sum(0).max())
+    assert float((part[:, 1].double().sum(0) - (dvd * xh).sum(0)).abs().max()) < 1e-4 * float((dvd * xh).abs().sum(0).max())
+    dx = torch.full((Pn, C), float("nan"), device=dev)
+    dgam, dbeta = torch.full((C,), float("nan"), device=dev), torch.full((C,), float("nan"), device=dev)
+    lib.lv_bn_bwd_apply_partials_f32(P(xd), P(dv), P(part), nblk, P(md), P(isd), P(gd), P(dx), P(dgam), P(dbeta), 0, Pn, C, _s(dev))
+    assert float((dx.cpu().double() - dx_r).abs().max()) < 5 * tol * float(dx_r.abs().max())
+    assert float((dgam.cpu().double() - dgam_r).abs().max()) < 5 * tol * float(dgam_r.abs().max() + dv_r.abs().sum(0).max() * 1e-3)
+    assert float((dbeta.cpu().double() - dbeta_r).abs().max()) < 5 * tol * float(dbeta_r.abs().max() + dv_r.abs().sum(0).max() * 1e-3)
+
+
+@pytest.mark.parametrize("P_,Cin,Cout", [(39200, 32, 64), (1000, 64, 32), (129, 32, 32)])
+def test_conv1x1_data_gradient_with_fused_batchnorm_backward(lib, hip_device, P_, Cin, Cout):
+    """lv_conv1x1_bnbwd_f32: the pointwise convolution's data gradient as the dv of the BatchNorm in front of it (Cin = channels of the
+    BatchNorm = input channels of the forward convolution)."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(P_ + Cin)
+    w = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5             # forward weight [Cout][Cin]
+    dyc = torch.randn(P_, Cout, generator=g)
+    xin = torch.randn(P_, Cin, generator=g)
+    mean, var = xin.double().mean(0), xin.double().var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    gamma = torch.rand(Cin, generator=g) + 0.5
+    ybn = (xin.double() - mean) * invstd * gamma.double()
+    yv = torch.where(ybn > 0, ybn, ybn.exp() - 1)
+    gref = dyc.double() @ w.double()                                 # dL/d(conv input) = dL/d(BN output)
+    dv_r, dx_r, dgam_r, dbeta_r = _bn_bwd_reference(gref, yv, xin.double(), mean, invstd, gamma.double(), 1)
+    nblk = int(lib.lv_conv1x1_blocks(P_))
+    dv = torch.full((P_, Cin), float("nan"), device=dev)
+    part = torch.full((nblk, 2, Cin), float("nan"), device=dev)
+    dyd, wd, xd, yd = dyc.to(dev), w.to(dev), xin.to(dev), yv.float().to(dev)
+    md, isd, gd = mean.float().to(dev), invstd.float().to(dev), gamma.to(dev)
+    lib.lv_conv1x1_bnbwd_f32(P(dyd), P(wd), P(dv), P(part), P_, Cout, Cin, P(yd), P(xd), P(md), P(isd), 1, _s(dev))
+    assert float((dv.cpu().double() - dv_r).abs().max()) < 2e-5 * float(dv_r.abs().max())
+    dx = torch.full((P_, Cin), float("nan"), device=dev)
+    dgam, dbeta = torch.full((Cin,), float("nan"), device=dev), torch.full((Cin,), float("nan"), device=dev)
+    lib.lv_bn_bwd_apply_partials_f32(P(xd), P(dv), P(part), nblk, P(md), P(isd), P(gd), P(dx), P(dgam), P(dbeta), 0, P_, Cin, _s(dev))
+    assert float((dx.cpu().double() - dx_r).abs().max()) < 1e-4 * float(dx_r.abs().max())
+    assert float((dgam.cpu().double() - dgam_r).abs().max()) < 1e-4 * float(dgam_r.abs().max() + dv_r.abs().sum(0).max() * 1e-3)
+
+
 @pytest.mark.parametrize("P_,Cin,Cout", [(39200, 64, 32), (1000, 32, 64), (300, 64, 64), (129, 32, 32)])
 def test_conv1x1_fwd_dgrad_wgrad(lib, hip_device, P_, Cin, Cout):
     dev = hip_device

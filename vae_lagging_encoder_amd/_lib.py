@@ -121,6 +121,9 @@ SIGNATURES = {
     "lv_conv1x1_wgrad_ws_floats": [_i, _i],
     "lv_conv32_pack_b16": [_vp, _vp, _i, _i, _i, _vp],
     "lv_conv32_b16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lv_conv32_bnbwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "lv_conv1x1_bnbwd_f32": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "lv_bn_bwd_apply_partials_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "lv_conv32_wgrad_b16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_conv32_wgrad_parts": [_i, _i],
     "lv_conv1x1_wgrad_parts": [_l],

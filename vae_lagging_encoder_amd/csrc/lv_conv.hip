@@ -767,6 +767,25 @@ extern "C" int lv_bn_bwd4_f32(const float* x, const float* dy, const float* dy2,
     return LV_OK;
 }
 
+// The BatchNorm backward whose stage 1 ran in the epilogue of the data-gradient convolution in front of it (lv_conv32_bnbwd /
+// lv_conv1x1_bnbwd_f32): dv and partial [nblk][2][C] (sum dv, sum dv * xhat per workgroup) are given; writes dx and dgamma / dbeta.
+extern "C" int lv_bn_bwd_apply_partials_f32(const float* x, const float* dv, const float* partial, int nblk, const float* mean,
+                                            const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                            int accumulate_param_grads, long P, int C, void* stream) {
+    if (!x || !dv || !partial || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta) return LV_ERR_ARG;
+    if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
+    if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)dv | (uintptr_t)dx | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
+    if (bn_v4_items(C) == 8)
+        LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, dv, partial, nblk, mean, invstd,
+                  gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+    else
+        LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, dv, partial, nblk, mean, invstd,
+                  gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
 extern "C" int lv_bn_bwd2_f32(const float* x, const float* dy, const float* dy2, const float* y, const float* mean, const float* invstd,
                               const float* gamma, int act_elu, float* dv, float* dx, float* dgamma, float* dbeta,
                               int accumulate_param_grads, float* ws, long P, int C, void* stream) {

@@ -19,6 +19,42 @@
 
 namespace {
 
+// Stage 1 of a BatchNorm BACKWARD inside the epilogue of the data-gradient convolution that produces its incoming gradient (round 4:
+// as the forward statistics come from the convolutions' epilogues).  The kernel's result g = dL/d(BN output) becomes
+// dv = g * ELU'(y) (y: the BatchNorm's saved output; ELU'(.) = 1 for y > 0, y + 1 otherwise) on its way out, and the workgroup
+// leaves the per-channel (sum dv, sum dv * xhat) of what it stored, xhat = (x - mean) * invstd, in partial[block][2][C] -- the layout
+// of bn_reduce_v4_kernel<1>, so that lv_bn_bwd_apply_partials_f32 (lv_conv.hip) finishes the BatchNorm with no reduction launch.
+struct BnBwdFuse {
+    const float* y;            // saved BatchNorm output [P][C] (null with act == 0)
+    const float* x;            // BatchNorm input [P][C]
+    const float* mean;         // [C]
+    const float* invstd;       // [C]
+    int act;                   // ELU behind the BatchNorm
+};
+// (all of a lane's y / x loads are issued before the first store: taken one element at a time -- load, compute, store -- every
+// element was its own memory round trip behind the previous element's store, and the fused epilogue cost 7 us per launch)
+__device__ __forceinline__ void bn_bwd_fuse16(const BnBwdFuse& f, const f32x16& acc, const long (&idx)[16], uint32_t valid, int c,
+                                              float* __restrict__ out, float& st0, float& st1) {
+    float yv[16], xv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xv[e] = f.x[idx[e]];
+    if (f.act) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yv[e] = f.y[idx[e]];
+    }
+    const float mu = f.mean[c], is = f.invstd[c];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float g = acc[e];
+        if (f.act) g = yv[e] > 0.f ? g : g * (yv[e] + 1.f);
+        if ((valid >> e) & 1u) {
+            out[idx[e]] = g;
+            st0 += g;
+            st1 += g * ((xv[e] - mu) * is);
+        }
+    }
+}
+
 constexpr int CC = 32;                 // channels in and out
 constexpr int IW = 28, IH = 28;        // feature map
 constexpr int TR = 4;                  // image rows per workgroup (one per wave)
@@ -48,7 +84,7 @@ __global__ __launch_bounds__(256) void conv32_pack_kernel(const float* __restric
 template <int KS>
 __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                             float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
-                                                            int mirror, int accumulate) {
+                                                            int mirror, int accumulate, BnBwdFuse fuse) {
     constexpr int TRW = TR / KS;         // image rows per workgroup
     __shared__ __attribute__((aligned(16))) float halo[(TRW + KMAX - 1) * (IW + KMAX - 1) * PP];
     __shared__ float sstat[TRW][2][CC];
@@ -135,7 +171,17 @@ __global__ __launch_bounds__(256) void conv32_direct_kernel(const float* __restr
     const int r = r0 + wr;
     const int col = l & 31;
     float st0 = 0.f, st1 = 0.f;
-    if (wk == 0) {
+    if (wk == 0 && fuse.x) {                                    // data gradient feeding a BatchNorm backward (see BnBwdFuse)
+        long idx[16];
+        uint32_t valid = 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            if (x < IW) valid |= 1u << e;
+            idx[e] = (((long)n * IH + r) * IW + (x < IW ? x : IW - 1)) * CC + col;      // clamped: loaded, never stored
+        }
+        bn_bwd_fuse16(fuse, acc, idx, valid, col, out, st0, st1);
+    } else if (wk == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
@@ -206,7 +252,7 @@ __global__ __launch_bounds__(256) void conv32_pack_b16_kernel(const float* __res
 template <int KS, int TERMS>
 __global__ __launch_bounds__(256) void conv32_direct_b16_kernel(const float* __restrict__ in, const uint4* __restrict__ wp,
                                                                 float* __restrict__ out, float* __restrict__ bn_partial, int k, int ntaps,
-                                                                int mirror, int accumulate) {
+                                                                int mirror, int accumulate, BnBwdFuse fuse) {
     constexpr int TRW = TR / KS;         // image rows per workgroup
     constexpr int HALO_PIX = (TRW + KMAX - 1) * (IW + KMAX - 1);
     __shared__ __attribute__((aligned(16))) unsigned char halo_hi[HALO_PIX * PPB];
@@ -305,7 +351,17 @@ __global__ __launch_bounds__(256) void conv32_direct_b16_kernel(const float* __r
     const int r = r0 + wr;
     const int col = l & 31;
     float st0 = 0.f, st1 = 0.f;
-    if (wk == 0) {
+    if (wk == 0 && fuse.x) {                                    // data gradient feeding a BatchNorm backward (see BnBwdFuse)
+        long idx[16];
+        uint32_t valid = 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            if (x < IW) valid |= 1u << e;
+            idx[e] = (((long)n * IH + r) * IW + (x < IW ? x : IW - 1)) * CC + col;      // clamped: loaded, never stored
+        }
+        bn_bwd_fuse16(fuse, acc, idx, valid, col, out, st0, st1);
+    } else if (wk == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int x = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
@@ -658,10 +714,10 @@ extern "C" int lv_conv32_f32(const float* in, const float* wp, float* out, int N
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
     if (conv32_ks(N) == 2)
         LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
-                  mirror, accumulate);
+                  mirror, accumulate, BnBwdFuse{});
     else
         LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, (float*)nullptr, k, ntaps,
-                  mirror, accumulate);
+                  mirror, accumulate, BnBwdFuse{});
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -675,9 +731,9 @@ extern "C" int lv_conv32_bnstat_f32(const float* in, const float* wp, float* out
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
     if (conv32_ks(N) == 2)
-        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0, BnBwdFuse{});
     else
-        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0);
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, 0, 0, BnBwdFuse{});
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -694,22 +750,56 @@ extern "C" int lv_conv32_pack_b16(const float* w, void* wp16, int k, int ntaps, 
     return LV_OK;
 }
 
-extern "C" int lv_conv32_b16(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror,
-                             int accumulate, int terms, void* stream) {
+static int conv32_b16_launch(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror,
+                             int accumulate, int terms, BnBwdFuse fuse, void* stream) {
     if (!in || !wp16 || !out) return LV_ERR_ARG;
     if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
     if (terms != 1 && terms != 3) return LV_ERR_ARG;
-    if (bn_partial && (mirror || accumulate)) return LV_ERR_ARG;
     if (((((uintptr_t)in) | ((uintptr_t)wp16)) & 15) != 0) return LV_ERR_ALIGN;
     const uint4* wp = reinterpret_cast<const uint4*>(wp16);
     const bool two = conv32_ks(N) == 2;
     const dim3 grid((unsigned)(N * (IH / (two ? 2 : TR))));
-    if (two && terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<2, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
-    else if (two) LV_LAUNCH((conv32_direct_b16_kernel<2, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
-    else if (terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<1, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
-    else LV_LAUNCH((conv32_direct_b16_kernel<1, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate);
+    if (two && terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<2, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate, fuse);
+    else if (two) LV_LAUNCH((conv32_direct_b16_kernel<2, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate, fuse);
+    else if (terms == 3) LV_LAUNCH((conv32_direct_b16_kernel<1, 3>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate, fuse);
+    else LV_LAUNCH((conv32_direct_b16_kernel<1, 1>), grid, dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror, accumulate, fuse);
     LV_CHECK_LAUNCH();
     return LV_OK;
+}
+
+extern "C" int lv_conv32_b16(const float* in, const void* wp16, float* out, float* bn_partial, int N, int k, int ntaps, int mirror,
+                             int accumulate, int terms, void* stream) {
+    if (bn_partial && (mirror || accumulate)) return LV_ERR_ARG;
+    return conv32_b16_launch(in, wp16, out, bn_partial, N, k, ntaps, mirror, accumulate, terms, BnBwdFuse{}, stream);
+}
+
+// The DATA GRADIENT of a masked convolution whose input came out of a BatchNorm (+ ELU), with stage 1 of that BatchNorm's backward in
+// its epilogue (BnBwdFuse): in = dL/d(conv output), wp = the transposed image; dv [N*784][32] = dL/d(BN output) * ELU'(y) is written
+// instead of the raw data gradient and partial [lv_conv32_blocks(N)][2][32] receives the per-channel (sum dv, sum dv * xhat) of every
+// workgroup; lv_bn_bwd_apply_partials_f32 finishes the BatchNorm.  y: the BatchNorm's saved output (= the convolution's input),
+// x: its input; act_elu = 0: no activation behind the BatchNorm (y unused).  terms = 0: the exact-f32 kernel (wp from
+// lv_conv32_pack_f32), 1 / 3: the split-bf16 kernels (lv_conv32_pack_b16).
+static int conv32_f32_launch(const float* in, const float* wp, float* out, float* bn_partial, int N, int k, int ntaps, int mirror,
+                             int accumulate, BnBwdFuse fuse, void* stream) {
+    if (!in || !wp || !out) return LV_ERR_ARG;
+    if (N <= 0 || k <= 0 || k > KMAX || !(k & 1) || ntaps <= 0 || ntaps > k * k) return LV_ERR_SHAPE;
+    if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
+    if (conv32_ks(N) == 2)
+        LV_LAUNCH(conv32_direct_kernel<2>, dim3((unsigned)(N * (IH / 2))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror,
+                  accumulate, fuse);
+    else
+        LV_LAUNCH(conv32_direct_kernel<1>, dim3((unsigned)(N * (IH / TR))), dim3(256), 0, stream, in, wp, out, bn_partial, k, ntaps, mirror,
+                  accumulate, fuse);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+extern "C" int lv_conv32_bnbwd(const float* in, const void* wp, float* dv, float* partial, int N, int k, int ntaps, const float* y,
+                               const float* x, const float* mean, const float* invstd, int act_elu, int terms, void* stream) {
+    if (!partial || !x || !mean || !invstd || (act_elu && !y)) return LV_ERR_ARG;
+    const BnBwdFuse fuse{y, x, mean, invstd, act_elu};
+    if (terms == 0) return conv32_f32_launch(in, reinterpret_cast<const float*>(wp), dv, partial, N, k, ntaps, 1, 0, fuse, stream);
+    return conv32_b16_launch(in, wp, dv, partial, N, k, ntaps, 1, 0, terms, fuse, stream);
 }
 
 // weight gradient over ALL k*k taps: dw [32][32][k*k] (=|+=) sum_pixels dy[p][co] x[p + off_t][ci]; ws: lv_conv32_wgrad_ws_floats
@@ -771,7 +861,7 @@ constexpr int PWT = 2 * PWP;           // threads
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
-                                                      float* __restrict__ bn_partial, long P, int w_transposed, int accumulate) {
+                                                      float* __restrict__ bn_partial, long P, int w_transposed, int accumulate, BnBwdFuse fuse) {
     constexpr int PA = CIN + 4;        // LDS pitches (floats): 16-byte slots per row odd -> conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) float sa[PWP * PA];
     __shared__ __attribute__((aligned(16))) float sw[COUT * PA];
@@ -824,14 +914,26 @@ __global__ __launch_bounds__(PWT) void conv1x1_kernel(const float* __restrict__ 
             acc = lv_mfma_32x32x2(av[s + 3], q.w, acc);
         }
         float st0 = 0.f, st1 = 0.f;
+        if (fuse.x) {                                           // data gradient feeding a BatchNorm backward (see BnBwdFuse)
+            long idx[16];
+            uint32_t valid = 0u;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const long pp = p0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-            if (pp < P) {
-                float* o = out + pp * COUT + nb * 32 + (l & 31);
-                const float v = accumulate ? *o + acc[e] : acc[e];
-                *o = v;
-                st0 += v; st1 += v * v;
+            for (int e = 0; e < 16; ++e) {
+                const long pp = p0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                if (pp < P) valid |= 1u << e;
+                idx[e] = (pp < P ? pp : P - 1) * COUT + nb * 32 + (l & 31);
+            }
+            bn_bwd_fuse16(fuse, acc, idx, valid, nb * 32 + (l & 31), out, st0, st1);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long pp = p0 + wv * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+                if (pp < P) {
+                    float* o = out + pp * COUT + nb * 32 + (l & 31);
+                    const float v = accumulate ? *o + acc[e] : acc[e];
+                    *o = v;
+                    st0 += v; st1 += v * v;
+                }
             }
         }
         if (bn_partial) {
@@ -964,12 +1066,12 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
 }  // namespace
 
 static int conv1x1_launch(const float* in, const float* w, float* out, float* bn_partial, long P, int Cin, int Cout, int w_transposed,
-                          int accumulate, void* stream) {
+                          int accumulate, void* stream, BnBwdFuse fuse = BnBwdFuse{}) {
     const dim3 grid((unsigned)lv_cdiv(P, PWP)), block(PWT);
-    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
-    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
-    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
-    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate);
+    if (Cin == 64 && Cout == 32) LV_LAUNCH((conv1x1_kernel<64, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, fuse);
+    else if (Cin == 32 && Cout == 64) LV_LAUNCH((conv1x1_kernel<32, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, fuse);
+    else if (Cin == 64 && Cout == 64) LV_LAUNCH((conv1x1_kernel<64, 64>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, fuse);
+    else if (Cin == 32 && Cout == 32) LV_LAUNCH((conv1x1_kernel<32, 32>), grid, block, 0, stream, in, w, out, bn_partial, P, w_transposed, accumulate, fuse);
     else return LV_ERR_UNSUPPORTED;
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -993,6 +1095,17 @@ extern "C" int lv_conv1x1_bnstat_f32(const float* in, const float* w, float* out
     if (P <= 0) return LV_ERR_SHAPE;
     if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
     return conv1x1_launch(in, w, out, bn_partial, P, Cin, Cout, 0, 0, stream);
+}
+
+// the pointwise convolution's DATA GRADIENT with stage 1 of the preceding BatchNorm's backward in its epilogue (see lv_conv32_bnbwd):
+// in = dL/d(conv output) [P][Cin], w = the forward's weight as stored ([Cin][Cout] from this call's point of view), dv [P][Cout],
+// partial [lv_conv1x1_blocks(P)][2][Cout]
+extern "C" int lv_conv1x1_bnbwd_f32(const float* in, const float* w, float* dv, float* partial, long P, int Cin, int Cout, const float* y,
+                                    const float* x, const float* mean, const float* invstd, int act_elu, void* stream) {
+    if (!in || !w || !dv || !partial || !x || !mean || !invstd || (act_elu && !y)) return LV_ERR_ARG;
+    if (P <= 0) return LV_ERR_SHAPE;
+    if ((((uintptr_t)in) & 15) != 0) return LV_ERR_ALIGN;
+    return conv1x1_launch(in, w, dv, partial, P, Cin, Cout, 1, 0, stream, BnBwdFuse{y, x, mean, invstd, act_elu});
 }
 
 extern "C" long lv_conv1x1_wgrad_ws_floats(int Cin, int Cout) { return (long)PW_PARTS_MAX * Cin * Cout; }

@@ -15,11 +15,14 @@ from .engine import P, FlatBuffer, _gemm, stream_ptr
 
 class Act(object):
     """An NHWC activation: t is a contiguous [N*H*W, C] fp32 tensor."""
-    __slots__ = ("t", "N", "H", "W", "C", "needs_grad", "bn_nblk")
+    __slots__ = ("t", "N", "H", "W", "C", "needs_grad", "bn_nblk", "uses", "bn_src", "fused")
 
     def __init__(self, t, N, H, W, C, needs_grad=True):
         self.t, self.N, self.H, self.W, self.C, self.needs_grad = t, N, H, W, C, needs_grad
         self.bn_nblk = 0       # > 0: the producer left this many BatchNorm stage-1 partial blocks in the tape's BN workspace
+        self.uses = 0          # tape operations that read this activation (a BatchNorm output with ONE reader, a direct or pointwise
+        self.bn_src = None     # convolution, has stage 1 of its backward done in that convolution's data-gradient epilogue:
+        self.fused = None      # bn_src = (BN input Act, mean, invstd, act) set by Tape.bn; fused = (dv, partials, blocks) by the reader)
 
     @property
     def P(self):
@@ -41,7 +44,7 @@ def pack_conv32(lib, s, ent):
 
 
 class Tape(object):
-    def __init__(self, device, precision="f32", train=True, wcache=None, wver=None):
+    def __init__(self, device, precision="f32", train=True, wcache=None, wver=None, fuse_bn_bwd=True):
         self.device = torch.device(device)
         self.lib = _eng.backend_for(self.device)
         # "f32": exact-f32 matrix pipe everywhere.  "bf16x3": the direct 32 -> 32 convolutions with every operand split into two
@@ -51,6 +54,9 @@ class Tape(object):
         self.precision = precision
         self.gemm_prec = "bf16" if precision == "bf16" else "f32"
         self.conv_terms = CONV_TERMS[precision]
+        # stage 1 of a BatchNorm's backward in the epilogue of the data-gradient convolution in front of it (_fused_bn_bwd_ok);
+        # an engine attribute (fuse_bn_bwd), off = the two-launch BatchNorm backward everywhere
+        self.fuse_bn_bwd = bool(fuse_bn_bwd)
         self.train = train
         self.back = []
         self.grads = {}
@@ -157,6 +163,7 @@ class Tape(object):
             return self._conv32(x, weight, gview, kh, nt, mask, bn_stats and self.train)
         if KK == 1 and stride == 1 and pad == 0 and mask is None and Cin in (32, 64) and Cout in (32, 64):
             return self._conv1x1(x, weight, gview, bn_stats and self.train)
+        x.uses += 1
         if mask is not None:
             # weight.data.mul_(mask) on EVERY forward, eval included (dec_pixelcnn_v2.py:29, G5): the weight gradient spans
             # all taps, so after a decoder update the masked taps are non-zero again until the next forward re-zeroes them
@@ -198,10 +205,17 @@ class Tape(object):
         self.back.append(bwd)
         return out
 
+    def _fused_bn_bwd_ok(self, x, nblk):
+        """The data gradient wrt x may leave its kernel as the dv of the BatchNorm that produced x: x is a BatchNorm output read by
+        this convolution alone, nothing has been added to its gradient, and the partial blocks fit."""
+        return (self.fuse_bn_bwd and self.train and x.bn_src is not None and x.uses == 1 and self.grads.get(id(x)) is None
+                and 0 < nblk <= _BN_MAX_BLOCKS)
+
     def _conv32(self, x, weight, gview, k, nt, mask, bn_stats=False):
         """32 -> 32 channel k x k convolution on a 28 x 28 map without an im2col buffer (lv_conv_direct.hip): forward and data
         gradient over the mask's tap prefix, weight gradient over all taps."""
         lib, s = self.lib, self.s()
+        x.uses += 1
         ent = self.wcache.get(id(weight))
         terms = self.conv_terms
         if ent is None:
@@ -239,8 +253,17 @@ class Tape(object):
             self.wgrad_pending.append((ws, gview, k * k * 1024, lib.lv_conv32_wgrad_parts(x.N, k), k * k))
             if x.needs_grad:
                 dx = self.f32(x.P, 32)
+                nblk = lib.lv_conv32_blocks(x.N)
                 with _eng._prof("conv_direct", 2.0 * x.P * 1024 * nt):
-                    if terms:
+                    if self._fused_bn_bwd_ok(x, nblk):
+                        # x came out of a BatchNorm (+ ELU) and nobody else reads it: stage 1 of that BatchNorm's backward rides in this
+                        # kernel's epilogue (dx leaves as dv, the workgroups leave the partial sums), its reduction launch is gone
+                        xin, mean, invstd, act = x.bn_src
+                        part = self.f32(nblk * 64)
+                        lib.lv_conv32_bnbwd(P(dy), P(wpt), P(dx), P(part), x.N, k, nt, P(x.t), P(xin.t), P(mean), P(invstd), int(act),
+                                            terms, s)
+                        x.fused = (dx, part, nblk)
+                    elif terms:
                         lib.lv_conv32_b16(P(dy), P(wpt), P(dx), None, x.N, k, nt, 1, 0, terms, s)
                     else:
                         lib.lv_conv32_f32(P(dy), P(wpt), P(dx), x.N, k, nt, 1, 0, s)
@@ -251,6 +274,7 @@ class Tape(object):
     def _conv1x1(self, x, weight, gview, bn_stats=False):
         """Pointwise convolution between 32 / 64 channels (lv_conv1x1_*: one pass over the pixels, no split-K)."""
         lib, s = self.lib, self.s()
+        x.uses += 1
         Cout, Cin = weight.shape[0], weight.shape[1]
         y = self.f32(x.P, Cout)
         out = Act(y, x.N, x.H, x.W, Cout)
@@ -273,8 +297,16 @@ class Tape(object):
                 # (accumulating into an existing gradient in the kernel's epilogue was measured slower than a separate vectorised add:
                 # the read-modify-write of 4-byte pieces costs the pointwise kernel 4 us, the add kernel 3)
                 dx = self.f32(x.P, Cin)
+                nblk = int(lib.lv_conv1x1_blocks(x.P))
                 with _eng._prof("conv_pointwise", 4.0 * x.P * (Cin + Cout)):
-                    lib.lv_conv1x1_f32(P(dy), P(weight), P(dx), x.P, Cout, Cin, 1, 0, s)
+                    if self._fused_bn_bwd_ok(x, nblk):         # (see _conv32)
+                        xin, mean, invstd, act = x.bn_src
+                        part = self.f32(nblk * 2 * Cin)
+                        lib.lv_conv1x1_bnbwd_f32(P(dy), P(weight), P(dx), P(part), x.P, Cout, Cin, P(x.t), P(xin.t), P(mean), P(invstd),
+                                                 int(act), s)
+                        x.fused = (dx, part, nblk)
+                    else:
+                        lib.lv_conv1x1_f32(P(dy), P(weight), P(dx), x.P, Cout, Cin, 1, 0, s)
                 self.add_grad(x, dx)
         self.back.append(bwd)
         return out
@@ -282,6 +314,9 @@ class Tape(object):
     def bn(self, x, bn, g_gamma, g_beta, res=None, act=True):
         """nn.BatchNorm2d (+ residual add) (+ nn.ELU).  Train mode: batch statistics + running-stat update."""
         lib, s = self.lib, self.s()
+        x.uses += 1
+        if res is not None:
+            res.uses += 1
         C, Pn = x.C, x.P
         y = self.f32(Pn, C)
         mean = self.f32(C)
@@ -306,14 +341,27 @@ class Tape(object):
                                P(res.t) if res is not None else None, int(act), P(y), P(mean), P(invstd), Pn, C, s)
         self._bn_prof.__exit__()
         out = Act(y, x.N, x.H, x.W, C)
+        if self.train:
+            out.bn_src = (x, mean, invstd, act)
 
         def bwd():
             terms = self.grad_terms(out)
             if terms is None:
                 return
+            dx = self.f32(Pn, C)
+            if out.fused is not None and len(terms) == 1 and terms[0] is out.fused[0]:
+                # stage 1 (dv and the partial sums) came out of the reading convolution's data-gradient kernel: the apply pass alone
+                dv, part, nblk = out.fused
+                with _eng._prof("batchnorm", 4.0 * Pn * C * 3):
+                    lib.lv_bn_bwd_apply_partials_f32(P(x.t), P(dv), P(part), nblk, P(mean), P(invstd), P(bn.weight), P(dx), P(g_gamma),
+                                                     P(g_beta), 0, Pn, C, s)
+                if res is not None and res.needs_grad:
+                    self.add_grad(res, dv)
+                if x.needs_grad:
+                    self.add_grad(x, dx)
+                return
             dys = [P(t_) for t_ in terms] + [None] * (4 - len(terms))
             dv = self.f32(Pn, C)
-            dx = self.f32(Pn, C)
             # reduce pass: x, y, the summands in, dv out; apply pass: x, dv in, dx out
             with _eng._prof("batchnorm", 4.0 * Pn * C * (6 + len(terms))):
                 lib.lv_bn_bwd4_f32(P(x.t), dys[0], dys[1], dys[2], dys[3], P(y), P(mean), P(invstd), P(bn.weight), int(act), P(dv), P(dx),
@@ -327,6 +375,8 @@ class Tape(object):
 
     def add(self, a, b):
         lib, s = self.lib, self.s()
+        a.uses += 1
+        b.uses += 1
         y = self.f32(a.P, a.C)
         lib.lv_add_f32(P(a.t), P(b.t), P(y), y.numel(), s)
         out = Act(y, a.N, a.H, a.W, a.C)
@@ -346,6 +396,8 @@ class Tape(object):
     def linear(self, x2d, xact, weight, bias, g_w, g_b):
         """y = x W^T + b on a [B, K] matrix.  xact: the Act providing x2d's gradient slot (or None for a leaf)."""
         lib, s = self.lib, self.s()
+        if xact is not None:
+            xact.uses += 1
         B, K = x2d.shape
         N = weight.shape[0]
         y = self.f32(B, N)
@@ -462,6 +514,7 @@ class ImageEncoderEngine(object):
         self.m = module
         self.flat = None
         self.precision = "f32"
+        self.fuse_bn_bwd = True
         self.gen = 0
 
     def ensure(self, device):
@@ -472,7 +525,7 @@ class ImageEncoderEngine(object):
 
     def forward(self, x_img):
         f = self.ensure(x_img.device)
-        self.tape = Tape(x_img.device, self.precision, train=self.m.training)
+        self.tape = Tape(x_img.device, self.precision, train=self.m.training, fuse_bn_bwd=self.fuse_bn_bwd)
         self.out = encoder_forward(self.tape, f, self.m, x_img)
         self.tape.bump_bn_counters()
         self.gen += 1
@@ -490,6 +543,7 @@ class ImageDecoderEngine(object):
         self.m = module
         self.flat = None
         self.precision = "f32"
+        self.fuse_bn_bwd = True
         self.gen = 0
         self.wgen = 0             # bumped by the fused trainer after a raw-pointer weight update
         self._wcache = {}
@@ -519,7 +573,7 @@ class ImageDecoderEngine(object):
         """-> rec [B] (BCE summed over pixels)."""
         f = self.ensure(x_img.device)
         wver = self.weights_version()
-        tp = Tape(x_img.device, self.precision, train=self.m.training, wcache=self._wcache, wver=wver)
+        tp = Tape(x_img.device, self.precision, train=self.m.training, wcache=self._wcache, wver=wver, fuse_bn_bwd=self.fuse_bn_bwd)
         self.tape = tp
         B = x_img.shape[0]
         self.zact = Act(z2d.contiguous(), B, 1, 1, z2d.shape[1])
