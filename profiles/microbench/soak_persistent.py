@@ -1,6 +1,6 @@
 """Soak test (measurement tooling): many aggressive inner steps on batches of varying shape (B <= 32, T <= 200) through the
 persistent LSTM launches, checking the finiteness of the loss and, at the end, that no step had to be replayed (ladder rung 0, no recoveries); prints steps/s.
-usage (GPU box): python profiles/microbench/soak_persistent.py [steps]"""
+usage (GPU box): python profiles/microbench/soak_persistent.py [steps] [max batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,6 +9,7 @@ from vae_lagging_encoder_amd.factory import build_text_vae
 from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+BMAX = int(sys.argv[2]) if len(sys.argv) > 2 else 32          # 128: also the 8- and 16-row instantiations of the persistent kernels
 dev = torch.device("cuda:0")
 V = 20001
 vae = build_text_vae(V, 512, 1024, 32, dev, seed=3)
@@ -17,7 +18,7 @@ rs = np.random.RandomState(5)
 t0 = time.time()
 shapes = set()
 for i in range(steps):
-    B = int(rs.randint(1, 33))
+    B = int(rs.randint(1, BMAX + 1))
     T = int(rs.randint(3, 201))
     shapes.add((B, T))
     x = torch.from_numpy(rs.randint(4, V - 1, size=(B, T))).to(dev)
