@@ -514,7 +514,7 @@ def check_fold_norm(device, V, ni, H, nz, B, T, precision="f32", use_graph=False
 
 
 def check_transactional_recovery(device, V=97, ni=12, H=20, nz=4, B=6, K=5, precision="f32", fault_at=(2,), rungs_down=1,
-                                 use_graph=False):
+                                 use_graph=False, decoder_grads="full"):
     """A persistent-launch hand-off timeout must never reach the weights (text.py:385-387: an update is computed from complete
     recurrences or not at all).  K inner steps + the joint decoder step with injected noise; before the steps listed in
     `fault_at` an engine's status word is set -- what a timed-out recurrence leaves behind.  The device-side gate then voids that
@@ -538,7 +538,7 @@ def check_transactional_recovery(device, V=97, ni=12, H=20, nz=4, B=6, K=5, prec
 
     def run(faulty):
         vae = build_vae(V, ni, H, nz, device, params=P)
-        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision, use_graph=use_graph)
+        tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision=precision, use_graph=use_graph, decoder_grads=decoder_grads)
         log = {"demotions": []}
         if faulty:
             def on_demote(rung):

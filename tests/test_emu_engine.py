@@ -91,3 +91,9 @@ def test_norm_folding_is_the_same_norm_emulated(emu_backend, shape):
     V, ni, H, nz, B, T = shape
     pc.check_fold_norm("cpu", V, ni, H, nz, B, T)
     pc.check_fold_norm("cpu", V, ni, H, nz, B, T, decoder_grads="norm")
+
+
+def test_voided_steps_with_norm_only_decoder_gradients_emulated(emu_backend):
+    """The transaction gate and decoder_grads="norm" together: a voided run of steps is replayed and lands, bit for bit, where a
+    fault-free run with the same option does (the joint decoder step in the sequence needs -- and gets -- full decoder gradients)."""
+    pc.check_transactional_recovery("cpu", fault_at=(1, 3), rungs_down=2, decoder_grads="norm")

@@ -645,3 +645,10 @@ def test_norm_folding_is_the_same_norm(hip_device, shape, precision, use_graph):
     pc.check_fold_norm(hip_device, V, ni, H, nz, B, T, precision=precision, use_graph=use_graph)
     if not use_graph:
         pc.check_fold_norm(hip_device, V, ni, H, nz, B, T, precision=precision, decoder_grads="norm")
+
+
+def test_timed_out_launch_with_norm_only_decoder_gradients(hip_device):
+    """As test_timed_out_persistent_launch_never_reaches_the_weights, with decoder_grads="norm" (the decoder's vocabulary-sized
+    gradients of encoder-only steps reduced to their norm in their producers): the replayed run equals the fault-free one."""
+    pc.check_transactional_recovery(hip_device, V=2003, ni=64, H=1024, nz=32, B=32, K=5, precision="bf16", fault_at=(1, 3), rungs_down=2,
+                                    decoder_grads="norm")
