@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- aggressive-loop sequences/sec on the BASELINE.json metric configuration.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts the N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W          (the same ranks under torchrun)
 
 One "step" = one body of the aggressive inner loop (reference text.py:373-387: zero_grad, VAE.loss, backward,
 clip_grad_norm_ over encoder+decoder grads, encoder SGD step) on one synthetic batch of the Yahoo LSTM-VAE
@@ -331,6 +331,58 @@ def side_run_text(workload, dev, steps, warmup, dtype="bf16", decoder_grads="ful
     return rec
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this command, one rank per GPU (rank r on
+    cuda:r), with the environment `torch.distributed.run` would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT), RCCL ("nccl") as the backend.  Rank 0 prints the one JSON line on the inherited stdout.  Returns the exit code:
+    0 when every rank returned 0; when a rank dies the others are terminated (by their PIDs) and its code is returned.
+    A box with fewer than N GPUs cannot run RCCL with N ranks (one communicator rank per device): the ranks then SHARE the devices
+    (rank r on cuda:r % device_count) and exchange over gloo -- a functional check of the data-parallel path, said loudly on stderr and
+    in the line's `config.dp_transport`; its seq/s is not a scaling number."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        print("bench.py: no GPU visible; --gpus %d needs MI355X GPUs (no CPU fallback)" % n, file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LVAE_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver supports dmabuf IPC only (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    if ndev < n:
+        env["LVAE_DIST_BACKEND"] = "gloo"
+        env["LVAE_SHARED_GPU"] = "%d ranks on %d GPU%s" % (n, ndev, "" if ndev == 1 else "s")
+        print("bench.py: --gpus %d on a box with %d GPU(s): RCCL needs one device per rank, so the ranks share the device(s) and "
+              "exchange over gloo -- a functional check of the data-parallel path, NOT a scaling measurement" % (n, ndev), file=sys.stderr)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                c = p.poll()
+                if c is None:
+                    continue
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 128 - c
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (procs.index(p), c), file=sys.stderr)
+                    for q in live:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,6 +421,9 @@ def main():
                     help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
                          "tokens repeat hundreds of times per batch, which the embedding backward's sort / scatter feel)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and prints nothing itself
+        sys.exit(self_launch(args.gpus))
     stress = args.workload == "stress"
     if args.steps is None:
         args.steps = 50 if stress else 20
@@ -382,8 +437,7 @@ def main():
 
     rank, local, world = lvdist.init_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or plain `python bench.py --gpus N`)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
@@ -487,10 +541,12 @@ def main():
         bd = sync.breakdown()
         names = ["encoder_allreduce_issue", "decoder_reduce_scatter_wait", "decoder_allreduce_wait", "scalar_allreduce",
                  "encoder_allreduce_wait"]
-        mine = torch.tensor([bd.get(k, 0.0) for k in names] + [1e3 * dt_local / args.steps], dtype=torch.float64, device=dev)
+        my_rung = max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec)) if args.dtype == "bf16" else -1
+        mine = torch.tensor([bd.get(k, 0.0) for k in names] + [1e3 * dt_local / args.steps, float(my_rung)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
-        rows = [[round(float(v), 4) for v in t.tolist()] for t in allr]
+        rungs = [int(t[-1].item()) for t in allr]
+        rows = [[round(float(v), 4) for v in t.tolist()[:-1]] for t in allr]
         exposed = [round(sum(r[:-1]), 4) for r in rows]
         dp_breakdown = {
             "unit": "ms per step on the compute stream (HIP events): time the step WAITED in each phase; hidden communication does not show",
@@ -500,6 +556,10 @@ def main():
             "bytes_on_wire": sync.bytes_on_wire(tr.enc.flat, tr.dec.flat, "encoder", micro_batches=args.micro_batches,
                                                 n_emb=(tr.enc.flat.offsets[tr.enc.flat.names[1]] // 1024 * 1024) if not args.graph else 0),
             "micro_batches": args.micro_batches,
+            # every rank's rung of the persistent recurrences' fallback ladder (0 = persistent launches with the XCD-local hand-off;
+            # a collective taking CUs from a persistent launch would show here as a rung > 0 on some rank)
+            "lstm_ladder_rung_per_rank": rungs if args.dtype == "bf16" else None,
+            "backend": torch.distributed.get_backend(),
             "encoder_bucket": "embedding gradient issued from inside the encoder backward (under dW_ih / dW_hh)" if not args.graph else "none (hipGraph split)"}
     stats = tr.read_stats()
 
@@ -516,6 +576,11 @@ def main():
                                                           ", fixed K=%d inner steps per loop (stress)" % args.steps if stress else ""),
                    "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                    "dp_exchange": ((args.dp_mode + ("/bf16-payload" if args.dp_payload == "bf16" else "")) if world > 1 else None),
+                   "dp_transport": (None if world == 1 else
+                                    ("gloo, %s: functional check of the data-parallel path, not a scaling measurement" % os.environ["LVAE_SHARED_GPU"]
+                                     if os.environ.get("LVAE_SHARED_GPU") else
+                                     "%s, one rank per GPU" % ("RCCL over xGMI" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend()))),
+                   "launcher": os.environ.get("LVAE_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none"),
                    "hipgraph": bool(args.graph),
                    "clip_norm": ("vocabulary-sized tensors' sums of squares emitted by their producers + one pass over the rest"
                                  if tr._fold is not None else "one streaming pass over both flat gradients"),
