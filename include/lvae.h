@@ -122,6 +122,10 @@ int lv_lstm_fwd_bf16(const float* gx, const float* whh, float* hs, float* cs, fl
  * lv_cvt_bf16_gates_f32 image of W_ih and lv_gate_interleave_f32-ed epilogue addends. */
 int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
                         const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
+/* the exact-f32 recurrence (lv_lstm_fwd_f32) on a UNIT-major gx: nn.LSTM of enc_lstm.py:55 in f32 behind an input projection in
+ * the bf16-image path's column order */
+int lv_lstm_fwd_f32_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                       const uint8_t* dmask, float dscale, float* hdrop, float* ws, int T, int B, int H, void* stream);
 /* The same recurrences as ONE persistent launch each (lv_lstm_persist16.hip; nn.LSTM of enc_lstm.py:55 / dec_lstm.py:104, forward
  * and BPTT): 256 workgroups in 8 XCD-sized groups (blockIdx % 8), each group carries a slice of the batch through all T steps with
  * its slice of W_hh held in registers and hands h_t (forward: all-gather) or partial dh sums (BPTT: reduce-scatter) around inside
@@ -153,6 +157,10 @@ int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, flo
 int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved, const float* hs,
                                const float* cs, uint16_t* dG16, float* dGsum, float* xch, int* status, float* dh0, float* dc0,
                                int tanh_init, int T, int B, int R, int flags, int H, void* stream);
+/* Saved activations of a forward that ran on the launch-per-timestep kernels (gates [T][B][H][4] records, cs [T+1][B][H]) -> the
+ * record buffer lv_lstm_bwd_bf16_persist16 reads, for the same T, B, R.  Used when the ENCODER's forward recurrence runs in exact
+ * f32 (the KL of encoder.py:55 is a function of its last state, enc_lstm.py:60-62) in front of the persistent BPTT. */
+int lv_lstm_persist16_import_saved(const float* gates, const float* cs, float* saved, int T, int B, int R, int H, void* stream);
 /* out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u]): gate-major rows (biases, the decoder's z-projection) -> unit-major */
 int lv_gate_interleave_f32(const float* a, const float* b, int R, int H, float* out, void* stream);
 int lv_lstm_bwd_bf16(const float* dh_ext, const float* dh_last, const uint8_t* dmask, float dscale,

@@ -224,6 +224,11 @@ def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg, 0)
 
 
+@pytest.mark.parametrize("T,B,R", [(3, 13, 2), (2, 32, 4), (2, 20, 16)])
+def test_persist16_import_saved_emulated(emu_backend, T, B, R):
+    K.test_persist16_import_saved(emu_backend, CPU, T, B, R)
+
+
 @pytest.mark.parametrize("cfg", [(5, 3, 70, 50, True), (3, 33, 128, 90, False)])
 def test_embed_gather_into_bf16_images(emu_backend, cfg):
     K.test_embed_gather_into_bf16_images(emu_backend, CPU, *cfg)

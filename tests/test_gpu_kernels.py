@@ -439,6 +439,23 @@ def _saved16_unpack(saved, T, B, R, H=1024):
     return g[:, :B].contiguous(), c[:, :B].contiguous()
 
 
+@pytest.mark.parametrize("T,B,R", [(5, 32, 4), (3, 13, 2), (4, 100, 13), (2, 128, 16), (7, 32, 8)])
+def test_persist16_import_saved(lib, hip_device, T, B, R):
+    """lv_lstm_persist16_import_saved: the step kernels' saved activations (gates [T][B][H][4], cs [T+1][B][H]) land in the persistent
+    BPTT's record buffer exactly where a persistent forward would have put them (rows beyond B of the last group are never read)."""
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(T * 31 + B)
+    gates = torch.randn(T, B, 4 * H, generator=g).to(dev)
+    cs = torch.randn(T + 1, B, H, generator=g).to(dev)
+    want = _saved16_pack(lib, gates, cs, R)
+    got = torch.full_like(want, float("nan"))
+    lib.lv_lstm_persist16_import_saved(P(gates), P(cs), P(got), T, B, R, H, _s(dev))
+    g2, c2 = _saved16_unpack(got, T, B, R)
+    g1, c1 = _saved16_unpack(want, T, B, R)
+    assert torch.equal(g2.cpu(), g1.cpu()) and torch.equal(c2.cpu(), c1.cpu())
+    assert torch.equal(g2.cpu(), gates.cpu()) and torch.equal(c2.cpu(), cs[1:].cpu())
+
+
 def _bf16_round(x):
     return x.to(torch.bfloat16).to(x.dtype)
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "lv_lstm_fwd_f32_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "lv_loss_assemble_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "lv_loss_assemble_rng_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u64, _vp],
     "lv_enc_head_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -58,6 +59,7 @@ SIGNATURES = {
     "lv_lstm_persist16_xch_floats": [],
     "lv_lstm_persist16_saved_floats": [_i, _i],
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
+    "lv_lstm_persist16_import_saved": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_persist16_pack2": [_vp, _vp, _vp, _i, _vp],
     "lv_lstm_fwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -682,6 +682,14 @@ extern "C" int lv_lstm_fwd_bf16_ug(const float* gx, const float* whh, float* hs,
     return lstm_fwd_impl<true>(gx, whh, hs, cs, gates, dmask, dscale, hdrop, ws, T, B, H, stream, 1);
 }
 
+// lv_lstm_fwd_f32 for a unit-major gx (column 4u + g): the exact-f32 recurrence behind an input projection that was produced
+// in the bf16-image path's column order (the encoder's exact forward, engine.LSTMEncoderEngine.exact_forward).
+extern "C" int lv_lstm_fwd_f32_ug(const float* gx, const float* whh, float* hs, float* cs, float* gates,
+                                  const uint8_t* dmask, float dscale, float* hdrop, float* ws,
+                                  int T, int B, int H, void* stream) {
+    return lstm_fwd_impl<false>(gx, whh, hs, cs, gates, dmask, dscale, hdrop, ws, T, B, H, stream, 1);
+}
+
 namespace {
 // out[r][4u + g] = a[r][g*H + u] (+ b[r][g*H + u])
 __global__ __launch_bounds__(256) void gate_interleave_kernel(const float* __restrict__ a, const float* __restrict__ b,

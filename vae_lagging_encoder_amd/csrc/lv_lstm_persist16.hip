@@ -661,6 +661,40 @@ extern "C" long lv_lstm_persist16_saved_floats(int T, int R) {
     return T < 0 || R < 1 || R > 16 ? 0 : (long)PGROUPS * PMEMBERS * T * R * SAVED_PER_ROW;
 }
 
+namespace {
+// canonical saved activations (gate records [T][B][H][4], cell states cs [T+1][B][H]: what the launch-per-timestep forward
+// kernels write) -> the workgroup-major record buffer the persistent BPTT reads.  One thread per (t, b, unit).
+__global__ __launch_bounds__(256) void import_saved16_kernel(const float* __restrict__ gates, const float* __restrict__ cs,
+                                                             float* __restrict__ saved, int T, int B, int R) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long BH = (long)B * PH;
+    if (idx >= (long)T * BH) return;
+    const int u = (int)(idx % PH), b = (int)((idx / PH) % B), t = (int)(idx / BH);
+    const int group = b / R, row = b % R, member = u >> 5, uw = u & 31;
+    const long rec = (long)R * SAVED_PER_ROW;
+    float* dst = saved + ((long)(group * PMEMBERS + member) * T + t) * rec;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gates + idx * 4);
+    *reinterpret_cast<f32x4*>(dst + (row * 32 + uw) * 4) = g;
+    dst[R * 128 + row * 32 + uw] = cs[idx + BH];          // record t carries c_t = cs[t + 1]
+}
+}  // namespace
+
+// Saved activations of a forward that ran on the launch-per-timestep kernels (lv_lstm_fwd_f32 / _bf16: gates [T][B][H][4], cs
+// [T+1][B][H]) -> the record buffer of lv_lstm_bwd_bf16_persist16 (lv_lstm_persist16_saved_floats(T, R) floats) for the same
+// T, B, R.  Lets an exact-f32 forward recurrence (the KL of encoder.py:55 depends on its last state alone) be followed by the
+// persistent BPTT.
+extern "C" int lv_lstm_persist16_import_saved(const float* gates, const float* cs, float* saved, int T, int B, int R, int H,
+                                              void* stream) {
+    if (!gates || !cs || !saved) return LV_ERR_ARG;
+    if (T < 0 || B <= 0) return LV_ERR_SHAPE;
+    if (H != PH || !check_R(B, R)) return LV_ERR_UNSUPPORTED;
+    if (((((uintptr_t)gates) | ((uintptr_t)saved)) & 15) != 0) return LV_ERR_ALIGN;
+    if (T == 0) return LV_OK;
+    LV_LAUNCH(import_saved16_kernel, dim3((unsigned)lv_cdiv((long)T * B * PH, 256)), dim3(256), 0, stream, gates, cs, saved, T, B, R);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
 // W_hh [4H][H] f32 -> the register image of lv_lstm_fwd_bf16_persist16 (backward = 0) / lv_lstm_bwd_bf16_persist16 (backward = 1):
 // lv_lstm_persist16_wpk_floats() floats, 16-byte aligned.  Re-run only when the weights change.
 extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream) {

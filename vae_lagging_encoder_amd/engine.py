@@ -648,6 +648,11 @@ class LSTMEncoderEngine(object):
         self.fold = None                        # norm folding (trainer._plan_fold): {"embed": (partials tensor, norm-only flag)}
         self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
+        # bf16 configuration only: which parts of the FORWARD run in exact f32 all the same -- "gx" (the input projection X W_ih^T)
+        # and / or "rec" (the recurrence).  mu / logvar, hence z and the KL (encoder.py:55), are functions of the forward's last
+        # state alone (enc_lstm.py:60-62); 200 recurrent steps on bf16 operands move it by 2e-4..5e-4 relative, the exact forward
+        # holds north_star's 1e-4 on the KL while every gradient product and the whole decoder stay on the bf16 pipe.
+        self.exact_forward = ()
         self._wimg = None
         self._aux = _AuxStream()
         self._sorts = _TokenSortCache()
@@ -662,6 +667,12 @@ class LSTMEncoderEngine(object):
         if not _LstmImages.usable(self.precision, self.native16, ni, H):
             return None
         return self.wsc.get(("b16", B, T), lambda: _LstmImages(self.wsc, T * B, ni, H, key=("b16", B, T)))
+
+    def _exact(self, img):
+        """The parts of the forward that run in exact f32 although the engine is in the bf16 configuration."""
+        ex = tuple(self.exact_forward or ())
+        assert all(e in ("gx", "rec") for e in ex), ex
+        return ex if (img is not None and self.precision == "bf16") else ()
 
     def fold_parts(self, B, T):
         """Partial sums of squares this engine's backward can emit from the kernels that complete its big gradient tensors
@@ -743,20 +754,38 @@ class LSTMEncoderEngine(object):
         w = self._ws(B, T)
         v = f.views
         img = self._b16(B, T)
-        if img is None:
+        exact = self._exact(img)
+        if img is None or "gx" in exact:
             lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
         # the backward's token sort depends on x only: taken from the per-batch cache, or queued now (auxiliary stream)
         self._sort = _sorted_tokens(self, lib, s, x, x_key, T, T, B, V, w)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
-        if img is not None:
+        gx_unit_major = True
+        if img is not None and "gx" in exact:
+            # exact-f32 input projection (gate-major columns, as the f32 recurrence reads them); the bf16 images of the embedded
+            # rows are still gathered: the backward's dW_ih product reads them
+            self.refresh_weight_images(B, x.device)
+            lib.lv_embed_gather_b16(P(v["embed.weight"]), P(x), T, None, 1.0, T, B, ni, V, P(img.X), ni, P(img.XT), img.ldr, s)
+            _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H, prec="f32", **biases)
+            gx_unit_major = False
+            if "rec" not in exact:          # (measurement only: the bf16 recurrences read a unit-major gx)
+                if getattr(w, "Gx_gm", None) is None:
+                    w.Gx_gm = self.wsc.f32(T * B, 4 * H)
+                w.Gx, w.Gx_gm = w.Gx_gm, w.Gx
+                lib.lv_gate_interleave_f32(P(w.Gx_gm), None, T * B, H, P(w.Gx), s)
+                gx_unit_major = True
+        elif img is not None:
             wi = self.refresh_weight_images(B, x.device)
             img.forward(lib, s, None, P(wi.W), P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, self.wsc,
                         gather=(P(v["embed.weight"]), P(x), T, None, 1.0, T, B, V))
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
-        with _prof("lstm_fwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
-            _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
+        if "rec" in exact:
+            self._exact_recurrence(lib, s, img, w, gx_unit_major, T, B, H, x.device)
+        else:
+            with _prof("lstm_fwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
+                _lstm_forward(self, lib, s, img, w, P(w.Gx), P(v["lstm.weight_hh_l0"]), None, 1.0, None, T, B, H, x.device)
         if head is not None and not fused_ends_ok(B, nz2 // 2, head[0].shape[1]):
             eps, z, kl = head
             _gemm(lib, s, 0, 1, B, nz2, H, P(w.hs, T * B * H), H, P(v["linear.weight"]), H, P(w.mulv), nz2)
@@ -770,6 +799,29 @@ class LSTMEncoderEngine(object):
         self.gen += 1
         self.last = (x, B, T, self.gen)
         return w.mulv
+
+    def _exact_recurrence(self, lib, s, img, w, gx_unit_major, T, B, H, device):
+        """The forward recurrence on the exact-f32 launch-per-timestep kernels inside the bf16 configuration (exact_forward has
+        "rec").  They save gates [T][B][H][4] / cs [T+1][B][H]; where the BPTT will be the persistent launch, those are copied
+        into its workgroup-major record buffer (lv_lstm_persist16_import_saved) -- the same T, B, R contract as a persistent
+        forward."""
+        v = self.flat.views
+        n = T * B * 4 * H
+        if getattr(w, "gates_canon", None) is None or w.gates_canon.numel() < n:
+            w.gates_canon = self.wsc.f32(n)
+        fwd = lib.lv_lstm_fwd_f32_ug if gx_unit_major else lib.lv_lstm_fwd_f32
+        persist_bwd = _persistent_ok(self, img, B, H, device, _PERSIST_BWD_MAX_B)
+        gates = w.gates_canon if persist_bwd else w.gates
+        with _prof("lstm_fwd_enc", float(T), T):
+            fwd(P(w.Gx), P(v["lstm.weight_hh_l0"]), P(w.hs), P(w.cs), P(gates), None, 1.0, None, P(w.lstm_ws), T, B, H, s)
+        w.saved_layout = ("canonical", T, B, 0)
+        if persist_bwd:
+            rows = _persist_rows(self, B)
+            need = lib.lv_lstm_persist16_saved_floats(T, rows)
+            if w.gates.numel() < need:
+                w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
+            lib.lv_lstm_persist16_import_saved(P(w.gates_canon), P(w.cs), P(w.gates), T, B, rows, H, s)
+            w.saved_layout = ("persist16", T, B, rows)
 
     def backward(self, dmulv, gen=None, head=None, after_bptt=None, after_embed=None):
         """dmulv [B][2nz] -> fills self.flat.grad (all encoder parameter grads, '=' semantics).

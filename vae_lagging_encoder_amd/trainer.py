@@ -38,8 +38,13 @@ class AggressiveTextTrainer(object):
     BUCKET_MIN_ELEMS = 1 << 20
 
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
-                 precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full"):
-        """decoder_grads = "norm" (needs fold_norm): in ENCODER-ONLY steps the decoder's two vocabulary-sized gradient tensors
+                 precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full", encoder_forward=None):
+        """encoder_forward = "f32" (with precision="bf16"): the encoder's FORWARD (input projection + recurrence) runs in exact f32
+        inside the bf16 configuration.  mu / logvar -- hence z and the KL of encoder.py:55 -- depend on the forward's last state
+        alone (enc_lstm.py:60-62); on bf16 operands 200 recurrent steps move it by 2e-4..5e-4 relative, with the exact forward
+        ELBO, reconstruction NLL AND KL hold north_star's 1e-4 while every gradient product and the whole decoder stay on the
+        bf16 matrix pipe.  None / "bf16": the plain bf16 configuration.
+        decoder_grads = "norm" (needs fold_norm): in ENCODER-ONLY steps the decoder's two vocabulary-sized gradient tensors
         (embedding table, dW_pred) are not written to memory at all -- text.py:383-387 needs them for the clip norm alone, the
         next backward overwrites them -- and their .grad is left unspecified by such a step; "full" (default) keeps every .grad
         as clip_grad_norm_ would leave it.
@@ -67,6 +72,8 @@ class AggressiveTextTrainer(object):
         self.dec.ensure(self.device)
         assert precision in ("f32", "bf16")
         self.enc.precision = self.dec.precision = precision   # large GEMMs: exact f32 (parity) or bf16 pipe (throughput)
+        assert encoder_forward in (None, "bf16", "f32")
+        self.enc.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
         if grad_sync is not None:
             grad_sync.resolve_payload(precision)              # "auto": bf16 wire for the bf16 configuration, exact fp32 otherwise
         self.enc.flat.attach_grads()
