@@ -102,6 +102,13 @@ int lv_keep_scale_f32(float* x, const uint8_t* keep, float kscale, int T, int Bs
  * of W^T [C][4H] in the standard order; either may be NULL */
 int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt,
                           void* stream);
+/* The LOW half of a split-bf16 operand, bf16(x - bf16(x)), in the layouts of the three conversions above: a plain matrix [R][C]
+ * (gate_H = 0, ids = NULL), an LSTM gate weight with unit-major rows (gate_H = H, R = 4H), or gathered embedding rows (ids [Bsz]
+ * [ids_stride], R = T*Bsz).  x = hi + lo up to 2^-17 |x|; hi.hi' + hi.lo' + lo.hi' on the bf16 pipe (lv_gemm_b16 with
+ * accumulate = 1) is an f32-like product.  Used by the encoder's exact forward (enc_lstm.py:47-64 -> encoder.py:55: the KL is a
+ * function of the forward's last state, and WEIGHT rounding is what moves it -- profiles/r05a_kl_ablation.txt). */
+int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz, int V,
+                       uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream);

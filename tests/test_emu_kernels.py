@@ -224,6 +224,11 @@ def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg, 0)
 
 
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
+def test_cvt_bf16_lo_emulated(emu_backend, mode, R, C):
+    K.test_cvt_bf16_lo(emu_backend, CPU, mode, R, C)
+
+
 @pytest.mark.parametrize("T,B,R", [(3, 13, 2), (2, 32, 4), (2, 20, 16)])
 def test_persist16_import_saved_emulated(emu_backend, T, B, R):
     K.test_persist16_import_saved(emu_backend, CPU, T, B, R)

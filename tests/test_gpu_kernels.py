@@ -101,6 +101,43 @@ def test_cvt_bf16(lib, hip_device, R, C):
     assert torch.equal(only_t.cpu()[:, :R], want.t())
 
 
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("plain", 64, 128), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
+def test_cvt_bf16_lo(lib, hip_device, mode, R, C):
+    """lv_cvt_bf16_lo_f32: the low half of a split-bf16 operand, bit for bit bf16(x - bf16(x)), in the plain, gate-interleaved and
+    gathered layouts of the three high-half conversions; hi + lo reproduces x to 2^-16 |x| (bf16 RNE of a residual <= 2^-9 |x|)."""
+    g = torch.Generator().manual_seed(R * 3 + C)
+    dev = hip_device
+    lds, ldd, ldt = C + 3, C + 8, R + 5
+    if mode == "gather":
+        T, B, V = 5, 7, 19
+        src = torch.randn(V, C, generator=g); lds = C
+        ids = torch.randint(0, V, (B, T + 2), generator=g)
+        rows = torch.stack([src[ids[b, t]] for t in range(T) for b in range(B)])
+    else:
+        src = torch.randn(R, lds, generator=g)
+        rows = src[:, :C]
+    hi = rows.to(torch.bfloat16).float()
+    want = _bf16_bits(rows - hi)
+    if mode == "gates":
+        H = R // 4
+        want_d = want[torch.arange(4 * H).view(4, H).t().reshape(-1)]
+    else:
+        want_d = want
+    d = torch.full((R, ldd), 0x1234, dtype=torch.int16, device=dev)
+    dT = torch.full((C, ldt), 0x1234, dtype=torch.int16, device=dev)
+    sd = src.to(dev)
+    if mode == "gather":
+        idd = ids.to(dev)
+        lib.lv_cvt_bf16_lo_f32(P(sd), lds, R, C, 0, P(idd), T + 2, B, V, P(d), ldd, P(dT), ldt, _s(dev))
+    else:
+        lib.lv_cvt_bf16_lo_f32(P(sd), lds, R, C, R // 4 if mode == "gates" else 0, None, 0, 1, 0, P(d), ldd, P(dT), ldt, _s(dev))
+    assert torch.equal(d.cpu()[:, :C], want_d)
+    assert torch.equal(dT.cpu()[:, :R], want.t())
+    assert bool((d.cpu()[:, C:] == 0x1234).all()) and bool((dT.cpu()[:, R:] == 0x1234).all())
+    lo = want.view(torch.bfloat16).float()
+    assert float((hi + lo - rows).abs().max()) <= 2.0 ** -16 * float(rows.abs().max())
+
+
 @pytest.mark.parametrize("H,C,R", [(8, 16, 3), (50, 33, 1), (256, 128, 5)])
 def test_gate_interleave_and_gate_weight_image(lib, hip_device, H, C, R):
     g = torch.Generator().manual_seed(H + C)

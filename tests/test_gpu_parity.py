@@ -205,7 +205,7 @@ def test_yahoo_full_size_fixture(hip_device):
     _check_full_size_fixture_dropin(hip_device, "text_yahoo_seeded")
 
 
-def _check_bf16_against_full_size_fixture(hip_device, name, out_name, kl_bound, encoder_forward=None):
+def _check_bf16_against_full_size_fixture(hip_device, name, out_name, kl_bound, encoder_forward=None, exact_impl="auto"):
     """One fused inner step in the throughput arithmetic against a full-size REFERENCE fixture; writes the measured deltas to
     gpurun_out/<out_name>.json and returns them."""
     import json, math, os
@@ -216,6 +216,7 @@ def _check_bf16_against_full_size_fixture(hip_device, name, out_name, kl_bound, 
     x = torch.from_numpy(fx["x"]).to(hip_device)
     noise = tuple(torch.from_numpy(fx[k]).to(hip_device) for k in ("eps", "mask_in", "mask_out"))
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16", encoder_forward=encoder_forward)
+    tr.enc.exact_impl = exact_impl
     tr.step(x, float(fx["kl_weight"]), noise=noise)
     st = tr.read_stats()                                   # raises if a persistent launch reported a hand-off timeout
     B, T, V = int(fx["B"]), int(fx["T"]), int(fx["V"])
@@ -276,15 +277,18 @@ def test_bf16_headline_path_at_headline_shape(hip_device):
     _check_bf16_against_full_size_fixture(hip_device, "text_yahoo_seeded", "bf16_headline_parity", kl_bound=1e-3)
 
 
+@pytest.mark.parametrize("impl", ["auto", "f32"])
 @pytest.mark.parametrize("name", ["text_yahoo_seeded", "text_yelp_wide_seeded"])
-def test_bf16_with_exact_encoder_forward_holds_all_three_at_1e4(hip_device, name):
-    """`AggressiveTextTrainer(precision="bf16", encoder_forward="f32")`: the bf16 configuration with the encoder's FORWARD (input
-    projection + recurrence) in exact f32.  mu / logvar -- hence z and the KL (encoder.py:55) -- are functions of that forward's
-    last state alone (enc_lstm.py:60-62), so this configuration meets north_star's 1e-4 on ELBO, reconstruction NLL AND KL against
-    the reference run at the headline shape (and the Yelp one), with every gradient product, the BPTTs (persistent launches fed
-    through lv_lstm_persist16_import_saved) and the whole decoder on the bf16 pipe; the gradient side keeps the bf16 bounds."""
-    out = _check_bf16_against_full_size_fixture(hip_device, name, "bf16_exact_encoder_forward_parity_" + name.split("_")[1], kl_bound=1e-4,
-                                                encoder_forward="f32")
+def test_bf16_with_exact_encoder_forward_holds_all_three_at_1e4(hip_device, name, impl):
+    """`AggressiveTextTrainer(precision="bf16", encoder_forward="f32")`: the bf16 configuration with an f32-accurate encoder FORWARD
+    (input projection + recurrence).  mu / logvar -- hence z and the KL (encoder.py:55) -- are functions of that forward's last
+    state alone (enc_lstm.py:60-62), so this configuration meets north_star's 1e-4 on ELBO, reconstruction NLL AND KL against the
+    reference run at the headline shape (and the Yelp one), with every gradient product, the BPTTs and the whole decoder on the
+    bf16 pipe; the gradient side keeps the bf16 bounds.  impl "auto" (persistent launches): split-bf16 input projection + the
+    two-pass recurrence (engine._exact_forward_split); "f32": exact-f32 GEMM + launch-per-timestep recurrence, imported into the
+    persistent BPTT's record buffer (lv_lstm_persist16_import_saved)."""
+    out = _check_bf16_against_full_size_fixture(hip_device, name, "bf16_exact_encoder_forward_parity_%s_%s" % (name.split("_")[1], impl),
+                                                kl_bound=1e-4, encoder_forward="f32", exact_impl=impl)
     assert out["kl_rel"] < 1e-4 and out["loss_rel"] < 1e-4 and out["rec_rel"] < 1e-4, out
 
 

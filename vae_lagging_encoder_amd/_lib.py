@@ -36,6 +36,7 @@ SIGNATURES = {
     "lv_cvt_f32_bf16_scaled": [_vp, _l, _f, _vp, _vp],
     "lv_keep_scale_f32": [_vp, _vp, _f, _i, _i, _i, _vp],
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
+    "lv_cvt_bf16_lo_f32": [_vp, _l, _i, _i, _i, _vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "lv_lstm_fwd_f32_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],

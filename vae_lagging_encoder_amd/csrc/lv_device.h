@@ -343,6 +343,12 @@ __device__ __forceinline__ uint32_t lv_f32_to_bf16_bits(float x) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
+__device__ __forceinline__ float lv_bf16_bits_to_f32(uint32_t b) {
+    const uint32_t u = b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
 __device__ __forceinline__ uint32_t lv_pack_bf16x2(float lo, float hi) {
     return lv_f32_to_bf16_bits(lo) | (lv_f32_to_bf16_bits(hi) << 16);
 }

@@ -1579,7 +1579,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
 __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ src, long lds_, int R, int C,
                                                       uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt,
                                                       int gate_H, const uint8_t* __restrict__ keep, float kscale, int Bsz,
-                                                      const int64_t* __restrict__ gids, long gstride, int gV) {
+                                                      const int64_t* __restrict__ gids, long gstride, int gV, int lo) {
+    // lo != 0: the image of the RESIDUAL x - bf16(x) (itself rounded to bf16, RNE): the low half of a split-bf16 operand
+    // (x = hi + lo up to 2^-17 |x|), see lv_cvt_bf16_lo_f32
     __shared__ uint16_t tile[64][66];
     const int t = (int)threadIdx.x;
     const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
@@ -1633,6 +1635,7 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
                     else x *= kp[u] ? kscale : 0.f;              // as h * (keep * scale) rounds (a dropped negative element is -0)
                 }
                 b = (uint16_t)lv_f32_to_bf16_bits(x);
+                if (lo) b = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b));
                 if (dst) {
                     const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
                     dst[dr * ldd + gc] = b;
@@ -1839,7 +1842,7 @@ extern "C" int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_
     if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
-              dst, ldd, dstT, ldt, 0, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0);
+              dst, ldd, dstT, ldt, 0, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -1853,7 +1856,7 @@ extern "C" int lv_cvt_bf16_keep_f32(const float* src, long lds, int T, int Bsz, 
     if (T < 0 || Bsz <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, (int)R, C,
-              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, (const int64_t*)nullptr, 0L, 0);
+              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -1869,7 +1872,7 @@ extern "C" int lv_embed_gather_b16(const float* emb, const int64_t* ids, long id
     if (T < 0 || Bsz <= 0 || C < 0 || V <= 0 || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, emb, (long)C, (int)R, C,
-              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, ids, ids_stride, V);
+              dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, ids, ids_stride, V, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -1882,11 +1885,31 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
     if (H <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < 4 * H)) return LV_ERR_SHAPE;
     if (C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(4 * H, 64)), dim3(256), 0, stream, src, lds, 4 * H, C,
-              dst, ldd, dstT, ldt, H, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0);
+              dst, ldd, dstT, ldt, H, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
 
+
+// The LOW half of a split-bf16 operand: image of bf16(x - bf16(x)) for the same sources and layouts as the conversions above
+// (x = hi + lo up to 2^-17 |x|; a product of two split operands, hi.hi' + hi.lo' + lo.hi' on the bf16 pipe with f32 accumulation,
+// is f32-like: the dropped lo.lo' is 2^-16 relative).  gate_H > 0: src = an LSTM gate weight [4 gate_H][C], dst rows unit-major as
+// lv_cvt_bf16_gates_f32; ids != NULL: src = an embedding table [V][C], row r = t*Bsz + b of the image is row ids[b*ids_stride + t]
+// (R = T*Bsz) as lv_embed_gather_b16; otherwise a plain [R][C] matrix as lv_cvt_bf16_f32.  Used where weight rounding -- a
+// perturbation that acts coherently over all timesteps -- would otherwise own the error of the encoder's last state
+// (profiles/r05a_kl_ablation.txt).
+extern "C" int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz,
+                                  int V, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream) {
+    if (!src || (!dst && !dstT)) return LV_ERR_ARG;
+    if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
+    if (gate_H > 0 && (R != 4 * gate_H || ids)) return LV_ERR_ARG;
+    if (ids && (Bsz <= 0 || V <= 0 || R % Bsz != 0)) return LV_ERR_SHAPE;
+    if (R == 0 || C == 0) return LV_OK;
+    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+              dst, ldd, dstT, ldt, gate_H > 0 ? gate_H : 0, (const uint8_t*)nullptr, 1.f, ids ? Bsz : 1, ids, ids_stride, ids ? V : 0, 1);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
 
 // LSTMDecoder's vocabulary projection fused with the statistics of nn.CrossEntropyLoss (modules/decoders/dec_lstm.py:117,
 // 140-146): logits = A . B^T (bf16 operands as lv_gemm_b16, transA = 0) are written ONCE, as binary16 [M][ldl16] (RNE of the

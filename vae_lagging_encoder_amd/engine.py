@@ -255,14 +255,14 @@ def _gemm(lib, s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, acc=0, add
         fn(tA, tB, M, N, K, alpha, A, lda, B, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2, P(ws), ws.numel(), s)
 
 
-def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, add1=None, ld1=0, mod1=1, add2=None, ld2=0, mod2=1, ws=None):
+def _gemm16(lib, s, tA, M, N, K, A16, lda, B16, ldb, C, ldc, add1=None, ld1=0, mod1=1, add2=None, ld2=0, mod2=1, ws=None, acc=0):
     """C = op(A) . B^T (+ add1 + add2) with operands already rounded to bf16 in HBM (lv_gemm_b16): B stored [N][K];
     A stored [M][K] (tA = 0) or [K][M] (tA = 1).  Bit-identical to _gemm(prec='bf16') on the f32 data (up to where
     split-K cuts), at half the operand bytes and with no conversion work in the GEMM."""
     if ws is None:
         ws = _gemm_ws(lib, s)
     with _prof("gemm_bf16", 2.0 * M * N * K):
-        lib.lv_gemm_b16(tA, M, N, K, 1.0, A16, lda, B16, ldb, C, ldc, 0, add1, ld1, mod1, add2, ld2, mod2,
+        lib.lv_gemm_b16(tA, M, N, K, 1.0, A16, lda, B16, ldb, C, ldc, acc, add1, ld1, mod1, add2, ld2, mod2,
                         P(ws), ws.numel(), s)
 
 
@@ -653,6 +653,10 @@ class LSTMEncoderEngine(object):
         # state alone (enc_lstm.py:60-62); 200 recurrent steps on bf16 operands move it by 2e-4..5e-4 relative, the exact forward
         # holds north_star's 1e-4 on the KL while every gradient product and the whole decoder stay on the bf16 pipe.
         self.exact_forward = ()
+        # how: "auto" = on the bf16 pipe itself wherever the forward recurrence is a persistent launch -- split-bf16 operands for
+        # the input projection and a two-pass recurrence whose second pass carries W_lo . h as part of gx (_exact_forward_split) --
+        # else, and with "f32", the exact-f32 GEMM and launch-per-timestep recurrence
+        self.exact_impl = "auto"
         self._wimg = None
         self._aux = _AuxStream()
         self._sorts = _TokenSortCache()
@@ -761,7 +765,10 @@ class LSTMEncoderEngine(object):
         self._sort = _sorted_tokens(self, lib, s, x, x_key, T, T, B, V, w)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         gx_unit_major = True
-        if img is not None and "gx" in exact:
+        split = (self.exact_impl == "auto" and set(exact) == {"gx", "rec"} and _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B))
+        if split:
+            self._exact_forward_split(lib, s, img, w, x, T, B, V, ni, H)
+        elif img is not None and "gx" in exact:
             # exact-f32 input projection (gate-major columns, as the f32 recurrence reads them); the bf16 images of the embedded
             # rows are still gathered: the backward's dW_ih product reads them
             self.refresh_weight_images(B, x.device)
@@ -781,7 +788,9 @@ class LSTMEncoderEngine(object):
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
-        if "rec" in exact:
+        if split:
+            pass
+        elif "rec" in exact:
             self._exact_recurrence(lib, s, img, w, gx_unit_major, T, B, H, x.device)
         else:
             with _prof("lstm_fwd_enc", float(T), 1 if _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B) else T):
@@ -799,6 +808,50 @@ class LSTMEncoderEngine(object):
         self.gen += 1
         self.last = (x, B, T, self.gen)
         return w.mulv
+
+    def _exact_forward_split(self, lib, s, img, w, x, T, B, V, ni, H):
+        """The encoder's forward with f32-like WEIGHTS on the bf16 pipe (exact_forward = gx + rec where the recurrence is a
+        persistent launch).  What moves the forward's last state -- hence mu / logvar, z and the KL of encoder.py:55 -- in the
+        bf16 configuration is the rounding of the weights, a perturbation that acts the same way at every timestep (measured,
+        profiles/r05a_kl_ablation.txt: W_hh alone 1.4e-4 relative on the KL, the embedding rows 0.4e-4..1.9e-4, W_ih 0.2e-4..1.2e-4),
+        not the rounding of h_{t-1} in the hand-off (<= 2.5e-5: fresh noise at every step, which averages out).  So:
+          * input projection: every operand split into hi + lo (both bf16; x = hi + lo up to 2^-17 |x|) and
+            Gx = X_hi W_hi^T + X_lo W_hi^T + X_hi W_lo^T as ONE product over K = 3 ni ([X_hi | X_lo | X_hi] . [W_hi | W_hi | W_lo]^T);
+          * recurrence: pass 1 = the persistent bf16 recurrence as it is -> h(1); then Gx += bf16(h(1)_{t-1}) . W_hh,lo^T for all t
+            at once (one GEMM); pass 2 = the same persistent launch on the corrected Gx.  Pass 2 computes W_hi . bf16(h(2)) +
+            W_lo . bf16(h(1)); against the exact W . h(2) that leaves W_lo . (h(1) - h(2)) ~ 2^-9 x 1e-3 and the hand-off rounding.
+        Everything the BPTT reads (gate records, cell states, hs) is what pass 2 wrote, in the persistent kernels' own layout."""
+        v = self.flat.views
+        TB = T * B
+        wi = self.refresh_weight_images(B, x.device)
+        c = self.wsc
+        if getattr(wi, "Ww", None) is None:
+            wi.Ww = c.i16(4 * H, 3 * ni)           # [W_hi | W_hi | W_lo], rows unit-major
+            wi.Whh_lo = c.i16(4 * H, H)            # low half of W_hh, rows unit-major (the column order of Gx)
+        wih, whh = v["lstm.weight_ih_l0"], v["lstm.weight_hh_l0"]
+        lib.lv_cvt_bf16_gates_f32(P(wih), wih.shape[1], H, ni, P(wi.Ww), 3 * ni, None, 0, s)
+        lib.lv_cvt_bf16_gates_f32(P(wih), wih.shape[1], H, ni, P(wi.Ww, ni), 3 * ni, None, 0, s)
+        lib.lv_cvt_bf16_lo_f32(P(wih), wih.shape[1], 4 * H, ni, H, None, 0, 1, 0, P(wi.Ww, 2 * ni), 3 * ni, None, 0, s)
+        lib.lv_cvt_bf16_lo_f32(P(whh), H, 4 * H, H, H, None, 0, 1, 0, P(wi.Whh_lo), H, None, 0, s)
+        if getattr(img, "Xw", None) is None:
+            img.Xw = c.i16(TB, 3 * ni)             # [X_hi | X_lo | X_hi]
+            img.h16 = c.i16(TB, H)                 # bf16(h(1)_{t-1}), rows t*B + b
+            if img.key is not None:
+                c.grew(img.key, TB * (3 * ni + H) * 2)
+        emb = P(v["embed.weight"])
+        lib.lv_embed_gather_b16(emb, P(x), T, None, 1.0, T, B, ni, V, P(img.Xw), 3 * ni, P(img.XT), img.ldr, s)      # (+ X^T for dW_ih)
+        lib.lv_cvt_bf16_lo_f32(emb, ni, TB, ni, 0, P(x), T, B, V, P(img.Xw, ni), 3 * ni, None, 0, s)
+        lib.lv_embed_gather_b16(emb, P(x), T, None, 1.0, T, B, ni, V, P(img.Xw, 2 * ni), 3 * ni, None, 0, s)
+        if img.addend is None or img.addend.shape[0] != 1:
+            img.addend = c.f32(1, 4 * H)
+        lib.lv_gate_interleave_f32(P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, H, P(img.addend), s)
+        _gemm16(lib, s, 0, TB, 4 * H, 3 * ni, P(img.Xw), 3 * ni, P(wi.Ww), 3 * ni, P(w.Gx), 4 * H, add1=P(img.addend), ld1=0, mod1=1)
+        with _prof("lstm_fwd_enc", float(T), 1):
+            _lstm_forward(self, lib, s, img, w, P(w.Gx), P(whh), None, 1.0, None, T, B, H, x.device)
+        lib.lv_cvt_bf16_f32(P(w.hs), H, TB, H, P(img.h16), H, None, 0, s)
+        _gemm16(lib, s, 0, TB, 4 * H, H, P(img.h16), H, P(wi.Whh_lo), H, P(w.Gx), 4 * H, acc=1)
+        with _prof("lstm_fwd_enc", float(T), 1):
+            _lstm_forward(self, lib, s, img, w, P(w.Gx), P(whh), None, 1.0, None, T, B, H, x.device)
 
     def _exact_recurrence(self, lib, s, img, w, gx_unit_major, T, B, H, device):
         """The forward recurrence on the exact-f32 launch-per-timestep kernels inside the bf16 configuration (exact_forward has
