@@ -11,27 +11,64 @@ RTOL = 1e-4
 GRAD_RTOL = 2e-4
 
 
-def run_reference_style_step(name, device, clip=5.0, lr=1.0):
+def run_reference_style_step(name, device, clip=5.0, lr=1.0, optim="torch"):
+    """text.py:373-387 literally, on the drop-in modules.  optim = "lvae": the same four lines with vae_lagging_encoder_amd.optim's
+    clip_grad_norm_ / SGD (streaming launches over the flat buffers) in place of torch's."""
+    from vae_lagging_encoder_amd import optim as lvo
     fx = load(name)
     V, ni, H, nz = int(fx["V"]), int(fx["ni"]), int(fx["H"]), int(fx["nz"])
     vae = build_vae(V, ni, H, nz, device, params=fixture_params(fx))
     x = torch.from_numpy(fx["x"]).to(device)
     noise = (torch.from_numpy(fx["eps"]).to(device), torch.from_numpy(fx["mask_in"]).to(device),
              torch.from_numpy(fx["mask_out"]).to(device))
-    enc_opt = torch.optim.SGD(vae.encoder.parameters(), lr=lr, momentum=0)
-    dec_opt = torch.optim.SGD(vae.decoder.parameters(), lr=lr, momentum=0)
+    SGD = lvo.SGD if optim == "lvae" else torch.optim.SGD
+    clipfn = lvo.clip_grad_norm_ if optim == "lvae" else torch.nn.utils.clip_grad_norm_
+    enc_opt = SGD(vae.encoder.parameters(), lr=lr, momentum=0)
+    dec_opt = SGD(vae.decoder.parameters(), lr=lr, momentum=0)
     enc_opt.zero_grad()
     dec_opt.zero_grad()
     loss, rec, kl = vae.loss(x, float(fx["kl_weight"]), nsamples=1, noise=noise)
     loss.mean(dim=-1).backward()
+    # after zero_grad() the backward leaves every .grad as a VIEW of its module's flat gradient buffer (no clones)
+    for m in (vae.encoder, vae.decoder):
+        assert m._hip.flat.grads_are_views()
     grads = {k: p.grad.detach().clone() for k, p in vae.named_parameters()}
-    total = float(torch.nn.utils.clip_grad_norm_(vae.parameters(), clip))
+    total = float(clipfn(vae.parameters(), clip))
     enc_opt.step()
     return fx, vae, loss.detach(), rec.detach(), kl.detach(), grads, total
 
 
-def check_step_against_fixture(name, device):
-    fx, vae, loss, rec, kl, grads, total = run_reference_style_step(name, device)
+def check_grad_accumulation_semantics(device, V=97, ni=12, H=20, nz=4, B=6, T=7):
+    """Two backward() calls without a zero_grad() in between ADD (autograd's semantics), although the first one left the .grad
+    tensors aliasing the flat buffer the second one's engine writes into; zero_grad(set_to_none=False) keeps working too."""
+    from oracle import text_vae_oracle as O
+    P = O.random_params(V, ni, H, nz, seed=3, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    xs = [O.synthetic_batch(B, T, V, seed=10 + i).to(device) for i in range(2)]
+    ns = []
+    for i in range(2):
+        eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=20 + i)
+        ns.append((eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device)))
+    single = []
+    for i in range(2):
+        vae.zero_grad()
+        vae.loss(xs[i], 0.5, noise=ns[i])[0].mean().backward()
+        single.append({k: p.grad.detach().clone() for k, p in vae.named_parameters()})
+    vae.zero_grad()
+    vae.loss(xs[0], 0.5, noise=ns[0])[0].mean().backward()
+    assert vae.encoder._hip.flat.grads_are_views()
+    vae.loss(xs[1], 0.5, noise=ns[1])[0].mean().backward()          # no zero_grad: must accumulate
+    for k, p in vae.named_parameters():
+        want = single[0][k] + single[1][k]
+        assert float((p.grad - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-12, k
+    vae.zero_grad(set_to_none=False)                                # zeros in place, .grad stays allocated
+    vae.loss(xs[1], 0.5, noise=ns[1])[0].mean().backward()
+    for k, p in vae.named_parameters():
+        assert float((p.grad - single[1][k]).abs().max()) <= 1e-6 * float(single[1][k].abs().max()) + 1e-12, k
+
+
+def check_step_against_fixture(name, device, optim="torch"):
+    fx, vae, loss, rec, kl, grads, total = run_reference_style_step(name, device, optim=optim)
     rec_scale = float(np.abs(fx["rec"]).max())
     assert rel_err(loss, fx["loss"]) < RTOL, ("loss", rel_err(loss, fx["loss"]))
     assert rel_err(rec, fx["rec"]) < RTOL

@@ -8,9 +8,14 @@ import torch
 import parity_common as pc
 
 
-@pytest.mark.parametrize("name", ["text_small_refinit", "text_small_wide", "text_edge_T2"])
-def test_inner_step_matches_reference_fixture_emulated(emu_backend, name):
-    pc.check_step_against_fixture(name, "cpu")
+@pytest.mark.parametrize("name,optim", [("text_small_refinit", "torch"), ("text_small_wide", "torch"), ("text_edge_T2", "torch"),
+                                        ("text_small_wide", "lvae"), ("text_edge_T2", "lvae")])
+def test_inner_step_matches_reference_fixture_emulated(emu_backend, name, optim):
+    pc.check_step_against_fixture(name, "cpu", optim=optim)
+
+
+def test_dropin_backward_keeps_autograd_accumulation_emulated(emu_backend):
+    pc.check_grad_accumulation_semantics("cpu")
 
 
 def test_cpu_tensors_refused_without_test_backend():
@@ -97,3 +102,25 @@ def test_voided_steps_with_norm_only_decoder_gradients_emulated(emu_backend):
     """The transaction gate and decoder_grads="norm" together: a voided run of steps is replayed and lands, bit for bit, where a
     fault-free run with the same option does (the joint decoder step in the sequence needs -- and gets -- full decoder gradients)."""
     pc.check_transactional_recovery("cpu", fault_at=(1, 3), rungs_down=2, decoder_grads="norm")
+
+
+def test_guarded_eval_repeats_a_pass_that_saw_a_timeout(emu_backend):
+    """training.guarded_eval: an evaluation pass is a forward-only use of the engines -- no transaction gate -- so a
+    hand-off timeout inside it is looked for afterwards; the engines go one rung down, the event is logged, the pass runs again."""
+    from helpers import build_vae
+    from vae_lagging_encoder_amd import engine as eng
+    from vae_lagging_encoder_amd.training import guarded_eval
+    vae = build_vae(53, 8, 16, 4, "cpu", seed=1)
+    for m in (vae.encoder, vae.decoder):
+        m._hip.ensure(torch.device("cpu"))
+    calls, msgs = [], []
+
+    def fn():
+        calls.append(1)
+        if len(calls) == 1:
+            vae.decoder._hip.status.fill_(237)          # what a timed-out persistent BPTT launch would leave
+        return len(calls)
+    assert guarded_eval(vae, fn, log=msgs.append) == 2
+    assert [eng.persist_rung(m._hip) for m in (vae.encoder, vae.decoder)] == [1, 1]
+    assert int(vae.decoder._hip.status.item()) == 0 and len(msgs) == 1 and "ladder rung 1" in msgs[0]
+    assert guarded_eval(vae, lambda: "fine", log=msgs.append) == "fine" and len(msgs) == 1

@@ -12,9 +12,14 @@ from oracle import text_vae_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("optim", ["torch", "lvae"])
 @pytest.mark.parametrize("name", ["text_small_refinit", "text_small_wide", "text_edge_T2", "text_toy", "text_mid"])
-def test_inner_step_matches_reference_fixture(hip_device, name):
-    pc.check_step_against_fixture(name, hip_device)
+def test_inner_step_matches_reference_fixture(hip_device, name, optim):
+    pc.check_step_against_fixture(name, hip_device, optim=optim)
+
+
+def test_dropin_backward_keeps_autograd_accumulation(hip_device):
+    pc.check_grad_accumulation_semantics(hip_device)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -533,9 +538,9 @@ def test_stress_batch_at_h1024(hip_device):
 
 def test_stress_config_at_full_size(hip_device):
     """BASELINE.json configs[4] AT ITS OWN SIZE: Yahoo dims (V=20001, ni=512, H=1024, nz=32), B = 128 sequences, T = 200, fixed
-    K = 50 inner steps, bf16 configuration.  (i) step 1: per-sequence loss / rec / KL of a 32-row slice against the oracle's
-    forward on those rows (the rows of a batch are independent in the forward pass; the gradient is a batch mean and is covered
-    at B = 128 by test_stress_batch_at_h1024); (ii) the 50-step loop is finite, moves only the encoder, and is bit-reproducible
+    K = 50 inner steps, bf16 configuration.  (i) step 1 against the oracle's whole inner step on all 128 sequences at T = 200
+    (the reference's ATen ops on the host cores, ~10 s): per-sequence loss / rec / KL, the clip norm and coefficient, every
+    gradient tensor's norm and the encoder's update, at the bf16 configuration's bounds; (ii) the 50-step loop is finite, moves only the encoder, and is bit-reproducible
     from the same seeds (Philox noise, same host batch picks)."""
     import numpy as np
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
@@ -544,8 +549,15 @@ def test_stress_config_at_full_size(hip_device):
     pool = [O.synthetic_batch(B, T, V, seed=90 + i) for i in range(4)]
     eps, m_in, m_out = O.draw_noise(B, T, ni, H, nz, seed=83)
     rows = slice(48, 80)
-    with torch.no_grad():
-        l_ref, rec_ref, kl_ref = O.vae_loss(P, pool[0][rows], klw, eps[rows], m_in[rows], m_out[rows], impl="aten")
+    # the oracle's whole inner step on all 128 sequences at T = 200 (the reference's ATen ops on the host cores; oneDNN's LSTM
+    # backward collapses with hundreds of threads, so 32): forward AND clip norm, coefficient, encoder update at the full size
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, nthreads))
+    try:
+        r_full = O.inner_step(P, pool[0], klw, eps, m_in, m_out, impl="aten")
+    finally:
+        torch.set_num_threads(nthreads)
+    l_ref, rec_ref, kl_ref = r_full["loss"][rows], r_full["rec"][rows], r_full["kl"][rows]
     finals = []
     for rep in range(2):
         vae = build_vae(V, ni, H, nz, hip_device, params=P)
@@ -558,6 +570,25 @@ def test_stress_config_at_full_size(hip_device):
             for name, got, ref in (("loss", st.loss, l_ref), ("rec", st.rec, rec_ref), ("kl", st.kl, kl_ref)):
                 e = rel_err(got[rows], ref.reshape(-1))
                 assert e < (1e-4 if name != "kl" else 1e-3), (name, e)
+            # ... and over ALL 128 rows, plus the backward side at this size (16 rows per XCD group in both persistent kernels):
+            # the clip norm (float64 norm of the oracle's gradients), the coefficient, per-tensor gradient norms and the encoder's
+            # update, at the bf16 configuration's bounds (tests above: norm 1e-4 measured 1e-6; per-tensor norms 2e-3; update 2e-2)
+            stats = tr.read_stats()
+            for name, ref in (("loss_sum", r_full["loss"]), ("rec_sum", r_full["rec"])):
+                assert abs(stats[name] - float(ref.sum())) / abs(float(ref.sum())) < 1e-4, name
+            assert abs(stats["kl_sum"] - float(r_full["kl"].sum())) / abs(float(r_full["kl"].sum())) < 1e-3
+            assert abs(stats["norm"] - r_full["total_norm"]) / r_full["total_norm"] < 1e-3, (stats["norm"], r_full["total_norm"])
+            assert abs(stats["coef"] - r_full["coef"]) <= 1e-3 * r_full["coef"]
+            named = dict(vae.named_parameters())
+            for k in ALL_KEYS:                                  # .grad holds the clipped gradient
+                ref_n = float(r_full["grads"][k].double().norm()) * r_full["coef"]
+                got_n = float(named[k].grad.double().norm())
+                assert abs(got_n - ref_n) <= 2e-3 * ref_n + 1e-12, (k, got_n, ref_n)
+            sd1 = vae.state_dict()
+            for k in ENC_KEYS:
+                upd_ref = (r_full["new_params"][k] - P[k]).double()
+                upd_got = (sd1[k].cpu() - P[k]).double()
+                assert float((upd_got - upd_ref).abs().max()) < 2e-2 * float(upd_ref.abs().max()) + 1e-12, k
             # start the loop from the same weights in both repetitions
             vae = build_vae(V, ni, H, nz, hip_device, params=P)
             tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16", seed=4242)

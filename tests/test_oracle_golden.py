@@ -79,3 +79,37 @@ def test_trajectory_fixture():
         assert rel_err(r["loss"], fx["loss"][it]) < 1e-5
     for k in ALL_KEYS:
         assert rel_err(P[k], fx["final/" + k]) < 1e-4, k
+
+
+# ---- the image oracle against the reference-generated Omniglot fixtures -----------------------------------------------------
+@pytest.mark.parametrize("name", ["image_b6", "image_b50"])
+def test_image_oracle_matches_reference_fixture(name):
+    """oracle/image_vae_oracle.py (the checker behind bench.py's Omniglot `cpu_baseline` and the image parity tests) against the
+    fixtures tests/golden/make_golden_image.py wrote from the imported reference: image.py:300-314 on seeded weights -- per-image
+    loss / rec / KL, the clip norm, every gradient tensor's norm and sampled entries, the encoder's Adam step-1 updates."""
+    from oracle import image_vae_oracle as IO
+    from vae_lagging_encoder_amd.factory import build_image_vae
+    fx = load(name)
+    vae = build_image_vae("cpu", int(fx["model_seed"]))
+    P = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+    keys = IO.param_keys(P)
+    for k in keys:          # the regenerated weights ARE the reference's
+        idx = torch.from_numpy(fx["sample_idx/" + k])
+        assert torch.equal(P[k].reshape(-1)[idx], torch.from_numpy(fx["sample_p0/" + k])), k
+    x = torch.from_numpy(fx["x"]).float()
+    r = IO.inner_step_adam(P, x, float(fx["kl_weight"]), torch.from_numpy(fx["eps"]))
+    assert rel_err(r["loss"], fx["loss"]) < 1e-5 and rel_err(r["rec"], fx["rec"]) < 1e-5
+    assert float(np.abs(r["kl"].numpy() - fx["kl"]).max()) < 1e-4 * float(np.abs(fx["kl"]).max()) + 1e-6
+    assert abs(r["total_norm"] - float(fx["total_norm64"])) / float(fx["total_norm64"]) < 1e-5
+    for k in keys:
+        ref_n = float(fx["gradnorm/" + k])
+        got_n = float(r["grads"][k].double().norm())
+        assert abs(got_n - ref_n) <= 1e-4 * ref_n + 1e-9, (k, got_n, ref_n)
+        idx = torch.from_numpy(fx["sample_idx/" + k])
+        sg = torch.from_numpy(fx["sample_grad/" + k])
+        assert float((r["grads"][k].reshape(-1)[idx] - sg).abs().max()) <= 1e-4 * float(sg.abs().max()) + 1e-4 * ref_n / max(1.0, P[k].numel() ** 0.5), k
+        if k.startswith("encoder."):
+            # Adam's first step moves every weight by ~lr * sign(g): compare the UPDATE
+            upd_ref = torch.from_numpy(fx["sample_new/" + k]) - torch.from_numpy(fx["sample_p0/" + k])
+            upd_got = r["new_params"][k].reshape(-1)[idx] - P[k].reshape(-1)[idx]
+            assert float((upd_got - upd_ref).abs().max()) < 2e-5, k

@@ -78,6 +78,7 @@ class FlatBuffer(object):
             self.gviews[n] = self.grad[o:o + p.numel()].view(p.shape)
 
         self._slots = [(self.grad_padded, self.grad, self.gviews)]
+        self.detached = False
 
     def use_slot(self, i):
         """Gradient accumulation over micro-batches (trainer.micro_batches): slice i of a step writes its gradients into slot i --
@@ -97,6 +98,35 @@ class FlatBuffer(object):
         """Make param.grad alias the flat gradient segments (fused driver path)."""
         for n, p in zip(self.names, self.params):
             p.grad = self._slots[0][2][n]
+        self.detached = False
+
+    def grads_are_views(self):
+        """True when every parameter's .grad IS its segment of the flat gradient buffer (slot 0)."""
+        gv = self._slots[0][2]
+        return all(p.grad is not None and p.grad.data_ptr() == gv[n].data_ptr() and p.grad.shape == gv[n].shape
+                   for n, p in zip(self.names, self.params))
+
+    def before_autograd_backward(self):
+        """Called by the drop-in autograd Functions BEFORE the engine writes a backward's gradients into the flat buffer: a .grad
+        that still aliases the buffer holds something the caller has not cleared (no zero_grad since the last backward, or a fused
+        trainer attached it), which autograd's += must see intact -- it is moved to storage of its own first."""
+        gv = self._slots[0][2]
+        for n, p in zip(self.names, self.params):
+            if p.grad is not None and p.grad.data_ptr() == gv[n].data_ptr():
+                p.grad = p.grad.clone()
+                self.detached = True          # (a fused trainer re-attaches before its next step)
+
+    def deliver_grads(self):
+        """What a drop-in autograd backward returns for the parameters once the engine has written this backward's gradients into
+        the flat buffer.  After `zero_grad()` (set_to_none, torch's default: every .grad is None -- the state text.py:373 leaves)
+        the parameters' .grad become VIEWS of the flat buffer and autograd is handed nothing to accumulate: no 215 MB of clones
+        per step at the Yahoo shape, and lvae.clip_grad_norm_ / lvae.SGD can then run as single streaming launches over the
+        flat buffers.  In any other state (a .grad that already holds something: gradient accumulation across backward calls,
+        zero_grad(set_to_none=False)) autograd's += semantics are kept: clones are returned and accumulated as usual."""
+        if self.gviews is self._slots[0][2] and all(p.grad is None for p in self.params):
+            self.attach_grads()
+            return tuple(None for _ in self.names)
+        return tuple(self.gviews[n].clone() for n in self.names)
 
 
 def _tensor_bytes(obj, depth=0):
@@ -133,6 +163,7 @@ class _WS(object):
         self.nbytes = {}
         self.total = 0
         self.evictable = True
+        self.hits = self.misses = self.evictions = 0      # (measurement: bench.py's mixed-shape run reports the hit rate)
         self.before_evict = None      # called once before workspaces are dropped (the engine orders its side streams first)
         if budget_bytes is None:
             if self.device.type == "cuda":
@@ -145,7 +176,9 @@ class _WS(object):
         ws = self.cache.get(key)
         if ws is not None:
             self.cache.move_to_end(key)
+            self.hits += 1
             return ws
+        self.misses += 1
         ws = builder()
         nb = _tensor_bytes(ws)
         self.cache[key] = ws
@@ -177,6 +210,7 @@ class _WS(object):
                 told = True
             del self.cache[k]
             self.total -= self.nbytes.pop(k)
+            self.evictions += 1
 
     def f32(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -707,6 +741,8 @@ class LSTMEncoderEngine(object):
             # the cached bf16 / packed weight images describe the OLD flat buffer (p.data = X, module._apply and device moves keep
             # the parameters' version counters, so weights_version() alone would not notice)
             self._wimg = None
+            for p in self.flat.params:
+                p._lvae_engine = self         # lets optim.clip_grad_norm_ / optim.SGD find the flat buffers from the parameters
         self.lib = backend_for(device)
         if self.status is None or self.status.device != device:
             self.status = torch.zeros(1, dtype=torch.int32, device=device)
@@ -1028,6 +1064,8 @@ class LSTMDecoderEngine(object):
             # the cached bf16 / packed weight images describe the OLD flat buffer (p.data = X, module._apply and device moves keep
             # the parameters' version counters, so weights_version() alone would not notice)
             self._wimg = None
+            for p in self.flat.params:
+                p._lvae_engine = self         # lets optim.clip_grad_norm_ / optim.SGD find the flat buffers from the parameters
         self.lib = backend_for(device)
         if self.status is None or self.status.device != device:
             self.status = torch.zeros(1, dtype=torch.int32, device=device)

@@ -26,10 +26,10 @@ class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drec):
         eng = ctx.eng
+        eng.flat.before_autograd_backward()
         dz = eng.backward(drec, ctx.gen).clone().view(ctx.zshape)
         eng.join()
-        grads = tuple(eng.flat.gviews[n].clone() for n in eng.flat.names)
-        return (None, None, dz, None, None, None, None) + grads
+        return (None, None, dz, None, None, None, None) + eng.flat.deliver_grads()
 
 
 class LSTMDecoder(DecoderBase):

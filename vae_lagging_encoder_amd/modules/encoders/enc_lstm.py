@@ -24,9 +24,9 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmulv):
         eng = ctx.eng
+        eng.flat.before_autograd_backward()
         eng.backward(dmulv, ctx.gen)
-        grads = tuple(eng.flat.gviews[n].clone() for n in eng.flat.names)
-        return (None, None) + grads
+        return (None, None) + eng.flat.deliver_grads()
 
 
 class LSTMEncoder(GaussianEncoderBase):

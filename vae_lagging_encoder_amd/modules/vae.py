@@ -25,6 +25,21 @@ class VAE(nn.Module):
         dev = args.device
         self.prior = torch.distributions.normal.Normal(torch.zeros(self.nz, device=dev), torch.ones(self.nz, device=dev))
 
+    def set_precision(self, precision, encoder_forward=None):
+        """Arithmetic of the HIP path behind this model's `loss` / `backward` (no counterpart in the reference, whose precision is
+        the tensors' dtype): "f32" (default; exact-f32 MFMA, north_star's 1e-4 parity path) or "bf16" (BASELINE.json's GPU
+        configuration: bf16 matrix pipe with f32 accumulation for the large products and the recurrent operands; master weights,
+        state, gradients and reductions stay f32).  encoder_forward="f32" with "bf16": the encoder's forward f32-accurate (the KL
+        then meets 1e-4 too; see trainer.AggressiveTextTrainer).  Image models also take "bf16x3".  Returns self."""
+        for m in (self.encoder, self.decoder):
+            eng = getattr(m, "_hip", None)
+            if eng is None:
+                raise TypeError("%s has no HIP engine" % type(m).__name__)
+            eng.precision = precision
+        if hasattr(self.encoder._hip, "exact_forward"):
+            self.encoder._hip.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
+        return self
+
     # ---- training path (reference vae.py:35-98) ---------------------------------------------------------
     def encode(self, x, nsamples=1, eps=None):
         """-> z (batch, nsamples, nz), KL (batch,).  `eps` injects the reparameterisation noise."""

@@ -32,6 +32,12 @@ def _rank_seed(seed, grad_sync):
     return (int(seed) + 0x9E3779B1 * rank) & 0x7FFFFFFFFFFFFFFF
 
 
+def _log_demotion(rung):
+    import sys
+    print("vae_lagging_encoder_amd: a persistent LSTM launch reported a hand-off timeout; the voided steps are replayed on ladder rung "
+          "%d (%s)" % (rung, _eng.PERSIST_RUNGS[rung]), file=sys.stderr)
+
+
 class AggressiveTextTrainer(object):
     # data parallel: the embedding gradient goes out as its own all-reduce bucket when it has at least this many elements
     # (below ~4 MB a second collective costs more in latency than its overlap buys)
@@ -76,6 +82,15 @@ class AggressiveTextTrainer(object):
         self.enc.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
         if grad_sync is not None:
             grad_sync.resolve_payload(precision)              # "auto": bf16 wire for the bf16 configuration, exact fp32 otherwise
+            if self.micro_batches > 1 and grad_sync.world > 1 and precision == "bf16" and (self.enc.persistent or self.dec.persistent):
+                # slice i's collectives are in flight during slice i + 1's recurrences BY DESIGN here; a persistent launch needs all 256
+                # CUs resident at once and would run into its bounded hand-off spin beside an RCCL kernel (a timeout per step, then the
+                # ladder): micro-batch mode under data parallelism runs on the launch-per-timestep kernels from the start
+                self.enc.persistent = self.dec.persistent = False
+                import sys
+                print("vae_lagging_encoder_amd: micro_batches > 1 under data parallelism overlaps collectives with the next slice's "
+                      "recurrences; the persistent LSTM launches (which need the whole GPU) are off: %s" % _eng.PERSIST_RUNGS[2],
+                      file=sys.stderr)
         self.enc.flat.attach_grads()
         self.dec.flat.attach_grads()
         self.lib = _eng.backend_for(self.device)
@@ -93,7 +108,7 @@ class AggressiveTextTrainer(object):
         self._klw_host = 0.0                  # host copy of scal[0]
         self._journal = []                    # steps queued since the last host check: (x, kl_weight, noise, update)
         self._committed_base = 0.0            # scal[9] at the last host check
-        self.on_demote = None                 # optional callback(rung) after a move down the persistent-launch ladder (logging)
+        self.on_demote = _log_demotion        # callback(rung) after a move down the persistent-launch ladder; default: one line on stderr
         self.recoveries = 0                   # how many times a voided run of steps was replayed
         self.norm_ws = torch.empty(self.lib.lv_sumsq_workspace_floats(), dtype=torch.float32, device=d)
         # Philox (seed, offset), uint64 bits.  Data parallel: every rank draws from its own substream (the rank is folded
@@ -163,6 +178,11 @@ class AggressiveTextTrainer(object):
             v = self.scal.cpu().tolist()
         self._committed_base = v[9]
         self._journal = []
+        if v[9] >= 4194304.0:
+            # the committed-step counter is a float32 incremented by 1.0 per step: long before increments stop registering (2^24)
+            # it goes back to zero -- nothing is in flight here (this is behind a host read) and the journal is empty
+            self.scal[9] = 0
+            self._committed_base = 0.0
         return v
 
     def reset_stats(self):
@@ -513,6 +533,9 @@ class AggressiveTextTrainer(object):
         if self.micro_batches > 1:
             return self._queue_micro(x, kl_weight, noise, update, self.micro_batches)
         B, T = x.shape
+        for e in (self.enc, self.dec):
+            if e.flat.detached:           # a drop-in autograd backward moved some .grad off the flat buffer (FlatBuffer.before_autograd_backward)
+                e.flat.attach_grads()
         st = self._static_for(B, T)
         if self.use_graph or not (x.is_contiguous() and x.device == self.device and x.dtype == torch.int64):
             st.x.copy_(x)                 # captured graphs read the per-shape static buffer

@@ -17,6 +17,7 @@ import time
 import numpy as np
 import torch
 
+from . import engine as _eng
 from . import evaluation as E
 from .trainer import AggressiveImageTrainer, AggressiveTextTrainer
 
@@ -24,6 +25,29 @@ CLIP_GRAD = 5.0          # text.py:17-20
 DECAY_EPOCH = 2
 LR_DECAY = 0.5
 MAX_DECAY = 5
+
+
+def guarded_eval(vae, fn, log=print):
+    """Run an evaluation pass -- a forward-only use of the engines: there is no transaction gate in it -- and look at the engines'
+    persistent-launch status words afterwards (one host read each; every evaluation ends in host reads anyway).  A hand-off
+    timeout during the pass would have left garbage in its statistics, which drive best-state selection, learning-rate decay and
+    the end of aggressive training: the engines are moved one rung down the fallback ladder (engine.demote_persistent), the event
+    is logged, and the pass is run again.  Engines without persistent launches (the image model's) have no status word."""
+    engines = [e for e in (getattr(vae.encoder, "_hip", None), getattr(vae.decoder, "_hip", None))
+               if e is not None and getattr(e, "status", None) is not None]
+    for _ in range(3):
+        out = fn()
+        bad = [e for e in engines if int(e.status.item()) != 0]
+        if not bad:
+            return out
+        for e in engines:          # both engines take the same rung, as the trainers' _settle does
+            if _eng.persist_rung(e) < 2:
+                _eng.demote_persistent(e)
+            else:
+                _eng.reset_persistent_status(e)
+        log("persistent LSTM launch timed out during an evaluation pass: engines moved to ladder rung %d (%s), pass repeated" % (
+            max(_eng.persist_rung(e) for e in engines), _eng.PERSIST_RUNGS[max(_eng.persist_rung(e) for e in engines)]))
+    raise _eng._lib.LvaeError("an evaluation pass kept reporting persistent-launch timeouts on every rung of the fallback ladder")
 
 
 class TextTrainingLoop(object):
@@ -63,8 +87,7 @@ class TextTrainingLoop(object):
     def _eval_mi_au(self):
         self.vae.eval()
         with torch.no_grad():
-            mi = E.calc_mi(self.vae, self.val_batches)
-            au, _ = E.calc_au(self.vae, self.val_batches)
+            mi, au = guarded_eval(self.vae, lambda: (E.calc_mi(self.vae, self.val_batches), E.calc_au(self.vae, self.val_batches)[0]), self.log)
         self.vae.train()
         return mi, au
 
@@ -72,7 +95,7 @@ class TextTrainingLoop(object):
         """text.py:447-455: called when a full epoch worth of iterations has passed while aggressive."""
         self.vae.eval()
         with torch.no_grad():
-            cur_mi = E.calc_mi(self.vae, self.val_batches)
+            cur_mi = guarded_eval(self.vae, lambda: E.calc_mi(self.vae, self.val_batches), self.log)
         self.vae.train()
         self.log("pre mi:%.4f. cur mi:%.4f" % (self.pre_mi, cur_mi))
         self.mi_checks.append((self.pre_mi, cur_mi))
@@ -146,8 +169,10 @@ class TextTrainingLoop(object):
             self.log("kl weight %.4f" % self.kl_weight)
             self.vae.eval()
             with torch.no_grad():
-                loss, nll, kl, ppl, mi = E.test(self.vae, self.val_batches, "VAL", args, verbose=False, np_rng=self.rng)
-                au, _ = E.calc_au(self.vae, self.val_batches)
+                # (np_rng: E.test draws from it; a repeated pass after a timeout draws again -- the recorded replays never time out)
+                loss, nll, kl, ppl, mi = guarded_eval(
+                    self.vae, lambda: E.test(self.vae, self.val_batches, "VAL", args, verbose=False, np_rng=self.rng), self.log)
+                au = guarded_eval(self.vae, lambda: E.calc_au(self.vae, self.val_batches)[0], self.log)
             self.log("VAL --- avg_loss: %.4f, kl: %.4f, mi: %.4f, nll: %.4f, ppl: %.4f, %d active units" % (loss, kl, mi, nll, ppl, au))
             self.history.append(dict(epoch=epoch, loss=loss, nll=nll, kl=kl, ppl=ppl, mi=mi, au=au, aggressive=self.aggressive,
                                      kl_weight=self.kl_weight, lr=self.opt["lr"]))
@@ -158,7 +183,7 @@ class TextTrainingLoop(object):
                 break
             if epoch % getattr(args, "test_nepoch", 5) == 0 and self.test_batches:
                 with torch.no_grad():
-                    E.test(self.vae, self.test_batches, "TEST", args, verbose=False, np_rng=self.rng)
+                    guarded_eval(self.vae, lambda: E.test(self.vae, self.test_batches, "TEST", args, verbose=False, np_rng=self.rng), self.log)
             self.vae.train()
         if self.best["state"] is not None:
             self.vae.load_state_dict(self.best["state"])
