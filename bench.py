@@ -388,8 +388,28 @@ def side_run_mixed_shapes(dev, steps=200, fixed_tokens_per_s=None):
            "steady_state_allocator_requests": int(m1["allocation.all.allocated"] - m0["allocation.all.allocated"]),
            "lstm_ladder_rung": rung, "recoveries": tr.recoveries}
     if fixed_tokens_per_s:
-        rec["tokens_per_s_vs_fixed_shape"] = round(rec["tokens_per_s"] / fixed_tokens_per_s, 3)
-    del tr, vae, pool
+        rec["tokens_per_s_vs_fixed_shape"] = round(rec["tokens_per_s"] / fixed_tokens_per_s, 3)      # vs the headline's T = 200
+    # control: the same trainer on a FIXED shape at the pool's mean length -- a step's cost per token rises as T falls (the
+    # vocabulary-sized products shrink, launch and per-recurrence fixed costs do not), so this, not the T = 200 headline, is
+    # what tells how much the MIXING of shapes costs
+    Tm = int(round(float(lens.mean())))
+    cpool = [synthetic_batch(32, Tm, V, seed=9500 + i).to(dev) for i in range(8)]
+    tr.prepare_batches(cpool)
+    for x in cpool:
+        tr.step(x, 0.1)
+    tr.commit()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(60):
+        tr.step(cpool[int(rs.randint(0, len(cpool)))], 0.1)
+        if (i + 1) % 15 == 0:
+            tr.read_stats()
+    tr.commit()
+    torch.cuda.synchronize(dev)
+    d1 = time.perf_counter() - t1
+    rec["fixed_shape_control"] = {"T": Tm, "B": 32, "tokens_per_s": round(60 * 32 * Tm / d1, 1), "ms_per_step": round(1e3 * d1 / 60, 4)}
+    rec["tokens_per_s_vs_fixed_shape_at_mean_length"] = round(rec["tokens_per_s"] / rec["fixed_shape_control"]["tokens_per_s"], 3)
+    del tr, vae, pool, cpool
     torch.cuda.empty_cache()
     return rec
 

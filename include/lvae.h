@@ -155,7 +155,13 @@ int lv_lstm_fwd_f32_ug(const float* gx, const float* whh, float* hs, float* cs, 
  * front of the next hand-off poll: 1.5 us of a 7.9 us BPTT timestep.)  hs: [T + 1][B][H] as everywhere; cs: [T + 1][B][H], of which
  * these kernels read slot 0 (the initial state) and write slot T (the final one) only. */
 long lv_lstm_persist16_wpk_floats(void);
+/* exchange buffer [forward half 0 | forward half 1 | BPTT half 0 | BPTT half 1].  flags bit 1 (2) of the two launches: double-buffered
+ * -- bit 2 (4) names the half this launch uses, which must be zero (allocate zeroed; alternate strictly per kind of launch); the launch
+ * zeroes the OTHER half of its kind in its prologue, so no memset launch precedes it.  BPTT: bits 3..4 name the instantiation (1 / 2 / 3 =
+ * up to 4 / 8 / 16 rows per group; 0 = this launch's own) of the launch that last used the other half = the extent to clear.  Without
+ * bit 1: half 0 behind a hipMemsetAsync (hipGraph replays cannot alternate).  lv_lstm_persist16_xch_clear zeroes the whole buffer. */
 long lv_lstm_persist16_xch_floats(void);
+int lv_lstm_persist16_xch_clear(float* xch, void* stream);
 long lv_lstm_persist16_saved_floats(int T, int R);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
 int lv_lstm_persist16_pack2(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream);   /* both images, one launch */

@@ -54,6 +54,7 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
             # the embedding gradient as a row list (all-gather of the touched rows) instead of inside the dense all-reduce
             assert tr.enable_row_exchange([x], mode="rows")
             tr.BUCKET_MIN_ELEMS = 1
+            os.environ["LVAE_DP_DEBUG"] = "1"       # every step checks that all ranks are on the same pool batch (dist.start_encoder_rows)
         if name_suffix.startswith("fault") and rank == 1:
             # what a timed-out persistent launch leaves behind, on ONE rank: the guard element of the encoder exchange must void
             # the step on BOTH ranks, and both must replay it one rung down the ladder (else the replicas diverge)

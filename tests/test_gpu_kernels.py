@@ -640,6 +640,64 @@ def test_lstm_bwd_persistent16(lib, hip_device, T, B, R, tanh_init, use_ext, use
         assert rms < 1e-3 and err < (2 ** -7 if what == "dG" else 1e-3) * sc, (what, err / sc, rms)
 
 
+@pytest.mark.parametrize("T,seq", [(6, [(32, 4), (128, 16), (32, 4), (13, 2), (64, 8), (32, 4)])])
+def test_persistent_exchange_halves_alternate_without_memsets(lib, hip_device, T, seq, local=1, repeat_fwd=3):
+    """flags bit 1 of the persistent launches: the exchange buffer's halves alternate per kind of launch and every launch zeroes the
+    other half of its kind in its prologue (engine._xch_flags keeps the state) -- no memset launch.  A run of forward + BPTT launches
+    whose batch size (hence instantiation and polled extent) changes from launch to launch, all on ONE buffer, must give bit for bit
+    what each launch gives on a freshly zeroed buffer in the memset form: a stale tag anywhere would be read as data."""
+    from types import SimpleNamespace
+    from vae_lagging_encoder_amd.engine import _xch_flags
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(77)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    wf = torch.empty(lib.lv_lstm_persist16_wpk_floats(), device=dev)
+    wb = torch.empty(lib.lv_lstm_persist16_wpk_floats(), device=dev)
+    lib.lv_lstm_persist16_pack2(P(whh), P(wf), P(wb), H, _s(dev))
+    shared = torch.zeros(lib.lv_lstm_persist16_xch_floats(), device=dev)
+    wi = SimpleNamespace(xstate={"f": 0, "g": 0, "gcls": [0, 0]})
+
+    def run(B, R, xch, ff, fb, seed):
+        gg = torch.Generator().manual_seed(seed)
+        gx = (torch.randn(T, B, 4 * H, generator=gg) * 0.5).to(dev)
+        dO = torch.randn(T, B, H, generator=gg).to(dev)
+        hs = torch.zeros(T + 1, B, H, device=dev)
+        cs = torch.zeros(T + 1, B, H, device=dev)
+        cs[0] = (torch.randn(B, H, generator=gg) * 0.5).to(dev)
+        saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, R), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.lv_lstm_fwd_bf16_persist16(P(gx), P(wf), P(hs), P(cs), P(saved), P(xch), P(status), T, B, R, ff, H, _s(dev))
+        dG16 = torch.zeros(T, B, 4 * H, dtype=torch.int16, device=dev)
+        dGsum = torch.empty(B, 4 * H, device=dev)
+        dc0 = torch.empty(B, H, device=dev)
+        lib.lv_lstm_bwd_bf16_persist16(P(dO), None, P(wb), P(saved), P(hs), P(cs), P(dG16), P(dGsum), P(xch), P(status), None, P(dc0), 0,
+                                       T, B, R, fb, H, _s(dev))
+        assert int(status.item()) == 0, int(status.item())
+        return hs.cpu(), dG16.cpu(), dGsum.cpu(), dc0.cpu()
+    for i, (B, R) in enumerate(seq):
+        fresh = torch.zeros(lib.lv_lstm_persist16_xch_floats(), device=dev)
+        want = run(B, R, fresh, local, local, 100 + i)                  # memset form, half 0 of a clean buffer
+        ff = local | _xch_flags(wi, "f", R, "cpu")
+        fb = local | _xch_flags(wi, "g", R, "cpu")
+        assert (ff & 2) and (fb & 2)
+        got = run(B, R, shared, ff, fb, 100 + i)
+        for a, b, what in zip(got, want, ("hs", "dG16", "dGsum", "dc0")):
+            assert torch.equal(a, b), (i, B, R, what)
+    # a second forward in a row (the encoder's two-pass exact forward, evaluation passes) keeps alternating
+    for i in range(repeat_fwd):
+        ff = local | _xch_flags(wi, "f", 4, "cpu")
+        gg = torch.Generator().manual_seed(5)
+        gx = (torch.randn(T, 32, 4 * H, generator=gg) * 0.5).to(dev)
+        hs = torch.zeros(T + 1, 32, H, device=dev); cs = torch.zeros(T + 1, 32, H, device=dev)
+        saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, 4), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.lv_lstm_fwd_bf16_persist16(P(gx), P(wf), P(hs), P(cs), P(saved), P(shared), P(status), T, 32, 4, ff, H, _s(dev))
+        assert int(status.item()) == 0
+        if i == 0:
+            first = hs.cpu()
+        assert torch.equal(hs.cpu(), first)
+
+
 @pytest.mark.parametrize("kernels", ["B32_R4", "B64_R8", "B128_R16", "B100_R13", "B13_R2"])
 def test_lstm_persistent_recurrences_at_headline_length(lib, hip_device, kernels):
     """Both persistent recurrences (lv_lstm_persist16.hip, hand-off in the XCD's L2) at the length the metric is quoted on

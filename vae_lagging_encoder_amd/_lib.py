@@ -58,6 +58,7 @@ SIGNATURES = {
     "lv_rng_noise_step": [_vp, _l, _vp, _l, _f, _vp, _l, _f, _vp, _u64, _vp],
     "lv_lstm_persist16_wpk_floats": [],
     "lv_lstm_persist16_xch_floats": [],
+    "lv_lstm_persist16_xch_clear": [_vp, _vp],
     "lv_lstm_persist16_saved_floats": [_i, _i],
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
     "lv_lstm_persist16_import_saved": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -111,7 +111,16 @@ struct Fwd16P {
     gran_t* hx;                 // exchange: [2 parity][8 groups][16 rows][H/2] granules, zeroed before the launch
     int* status;
     int T, B, R;
+    uint4* clr; long clr_n;     // double-buffered exchange (flags bit 1): the OTHER half, zeroed by this launch for the next one (clr_n uint4s)
 };
+
+// Zero `n` uint4s, the whole grid sharing the work (the first thing a persistent launch does, before a group without rows leaves):
+// the exchange half the NEXT launch of this kind will poll.  Nobody reads it during this launch; the kernel boundary publishes it.
+__device__ __forceinline__ void clear_other_half(uint4* q, long n) {
+    if (!q) return;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 
 // =====================================================================================================================
 // forward.  RP: rows per group this instantiation carries (4 / 8 / 16); NP = pairs (row, unit) per thread; SBK = timesteps per
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     const int B = p.B, R = p.R, T = p.T;
     const int b0 = group * R;
     const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    clear_other_half(p.clr, p.clr_n);
     if (rows == 0) return;                                    // a group without rows leaves its XCD to whoever else wants it
     if (tid == 0) s_abort = 0;
 
@@ -342,6 +352,7 @@ struct Bwd16P {
     gran_t* gxch;
     int* status;
     int T, B, R;
+    uint4* clr; long clr_n;     // as Fwd16P
 };
 
 template <int RP>
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     const int B = p.B, R = p.R, T = p.T;
     const int b0 = group * R;
     const int rows = (b0 >= B) ? 0 : ((B - b0) < R ? (B - b0) : R);
+    clear_other_half(p.clr, p.clr_n);
     if (rows == 0) return;
     if (tid == 0) s_abort = 0;
     for (int i = tid; i < 2 * 16 * DP16; i += 256) sm.dgl[0][i] = 0u;      // rows the slice does not have multiply as zeros
@@ -651,7 +663,19 @@ int check_R(int B, int R) { return R >= 1 && R <= 16 && (long)R * PGROUPS >= B; 
 
 }  // namespace
 
-extern "C" long lv_lstm_persist16_xch_floats(void) { return XCH_RS16_BYTES / 4 + 64; }
+// exchange buffer: [forward half 0 | forward half 1 | BPTT half 0 | BPTT half 1] (+ slack).  flags bit 1 of the two launches: the
+// caller alternates the halves -- bit 2 says which one this launch uses -- and every launch zeroes the other half of its own kind
+// in its prologue, so no memset launch precedes it (4 x (4.8 us + a kernel boundary) per training step, profiles/r04z_lstm_fixed_cost.txt).
+// The buffer must be zero when first used, and the half named by bit 2 must have been cleared by the previous launch of that kind
+// (alternate strictly; lv_lstm_persist16_xch_clear zeroes everything, e.g. after the bit has been used inconsistently).
+// Without bit 1 a launch uses half 0 behind a hipMemsetAsync, as before (hipGraph capture: a replay cannot alternate).
+constexpr long XCH_FWD_OFF[2] = {0, XCH_FWD16_BYTES};
+constexpr long XCH_BWD_OFF[2] = {2 * XCH_FWD16_BYTES, 2 * XCH_FWD16_BYTES + XCH_RS16_BYTES};
+extern "C" long lv_lstm_persist16_xch_floats(void) { return (2 * XCH_FWD16_BYTES + 2 * XCH_RS16_BYTES) / 4 + 64; }
+extern "C" int lv_lstm_persist16_xch_clear(float* xch, void* stream) {
+    if (!xch) return LV_ERR_ARG;
+    return (int)hipMemsetAsync(xch, 0, (size_t)(2 * XCH_FWD16_BYTES + 2 * XCH_RS16_BYTES), (hipStream_t)stream);
+}
 // floats of ONE packed bf16 image of W_hh (forward or BPTT form: 128 waves x 64 fragments x 64 lanes x 16 bytes = 8 MB)
 extern "C" long lv_lstm_persist16_wpk_floats(void) { return 128L * 64 * 64 * 16 / 4; }
 
@@ -737,9 +761,12 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
         return LV_ERR_ALIGN;
     if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;      // the groups in use must be resident at once
     if (T == 0) return LV_OK;
-    gran_t* hx = reinterpret_cast<gran_t*>(xch);
-    (void)hipMemsetAsync(hx, 0, (size_t)XCH_FWD16_BYTES, (hipStream_t)stream);
-    Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, saved, hx, status, T, B, R};
+    char* const xb = reinterpret_cast<char*>(xch);
+    const int dbl = (flags >> 1) & 1, half = dbl ? (flags >> 2) & 1 : 0;
+    gran_t* hx = reinterpret_cast<gran_t*>(xb + XCH_FWD_OFF[half]);
+    if (!dbl) (void)hipMemsetAsync(hx, 0, (size_t)XCH_FWD16_BYTES, (hipStream_t)stream);
+    Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, saved, hx, status, T, B, R,
+             dbl ? reinterpret_cast<uint4*>(xb + XCH_FWD_OFF[1 - half]) : nullptr, XCH_FWD16_BYTES / 16};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
     if (flags & 1) {
         if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, true>), grid, block, 0, stream, p);
@@ -766,10 +793,19 @@ extern "C" int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_l
     if ((((uintptr_t)wpk) & 15) != 0 || (((uintptr_t)saved) & 15) != 0 || (((uintptr_t)xch) & 15) != 0 || (((uintptr_t)dG16) & 15) != 0)
         return LV_ERR_ALIGN;
     if (lv_device_cus() < PGROUPS * PMEMBERS) return LV_ERR_UNSUPPORTED;
-    gran_t* gxch = reinterpret_cast<gran_t*>(xch);
+    char* const xb = reinterpret_cast<char*>(xch);
+    const int dbl = (flags >> 1) & 1, half = dbl ? (flags >> 2) & 1 : 0;
+    gran_t* gxch = reinterpret_cast<gran_t*>(xb + XCH_BWD_OFF[half]);
     const int RPi = R <= 4 ? 4 : (R <= 8 ? 8 : 16);
-    (void)hipMemsetAsync(gxch, 0, (size_t)(XCH_RS16_BYTES / RS16_SLOTS_MAX * 16 * RPi), (hipStream_t)stream);      // the instantiation's dense extent
-    Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), saved, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R};
+    const long extent = XCH_RS16_BYTES / RS16_SLOTS_MAX * 16 * RPi;                  // the instantiation's dense extent
+    // double-buffered: the other half is cleared over the extent of the launch that last USED it -- flags bits 3..4 name that
+    // launch's instantiation (1 / 2 / 3 = 4 / 8 / 16 rows; 0 = the same as this one): a batch size that changes between launches
+    // changes the extent, and stale tags beyond a smaller clear would be read as data
+    const int ccls = (flags >> 3) & 3;
+    const long cextent = XCH_RS16_BYTES / RS16_SLOTS_MAX * 16 * (ccls == 0 ? RPi : (4 << (ccls - 1)));
+    if (!dbl) (void)hipMemsetAsync(gxch, 0, (size_t)extent, (hipStream_t)stream);
+    Bwd16P p{dh_ext, dh_last, reinterpret_cast<const uint4*>(wpk), saved, cs, hs, dG16, dGsum, dh0, dc0, tanh_init, gxch, status, T, B, R,
+             dbl ? reinterpret_cast<uint4*>(xb + XCH_BWD_OFF[1 - half]) : nullptr, cextent / 16};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
     if (flags & 1) {
         if (R <= 4) LV_LAUNCH_RESIDENT((lstm_bwd_persist_rs16_kernel<4, true>), grid, block, 0, stream, p);

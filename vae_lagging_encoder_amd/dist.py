@@ -267,6 +267,15 @@ class GradSync(object):
         n_emb]): gather this rank's `cap` rows into the wire buffer (f32, or bf16 under the bf16 payload), all-gather them.
         sync_collect() rebuilds the dense mean in place."""
         R = self.rows
+        if os.environ.get("LVAE_DP_DEBUG"):
+            # the gathered rows are paired with id lists by POOL INDEX: every rank must be on the same j (the aggressive loop's
+            # replicated host draws give that; a rank-specific seed or skip would silently mis-pair rows).  Debug mode: one small
+            # host-synchronising all-gather per step.
+            js = [None] * self.world
+            dist.all_gather_object(js, int(j), group=self.group)
+            if any(v != js[0] for v in js):
+                raise _eng._lib.LvaeError("row-list exchange: the ranks are on different pool batches this step (%r); their host "
+                                          "random streams have diverged" % (js,))
         lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
         st = self._cur
         cap, ni, V = R["cap"], R["ni"], R["V"]

@@ -501,10 +501,35 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
         if wi.fwd16 is None:
             n = lib.lv_lstm_persist16_wpk_floats()
             wi.fwd16, wi.bwd16 = c.f32(n), c.f32(n)
-            wi.xch = c.f32(lib.lv_lstm_persist16_xch_floats())
+            # hand-off exchange buffer, zeroed once: the launches alternate its halves and clear the other one themselves
+            wi.xch = torch.zeros(lib.lv_lstm_persist16_xch_floats(), dtype=torch.float32, device=c.device)
+            wi.xstate = {"f": 0, "g": 0, "gcls": [0, 0]}      # next half per kind of launch; instantiation that last used each BPTT half
         lib.lv_lstm_persist16_pack2(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), P(wi.bwd16), H, s)
         wi.packed16 = True
     return wi
+
+
+def _xch_flags(wi, kind, rows, device):
+    """Flag bits 1.. of a persistent launch (lv_lstm_persist16_xch_floats): the exchange buffer's halves alternate per kind of launch
+    ("f" forward, "g" BPTT) and every launch clears the other half of its kind itself -- no memset launch in front (4 per training
+    step before: ~26 us).  Not under hipGraph capture: a replay repeats the captured half, so captured launches keep half 0 behind
+    their memset (and leave the alternation state alone)."""
+    st = wi.xstate
+    if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+        st["captured"] = True
+    if st.get("captured"):
+        # a captured launch dirties half 0 at every replay, unseen from here: once an engine's launches live in a graph, ALL its
+        # launches (eager ones too) stay in the memset form
+        return 0
+    half = st[kind]
+    st[kind] = 1 - half
+    fl = 2 | (half << 2)
+    if kind == "g":
+        cls = 1 if rows <= 4 else (2 if rows <= 8 else 3)
+        fl |= st["gcls"][1 - half] << 3          # clear the other half over what its last user dirtied (0: never used -> own extent)
+        st["gcls"][half] = cls
+        st["gcls"][1 - half] = 0
+    return fl
 
 
 def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, device):
@@ -524,7 +549,8 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         need = lib.lv_lstm_persist16_saved_floats(T, rows)
         if w.gates.numel() < need:              # eng.persist_rows / eng.persistent changed after the workspace was built
             w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
-        lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(eng.status), T, B, rows, eng.persist_flags, H, s)
+        lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(eng.status), T, B, rows,
+                                       eng.persist_flags | _xch_flags(wi, "f", rows, device), H, s)
         w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
@@ -570,7 +596,7 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
             raise _lib.LvaeError("the saved activations were not written by a persistent forward with the same T, B and rows per "
                                  "group (%r): eng.persist_rows / eng.persistent changed between forward and backward" % (getattr(w, "saved_layout", None),))
         lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
-                                       P(eng.status), dh0, dc0, tanh_init, T, B, rows, eng.persist_flags, H, s)
+                                       P(eng.status), dh0, dc0, tanh_init, T, B, rows, eng.persist_flags | _xch_flags(wi, "g", rows, device), H, s)
     else:
         _need_canonical_saved(w)
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
