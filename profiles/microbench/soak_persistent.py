@@ -1,6 +1,6 @@
 """Soak test (measurement tooling): many aggressive inner steps on batches of varying shape (B <= 32, T <= 200) through the
 persistent LSTM launches, checking the finiteness of the loss and, at the end, that no step had to be replayed (ladder rung 0, no recoveries); prints steps/s.
-usage (GPU box): python profiles/microbench/soak_persistent.py [steps] [max batch]"""
+usage (GPU box): python profiles/microbench/soak_persistent.py [steps] [max batch] [exact]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -13,7 +13,8 @@ BMAX = int(sys.argv[2]) if len(sys.argv) > 2 else 32          # 128: also the 8-
 dev = torch.device("cuda:0")
 V = 20001
 vae = build_text_vae(V, 512, 1024, 32, dev, seed=3)
-tr = AggressiveTextTrainer(vae, lr=0.05, clip=5.0, precision="bf16", seed=11)
+EXACT = len(sys.argv) > 3 and sys.argv[3] == "exact"           # the encoder's two-pass exact forward (two forward launches in a row)
+tr = AggressiveTextTrainer(vae, lr=0.05, clip=5.0, precision="bf16", seed=11, encoder_forward="f32" if EXACT else None)
 rs = np.random.RandomState(5)
 t0 = time.time()
 shapes = set()

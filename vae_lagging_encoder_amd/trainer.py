@@ -22,8 +22,10 @@ class _Static(object):
     pass
 
 
-# eager mode: how many (B, T) shapes keep their per-shape step buffers (inputs, masks, per-row scalars; ~7 MB each at the Yahoo dims)
-STATIC_SHAPES = 64
+# eager mode: how many (B, T) shapes keep their per-shape step buffers (inputs, masks, per-row scalars; <= 10 MB each at the Yahoo
+# dims: 5 GB at most).  A corpus bucketed by sentence length (data/text_data.py:219-255) cycles through one shape per length plus
+# the tails: with 64 slots bench.py's 71-shape mixed pool rebuilt a slot -- one allocator request -- on every step (round 5).
+STATIC_SHAPES = 512
 
 
 def _rank_seed(seed, grad_sync):
