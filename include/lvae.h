@@ -109,6 +109,15 @@ int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, uint16_t* ds
  * function of the forward's last state, and WEIGHT rounding is what moves it -- profiles/r05a_kl_ablation.txt). */
 int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz, int V,
                        uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
+/* Operand images for a forward product on the BINARY16 matrix pipe: dst = IEEE half (RNE) in the plain / unit-major gate rows / gathered
+ * embedding rows layouts (arguments as lv_cvt_bf16_lo_f32), dstT = the transposed BF16 image the gradient products of the same operand
+ * read.  lv_gemm_h16 = lv_gemm_b16 (transA = 0, 128 x 128 tile) on such operands: v_mfma_f32_32x32x16_f16, f32 accumulation.  The
+ * encoder's input projection X W_ih^T (enc_lstm.py:50-55).  Values beyond 65504 become infinities: bounded operands only. */
+int lv_cvt_h16_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz, int V,
+                   uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
+int lv_gemm_h16(int M, int N, int K, float alpha, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                float* C, long ldc, int accumulate, const float* add1, long ld1, int mod1,
+                const float* add2, long ld2, int mod2, float* ws, long ws_floats, void* stream);
 /* out[cols][rows] = in[rows][cols]^T  (W_hh^T for BPTT) */
 int lv_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int lv_transpose_ld_f32(const float* in, long in_ld, float* out, long out_ld, int rows, int cols, void* stream);
@@ -165,6 +174,13 @@ int lv_lstm_persist16_xch_clear(float* xch, void* stream);
 long lv_lstm_persist16_saved_floats(int T, int R);
 int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward, int H, void* stream);
 int lv_lstm_persist16_pack2(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream);   /* both images, one launch */
+/* BINARY16 recurrent operands for the FORWARD (flags bit 5 = 32 of lv_lstm_fwd_bf16_persist16; weight image from
+ * lv_lstm_persist16_pack(.., backward = 2, ..) or lv_lstm_persist16_pack2_h16, which also writes the bf16 BPTT image): W_hh and the h
+ * granules as IEEE half on v_mfma_f32_16x16x32_f16 -- 11 instead of 8 bits of significand at the same cost.  For the ENCODER
+ * (enc_lstm.py:55-62): the KL of encoder.py:55 is a function of the forward's last state, and what moves that state in the bf16
+ * configuration is the rounding of the WEIGHTS (the same perturbation at every timestep), not of h.  LSTM weights and h in (-1, 1) are
+ * far inside binary16's range; the BPTT stays bf16 (gradients need the exponent range). */
+int lv_lstm_persist16_pack2_h16(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream);
 int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, float* hs, float* cs, float* saved, float* xch, int* status,
                                int T, int B, int R, int flags, int H, void* stream);
 int lv_lstm_bwd_bf16_persist16(const float* dh_ext, const float* dh_last, const float* wpk, const float* saved, const float* hs,

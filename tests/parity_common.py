@@ -282,6 +282,7 @@ def check_bf16_native_operands_equal_on_the_fly(device, V=333, ni=24, H=64, nz=8
         vae = build_vae(V, ni, H, nz, device, params=P)
         tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
         tr.dec.native16 = tr.enc.native16 = native
+        tr.enc.fwd_operands = "bf16"            # (the image path's default forward operands are binary16; this compares the two bf16 routes)
         tr.step(x.to(device), 0.6, noise=noise)
         st = tr.read_stats()
         grads = {k: p.grad.detach().cpu().clone() for k, p in vae.named_parameters()}

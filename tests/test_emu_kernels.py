@@ -224,6 +224,20 @@ def test_lstm_bwd_persistent16_emulated(emu_backend, cfg):
     K.test_lstm_bwd_persistent16(emu_backend, CPU, *cfg, 0)
 
 
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
+def test_cvt_h16_emulated(emu_backend, mode, R, C):
+    K.test_cvt_h16(emu_backend, CPU, mode, R, C)
+
+
+@pytest.mark.parametrize("M,N,K_,acc", [(130, 140, 96, 0), (64, 64, 72, 1)])
+def test_gemm_h16_emulated(emu_backend, M, N, K_, acc):
+    K.test_gemm_h16(emu_backend, CPU, M, N, K_, acc)
+
+
+def test_lstm_fwd_persistent16_binary16_operands_emulated(emu_backend):
+    K.test_lstm_fwd_persistent16_binary16_operands(emu_backend, CPU, 2, 8, 1, 0)
+
+
 def test_persistent_exchange_halves_alternate_without_memsets_emulated(emu_backend):
     K.test_persistent_exchange_halves_alternate_without_memsets(emu_backend, CPU, 1, [(8, 1), (27, 14), (8, 1)], local=0, repeat_fwd=0)
 

@@ -566,6 +566,110 @@ def test_lstm_fwd_persistent16(lib, hip_device, T, B, R, flags):
         assert float((a - b).abs().max()) < 1e-3, what
 
 
+@pytest.mark.parametrize("T,B,R,flags", [(6, 32, 4, 1), (9, 32, 8, 0), (7, 128, 16, 1), (3, 13, 2, 1), (60, 32, 4, 1)])
+def test_lstm_fwd_persistent16_binary16_operands(lib, hip_device, T, B, R, flags):
+    """flags bit 5 of the persistent forward: W_hh (register image packed with backward = 2) and the h granules as IEEE binary16 on
+    v_mfma_f32_16x16x32_f16.  Against the float64 recurrence whose recurrent product sees binary16-rounded W_hh and h_{t-1} at
+    2e-4 (the bf16 form is held to 1e-3 against ITS rounding), and CLOSER to the exact float64 recurrence than the bf16 form is
+    (what the format is for: 11 instead of 8 bits of significand on the weights)."""
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(T * 100 + B + 3)
+    gx = (torch.randn(T, B, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev)
+    c0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    h0 = torch.tanh(c0)
+
+    def ref(rnd):
+        w = rnd(whh.float()).double()
+        h, c = h0.double(), c0.double()
+        hs = [h]
+        for t in range(T):
+            a = gx[t].double() + rnd(h.float()).double() @ w.t()
+            i, f, gg, o = a.chunk(4, -1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hs.append(h)
+        return torch.stack(hs)
+    hs_h = ref(lambda v: v.to(torch.float16).float())
+    hs_exact = ref(lambda v: v)
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1).to(dev)
+    gxu = gx[:, :, perm].contiguous()
+    errs = {}
+    for fmt, pk, fl in (("f16", 2, flags | 32), ("bf16", 0, flags)):
+        hs = torch.zeros(T + 1, B, H, device=dev)
+        cs = torch.zeros(T + 1, B, H, device=dev)
+        hs[0], cs[0] = h0, c0
+        wpk = torch.full((lib.lv_lstm_persist16_wpk_floats(),), float("nan"), device=dev)
+        xch = torch.zeros(lib.lv_lstm_persist16_xch_floats(), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib.lv_lstm_persist16_pack(P(whh), P(wpk), pk, H, _s(dev))
+        saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, R), device=dev)
+        lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(xch), P(status), T, B, R, fl, H, _s(dev))
+        assert int(status.item()) == 0
+        if fmt == "f16":
+            assert float((hs.double() - hs_h).abs().max()) < 2e-4
+        errs[fmt] = float((hs.double() - hs_exact).pow(2).mean().sqrt())
+    assert errs["f16"] < 0.35 * errs["bf16"], errs        # ~8x finer operand rounding (rms over all h_t; measured ~0.13)
+
+
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
+def test_cvt_h16(lib, hip_device, mode, R, C):
+    """lv_cvt_h16_f32: dst = IEEE binary16 (RNE) in the plain / unit-major gate rows / gathered layouts, dstT = the transposed BF16
+    image (forward operand on the binary16 pipe, gradient operand on the bf16 pipe, one launch)."""
+    g = torch.Generator().manual_seed(R * 7 + C)
+    dev = hip_device
+    lds, ldd, ldt = C + 3, C + 8, R + 5
+    if mode == "gather":
+        T, B, V = 5, 7, 19
+        src = torch.randn(V, C, generator=g); lds = C
+        ids = torch.randint(0, V, (B, T + 2), generator=g)
+        rows = torch.stack([src[ids[b, t]] for t in range(T) for b in range(B)])
+    else:
+        src = torch.randn(R, lds, generator=g)
+        src[0, 0] = 1.00048828125          # a tie between two binary16 values: RNE picks the even significand (1.0)
+        rows = src[:, :C]
+    want_d = rows.to(torch.float16).view(torch.int16)
+    if mode == "gates":
+        H = R // 4
+        want_d = want_d[torch.arange(4 * H).view(4, H).t().reshape(-1)]
+    d = torch.full((R, ldd), 0x1234, dtype=torch.int16, device=dev)
+    dT = torch.full((C, ldt), 0x1234, dtype=torch.int16, device=dev)
+    sd = src.to(dev)
+    if mode == "gather":
+        lib.lv_cvt_h16_f32(P(sd), lds, R, C, 0, P(ids.to(dev)), T + 2, B, V, P(d), ldd, P(dT), ldt, _s(dev))
+    else:
+        lib.lv_cvt_h16_f32(P(sd), lds, R, C, R // 4 if mode == "gates" else 0, None, 0, 1, 0, P(d), ldd, P(dT), ldt, _s(dev))
+    assert torch.equal(d.cpu()[:, :C], want_d)
+    assert torch.equal(dT.cpu()[:, :R], _bf16_bits(rows).t())
+    assert bool((d.cpu()[:, C:] == 0x1234).all()) and bool((dT.cpu()[:, R:] == 0x1234).all())
+
+
+@pytest.mark.parametrize("M,N,K,acc", [(130, 140, 96, 0), (256, 128, 512, 0), (64, 64, 72, 1), (200, 4096, 544, 0), (6400, 512, 4096, 0)])
+def test_gemm_h16(lib, hip_device, M, N, K, acc):
+    """lv_gemm_h16: C = A . B^T (+ row-cyclic addend, accumulate) on binary16 operand images, f32 accumulation: against the
+    float64 product of the binary16-rounded operands (f32 summation order is all that differs), incl. a ragged K tile, the
+    decoder-sized K = 544 and a split-K shape."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 0.3
+    Bm = torch.randn(N, K, generator=g) * 0.1
+    add = torch.randn(3, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    lda, ldb = (K + 7) // 8 * 8, (K + 7) // 8 * 8
+    A16 = torch.zeros(M, lda, dtype=torch.int16, device=dev)
+    B16 = torch.zeros(N, ldb, dtype=torch.int16, device=dev)
+    lib.lv_cvt_h16_f32(P(A.to(dev)), K, M, K, 0, None, 0, 1, 0, P(A16), lda, None, 0, _s(dev))
+    lib.lv_cvt_h16_f32(P(Bm.to(dev)), K, N, K, 0, None, 0, 1, 0, P(B16), ldb, None, 0, _s(dev))
+    C = C0.clone().to(dev)
+    ws = torch.empty(1 << 24, device=dev)
+    addd = add.to(dev)
+    lib.lv_gemm_h16(M, N, K, 1.0, P(A16), lda, P(B16), ldb, P(C), N, acc, P(addd), N, 3, None, 0, 1, P(ws), ws.numel(), _s(dev))
+    ref = A.to(torch.float16).double() @ Bm.to(torch.float16).double().t() + add.double()[torch.arange(M) % 3]
+    if acc:
+        ref = ref + C0.double()
+    assert float((C.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5)
+
+
 @pytest.mark.parametrize("T,B,R,tanh_init,use_ext,use_last", [
     (6, 32, 4, True, True, False), (9, 32, 8, False, True, True), (5, 64, 8, True, True, False), (7, 128, 16, True, True, False),
     (40, 32, 8, True, True, False), (3, 13, 2, True, True, True), (4, 100, 13, False, True, True), (17, 8, 1, False, False, True),

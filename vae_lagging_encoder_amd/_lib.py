@@ -22,6 +22,7 @@ SIGNATURES = {
     "lv_gemm_f32": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_bf16": [_i, _i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16": [_i, _i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
+    "lv_gemm_h16": [_i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16_keep": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _vp, _l, _vp],
     "lv_gemm_b16_sumsq_parts": [_i, _i, _i, _l],
     "lv_gemm_b16_sumsq": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp],
@@ -37,6 +38,7 @@ SIGNATURES = {
     "lv_keep_scale_f32": [_vp, _vp, _f, _i, _i, _i, _vp],
     "lv_cvt_bf16_gates_f32": [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_cvt_bf16_lo_f32": [_vp, _l, _i, _i, _i, _vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
+    "lv_cvt_h16_f32": [_vp, _l, _i, _i, _i, _vp, _l, _i, _i, _vp, _l, _vp, _l, _vp],
     "lv_gate_interleave_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "lv_lstm_fwd_bf16_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "lv_lstm_fwd_f32_ug": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
@@ -63,6 +65,7 @@ SIGNATURES = {
     "lv_lstm_persist16_pack": [_vp, _vp, _i, _i, _vp],
     "lv_lstm_persist16_import_saved": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lv_lstm_persist16_pack2": [_vp, _vp, _vp, _i, _vp],
+    "lv_lstm_persist16_pack2_h16": [_vp, _vp, _vp, _i, _vp],
     "lv_lstm_fwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lv_lstm_bwd_bf16_persist16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lv_transpose_f32": [_vp, _vp, _i, _i, _vp],

@@ -116,6 +116,51 @@ static inline float lv_f16_bits_to_f32(uint16_t h) {
 static inline float lv_lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
 // two f32 -> packed binary16 (RNE), lo in bits 0..15
 static inline uint32_t lv_pack_f16x2(float lo, float hi) { return (uint32_t)lv_f32_to_f16_bits(lo) | ((uint32_t)lv_f32_to_f16_bits(hi) << 16); }
+// binary16 forms of the two 16-bit-operand MFMAs (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16): the lane maps of the bf16
+// forms, elements decoded as IEEE half
+static inline f32x16 lv_mfma_32x32x16_f16(uint4 a, uint4 b, f32x16 c) {
+    auto& w = lv_emu::my_wave();
+    const int l = lv_emu::lane();
+    w.qa[l] = a; w.qb[l] = b;
+    lv_emu::wave_sync();
+    f32x16 d = c;
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            unsigned short ea[8], eb[8];
+            memcpy(ea, &w.qa[row + 32 * h], 16);
+            memcpy(eb, &w.qb[col + 32 * h], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf(lv_f16_bits_to_f32(ea[e]), lv_f16_bits_to_f32(eb[e]), acc);
+        }
+        d[r] = acc;
+    }
+    lv_emu::wave_sync();
+    return d;
+}
+static inline f32x4 lv_mfma_16x16x32_f16_areg(uint4 a, uint4 b, f32x4 c) {
+    auto& w = lv_emu::my_wave();
+    const int l = lv_emu::lane();
+    w.qa[l] = a; w.qb[l] = b;
+    lv_emu::wave_sync();
+    f32x4 d = c;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            unsigned short ea[8], eb[8];
+            memcpy(ea, &w.qa[row + 16 * g], 16);
+            memcpy(eb, &w.qb[col + 16 * g], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf(lv_f16_bits_to_f32(ea[e]), lv_f16_bits_to_f32(eb[e]), acc);
+        }
+        d[r] = acc;
+    }
+    lv_emu::wave_sync();
+    return d;
+}
+static inline f32x4 lv_mfma_16x16x32_f16_areg_first(uint4 a, uint4 b) { return lv_mfma_16x16x32_f16_areg(a, b, f32x4{0.f, 0.f, 0.f, 0.f}); }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -199,6 +244,23 @@ __device__ __forceinline__ f32x4 lv_mfma_16x16x32_bf16_areg_first(uint4 a, uint4
     const lv_u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
     f32x4 c;
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "a"(av), "v"(bv));
+    return c;
+}
+// the binary16 forms (same shapes, lane maps and rates; 11 bits of significand instead of 8 -- for operands whose range permits:
+// the ENCODER's forward, whose weight rounding is what moves the KL, profiles/r05a_kl_ablation.txt)
+typedef _Float16 lv_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 lv_mfma_32x32x16_f16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<lv_f16x8*>(&a), *reinterpret_cast<lv_f16x8*>(&b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 lv_mfma_16x16x32_f16_areg(uint4 a, uint4 b, f32x4 c) {
+    const lv_u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(av), "v"(bv));
+    return c;
+}
+__device__ __forceinline__ f32x4 lv_mfma_16x16x32_f16_areg_first(uint4 a, uint4 b) {
+    const lv_u32x4v av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+    f32x4 c;
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "a"(av), "v"(bv));
     return c;
 }
 #define LV_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")

@@ -444,8 +444,10 @@ template <> struct SecondPair<true> { int unused; };
 // and the K-contiguous MFMA fragment is taken out of that M-contiguous image by ds_read_b64_tr_b16 (two per fragment; the 16
 // addresses of a lane group are 4 k rows x 32 contiguous bytes, on distinct banks thanks to the permutation).  The
 // register-staged lv_gemm_b16_kernel<false> did this transposition with 16 integer ops per 8 x 4 block (dW_pred: 464 us).
-template <bool SINGLE, bool NLL = false, bool TN = false>
+template <bool SINGLE, bool NLL = false, bool TN = false, bool F16 = false>
 __global__ __launch_bounds__(256, (SINGLE && !NLL && LV_B16_SINGLE_WAVES) ? LV_B16_SINGLE_WAVES : 1) void lv_gemm_b16_nt_glds_kernel(GemmQ p) {
+    // F16: the operands are IEEE binary16 images (lv_cvt_h16_f32) and the products run on v_mfma_f32_32x32x16_f16 -- staging, LDS
+    // images, swizzles and the epilogue are format-blind (16-bit elements)
     // separate LDS objects per buffer: the compiler orders an LDS read behind every in-flight LDS-DMA it cannot prove
     // disjoint (with one double-buffered array it put an s_waitcnt vmcnt(0) between the DMA issue and the first fragment read)
     __shared__ __attribute__((aligned(1024))) LdsTile As0, Bs0;
@@ -576,7 +578,8 @@ __global__ __launch_bounds__(256, (SINGLE && !NLL && LV_B16_SINGLE_WAVES) ? LV_B
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = F16 ? lv_mfma_32x32x16_f16(fa[cur][i], fb[cur][j], acc[i][j]) : lv_mfma_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j]);
         }
         if (hand_over) LV_WAIT_VMEM();
         __syncthreads();
@@ -1580,8 +1583,10 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
                                                       uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt,
                                                       int gate_H, const uint8_t* __restrict__ keep, float kscale, int Bsz,
                                                       const int64_t* __restrict__ gids, long gstride, int gV, int lo) {
-    // lo != 0: the image of the RESIDUAL x - bf16(x) (itself rounded to bf16, RNE): the low half of a split-bf16 operand
+    // lo == 1: the image of the RESIDUAL x - bf16(x) (itself rounded to bf16, RNE): the low half of a split-bf16 operand
     // (x = hi + lo up to 2^-17 |x|), see lv_cvt_bf16_lo_f32
+    // lo == 2: dst as IEEE binary16 (RNE), dstT as bf16: the operand of a FORWARD product that takes the binary16 matrix pipe
+    // (lv_gemm_h16) next to the transposed bf16 image a gradient product reads, see lv_cvt_h16_f32
     __shared__ uint16_t tile[64][66];
     const int t = (int)threadIdx.x;
     const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
@@ -1635,10 +1640,10 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
                     else x *= kp[u] ? kscale : 0.f;              // as h * (keep * scale) rounds (a dropped negative element is -0)
                 }
                 b = (uint16_t)lv_f32_to_bf16_bits(x);
-                if (lo) b = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b));
+                if (lo == 1) b = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b));
                 if (dst) {
                     const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
-                    dst[dr * ldd + gc] = b;
+                    dst[dr * ldd + gc] = lo == 2 ? lv_f32_to_f16_bits(x) : b;
                 }
             }
             tile[q + 4 * (i0 + u)][lane] = b;
@@ -1709,8 +1714,12 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
                            const float* add1, long ld1, int mod1,
                            const float* add2, long ld2, int mod2,
                            float* ws, long ws_floats, void* stream, const uint8_t* keep, float kscale, int Bsz,
-                           float* sq = nullptr, int sq_only = 0) {
+                           float* sq = nullptr, int sq_only = 0, int f16 = 0) {
     if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
+    if (f16) {                       // binary16 operands: the K-contiguous 128-tile LDS-DMA kernel only (forward products)
+        if (transA || keep || sq || !LV_B16_GLDS) return LV_ERR_UNSUPPORTED;
+        tile = 128;
+    }
     if (M < 0 || N < 0 || K < 0) return LV_ERR_SHAPE;
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
@@ -1771,6 +1780,8 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     if (transA && LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<false, false, true>), grid, block, 0, stream, p);
     else if (transA && LV_B16_GLDS) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, false, true>), grid, block, 0, stream, p);
     else if (transA) LV_LAUNCH((lv_gemm_b16_kernel<false>), grid, block, 0, stream, p);
+    else if (f16 && p.kt_per_split > 32) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<false, false, false, true>), grid, block, 0, stream, p);
+    else if (f16) LV_LAUNCH((lv_gemm_b16_nt_glds_kernel<true, false, false, true>), grid, block, 0, stream, p);
     else if (LV_B16_GLDS == 1 && p.kt_per_split > 32) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<false>, grid, block, 0, stream, p);
     else if (LV_B16_GLDS) LV_LAUNCH(lv_gemm_b16_nt_glds_kernel<true>, grid, block, 0, stream, p);
     else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
@@ -1833,6 +1844,16 @@ extern "C" int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
                            float* ws, long ws_floats, void* stream) {
     return lv_gemm_b16_tile(0, transA, M, N, K, alpha, A, lda, B, ldb, C, ldc, accumulate, add1, ld1, mod1, add2, ld2, mod2, ws,
                             ws_floats, stream);
+}
+
+// C = A . B^T (+ addends / accumulate) as lv_gemm_b16 with transA = 0, on operands that are IEEE BINARY16 images (lv_cvt_h16_f32):
+// v_mfma_f32_32x32x16_f16, f32 accumulation -- the forward input projection of the encoder (enc_lstm.py:50-55), whose operands'
+// rounding is a third of what moves the KL in the bf16 configuration (profiles/r05a_kl_ablation.txt)
+extern "C" int lv_gemm_h16(int M, int N, int K, float alpha, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                           float* C, long ldc, int accumulate, const float* add1, long ld1, int mod1,
+                           const float* add2, long ld2, int mod2, float* ws, long ws_floats, void* stream) {
+    return gemm_b16_launch(128, 0, M, N, K, alpha, A, lda, B, ldb, C, ldc, accumulate, add1, ld1, mod1, add2, ld2, mod2, ws, ws_floats,
+                           stream, nullptr, 1.f, 1, nullptr, 0, 1);
 }
 
 // src f32 [R][C] (lds) -> dst bf16 [R][C] (ldd) and/or dstT bf16 [C][R] (ldt); either destination may be null.
@@ -1907,6 +1928,24 @@ extern "C" int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int 
     if (R == 0 || C == 0) return LV_OK;
     LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
               dst, ldd, dstT, ldt, gate_H > 0 ? gate_H : 0, (const uint8_t*)nullptr, 1.f, ids ? Bsz : 1, ids, ids_stride, ids ? V : 0, 1);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// Operand images for a forward product on the BINARY16 matrix pipe (lv_gemm_h16): dst = IEEE half (RNE) in the layouts of the bf16
+// conversions (plain / gate_H > 0: unit-major LSTM gate rows / ids != NULL: gathered embedding rows), dstT = the transposed BF16
+// image (what the gradient products of the same operand read: gradients need bf16's exponent range, forward operands of an LSTM --
+// weights U(-0.01, 0.01)-ish, embeddings, h in (-1, 1) -- do not, and binary16's 11-bit significand rounds them 8 x finer).  Values
+// beyond 65504 become infinities: not for operands without a bound.
+extern "C" int lv_cvt_h16_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz,
+                              int V, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream) {
+    if (!src || (!dst && !dstT)) return LV_ERR_ARG;
+    if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
+    if (gate_H > 0 && (R != 4 * gate_H || ids)) return LV_ERR_ARG;
+    if (ids && (Bsz <= 0 || V <= 0 || R % Bsz != 0)) return LV_ERR_SHAPE;
+    if (R == 0 || C == 0) return LV_OK;
+    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+              dst, ldd, dstT, ldt, gate_H > 0 ? gate_H : 0, (const uint8_t*)nullptr, 1.f, ids ? Bsz : 1, ids, ids_stride, ids ? V : 0, 2);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

@@ -62,20 +62,25 @@ template <int V> struct lv_const { static constexpr int value = V; };
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // forward:  Wk16[wave_id (128) = 4m + w][ks (8)][nb (8)][lane (64)] uint4.  Lane (c = l & 15, kq = l >> 4) holds, for gate column
 //           16 nb + c of workgroup m (unit 32m + ((16 nb + c) >> 2), gate c & 3), the 8 weights of k = 256w + 32ks + 8kq + e.
-__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk);
+__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk, int f16);
 // BPTT:     Wrs16[wave_id (128) = 4m + w][ks (4)][nb (16)][lane (64)] uint4.  Lane (c, kq) holds, for output unit
 //           j = 256w + 16 nb + c, the 8 weights W_hh[gate * H + unit][j] of the workgroup's local gate rows n'' = 32ks + 8kq + e
 //           (unit = 32m + (n'' >> 2), gate = n'' & 3).
 __global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk);
 
 // both images in one launch (the encoder's W_hh changes every inner step: blocks [0, n) pack the forward image, [n, 2n) the BPTT one)
-__device__ __forceinline__ void pack_w_k16_one(const float* __restrict__ whh, uint4* __restrict__ wpk, long idx) {
+// (f16: the image holds IEEE binary16 -- the forward kernel's F16 instantiation; 11 bits of significand instead of 8)
+__device__ __forceinline__ void pack_w_k16_one(const float* __restrict__ whh, uint4* __restrict__ wpk, long idx, int f16 = 0) {
     const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 7), ks = (int)((idx >> 9) & 7);
     const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
     const int c = l & 15, kq = l >> 4, col = 16 * nb + c;
     const float* row = whh + ((long)(col & 3) * PH + 32 * m + (col >> 2)) * PH + 256 * w + 32 * ks + 8 * kq;
-    wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
-                          lv_pack_bf16x2(row[6], row[7]));
+    if (f16)
+        wpk[idx] = make_uint4(lv_pack_f16x2(row[0], row[1]), lv_pack_f16x2(row[2], row[3]), lv_pack_f16x2(row[4], row[5]),
+                              lv_pack_f16x2(row[6], row[7]));
+    else
+        wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
+                              lv_pack_bf16x2(row[6], row[7]));
 }
 __device__ __forceinline__ void pack_w_rs16_one(const float* __restrict__ whh, uint4* __restrict__ wpk, long idx) {
     const int l = (int)(idx & 63), nb = (int)((idx >> 6) & 15), ks = (int)((idx >> 10) & 3);
@@ -89,16 +94,17 @@ __device__ __forceinline__ void pack_w_rs16_one(const float* __restrict__ whh, u
     }
     wpk[idx] = make_uint4(lv_pack_bf16x2(v[0], v[1]), lv_pack_bf16x2(v[2], v[3]), lv_pack_bf16x2(v[4], v[5]), lv_pack_bf16x2(v[6], v[7]));
 }
-__global__ __launch_bounds__(256) void pack_w_both16_kernel(const float* __restrict__ whh, uint4* __restrict__ wfwd, uint4* __restrict__ wbwd) {
+__global__ __launch_bounds__(256) void pack_w_both16_kernel(const float* __restrict__ whh, uint4* __restrict__ wfwd, uint4* __restrict__ wbwd,
+                                                            int fwd_f16) {
     const long n = 128L * 64 * 64;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < n) pack_w_k16_one(whh, wfwd, idx);
+    if (idx < n) pack_w_k16_one(whh, wfwd, idx, fwd_f16);
     else if (idx < 2 * n) pack_w_rs16_one(whh, wbwd, idx - n);
 }
 
-__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
+__global__ __launch_bounds__(256) void pack_w_k16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk, int f16) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < 128L * 8 * 8 * 64) pack_w_k16_one(whh, wpk, idx);
+    if (idx < 128L * 8 * 8 * 64) pack_w_k16_one(whh, wpk, idx, f16);
 }
 __global__ __launch_bounds__(256) void pack_w_rs16_kernel(const float* __restrict__ whh, uint4* __restrict__ wpk) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -140,9 +146,14 @@ struct __attribute__((aligned(16))) Fwd16Lds {
     int abort;
 };
 
-template <int RP, bool LOCAL>
+template <int RP, bool LOCAL, bool F16 = false>
 __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     // LOCAL: hand-off stores without the agent-scope write-through (lv_xcd_store_u64): valid while a group's 32 workgroups share an XCD
+    // F16: the recurrent operands -- the register image of W_hh and the h granules -- are IEEE binary16 and the products run on
+    // v_mfma_f32_16x16x32_f16: the same kernel at 11 instead of 8 bits of significand for the WEIGHTS, whose rounding acts at every
+    // timestep alike (the encoder's forward: 1.4e-4 -> 2e-5 relative on the KL, profiles/r05a_kl_ablation.txt); h in (-1, 1) and
+    // LSTM weights are far inside binary16's range.  The BPTT keeps bf16 (gradients need the exponent range).
+    auto h16 = [](float v) -> uint32_t { return F16 ? (uint32_t)lv_f32_to_f16_bits(v) : lv_f32_to_bf16_bits(v); };
     auto put = [](gran_t* q, gran_t v) { if (LOCAL) lv_xcd_store_u64(q, v); else gran_store(q, v); };
     constexpr int NP = Cfg16<RP>::NP, SBK = Cfg16<RP>::SBK, GJ = Cfg16<RP>::GJ;
     LV_BLOCK_SHARED(Fwd16Lds<RP>, sm);
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 
 #pragma unroll
     for (int q = 0; q < NP; ++q) {      // publish the initial state hs[0] as state 0 (tag 1)
-        const uint32_t mine = lv_f32_to_bf16_bits(own[q] ? p.hs[pidx[q]] : 0.f);
+        const uint32_t mine = h16(own[q] ? p.hs[pidx[q]] : 0.f);
         const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
         if (own[q] && even) put(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
     }
@@ -287,7 +298,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb)
-                    acc[nb] = ks == 0 ? lv_mfma_16x16x32_bf16_areg_first(wreg[0][nb], bfr[0]) : lv_mfma_16x16x32_bf16_areg(wreg[ks][nb], bfr[ks], acc[nb]);
+                    if constexpr (F16)
+                        acc[nb] = ks == 0 ? lv_mfma_16x16x32_f16_areg_first(wreg[0][nb], bfr[0]) : lv_mfma_16x16x32_f16_areg(wreg[ks][nb], bfr[ks], acc[nb]);
+                    else
+                        acc[nb] = ks == 0 ? lv_mfma_16x16x32_bf16_areg_first(wreg[0][nb], bfr[0]) : lv_mfma_16x16x32_bf16_areg(wreg[ks][nb], bfr[ks], acc[nb]);
             LV_MFMA_DRAIN();
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) LV_MFMA_RESULT(acc[nb]);
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     recb[q][s2] = f32x4{ig, fg, gg, og};
                     cb[q][s2] = c; hb[q][s2] = h;
                 }
-                const uint32_t mine = lv_f32_to_bf16_bits(h);
+                const uint32_t mine = h16(h);
                 const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
                 if (own[q] && even)
                     put(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
@@ -726,8 +740,8 @@ extern "C" int lv_lstm_persist16_pack(const float* whh, float* wpk, int backward
     if (H != PH) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)wpk) & 15) != 0) return LV_ERR_ALIGN;
     const dim3 grid((unsigned)lv_cdiv(128L * 64 * 64, 256)), block(256);
-    if (backward) LV_LAUNCH(pack_w_rs16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
-    else LV_LAUNCH(pack_w_k16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    if (backward == 1) LV_LAUNCH(pack_w_rs16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk));
+    else LV_LAUNCH(pack_w_k16_kernel, grid, block, 0, stream, whh, reinterpret_cast<uint4*>(wpk), backward == 2 ? 1 : 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -738,7 +752,17 @@ extern "C" int lv_lstm_persist16_pack2(const float* whh, float* wpk_fwd, float* 
     if (H != PH) return LV_ERR_UNSUPPORTED;
     if (((((uintptr_t)wpk_fwd) | ((uintptr_t)wpk_bwd)) & 15) != 0) return LV_ERR_ALIGN;
     LV_LAUNCH(pack_w_both16_kernel, dim3((unsigned)lv_cdiv(2 * 128L * 64 * 64, 256)), dim3(256), 0, stream, whh,
-              reinterpret_cast<uint4*>(wpk_fwd), reinterpret_cast<uint4*>(wpk_bwd));
+              reinterpret_cast<uint4*>(wpk_fwd), reinterpret_cast<uint4*>(wpk_bwd), 0);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+// ... with the FORWARD image in IEEE binary16 (for lv_lstm_fwd_bf16_persist16 with flags bit 5) and the BPTT image in bf16
+extern "C" int lv_lstm_persist16_pack2_h16(const float* whh, float* wpk_fwd, float* wpk_bwd, int H, void* stream) {
+    if (!whh || !wpk_fwd || !wpk_bwd) return LV_ERR_ARG;
+    if (H != PH) return LV_ERR_UNSUPPORTED;
+    if (((((uintptr_t)wpk_fwd) | ((uintptr_t)wpk_bwd)) & 15) != 0) return LV_ERR_ALIGN;
+    LV_LAUNCH(pack_w_both16_kernel, dim3((unsigned)lv_cdiv(2 * 128L * 64 * 64, 256)), dim3(256), 0, stream, whh,
+              reinterpret_cast<uint4*>(wpk_fwd), reinterpret_cast<uint4*>(wpk_bwd), 1);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -768,6 +792,19 @@ extern "C" int lv_lstm_fwd_bf16_persist16(const float* gx, const float* wpk, flo
     Fwd16P p{gx, reinterpret_cast<const uint4*>(wpk), hs, cs, saved, hx, status, T, B, R,
              dbl ? reinterpret_cast<uint4*>(xb + XCH_FWD_OFF[1 - half]) : nullptr, XCH_FWD16_BYTES / 16};
     const dim3 grid(PGROUPS * PMEMBERS), block(256);
+    if (flags & 32) {                // binary16 recurrent operands (wpk packed by lv_lstm_persist16_pack(.., 2, ..) / _pack2_h16)
+        if (flags & 1) {
+            if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, true, true>), grid, block, 0, stream, p);
+            else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<8, true, true>), grid, block, 0, stream, p);
+            else LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<16, true, true>), grid, block, 0, stream, p);
+        } else {
+            if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, false, true>), grid, block, 0, stream, p);
+            else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<8, false, true>), grid, block, 0, stream, p);
+            else LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<16, false, true>), grid, block, 0, stream, p);
+        }
+        LV_CHECK_LAUNCH();
+        return LV_OK;
+    }
     if (flags & 1) {
         if (R <= 4) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<4, true>), grid, block, 0, stream, p);
         else if (R <= 8) LV_LAUNCH_RESIDENT((lstm_fwd_persist_k16_kernel<8, true>), grid, block, 0, stream, p);

@@ -488,11 +488,16 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
             wi.predT = c.i16(H, wi.ldv)
         wi.packed16 = False
     ver = weights_version(eng) if eng.cache_weight_images else object()
-    stale = wi.ver != ver
+    h16 = bool(getattr(eng, "_h16_now", False))      # the forward's operand images in IEEE binary16 (LSTMEncoderEngine.fwd_operands)
+    stale = wi.ver != ver or getattr(wi, "h16", False) != h16
     if stale:
         wih = v["lstm.weight_ih_l0"]
-        if wi.W is not None:
+        if wi.W is not None and h16:
+            # W (forward: Gx) as binary16, W^T (backward: dX) as bf16, one launch
+            lib.lv_cvt_h16_f32(P(wih), wih.shape[1], 4 * H, ni, H, None, 0, 1, 0, P(wi.W), ni, P(wi.WT), 4 * H, s)
+        elif wi.W is not None:
             lib.lv_cvt_bf16_gates_f32(P(wih), wih.shape[1], H, ni, P(wi.W), ni, P(wi.WT), 4 * H, s)
+        wi.h16 = h16
         if wi.pred is not None:
             lib.lv_cvt_bf16_f32(P(v["pred_linear.weight"]), H, V, H, P(wi.pred), H, P(wi.predT), wi.ldv, s)
         wi.ver = ver
@@ -504,7 +509,7 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
             # hand-off exchange buffer, zeroed once: the launches alternate its halves and clear the other one themselves
             wi.xch = torch.zeros(lib.lv_lstm_persist16_xch_floats(), dtype=torch.float32, device=c.device)
             wi.xstate = {"f": 0, "g": 0, "gcls": [0, 0]}      # next half per kind of launch; instantiation that last used each BPTT half
-        lib.lv_lstm_persist16_pack2(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), P(wi.bwd16), H, s)
+        (lib.lv_lstm_persist16_pack2_h16 if h16 else lib.lv_lstm_persist16_pack2)(P(v["lstm.weight_hh_l0"]), P(wi.fwd16), P(wi.bwd16), H, s)
         wi.packed16 = True
     return wi
 
@@ -550,7 +555,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         if w.gates.numel() < need:              # eng.persist_rows / eng.persistent changed after the workspace was built
             w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
         lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(eng.status), T, B, rows,
-                                       eng.persist_flags | _xch_flags(wi, "f", rows, device), H, s)
+                                       eng.persist_flags | _xch_flags(wi, "f", rows, device) | (32 if getattr(wi, "h16", False) else 0), H, s)
         w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
@@ -621,7 +626,7 @@ class _LstmImages(object):
     def usable(precision, native16, ni, H):
         return precision == "bf16" and native16 and ni % 8 == 0 and H % 8 == 0
 
-    def forward(self, lib, s, X, W16, Gx, add_a, add_b, rows, wsc, addend_um=None, gather=None):
+    def forward(self, lib, s, X, W16, Gx, add_a, add_b, rows, wsc, addend_um=None, gather=None, h16=False):
         """Gx[r][4u + g] = X[r] . W_ih[g*H + u] + (add_a + add_b)[r % rows][g*H + u]; W16: the unit-major bf16 image of W_ih
         (engine-level, _weight_images); add_a/add_b: gate-major [rows][4H] (add_b may be None), or addend_um: the addend
         already in unit-major order.  gather = (emb, ids, ids_stride, keep, kscale, T, B, V): the layer input is an embedding
@@ -636,6 +641,16 @@ class _LstmImages(object):
                     wsc.grew(self.key, rows * 4 * H * 4)
             lib.lv_gate_interleave_f32(add_a, add_b, rows, H, P(self.addend), s)
             addend = P(self.addend)
+        if h16:
+            # binary16 forward operands (W16 is the binary16 image of W_ih): X as binary16 for this product, X^T as bf16 for dW_ih
+            emb, ids, ids_stride, keep, kscale, T, B, V = gather
+            assert keep is None
+            lib.lv_cvt_h16_f32(emb, ni, TB, ni, 0, ids, ids_stride, B, V, P(self.X), ni, P(self.XT), self.ldr, s)
+            ws = _gemm_ws(lib, s)
+            with _prof("gemm_bf16", 2.0 * TB * 4 * H * ni):
+                lib.lv_gemm_h16(TB, 4 * H, ni, 1.0, P(self.X), ni, W16, ni, Gx, 4 * H, 0, addend, 4 * H if rows > 1 else 0, rows, None, 0, 1,
+                                P(ws), ws.numel(), s)
+            return
         if gather is not None:
             emb, ids, ids_stride, keep, kscale, T, B, V = gather
             lib.lv_embed_gather_b16(emb, ids, ids_stride, keep, kscale, T, B, ni, V, P(self.X), ni, P(self.XT), self.ldr, s)
@@ -717,6 +732,15 @@ class LSTMEncoderEngine(object):
         # the input projection and a two-pass recurrence whose second pass carries W_lo . h as part of gx (_exact_forward_split) --
         # else, and with "f32", the exact-f32 GEMM and launch-per-timestep recurrence
         self.exact_impl = "auto"
+        # bf16 configuration: number format of the FORWARD's matrix-pipe operands (embedded rows, W_ih, W_hh, the h hand-off).
+        # "f16" (default): IEEE binary16 -- the same instructions at the same rates with 11 instead of 8 bits of significand.  What
+        # moves the forward's last state (hence mu / logvar, z and the KL of encoder.py:55) in the bf16 configuration is the
+        # rounding of the WEIGHTS and embeddings, the same perturbation at every timestep (profiles/r05a_kl_ablation.txt: W_hh
+        # 1.4e-4, embedding 0.4-1.9e-4, W_ih 0.2-1.2e-4 relative on the KL; the h hand-off <= 2.5e-5); these operands are bounded
+        # (weights ~U(-0.01, 0.01)-ish, h in (-1, 1)), so they do not need bf16's exponent range.  The gradient products and the
+        # BPTT keep bf16.  "bf16": the round-1..4 arithmetic.
+        self.fwd_operands = "f16"
+        self._h16_now = False
         self._wimg = None
         self._aux = _AuxStream()
         self._sorts = _TokenSortCache()
@@ -821,6 +845,7 @@ class LSTMEncoderEngine(object):
         v = f.views
         img = self._b16(B, T)
         exact = self._exact(img)
+        self._h16_now = img is not None and not exact and self.fwd_operands == "f16"
         if img is None or "gx" in exact:
             lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
         # the backward's token sort depends on x only: taken from the per-batch cache, or queued now (auxiliary stream)
@@ -846,7 +871,7 @@ class LSTMEncoderEngine(object):
         elif img is not None:
             wi = self.refresh_weight_images(B, x.device)
             img.forward(lib, s, None, P(wi.W), P(w.Gx), P(v["lstm.bias_ih_l0"]), P(v["lstm.bias_hh_l0"]), 1, self.wsc,
-                        gather=(P(v["embed.weight"]), P(x), T, None, 1.0, T, B, V))
+                        gather=(P(v["embed.weight"]), P(x), T, None, 1.0, T, B, V), h16=self._h16_now)
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
