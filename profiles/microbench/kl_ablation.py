@@ -36,7 +36,7 @@ def main():
         noise = tuple(torch.from_numpy(fx[k]).to(dev) for k in ("eps", "mask_in", "mask_out"))
         kl_ref, rec_ref, loss_ref = (float(fx[k].sum()) for k in ("kl", "rec", "loss"))
 
-        def run(exact, pre_round=()):
+        def run(exact, pre_round=(), operands="bf16"):
             vae = TP._seeded_full_size_vae(fx, dev)
             with torch.no_grad():
                 for k in pre_round:
@@ -44,11 +44,13 @@ def main():
                     p.copy_(bf16_round(p))
             tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
             tr.enc.exact_forward = exact
+            tr.enc.fwd_operands = operands
             tr.step(x, float(fx["kl_weight"]), noise=noise)
             st = tr.read_stats()
             return {"kl_rel": abs(st["kl_sum"] - kl_ref) / abs(kl_ref), "rec_rel": abs(st["rec_sum"] - rec_ref) / abs(rec_ref),
                     "loss_rel": abs(st["loss_sum"] - loss_ref) / abs(loss_ref), "kl_signed": (st["kl_sum"] - kl_ref) / abs(kl_ref)}
         rows = {
+            "binary16 forward operands (the default since round 5: X, W_ih, W_hh, h hand-off as IEEE half)": run((), operands="f16"),
             "bf16 configuration (all four roundings)": run(()),
             "exact input projection only (exact_forward = gx)": run(("gx",)),
             "exact recurrence only (exact_forward = rec)": run(("rec",)),
