@@ -13,6 +13,11 @@ python bench.py --graph 1 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_hip
 python bench.py --workload yelp --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yelp.json 2>/dev/null
 python bench.py --workload stress --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_stress.json 2>/dev/null
 python bench.py --dtype f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_yahoo_f32.json 2>/dev/null
+# round 5: the split-bf16 / two-pass exact encoder forward as its own line, the bf16 forward operands of rounds 1-4 as the A/B of the
+# binary16 default, and the self-launching data-parallel entry (2 ranks; on a one-GPU box they share the device and exchange over gloo)
+python bench.py --encoder-forward f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_kl_exact.json 2>/dev/null
+python bench.py --forward-operands bf16 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_bf16_forward_operands.json 2>/dev/null
+python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_gpus2_selflaunch.json 2> $O/${TAG}_bench_gpus2_selflaunch.err
 # Omniglot (BASELINE.json configs[3]): the dtype is named explicitly (the decoder's convolutions are exact f32 in both modes;
 # --dtype only moves the encoder's im2col GEMMs) so that file names and the "dtype" field cannot disagree
 python bench.py --workload omniglot --dtype f32 --steps 30 --warmup 5 > $O/${TAG}_bench_omniglot_f32.json 2>/dev/null
@@ -44,6 +49,7 @@ timeout 100 python profiles/microbench/lstm_fixed_cost_probe.py > $O/${TAG}_lstm
 rm -rf $O/prof_${TAG} $O/prof_omni_${TAG} $O/pmc_*_${TAG}
 cut -c1-400 $O/${TAG}_bench_default.json
 cut -c1-200 $O/${TAG}_bench_hipgraph.json $O/${TAG}_bench_yelp.json $O/${TAG}_bench_stress.json $O/${TAG}_bench_yahoo_f32.json
+cut -c1-200 $O/${TAG}_bench_kl_exact.json $O/${TAG}_bench_bf16_forward_operands.json $O/${TAG}_bench_gpus2_selflaunch.json; tail -2 $O/${TAG}_bench_gpus2_selflaunch.err
 cut -c1-200 $O/${TAG}_bench_omniglot_f32.json $O/${TAG}_bench_omniglot_f32_hipgraph.json $O/${TAG}_bench_omniglot_bf16_hipgraph.json
 head -8 $O/${TAG}_omniglot_kernel_stats.txt | cut -c1-170
 head -14 $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt | cut -c1-170
