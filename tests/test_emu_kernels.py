@@ -235,7 +235,7 @@ def test_gemm_h16_emulated(emu_backend, M, N, K_, acc):
 
 
 def test_lstm_fwd_persistent16_binary16_operands_emulated(emu_backend):
-    K.test_lstm_fwd_persistent16_binary16_operands(emu_backend, CPU, 2, 8, 1, 0)
+    K.test_lstm_fwd_persistent16_binary16_operands(emu_backend, CPU, 2, 4, 1, 0)
 
 
 def test_persistent_exchange_halves_alternate_without_memsets_emulated(emu_backend):
