@@ -723,10 +723,10 @@ class LSTMEncoderEngine(object):
         self.fold = None                        # norm folding (trainer._plan_fold): {"embed": (partials tensor, norm-only flag)}
         self.cache_weight_images = False        # the encoder is stepped every inner iteration: its images are rebuilt per call
         self.wgen = 0                           # bumped by the fused trainer after a raw-pointer weight update
-        # bf16 configuration only: which parts of the FORWARD run in exact f32 all the same -- "gx" (the input projection X W_ih^T)
-        # and / or "rec" (the recurrence).  mu / logvar, hence z and the KL (encoder.py:55), are functions of the forward's last
-        # state alone (enc_lstm.py:60-62); 200 recurrent steps on bf16 operands move it by 2e-4..5e-4 relative, the exact forward
-        # holds north_star's 1e-4 on the KL while every gradient product and the whole decoder stay on the bf16 pipe.
+        # bf16 configuration only: which parts of the FORWARD run f32-accurately all the same -- "gx" (the input projection
+        # X W_ih^T) and / or "rec" (the recurrence).  mu / logvar, hence z and the KL (encoder.py:55), are functions of the forward's
+        # last state alone (enc_lstm.py:60-62); the weights' rounding to bf16 moves it by 2e-4..5e-4 relative (to binary16, the
+        # default below: 1e-5..7e-5), the exact forward holds 2e-5 while every gradient product and the decoder stay on the bf16 pipe.
         self.exact_forward = ()
         # how: "auto" = on the bf16 pipe itself wherever the forward recurrence is a persistent launch -- split-bf16 operands for
         # the input projection and a two-pass recurrence whose second pass carries W_lo . h as part of gx (_exact_forward_split) --

@@ -47,11 +47,13 @@ class AggressiveTextTrainer(object):
 
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
                  precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full", encoder_forward=None):
-        """encoder_forward = "f32" (with precision="bf16"): the encoder's FORWARD (input projection + recurrence) runs in exact f32
-        inside the bf16 configuration.  mu / logvar -- hence z and the KL of encoder.py:55 -- depend on the forward's last state
-        alone (enc_lstm.py:60-62); on bf16 operands 200 recurrent steps move it by 2e-4..5e-4 relative, with the exact forward
-        ELBO, reconstruction NLL AND KL hold north_star's 1e-4 while every gradient product and the whole decoder stay on the
-        bf16 matrix pipe.  None / "bf16": the plain bf16 configuration.
+        """encoder_forward = "f32" (with precision="bf16"): the encoder's FORWARD (input projection + recurrence) with f32-like
+        weights inside the bf16 configuration (engine._exact_forward_split: split-bf16 operands + a two-pass recurrence; on a
+        fallback rung the exact-f32 kernels).  mu / logvar -- hence z and the KL of encoder.py:55 -- depend on the forward's last
+        state alone (enc_lstm.py:60-62), which the WEIGHTS' rounding moves (profiles/r05a_kl_ablation.txt): KL within 2e-5 of the
+        reference instead of 1e-5..7e-5 (the default: binary16 forward operands, engine.LSTMEncoderEngine.fwd_operands) or
+        2e-4..5e-4 (bf16 forward operands, rounds 1-4), at +0.6 ms per step; gradient products and the decoder stay on the bf16
+        matrix pipe.  None / "bf16": the plain bf16 configuration.
         decoder_grads = "norm" (needs fold_norm): in ENCODER-ONLY steps the decoder's two vocabulary-sized gradient tensors
         (embedding table, dW_pred) are not written to memory at all -- text.py:383-387 needs them for the clip norm alone, the
         next backward overwrites them -- and their .grad is left unspecified by such a step; "full" (default) keeps every .grad
