@@ -558,6 +558,10 @@ def main():
                     help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
                          "tokens repeat hundreds of times per batch, which the embedding backward's sort / scatter feel)")
     args = ap.parse_args()
+    if os.environ.get("LVAE_BENCH_WATCHDOG"):
+        # diagnostics: dump every thread's Python stack to stderr after this many seconds (and again every period) without exiting
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["LVAE_BENCH_WATCHDOG"]), repeat=True, exit=False)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and prints nothing itself
         sys.exit(self_launch(args.gpus))
