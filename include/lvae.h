@@ -56,6 +56,14 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
  * sum exp(x - max)) with parts = lv_gemm_b16_nll_parts(N), + tgt_logit [M] = the logit of row r's target token
  * ids[(r % Bsz) * ids_stride + r / Bsz + tgt_off].  lv_softmax_nll_merge_f32 finishes lse / nll; lv_softmax_nll_bwd_h16 is the
  * backward over the binary16 image.  ldl16 % 8 == 0. */
+/* ONE product, TWO destinations: C1 [M][nsplit] = columns [0, nsplit) of op(A) . B^T, C2 [M][N - nsplit] the rest (lv_gemm_b16 otherwise:
+ * bf16 operand images, f32 accumulation; no addends).  The two weight gradients of an LSTM layer that share their A operand --
+ * dW_ih = dG^T X and dW_hh = dG^T h_prev, the backward of nn.LSTM at enc_lstm.py:55 / dec_lstm.py:104 -- as one launch over the image
+ * [X^T ; h_prev^T] ([ni + H][T*B]) and one reduction stage.  lv_gemm_b16_dual_supported: 1 where the shape takes the split-K route
+ * the column split rides in (not the 256 x 256 tile), else 0 and the entry returns LV_ERR_UNSUPPORTED. */
+int lv_gemm_b16_dual_supported(int M, int N, int K, long ws_floats);
+int lv_gemm_b16_dual(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                     float* C1, long ldc1, int nsplit, float* C2, long ldc2, float* ws, long ws_floats, void* stream);
 /* C [M][N] = (A . B^T) * (keep ? kscale : 0): lv_gemm_b16 (transA = 0, plain output, ldc = N) with the backward of nn.Dropout on the
  * LSTM output (dec_lstm.py:106; dO = dlogits . W_pred then masked) applied in the product's reduction stage instead of by a pass of
  * its own; rows time-major (r = t * Bsz + b), keep = the reference-layout mask [Bsz][M / Bsz][N], uint8. */

@@ -229,6 +229,11 @@ def test_cvt_h16_emulated(emu_backend, mode, R, C):
     K.test_cvt_h16(emu_backend, CPU, mode, R, C)
 
 
+@pytest.mark.parametrize("M,N,K_,nsplit", [(64, 96, 200, 32), (130, 72, 600, 20)])
+def test_gemm_b16_dual_emulated(emu_backend, M, N, K_, nsplit):
+    K.test_gemm_b16_dual(emu_backend, CPU, M, N, K_, nsplit)
+
+
 @pytest.mark.parametrize("M,N,K_,acc", [(130, 140, 96, 0), (64, 64, 72, 1)])
 def test_gemm_h16_emulated(emu_backend, M, N, K_, acc):
     K.test_gemm_h16(emu_backend, CPU, M, N, K_, acc)

@@ -644,6 +644,42 @@ def test_cvt_h16(lib, hip_device, mode, R, C):
     assert bool((d.cpu()[:, C:] == 0x1234).all()) and bool((dT.cpu()[:, R:] == 0x1234).all())
 
 
+@pytest.mark.parametrize("M,N,K,nsplit", [(64, 96, 200, 32), (4096, 1536, 6400, 512), (4096, 1024 + 512, 3200, 512), (130, 72, 1000, 20)])
+def test_gemm_b16_dual(lib, hip_device, M, N, K, nsplit):
+    """lv_gemm_b16_dual: one weight-gradient-form product (A stored [K][M]) whose columns [0, nsplit) land in C1 (its own leading
+    dimension, here wider than nsplit like the decoder's dW_ih inside [4H][ni + nz]) and the rest in C2 -- against the two separate
+    lv_gemm_b16 products of the same operands (f32 summation order differs: the pieces are cut differently), untouched padding, and
+    the forced two-piece split of a shape that would not split by itself."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(K, M, generator=g) * 0.2).to(dev)           # [K][M]: transA = 1
+    Bm = (torch.randn(N, K, generator=g) * 0.2).to(dev)          # [N][K]
+    ldk = (K + 7) // 8 * 8
+    A16 = torch.zeros(K, (M + 7) // 8 * 8, dtype=torch.int16, device=dev)
+    B16 = torch.zeros(N, ldk, dtype=torch.int16, device=dev)
+    lib.lv_cvt_bf16_f32(P(A), M, K, M, P(A16), A16.shape[1], None, 0, _s(dev))
+    lib.lv_cvt_bf16_f32(P(Bm), K, N, K, P(B16), ldk, None, 0, _s(dev))
+    ws = torch.empty(1 << 25, device=dev)
+    if not lib.lv_gemm_b16_dual_supported(M, N, K, ws.numel()):
+        pytest.skip("shape takes the 256-tile route")
+    ld1, ld2 = nsplit + 12, N - nsplit
+    C1 = torch.full((M, ld1), 7.0, device=dev)
+    C2 = torch.full((M, ld2), 7.0, device=dev)
+    lib.lv_gemm_b16_dual(1, M, N, K, P(A16), A16.shape[1], P(B16), ldk, P(C1), ld1, nsplit, P(C2), ld2, P(ws), ws.numel(), _s(dev))
+    R1 = torch.empty(M, nsplit, device=dev)
+    R2 = torch.empty(M, N - nsplit, device=dev)
+    lib.lv_gemm_b16(1, M, nsplit, K, 1.0, P(A16), A16.shape[1], P(B16), ldk, P(R1), nsplit, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), _s(dev))
+    lib.lv_gemm_b16(1, M, N - nsplit, K, 1.0, P(A16), A16.shape[1], P(B16, nsplit * ldk), ldk, P(R2), N - nsplit, 0, None, 0, 1, None, 0, 1,
+                    P(ws), ws.numel(), _s(dev))
+    sc = float(torch.cat([R1, R2], 1).abs().max())
+    assert float((C1[:, :nsplit] - R1).abs().max()) < 2e-5 * sc * max(1.0, (K / 1000) ** 0.5)
+    assert float((C2 - R2).abs().max()) < 2e-5 * sc * max(1.0, (K / 1000) ** 0.5)
+    assert bool((C1[:, nsplit:] == 7.0).all())
+    ref = (A.to(torch.bfloat16).double().t() @ Bm.to(torch.bfloat16).double().t()).cpu()
+    got = torch.cat([C1[:, :nsplit], C2], 1).cpu().double()
+    assert float((got - ref).abs().max()) < 3e-5 * float(ref.abs().max()) * max(1.0, (K / 1000) ** 0.5)
+
+
 @pytest.mark.parametrize("M,N,K,acc", [(130, 140, 96, 0), (256, 128, 512, 0), (64, 64, 72, 1), (200, 4096, 544, 0), (6400, 512, 4096, 0)])
 def test_gemm_h16(lib, hip_device, M, N, K, acc):
     """lv_gemm_h16: C = A . B^T (+ row-cyclic addend, accumulate) on binary16 operand images, f32 accumulation: against the

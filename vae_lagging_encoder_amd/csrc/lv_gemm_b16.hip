@@ -68,6 +68,8 @@ struct GemmQ {
     // sum of squares of the product emitted by the kernels that hold its final values (lv_gemm_b16_sumsq: the 256 x 256 tile's
     // epilogue and the tail reduce; one partial per wave, fixed slots: deterministic); sq_only: C itself is not written
     float* sq; int sq_only;
+    // two destinations (lv_gemm_b16_dual: split-K products only): columns >= nsplit of the product go to C2 [M][ldc2] (column - nsplit)
+    float* C2; long ldc2; int nsplit;
 };
 
 __device__ __forceinline__ uint4 load_chunk(const uint16_t* __restrict__ p, int valid) {
@@ -1547,7 +1549,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_v4_kernel(GemmQ p) {
         o.z = (mk & 0xFF0000u) ? o.z * p.kscale : 0.f;
         o.w = (mk & 0xFF000000u) ? o.w * p.kscale : 0.f;
     }
-    *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = o;
+    if (p.nsplit > 0 && col >= p.nsplit) *reinterpret_cast<float4*>(p.C2 + (long)row * p.ldc2 + (col - p.nsplit)) = o;
+    else *reinterpret_cast<float4*>(p.C + (long)row * p.ldc + col) = o;
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
@@ -1564,7 +1567,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(GemmQ p) {
     float v = p.alpha * s;
     if (p.add1) v += p.add1[(long)(row % p.mod1) * p.ld1 + col];
     if (p.add2) v += p.add2[(long)(row % p.mod2) * p.ld2 + col];
-    float* c = p.C + (long)row * p.ldc + col;
+    float* c = (p.nsplit > 0 && col >= p.nsplit) ? p.C2 + (long)row * p.ldc2 + (col - p.nsplit) : p.C + (long)row * p.ldc + col;
     if (p.accumulate) v += *c;
     if (p.keep) v *= p.keep[((long)(row % p.Bsz) * p.keepT + row / p.Bsz) * p.N + col] ? p.kscale : 0.f;
     *c = v;
@@ -1714,7 +1717,7 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
                            const float* add1, long ld1, int mod1,
                            const float* add2, long ld2, int mod2,
                            float* ws, long ws_floats, void* stream, const uint8_t* keep, float kscale, int Bsz,
-                           float* sq = nullptr, int sq_only = 0, int f16 = 0) {
+                           float* sq = nullptr, int sq_only = 0, int f16 = 0, float* C2 = nullptr, long ldc2 = 0, int nsplit = 0) {
     if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) return LV_ERR_ARG;
     if (f16) {                       // binary16 operands: the K-contiguous 128-tile LDS-DMA kernel only (forward products)
         if (transA || keep || sq || !LV_B16_GLDS) return LV_ERR_UNSUPPORTED;
@@ -1724,7 +1727,7 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     if (M == 0 || N == 0) return LV_OK;
     if (!A || !B || !C) return LV_ERR_ARG;
     if ((add1 && mod1 <= 0) || (add2 && mod2 <= 0)) return LV_ERR_ARG;
-    if (lda < (transA ? M : K) || ldb < K || ldc < N) return LV_ERR_SHAPE;
+    if (lda < (transA ? M : K) || ldb < K || ldc < (C2 && nsplit > 0 ? nsplit : N)) return LV_ERR_SHAPE;
     if (ldb % 8 != 0 || (((uintptr_t)B) & 15) != 0) return LV_ERR_ALIGN;
     if (lda % 8 != 0 || (((uintptr_t)A) & 15) != 0) return LV_ERR_ALIGN;
     GemmQ p{};
@@ -1735,6 +1738,11 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     p.ws = ws;
     p.keep = nullptr; p.kscale = 1.f; p.keepT = 1; p.Bsz = Bsz > 0 ? Bsz : 1;
     p.sq = sq; p.sq_only = sq ? sq_only : 0;
+    p.C2 = C2; p.ldc2 = ldc2; p.nsplit = C2 ? nsplit : 0;
+    if (p.nsplit > 0) {              // two destinations: written by the split-K reduction stage only (see lv_gemm_b16_dual)
+        if (p.nsplit >= N || ldc < p.nsplit || ldc2 < N - p.nsplit || add1 || add2 || accumulate || keep || sq || f16) return LV_ERR_ARG;
+        if (t256_wanted(tile, M, N, K) || !ws) return LV_ERR_UNSUPPORTED;
+    }
     if (sq && (!t256_wanted(tile, M, N, K) || accumulate || add1 || add2 || keep)) return LV_ERR_ARG;     // see lv_gemm_b16_sumsq_parts
     // a keep-mask rides in the reduction kernel when every output element passes through one; else a pass of its own follows
     bool keep_pending = keep != nullptr;
@@ -1772,6 +1780,10 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
         if (sp > cap) sp = cap;
         if (sp > 1) splits = (int)sp;
     }
+    if (p.nsplit > 0 && splits < 2) {
+        if (nk < 2 || ws_floats < 2L * M * N) return LV_ERR_UNSUPPORTED;
+        splits = 2;
+    }
     p.kt_per_split = lv_cdiv(nk, splits);
     splits = lv_cdiv(nk, p.kt_per_split);
     p.splits = splits;
@@ -1787,7 +1799,8 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     else LV_LAUNCH((lv_gemm_b16_kernel<true>), grid, block, 0, stream, p);
     if (splits > 1) {
         const bool v4 = !add1 && !add2 && !accumulate && N % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)C | (uintptr_t)ws) & 15) == 0 &&
-                        (((uintptr_t)p.keep) & 3) == 0;
+                        (((uintptr_t)p.keep) & 3) == 0 &&
+                        (p.nsplit == 0 || (p.nsplit % 4 == 0 && ldc2 % 4 == 0 && (((uintptr_t)C2) & 15) == 0));
         if (v4) LV_LAUNCH(splitk_reduce_b16_v4_kernel, dim3((unsigned)lv_cdiv((long)M * N / 4, 256)), dim3(256), 0, stream, p);
         else LV_LAUNCH(splitk_reduce_b16_kernel, dim3((unsigned)lv_cdiv((long)M * N, 256)), dim3(256), 0, stream, p);
     }
@@ -1804,6 +1817,23 @@ extern "C" int lv_gemm_b16_tile(int tile, int transA, int M, int N, int K, float
                                 float* ws, long ws_floats, void* stream) {
     return gemm_b16_launch(tile, transA, M, N, K, alpha, A, lda, B, ldb, C, ldc, accumulate, add1, ld1, mod1, add2, ld2, mod2, ws, ws_floats,
                            stream, nullptr, 1.f, 1);
+}
+
+// ONE product, TWO destinations: C1 [M][nsplit] (ldc1) = columns [0, nsplit) of op(A) . B^T, C2 [M][N - nsplit] (ldc2) the rest.  For
+// the two weight gradients of an LSTM layer that share their A operand, dW_ih = dG^T X and dW_hh = dG^T h_prev (dec_lstm.py:104 /
+// enc_lstm.py:55 backward): with X^T and h_prev^T stored as one [ni + H][T*B] image they are ONE product of N = ni + H columns --
+// one launch that fills the chip better than a 27- and a 54-GFLOP one, and one reduction stage instead of two.  The split of the
+// columns happens in the split-K reduction stage, so the product must take one (forced to two pieces if the shape alone would not
+// split); LV_ERR_UNSUPPORTED where it would take the 256 x 256 tile (lv_gemm_b16_dual_supported says so beforehand).
+extern "C" int lv_gemm_b16_dual_supported(int M, int N, int K, long ws_floats) {
+    if (M <= 0 || N <= 0 || K <= 0 || t256_wanted(0, M, N, K)) return 0;
+    return lv_cdiv(K, BK) >= 2 && ws_floats >= 2L * M * N;
+}
+extern "C" int lv_gemm_b16_dual(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
+                                float* C1, long ldc1, int nsplit, float* C2, long ldc2, float* ws, long ws_floats, void* stream) {
+    if (!C2 || nsplit <= 0) return LV_ERR_ARG;
+    return gemm_b16_launch(0, transA, M, N, K, 1.f, A, lda, B, ldb, C1, ldc1, 0, nullptr, 0, 1, nullptr, 0, 1, ws, ws_floats, stream,
+                           nullptr, 1.f, 1, nullptr, 0, 0, C2, ldc2, nsplit);
 }
 
 // C [M][N] (ldc = N) = (A . B^T) * (keep ? kscale : 0): the product of lv_gemm_b16 (transA = 0) with the backward of nn.Dropout

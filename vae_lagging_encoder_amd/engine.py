@@ -10,6 +10,7 @@ LSTM timestep is a contiguous slab; parameters of one module live in one flat fp
 segments back the module's nn.Parameters, gradients in a parallel flat buffer.
 """
 import ctypes
+import os
 
 import torch
 
@@ -608,6 +609,10 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
                                  P(w.lstm_ws), dh0, dc0, tanh_init, T, B, H, s)
 
 
+# dW_ih and dW_hh of an LSTM layer as one product where the shape allows (LVAE_DUAL_WGRAD=0: two products, for A/B measurements)
+DUAL_WGRAD = os.environ.get("LVAE_DUAL_WGRAD", "1") != "0"
+
+
 class _LstmImages(object):
     """bf16 operand images of one LSTM layer's input-side GEMMs (Gx = X.W_ih^T forward; dX = dG.W_ih,
     dW_ih = dG^T.X, dW_hh = dG^T.h_prev backward), built with lv_cvt_bf16_f32 next to the f32 originals."""
@@ -617,10 +622,19 @@ class _LstmImages(object):
         self.key = key                      # this object's key in the workspace cache (byte accounting of the lazy addend)
         self.ldr = _round_up(TB, 8)
         self.X = c.i16(TB, ni)              # layer input rows            [T*B][ni]
-        self.XT = c.i16(ni, self.ldr)       # ... transposed              [ni][T*B]
+        # X^T [ni][T*B] and h_{t-1}^T [H][T*B] in ONE buffer: the two weight gradients that share dG as their A operand,
+        # dW_ih = dG^T X and dW_hh = dG^T h_prev, are then one product over the image [X^T ; h_prev^T] (lv_gemm_b16_dual)
+        self.XhT = c.i16(ni + H, self.ldr)
         self.addend = None                  # unit-major copy of the Gx epilogue addend (biases / z-projection)
         self.dG = c.i16(TB, 4 * H)          # gate pre-activation grads   [T*B][4H]
-        self.hT = c.i16(H, self.ldr)        # h_{t-1} rows, transposed    [H][T*B]
+
+    @property
+    def XT(self):                           # layer input rows, transposed [ni][T*B]
+        return self.XhT[:self.ni]
+
+    @property
+    def hT(self):                           # h_{t-1} rows, transposed     [H][T*B]
+        return self.XhT[self.ni:]
 
     @staticmethod
     def usable(precision, native16, ni, H):
@@ -671,6 +685,13 @@ class _LstmImages(object):
         if between is not None:
             between()
         lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
+        wsd = ws if ws is not None else _gemm_ws(lib, s)
+        if DUAL_WGRAD and ni % 4 == 0 and lib.lv_gemm_b16_dual_supported(4 * H, ni + H, TB, wsd.numel()):
+            # both weight gradients as one product (N = ni + H columns, split between the two destinations in its reduction stage)
+            with _prof("gemm_bf16", 2.0 * 4 * H * (ni + H) * TB):
+                lib.lv_gemm_b16_dual(1, 4 * H, ni + H, TB, P(self.dG), 4 * H, P(self.XhT), self.ldr, gW_ih, ld_gw, ni, gW_hh, H,
+                                     P(wsd), wsd.numel(), s)
+            return
         _gemm16(lib, s, 1, 4 * H, ni, TB, P(self.dG), 4 * H, P(self.XT), self.ldr, gW_ih, ld_gw, ws=ws)
         _gemm16(lib, s, 1, 4 * H, H, TB, P(self.dG), 4 * H, P(self.hT), self.ldr, gW_hh, H, ws=ws)
 
