@@ -1784,6 +1784,13 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
         if (nk < 2 || ws_floats < 2L * M * N) return LV_ERR_UNSUPPORTED;
         splits = 2;
     }
+    if (p.nsplit > 0) {
+        // ... and into pieces of <= 32 K tiles: those take the single-buffer instantiation (3 workgroups per CU).  Measured on the
+        // two LSTM weight gradients as one product (M = 4096, N = 1536, K = 6400: 384 tiles): 2 pieces of 50 K tiles = 768
+        // workgroups on 512 slots (one and a half rounds) lost 30 us against the two separate products; 4 pieces of 25 = 1536
+        // workgroups on 768 slots, two whole rounds (profiles/r05j_gemm_dual.txt)
+        while (lv_cdiv(nk, splits) > 32 && splits < 64 && ws_floats >= (long)(splits + 1) * M * N) ++splits;
+    }
     p.kt_per_split = lv_cdiv(nk, splits);
     splits = lv_cdiv(nk, p.kt_per_split);
     p.splits = splits;
