@@ -599,6 +599,13 @@ def main():
     if args.overlap != "auto":
         tr.dec.overlap = (args.overlap == "on")
     tr.enc.persistent = tr.dec.persistent = bool(args.persistent)
+    if os.environ.get("LVAE_SHARED_GPU") and args.persistent:
+        # ranks sharing a device (the launcher's functional-check mode): every rank's persistent launch wants all 256 CUs resident at
+        # once, two of them beside each other starve each other into their bounded spins (seconds per timeout, then the ladder).  The
+        # check is of the data-parallel logic, so it runs on the launch-per-timestep kernels from the start
+        tr.enc.persistent = tr.dec.persistent = False
+        if rank == 0:
+            print("bench.py: ranks share a device: persistent LSTM launches off (%s)" % engine.PERSIST_RUNGS[2], file=sys.stderr)
     if sync is not None:
         args.dp_payload = sync.payload                      # "auto" resolved by the trainer
     pool = [synthetic_batch(B, T, V, seed=1000 * rank + i, dist=args.tokens).to(dev) for i in range(args.pool)]
