@@ -120,7 +120,7 @@ int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int gate_H, con
 /* Operand images for a forward product on the BINARY16 matrix pipe: dst = IEEE half (RNE) in the plain / unit-major gate rows / gathered
  * embedding rows layouts (arguments as lv_cvt_bf16_lo_f32), dstT = the transposed BF16 image the gradient products of the same operand
  * read.  lv_gemm_h16 = lv_gemm_b16 (transA = 0, 128 x 128 tile) on such operands: v_mfma_f32_32x32x16_f16, f32 accumulation.  The
- * encoder's input projection X W_ih^T (enc_lstm.py:50-55).  Values beyond 65504 become infinities: bounded operands only. */
+ * encoder's input projection X W_ih^T (enc_lstm.py:50-55).  Values beyond +-65504 saturate. */
 int lv_cvt_h16_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz, int V,
                    uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream);
 int lv_gemm_h16(int M, int N, int K, float alpha, const uint16_t* A, long lda, const uint16_t* B, long ldb,

@@ -627,8 +627,9 @@ def test_cvt_h16(lib, hip_device, mode, R, C):
     else:
         src = torch.randn(R, lds, generator=g)
         src[0, 0] = 1.00048828125          # a tie between two binary16 values: RNE picks the even significand (1.0)
+        src[1, 1], src[2, 3] = 1.0e6, -3.0e5   # beyond binary16's range: the image saturates at +-65504 (never inf); the bf16 image keeps them
         rows = src[:, :C]
-    want_d = rows.to(torch.float16).view(torch.int16)
+    want_d = rows.clamp(-65504.0, 65504.0).to(torch.float16).view(torch.int16)
     if mode == "gates":
         H = R // 4
         want_d = want_d[torch.arange(4 * H).view(4, H).t().reshape(-1)]

@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
                 if (lo == 1) b = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b));
                 if (dst) {
                     const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
-                    dst[dr * ldd + gc] = lo == 2 ? lv_f32_to_f16_bits(x) : b;
+                    dst[dr * ldd + gc] = lo == 2 ? lv_f32_to_f16_bits(fminf(fmaxf(x, -65504.f), 65504.f)) : b;      // binary16 saturates, never inf
                 }
             }
             tile[q + 4 * (i0 + u)][lane] = b;
@@ -1973,7 +1973,7 @@ extern "C" int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int 
 // conversions (plain / gate_H > 0: unit-major LSTM gate rows / ids != NULL: gathered embedding rows), dstT = the transposed BF16
 // image (what the gradient products of the same operand read: gradients need bf16's exponent range, forward operands of an LSTM --
 // weights U(-0.01, 0.01)-ish, embeddings, h in (-1, 1) -- do not, and binary16's 11-bit significand rounds them 8 x finer).  Values
-// beyond 65504 become infinities: not for operands without a bound.
+// beyond +-65504 saturate (a weight of that size has no business in an LSTM; the bf16 image of the same operand keeps its range).
 extern "C" int lv_cvt_h16_f32(const float* src, long lds, int R, int C, int gate_H, const int64_t* ids, long ids_stride, int Bsz,
                               int V, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, void* stream) {
     if (!src || (!dst && !dstT)) return LV_ERR_ARG;

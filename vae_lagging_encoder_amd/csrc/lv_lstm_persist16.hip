@@ -75,9 +75,12 @@ __device__ __forceinline__ void pack_w_k16_one(const float* __restrict__ whh, ui
     const int wave_id = (int)(idx >> 12), m = wave_id >> 2, w = wave_id & 3;
     const int c = l & 15, kq = l >> 4, col = 16 * nb + c;
     const float* row = whh + ((long)(col & 3) * PH + 32 * m + (col >> 2)) * PH + 256 * w + 32 * ks + 8 * kq;
-    if (f16)
-        wpk[idx] = make_uint4(lv_pack_f16x2(row[0], row[1]), lv_pack_f16x2(row[2], row[3]), lv_pack_f16x2(row[4], row[5]),
-                              lv_pack_f16x2(row[6], row[7]));
+    if (f16) {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = fminf(fmaxf(row[e], -65504.f), 65504.f);      // binary16 saturates, never inf
+        wpk[idx] = make_uint4(lv_pack_f16x2(r[0], r[1]), lv_pack_f16x2(r[2], r[3]), lv_pack_f16x2(r[4], r[5]), lv_pack_f16x2(r[6], r[7]));
+    }
     else
         wpk[idx] = make_uint4(lv_pack_bf16x2(row[0], row[1]), lv_pack_bf16x2(row[2], row[3]), lv_pack_bf16x2(row[4], row[5]),
                               lv_pack_bf16x2(row[6], row[7]));
