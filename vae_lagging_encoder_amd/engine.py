@@ -867,13 +867,13 @@ class LSTMEncoderEngine(object):
         img = self._b16(B, T)
         exact = self._exact(img)
         self._h16_now = img is not None and not exact and self.fwd_operands == "f16"
-        if img is None or "gx" in exact:
-            lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)
+        split = (self.exact_impl == "auto" and set(exact) == {"gx", "rec"} and _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B))
+        if img is None or ("gx" in exact and not split):
+            lib.lv_embed_gather_f32(P(v["embed.weight"]), P(x), T, None, 1.0, P(w.X), T, B, ni, V, s)      # f32 rows: the exact-f32 / fallback GEMM's operand
         # the backward's token sort depends on x only: taken from the per-batch cache, or queued now (auxiliary stream)
         self._sort = _sorted_tokens(self, lib, s, x, x_key, T, T, B, V, w)
         biases = dict(add1=P(v["lstm.bias_ih_l0"]), ld1=0, mod1=1, add2=P(v["lstm.bias_hh_l0"]), ld2=0, mod2=1)
         gx_unit_major = True
-        split = (self.exact_impl == "auto" and set(exact) == {"gx", "rec"} and _persistent_ok(self, img, B, H, x.device, _PERSIST_MAX_B))
         if split:
             self._exact_forward_split(lib, s, img, w, x, T, B, V, ni, H)
         elif img is not None and "gx" in exact:
