@@ -59,7 +59,14 @@ def fwd_flops(V, ni, H, nz, B, T):
 def bench_omniglot(args, dev, rank, world):
     out = measure_omniglot(args, dev, rank, world, cpu_baseline=(rank == 0 and not args.no_cpu_baseline))
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
+
+
+def emit(out):
+    """The one JSON line; a supervised rank 0 then tells its supervisor that the line is out (whatever teardown does)."""
+    print(json.dumps(out), flush=True)
+    if os.environ.get("LVAE_BENCH_DONE"):
+        open(os.environ["LVAE_BENCH_DONE"], "w").write("done\n")
 
 
 def measure_omniglot(args, dev, rank, world, cpu_baseline=False, profile_eager=False):
@@ -460,56 +467,192 @@ def measure_dropin(V, ni, H, nz, B, pool, kl_weight, dev, steps=8, warmup=3):
     return res
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher around it: start N copies of this command, one rank per GPU (rank r on
-    cuda:r), with the environment `torch.distributed.run` would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
-    MASTER_PORT), RCCL ("nccl") as the backend.  Rank 0 prints the one JSON line on the inherited stdout.  Returns the exit code:
-    0 when every rank returned 0; when a rank dies the others are terminated (by their PIDs) and its code is returned.
-    A box with fewer than N GPUs cannot run RCCL with N ranks (one communicator rank per device): the ranks then SHARE the devices
-    (rank r on cuda:r % device_count) and exchange over gloo -- a functional check of the data-parallel path, said loudly on stderr and
-    in the line's `config.dp_transport`; its seq/s is not a scaling number."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# Launching N > 1 ranks: a supervisor with a deadline and a ladder of exchange schedules.
+#
+# The first execution of this path over RCCL is the round driver's scaling run, and the driver gets one shot per N: a rank that
+# hangs (or dies) must not turn into "no JSON line".  Every multi-rank run is therefore SUPERVISED: the rank processes are
+# children of a supervisor that gives each attempt a deadline, asks hung ranks for their Python stacks (SIGUSR1 ->
+# faulthandler), stops them, and starts the next attempt on a more conservative schedule; when every attempt has failed the
+# supervisor itself prints ONE JSON line {"error": ..., "n_gpus": N, "attempts": [...]} and exits non-zero.
+#   plain `python bench.py --gpus N`:  one supervisor (this process) owns all N ranks;
+#   under torch.distributed.run:       each torchrun child supervises ITS OWN rank (the attempts line up by wall clock: every
+#                                      supervisor gives attempt k the window [t0 + k D, t0 + (k+1) D), t0 = its own start).
+LAUNCH_LADDER = [
+    ("default", {},
+     "persistent LSTM launches; embedding bucket and decoder exchange issued from inside the encoder backward (asynchronous)"),
+    ("conservative-exchange", {"LVAE_DP_CONSERVATIVE": "1"},
+     "persistent LSTM launches; every collective issued after the backward, device-synchronised on both sides (no kernel ever "
+     "runs beside an RCCL kernel)"),
+    ("conservative-exchange+step-kernels", {"LVAE_DP_CONSERVATIVE": "1", "LVAE_BENCH_PERSISTENT": "0"},
+     "launch-per-timestep LSTM kernels; every collective issued after the backward, device-synchronised on both sides"),
+]
+
+
+def _free_port():
     import socket
-    import subprocess
-    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev == 0:
-        print("bench.py: no GPU visible; --gpus %d needs MI355X GPUs (no CPU fallback)" % n, file=sys.stderr)
-        return 2
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
         so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
+        return so.getsockname()[1]
+
+
+def _done_marker(port):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "lvae_bench_%s_%s.done" % (port, os.environ.get("TORCHELASTIC_RUN_ID", "self")))
+
+
+def supervise(n, my_ranks, base_env, deadline_s, attempts, port_for_attempt, marker, print_error, t0=None):
+    """Run up to `attempts` rungs of LAUNCH_LADDER.  my_ranks: the ranks this supervisor owns.  Returns the exit code.
+    An attempt succeeds when rank 0 has written the marker file (its JSON line is out) or all owned ranks returned 0."""
+    import signal
+    import subprocess
+    t0 = time.time() if t0 is None else t0
+    history = []
+
+    def _term(signum, frame):                 # the launcher above us stops the job: take the ranks down with us (finally: below)
+        raise SystemExit(128 + signum)
+    try:
+        signal.signal(signal.SIGTERM, _term)
+    except ValueError:                          # not the main thread (tests)
+        pass
+    rc = 1
+    for k in range(attempts):
+        name, extra, what = LAUNCH_LADDER[min(k, len(LAUNCH_LADDER) - 1)]
+        window_end = t0 + (k + 1) * deadline_s
+        env = dict(base_env)
+        env.update(extra)
+        env.update(port_for_attempt(k))
+        env.update(LVAE_BENCH_WORKER="1", LVAE_BENCH_ATTEMPT=str(k), LVAE_BENCH_SCHEDULE=name, LVAE_BENCH_DONE=marker,
+                   LVAE_BENCH_PRIOR=json.dumps(history))
+        # a collective timeout inside the ranks well before the supervisor's own deadline: the ranks then fail with a message
+        env.setdefault("LVAE_DIST_TIMEOUT", str(int(max(30, min(180, deadline_s / 2)))))
+        if k > 0:
+            print("bench.py: attempt %d of %d on schedule '%s' (%s)" % (k + 1, attempts, name, what), file=sys.stderr, flush=True)
+        procs = {}
+        for r in my_ranks:
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs[r] = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e)
+        outcome, codes = None, {}
+        try:
+            live = dict(procs)
+            while live and outcome is None:
+                time.sleep(0.05)
+                for r, p in list(live.items()):
+                    c = p.poll()
+                    if c is None:
+                        continue
+                    del live[r]
+                    codes[r] = c
+                    if c != 0:
+                        rc = c if c > 0 else 128 - c
+                        outcome = "rank %d exited with %d" % (r, c)
+                if outcome is None and live and time.time() > window_end:
+                    outcome = "timeout: ranks %s still running after %.0f s" % (sorted(live), deadline_s)
+                    rc = 124
+            if outcome is None:
+                return 0                                        # every owned rank returned 0
+            if os.path.exists(marker):
+                # the JSON line is out; what failed / hung afterwards is process teardown
+                print("bench.py: %s after the result line was printed; ignoring" % outcome, file=sys.stderr, flush=True)
+                return 0
+            print("bench.py: attempt %d ('%s') failed: %s; stopping its ranks" % (k + 1, name, outcome), file=sys.stderr, flush=True)
+            for p in live.values():                             # where is it stuck?  (faulthandler in the ranks dumps all threads)
+                try:
+                    p.send_signal(signal.SIGUSR1)
+                except OSError:
+                    pass
+            if live:
+                time.sleep(1.5)
+            for p in live.values():
+                p.terminate()
+            t_kill = time.time() + 5
+            while any(p.poll() is None for p in live.values()) and time.time() < t_kill:
+                time.sleep(0.05)
+        finally:
+            for p in procs.values():
+                if p.poll() is None:
+                    p.kill()
+        history.append({"schedule": name, "outcome": outcome, "exit_codes": {str(r): c for r, c in sorted(codes.items())},
+                        "ranks_alive_at_stop": sorted(set(procs) - set(codes))})
+        if k + 1 < attempts and len(my_ranks) < n:
+            # a supervisor per rank (torchrun): the next attempt starts when the window ends on every supervisor's clock
+            while time.time() < window_end:
+                if os.path.exists(marker):
+                    return 0
+                time.sleep(0.2)
+    if os.path.exists(marker):
+        return 0
+    if print_error:
+        print(json.dumps({"error": "every launch attempt failed", "metric": "aggressive-loop seqs/sec", "value": None, "unit": "seq/s",
+                          "n_gpus": n, "attempts": history,
+                          "ranks_alive": history[-1]["ranks_alive_at_stop"] if history else []}), flush=True)
+    return rc if rc != 0 else 1
+
+
+def self_launch(n, deadline_s=420.0, attempts=3):
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this command, one rank per GPU (rank r on
+    cuda:r), with the environment `torch.distributed.run` would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+    MASTER_PORT), RCCL ("nccl") as the backend, under `supervise` (deadline per attempt, ladder of schedules, a JSON error line
+    when all fail).  Rank 0 prints the one JSON line on the inherited stdout.  Returns the exit code: 0 on success, else the code
+    of the rank that failed last (124 for a timeout).
+    A box with fewer than N GPUs cannot run RCCL with N ranks (one communicator rank per device): the ranks then SHARE the devices
+    (rank r on cuda:r % device_count) and exchange over gloo -- a functional check of the data-parallel path, said loudly on stderr and
+    in the line's `config.dp_transport`; its seq/s is not a scaling number (one attempt: the ladder is about RCCL)."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    emu = os.environ.get("LVAE_BENCH_EMU") == "1"            # test hook, see main()
+    if ndev == 0 and not emu:
+        print("bench.py: no GPU visible; --gpus %d needs MI355X GPUs (no CPU fallback)" % n, file=sys.stderr)
+        return 2
     env = dict(os.environ)
-    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LVAE_BENCH_LAUNCHER="self")
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", LVAE_BENCH_LAUNCHER="self")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver supports dmabuf IPC only (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    if ndev < n:
+    if emu:
+        env["LVAE_DIST_BACKEND"] = "gloo"
+        env["LVAE_SHARED_GPU"] = "%d ranks on the CPU emulator (test hook)" % n
+        env["OMP_NUM_THREADS"] = "1"
+        attempts = 1
+    elif ndev < n:
         env["LVAE_DIST_BACKEND"] = "gloo"
         env["LVAE_SHARED_GPU"] = "%d ranks on %d GPU%s" % (n, ndev, "" if ndev == 1 else "s")
+        attempts = 1
         print("bench.py: --gpus %d on a box with %d GPU(s): RCCL needs one device per rank, so the ranks share the device(s) and "
               "exchange over gloo -- a functional check of the data-parallel path, NOT a scaling measurement" % (n, ndev), file=sys.stderr)
-    procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
-    rc = 0
+    else:
+        print("bench.py: launching %d ranks, one per GPU (%d visible), RCCL; %d attempt(s) of %.0f s" % (n, ndev, attempts, deadline_s),
+              file=sys.stderr, flush=True)
+    marker = _done_marker(_free_port())
+    if os.path.exists(marker):
+        os.remove(marker)
     try:
-        live = list(procs)
-        while live:
-            time.sleep(0.05)
-            for p in list(live):
-                c = p.poll()
-                if c is None:
-                    continue
-                live.remove(p)
-                if c != 0 and rc == 0:
-                    rc = c if c > 0 else 128 - c
-                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (procs.index(p), c), file=sys.stderr)
-                    for q in live:
-                        q.terminate()
+        return supervise(n, list(range(n)), env, deadline_s, attempts, lambda k: {"MASTER_PORT": str(_free_port())}, marker, True)
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    return rc
+        if os.path.exists(marker):
+            os.remove(marker)
+
+
+def supervise_own_rank(n, deadline_s=420.0, attempts=3):
+    """Under torch.distributed.run (WORLD_SIZE / RANK set by the launcher): this process stays the launcher's child and runs ITS rank
+    as a grandchild under `supervise`.  Attempt 0 uses the launcher's own rendezvous (MASTER_PORT, the agent's store) -- exactly a
+    plain torchrun start; later attempts rendezvous on MASTER_PORT + k with rank 0 hosting the store."""
+    rank = int(os.environ["RANK"])
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("LVAE_BENCH_LAUNCHER", "torch.distributed.run")
+    marker = _done_marker(base_port)
+    if rank == 0 and os.path.exists(marker):
+        os.remove(marker)
+
+    def port_for_attempt(k):
+        if k == 0:
+            return {}
+        return {"MASTER_PORT": str(base_port + k), "TORCHELASTIC_USE_AGENT_STORE": "False"}
+    try:
+        return supervise(n, [rank], env, deadline_s, attempts, port_for_attempt, marker, rank == 0)
+    finally:
+        if rank == 0 and os.path.exists(marker):
+            time.sleep(1.0)                # the other supervisors look at it when their rank's exit was not clean
+            os.remove(marker)
 
 
 def main():
@@ -554,6 +697,13 @@ def main():
                          "decoder's two vocabulary-sized gradient tensors are reduced to their sums of squares in their producers and "
                          "never written (text.py:383-387 uses them for the clip norm alone); single GPU")
     ap.add_argument("--pool", type=int, default=None)
+    ap.add_argument("--launch-timeout", type=float, default=420.0,
+                    help="--gpus N > 1: seconds one launch attempt may take before its ranks are stopped (stacks dumped) and the "
+                         "next rung of the schedule ladder is tried; after the last the supervisor prints a JSON error line")
+    ap.add_argument("--launch-attempts", type=int, default=3, help="--gpus N > 1: rungs of LAUNCH_LADDER to try (RCCL runs)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="--gpus 1: run the data-parallel exchange anyway, on a one-rank RCCL process group -- every collective of the "
+                         "schedule executes on the real backend (all a one-GPU box can reach of RCCL); reported as `rccl_single_rank`")
     ap.add_argument("--tokens", default="uniform", choices=["uniform", "zipf"],
                     help="distribution of the synthetic token ids: uniform (SURVEY.md 8d, the default) or Zipf-like (natural text: frequent "
                          "tokens repeat hundreds of times per batch, which the embedding backward's sort / scatter feel)")
@@ -562,9 +712,19 @@ def main():
         # diagnostics: dump every thread's Python stack to stderr after this many seconds (and again every period) without exiting
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["LVAE_BENCH_WATCHDOG"]), repeat=True, exit=False)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and prints nothing itself
-        sys.exit(self_launch(args.gpus))
+    if args.gpus > 1 and "LVAE_BENCH_WORKER" not in os.environ:
+        # this process becomes the SUPERVISOR of the rank processes (deadline per attempt, ladder of exchange schedules, a JSON error
+        # line when every attempt fails) and prints nothing else itself
+        if "WORLD_SIZE" not in os.environ:
+            # plain `python bench.py --gpus N`: supervisor of all N ranks (one per GPU)
+            sys.exit(self_launch(args.gpus, args.launch_timeout, args.launch_attempts))
+        # under torch.distributed.run: supervisor of this launcher child's own rank
+        sys.exit(supervise_own_rank(args.gpus, args.launch_timeout,
+                                    1 if os.environ.get("LVAE_DIST_BACKEND") == "gloo" else args.launch_attempts))
+    if os.environ.get("LVAE_BENCH_WORKER"):
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)      # the supervisor asks a stuck rank where it is
     stress = args.workload == "stress"
     if args.steps is None:
         args.steps = 50 if stress else 20
@@ -576,12 +736,33 @@ def main():
     from vae_lagging_encoder_amd.trainer import AggressiveTextTrainer
     from vae_lagging_encoder_amd.factory import build_text_vae as build_vae, synthetic_batch
 
-    rank, local, world = lvdist.init_from_env()
+    rank, local, world = lvdist.init_from_env(banner=args.gpus > 1 or args.force_dp, force=args.force_dp)
+    if os.environ.get("LVAE_BENCH_PERSISTENT") == "0":      # a rung of LAUNCH_LADDER
+        args.persistent = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or plain `python bench.py --gpus N`)" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    dev = torch.device("cuda", local % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
+    emu = os.environ.get("LVAE_BENCH_EMU") == "1"
+    if emu:
+        # TEST HOOK (tests/test_bench_launch.py): the same .hip sources compiled for the host by tests/emu, on device "cpu", so that
+        # the multi-rank control flow of THIS file (launch ladder, exchange, loop exit, dp_breakdown) runs on the CPU-only CI box
+        # over gloo.  Not a fallback: without this variable a missing GPU is the loud exit below; its numbers mean nothing.
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from build_emu import build_emu
+        import install as emu_install
+        from vae_lagging_encoder_amd import _lib
+        emu_install.install(_lib.bind(ctypes.CDLL(build_emu())))
+        torch.set_num_threads(1)
+        dev = torch.device("cpu")
+        args.no_side_runs = args.no_cpu_baseline = True
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+        dev = torch.device("cuda", local % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+
+    def dsync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
     cfg = WORKLOADS[args.workload]
     if args.workload == "omniglot":
         return bench_omniglot(args, dev, rank, world)
@@ -591,7 +772,8 @@ def main():
 
     # reference init (text.py:265-266) from the reference's default seed (text.py:54,73); same replica on every rank
     vae = build_vae(V, ni, H, nz, dev, seed=783435)
-    sync = lvdist.GradSync(mode=args.dp_mode, payload=args.dp_payload) if world > 1 else None
+    sync = lvdist.GradSync(mode=args.dp_mode, payload=args.dp_payload, force=args.force_dp) if (world > 1 or args.force_dp) else None
+    dp = sync is not None
     tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, seed=783435, grad_sync=sync, use_graph=bool(args.graph),
                                precision=args.dtype, micro_batches=args.micro_batches, decoder_grads=args.decoder_grads,
                                encoder_forward=args.encoder_forward if args.dtype == "bf16" else None)
@@ -643,21 +825,22 @@ def main():
     def warm_up():
         for _ in range(args.warmup):
             one_step()
-        torch.cuda.synchronize(dev)
+        dsync()
 
+    rung_before = max(engine.persist_rung(tr.enc), engine.persist_rung(tr.dec))
     warm_up()
     # The persistent LSTM launches assume that the whole GPU is resident at once and (rung 0) that a group's workgroups share an
     # XCD.  A hand-off timeout voids the step on the device; the trainer notices it at this host read, moves down its fallback
     # ladder (write-through hand-off, then the launch-per-timestep kernels) and replays -- data parallel on all ranks alike.
     rung = tr.commit()
-    if rung > 0:
+    if rung > rung_before:
         print("bench: persistent LSTM launches timed out during warm-up; running on ladder rung %d (%s)"
               % (rung, engine.PERSIST_RUNGS[rung]), file=sys.stderr)
         warm_up()
         tr.commit()
-    if world > 1:
+    if dp:
         torch.distributed.barrier()
-    if not args.graph:
+    if not args.graph and not emu:
         # the dominant kernel group (the four LSTM recurrences) is bracketed live inside the timed region; the GEMM group's events
         # (22 records per step, ~5 us of queue idle each) are taken in a separate untimed pass right after it
         prof = {}
@@ -666,11 +849,11 @@ def main():
     if sync is not None:
         sync.profile = True                                  # HIP events around the phases of the gradient exchange
     tr.reset_stats()
-    torch.cuda.synchronize(dev)
+    dsync()
     t0 = time.perf_counter()
     timed_region()
-    torch.cuda.synchronize(dev)
-    if world > 1:
+    dsync()
+    if dp:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     engine.PROFILE = None
@@ -682,11 +865,11 @@ def main():
         engine.PROFILE, engine.PROFILE_PREFIX = prof_gemm, "gemm_"
         for _ in range(gemm_steps):
             one_step()
-        torch.cuda.synchronize(dev)
+        dsync()
         tr.commit()
         engine.PROFILE = engine.PROFILE_PREFIX = None
     dp_breakdown = None
-    if world > 1:
+    if dp:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt_local, dt = dt, float(tmax.item())
@@ -699,6 +882,12 @@ def main():
         mine = torch.tensor([bd.get(k, 0.0) for k in names] + [1e3 * dt_local / args.steps, float(my_rung)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
+        # replicas must hold the same bits after the run (every rank applied the same mean gradient): an integer checksum of the
+        # encoder's parameter buffer, compared across ranks
+        chk = tr.enc.flat.data.view(torch.int32).to(torch.int64).sum().reshape(1)
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(chks, chk)
+        replicas_identical = all(int(c.item()) == int(chks[0].item()) for c in chks)
         rungs = [int(t[-1].item()) for t in allr]
         rows = [[round(float(v), 4) for v in t.tolist()[:-1]] for t in allr]
         exposed = [round(sum(r[:-1]), 4) for r in rows]
@@ -714,18 +903,20 @@ def main():
             # a collective taking CUs from a persistent launch would show here as a rung > 0 on some rank)
             "lstm_ladder_rung_per_rank": rungs if args.dtype == "bf16" else None,
             "backend": torch.distributed.get_backend(),
+            "replicas_identical": replicas_identical,
+            "schedule": os.environ.get("LVAE_BENCH_SCHEDULE", "default") + (" (conservative)" if sync.conservative else ""),
             "encoder_bucket": "embedding gradient issued from inside the encoder backward (under dW_ih / dW_hh)" if not args.graph else "none (hipGraph split)"}
     cold = None
     if world == 1 and not args.graph and not stress and not args.no_side_runs:
         # the same step on batches it has never seen: the (token, row) sort of the embedding backward, which the aggressive loop pays
         # once per batch of the epoch (trainer.prepare_batches / first use) and the headline's pool has cached, inside every step
         fresh = [synthetic_batch(B, T, V, seed=50000 + i, dist=args.tokens).to(dev) for i in range(args.steps)]
-        torch.cuda.synchronize(dev)
+        dsync()
         tc0 = time.perf_counter()
         for xb in fresh:
             tr.step(xb, kl_weight)
         tr.commit()
-        torch.cuda.synchronize(dev)
+        dsync()
         cold = B * len(fresh) / (time.perf_counter() - tc0)
         del fresh
 
@@ -770,6 +961,13 @@ def main():
                                                 "has it cached)"}
     if dp_breakdown is not None:
         out["dp_breakdown"] = dp_breakdown
+    if args.force_dp and world == 1:
+        out["rccl_single_rank"] = ("one-rank %s process group: every collective of the data-parallel schedule executed on the real "
+                                   "backend beside the engines' streams (no peer: not a scaling number)" % torch.distributed.get_backend())
+    if os.environ.get("LVAE_BENCH_WORKER"):
+        # which rung of the launch ladder produced this line, and what the earlier ones died of
+        out["launch"] = {"attempt": int(os.environ.get("LVAE_BENCH_ATTEMPT", "0")) + 1, "schedule": os.environ.get("LVAE_BENCH_SCHEDULE", "default"),
+                         "failed_attempts": json.loads(os.environ.get("LVAE_BENCH_PRIOR", "[]"))}
     # what this arithmetic is held to against the reference's CPU path (tests/test_gpu_parity.py)
     out["parity_contract"] = ({"elbo_rel": 1e-4, "rec_rel": 1e-4, "kl_rel": 1e-4, "note": "exact-f32 path: north_star's bound on all three"}
                               if args.dtype == "f32" else
@@ -832,12 +1030,12 @@ def main():
         for _ in range(3):
             one_step()
         tr.commit()
-        torch.cuda.synchronize(dev)
+        dsync()
         tk0 = time.perf_counter()
         nk = max(5, args.steps // 2)
         for _ in range(nk):
             one_step()
-        torch.cuda.synchronize(dev)
+        dsync()
         dk = time.perf_counter() - tk0
         tr.commit()
         tr.enc.exact_forward = ()
@@ -850,12 +1048,12 @@ def main():
         tr.enc.precision = tr.dec.precision = "f32"
         for _ in range(2):
             one_step()
-        torch.cuda.synchronize(dev)
+        dsync()
         tf0 = time.perf_counter()
         n32 = max(3, args.steps // 4)
         for _ in range(n32):
             one_step()
-        torch.cuda.synchronize(dev)
+        dsync()
         d32 = time.perf_counter() - tf0
         tr.enc.precision = tr.dec.precision = args.dtype
         out["f32_parity_path"] = {"value": round(B * n32 / d32, 2), "unit": "seq/s", "ms_per_step": round(1e3 * d32 / n32, 4),
@@ -898,7 +1096,7 @@ def main():
         out["side_runs"] = side
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline_and_elbo(out, args, vae, pool, kl_weight, V, ni, H, nz, B, T, dev, value)
-    print(json.dumps(out))
+    emit(out)
 
 
 def cpu_text_leg(O, P, xs, kl_weight, es, mis, mos, Bc, T, ncpu, counts=(16, 32)):

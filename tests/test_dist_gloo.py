@@ -85,7 +85,7 @@ def _worker(rank, world, port, name, mode, q, device="cpu"):
                          + [("text_mid", "norm/bucket16"), ("text_mid", "allreduce/bucket"), ("text_mid", "norm/micro"),
                             ("text_mid", "allreduce/micro"), ("text_mid", "norm/micro16"), ("text_small_wide", "norm/micro"),
                             ("text_mid", "norm/rows"), ("text_mid", "allreduce/rows16"), ("text_small_wide", "norm/rows")])
-def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, device="cpu"):
+def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, device="cpu", world=2):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     if device == "cpu":
         from build_emu import build_emu
@@ -95,7 +95,7 @@ def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, devic
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, "strict/" + decoder, q, device)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, "strict/" + decoder, q, device)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -106,7 +106,8 @@ def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, devic
         assert tb is None, tb
         # every rank sees the GLOBAL clipped norm (fixture has norm > 5: the clip is active); a bf16 wire format rounds every
         # gradient element to 8 bits of mantissa (2^-9 relative), which the norm averages out and the update does not
-        tol = 5e-3 if decoder.endswith("16") else 1e-4
+        # (the wire SUMS in bf16 too: P - 1 roundings per element, so the bound grows like sqrt(P) -- 5e-3 at P = 2, 1e-2 at P = 8)
+        tol = 5e-3 * max(1.0, world / 2.0) ** 0.5 if decoder.endswith("16") else 1e-4
         assert abs(norm - float(fx["total_norm"])) / float(fx["total_norm"]) < tol
         glob = errs.pop("_dec_grad_is_global")
         nbytes = errs.pop("_bytes")
@@ -116,10 +117,35 @@ def test_two_rank_strict_dp_equals_single_process_reference(name, decoder, devic
             assert e < tol, (rank, k, e)
         # "norm": the decoder gradient travelled as a reduce-scatter + one scalar (its .grad stays local, and differs from the
         # global mean); "allreduce": every replica holds the clipped global mean gradient, as the reference's .grad would
-        assert (glob < tol) == decoder.startswith("allreduce"), (decoder, glob)
+        if world > 1:       # (one forced rank: the local gradient IS the global mean)
+            assert (glob < tol) == decoder.startswith("allreduce"), (decoder, glob)
         bytes_by_mode.append(nbytes)
     # the ranks' local loss sums add up to the reference's batch loss sum
     assert abs(sum(r[2] for r in res) - float(fx["loss"].sum())) / abs(float(fx["loss"].sum())) < 1e-4
+
+
+@pytest.mark.parametrize("world,decoder", [(4, "norm"), (4, "allreduce"), (4, "norm/bf16"), (4, "norm/bucket16"), (4, "allreduce/bucket"),
+                                           (4, "norm/hook"), (8, "norm"), (8, "allreduce/bf16"), (8, "norm/bucket16")])
+def test_four_and_eight_rank_strict_dp_equals_single_process_reference(world, decoder):
+    """SURVEY.md section 4's strong-scaling identity at the driver's other SCALE points: P ranks x B/P rows == 1 x B rows of the
+    reference-generated fixture (text_mid, B = 32), for P = 4 and P = 8 -- the norm-only decoder exchange (reduce-scatter shards of
+    1/4 and 1/8 of the padded buffer), the full all-reduce, the bf16 wire and the bucketed encoder exchange.  (VERDICT r5 item 1a:
+    `bench.py --gpus 4` on one shared device did not finish while 2 and 8 did; this rules the exchange logic itself out.)"""
+    test_two_rank_strict_dp_equals_single_process_reference("text_mid", decoder, world=world)
+
+
+@pytest.mark.parametrize("decoder", ["norm/hook", "allreduce/bucket", "norm/bf16"])
+def test_forced_single_rank_exchange_equals_reference(decoder, monkeypatch):
+    """LVAE_DP_FORCE=1: a process group of ONE rank still runs every collective of the schedule (GradSync.active) -- the mode the
+    one-GPU box uses to execute the exchange on RCCL itself (tests/test_rccl_single_rank.py); here over gloo on the emulator."""
+    monkeypatch.setenv("LVAE_DP_FORCE", "1")
+    test_two_rank_strict_dp_equals_single_process_reference("text_small_wide", decoder, world=1)
+
+
+def test_conservative_schedule_equals_reference(monkeypatch):
+    """LVAE_DP_CONSERVATIVE=1 (second rung of bench.py's launch ladder): nothing issued from inside the backward, same result."""
+    monkeypatch.setenv("LVAE_DP_CONSERVATIVE", "1")
+    test_two_rank_strict_dp_equals_single_process_reference("text_mid", "norm/bucket16", world=2)
 
 
 @pytest.mark.gpu

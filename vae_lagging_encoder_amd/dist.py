@@ -19,20 +19,40 @@ from . import engine as _eng
 from .engine import P
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+def init_from_env(backend=None, timeout_s=None, force=False, banner=False):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
+
+    timeout_s (default LVAE_DIST_TIMEOUT or 180): the process group's collective timeout -- a rank that never arrives turns into
+    an exception on the others instead of a wait without end (the default of 10 / 30 minutes outlives any launcher's patience).
+    RCCL gets `device_id` (the communicator is bound to this rank's GPU and created eagerly: a bad device mapping fails HERE, with
+    a message, not inside the first collective).  force: create the group for a world of one too (GradSync(force=True)).
+    banner: one line per rank on stderr -- rank, device, visible devices, backend -- so that a first multi-GPU run explains
+    itself."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("LVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("LVAE_DIST_TIMEOUT", "180"))
+        kw = {}
         if torch.cuda.is_available():
             # one process per GPU; LVAE_DIST_BACKEND=gloo lets several ranks share a device (single-GPU smoke tests)
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", local)
+                os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL's own warnings on stderr (topology, transport fallbacks)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if banner:
+            import sys
+            print("vae_lagging_encoder_amd.dist: rank %d/%d local %d -> %s of %d visible device(s), backend %s, timeout %.0f s"
+                  % (rank, world, local, ("cuda:%d" % local) if torch.cuda.is_available() else "cpu",
+                     torch.cuda.device_count() if torch.cuda.is_available() else 0, backend, timeout_s), file=sys.stderr, flush=True)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local, world
 
 
@@ -62,7 +82,7 @@ class GradSync(object):
     on the compute stream (`breakdown()`): what a step spends WAITING for each collective, i.e. the exposed communication.
     """
 
-    def __init__(self, group=None, mode="strict", decoder="auto", payload="auto"):
+    def __init__(self, group=None, mode="strict", decoder="auto", payload="auto", force=False):
         assert mode in ("strict", "encoder_only")
         assert decoder in ("auto", "norm", "allreduce")
         assert payload in ("auto", "f32", "bf16")
@@ -73,6 +93,19 @@ class GradSync(object):
         self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # `active`: the exchange runs.  A world of ONE is normally a no-op; LVAE_DP_FORCE=1 (or force=True) runs every collective of
+        # the schedule anyway -- a one-rank process group over RCCL on a one-GPU box executes the product's own calls (bf16
+        # reduce-scatter, asynchronous all-reduces beside the engines' streams, the scalar exchanges) on the real backend, which
+        # is all of RCCL a box with one device can reach (tests/test_rccl_single_rank.py, bench.py --force-dp)
+        force = bool(force) or os.environ.get("LVAE_DP_FORCE", "") not in ("", "0")
+        if force and not dist.is_initialized():
+            raise RuntimeError("GradSync(force=True) needs an initialised process group (dist.init_from_env(force=True))")
+        self.active = self.world > 1 or force
+        # conservative schedule (LVAE_DP_CONSERVATIVE=1; a rung of bench.py's launch ladder): nothing is issued from inside the
+        # backward, every collective is issued by sync() with the device idle before and after -- no kernel of ours is ever in
+        # flight beside an RCCL kernel.  Slower (nothing overlaps), and the fallback if the overlapped schedule misbehaves on
+        # a transport it has not met.
+        self.conservative = os.environ.get("LVAE_DP_CONSERVATIVE", "") not in ("", "0")
         self.decoder = decoder
         self._inv = None
         # per-slot state (slot = micro-batch slice of a step, trainer.micro_batches; slot 0 alone without gradient accumulation):
@@ -218,7 +251,7 @@ class GradSync(object):
         """Issue the mean all-reduce of encoder-gradient elements [lo, hi) now (lo, hi multiples of 1024 elements, or hi = the
         padded end): called from inside the encoder's backward as soon as that part of the gradient is final, so that the
         collective runs under the backward work still queued behind it.  sync() completes it and exchanges what is left."""
-        if self.world == 1:
+        if not self.active or self.conservative:
             return
         pad = enc_flat.grad_padded.numel()
         hi = min(hi, pad)
@@ -238,7 +271,7 @@ class GradSync(object):
         `cap` gradient rows per rank (lv_rows_merge_f32 rebuilds the dense mean).  mode "auto": only when that is fewer bytes
         than the ring all-reduce (cap * world < 2 V: Zipf-distributed natural text, small worlds), else dense; "rows" forces it.
         Returns True when the row-list exchange is in use."""
-        if self.world == 1:
+        if not self.active or self.conservative:          # (conservative: the dense exchange inside sync() only)
             return False
         dev = unique_ids[0].device
         cap = torch.tensor([max(int(u.numel()) for u in unique_ids), len(unique_ids)], dtype=torch.int64)
@@ -305,7 +338,7 @@ class GradSync(object):
         """Issue the decoder-gradient exchange (strict mode) once the decoder's backward has been queued: RCCL runs it on its
         own stream, behind everything queued on the compute stream so far and beside what is queued afterwards (the
         encoder's backward, or its weight-gradient GEMMs when the BPTT is a persistent launch).  Completed by sync()."""
-        if self.world == 1 or self.mode != "strict":
+        if not self.active or self.mode != "strict" or self.conservative:
             return
         if self._norm_only(dec_flat, update):
             self._cur.h_rs = self._reduce_scatter(dec_flat, update, async_op=True)
@@ -334,17 +367,23 @@ class GradSync(object):
         """Exchange the gradients of one step.  Returns None when both buffers now hold the global mean gradient, or a
         device scalar with the sum of squares of the mean decoder gradient when only that was exchanged (the trainer adds
         it to the encoder's sum of squares for the clip coefficient)."""
-        if self.world == 1:
+        if not self.active:
             return None
+        quiesce = self.conservative and enc_flat.device.type == "cuda"
+        if quiesce:
+            torch.cuda.synchronize(enc_flat.device)
         self.sync_issue(enc_flat, dec_flat, update)
         self.sync_collect(enc_flat, dec_flat, update)
-        return self.sync_norm(dec_flat, update, (self._slot,))
+        ss = self.sync_norm(dec_flat, update, (self._slot,))
+        if quiesce:
+            torch.cuda.synchronize(enc_flat.device)
+        return ss
 
     def sync_issue(self, enc_flat, dec_flat, update="encoder"):
         """First half of sync() for the current slot: every collective of this slice's gradients that is not in flight yet is
         issued (asynchronously); nothing is waited for.  With micro-batches the trainer calls this after each slice's backward
         and goes on to the next slice -- the exchange runs underneath it (weights are frozen within a step)."""
-        if self.world == 1:
+        if not self.active:
             return
         st = self._cur
         dev = enc_flat.device
@@ -360,7 +399,7 @@ class GradSync(object):
         """Second half for the current slot (the flat buffers must have the same gradient slot selected): wait for this slice's
         collectives and unpack them -- the encoder (and, where it was all-reduced, the decoder) buffer then holds the mean over
         ranks of this slice's gradient, the reduce-scatter shard the SUM over ranks of this rank's share of the decoder's."""
-        if self.world == 1:
+        if not self.active:
             return
         st = self._cur
         lib, s = _eng.backend_for(enc_flat.device), _eng.stream_ptr(enc_flat.device)
@@ -385,7 +424,7 @@ class GradSync(object):
         """Norm-only decoder exchange: sum of squares of the MEAN decoder gradient from the reduce-scatter shards of the listed
         slots (their sum = this rank's share of the gradient summed over ranks and micro-batches) + one scalar all-reduce.
         Returns the device scalar, or None when the decoder gradient was all-reduced in full (or not exchanged)."""
-        if self.world == 1 or not self._norm_only(dec_flat, update):
+        if not self.active or not self._norm_only(dec_flat, update):
             return None
         lib, s = _eng.backend_for(dec_flat.device), _eng.stream_ptr(dec_flat.device)
         dev = dec_flat.device
@@ -423,7 +462,7 @@ class GradSync(object):
 
     def ss_handle(self, dec_flat, update="encoder"):
         """The device scalar sync() will return for this kind of step (None when it returns None); no communication."""
-        if self.world == 1 or not self._norm_only(dec_flat, update):
+        if not self.active or not self._norm_only(dec_flat, update):
             return None
         src = dec_flat.grad_padded
         if self._ss is None or self._ss.device != src.device:
@@ -465,7 +504,7 @@ class GradSync(object):
     def window_mean(self, loss_sum, num_words):
         """Global mean loss per word of one exit window (text.py:393-396): sum of the ranks' loss sums over the sum of
         their word counts, identical on every rank, so all ranks take the same data-dependent `break`."""
-        if self.world == 1:
+        if not self.active:
             return loss_sum / num_words
         t = torch.tensor([loss_sum, float(num_words)], dtype=torch.float64)
         if dist.get_backend(self.group) == "nccl":

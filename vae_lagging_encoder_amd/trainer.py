@@ -86,7 +86,7 @@ class AggressiveTextTrainer(object):
         self.enc.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
         if grad_sync is not None:
             grad_sync.resolve_payload(precision)              # "auto": bf16 wire for the bf16 configuration, exact fp32 otherwise
-            if self.micro_batches > 1 and grad_sync.world > 1 and precision == "bf16" and (self.enc.persistent or self.dec.persistent):
+            if self.micro_batches > 1 and grad_sync.active and precision == "bf16" and (self.enc.persistent or self.dec.persistent):
                 # slice i's collectives are in flight during slice i + 1's recurrences BY DESIGN here; a persistent launch needs all 256
                 # CUs resident at once and would run into its bounded hand-off spin beside an RCCL kernel (a timeout per step, then the
                 # ladder): micro-batch mode under data parallelism runs on the launch-per-timestep kernels from the start
@@ -224,7 +224,7 @@ class AggressiveTextTrainer(object):
         ring all-reduce (capacity * world < 2 V: natural, Zipf-distributed text; small worlds); "rows" forces it.  Collective:
         every rank must call it.  Returns True when the row-list exchange is in use afterwards."""
         gs = self.grad_sync
-        if gs is None or gs.world == 1:
+        if gs is None or not gs.active:
             return False
         if self.micro_batches != 1 or self.use_graph:
             raise ValueError("the row-list exchange runs with micro_batches = 1 in eager mode")
@@ -316,7 +316,7 @@ class AggressiveTextTrainer(object):
                                      self._s(10), T - 1, B, s)
         dzp, parts = self.dec.backward(st.rowscale, partial_dz=True)
         hook = bucket = None
-        if self.grad_sync is not None and not self._capturing and self.grad_sync.world > 1:
+        if self.grad_sync is not None and not self._capturing and self.grad_sync.active:
             ef = self.enc.flat
             align = 1024 if self.grad_sync.payload == "bf16" else 4      # bf16 wire rows are 1024 elements wide
             n_emb = ef.offsets[ef.names[1]] // align * align             # the embedding table leads the flat buffer
@@ -347,7 +347,7 @@ class AggressiveTextTrainer(object):
                 start()                   # step kernels: the collective runs under the whole encoder backward
         self.enc.backward(None, head=(st.eps, dzp, parts, st.dkl), after_bptt=hook, after_embed=bucket)
         self.dec.join()           # decoder weight-gradient GEMMs ran on the side stream underneath the BPTT chains
-        if self.grad_sync is not None and self.grad_sync.world > 1:
+        if self.grad_sync is not None and self.grad_sync.active:
             # data parallel: this rank's timeout flag rides in the tail padding of the encoder gradient (exchanged by sync())
             ef = self.enc.flat
             lib.lv_txn_guard_f32(_eng.status_ptr(self.enc), _eng.status_ptr(self.dec), P(ef.grad_padded, ef.guard_index), s)
@@ -361,7 +361,7 @@ class AggressiveTextTrainer(object):
         ef, df = self.enc.flat, self.dec.flat
         # the transaction gate rides in the clip coefficient's launch: status words of both engines, data parallel also the
         # exchanged guard element; it commits the step's report sums (scal[10..12] -> scal[5..7]) or raises the void flag scal[8]
-        dp = self.grad_sync is not None and self.grad_sync.world > 1
+        dp = self.grad_sync is not None and self.grad_sync.active
         gate = (_eng.status_ptr(self.enc), _eng.status_ptr(self.dec), P(ef.grad_padded, ef.guard_index) if dp else None,
                 self._s(8), self._s(5))
         if dec_ss is None and self._fold is not None:
@@ -486,7 +486,7 @@ class AggressiveTextTrainer(object):
         draw = noise is None
         ef, df = self.enc.flat, self.dec.flat
         gs = self.grad_sync
-        dp = gs is not None and gs.world > 1
+        dp = gs is not None and gs.active
         self._update = update
         self._fold = None                 # (the norm is that of the slots' sum: no folding, _plan_fold)
         if gs is not None:
