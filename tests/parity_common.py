@@ -67,6 +67,64 @@ def check_grad_accumulation_semantics(device, V=97, ni=12, H=20, nz=4, B=6, T=7)
         assert float((p.grad - single[1][k]).abs().max()) <= 1e-6 * float(single[1][k].abs().max()) + 1e-12, k
 
 
+def check_autograd_grad_and_frozen_modules(device, V=97, ni=12, H=20, nz=4, B=6, T=7):
+    """the zero-copy gradient route is taken only inside a plain `loss.backward()`, per parameter.
+    (a) torch.autograd.grad(loss, params) returns real tensors (equal to what backward() leaves) and touches no .grad;
+    (b) a frozen module (requires_grad False) gets no .grad, the other module still gets its views;
+    (c) backward(inputs=[encoder params]) leaves the decoder's .grad alone;
+    (d) VAE.use_flat_grads(False): .grad tensors own their storage (a kept gradient survives the next backward)."""
+    from oracle import text_vae_oracle as O
+    P = O.random_params(V, ni, H, nz, seed=3, scale=0.3, emb_scale=0.5, head_scale=0.5)
+    vae = build_vae(V, ni, H, nz, device, params=P)
+    x = O.synthetic_batch(B, T, V, seed=10).to(device)
+    eps, mi, mo = O.draw_noise(B, T, ni, H, nz, seed=20)
+    noise = (eps.to(device), mi.to(torch.uint8).to(device), mo.to(torch.uint8).to(device))
+    params = list(vae.parameters())
+    vae.zero_grad()
+    vae.loss(x, 0.5, noise=noise)[0].mean().backward()
+    assert vae.encoder._hip.flat.grads_are_views() and vae.decoder._hip.flat.grads_are_views()
+    want = [p.grad.detach().clone() for p in params]
+    # (a)
+    vae.zero_grad()
+    got = torch.autograd.grad(vae.loss(x, 0.5, noise=noise)[0].mean(), params, allow_unused=True)
+    assert all(p.grad is None for p in params), "autograd.grad must not populate .grad"
+    for g, w, (k, _) in zip(got, want, vae.named_parameters()):
+        assert g is not None and float((g - w).abs().max()) <= 1e-6 * float(w.abs().max()) + 1e-12, k
+    flat_ptrs = {id(e): (e.flat.grad.data_ptr(), e.flat.grad.data_ptr() + 4 * e.flat.numel) for e in (vae.encoder._hip, vae.decoder._hip)}
+    for g in got:       # fresh storage, not views of the flat buffers
+        assert not any(lo <= g.data_ptr() < hi for lo, hi in flat_ptrs.values())
+    # (b)
+    for p in vae.decoder.parameters():
+        p.requires_grad_(False)
+    vae.zero_grad()
+    vae.loss(x, 0.5, noise=noise)[0].mean().backward()
+    assert all(p.grad is None for p in vae.decoder.parameters()), "a frozen module must not receive gradients"
+    assert vae.encoder._hip.flat.grads_are_views()
+    for p, w in zip(params, want):
+        if p.grad is not None:
+            assert float((p.grad - w).abs().max()) <= 1e-6 * float(w.abs().max()) + 1e-12
+    for p in vae.decoder.parameters():
+        p.requires_grad_(True)
+    # (c)
+    vae.zero_grad()
+    vae.loss(x, 0.5, noise=noise)[0].mean().backward(inputs=list(vae.encoder.parameters()))
+    assert all(p.grad is None for p in vae.decoder.parameters()) and all(p.grad is not None for p in vae.encoder.parameters())
+    # (d)
+    assert vae.use_flat_grads(False) is vae
+    vae.zero_grad()
+    vae.loss(x, 0.5, noise=noise)[0].mean().backward()
+    assert not vae.encoder._hip.flat.grads_are_views()
+    kept = params[0].grad
+    snapshot = kept.clone()
+    vae.zero_grad()
+    vae.loss(O.synthetic_batch(B, T, V, seed=11).to(device), 0.5, noise=noise)[0].mean().backward()
+    assert torch.equal(kept, snapshot), "with flat grads off a kept gradient tensor must survive the next backward"
+    vae.use_flat_grads(True)
+    vae.zero_grad()
+    vae.loss(x, 0.5, noise=noise)[0].mean().backward()
+    assert vae.encoder._hip.flat.grads_are_views()
+
+
 def check_step_against_fixture(name, device, optim="torch"):
     fx, vae, loss, rec, kl, grads, total = run_reference_style_step(name, device, optim=optim)
     rec_scale = float(np.abs(fx["rec"]).max())

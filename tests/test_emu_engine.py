@@ -18,6 +18,10 @@ def test_dropin_backward_keeps_autograd_accumulation_emulated(emu_backend):
     pc.check_grad_accumulation_semantics("cpu")
 
 
+def test_dropin_backward_under_autograd_grad_and_frozen_modules_emulated(emu_backend):
+    pc.check_autograd_grad_and_frozen_modules("cpu")
+
+
 def test_cpu_tensors_refused_without_test_backend():
     import os
     import sys

@@ -243,6 +243,11 @@ def test_lstm_fwd_persistent16_binary16_operands_emulated(emu_backend):
     K.test_lstm_fwd_persistent16_binary16_operands(emu_backend, CPU, 2, 4, 1, 0)
 
 
+def test_binary16_subnormal_weights_survive_the_packing_emulated(emu_backend):
+    """(the emulator's MFMA keeps subnormals by construction: this leg covers the f32 -> binary16 packing conversion)"""
+    K.test_binary16_subnormal_weights_survive_the_matrix_pipe(emu_backend, CPU, 2, 4, 1, 32)
+
+
 def test_persistent_exchange_halves_alternate_without_memsets_emulated(emu_backend):
     K.test_persistent_exchange_halves_alternate_without_memsets(emu_backend, CPU, 1, [(8, 1), (27, 14), (8, 1)], local=0, repeat_fwd=0)
 

@@ -1,5 +1,6 @@
 """MI355X kernel-level parity: every C-ABI entry point against a float64 torch restatement of the same op."""
 import ctypes
+import math
 
 import numpy as np
 import pytest
@@ -612,6 +613,55 @@ def test_lstm_fwd_persistent16_binary16_operands(lib, hip_device, T, B, R, flags
     assert errs["f16"] < 0.35 * errs["bf16"], errs        # ~8x finer operand rounding (rms over all h_t; measured ~0.13)
 
 
+def test_binary16_subnormal_weights_survive_the_matrix_pipe(lib, hip_device, T=3, B=32, R=4, flags=33):
+    """at the reference init U(-0.01, 0.01) about 0.6 % of the W_hh / W_ih entries are below binary16's smallest
+    normal number (6.1e-5) and reach the forward's v_mfma_f32_16x16x32_f16 as SUBNORMAL operands.  Here EVERY recurrent weight is
+    a positive binary16 subnormal in [1e-7, 6e-5] and h is positive, so the recurrent product is O(1e-2) per gate if subnormal
+    operands are honoured and exactly 0 if the packing conversion or the matrix pipe flushes them.  The kernel must match the
+    float64 recurrence that KEEPS them (binary16-rounded, as torch's .to(float16) does) and be far from the flushed one."""
+    dev, H = hip_device, 1024
+    g = torch.Generator().manual_seed(77)
+    lo, hi = math.log(1e-7), math.log(6e-5)
+    whh = torch.exp(lo + (hi - lo) * torch.rand(4 * H, H, generator=g)).to(dev)
+    assert float(whh.max()) < 6.1e-5
+    gx = torch.zeros(T, B, 4 * H, device=dev)
+    c0 = (0.5 + torch.rand(B, H, generator=g)).to(dev)
+    h0 = torch.tanh(c0)
+
+    def ref(w):
+        h, c = h0.double(), c0.double()
+        hs = [h]
+        for t in range(T):
+            a = h.float().to(torch.float16).double() @ w.t()
+            i, f, gg, o = a.chunk(4, -1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hs.append(h)
+        return torch.stack(hs)
+    w16 = whh.to(torch.float16)
+    assert float((w16.float() - whh).abs().max()) <= 2.0 ** -25 + 1e-12      # subnormal spacing 2^-24: the image keeps them
+    hs_keep = ref(w16.double())
+    hs_flush = ref(torch.zeros_like(whh).double())
+    signal = float((hs_keep - hs_flush).abs().max())
+    assert signal > 1e-3                                                        # the two hypotheses are far apart
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1).to(dev)
+    gxu = gx[:, :, perm].contiguous()
+    hs = torch.zeros(T + 1, B, H, device=dev)
+    cs = torch.zeros(T + 1, B, H, device=dev)
+    hs[0], cs[0] = h0, c0
+    wpk = torch.full((lib.lv_lstm_persist16_wpk_floats(),), float("nan"), device=dev)
+    xch = torch.zeros(lib.lv_lstm_persist16_xch_floats(), device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib.lv_lstm_persist16_pack(P(whh), P(wpk), 2, H, _s(dev))
+    saved = torch.empty(lib.lv_lstm_persist16_saved_floats(T, R), device=dev)
+    lib.lv_lstm_fwd_bf16_persist16(P(gxu), P(wpk), P(hs), P(cs), P(saved), P(xch), P(status), T, B, R, flags, H, _s(dev))
+    assert int(status.item()) == 0
+    e_keep = float((hs.double() - hs_keep).abs().max())
+    e_flush = float((hs.double() - hs_flush).abs().max())
+    print("binary16 subnormal W_hh: |h - keep| %.3e, |h - flushed| %.3e (hypotheses %.3e apart)" % (e_keep, e_flush, signal))
+    assert e_keep < 2e-5 and e_flush > 0.5 * signal, (e_keep, e_flush, signal)
+
+
 @pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
 def test_cvt_h16(lib, hip_device, mode, R, C):
     """lv_cvt_h16_f32: dst = IEEE binary16 (RNE) in the plain / unit-major gate rows / gathered layouts, dstT = the transposed BF16
@@ -628,6 +678,7 @@ def test_cvt_h16(lib, hip_device, mode, R, C):
         src = torch.randn(R, lds, generator=g)
         src[0, 0] = 1.00048828125          # a tie between two binary16 values: RNE picks the even significand (1.0)
         src[1, 1], src[2, 3] = 1.0e6, -3.0e5   # beyond binary16's range: the image saturates at +-65504 (never inf); the bf16 image keeps them
+        src[3, 2] = float("nan")               # a NaN stays a NaN in both images (the clamp used to turn it into -65504)
         rows = src[:, :C]
     want_d = rows.clamp(-65504.0, 65504.0).to(torch.float16).view(torch.int16)
     if mode == "gates":
@@ -641,7 +692,12 @@ def test_cvt_h16(lib, hip_device, mode, R, C):
     else:
         lib.lv_cvt_h16_f32(P(sd), lds, R, C, R // 4 if mode == "gates" else 0, None, 0, 1, 0, P(d), ldd, P(dT), ldt, _s(dev))
     assert torch.equal(d.cpu()[:, :C], want_d)
-    assert torch.equal(dT.cpu()[:, :R], _bf16_bits(rows).t())
+    gotT, wantT = dT.cpu()[:, :R], _bf16_bits(rows).t()
+    nan = torch.isnan(rows).t()
+    assert torch.equal(gotT[~nan], wantT[~nan])
+    if bool(nan.any()):     # a NaN stays a NaN in the bf16 image too (any payload): exponent all ones, significand non-zero
+        b = gotT[nan].to(torch.int32) & 0xFFFF
+        assert bool(((b & 0x7F80) == 0x7F80).all()) and bool(((b & 0x007F) != 0).all())
     assert bool((d.cpu()[:, C:] == 0x1234).all()) and bool((dT.cpu()[:, R:] == 0x1234).all())
 
 

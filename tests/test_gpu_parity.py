@@ -22,6 +22,10 @@ def test_dropin_backward_keeps_autograd_accumulation(hip_device):
     pc.check_grad_accumulation_semantics(hip_device)
 
 
+def test_dropin_backward_under_autograd_grad_and_frozen_modules(hip_device):
+    pc.check_autograd_grad_and_frozen_modules(hip_device)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_fused_trainer_trajectory(hip_device, use_graph):
     pc.check_trajectory_against_fixture(hip_device, use_graph=use_graph)
@@ -580,14 +584,17 @@ def test_stress_config_at_full_size(hip_device):
             torch.cuda.synchronize()
             for name, got, ref in (("loss", st.loss, l_ref), ("rec", st.rec, rec_ref), ("kl", st.kl, kl_ref)):
                 e = rel_err(got[rows], ref.reshape(-1))
-                assert e < (1e-4 if name != "kl" else 1e-3), (name, e)
+                print("stress B=128 T=200 step 1, rows 48..79: %s rel err %.3e" % (name, e))
+                assert e < 1e-4, (name, e)          # north_star's bound on all three (KL too: binary16 forward operands, 16 rows per group)
             # ... and over ALL 128 rows, plus the backward side at this size (16 rows per XCD group in both persistent kernels):
             # the clip norm (float64 norm of the oracle's gradients), the coefficient, per-tensor gradient norms and the encoder's
             # update, at the bf16 configuration's bounds (tests above: norm 1e-4 measured 1e-6; per-tensor norms 2e-3; update 2e-2)
             stats = tr.read_stats()
             for name, ref in (("loss_sum", r_full["loss"]), ("rec_sum", r_full["rec"])):
                 assert abs(stats[name] - float(ref.sum())) / abs(float(ref.sum())) < 1e-4, name
-            assert abs(stats["kl_sum"] - float(r_full["kl"].sum())) / abs(float(r_full["kl"].sum())) < 1e-3
+            e_kl = abs(stats["kl_sum"] - float(r_full["kl"].sum())) / abs(float(r_full["kl"].sum()))
+            print("stress B=128 T=200 step 1, all rows: kl_sum rel err %.3e" % e_kl)
+            assert e_kl < 1e-4
             assert abs(stats["norm"] - r_full["total_norm"]) / r_full["total_norm"] < 1e-3, (stats["norm"], r_full["total_norm"])
             assert abs(stats["coef"] - r_full["coef"]) <= 1e-3 * r_full["coef"]
             named = dict(vae.named_parameters())

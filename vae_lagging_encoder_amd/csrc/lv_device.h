@@ -73,6 +73,9 @@ template <int SHIFT, int BANK> static inline float lv_row_shr_into(float old, fl
     lv_emu::wave_sync();
     return out;
 }
+// saturation in front of a binary16 conversion: finite values beyond +-65504 clamp (never inf), NaN stays NaN (fmaxf / fminf
+// would turn it into -65504: a poisoned weight must poison the forward as it poisons the bf16 images of the backward)
+static inline float lv_sat_f16(float x) { return x != x ? x : fminf(fmaxf(x, -65504.f), 65504.f); }
 // IEEE binary16 <-> f32 in software (round-to-nearest-even, as v_cvt_f16_f32 does): g++ 11 has no _Float16
 static inline uint16_t lv_f32_to_f16_bits(float x) {
     uint32_t u;
@@ -315,6 +318,9 @@ __device__ __forceinline__ uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {
     lv_s16x4_lds v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lv_s16x4_lds*)lds_ptr);
     return *reinterpret_cast<uint2*>(&v);
 }
+// saturation in front of a binary16 conversion: finite values beyond +-65504 clamp (never inf), NaN stays NaN (fmaxf / fminf
+// would turn it into -65504: a poisoned weight must poison the forward as it poisons the bf16 images of the backward)
+__device__ __forceinline__ float lv_sat_f16(float x) { return x != x ? x : fminf(fmaxf(x, -65504.f), 65504.f); }
 // IEEE binary16 <-> f32 (v_cvt_f16_f32 / v_cvt_f32_f16, round-to-nearest-even)
 __device__ __forceinline__ uint16_t lv_f32_to_f16_bits(float x) {
     const _Float16 h = (_Float16)x;

@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
                 if (lo == 1) b = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b));
                 if (dst) {
                     const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
-                    dst[dr * ldd + gc] = lo == 2 ? lv_f32_to_f16_bits(fminf(fmaxf(x, -65504.f), 65504.f)) : b;      // binary16 saturates, never inf
+                    dst[dr * ldd + gc] = lo == 2 ? lv_f32_to_f16_bits(lv_sat_f16(x)) : b;      // binary16 saturates, never inf; NaN stays NaN
                 }
             }
             tile[q + 4 * (i0 + u)][lane] = b;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void pack_w_k16_one(const float* __restrict__ whh, ui
     if (f16) {
         float r[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = fminf(fmaxf(row[e], -65504.f), 65504.f);      // binary16 saturates, never inf
+        for (int e = 0; e < 8; ++e) r[e] = lv_sat_f16(row[e]);      // binary16 saturates, never inf; NaN stays NaN
         wpk[idx] = make_uint4(lv_pack_f16x2(r[0], r[1]), lv_pack_f16x2(r[2], r[3]), lv_pack_f16x2(r[4], r[5]), lv_pack_f16x2(r[6], r[7]));
     }
     else

@@ -44,7 +44,10 @@ def init_from_env(backend=None, timeout_s=None, force=False, banner=False):
             torch.cuda.set_device(local)
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local)
-                os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL's own warnings on stderr (topology, transport fallbacks)
+                # RCCL's own warnings (topology, transport fallbacks) -- on STDERR: its default sink is stdout, where the version
+                # banner would land behind a caller's result line
+                os.environ.setdefault("NCCL_DEBUG", "WARN")
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if banner:

@@ -117,17 +117,50 @@ class FlatBuffer(object):
                 p.grad = p.grad.clone()
                 self.detached = True          # (a fused trainer re-attaches before its next step)
 
+    # the drop-in path hands gradients out as views of the flat buffer (see deliver_grads); False = always as clones
+    flat_grads = True
+
+    @staticmethod
+    def _accumulates_into(p):
+        """True when the running backward will ACCUMULATE into leaf p's .grad -- i.e. this is a plain `loss.backward()` (or
+        `backward(inputs=[..., p, ...])`).  False when the engine will not visit p's accumulation node (`backward(inputs=` without
+        p, `autograd.grad` for other tensors); None under `torch.autograd.grad(..., p)`, which must be handed a real tensor to
+        capture (torch refuses the query for a leaf in that mode and says so)."""
+        try:
+            node = torch.autograd.graph.get_gradient_edge(p).node
+            return bool(torch._C._will_engine_execute_node(node))
+        except RuntimeError:
+            return None
+
     def deliver_grads(self):
         """What a drop-in autograd backward returns for the parameters once the engine has written this backward's gradients into
-        the flat buffer.  After `zero_grad()` (set_to_none, torch's default: every .grad is None -- the state text.py:373 leaves)
-        the parameters' .grad become VIEWS of the flat buffer and autograd is handed nothing to accumulate: no 215 MB of clones
-        per step at the Yahoo shape, and lvae.clip_grad_norm_ / lvae.SGD can then run as single streaming launches over the
-        flat buffers.  In any other state (a .grad that already holds something: gradient accumulation across backward calls,
-        zero_grad(set_to_none=False)) autograd's += semantics are kept: clones are returned and accumulated as usual."""
-        if self.gviews is self._slots[0][2] and all(p.grad is None for p in self.params):
-            self.attach_grads()
-            return tuple(None for _ in self.names)
-        return tuple(self.gviews[n].clone() for n in self.names)
+        the flat buffer, PER PARAMETER:
+          * frozen (requires_grad False): None, and its .grad is not touched;
+          * a plain `loss.backward()` reaching a parameter whose .grad is None (the state `zero_grad()` leaves, text.py:373): the
+            .grad becomes a VIEW of the flat buffer and autograd is handed nothing to accumulate -- no 215 MB of clones per step at
+            the Yahoo shape, and lvae.clip_grad_norm_ / lvae.SGD can run as single streaming launches over the flat buffers;
+          * a backward that will not accumulate into it (`backward(inputs=...)` without it): None;
+          * everything else -- `torch.autograd.grad(loss, params)` (the caller wants tensors back, .grad must stay untouched), a
+            .grad that already holds something (accumulation across backward calls, zero_grad(set_to_none=False)), gradients being
+            written to a micro-batch slot, `flat_grads = False` -- a clone, with autograd's usual semantics.
+        ALIASING (documented contract of the zero-copy route): such a .grad is overwritten in place by the NEXT backward of the
+        module; code that keeps a gradient tensor across steps (`g = p.grad; zero_grad(); ...; backward()`) must clone it, or
+        switch the route off (`VAE.use_flat_grads(False)`)."""
+        slot0 = self.gviews is self._slots[0][2]
+        out = []
+        for n, p in zip(self.names, self.params):
+            if not p.requires_grad:
+                out.append(None)
+                continue
+            acc = self._accumulates_into(p)
+            if acc is False:
+                out.append(None)
+            elif acc and slot0 and self.flat_grads and p.grad is None:
+                p.grad = self.gviews[n]
+                out.append(None)
+            else:
+                out.append(self.gviews[n].clone())
+        return tuple(out)
 
 
 def _tensor_bytes(obj, depth=0):
@@ -421,6 +454,9 @@ def demote_persistent(eng):
     else:
         raise _lib.LvaeError("a persistent-launch timeout was reported although the engine runs the launch-per-timestep kernels")
     reset_persistent_status(eng)
+    # whoever demotes (a trainer's _settle, training.guarded_eval): captured hipGraphs hold the launches of the rung that failed --
+    # the trainers key their graphs by this counter and re-capture (guarded_eval demoted behind the trainer's back)
+    eng.ladder_gen = getattr(eng, "ladder_gen", 0) + 1
     return r + 1
 
 
@@ -515,12 +551,16 @@ def _weight_images(eng, lib, s, device, want_persist, lstm=True, pred=False):
     return wi
 
 
-def _xch_flags(wi, kind, rows, device):
+def _xch_flags(wi, kind, rows, device, T=1):
     """Flag bits 1.. of a persistent launch (lv_lstm_persist16_xch_floats): the exchange buffer's halves alternate per kind of launch
     ("f" forward, "g" BPTT) and every launch clears the other half of its kind itself -- no memset launch in front (4 per training
     step before: ~26 us).  Not under hipGraph capture: a replay repeats the captured half, so captured launches keep half 0 behind
     their memset (and leave the alternation state alone)."""
     st = wi.xstate
+    if T <= 0:
+        # the launch returns before it touches the exchange (and before it would clear the other half): the alternation must not
+        # advance, or the next launch of this kind would poll a half that still holds the tags of the launch before last (ADVICE r5)
+        return 0
     if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
         st["captured"] = True
     if st.get("captured"):
@@ -556,7 +596,7 @@ def _lstm_forward(eng, lib, s, img, w, Gx, whh, mask, scale, hdrop, T, B, H, dev
         if w.gates.numel() < need:              # eng.persist_rows / eng.persistent changed after the workspace was built
             w.gates = torch.empty(need, dtype=torch.float32, device=w.gates.device)
         lib.lv_lstm_fwd_bf16_persist16(Gx, P(wi.fwd16), P(w.hs), P(w.cs), P(w.gates), P(wi.xch), P(eng.status), T, B, rows,
-                                       eng.persist_flags | _xch_flags(wi, "f", rows, device) | (32 if getattr(wi, "h16", False) else 0), H, s)
+                                       eng.persist_flags | _xch_flags(wi, "f", rows, device, T) | (32 if getattr(wi, "h16", False) else 0), H, s)
         w.saved_layout = ("persist16", T, B, rows)      # what w.gates holds now: the BPTT must be given the same T, B, R
     else:
         lib.lv_lstm_fwd_bf16_ug(*args, P(w.lstm_ws), T, B, H, s)
@@ -602,7 +642,7 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
             raise _lib.LvaeError("the saved activations were not written by a persistent forward with the same T, B and rows per "
                                  "group (%r): eng.persist_rows / eng.persistent changed between forward and backward" % (getattr(w, "saved_layout", None),))
         lib.lv_lstm_bwd_bf16_persist16(dh_ext, dh_last, P(wi.bwd16), P(w.gates), P(w.hs), P(w.cs), dG16, P(w.dGsum), P(wi.xch),
-                                       P(eng.status), dh0, dc0, tanh_init, T, B, rows, eng.persist_flags | _xch_flags(wi, "g", rows, device), H, s)
+                                       P(eng.status), dh0, dc0, tanh_init, T, B, rows, eng.persist_flags | _xch_flags(wi, "g", rows, device, T), H, s)
     else:
         _need_canonical_saved(w)
         lib.lv_lstm_bwd_bf16_img(dh_ext, dh_last, mask, scale, whh, P(w.gates), P(w.hs), P(w.cs), dG, dG16, P(w.dGsum),
@@ -806,6 +846,7 @@ class LSTMEncoderEngine(object):
                      ("lstm.weight_hh_l0", self.m.lstm.weight_hh_l0), ("lstm.bias_ih_l0", self.m.lstm.bias_ih_l0),
                      ("lstm.bias_hh_l0", self.m.lstm.bias_hh_l0), ("linear.weight", self.m.linear.weight)]
             self.flat = FlatBuffer(named, device)
+            self.flat.flat_grads = getattr(self, "_flat_grads_pref", True)      # VAE.use_flat_grads before the buffers existed
             self.wsc = _WS(device)
             self.wsc.evictable = self.ws_evictable
             self.wsc.before_evict = self._quiesce_side_streams
@@ -1130,6 +1171,7 @@ class LSTMDecoderEngine(object):
                      ("lstm.bias_ih_l0", m.lstm.bias_ih_l0), ("lstm.bias_hh_l0", m.lstm.bias_hh_l0),
                      ("pred_linear.weight", m.pred_linear.weight)]
             self.flat = FlatBuffer(named, device)
+            self.flat.flat_grads = getattr(self, "_flat_grads_pref", True)      # VAE.use_flat_grads before the buffers existed
             self.wsc = _WS(device)
             self.wsc.evictable = self.ws_evictable
             self.wsc.before_evict = self._quiesce_side_streams

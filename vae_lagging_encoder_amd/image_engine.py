@@ -521,6 +521,7 @@ class ImageEncoderEngine(object):
         device = torch.device(device)
         if self.flat is None or self.flat.device != device or not self.flat.bound():
             self.flat = FlatBuffer(list(self.m.named_parameters()), device)
+            self.flat.flat_grads = getattr(self, "_flat_grads_pref", True)      # VAE.use_flat_grads before the buffers existed
         return self.flat
 
     def forward(self, x_img):
@@ -552,6 +553,7 @@ class ImageDecoderEngine(object):
         device = torch.device(device)
         if self.flat is None or self.flat.device != device or not self.flat.bound():
             self.flat = FlatBuffer(list(self.m.named_parameters()), device)
+            self.flat.flat_grads = getattr(self, "_flat_grads_pref", True)      # VAE.use_flat_grads before the buffers existed
         return self.flat
 
     def weights_version(self):

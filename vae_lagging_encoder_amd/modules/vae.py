@@ -25,7 +25,7 @@ class VAE(nn.Module):
         dev = args.device
         self.prior = torch.distributions.normal.Normal(torch.zeros(self.nz, device=dev), torch.ones(self.nz, device=dev))
 
-    def set_precision(self, precision, encoder_forward=None):
+    def set_precision(self, precision, encoder_forward=None, forward_operands=None):
         """Arithmetic of the HIP path behind this model's `loss` / `backward` (no counterpart in the reference, whose precision is
         the tensors' dtype): "f32" (default; exact-f32 MFMA, north_star's 1e-4 parity path) or "bf16" (BASELINE.json's GPU
         configuration: bf16 matrix pipe with f32 accumulation for the large products and the recurrent operands; master weights,
@@ -38,7 +38,42 @@ class VAE(nn.Module):
             eng.precision = precision
         if hasattr(self.encoder._hip, "exact_forward"):
             self.encoder._hip.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
+        if forward_operands is not None:
+            self.set_forward_operands(forward_operands)
         return self
+
+    def set_forward_operands(self, fmt):
+        """Number format of the ENCODER FORWARD's matrix-pipe operands under precision "bf16": "f16" (default: IEEE binary16 images
+        of X, W_ih, W_hh and the h hand-off -- 11-bit significands on the same instructions and rates as bf16, which puts the KL
+        within north_star's 1e-4; range assumption: |weights|, |embeddings|, |h| << 65504 (values beyond saturate at +-65504, values
+        below 6e-5 are kept as binary16 subnormals: tests/test_gpu_kernels.py::test_binary16_subnormal_*) or "bf16" (the arithmetic of
+        rounds 1-4: KL 2e-4..5e-4).  Gradient products and the BPTT are bf16 either way.  Returns self."""
+        if fmt not in ("f16", "bf16"):
+            raise ValueError("forward operands: 'f16' or 'bf16'")
+        eng = getattr(self.encoder, "_hip", None)
+        if eng is None or not hasattr(eng, "fwd_operands"):
+            raise TypeError("%s has no binary16 forward" % type(self.encoder).__name__)
+        eng.fwd_operands = fmt
+        return self
+
+    def use_flat_grads(self, flag=True):
+        """Drop-in autograd path: hand the parameters' gradients out as VIEWS of the engines' flat gradient buffers after a plain
+        `loss.backward()` (default; zero-copy, engine.FlatBuffer.deliver_grads -- a .grad obtained this way is overwritten by the next
+        backward) or always as fresh tensors (False: stock autograd aliasing semantics, 215 MB of copies per step at the Yahoo
+        shape).  Returns self."""
+        for m in (self.encoder, self.decoder):
+            eng = getattr(m, "_hip", None)
+            if eng is not None and getattr(eng, "flat", None) is not None:
+                eng.flat.flat_grads = bool(flag)
+            elif eng is not None:
+                eng._flat_grads_pref = bool(flag)
+        return self
+
+    def arithmetic(self):
+        """The run-config record of the HIP path's arithmetic (what a checkpoint's sidecar / a log line should carry)."""
+        e = getattr(self.encoder, "_hip", None)
+        return {"precision": getattr(e, "precision", None), "encoder_forward": "f32" if getattr(e, "exact_forward", ()) else "operands",
+                "forward_operands": getattr(e, "fwd_operands", None)}
 
     # ---- training path (reference vae.py:35-98) ---------------------------------------------------------
     def encode(self, x, nsamples=1, eps=None):

@@ -46,7 +46,7 @@ class AggressiveTextTrainer(object):
     BUCKET_MIN_ELEMS = 1 << 20
 
     def __init__(self, vae, lr=1.0, clip=5.0, seed=783435, grad_sync=None, use_graph=False, device=None,
-                 precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full", encoder_forward=None):
+                 precision="f32", micro_batches=1, fold_norm=True, decoder_grads="full", encoder_forward=None, forward_operands=None):
         """encoder_forward = "f32" (with precision="bf16"): the encoder's FORWARD (input projection + recurrence) with f32-like
         weights inside the bf16 configuration (engine._exact_forward_split: split-bf16 operands + a two-pass recurrence; on a
         fallback rung the exact-f32 kernels).  mu / logvar -- hence z and the KL of encoder.py:55 -- depend on the forward's last
@@ -84,6 +84,12 @@ class AggressiveTextTrainer(object):
         self.enc.precision = self.dec.precision = precision   # large GEMMs: exact f32 (parity) or bf16 pipe (throughput)
         assert encoder_forward in (None, "bf16", "f32")
         self.enc.exact_forward = ("gx", "rec") if (encoder_forward == "f32" and precision == "bf16") else ()
+        # forward_operands ("f16" / "bf16"; None keeps the engine's setting, default "f16"): number format of the encoder forward's
+        # matrix-pipe operands under precision "bf16" (VAE.set_forward_operands: binary16 puts the KL within 1e-4; range assumption
+        # |weights|, |embeddings| << 65504)
+        if forward_operands is not None:
+            assert forward_operands in ("f16", "bf16")
+            self.enc.fwd_operands = forward_operands
         if grad_sync is not None:
             grad_sync.resolve_payload(precision)              # "auto": bf16 wire for the bf16 configuration, exact fp32 otherwise
             if self.micro_batches > 1 and grad_sync.active and precision == "bf16" and (self.enc.persistent or self.dec.persistent):
@@ -566,9 +572,14 @@ class AggressiveTextTrainer(object):
             # replays exactly what was queued at capture time, and at capture time they are fresh
             self.enc.refresh_weight_images(B, self.device)
             self.dec.refresh_weight_images(B, self.device)
-            key = (update, draw, self.vae.training)
+            gens = (getattr(self.enc, "ladder_gen", 0), getattr(self.dec, "ladder_gen", 0))
+            key = (update, draw, self.vae.training) + gens
             g = st.graphs.get(key)
             if g is None:
+                # graphs captured on an earlier rung of the persistent-launch ladder (a demotion by this trainer's _settle or by
+                # training.guarded_eval) replay launches of the rung that failed: dropped, never replayed
+                for k in [k for k in st.graphs if k[3:] != gens]:
+                    del st.graphs[k]
                 # eager warm-up (allocates every workspace), then capture
                 self._run(st, update, draw)
                 torch.cuda.synchronize(self.device)
