@@ -1186,6 +1186,13 @@ def vendor_leg_main(kind, autocast, dev=None):
     amp = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=bool(autocast))
     if kind != "omniglot":
         from oracle import text_vae_oracle as O
+        if dev.type == "cuda":
+            # nn.LSTM passes its `training` flag to the ATen op (enc_lstm.py:60 / dec_lstm.py:104 run under vae.train()); MIOpen's RNN
+            # backward insists on it, the CPU op does not care (dropout 0, one layer: same numbers) -- the oracle's CPU call says False
+            def lstm_train(x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+                out, hT, cT = torch._VF.lstm(x, (h0.unsqueeze(0), c0.unsqueeze(0)), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, True, False, True)
+                return out, (hT[0], cT[0])
+            O.lstm_aten = lstm_train
         cfg = WORKLOADS[kind]
         V, ni, H, nz, B, T = (cfg[k] for k in ("V", "ni", "H", "nz", "B", "T"))
         Q = {k: v.to(dev).requires_grad_(True) for k, v in O.random_params(V, ni, H, nz, seed=783435).items()}

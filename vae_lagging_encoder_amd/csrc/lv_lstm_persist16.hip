@@ -47,10 +47,20 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_GJ16
 #define LV_GJ16 16
 #endif
+#ifndef LV_P16_ABL
+#define LV_P16_ABL 0                    // measurement knob (profiles/microbench/lstm_anatomy_probe.py): WHAT-IF builds of the final
+#endif                                  // kernels with one phase of a timestep removed -- results are garbage, the time is the point.
+                                        // bit 0: no MFMAs; bit 1: hand-off tags not tested (no step waits for its producers: the
+                                        // local pipeline alone); bit 2: no transcendental cell / gate-gradient math; bit 3: no
+                                        // LDS quarter-sum exchange + barrier (forward) / dG image barrier (BPTT); bit 4 (forward): the
+                                        // gathered granules are not staged through LDS (fragments straight from the poll registers);
+                                        // bit 5 (forward): the granules are not loaded at all
 
 namespace {
 
 using namespace lvp;
+
+__device__ __forceinline__ float abl_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }      // (what-if builds only)
 
 constexpr int HP16 = PH / 2 + 8;        // dwords per row of the gathered h image (130 slots: = 2 mod 16)
 constexpr int DP16 = 64 + 8;            // dwords per row of the dG image (18 slots)
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     const int nq = rows * 128;                                 // granules of this wave's K quarter
     const int brow = (l & 15) < rows ? (l & 15) : 0;           // batch row of this lane's B fragments (rows beyond the slice re-read row 0)
     const int kq = l >> 4;
+    uint32_t abl_keep[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // (LV_P16_ABL bit 4 only)
     for (int tb = 0; tb < T; tb += SBK) {
 #pragma unroll
         for (int s2 = 0; s2 < SBK; ++s2) {
@@ -265,18 +276,24 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     for (int j = 0; j < GJ; ++j) {
                         const int q = base + j * 64 + l;
                         const bool in = q < nq;
+                        if constexpr (LV_P16_ABL & 32) { v[j] = ((gran_t)want << 32) | (gran_t)(uint32_t)(q + t); continue; }
                         v[j] = gran_load(src + (in ? (q >> 7) * (PH / 2) + (q & 127) : 0));      // out-of-range lanes re-read granule 0: no branch
-                        ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
+                        if (!(LV_P16_ABL & 2)) ok = ok && (!in || (uint32_t)(v[j] >> 32) == want);
                     }
                     ok = __all(ok);
                     if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
                 } while (!ok);
                 LV_TRACE_VAL(t, 6, spins);
+                if constexpr (LV_P16_ABL & 16) {
+#pragma unroll
+                    for (int j = 0; j < GJ; ++j) abl_keep[j & 7] ^= (uint32_t)v[j];
+                } else {
 #pragma unroll
                 for (int j = 0; j < GJ; ++j) {
                     const int q = base + j * 64 + l;
                     uint32_t* dstw = q < nq ? &sm.hl[(q >> 7) * HP16 + 128 * w + (q & 127)] : &sm.dump[tid];
                     *dstw = (uint32_t)v[j];
+                }
                 }
             }
             // Bulk I/O goes out right BEHIND a completed gather: a wave's loads and stores retire in order, so whatever is issued in
@@ -293,10 +310,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             f32x4 acc[8];
             const uint4* bp = reinterpret_cast<const uint4*>(sm.hl + brow * HP16 + 128 * w) + kq;
             uint4 bfr[8];
+            if constexpr (LV_P16_ABL & 16) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) bfr[ks] = make_uint4(abl_keep[ks], abl_keep[(ks + 1) & 7], abl_keep[(ks + 2) & 7], abl_keep[(ks + 3) & 7]);
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) bfr[ks] = bp[ks * 4];
+            }
             LV_SCHED_BARRIER();                                // all eight fragment reads in flight before the first MFMA (left alone the
                                                                // compiler reads each one right before its eight MFMAs, behind lgkmcnt(0))
+            if constexpr (LV_P16_ABL & 1) {
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{abl_u2f(bfr[nb].x), abl_u2f(bfr[nb].y), 0.f, 0.f};
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             LV_MFMA_DRAIN();
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) LV_MFMA_RESULT(acc[nb]);
+            }
             // D: lane (c = l & 15: batch row, rq = l >> 4) holds gate columns 16 nb + 4 rq + r = the (i, f, g, o) of unit 4 nb + rq
             if ((l & 15) < RP) {
                 f32x4* rd = sm.red[t & 1][w][l & 15];
@@ -315,6 +342,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 for (int nb = 0; nb < 8; ++nb) rd[4 * nb + kq] = acc[nb];
             }
             LV_TRACE_MARK(t, 3);
+            if (!(LV_P16_ABL & 8))
             __syncthreads();                                   // the four quarter products (double-buffered by step parity); compiles to
                                                                // lgkmcnt(0) + s_barrier: the block loads issued above stay in flight
             LV_TRACE_MARK(t, 4);
@@ -328,12 +356,14 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     const f32x4 q0 = sm.red[t & 1][0][prow[q]][uw], q1 = sm.red[t & 1][1][prow[q]][uw];
                     const f32x4 q2 = sm.red[t & 1][2][prow[q]][uw], q3 = sm.red[t & 1][3][prow[q]][uw];
                     const float4 gxv = gxb[q][s2];
-                    const float ig = lv_sigmoid_fast(gxv.x + ((q0[0] + q1[0]) + (q2[0] + q3[0])));
-                    const float fg = lv_sigmoid_fast(gxv.y + ((q0[1] + q1[1]) + (q2[1] + q3[1])));
-                    const float gg = lv_tanh_fast(gxv.z + ((q0[2] + q1[2]) + (q2[2] + q3[2])));
-                    const float og = lv_sigmoid_fast(gxv.w + ((q0[3] + q1[3]) + (q2[3] + q3[3])));
+                    auto sg_ = [](float x) { return (LV_P16_ABL & 4) ? 0.5f + 0.25f * x : lv_sigmoid_fast(x); };
+                    auto th_ = [](float x) { return (LV_P16_ABL & 4) ? 0.9f * x : lv_tanh_fast(x); };
+                    const float ig = sg_(gxv.x + ((q0[0] + q1[0]) + (q2[0] + q3[0])));
+                    const float fg = sg_(gxv.y + ((q0[1] + q1[1]) + (q2[1] + q3[1])));
+                    const float gg = th_(gxv.z + ((q0[2] + q1[2]) + (q2[2] + q3[2])));
+                    const float og = sg_(gxv.w + ((q0[3] + q1[3]) + (q2[3] + q3[3])));
                     const float c = fg * c_state[q] + ig * gg;
-                    h = og * lv_tanh_fast(c);
+                    h = og * th_(c);
                     c_state[q] = c;
                     recb[q][s2] = f32x4{ig, fg, gg, og};
                     cb[q][s2] = c; hb[q][s2] = h;
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     v[bt][j] = gran_load(src + (long)j * SLOTS + 16 * (h0 + bt));
-                    ok = ok && (uint32_t)(v[bt][j] >> 56) == want;
+                    if (!(LV_P16_ABL & 2)) ok = ok && (uint32_t)(v[bt][j] >> 56) == want;
                 }
             ok = __all(ok);
             if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
@@ -522,6 +552,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         if constexpr (NB > HB) {
             if (!receive_round(lv_const<HB>(), src, want, dh_rec)) return false;
         }
+        if constexpr (NB > 2 * HB) {                  // (LV_HB16 = 1 at 16 rows: four rounds; the shipped HB = 2 stops above)
+            if (!receive_round(lv_const<2 * HB>(), src, want, dh_rec)) return false;
+        }
+        if constexpr (NB > 3 * HB) {
+            if (!receive_round(lv_const<3 * HB>(), src, want, dh_rec)) return false;
+        }
         return true;
     };
     // multiply the dG image of step parity `par` with this wave's 256 output units and send phase k to their owners
@@ -538,6 +574,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         // of chunk n4 are merged, packed and stored (the weights are read from AGPRs by inline-assembly MFMAs, which the compiler
         // neither reorders nor guards: two accumulator sets, and one drain in front of the last chunk's reads).
         auto chunk_mfma = [&](int n4, f32x4 (&acc)[4]) {
+            if constexpr (LV_P16_ABL & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = f32x4{abl_u2f(bfr[j].x + n4), abl_u2f(bfr[j].y), 0.f, 0.f};
+                return;
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -612,7 +653,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                     float dh = (has_ext ? dhb[q][s2] : 0.f) + dh_rec[q];
                     if (t == T - 1 && p.dh_last) dh += p.dh_last[pidx[q]];
                     const float ig = recb[q][s2].x, fg = recb[q][s2].y, gg = recb[q][s2].z, og_ = recb[q][s2].w;
-                    const float tc = lv_tanh_fast(ctb[q][s2]);
+                    const float tc = (LV_P16_ABL & 4) ? 0.9f * ctb[q][s2] : lv_tanh_fast(ctb[q][s2]);
                     const float dc = dh * og_ * (1.f - tc * tc) + dc_rec[q];
                     const float d_o = dh * tc;
                     const float d_i = dc * gg, d_g = dc * ig, d_f = dc * ctb[q][s2 + 1];
@@ -636,6 +677,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             // (the first build loaded at the block boundary, i.e. in front of the next receive: 3.8 us per boundary at 16 rows).
             if (s2 == SBK - 1) load_block(t_hi - SBK);
             LV_TRACE_MARK(t, 2);
+            if (!(LV_P16_ABL & 8))
             __syncthreads();                    // the workgroup's dG image of this step (double-buffered by step parity); compiles to
                                                 // lgkmcnt(0) + s_barrier: the next block's loads stay in flight across it
             LV_TRACE_MARK(t, 3);

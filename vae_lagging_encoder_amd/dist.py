@@ -59,6 +59,22 @@ def init_from_env(backend=None, timeout_s=None, force=False, banner=False):
     return rank, local, world
 
 
+class _HostStaged(object):
+    """Handle of a collective on DEVICE tensors over gloo (ranks sharing a GPU: the functional-check layout of bench.py / the GPU
+    tests, never the product's): the tensors travel as host copies made by us -- one D2H before, one H2D in wait() -- instead of
+    through gloo's own CUDA path, whose chunked staging costs a device synchronisation per chunk; with four processes
+    time-slicing one GPU that turned a 66 MB all-reduce into 13 s per step (profiles/r06b_four_ranks_on_one_gpu.txt)."""
+
+    def __init__(self, work, back):
+        self.work, self.back = work, back           # back: [(device tensor, host tensor)] copied at wait()
+
+    def wait(self):
+        self.work.wait()
+        for dst, host in self.back:
+            dst.copy_(host)
+        return True
+
+
 class GradSync(object):
     """Gradient exchange of the data-parallel inner loop: mean over ranks of the flat gradient buffers of (encoder, decoder).
 
@@ -109,6 +125,8 @@ class GradSync(object):
         # flight beside an RCCL kernel.  Slower (nothing overlaps), and the fallback if the overlapped schedule misbehaves on
         # a transport it has not met.
         self.conservative = os.environ.get("LVAE_DP_CONSERVATIVE", "") not in ("", "0")
+        # gloo with device tensors (several ranks on one GPU): host-staged by us, see _HostStaged
+        self._stage = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self.decoder = decoder
         self._inv = None
         # per-slot state (slot = micro-batch slice of a step, trainer.micro_batches; slot 0 alone without gradient accumulation):
@@ -129,6 +147,28 @@ class GradSync(object):
             self.b16 = {}         # bf16 wire images of the flat gradient buffers (payload "bf16")
             self.shard16 = None
             self.shard = None
+
+    # ---- the three collectives of the schedule (RCCL: as they are; gloo + device tensors: host-staged) -------------------------
+    def _c_all_reduce(self, t, async_op=False):
+        if not (self._stage and t.is_cuda):
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        h = t.cpu()
+        w = _HostStaged(dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group, async_op=True), [(t, h)])
+        return w if async_op else w.wait() and None
+
+    def _c_reduce_scatter(self, dst, src, async_op=False):
+        if not (self._stage and src.is_cuda):
+            return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        hs, hd = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+        w = _HostStaged(dist.reduce_scatter_tensor(hd, hs, op=dist.ReduceOp.SUM, group=self.group, async_op=True), [(dst, hd)])
+        return w if async_op else w.wait() and None
+
+    def _c_all_gather(self, dst, src, async_op=False):
+        if not (self._stage and src.is_cuda):
+            return dist.all_gather_into_tensor(dst, src, group=self.group, async_op=async_op)
+        hs, hd = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+        w = _HostStaged(dist.all_gather_into_tensor(hd, hs, group=self.group, async_op=True), [(dst, hd)])
+        return w if async_op else w.wait() and None
 
     @property
     def _cur(self):
@@ -232,8 +272,8 @@ class GradSync(object):
         hi = flat.grad_padded.numel() if hi is None else hi
         if self.payload == "bf16":
             t16 = self._wire(flat, lo, hi)
-            return (dist.all_reduce(t16.view(torch.bfloat16), op=dist.ReduceOp.SUM, group=self.group, async_op=True), t16, lo, hi)
-        return (dist.all_reduce(flat.grad_padded[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, lo, hi)
+            return (self._c_all_reduce(t16.view(torch.bfloat16), async_op=True), t16, lo, hi)
+        return (self._c_all_reduce(flat.grad_padded[lo:hi], async_op=True), None, lo, hi)
 
     def _all_reduce_mean_finish(self, flat, started):
         h, t16, lo, hi = started
@@ -293,7 +333,7 @@ class GradSync(object):
         for j, u in enumerate(unique_ids):
             mine[j, 0, :u.numel()] = u
         ids_all = torch.empty(self.world, nb, cap, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(ids_all.view(-1), mine.view(-1), group=self.group)
+        self._c_all_gather(ids_all.view(-1), mine.view(-1))
         self.rows = dict(cap=cap, ni=int(ni), V=int(V), n_emb=int(n_emb), mine=mine,
                          ids_all=ids_all.permute(1, 0, 2).contiguous())      # [batch][rank][cap]
         return True
@@ -326,10 +366,10 @@ class GradSync(object):
         ids = R["mine"][j]                                   # [1][cap]: batch-first ids of the gather kernels (B = 1, T = cap)
         if bf:
             lib.lv_embed_gather_b16(P(enc_flat.grad), P(ids), cap, None, 1.0, cap, 1, ni, V, P(send), ni, None, 0, s)
-            h = dist.all_gather_into_tensor(recv.view(torch.bfloat16).view(-1), send.view(torch.bfloat16).view(-1), group=self.group, async_op=True)
+            h = self._c_all_gather(recv.view(torch.bfloat16).view(-1), send.view(torch.bfloat16).view(-1), async_op=True)
         else:
             lib.lv_embed_gather_f32(P(enc_flat.grad), P(ids), cap, None, 1.0, P(send), cap, 1, ni, V, s)
-            h = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group, async_op=True)
+            h = self._c_all_gather(recv.view(-1), send.view(-1), async_op=True)
         align = 1024 if bf else 4
         st.buckets.append((h, ("rows", j, recv), 0, R["n_emb"] // align * align))
 
@@ -364,7 +404,7 @@ class GradSync(object):
         # the same call on RCCL and on gloo (torch >= 2.10's gloo has reduce_scatter_tensor, bf16 included): the CPU tests
         # exercise the product's collective, not a substitute
         dst = st.shard16.view(torch.bfloat16) if bf else st.shard
-        return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return self._c_reduce_scatter(dst, src, async_op=async_op)
 
     def sync(self, enc_flat, dec_flat, update="encoder"):
         """Exchange the gradients of one step.  Returns None when both buffers now hold the global mean gradient, or a
@@ -445,7 +485,7 @@ class GradSync(object):
             lib.lv_sumsq_f32(P(total), n, P(self._ws), P(self._ss), 0, s)
             lib.lv_scale_f32(P(self._ss), 1, P(self._inv2), s)          # shard of the SUM -> shard of the mean
         with self._Phase(self, "scalar_allreduce", dev):
-            dist.all_reduce(self._ss, op=dist.ReduceOp.SUM, group=self.group)
+            self._c_all_reduce(self._ss)
         return self._ss
 
     def _start_encoder_rest(self, enc_flat):
