@@ -352,28 +352,45 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(const float* __restri
 // per-(q, c) totals of the per-block partials, all 256 threads cooperating: thread t sums float4 group t % (C/2) over blocks
 // t / (C/2), + 256/(C/2), ... (16 independent loads in flight per batch: a runtime-length load -> add loop would pay one L2
 // round trip per block), f64, fixed order; tot: 2*C doubles, scratch: 1024 doubles (LDS)
+#ifndef LV_BN_TOT_BATCH
+#define LV_BN_TOT_BATCH 8               // partial rows a thread has in flight per round trip.  Round 6 A/B on the Omniglot step (hipGraph,
+                                        // profiles/r06i_omniglot_bn_prologue_ab.txt): 4: 9 450, 6: 9 380, 8: 9 640, 12: 9 480, 16 (rounds 3-5): 9 500,
+                                        // 32: 9 250 img/s -- every workgroup of every apply launch re-reads ALL partial rows (27 MB per launch at
+                                        // 350 rows x 306 workgroups, more than the activation itself), and the tail batch's clamped dummy loads are
+                                        // part of that traffic: the batch length trades round trips against wasted loads.  Same sums, same order
+#endif
+#ifndef LV_BN_TOT_CLAMP_OWN
+#define LV_BN_TOT_CLAMP_OWN 0           // measurement knob: rows beyond nblk re-read the thread's OWN first row instead of row 0
+#endif
 __device__ __forceinline__ void bn_block_totals(const float* __restrict__ partial, int nblk, int C, double* tot, double* scratch) {
+    constexpr int NB = LV_BN_TOT_BATCH;
     const int tid = (int)threadIdx.x, npair = 2 * C, NF4 = C >> 1, nsub = 256 / NF4;
     const int pg = tid & (NF4 - 1), bsub = tid / NF4;
     const float4* p4 = reinterpret_cast<const float4*>(partial) + pg;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = bsub;
-    for (; b + 15 * nsub < nblk; b += 16 * nsub) {
-        float4 v[16];
+#ifdef LV_BN_TOT_WHATIF               // measurement knob: no statistics prologue at all (garbage results; the time is the point)
+    if (tid < npair) tot[tid] = tid < C ? 0.0 : (double)nblk;
+    __syncthreads();
+    return;
+#endif
+    for (; b + (NB - 1) * nsub < nblk; b += NB * nsub) {
+        float4 v[NB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p4[(long)(b + u * nsub) * NF4];
+        for (int u = 0; u < NB; ++u) v[u] = p4[(long)(b + u * nsub) * NF4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+        for (int u = 0; u < NB; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
     }
     {
-        float4 v[16];
+        float4 v[NB];
+        const int spare = LV_BN_TOT_CLAMP_OWN ? (bsub < nblk ? bsub : 0) : 0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {                 // unconditional loads from clamped indices (a load behind a condition is
-            const int bb = b + u * nsub;                // waited for right behind its issue: 16 round trips instead of one)
-            v[u] = p4[(long)(bb < nblk ? bb : 0) * NF4];
+        for (int u = 0; u < NB; ++u) {                 // unconditional loads from clamped indices (a load behind a condition is
+            const int bb = b + u * nsub;                // waited for right behind its issue: NB round trips instead of one)
+            v[u] = p4[(long)(bb < nblk ? bb : spare) * NF4];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < NB; ++u) {
             if (b + u * nsub < nblk) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
         }
     }
@@ -382,6 +399,21 @@ __device__ __forceinline__ void bn_block_totals(const float* __restrict__ partia
     __syncthreads();
     for (int t = tid; t < npair; t += 256) {
         double acc = 0.0;
+#ifdef LV_BN_TOT_L2_UNROLL            // measurement knob: the second level reads its nsub values before it adds them (same order)
+        if (nsub == 16) {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = scratch[(long)k * npair + t];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += v[k];
+        } else if (nsub == 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = scratch[(long)k * npair + t];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        } else
+#endif
         for (int k = 0; k < nsub; ++k) acc += scratch[(long)k * npair + t];
         tot[t] = acc;
     }
@@ -506,7 +538,22 @@ static inline int bn_v4_blocks(long P, int C) {
 }
 // float4 per thread of the apply kernels: every workgroup re-reads all the partials (nblk * 2C floats), so the wider layers
 // use fewer, fatter workgroups
-static inline int bn_v4_items(int C) { return C >= 64 ? 8 : 4; }
+#ifndef LV_BN_ITEMS_NARROW
+#define LV_BN_ITEMS_NARROW 4            // float4 per thread of the apply kernels at C < 64 / C >= 64 (2, 4, 8 or 16): measurement knobs
+#endif
+#ifndef LV_BN_ITEMS_WIDE
+#define LV_BN_ITEMS_WIDE 8
+#endif
+static inline int bn_v4_items(int C) { return C >= 64 ? LV_BN_ITEMS_WIDE : LV_BN_ITEMS_NARROW; }
+// launch an apply kernel template on its item count
+#define BN_APPLY_LAUNCH(KERN, n4, C, stream, ...)                                                                                     \
+    do {                                                                                                                              \
+        const int it_ = bn_v4_items(C);                                                                                               \
+        if (it_ == 16) LV_LAUNCH(KERN<16>, dim3(bn_v4_apply_grid((n4), 16)), dim3(256), 0, stream, __VA_ARGS__);                      \
+        else if (it_ == 8) LV_LAUNCH(KERN<8>, dim3(bn_v4_apply_grid((n4), 8)), dim3(256), 0, stream, __VA_ARGS__);                    \
+        else if (it_ == 2) LV_LAUNCH(KERN<2>, dim3(bn_v4_apply_grid((n4), 2)), dim3(256), 0, stream, __VA_ARGS__);                    \
+        else LV_LAUNCH(KERN<4>, dim3(bn_v4_apply_grid((n4), 4)), dim3(256), 0, stream, __VA_ARGS__);                                  \
+    } while (0)
 static inline unsigned bn_v4_apply_grid(long n4, int items) { return (unsigned)lv_cdiv(n4, 256L * items); }
 
 // rec[b] = -sum_pix x*log(p+eps) + (1-x)*log(1-p+eps), p = sigmoid(logit); one workgroup per image
@@ -691,12 +738,7 @@ extern "C" int lv_bn_fwd_f32(const float* x, const float* gamma, const float* be
         LV_LAUNCH((bn_reduce_v4_kernel<0>), dim3((unsigned)nb), dim3(256), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0,
                   (float*)nullptr, ws, P, C, nb);
-        if (bn_v4_items(C) == 8)
-            LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
-                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
-        else
-            LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)ws, nb, gamma,
-                      beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+        BN_APPLY_LAUNCH(bn_apply_fwd_v4_kernel, P * (C >> 2), C, stream, x, (const float*)ws, nb, gamma, beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
@@ -722,12 +764,7 @@ extern "C" int lv_bn_fwd_partials_f32(const float* x, const float* gamma, const 
     if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
     if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
-    if (bn_v4_items(C) == 8)
-        LV_LAUNCH(bn_apply_fwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
-                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
-    else
-        LV_LAUNCH(bn_apply_fwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, partial, nblk, gamma, beta, res,
-                  act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
+    BN_APPLY_LAUNCH(bn_apply_fwd_v4_kernel, P * (C >> 2), C, stream, x, partial, nblk, gamma, beta, res, act_elu, y, mean, invstd, run_mean, run_var, P, C, eps, momentum);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
@@ -745,12 +782,7 @@ extern "C" int lv_bn_bwd4_f32(const float* x, const float* dy, const float* dy2,
     if (bn_v4_ok(C) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dy3 | (uintptr_t)dy4 | (uintptr_t)y | (uintptr_t)dv | (uintptr_t)dx) & 15) == 0) {
         const int nb = bn_v4_blocks(P, C);
         LV_LAUNCH((bn_reduce_v4_kernel<1>), dim3((unsigned)nb), dim3(256), 0, stream, x, dy, dy2, dy3, dy4, y, mean, invstd, act_elu, dv, ws, P, C, nb);
-        if (bn_v4_items(C) == 8)
-            LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, (const float*)dv,
-                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
-        else
-            LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, (const float*)dv,
-                      (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+        BN_APPLY_LAUNCH(bn_apply_bwd_v4_kernel, P * (C >> 2), C, stream, x, (const float*)dv, (const float*)ws, nb, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
         LV_CHECK_LAUNCH();
         return LV_OK;
     }
@@ -776,12 +808,7 @@ extern "C" int lv_bn_bwd_apply_partials_f32(const float* x, const float* dv, con
     if (P <= 0 || C <= 0 || nblk <= 0 || nblk > BN_BLOCKS) return LV_ERR_SHAPE;
     if (!bn_v4_ok(C)) return LV_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)dv | (uintptr_t)dx | (uintptr_t)partial) & 15) != 0) return LV_ERR_ALIGN;
-    if (bn_v4_items(C) == 8)
-        LV_LAUNCH(bn_apply_bwd_v4_kernel<8>, dim3(bn_v4_apply_grid(P * (C >> 2), 8)), dim3(256), 0, stream, x, dv, partial, nblk, mean, invstd,
-                  gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
-    else
-        LV_LAUNCH(bn_apply_bwd_v4_kernel<4>, dim3(bn_v4_apply_grid(P * (C >> 2), 4)), dim3(256), 0, stream, x, dv, partial, nblk, mean, invstd,
-                  gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
+    BN_APPLY_LAUNCH(bn_apply_bwd_v4_kernel, P * (C >> 2), C, stream, x, dv, partial, nblk, mean, invstd, gamma, dgamma, dbeta, accumulate_param_grads, dx, P, C, 1.0f / (float)P);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }
