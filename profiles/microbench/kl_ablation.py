@@ -36,7 +36,7 @@ def main():
         noise = tuple(torch.from_numpy(fx[k]).to(dev) for k in ("eps", "mask_in", "mask_out"))
         kl_ref, rec_ref, loss_ref = (float(fx[k].sum()) for k in ("kl", "rec", "loss"))
 
-        def run(exact, pre_round=(), operands="bf16"):
+        def run(exact, pre_round=(), operands="bf16", gx_round=None):
             vae = TP._seeded_full_size_vae(fx, dev)
             with torch.no_grad():
                 for k in pre_round:
@@ -45,12 +45,15 @@ def main():
             tr = AggressiveTextTrainer(vae, lr=1.0, clip=5.0, precision="bf16")
             tr.enc.exact_forward = exact
             tr.enc.fwd_operands = operands
+            tr.enc.gx_round = gx_round
             tr.step(x, float(fx["kl_weight"]), noise=noise)
             st = tr.read_stats()
             return {"kl_rel": abs(st["kl_sum"] - kl_ref) / abs(kl_ref), "rec_rel": abs(st["rec_sum"] - rec_ref) / abs(rec_ref),
                     "loss_rel": abs(st["loss_sum"] - loss_ref) / abs(loss_ref), "kl_signed": (st["kl_sum"] - kl_ref) / abs(kl_ref)}
         rows = {
             "binary16 forward operands (the default since round 5: X, W_ih, W_hh, h hand-off as IEEE half)": run((), operands="f16"),
+            "binary16 forward operands + Gx rounded to binary16 before the recurrence (round 6: price of a 16-bit Gx image)": run((), operands="f16", gx_round="f16"),
+            "binary16 forward operands + Gx rounded to bf16 before the recurrence": run((), operands="f16", gx_round="bf16"),
             "bf16 configuration (all four roundings)": run(()),
             "exact input projection only (exact_forward = gx)": run(("gx",)),
             "exact recurrence only (exact_forward = rec)": run(("rec",)),

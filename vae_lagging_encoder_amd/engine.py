@@ -937,6 +937,11 @@ class LSTMEncoderEngine(object):
         else:
             _gemm(lib, s, 0, 1, T * B, 4 * H, ni, P(w.X), ni, P(v["lstm.weight_ih_l0"]), ni, P(w.Gx), 4 * H,
                   prec=self.precision, **biases)
+        gx_round = getattr(self, "gx_round", None)
+        if gx_round is not None and not split:
+            # MEASUREMENT ONLY (profiles/microbench/kl_ablation.py): what a 16-bit Gx image would cost the KL -- the f32 Gx rounded to
+            # binary16 / bf16 in place before the recurrence reads it (never set by the product)
+            w.Gx.copy_(w.Gx.to(torch.float16 if gx_round == "f16" else torch.bfloat16).to(torch.float32))
         if split:
             pass
         elif "rec" in exact:
