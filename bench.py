@@ -850,6 +850,10 @@ def main():
                 # idle (8 records per step around the four recurrences), and a quarter of the launches estimates their average
                 if prof is not None:
                     engine.PROFILE = prof if i % EVENT_EVERY == 0 else None
+                if sync is not None:
+                    # ... and the exchange phases' events (8-10 records per step) on those steps only: every record is ~5 us of queue
+                    # idle, i.e. ~45 us of a data-parallel step if taken everywhere (breakdown() averages over the bracketed steps)
+                    sync.profile = (i % EVENT_EVERY == 0)
                 one_step()
                 if (i + 1) % 15 == 0:
                     window_stats.append(tr.read_stats())       # the loop's host read per 15-iteration window (text.py:393-396)
@@ -880,7 +884,7 @@ def main():
         engine.PROFILE = prof
         engine.PROFILE_PREFIX = "lstm_"
     if sync is not None:
-        sync.profile = True                                  # HIP events around the phases of the gradient exchange
+        sync.profile = stress                                # HIP events around the phases of the gradient exchange (text loop: every EVENT_EVERY-th step)
     tr.reset_stats()
     dsync()
     t0 = time.perf_counter()

@@ -44,10 +44,10 @@ def init_from_env(backend=None, timeout_s=None, force=False, banner=False):
             torch.cuda.set_device(local)
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local)
-                # RCCL's own warnings (topology, transport fallbacks) -- on STDERR: its default sink is stdout, where the version
-                # banner would land behind a caller's result line
+                # RCCL's own warnings (topology, transport fallbacks).  Its sink is STDOUT (version banner included, buffered until exit):
+                # a caller that owns a one-line stdout contract points fd 1 elsewhere first (bench.protect_stdout); NCCL_DEBUG_FILE is
+                # deliberately not set -- RCCL opens it with "w", and /dev/stderr of a redirected job is a file every rank would truncate
                 os.environ.setdefault("NCCL_DEBUG", "WARN")
-                os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if banner:
