@@ -207,6 +207,30 @@ def test_bench_gpus_4_completes_on_the_emulator_over_gloo(n):
     assert out["launch"] == {"attempt": 1, "schedule": "default", "failed_attempts": []}
 
 
+def test_the_drivers_torchrun_command_end_to_end_on_the_emulator():
+    """The round driver's multi-GPU form, literally: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- here on the CPU emulator over gloo (LVAE_BENCH_EMU test hook).
+    Every launcher child becomes the supervisor of its own rank (attempt 0 on the launcher's own rendezvous / agent store); rank 0's
+    worker prints the one line."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU emulator leg")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(LVAE_BENCH_EMU="1", LVAE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "toy", "--dtype", "f32",
+                        "--pool", "4"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["launcher"] == "torch.distributed.run"
+    assert out["launch"]["attempt"] == 1 and out["dp_breakdown"]["replicas_identical"] is True
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_runs_end_to_end_on_this_box():
     """VERDICT r4 item 1, literally: `python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline` -> rc 0, one JSON line with
