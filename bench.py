@@ -80,7 +80,9 @@ def emit(out):
     """The one JSON line; a supervised rank 0 then tells its supervisor that the line is out (whatever teardown does)."""
     line = (json.dumps(out) + "\n").encode()
     if _RESULT_FD is not None:
-        os.write(_RESULT_FD, line)
+        view = memoryview(line)
+        while len(view):                        # (a pipe may take the line in pieces)
+            view = view[os.write(_RESULT_FD, view):]
     else:
         sys.stdout.write(line.decode())
         sys.stdout.flush()

@@ -18,6 +18,12 @@ python bench.py --dtype f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_y
 python bench.py --encoder-forward f32 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_kl_exact.json 2>/dev/null
 python bench.py --forward-operands bf16 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_bf16_forward_operands.json 2>/dev/null
 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_gpus2_selflaunch.json 2> $O/${TAG}_bench_gpus2_selflaunch.err
+# round 6: the other SCALE points on the shared device (host-staged gloo), the driver's torchrun form, and the exchange on a one-rank RCCL group
+python bench.py --gpus 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_gpus4_selflaunch.json 2> $O/${TAG}_bench_gpus4_selflaunch.err
+python bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_gpus8_selflaunch.json 2> $O/${TAG}_bench_gpus8_selflaunch.err
+LVAE_DIST_BACKEND=gloo LVAE_SHARED_GPU="2 ranks on 1 GPU (torchrun form)" python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29733 \
+  bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_gpus2_torchrun.json 2> $O/${TAG}_bench_gpus2_torchrun.err
+python bench.py --gpus 1 --force-dp --steps 30 --warmup 5 --no-cpu-baseline --no-side-runs > $O/${TAG}_bench_force_dp_rccl_one_rank.json 2> $O/${TAG}_bench_force_dp_rccl_one_rank.err
 # Omniglot (BASELINE.json configs[3]): the dtype is named explicitly (the decoder's convolutions are exact f32 in both modes;
 # --dtype only moves the encoder's im2col GEMMs) so that file names and the "dtype" field cannot disagree
 python bench.py --workload omniglot --dtype f32 --steps 30 --warmup 5 > $O/${TAG}_bench_omniglot_f32.json 2>/dev/null
@@ -50,6 +56,7 @@ rm -rf $O/prof_${TAG} $O/prof_omni_${TAG} $O/pmc_*_${TAG}
 cut -c1-400 $O/${TAG}_bench_default.json
 cut -c1-200 $O/${TAG}_bench_hipgraph.json $O/${TAG}_bench_yelp.json $O/${TAG}_bench_stress.json $O/${TAG}_bench_yahoo_f32.json
 cut -c1-200 $O/${TAG}_bench_kl_exact.json $O/${TAG}_bench_bf16_forward_operands.json $O/${TAG}_bench_gpus2_selflaunch.json; tail -2 $O/${TAG}_bench_gpus2_selflaunch.err
+cut -c1-160 $O/${TAG}_bench_gpus4_selflaunch.json $O/${TAG}_bench_gpus8_selflaunch.json $O/${TAG}_bench_gpus2_torchrun.json $O/${TAG}_bench_force_dp_rccl_one_rank.json; wc -l $O/${TAG}_bench_force_dp_rccl_one_rank.json
 cut -c1-200 $O/${TAG}_bench_omniglot_f32.json $O/${TAG}_bench_omniglot_f32_hipgraph.json $O/${TAG}_bench_omniglot_bf16_hipgraph.json
 head -8 $O/${TAG}_omniglot_kernel_stats.txt | cut -c1-170
 head -14 $O/${TAG}_bench_yahoo_bf16_kernel_stats.txt | cut -c1-170
