@@ -2,7 +2,9 @@
 //
 // The product build is hipcc --offload-arch=gfx950.  The single LV_EMU switch below exists only so
 // that the GPU-less CI can compile the same kernel sources with g++ against tests/emu/hip_emu.h
-// (a thread-level emulator used by the `-m "not gpu"` tests); no kernel file contains an #ifdef.
+// (a thread-level emulator used by the `-m "not gpu"` tests): no kernel file switches on the PLATFORM.  What the kernel files do
+// contain are `#ifndef LV_<KNOB>` defaults of measurement knobs (tile schedules, block lengths, the what-if builds of
+// profiles/microbench/): the product build defines none of them, the probes build variant libraries with -D.
 #pragma once
 
 #ifdef LV_EMU
