@@ -1,6 +1,8 @@
 """Soak test (measurement tooling): many aggressive inner steps on batches of varying shape (B <= 32, T <= 200) through the
 persistent LSTM launches, checking the finiteness of the loss and, at the end, that no step had to be replayed (ladder rung 0, no recoveries); prints steps/s.
-usage (GPU box): python profiles/microbench/soak_persistent.py [steps] [max batch] [exact]"""
+usage (GPU box): python profiles/microbench/soak_persistent.py [steps] [max batch] [exact | dp]
+dp (round 6): the same soak with the data-parallel exchange FORCED ON over a one-rank RCCL process group (GradSync(force=True)): every
+step issues its asynchronous bf16 all-reduces / reduce-scatter from inside the encoder backward, RCCL's stream beside the persistent launches."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -14,7 +16,14 @@ dev = torch.device("cuda:0")
 V = 20001
 vae = build_text_vae(V, 512, 1024, 32, dev, seed=3)
 EXACT = len(sys.argv) > 3 and sys.argv[3] == "exact"           # the encoder's two-pass exact forward (two forward launches in a row)
-tr = AggressiveTextTrainer(vae, lr=0.05, clip=5.0, precision="bf16", seed=11, encoder_forward="f32" if EXACT else None)
+DP = len(sys.argv) > 3 and sys.argv[3] == "dp"
+gs = None
+if DP:
+    from vae_lagging_encoder_amd import dist as lvdist
+    os.environ.setdefault("MASTER_PORT", "29577")
+    lvdist.init_from_env(force=True, banner=True)
+    gs = lvdist.GradSync(mode="strict", force=True)
+tr = AggressiveTextTrainer(vae, lr=0.05, clip=5.0, precision="bf16", seed=11, encoder_forward="f32" if EXACT else None, grad_sync=gs)
 rs = np.random.RandomState(5)
 t0 = time.time()
 shapes = set()
@@ -32,6 +41,9 @@ torch.cuda.synchronize()
 from vae_lagging_encoder_amd import engine
 print("ladder rung at the end: enc %d / dec %d (0 = XCD-local hand-off), recoveries %d, status words %s / %s" % (
     engine.persist_rung(tr.enc), engine.persist_rung(tr.dec), tr.recoveries, tr.enc.status.tolist(), tr.dec.status.tolist()))
+if DP:
+    import torch.distributed as dist
+    print("data-parallel exchange forced on: backend %s, payload %s" % (dist.get_backend(), gs.payload))
 print("soak ok: %d steps, %d distinct (B, T) shapes, %.1f steps/s, peak device memory %.1f GB (workspace caches: enc %.1f GB / %d shapes"
       ", dec %.1f GB / %d shapes)" % (steps, len(shapes), steps / (time.time() - t0), torch.cuda.max_memory_allocated() / 1e9,
                                       tr.enc.wsc.total / 1e9, len(tr.enc.wsc.cache), tr.dec.wsc.total / 1e9, len(tr.dec.wsc.cache)))

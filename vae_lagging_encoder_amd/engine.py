@@ -129,7 +129,7 @@ class FlatBuffer(object):
         try:
             node = torch.autograd.graph.get_gradient_edge(p).node
             return bool(torch._C._will_engine_execute_node(node))
-        except RuntimeError:
+        except (RuntimeError, AttributeError):        # autograd.grad mode -- or a torch without these hooks: hand out real tensors
             return None
 
     def deliver_grads(self):
