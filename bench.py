@@ -611,6 +611,10 @@ def supervise(n, my_ranks, base_env, deadline_s, attempts, port_for_attempt, mar
                 time.sleep(0.2)
     if os.path.exists(marker):
         return 0
+    if not print_error and len(my_ranks) < n:
+        # a supervisor per rank (torchrun): the launcher stops everybody as soon as ONE child reports failure -- rank 0's supervisor
+        # must get its error line out first
+        time.sleep(3.0)
     if print_error:
         print(json.dumps({"error": "every launch attempt failed", "metric": "aggressive-loop seqs/sec", "value": None, "unit": "seq/s",
                           "n_gpus": n, "attempts": history,
