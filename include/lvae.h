@@ -64,6 +64,19 @@ int lv_gemm_b16(int transA, int M, int N, int K, float alpha,
 int lv_gemm_b16_dual_supported(int M, int N, int K, long ws_floats);
 int lv_gemm_b16_dual(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
                      float* C1, long ldc1, int nsplit, float* C2, long ldc2, float* ws, long ws_floats, void* stream);
+/* TWO independent products in ONE launch of one workgroup per CU: C0 (| C0b) = op(A0) . B0^T and C1 = A1 . B1^T (operands, layouts and
+ * alignment as lv_gemm_b16; plain outputs; nsplit0 > 0: columns >= nsplit0 of the first product go to C0b as in lv_gemm_b16_dual; the
+ * second product is in the transA = 0 form; M1 == 0: one product).  The backward of one nn.LSTM layer's input side (enc_lstm.py:55 /
+ * dec_lstm.py:104 under autograd): [dW_ih | dW_hh] = dG^T [X ; h_prev] and dX = dG . W_ih, which as single launches leave 256 x 256 tiles
+ * for 96 and 50 of the 256 CUs.  Both products run on the 256 x 256 quadrant K loop; a tile whose K range is shared between workgroups
+ * is summed INSIDE the launch by whichever of them arrives last, in K order (deterministic; no reduction launch, nobody waits).
+ * lv_gemm_b16_pair_supported: 1 where that is possible AND worth it (both products present, >= 8 K tiles per workgroup), else 0; the
+ * entry itself only refuses the impossible (LV_ERR_UNSUPPORTED: second product transposed, > 1024 tiles, ws_floats < 2 * 256 * 65536). */
+int lv_gemm_b16_pair_supported(int transA0, int M0, int N0, int K0, int transA1, int M1, int N1, int K1, long ws_floats);
+int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint16_t* A0, long lda0, const uint16_t* B0, long ldb0,
+                     float* C0, long ldc0, int nsplit0, float* C0b, long ldc0b,
+                     int transA1, int M1, int N1, int K1, const uint16_t* A1, long lda1, const uint16_t* B1, long ldb1,
+                     float* C1, long ldc1, float* ws, long ws_floats, void* stream);
 /* C [M][N] = (A . B^T) * (keep ? kscale : 0): lv_gemm_b16 (transA = 0, plain output, ldc = N) with the backward of nn.Dropout on the
  * LSTM output (dec_lstm.py:106; dO = dlogits . W_pred then masked) applied in the product's reduction stage instead of by a pass of
  * its own; rows time-major (r = t * Bsz + b), keep = the reference-layout mask [Bsz][M / Bsz][N], uint8. */

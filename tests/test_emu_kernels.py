@@ -234,6 +234,13 @@ def test_gemm_b16_dual_emulated(emu_backend, M, N, K_, nsplit):
     K.test_gemm_b16_dual(emu_backend, CPU, M, N, K_, nsplit)
 
 
+@pytest.mark.parametrize("shape", [(1, 300, 520, 200, 264, 260, 100, 500), (0, 300, 270, 330, 0, 0, 0, 0)])
+def test_gemm_b16_pair_emulated(emu_backend, shape):
+    """the grouped stream-K launch on the emulator: workgroups run one after the other there, so the LAST one of a tile to run finds
+    every slab and does the sum -- the same code path as the last arriver on the GPU"""
+    K.test_gemm_b16_pair(emu_backend, CPU, *shape)
+
+
 @pytest.mark.parametrize("M,N,K_,acc", [(130, 140, 96, 0), (64, 64, 72, 1)])
 def test_gemm_h16_emulated(emu_backend, M, N, K_, acc):
     K.test_gemm_h16(emu_backend, CPU, M, N, K_, acc)

@@ -737,6 +737,73 @@ def test_gemm_b16_dual(lib, hip_device, M, N, K, nsplit):
     assert float((got - ref).abs().max()) < 3e-5 * float(ref.abs().max()) * max(1.0, (K / 1000) ** 0.5)
 
 
+def _b16_image(lib, dev, X, rows, cols):
+    ld = (cols + 7) // 8 * 8
+    img = torch.zeros(rows, ld, dtype=torch.int16, device=dev)
+    lib.lv_cvt_bf16_f32(P(X), cols, rows, cols, P(img), ld, None, 0, _s(dev))
+    return img, ld
+
+
+PAIR_SHAPES = [
+    # (transA0, M0, N0, K0, nsplit0, M1, N1, K1)
+    (1, 4096, 1536, 6400, 512, 6400, 512, 4096),        # the Yahoo bench shape: [dW_ih | dW_hh] + dX of one LSTM layer
+    (1, 4096, 1536, 3200, 512, 3200, 512, 4096),        # Yelp
+    (1, 300, 520, 200, 264, 260, 100, 500),             # ragged everywhere, ragged K tiles, most workgroups idle
+    (0, 700, 300, 1000, 0, 0, 0, 0),                    # one product, NT, stream-K over all 256 workgroups
+    (1, 513, 257, 1111, 0, 0, 0, 0),                    # one product, TN
+]
+
+
+@pytest.mark.parametrize("tA0,M0,N0,K0,nsplit,M1,N1,K1", PAIR_SHAPES)
+def test_gemm_b16_pair(lib, hip_device, tA0, M0, N0, K0, nsplit, M1, N1, K1):
+    """lv_gemm_b16_pair: two independent products in one grouped stream-K launch (tiles shared between workgroups are summed inside
+    the launch by the last arriver, in K order): both against the float64 product of the bf16-rounded operands, padding of every
+    destination untouched, and -- the point of the in-launch hand-off -- a second and third launch over the same workspace
+    (arrival counters back at zero, stale slabs in the caller's L1 / L2) bit-identical to the first."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(M0 + N0 + K0 + M1)
+    A0 = (torch.randn(K0, M0, generator=g) * 0.2) if tA0 else (torch.randn(M0, K0, generator=g) * 0.2)
+    B0 = torch.randn(N0, K0, generator=g) * 0.2
+    A0i, lda0 = _b16_image(lib, dev, A0.to(dev), *A0.shape)
+    B0i, ldb0 = _b16_image(lib, dev, B0.to(dev), N0, K0)
+    two = M1 > 0
+    if two:
+        A1 = torch.randn(M1, K1, generator=g) * 0.2
+        B1 = torch.randn(N1, K1, generator=g) * 0.2
+        A1i, lda1 = _b16_image(lib, dev, A1.to(dev), M1, K1)
+        B1i, ldb1 = _b16_image(lib, dev, B1.to(dev), N1, K1)
+    ws = torch.full((2 * 256 * 65536 + 64,), float("nan"), device=dev)
+    n0a = nsplit if nsplit > 0 else N0
+    ld0, ld0b, ld1 = n0a + 12, max(N0 - nsplit, 1) + 4, N1 + 8
+
+    def run():
+        C0 = torch.full((M0, ld0), 7.0, device=dev)
+        C0b = torch.full((M0, ld0b), 7.0, device=dev)
+        C1 = torch.full((max(M1, 1), ld1), 7.0, device=dev)
+        lib.lv_gemm_b16_pair(tA0, M0, N0, K0, P(A0i), lda0, P(B0i), ldb0, P(C0), ld0, nsplit, P(C0b) if nsplit > 0 else None, ld0b,
+                             0, M1, N1, K1, P(A1i) if two else None, lda1 if two else 0, P(B1i) if two else None, ldb1 if two else 0,
+                             P(C1) if two else None, ld1, P(ws), ws.numel(), _s(dev))
+        return C0.cpu(), C0b.cpu(), C1.cpu()
+
+    C0, C0b, C1 = run()
+    a0 = A0.to(torch.bfloat16).double()
+    ref0 = (a0.t() if tA0 else a0) @ B0.to(torch.bfloat16).double().t()
+    got0 = torch.cat([C0[:, :n0a], C0b[:, :N0 - nsplit]], 1).double() if nsplit > 0 else C0[:, :N0].double()
+    assert float((got0 - ref0).abs().max()) < 3e-5 * float(ref0.abs().max()) * max(1.0, (K0 / 1000) ** 0.5)
+    assert bool((C0[:, n0a:] == 7.0).all())
+    if nsplit > 0:
+        assert bool((C0b[:, N0 - nsplit:] == 7.0).all())
+    else:
+        assert bool((C0b == 7.0).all())
+    if two:
+        ref1 = A1.to(torch.bfloat16).double() @ B1.to(torch.bfloat16).double().t()
+        assert float((C1[:, :N1].double() - ref1).abs().max()) < 3e-5 * float(ref1.abs().max()) * max(1.0, (K1 / 1000) ** 0.5)
+        assert bool((C1[:, N1:] == 7.0).all())
+    for _ in range(2):
+        D0, D0b, D1 = run()
+        assert torch.equal(D0, C0) and torch.equal(D0b, C0b) and torch.equal(D1, C1)
+
+
 @pytest.mark.parametrize("M,N,K,acc", [(130, 140, 96, 0), (256, 128, 512, 0), (64, 64, 72, 1), (200, 4096, 544, 0), (6400, 512, 4096, 0)])
 def test_gemm_h16(lib, hip_device, M, N, K, acc):
     """lv_gemm_h16: C = A . B^T (+ row-cyclic addend, accumulate) on binary16 operand images, f32 accumulation: against the

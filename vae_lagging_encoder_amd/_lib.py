@@ -25,6 +25,9 @@ SIGNATURES = {
     "lv_gemm_h16": [_i, _i, _i, _f, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp],
     "lv_gemm_b16_dual_supported": [_i, _i, _i, _l],
     "lv_gemm_b16_dual": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
+    "lv_gemm_b16_pair_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _l],
+    "lv_gemm_b16_pair": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l,
+                         _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp],
     "lv_gemm_b16_keep": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _vp, _l, _vp],
     "lv_gemm_b16_sumsq_parts": [_i, _i, _i, _l],
     "lv_gemm_b16_sumsq": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp],
@@ -188,7 +191,7 @@ class Lib(object):
         if missing:
             raise LvaeError("%s does not export: %s" % (path, ", ".join(missing)))
         # functions that return a value rather than a status
-        self._value_fns = {"lv_gemm_b16_dual_supported", "lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_gemm_b16_sumsq_parts", "lv_embed_scatter_sumsq_parts", "lv_conv32_wpack_floats",
+        self._value_fns = {"lv_gemm_b16_dual_supported", "lv_gemm_b16_pair_supported", "lv_lstm_bwd_ksplit", "lv_dec_tail_parts", "lv_gemm_b16_nll_parts", "lv_gemm_b16_sumsq_parts", "lv_embed_scatter_sumsq_parts", "lv_conv32_wpack_floats",
                            "lv_conv32_wgrad_slabs", "lv_conv32_wgrad_ws_floats", "lv_conv32_wgrad_parts", "lv_conv1x1_wgrad_parts", "lv_conv32_blocks", "lv_conv1x1_blocks", "lv_conv1x1_wgrad_ws_floats", "lv_sumsq_workspace_floats", "lv_lstm_ws_floats", "lv_bn_workspace_floats",
                            "lv_lstm_persist16_wpk_floats", "lv_lstm_persist16_xch_floats", "lv_lstm_persist16_saved_floats",
                            "lv_pixelcnn_net_words", "lv_pixelcnn_block_words", "lv_conv32_tap_split"}

@@ -42,6 +42,10 @@ static inline void lv_glds16(const void* g, void* lds_wave_base) { memcpy((char*
 static inline void lv_glds16_uncounted(const void* g, void* lds_wave_base) { lv_glds16(g, lds_wave_base); }
 #define LV_WAIT_VMEM() do { } while (0)
 #define LV_WAIT_VMEM_N(n) do { } while (0)
+// in-launch hand-off of a slab to whichever workgroup arrives last (grouped stream-K GEMM): write-through payload store, agent acquire
+static inline void lv_store_wt_f4(float4* p, float4 v) { *p = v; }
+static inline void lv_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 #define LV_S_BARRIER() __syncthreads()      // a bare workgroup barrier (no counter waits attached); fibers: the same rendezvous
 #define LV_SETPRIO(n) do { } while (0)
 static inline uint2 lv_ds_read_tr16_b64(const void* lds_ptr) {            // lane map: see the HIP definition below
@@ -304,6 +308,17 @@ __device__ __forceinline__ void lv_glds16_uncounted(const void* g, void* lds_wav
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 #define LV_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// In-launch hand-off of a slab between workgroups (cdna_hip_programming.md Guideline 16, form R1): the payload leaves as 16-byte
+// WRITE-THROUGH stores (sc1: the bytes reach memory, no release fence needed; the s_nop keeps hipcc from reusing the data registers
+// before the store has read them), every storing wave drains them (LV_WAIT_VMEM: the statement is outside hipcc's counters), then a
+// workgroup barrier and ONE lane's agent-scope atomic; the consumer's one lane issues lv_acquire_agent() (drops this CU's stale L1
+// lines) behind its atomic, a workgroup barrier, then plain loads.
+typedef float lv_f32x4_wt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lv_store_wt_f4(float4* p, float4 v) {
+    const lv_f32x4_wt x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void lv_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // counted form: all but the newest n vector-memory operations of this wave have completed (n a literal)
 #define LV_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // s_barrier alone: __syncthreads() puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of it whenever anything is in flight -- for

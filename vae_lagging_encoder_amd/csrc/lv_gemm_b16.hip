@@ -1226,21 +1226,15 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256_kernel(GemmQ p, Tail256 
 // half 8 x 4, both B halves 2 x 4 x 4 = 64 (the k-step schedules: 24 / 48).  The LDS images of B and of a K-contiguous A are the
 // ones above (a half-tile is a set of whole 8-row DMA units); the M-contiguous A of the weight-gradient form is kept per half as
 // [64 k][16 slots of 16 B] (slot = (8 wm + m / 8) ^ 4 (k & 3): the swizzle stays inside the half).
-template <bool NLL, bool TN>
-__global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256 q) {
-    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
-    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
-
-    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
-    const int kt0 = pk.kt0, kt1 = pk.kt1;
-    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
-
-    const int t = (int)threadIdx.x;
-    const int l = t & 63, w = lv_wave_uniform(t >> 6);
+// The K loop of the quadrant schedule as a function of (tile origin, K-tile range): the kernel below runs it once per workgroup, the
+// grouped stream-K kernel (lv_gemm_b16_t256g_kernel) once per segment of a workgroup's unit range.  On return every wave has passed a
+// barrier behind its last read of the K tiles and no LDS-DMA is in flight: the four LDS buffers are free.
+template <bool TN>
+__device__ __forceinline__ void t256q_run(const GemmQ& p, int m0, int n0, int kt0, int kt1, f32x16 (&acc)[4][2], LdsTile2& As0, LdsTile2& Bs0,
+                                          LdsTile2& As1, LdsTile2& Bs1, int l, int w) {
     const int wm = w >> 2, wn = w & 3;
     const int li = l & 31, lh = l >> 5;
 
-    f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1444,7 +1438,165 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256
         __syncthreads();
     }
 #undef LV_Q_WAIT
-    t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, wm, wn, lh);
+}
+
+template <bool NLL, bool TN>
+__global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256 q) {
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
+
+    const T256Pick pk = t256_pick(p, q, (int)blockIdx.x);
+    const int m0 = pk.tm * BT2, n0 = pk.tn * BT2;
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = lv_wave_uniform(t >> 6);
+
+    f32x16 acc[4][2];
+    t256q_run<TN>(p, m0, n0, pk.kt0, pk.kt1, acc, As0, Bs0, As1, Bs1, l, w);
+    t256_epilogue<NLL>(p, q, acc, As0, Bs0, As1, Bs1, pk.tile, pk.piece, pk.tn, m0, n0, t, l, w >> 2, w & 3, l >> 5);
+}
+
+// ---- grouped stream-K launch over the quadrant K loop (round 6) ---------------------------------------------------------------
+// The LSTM-sized gradient products do not fill 256 CUs with 256 x 256 tiles (dW_ih | dW_hh as one product: 96 tiles; dX: 50), which
+// is why they ran on the 128 x 128 kernel (twice the L2 -> LDS bytes per flop) under split-K with a reduction launch each.  Here ONE
+// launch of exactly one workgroup per CU works on up to TWO independent products: product j owns `rows_j` of the 32 workgroup rows
+// (8 workgroups each, one per XCD), its tiles x K tiles are laid out as one line of UNITS in tile-major order, and logical workgroup s
+// of its 8 rows_j takes units [s U / n, (s + 1) U / n) -- a run of SEGMENTS (tile, K-tile range), each through t256q_run.  Where the
+// unit count per workgroup divides the K tiles of a tile the segments are aligned pieces (the weight gradients at the bench shapes:
+// two halves per tile, and an XCD's workgroups -- consecutive logical ids -- walk neighbouring tiles over the same K range, sharing
+// operand tiles in its L2); where it does not (dX on the rows that are left) a workgroup ends one tile and starts the next.
+// A segment that covers its tile's whole K range goes straight to C.  Any other is handed over inside the launch: the accumulators
+// leave as a 256 KB slab of write-through stores, one lane draws a ticket from the tile's arrival counter, and whichever workgroup
+// arrives LAST adds the tile's slabs in K order (its own included, read back: the order of the additions never depends on who is
+// last) and writes C.  Nobody waits for anybody: no residency or dispatch-order assumption, nothing to time out, and on a sequential
+// executor (the CI emulator) the last workgroup to run simply finds all slabs there.  The counters live in a zero-initialised device
+// array; the last arriver puts its counter back to zero, and concurrent launches take different slots of the array.
+constexpr int SK_SLOTS = 32;                 // launches that may hold arrival counters at the same time (round-robin)
+constexpr int SK_TILES = 1024;               // 256 x 256 tiles per launch, both products together
+__device__ unsigned lv_sk_arrivals[SK_SLOTS * SK_TILES];
+
+struct SkProb {
+    GemmQ q;              // operands, shape, tilesM / tilesN (256-tiles), C / ldc (+ C2 / ldc2 / nsplit: two destinations)
+    int rows;             // workgroup rows of the launch that work on this product (0: none); workgroups = 8 rows
+    int nk;               // K tiles
+    long units;           // tilesM * tilesN * nk
+    float* slabs;         // 2 slabs of 256 x 256 floats per workgroup: [2 s] the partial tile its range starts in, [2 s + 1] a later one
+    int cnt0;             // index of this product's first arrival counter (one per tile) in lv_sk_arrivals
+};
+struct GemmG { SkProb pr[2]; };
+
+// the workgroup whose unit range [s U / n, (s + 1) U / n) holds unit u
+__device__ __forceinline__ int sk_owner(long u, long units, int nwg) { return (int)(((u + 1) * nwg - 1) / units); }
+
+// a finished 256 x 256 tile -> C (columns >= nsplit of a two-destination product -> C2)
+__device__ __forceinline__ void sk_store_tile(const GemmQ& p, const f32x16 (&acc)[4][2], int m0, int n0, int l, int w) {
+    const int wm = w >> 2, wn = w & 3;
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (l & 31);
+            if (col >= p.N) continue;
+            const int rbase = m0 + wm * 128 + i2 * 32 + 4 * (l >> 5);
+            float* cb = (p.nsplit > 0 && col >= p.nsplit) ? p.C2 + (long)rbase * p.ldc2 + (col - p.nsplit) : p.C + (long)rbase * p.ldc + col;
+            const long ld = (p.nsplit > 0 && col >= p.nsplit) ? p.ldc2 : p.ldc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);
+                if (rbase + ro < p.M) cb[(long)ro * ld] = p.alpha * acc[i2][j][e];
+            }
+        }
+}
+
+template <bool TN>
+__device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, LdsTile2& Bs0, LdsTile2& As1, LdsTile2& Bs1, int t, int l, int w) {
+    const int nwg = 8 * P.rows;
+    const long u0 = (long)s * P.units / nwg, u1 = (long)(s + 1) * P.units / nwg;
+    const int first_tile = (int)(u0 / P.nk);
+    unsigned* const flag = reinterpret_cast<unsigned*>(&As0[0][0]);          // free between two segments (see t256q_run)
+    unsigned* const cnt = lv_sk_arrivals + P.cnt0;
+    for (long u = u0; u < u1;) {
+        const int tile = (int)(u / P.nk), kb = (int)(u - (long)tile * P.nk);
+        const long left = u1 - u;
+        const int ke = left < (long)(P.nk - kb) ? kb + (int)left : P.nk;
+        int tm, tn;
+        t256_tile_of(P.q, tile, tm, tn);
+        const int m0 = tm * BT2, n0 = tn * BT2;
+        f32x16 acc[4][2];
+        t256q_run<TN>(P.q, m0, n0, kb, ke, acc, As0, Bs0, As1, Bs1, l, w);
+        u += ke - kb;
+        bool done = kb == 0 && ke == P.nk;
+        if (!done) {
+            // hand the partial tile over: slab (element q of thread t at float4 slot (q / 4) * 512 + t: every store instruction of the
+            // workgroup is 8 KB contiguous), drained by every wave, then ONE ticket
+            float4* const mine = reinterpret_cast<float4*>(P.slabs + (2L * s + (tile != first_tile)) * (BT2 * BT2));
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        lv_store_wt_f4(mine + ((i2 * 2 + j) * 4 + a) * 512 + t,
+                                       make_float4(acc[i2][j][4 * a], acc[i2][j][4 * a + 1], acc[i2][j][4 * a + 2], acc[i2][j][4 * a + 3]));
+            LV_WAIT_VMEM();
+            __syncthreads();
+            const long t0 = (long)tile * P.nk;
+            const int c0 = sk_owner(t0, P.units, nwg), c1 = sk_owner(t0 + P.nk - 1, P.units, nwg);
+            if (t == 0) {
+                int others = 0;                            // contributors besides this one: the workgroups of [c0, c1] whose range is not empty
+                for (int c = c0; c <= c1; ++c) others += (long)c * P.units / nwg < (long)(c + 1) * P.units / nwg;
+                const unsigned before = atomicAdd(cnt + tile, 1u);
+                const bool last = before == (unsigned)(others - 1);
+                if (last) {
+                    atomicExch(cnt + tile, 0u);          // every other contributor has drawn its ticket: ready for the next launch
+                    lv_acquire_agent();
+                }
+                *flag = last ? 1u : 0u;
+            }
+            __syncthreads();
+            const bool last = lv_wave_uniform((int)*flag) != 0;
+            __syncthreads();                               // the flag's LDS word belongs to the next segment's first K tile again
+            if (last) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i2][j][e] = 0.f;
+                for (int c = c0; c <= c1; ++c) {           // K order: contributor c holds the K range right behind c - 1's
+                    const long cu0 = (long)c * P.units / nwg;
+                    if (cu0 == (long)(c + 1) * P.units / nwg) continue;          // (an empty range: fewer units than workgroups)
+                    const int cfirst = (int)(cu0 / P.nk);
+                    const float4* sl = reinterpret_cast<const float4*>(P.slabs + (2L * c + (tile != cfirst)) * (BT2 * BT2)) + t;
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float4 v[4];
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) v[a] = sl[((i2 * 2 + j) * 4 + a) * 512];
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) {
+                                acc[i2][j][4 * a] += v[a].x; acc[i2][j][4 * a + 1] += v[a].y;
+                                acc[i2][j][4 * a + 2] += v[a].z; acc[i2][j][4 * a + 3] += v[a].w;
+                            }
+                        }
+                }
+                done = true;
+            }
+        }
+        if (done) sk_store_tile(P.q, acc, m0, n0, l, w);
+    }
+}
+
+template <bool TN0, bool TN1>
+__global__ __launch_bounds__(512) void lv_gemm_b16_t256g_kernel(GemmG g) {
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
+    __shared__ __attribute__((aligned(1024))) LdsTile2 As1, Bs1;
+    const int t = (int)threadIdx.x;
+    const int l = t & 63, w = lv_wave_uniform(t >> 6);
+    const int bid = (int)blockIdx.x, xcd = bid % 8, row = bid / 8;           // (workgroup b runs on XCD b % 8: for L2 locality only)
+    if (row < g.pr[0].rows) sk_work<TN0>(g.pr[0], xcd * g.pr[0].rows + row, As0, Bs0, As1, Bs1, t, l, w);
+    else sk_work<TN1>(g.pr[1], xcd * g.pr[1].rows + (row - g.pr[0].rows), As0, Bs0, As1, Bs1, t, l, w);
 }
 
 // the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)
@@ -1813,6 +1965,86 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
     }
     LV_CHECK_LAUNCH();
     if (keep_pending) return lv_keep_scale_f32(C, keep, kscale, M / p.Bsz, p.Bsz, N, stream);
+    return LV_OK;
+}
+
+// ---- grouped stream-K launch (lv_gemm_b16_t256g_kernel): up to two independent products on one workgroup per CU ----------------
+// How the 32 workgroup rows are divided: the split that minimises the longer of the two unit runs per workgroup, with a 10 % handicap
+// on a first product whose runs are not whole aligned pieces of its tiles (its workgroups then share less in L2).
+static int sk_rows0(long U0, int nk0, long U1) {
+    if (U1 <= 0) return 32;
+    int best = 0;
+    double bestc = 0.;
+    for (int r0 = 1; r0 < 32; ++r0) {
+        const long n0 = 8L * r0, n1 = 8L * (32 - r0);
+        const long L0 = lv_cdiv(U0, n0), L1 = lv_cdiv(U1, n1);
+        double c = (double)(L0 > L1 ? L0 : L1);
+        if (U0 % n0 != 0 || nk0 % L0 != 0) c *= 1.1;
+        if (!best || c < bestc) { best = r0; bestc = c; }
+    }
+    return best;
+}
+static bool sk_fits32(int transA, int M, int N, int K, long lda, long ldb) {
+    const long ea = (long)(transA ? K : M) * lda + 64, eb = (long)N * ldb + 64;      // element offsets the K loop forms from A / B
+    return ea < (1L << 32) && eb < (1L << 32) && (transA ? K : M) < (1 << 30);
+}
+static long sk_ws_floats() { return 2L * 256 * BT2 * BT2; }
+
+// Possible: operands as lv_gemm_b16 asks, the second product (if any) in NT form, the workspace holds the slabs, the tiles fit the
+// arrival counters.  lv_gemm_b16_pair_supported adds "worth it": two products, big enough that a workgroup walks >= 8 K tiles.
+static bool sk_possible(int transA1, int M0, int N0, int K0, int M1, int N1, int K1, long ws_floats) {
+    if (!LV_B16_GLDS) return false;
+    if (M0 <= 0 || N0 <= 0 || K0 <= 0 || M1 < 0 || N1 < 0 || K1 < 0) return false;
+    const bool two = M1 > 0 && N1 > 0 && K1 > 0;
+    if (transA1 != 0 && two) return false;                                // instantiated: (TN | NT) + NT
+    const long t0 = (long)lv_cdiv(M0, BT2) * lv_cdiv(N0, BT2), t1 = two ? (long)lv_cdiv(M1, BT2) * lv_cdiv(N1, BT2) : 0;
+    return t0 + t1 <= SK_TILES && ws_floats >= sk_ws_floats();
+}
+extern "C" int lv_gemm_b16_pair_supported(int transA0, int M0, int N0, int K0, int transA1, int M1, int N1, int K1, long ws_floats) {
+    (void)transA0;
+    if (!sk_possible(transA1, M0, N0, K0, M1, N1, K1, ws_floats) || M1 <= 0 || N1 <= 0 || K1 <= 0) return 0;
+    const long U = (long)lv_cdiv(M0, BT2) * lv_cdiv(N0, BT2) * lv_cdiv(K0, BK) + (long)lv_cdiv(M1, BT2) * lv_cdiv(N1, BT2) * lv_cdiv(K1, BK);
+    return U >= 256L * 8;
+}
+
+// C0 (| C0b) = op(A0) . B0^T and C1 = A1 . B1^T in ONE launch (operands, layouts and alignment as lv_gemm_b16; plain outputs, no
+// addends; nsplit0 > 0: columns >= nsplit0 of the first product go to C0b [M0][ldc0b] as in lv_gemm_b16_dual).  M1 == 0: one product.
+extern "C" int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint16_t* A0, long lda0, const uint16_t* B0, long ldb0,
+                                float* C0, long ldc0, int nsplit0, float* C0b, long ldc0b,
+                                int transA1, int M1, int N1, int K1, const uint16_t* A1, long lda1, const uint16_t* B1, long ldb1,
+                                float* C1, long ldc1, float* ws, long ws_floats, void* stream) {
+    if (!sk_possible(transA1, M0, N0, K0, M1, N1, K1, ws_floats)) return LV_ERR_UNSUPPORTED;
+    const bool two = M1 > 0 && N1 > 0 && K1 > 0;
+    if (!A0 || !B0 || !C0 || !ws || (two && (!A1 || !B1 || !C1))) return LV_ERR_ARG;
+    if (nsplit0 < 0 || (nsplit0 > 0 && (!C0b || nsplit0 >= N0 || ldc0b < N0 - nsplit0))) return LV_ERR_ARG;
+    if (lda0 < (transA0 ? M0 : K0) || ldb0 < K0 || ldc0 < (nsplit0 > 0 ? nsplit0 : N0)) return LV_ERR_SHAPE;
+    if (two && (lda1 < K1 || ldb1 < K1 || ldc1 < N1)) return LV_ERR_SHAPE;
+    if (lda0 % 8 != 0 || ldb0 % 8 != 0 || ((((uintptr_t)A0) | ((uintptr_t)B0)) & 15) != 0) return LV_ERR_ALIGN;
+    if (two && (lda1 % 8 != 0 || ldb1 % 8 != 0 || ((((uintptr_t)A1) | ((uintptr_t)B1)) & 15) != 0)) return LV_ERR_ALIGN;
+    if ((((uintptr_t)ws) & 15) != 0) return LV_ERR_ALIGN;
+    if (!sk_fits32(transA0, M0, N0, K0, lda0, ldb0) || (two && !sk_fits32(0, M1, N1, K1, lda1, ldb1))) return LV_ERR_UNSUPPORTED;
+    static unsigned next_slot = 0;
+    const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % SK_SLOTS;
+    GemmG g{};
+    auto fill = [&](SkProb& P, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb, float* C, long ldc) {
+        P.q.A = A; P.q.B = B; P.q.C = C; P.q.M = M; P.q.N = N; P.q.K = K;
+        P.q.lda = lda; P.q.ldb = ldb; P.q.ldc = ldc; P.q.alpha = 1.f;
+        P.q.tilesM = lv_cdiv(M, BT2); P.q.tilesN = lv_cdiv(N, BT2);
+        P.nk = lv_cdiv(K, BK);
+        P.units = (long)P.q.tilesM * P.q.tilesN * P.nk;
+    };
+    fill(g.pr[0], M0, N0, K0, A0, lda0, B0, ldb0, C0, ldc0);
+    g.pr[0].q.C2 = nsplit0 > 0 ? C0b : nullptr; g.pr[0].q.ldc2 = ldc0b; g.pr[0].q.nsplit = nsplit0 > 0 ? nsplit0 : 0;
+    if (two) fill(g.pr[1], M1, N1, K1, A1, lda1, B1, ldb1, C1, ldc1);
+    g.pr[0].rows = sk_rows0(g.pr[0].units, g.pr[0].nk, two ? g.pr[1].units : 0);
+    g.pr[1].rows = 32 - g.pr[0].rows;
+    g.pr[0].slabs = ws;
+    g.pr[1].slabs = ws + 2L * 8 * g.pr[0].rows * (BT2 * BT2);
+    g.pr[0].cnt0 = (int)(slot * SK_TILES);
+    g.pr[1].cnt0 = g.pr[0].cnt0 + g.pr[0].q.tilesM * g.pr[0].q.tilesN;
+    if (transA0) LV_LAUNCH((lv_gemm_b16_t256g_kernel<true, false>), dim3(256), dim3(512), 0, stream, g);
+    else LV_LAUNCH((lv_gemm_b16_t256g_kernel<false, false>), dim3(256), dim3(512), 0, stream, g);
+    LV_CHECK_LAUNCH();
     return LV_OK;
 }
 

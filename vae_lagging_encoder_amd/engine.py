@@ -651,6 +651,9 @@ def _lstm_backward(eng, lib, s, img, w, dh_ext, dh_last, mask, scale, whh, dh0, 
 
 # dW_ih and dW_hh of an LSTM layer as one product where the shape allows (LVAE_DUAL_WGRAD=0: two products, for A/B measurements)
 DUAL_WGRAD = os.environ.get("LVAE_DUAL_WGRAD", "1") != "0"
+# ... and dX with them in one grouped stream-K launch on the 256 x 256 tile where the shapes are big enough (LVAE_PAIR_WGRAD=0: the
+# separate launches, for A/B measurements)
+PAIR_WGRAD = os.environ.get("LVAE_PAIR_WGRAD", "1") != "0"
 
 
 class _LstmImages(object):
@@ -721,11 +724,21 @@ class _LstmImages(object):
         TB, ni, H = self.TB, self.ni, self.H
         if dG is not None:
             lib.lv_cvt_bf16_f32(dG, 4 * H, TB, 4 * H, P(self.dG), 4 * H, None, 0, s)
+        wsd = ws if ws is not None else _gemm_ws(lib, s)
+        if PAIR_WGRAD and DUAL_WGRAD and lib.lv_gemm_b16_pair_supported(1, 4 * H, ni + H, TB, 0, TB, ni, 4 * H, wsd.numel()):
+            # all three products of the layer in ONE grouped launch on the 256 x 256 tile (lv_gemm_b16_pair): [dW_ih | dW_hh] on the
+            # share of the CUs its flops ask for, dX on the rest, tiles shared between workgroups summed inside the launch
+            lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
+            with _prof("gemm_bf16", 2.0 * 4 * H * (ni + H) * TB + 2.0 * TB * ni * 4 * H):
+                lib.lv_gemm_b16_pair(1, 4 * H, ni + H, TB, P(self.dG), 4 * H, P(self.XhT), self.ldr, gW_ih, ld_gw, ni, gW_hh, H,
+                                     0, TB, ni, 4 * H, P(self.dG), 4 * H, WT16, 4 * H, dX, ni, P(wsd), wsd.numel(), s)
+            if between is not None:
+                between()
+            return
         _gemm16(lib, s, 0, TB, ni, 4 * H, P(self.dG), 4 * H, WT16, 4 * H, dX, ni, ws=ws)
         if between is not None:
             between()
         lib.lv_cvt_bf16_f32(h_prev, H, TB, H, None, 0, P(self.hT), self.ldr, s)
-        wsd = ws if ws is not None else _gemm_ws(lib, s)
         if DUAL_WGRAD and ni % 4 == 0 and lib.lv_gemm_b16_dual_supported(4 * H, ni + H, TB, wsd.numel()):
             # both weight gradients as one product (N = ni + H columns, split between the two destinations in its reduction stage)
             with _prof("gemm_bf16", 2.0 * 4 * H * (ni + H) * TB):
