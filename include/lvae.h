@@ -69,8 +69,10 @@ int lv_gemm_b16_dual(int transA, int M, int N, int K, const uint16_t* A, long ld
  * second product is in the transA = 0 form; M1 == 0: one product).  The backward of one nn.LSTM layer's input side (enc_lstm.py:55 /
  * dec_lstm.py:104 under autograd): [dW_ih | dW_hh] = dG^T [X ; h_prev] and dX = dG . W_ih, which as single launches leave 256 x 256 tiles
  * for 96 and 50 of the 256 CUs.  Both products run on the 256 x 256 quadrant K loop; a tile whose K range is shared between workgroups
- * is summed INSIDE the launch by whichever of them arrives last, in K order (deterministic; no reduction launch, nobody waits).
- * lv_gemm_b16_pair_supported: 1 where that is possible AND worth it (both products present, >= 8 K tiles per workgroup), else 0; the
+ * is summed INSIDE the launch, in descending K order whoever does it (deterministic): by the workgroup that closes the tile's K range if
+ * it finds the others arrived (a bounded look; its own piece then never leaves its registers), else by whichever draws the last ticket
+ * (no reduction launch, no wait that progress depends on).
+ * lv_gemm_b16_pair_supported: 1 where that is possible AND worth it (both products present, >= 12 K tiles per workgroup), else 0; the
  * entry itself only refuses the impossible (LV_ERR_UNSUPPORTED: second product transposed, > 1024 tiles, ws_floats < 2 * 256 * 65536). */
 int lv_gemm_b16_pair_supported(int transA0, int M0, int N0, int K0, int transA1, int M1, int N1, int K1, long ws_floats);
 int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint16_t* A0, long lda0, const uint16_t* B0, long ldb0,

@@ -2,12 +2,14 @@
 as the separate launches (lv_gemm_b16 with its split-K reduce + lv_gemm_b16_dual with its reduce) against ONE grouped stream-K launch
 (lv_gemm_b16_pair), interleaved, at the bench shapes; plus a bit-identity soak of the in-launch hand-off while a second stream keeps
 some CUs busy (uneven load)."""
-import os, sys, torch
+import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vae_lagging_encoder_amd import _lib
 from vae_lagging_encoder_amd.engine import P, stream_ptr
 dev = torch.device("cuda:0")
 L = _lib.load()
+alts = [(os.path.basename(q).replace("liblvae_", "").replace(".so", ""), _lib.bind(ctypes.CDLL(q), q))
+        for q in os.environ.get("LVAE_PROBE_LIBS", "").split(",") if q]           # alternative builds (profiles/microbench/build_gemm_variant.sh)
 s = stream_ptr(dev)
 ws = torch.empty(1 << 26, device=dev)
 H, ni = 1024, 512
@@ -38,11 +40,17 @@ for name, TB in (("yahoo B=32 T=200", 6400), ("yelp B=32 T~100", 3200), ("stress
     dX = torch.empty(TB, ni, device=dev); gWi = torch.empty(4 * H, ni, device=dev); gWh = torch.empty(4 * H, H, device=dev)
     dX2 = torch.empty_like(dX); gWi2 = torch.empty_like(gWi); gWh2 = torch.empty_like(gWh)
 
+    dual_ok = L.lv_gemm_b16_dual_supported(4 * H, ni + H, TB, ws.numel())
+
     def old():
         L.lv_gemm_b16(0, TB, ni, 4 * H, 1.0, P(dG), 4 * H, P(WT), 4 * H, P(dX), ni, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
-        L.lv_gemm_b16_dual(1, 4 * H, ni + H, TB, P(dG), 4 * H, P(XhT), ldr, P(gWi), ni, ni, P(gWh), H, P(ws), ws.numel(), s)
+        if dual_ok:
+            L.lv_gemm_b16_dual(1, 4 * H, ni + H, TB, P(dG), 4 * H, P(XhT), ldr, P(gWi), ni, ni, P(gWh), H, P(ws), ws.numel(), s)
+        else:       # (the 256-tile route: two products, as the engine falls back)
+            L.lv_gemm_b16(1, 4 * H, ni, TB, 1.0, P(dG), 4 * H, P(XhT), ldr, P(gWi), ni, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
+            L.lv_gemm_b16(1, 4 * H, H, TB, 1.0, P(dG), 4 * H, P(XhT, ni * ldr), ldr, P(gWh), H, 0, None, 0, 1, None, 0, 1, P(ws), ws.numel(), s)
 
-    def new():
+    def new(L=L):
         L.lv_gemm_b16_pair(1, 4 * H, ni + H, TB, P(dG), 4 * H, P(XhT), ldr, P(gWi2), ni, ni, P(gWh2), H,
                            0, TB, ni, 4 * H, P(dG), 4 * H, P(WT), 4 * H, P(dX2), ni, P(ws), ws.numel(), s)
 
@@ -69,7 +77,26 @@ for name, TB in (("yahoo B=32 T=200", 6400), ("yelp B=32 T~100", 3200), ("stress
     for rep in range(3):
         a, b = med(old), med(new)
         c, d = med(new_dual_only), med(new_dx_only)
-        print("   separate %7.1f us %6.1f TF | pair %7.1f us %6.1f TF | pair(dual only) %7.1f us | pair(dX only) %7.1f us" % (a, gf / a * 1e3, b, gf / b * 1e3, c, d), flush=True)
+        line = "   separate %7.1f us %6.1f TF | pair %7.1f us %6.1f TF | pair(dual only) %7.1f us | pair(dX only) %7.1f us" % (a, gf / a * 1e3, b, gf / b * 1e3, c, d)
+        for nm, La in alts:
+            line += " | %s %7.1f us" % (nm, med(lambda: new(La)))
+        print(line, flush=True)
+
+# the two ways a tile can be summed give the same bits: the product build (the closing contributor usually finds the others arrived and
+# sums into its registers) against a build whose closing contributor never looks (LV_SK_SPIN=0: every piece travels, the last ticket sums)
+for nm, La in alts:
+    if "spin0" not in nm:
+        continue
+    TB = 6400
+    dG = b16(TB, 4 * H); XhT = b16(ni + H, TB); WT = b16(ni, 4 * H)
+    res = []
+    for lib in (L, La):
+        o = [torch.empty(TB, ni, device=dev), torch.empty(4 * H, ni, device=dev), torch.empty(4 * H, H, device=dev)]
+        lib.lv_gemm_b16_pair(1, 4 * H, ni + H, TB, P(dG), 4 * H, P(XhT), TB, P(o[1]), ni, ni, P(o[2]), H,
+                             0, TB, ni, 4 * H, P(dG), 4 * H, P(WT), 4 * H, P(o[0]), ni, P(ws), ws.numel(), s)
+        torch.cuda.synchronize()
+        res.append(o)
+    print("product build vs %s: bit-identical = %s" % (nm, all(torch.equal(a, b) for a, b in zip(*res))))
 
 # soak: the hand-off under uneven load -- a second stream runs a long, narrow kernel chain (a few CUs busy, the rest free), the
 # grouped launch runs 300 times; every result must be bit-identical to the first

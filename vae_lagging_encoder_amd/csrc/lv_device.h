@@ -45,6 +45,9 @@ static inline void lv_glds16_uncounted(const void* g, void* lds_wave_base) { lv_
 // in-launch hand-off of a slab to whichever workgroup arrives last (grouped stream-K GEMM): write-through payload store, agent acquire
 static inline void lv_store_wt_f4(float4* p, float4 v) { *p = v; }
 static inline void lv_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+static inline unsigned lv_agent_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+static inline void lv_sleep_short() { }
+#define LV_ARRIVAL_POLLS 2                  // bounded look for other workgroups' arrivals: they run one after the other here -- what has not arrived will not
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 #define LV_S_BARRIER() __syncthreads()      // a bare workgroup barrier (no counter waits attached); fibers: the same rendezvous
 #define LV_SETPRIO(n) do { } while (0)
@@ -319,6 +322,9 @@ __device__ __forceinline__ void lv_store_wt_f4(float4* p, float4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
 }
 __device__ __forceinline__ void lv_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ unsigned lv_agent_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lv_sleep_short() { __builtin_amdgcn_s_sleep(8); }
+#define LV_ARRIVAL_POLLS 64                 // bounded look for other workgroups' arrivals (~0.5-1 us per poll): never a condition of progress
 // counted form: all but the newest n vector-memory operations of this wave have completed (n a literal)
 #define LV_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // s_barrier alone: __syncthreads() puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of it whenever anything is in flight -- for

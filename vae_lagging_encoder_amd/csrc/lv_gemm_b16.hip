@@ -1470,6 +1470,15 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256
 // last) and writes C.  Nobody waits for anybody: no residency or dispatch-order assumption, nothing to time out, and on a sequential
 // executor (the CI emulator) the last workgroup to run simply finds all slabs there.  The counters live in a zero-initialised device
 // array; the last arriver puts its counter back to zero, and concurrent launches take different slots of the array.
+#ifndef LV_SK_ABL
+#define LV_SK_ABL 0       // measurement only (profiles/microbench/gemm_pair_probe.py; results are wrong): 1 = partial tiles are dropped (no slab, no ticket, no sum), 2 = no C stores
+#endif
+#ifndef LV_SK_SPIN
+#define LV_SK_SPIN LV_ARRIVAL_POLLS     // polls the closing contributor of a tile spends looking for the others before it hands its own piece over too; 0 = never
+#endif
+#ifndef LV_SK_ROWS0
+#define LV_SK_ROWS0 0     // measurement only: workgroup rows of the first product (0 = by the cost model)
+#endif
 constexpr int SK_SLOTS = 32;                 // launches that may hold arrival counters at the same time (round-robin)
 constexpr int SK_TILES = 1024;               // 256 x 256 tiles per launch, both products together
 __device__ unsigned lv_sk_arrivals[SK_SLOTS * SK_TILES];
@@ -1507,6 +1516,23 @@ __device__ __forceinline__ void sk_store_tile(const GemmQ& p, const f32x16 (&acc
         }
 }
 
+// acc += the slab at sl (this thread's 32 float4 of it), four float4 in flight at a time
+__device__ __forceinline__ void sk_add_slab(f32x16 (&acc)[4][2], const float4* sl) {
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 v[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = sl[((i2 * 2 + j) * 4 + a) * 512];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc[i2][j][4 * a] += v[a].x; acc[i2][j][4 * a + 1] += v[a].y;
+                acc[i2][j][4 * a + 2] += v[a].z; acc[i2][j][4 * a + 3] += v[a].w;
+            }
+        }
+}
+
 template <bool TN>
 __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, LdsTile2& Bs0, LdsTile2& As1, LdsTile2& Bs1, int t, int l, int w) {
     const int nwg = 8 * P.rows;
@@ -1514,77 +1540,97 @@ __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, L
     const int first_tile = (int)(u0 / P.nk);
     unsigned* const flag = reinterpret_cast<unsigned*>(&As0[0][0]);          // free between two segments (see t256q_run)
     unsigned* const cnt = lv_sk_arrivals + P.cnt0;
-    for (long u = u0; u < u1;) {
-        const int tile = (int)(u / P.nk), kb = (int)(u - (long)tile * P.nk);
-        const long left = u1 - u;
-        const int ke = left < (long)(P.nk - kb) ? kb + (int)left : P.nk;
+    // The segments of the range from its END: the piece of a tile this workgroup runs last is then the one that closes that tile's K
+    // range (every other contributor of the tile either ran its piece first, long ago, or finishes at the same time).
+    for (long e = u1; e > u0;) {
+        const int tile = (int)((e - 1) / P.nk);
+        const long t0 = (long)tile * P.nk;
+        const int ke = (int)(e - t0), kb = u0 > t0 ? (int)(u0 - t0) : 0;
+        e = t0 + kb;
         int tm, tn;
         t256_tile_of(P.q, tile, tm, tn);
         const int m0 = tm * BT2, n0 = tn * BT2;
         f32x16 acc[4][2];
         t256q_run<TN>(P.q, m0, n0, kb, ke, acc, As0, Bs0, As1, Bs1, l, w);
-        u += ke - kb;
         bool done = kb == 0 && ke == P.nk;
-        if (!done) {
-            // hand the partial tile over: slab (element q of thread t at float4 slot (q / 4) * 512 + t: every store instruction of the
-            // workgroup is 8 KB contiguous), drained by every wave, then ONE ticket
-            float4* const mine = reinterpret_cast<float4*>(P.slabs + (2L * s + (tile != first_tile)) * (BT2 * BT2));
-#pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        lv_store_wt_f4(mine + ((i2 * 2 + j) * 4 + a) * 512 + t,
-                                       make_float4(acc[i2][j][4 * a], acc[i2][j][4 * a + 1], acc[i2][j][4 * a + 2], acc[i2][j][4 * a + 3]));
-            LV_WAIT_VMEM();
-            __syncthreads();
-            const long t0 = (long)tile * P.nk;
+        if (!done && !(LV_SK_ABL & 1)) {
+            // ---- a partial tile: handed over inside the launch.  The tile's value is DEFINED as the sum of its pieces in descending K
+            // order, (((p_c1 + p_c1-1) + ...) + p_c0), whoever computes it.
             const int c0 = sk_owner(t0, P.units, nwg), c1 = sk_owner(t0 + P.nk - 1, P.units, nwg);
+            // (1) The contributor that closes the K range, on the last segment it runs, looks (for a bounded while: it has nothing
+            // else left to do) whether everybody else has arrived; if so it adds their slabs to its registers in that order and its own
+            // piece never travels.
             if (t == 0) {
-                int others = 0;                            // contributors besides this one: the workgroups of [c0, c1] whose range is not empty
+                int others = -1;                           // contributors besides this one: the workgroups of [c0, c1] whose range is not empty
                 for (int c = c0; c <= c1; ++c) others += (long)c * P.units / nwg < (long)(c + 1) * P.units / nwg;
-                const unsigned before = atomicAdd(cnt + tile, 1u);
-                const bool last = before == (unsigned)(others - 1);
-                if (last) {
-                    atomicExch(cnt + tile, 0u);          // every other contributor has drawn its ticket: ready for the next launch
-                    lv_acquire_agent();
+                unsigned role = 0;                         // 0: hand the piece over, 1: sum the others' into the registers
+                if (s == c1 && e == u0) {
+                    for (int spin = 0; spin < LV_SK_SPIN; ++spin) {
+                        if (lv_agent_load_u32(cnt + tile) == (unsigned)others) { role = 1; break; }
+                        lv_sleep_short();
+                    }
+                    if (role) {
+                        atomicExch(cnt + tile, 0u);        // nobody else touches it any more: ready for the next launch
+                        lv_acquire_agent();
+                    }
                 }
-                *flag = last ? 1u : 0u;
+                flag[0] = role; flag[1] = (unsigned)others;
             }
             __syncthreads();
-            const bool last = lv_wave_uniform((int)*flag) != 0;
-            __syncthreads();                               // the flag's LDS word belongs to the next segment's first K tile again
-            if (last) {
+            const bool closer = lv_wave_uniform((int)flag[0]) != 0;
+            const int others = lv_wave_uniform((int)flag[1]);
+            __syncthreads();
+            bool last = false;
+            if (!closer) {
+                // (2) Everybody else: the piece leaves as a slab (element q of thread t at float4 slot (q / 4) * 512 + t: every store
+                // instruction of the workgroup is 8 KB contiguous) of write-through stores, drained by every wave, then ONE ticket;
+                // whoever draws the last one reads all slabs back, its own included, in the defining order.
+                float4* const mine = reinterpret_cast<float4*>(P.slabs + (2L * s + (tile != first_tile)) * (BT2 * BT2));
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i2][j][e] = 0.f;
-                for (int c = c0; c <= c1; ++c) {           // K order: contributor c holds the K range right behind c - 1's
-                    const long cu0 = (long)c * P.units / nwg;
-                    if (cu0 == (long)(c + 1) * P.units / nwg) continue;          // (an empty range: fewer units than workgroups)
-                    const int cfirst = (int)(cu0 / P.nk);
-                    const float4* sl = reinterpret_cast<const float4*>(P.slabs + (2L * c + (tile != cfirst)) * (BT2 * BT2)) + t;
+                        for (int a = 0; a < 4; ++a)
+                            lv_store_wt_f4(mine + ((i2 * 2 + j) * 4 + a) * 512 + t,
+                                           make_float4(acc[i2][j][4 * a], acc[i2][j][4 * a + 1], acc[i2][j][4 * a + 2], acc[i2][j][4 * a + 3]));
+                LV_WAIT_VMEM();
+                __syncthreads();
+                if (t == 0) {
+                    const bool l0 = atomicAdd(cnt + tile, 1u) == (unsigned)others;
+                    if (l0) {
+                        atomicExch(cnt + tile, 0u);
+                        lv_acquire_agent();
+                    }
+                    flag[0] = l0 ? 1u : 0u;
+                }
+                __syncthreads();
+                last = lv_wave_uniform((int)flag[0]) != 0;
+                __syncthreads();                           // the flag's LDS words belong to the next segment's first K tile again
+                if (last) {
 #pragma unroll
                     for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            float4 v[4];
+                        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) v[a] = sl[((i2 * 2 + j) * 4 + a) * 512];
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                acc[i2][j][4 * a] += v[a].x; acc[i2][j][4 * a + 1] += v[a].y;
-                                acc[i2][j][4 * a + 2] += v[a].z; acc[i2][j][4 * a + 3] += v[a].w;
-                            }
-                        }
+                            for (int q = 0; q < 16; ++q) acc[i2][j][q] = 0.f;
                 }
-                done = true;
             }
+            const bool summed = closer || last;
+            if (summed) {                                  // p_c1 (in the registers, or read back first into zeroed ones), then c1 - 1 ... c0
+                for (int c = closer ? c1 - 1 : c1; c >= c0; --c) {
+                    const long cu0 = (long)c * P.units / nwg;
+                    if (cu0 == (long)(c + 1) * P.units / nwg) continue;          // (an empty range: fewer units than workgroups)
+                    sk_add_slab(acc, reinterpret_cast<const float4*>(P.slabs + (2L * c + (tile != (int)(cu0 / P.nk))) * (BT2 * BT2)) + t);
+                }
+            }
+            done = summed;
         }
+#if LV_SK_ABL & 2
+        if (done && acc[0][0][0] == 1.2345e-30f) sk_store_tile(P.q, acc, m0, n0, l, w);
+#else
         if (done) sk_store_tile(P.q, acc, m0, n0, l, w);
+#endif
     }
 }
 
@@ -1599,9 +1645,15 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256g_kernel(GemmG g) {
     else sk_work<TN1>(g.pr[1], xcd * g.pr[1].rows + (row - g.pr[0].rows), As0, Bs0, As1, Bs1, t, l, w);
 }
 
-// the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, 32 rows)
+// the K pieces of the tail tiles, added in piece order, + the epilogue; one workgroup per (tail tile, TR_ROWS rows).  TR_ROWS = 8 since
+// round 6 (32 before): a thread's row iterations are dependent memory round trips (4 pieces in flight each), and with 8 of them on
+// 480 workgroups the launch ran at 2 TB/s (dW_pred's: 31 us for 63 MB)
+#ifndef LV_TR_ROWS
+#define LV_TR_ROWS 8
+#endif
+constexpr int TR_ROWS = LV_TR_ROWS, TR_WGS = BT2 / TR_ROWS;
 __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 q) {
-    const int tile = q.full + (int)blockIdx.x / 8;
+    const int tile = q.full + (int)blockIdx.x / TR_WGS;
     int tm, tn;
     t256_tile_of(p, tile, tm, tn);
     const float* slab = p.ws + (long)(tile - q.full) * q.tail_s * (BT2 * BT2);
@@ -1611,8 +1663,8 @@ __global__ __launch_bounds__(256) void tail_reduce_t256_kernel(GemmQ p, Tail256 
     const bool fast = !p.add1 && !p.add2 && !p.accumulate && p.ldc % 4 == 0 && p.N % 4 == 0 && (((uintptr_t)p.C) & 15) == 0 &&
                       (((uintptr_t)p.keep) & 3) == 0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int rr = ((int)blockIdx.x % 8) * 32 + 4 * it + (t >> 6);
+    for (int it = 0; it < TR_ROWS / 4; ++it) {
+        const int rr = ((int)blockIdx.x % TR_WGS) * TR_ROWS + 4 * it + (t >> 6);
         const int row = tm * BT2 + rr;
         if (row >= p.M) continue;
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1915,7 +1967,7 @@ static int gemm_b16_launch(int tile, int transA, int M, int N, int K, float alph
             else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false, true>), grid, block, 0, stream, p, q);
         } else if (transA) LV_LAUNCH((lv_gemm_b16_t256_kernel<false, true>), grid, block, 0, stream, p, q);
         else LV_LAUNCH((lv_gemm_b16_t256_kernel<false, false>), grid, block, 0, stream, p, q);
-        if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * 8)), dim3(256), 0, stream, p, q);
+        if (q.tail_s > 1) LV_LAUNCH(tail_reduce_t256_kernel, dim3((unsigned)(tail * TR_WGS)), dim3(256), 0, stream, p, q);
         LV_CHECK_LAUNCH();
         if (keep_pending) return lv_keep_scale_f32(C, keep, kscale, M / p.Bsz, p.Bsz, N, stream);
         return LV_OK;
@@ -1991,7 +2043,7 @@ static bool sk_fits32(int transA, int M, int N, int K, long lda, long ldb) {
 static long sk_ws_floats() { return 2L * 256 * BT2 * BT2; }
 
 // Possible: operands as lv_gemm_b16 asks, the second product (if any) in NT form, the workspace holds the slabs, the tiles fit the
-// arrival counters.  lv_gemm_b16_pair_supported adds "worth it": two products, big enough that a workgroup walks >= 8 K tiles.
+// arrival counters.  lv_gemm_b16_pair_supported adds "worth it": two products, big enough that a workgroup walks >= 12 K tiles.
 static bool sk_possible(int transA1, int M0, int N0, int K0, int M1, int N1, int K1, long ws_floats) {
     if (!LV_B16_GLDS) return false;
     if (M0 <= 0 || N0 <= 0 || K0 <= 0 || M1 < 0 || N1 < 0 || K1 < 0) return false;
@@ -2003,8 +2055,10 @@ static bool sk_possible(int transA1, int M0, int N0, int K0, int M1, int N1, int
 extern "C" int lv_gemm_b16_pair_supported(int transA0, int M0, int N0, int K0, int transA1, int M1, int N1, int K1, long ws_floats) {
     (void)transA0;
     if (!sk_possible(transA1, M0, N0, K0, M1, N1, K1, ws_floats) || M1 <= 0 || N1 <= 0 || K1 <= 0) return 0;
+    // measured (profiles/r06o_gemm_pair_probe.txt; H = 1024, ni = 512; pair / separate launches): T*B = 6400 -> 110 / 156 us, 3200 -> 73 / 91,
+    // 25600 -> 385 / 506, 1600 -> 58 / 65 (13 K tiles per workgroup); below that the hand-off (~20 us) is no longer paid for
     const long U = (long)lv_cdiv(M0, BT2) * lv_cdiv(N0, BT2) * lv_cdiv(K0, BK) + (long)lv_cdiv(M1, BT2) * lv_cdiv(N1, BT2) * lv_cdiv(K1, BK);
-    return U >= 256L * 8;
+    return U >= 256L * 12;
 }
 
 // C0 (| C0b) = op(A0) . B0^T and C1 = A1 . B1^T in ONE launch (operands, layouts and alignment as lv_gemm_b16; plain outputs, no
@@ -2036,7 +2090,7 @@ extern "C" int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint1
     fill(g.pr[0], M0, N0, K0, A0, lda0, B0, ldb0, C0, ldc0);
     g.pr[0].q.C2 = nsplit0 > 0 ? C0b : nullptr; g.pr[0].q.ldc2 = ldc0b; g.pr[0].q.nsplit = nsplit0 > 0 ? nsplit0 : 0;
     if (two) fill(g.pr[1], M1, N1, K1, A1, lda1, B1, ldb1, C1, ldc1);
-    g.pr[0].rows = sk_rows0(g.pr[0].units, g.pr[0].nk, two ? g.pr[1].units : 0);
+    g.pr[0].rows = (LV_SK_ROWS0 > 0 && two) ? LV_SK_ROWS0 : sk_rows0(g.pr[0].units, g.pr[0].nk, two ? g.pr[1].units : 0);
     g.pr[1].rows = 32 - g.pr[0].rows;
     g.pr[0].slabs = ws;
     g.pr[1].slabs = ws + 2L * 8 * g.pr[0].rows * (BT2 * BT2);
@@ -2094,7 +2148,7 @@ extern "C" int lv_gemm_b16_sumsq_parts(int M, int N, int K, long ws_floats) {
     if (M <= 0 || N <= 0 || K <= 0 || !t256_wanted(0, M, N, K)) return 0;
     const long tiles = (long)lv_cdiv(M, BT2) * lv_cdiv(N, BT2);
     const Tail256 q = t256_plan(tiles, lv_cdiv(K, BK), ws_floats);
-    return (int)(tiles * 8 + (q.tail_s > 1 ? (long)q.tail * 32 : 0));
+    return (int)(tiles * 8 + (q.tail_s > 1 ? (long)q.tail * TR_WGS * 4 : 0));
 }
 
 extern "C" int lv_gemm_b16_sumsq(int transA, int M, int N, int K, const uint16_t* A, long lda, const uint16_t* B, long ldb,
