@@ -238,7 +238,7 @@ def text_rooflines(prof, steps, workload, dtype, B, T, H, peak_mfma):
     gemm = groups.get(gname, dict(ms=0.0, work=0.0, launches=0))
     gemm_tf = gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0
     gemm_roof = {
-        "bound": "mfma", "kernel": "lv_gemm_b16_t256_kernel (256x256x64, the three vocabulary-sized products) / lv_gemm_b16_nt_glds_kernel (128x128x64, the LSTM-sized ones)" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2),
+        "bound": "mfma", "kernel": "lv_gemm_b16_t256_kernel / _t256q_kernel (256x256x64, the three vocabulary-sized products) / lv_gemm_b16_t256g_kernel (the same K loop as one grouped stream-K launch per LSTM layer: dX + [dW_ih | dW_hh], tiles summed inside the launch) / lv_gemm_b16_nt_glds_kernel (128x128x64: the two input projections)" if args.dtype == "bf16" else "lv_gemm_f32_kernel", "achieved": round(gemm_tf, 2),
         "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(gemm_tf / peak_mfma, 4), "traffic": None,
         "launches_per_step": gemm["launches"] // args.steps, "ms_per_step": round(gemm["ms"] / args.steps, 4),
         "gflop_per_step": round(gemm["work"] / args.steps / 1e9, 1)}
