@@ -1476,6 +1476,9 @@ __global__ __launch_bounds__(512) void lv_gemm_b16_t256q_kernel(GemmQ p, Tail256
 #ifndef LV_SK_SPIN
 #define LV_SK_SPIN LV_ARRIVAL_POLLS     // polls the closing contributor of a tile spends looking for the others before it hands its own piece over too; 0 = never
 #endif
+#ifndef LV_SK_SKEW
+#define LV_SK_SKEW 3      // K tiles the closing piece of an aligned tile is longer (and its first piece shorter) than an even split; 0 = even (A/B knob)
+#endif
 #ifndef LV_SK_ROWS0
 #define LV_SK_ROWS0 0     // measurement only: workgroup rows of the first product (0 = by the cost model)
 #endif
@@ -1490,11 +1493,27 @@ struct SkProb {
     long units;           // tilesM * tilesN * nk
     float* slabs;         // 2 slabs of 256 x 256 floats per workgroup: [2 s] the partial tile its range starts in, [2 s + 1] a later one
     int cnt0;             // index of this product's first arrival counter (one per tile) in lv_sk_arrivals
+    // skew > 0 (only where the ranges are `pieces` whole aligned pieces of `plen` K tiles per tile): every boundary INSIDE a tile lies
+    // `skew` K tiles early -- the first piece of a tile is that much shorter, the last (closing) one that much longer, so that the
+    // others' slabs are on their way while the closing workgroup still multiplies and it finds them arrived when it looks
+    int skew, pieces, plen;
 };
 struct GemmG { SkProb pr[2]; };
 
-// the workgroup whose unit range [s U / n, (s + 1) U / n) holds unit u
-__device__ __forceinline__ int sk_owner(long u, long units, int nwg) { return (int)(((u + 1) * nwg - 1) / units); }
+// first unit of logical workgroup s (s = nwg: one past the last unit), and the workgroup whose range holds unit u
+__device__ __forceinline__ long sk_start(const SkProb& P, int nwg, int s) {
+    const long b = (long)s * P.units / nwg;
+    return (P.skew > 0 && s % P.pieces != 0) ? b - P.skew : b;
+}
+__device__ __forceinline__ int sk_owner(const SkProb& P, int nwg, long u) {
+    if (P.skew > 0) {
+        const int tile = (int)(u / P.nk), k = (int)(u - (long)tile * P.nk);
+        int j = k / P.plen;
+        if (j + 1 < P.pieces && k >= (j + 1) * P.plen - P.skew) ++j;
+        return tile * P.pieces + j;
+    }
+    return (int)(((u + 1) * nwg - 1) / P.units);
+}
 
 // a finished 256 x 256 tile -> C (columns >= nsplit of a two-destination product -> C2)
 __device__ __forceinline__ void sk_store_tile(const GemmQ& p, const f32x16 (&acc)[4][2], int m0, int n0, int l, int w) {
@@ -1536,7 +1555,7 @@ __device__ __forceinline__ void sk_add_slab(f32x16 (&acc)[4][2], const float4* s
 template <bool TN>
 __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, LdsTile2& Bs0, LdsTile2& As1, LdsTile2& Bs1, int t, int l, int w) {
     const int nwg = 8 * P.rows;
-    const long u0 = (long)s * P.units / nwg, u1 = (long)(s + 1) * P.units / nwg;
+    const long u0 = sk_start(P, nwg, s), u1 = sk_start(P, nwg, s + 1);
     const int first_tile = (int)(u0 / P.nk);
     unsigned* const flag = reinterpret_cast<unsigned*>(&As0[0][0]);          // free between two segments (see t256q_run)
     unsigned* const cnt = lv_sk_arrivals + P.cnt0;
@@ -1556,13 +1575,13 @@ __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, L
         if (!done && !(LV_SK_ABL & 1)) {
             // ---- a partial tile: handed over inside the launch.  The tile's value is DEFINED as the sum of its pieces in descending K
             // order, (((p_c1 + p_c1-1) + ...) + p_c0), whoever computes it.
-            const int c0 = sk_owner(t0, P.units, nwg), c1 = sk_owner(t0 + P.nk - 1, P.units, nwg);
+            const int c0 = sk_owner(P, nwg, t0), c1 = sk_owner(P, nwg, t0 + P.nk - 1);
             // (1) The contributor that closes the K range, on the last segment it runs, looks (for a bounded while: it has nothing
             // else left to do) whether everybody else has arrived; if so it adds their slabs to its registers in that order and its own
             // piece never travels.
             if (t == 0) {
                 int others = -1;                           // contributors besides this one: the workgroups of [c0, c1] whose range is not empty
-                for (int c = c0; c <= c1; ++c) others += (long)c * P.units / nwg < (long)(c + 1) * P.units / nwg;
+                for (int c = c0; c <= c1; ++c) others += sk_start(P, nwg, c) < sk_start(P, nwg, c + 1);
                 unsigned role = 0;                         // 0: hand the piece over, 1: sum the others' into the registers
                 if (s == c1 && e == u0) {
                     for (int spin = 0; spin < LV_SK_SPIN; ++spin) {
@@ -1619,8 +1638,8 @@ __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, L
             const bool summed = closer || last;
             if (summed) {                                  // p_c1 (in the registers, or read back first into zeroed ones), then c1 - 1 ... c0
                 for (int c = closer ? c1 - 1 : c1; c >= c0; --c) {
-                    const long cu0 = (long)c * P.units / nwg;
-                    if (cu0 == (long)(c + 1) * P.units / nwg) continue;          // (an empty range: fewer units than workgroups)
+                    const long cu0 = sk_start(P, nwg, c);
+                    if (cu0 == sk_start(P, nwg, c + 1)) continue;                // (an empty range: fewer units than workgroups)
                     sk_add_slab(acc, reinterpret_cast<const float4*>(P.slabs + (2L * c + (tile != (int)(cu0 / P.nk))) * (BT2 * BT2)) + t);
                 }
             }
@@ -2092,6 +2111,15 @@ extern "C" int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint1
     if (two) fill(g.pr[1], M1, N1, K1, A1, lda1, B1, ldb1, C1, ldc1);
     g.pr[0].rows = (LV_SK_ROWS0 > 0 && two) ? LV_SK_ROWS0 : sk_rows0(g.pr[0].units, g.pr[0].nk, two ? g.pr[1].units : 0);
     g.pr[1].rows = 32 - g.pr[0].rows;
+    for (int j = 0; j < 2; ++j) {
+        SkProb& P = g.pr[j];
+        const long n = 8L * P.rows;
+        if (LV_SK_SKEW <= 0 || n == 0 || P.units % n != 0) continue;
+        const long L = P.units / n;                        // units per workgroup
+        if (L < 8 || P.nk % L != 0 || P.nk / L < 2) continue;
+        P.pieces = (int)(P.nk / L); P.plen = (int)L;
+        P.skew = LV_SK_SKEW < L / 8 ? LV_SK_SKEW : (int)(L / 8);
+    }
     g.pr[0].slabs = ws;
     g.pr[1].slabs = ws + 2L * 8 * g.pr[0].rows * (BT2 * BT2);
     g.pr[0].cnt0 = (int)(slot * SK_TILES);
