@@ -385,8 +385,14 @@ __device__ __forceinline__ void nll_piece_stats(const float (&v)[64], int valid,
 // modulo per element inside the store loop the bias cost the K = 512 input projection 55 -> 72 us and the decoder's z addend
 // 55 -> 98 us.  One copy of this code per fragment and no second, unchecked variant: the epilogue is straight-line code run once
 // per workgroup, and doubling it for interior tiles made the 256 x 256 kernel SLOWER (instruction fetch: Gx 48 -> 64 us).
+#ifndef LV_B16_EPI_ABL
+#define LV_B16_EPI_ABL 0        // measurement only (profiles/microbench/gemm_lstm_shapes.py; results are wrong): 1 = the f32 epilogue stores nothing
+#endif
 __device__ __forceinline__ void store_frag_f32(const GemmQ& p, const f32x16& a, int rbase, int col) {
     if (col >= p.N) return;
+#if LV_B16_EPI_ABL & 1
+    if (a[0] != 1.2345e-30f) return;
+#endif
     if (!p.add1 && !p.add2 && !p.accumulate) {           // plain store: no per-element branches
         float* cb = p.C + (long)rbase * p.ldc + col;
 #pragma unroll
