@@ -75,6 +75,7 @@ int lv_gemm_b16_dual(int transA, int M, int N, int K, const uint16_t* A, long ld
  * lv_gemm_b16_pair_supported: 1 where that is possible AND worth it (both products present, >= 12 K tiles per workgroup), else 0; the
  * entry itself only refuses the impossible (LV_ERR_UNSUPPORTED: second product transposed, > 1024 tiles, ws_floats < 2 * 256 * 65536). */
 int lv_gemm_b16_pair_supported(int transA0, int M0, int N0, int K0, int transA1, int M1, int N1, int K1, long ws_floats);
+int lv_gemm_b16_pair_pending(int* pending, void* stream);   /* diagnostic: *pending (device int) = arrival counters not back at zero; 0 between launches */
 int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint16_t* A0, long lda0, const uint16_t* B0, long ldb0,
                      float* C0, long ldc0, int nsplit0, float* C0b, long ldc0b,
                      int transA1, int M1, int N1, int K1, const uint16_t* A1, long lda1, const uint16_t* B1, long ldb1,

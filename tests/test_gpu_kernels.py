@@ -754,7 +754,7 @@ PAIR_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tA0,M0,N0,K0,nsplit,M1,N1,K1", PAIR_SHAPES)
+@pytest.mark.parametrize("tA0,M0,N0,K0,nsplit,M1,N1,K1", PAIR_SHAPES, ids=["PAIR%d" % i for i in range(len(PAIR_SHAPES))])
 def test_gemm_b16_pair(lib, hip_device, tA0, M0, N0, K0, nsplit, M1, N1, K1):
     """lv_gemm_b16_pair: two independent products in one grouped stream-K launch (tiles shared between workgroups are summed inside
     the launch by the last arriver, in K order): both against the float64 product of the bf16-rounded operands, padding of every
@@ -783,6 +783,9 @@ def test_gemm_b16_pair(lib, hip_device, tA0, M0, N0, K0, nsplit, M1, N1, K1):
         lib.lv_gemm_b16_pair(tA0, M0, N0, K0, P(A0i), lda0, P(B0i), ldb0, P(C0), ld0, nsplit, P(C0b) if nsplit > 0 else None, ld0b,
                              0, M1, N1, K1, P(A1i) if two else None, lda1 if two else 0, P(B1i) if two else None, ldb1 if two else 0,
                              P(C1) if two else None, ld1, P(ws), ws.numel(), _s(dev))
+        pend = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        lib.lv_gemm_b16_pair_pending(P(pend), _s(dev))
+        assert int(pend.cpu()[0]) == 0          # every arrival counter is back at zero when the launch is over
         return C0.cpu(), C0b.cpu(), C1.cpu()
 
     C0, C0b, C1 = run()

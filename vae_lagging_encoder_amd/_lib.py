@@ -26,6 +26,7 @@ SIGNATURES = {
     "lv_gemm_b16_dual_supported": [_i, _i, _i, _l],
     "lv_gemm_b16_dual": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
     "lv_gemm_b16_pair_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _l],
+    "lv_gemm_b16_pair_pending": [_vp, _vp],
     "lv_gemm_b16_pair": [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _vp, _l,
                          _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp],
     "lv_gemm_b16_keep": [_i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _f, _i, _vp, _l, _vp],

@@ -1659,6 +1659,17 @@ __device__ __forceinline__ void sk_work(const SkProb& P, int s, LdsTile2& As0, L
     }
 }
 
+// diagnostic: how many arrival counters are not back at zero (between launches: none)
+__global__ __launch_bounds__(256) void sk_pending_kernel(int* out) {
+    int n = 0;
+    for (int i = (int)threadIdx.x; i < SK_SLOTS * SK_TILES; i += 256) n += lv_sk_arrivals[i] != 0u;
+    n = lv_wave_sum(n);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = part[0] + part[1] + part[2] + part[3];
+}
+
 template <bool TN0, bool TN1>
 __global__ __launch_bounds__(512) void lv_gemm_b16_t256g_kernel(GemmG g) {
     __shared__ __attribute__((aligned(1024))) LdsTile2 As0, Bs0;
@@ -2132,6 +2143,15 @@ extern "C" int lv_gemm_b16_pair(int transA0, int M0, int N0, int K0, const uint1
     g.pr[1].cnt0 = g.pr[0].cnt0 + g.pr[0].q.tilesM * g.pr[0].q.tilesN;
     if (transA0) LV_LAUNCH((lv_gemm_b16_t256g_kernel<true, false>), dim3(256), dim3(512), 0, stream, g);
     else LV_LAUNCH((lv_gemm_b16_t256g_kernel<false, false>), dim3(256), dim3(512), 0, stream, g);
+    LV_CHECK_LAUNCH();
+    return LV_OK;
+}
+
+// *pending (device int) = the number of arrival counters of the grouped launches that are not zero: 0 whenever no such launch is in
+// flight on the device (every launch returns its counters to zero) -- tests and soaks check exactly that.
+extern "C" int lv_gemm_b16_pair_pending(int* pending, void* stream) {
+    if (!pending) return LV_ERR_ARG;
+    LV_LAUNCH(sk_pending_kernel, dim3(1), dim3(256), 0, stream, pending);
     LV_CHECK_LAUNCH();
     return LV_OK;
 }

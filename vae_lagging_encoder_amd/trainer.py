@@ -12,11 +12,32 @@ import collections
 import ctypes
 
 import numpy as np
+import contextlib
+import gc
 import torch
 
 from . import engine as _eng
 from .engine import P
 
+
+
+@contextlib.contextmanager
+def _capture_graph(graph, stream):
+    """`torch.cuda.graph(graph, stream=stream)` with Python's cyclic garbage collector held off for the duration of the capture.
+    The collector runs whenever allocation counts say so -- also in the middle of a capture -- and whatever it frees then runs its
+    destructor there: a `torch.cuda.CUDAGraph` of an earlier trainer (they sit in reference cycles with the trainer that replays
+    them) synchronises the device in `~CUDAGraph`, which HIP refuses while a stream is capturing ("operation not permitted when
+    stream is capturing"), and an exception in a destructor is `std::terminate`: the process aborts.  Seen on the GPU suite once the
+    test count moved the collector's schedule (profiles/r06x4_*); `torch.cuda.graph.__enter__` itself collects BEFORE the capture
+    begins, so everything unreachable by then is gone in an orderly way."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 class _Static(object):
     pass
@@ -608,7 +629,7 @@ class AggressiveTextTrainer(object):
             gr = torch.cuda.CUDAGraph()
             self._capturing = True
             try:
-                with torch.cuda.graph(gr, stream=stream):
+                with _capture_graph(gr, stream):
                     fn()
             finally:
                 self._capturing = False
@@ -811,7 +832,7 @@ class AggressiveImageTrainer(object):
             snap = (self.enc.flat.data.clone(), self.dec.flat.data.clone(), self.scal.clone(), self.rng_state.clone(),
                     {k: v.clone() for k, v in self.m.items()}, {k: v.clone() for k, v in self.v.items()},
                     {k: b.clone() for k, b in self.vae.named_buffers()})
-            with torch.cuda.graph(g, stream=stream):
+            with _capture_graph(g, stream):
                 self._body(st["x"], None if eps is None else st["eps"], update)
             self.enc.flat.data.copy_(snap[0]); self.dec.flat.data.copy_(snap[1]); self.scal.copy_(snap[2])
             self.rng_state.copy_(snap[3])
