@@ -17,7 +17,9 @@ NAMES = {0: "product kernel", 1: "no MFMAs", 2: "no waiting for producers", 3: "
          10: "no waiting, no barrier", 15: "none of the four (loads, LDS traffic, stores, loop)",
          16: "gathered granules not staged through LDS (fwd)", 18: "no waiting, no LDS staging of the gather (fwd)",
          32: "h granules not loaded (fwd)", 34: "no waiting, h granules not loaded (fwd)",
-         50: "no waiting, no granule loads, no LDS staging (fwd)", 63: "none of the six (fwd: Gx loads, quarter-sum LDS, stores, loop)"}
+         50: "no waiting, no granule loads, no LDS staging (fwd)",
+         64: "BPTT exchange as 16-byte accesses (what-if: half the load / store instructions; tags not tested)",
+         66: "no waiting + BPTT exchange as 16-byte accesses", 63: "none of the six (fwd: Gx loads, quarter-sum LDS, stores, loop)"}
 
 
 def timeit(f, n=20):
