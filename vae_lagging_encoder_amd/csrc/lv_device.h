@@ -126,6 +126,10 @@ static inline float lv_f16_bits_to_f32(uint16_t h) {
 }
 // the value held by lane (l ^ 1)
 static inline float lv_lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
+static inline uint32_t lv_lane_xor1_u32(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }
+// x + (the value of lane l ^ 16) / (l ^ 32): one step of a butterfly sum across a wave's 16-lane rows / its two halves
+static inline float lv_add_xor16(float x) { return x + __shfl_xor(x, 16, 64); }
+static inline float lv_add_xor32(float x) { return x + __shfl_xor(x, 32, 64); }
 // two f32 -> packed binary16 (RNE), lo in bits 0..15
 static inline uint32_t lv_pack_f16x2(float lo, float hi) { return (uint32_t)lv_f32_to_f16_bits(lo) | ((uint32_t)lv_f32_to_f16_bits(hi) << 16); }
 // binary16 forms of the two 16-bit-operand MFMAs (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16): the lane maps of the bf16
@@ -360,6 +364,22 @@ __device__ __forceinline__ float lv_f16_bits_to_f32(uint16_t b) {
 __device__ __forceinline__ float lv_lane_xor1(float v) {
     const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
     return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ uint32_t lv_lane_xor1_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+// x + (the value of lane l ^ 16) / (l ^ 32): one step of a butterfly sum across a wave's 16-lane rows / its two halves, on gfx950's
+// lane-swap instructions (v_permlane16_swap / v_permlane32_swap: VALU, a few cycles) instead of __shfl_xor's ds_bpermute (an LDS
+// crossbar round trip, ~120 cycles on a timestep's critical path).  With both operands the same register the swap leaves the even
+// rows' (lower half's) values in one result and the odd rows' (upper half's) in the other, in EVERY lane: their sum is self + partner
+// in the partner-less order -- the same bits as the shuffle form, since the one add is commutative.
+__device__ __forceinline__ float lv_add_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float lv_add_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 // DPP row_shr with a bank mask (v_mov_b32_dpp row_shr:SHIFT bank_mask:1 << BANK): lanes of bank BANK (lanes 4 BANK .. 4 BANK + 3 of
 // every 16-lane row) take src from the lane SHIFT positions lower in their row, every other lane keeps old.  Merges the valid

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {      // publish the initial state hs[0] as state 0 (tag 1)
         const uint32_t mine = h16(own[q] ? p.hs[pidx[q]] : 0.f);
-        const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+        const uint32_t next = lv_lane_xor1_u32(mine);      // (even lanes: their right-hand neighbour; DPP, no LDS round trip)
         if (own[q] && even) put(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
     }
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     cb[q][s2] = c; hb[q][s2] = h;
                 }
                 const uint32_t mine = h16(h);
-                const uint32_t next = (uint32_t)__shfl_down((int)mine, 1, 64);
+                const uint32_t next = lv_lane_xor1_u32(mine);      // (even lanes: their right-hand neighbour; DPP, no LDS round trip)
                 if (own[q] && even)
                     put(hx_g + (long)((t + 1) & 1) * hx_par + (long)prow[q] * (PH / 2) + (punit >> 1),
                         ((gran_t)(uint32_t)(t + 2) << 32) | (gran_t)(mine | (next << 16)));
@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a += rs_lo(v[bt][j]); b += rs_hi(v[bt][j]); }
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            a = lv_add_xor16(a); b = lv_add_xor16(b);      // the four lane groups' (= 4 x 8 senders') sums, on the lane-swap instructions
+            a = lv_add_xor32(a); b = lv_add_xor32(b);
             // batch h0 + bt belongs to pair q = (h0 + bt) >> 1 of the lanes with (l >> 5) == ((h0 + bt) & 1)
             if ((l >> 5) == ((h0 + bt) & 1)) dh_rec[(h0 + bt) >> 1] = (l & 16) ? b : a;
         }
