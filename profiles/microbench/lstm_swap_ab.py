@@ -1,5 +1,5 @@
 """Microbenchmark (measurement tooling): the persistent recurrences of two builds of the library side by side -- every output compared
-BIT FOR BIT on the same inputs (hs, cs, the saved records, dG16, dGsum, dc0), then microseconds per timestep (slope between T = 40 and
+BIT FOR BIT on the same inputs (where the bits differ: the largest difference beside the largest value) (hs, cs, the saved records, dG16, dGsum, dc0), then microseconds per timestep (slope between T = 40 and
 T = 200, 20 launches each, the two libraries alternating).   usage: lstm_swap_ab.py <other .so> [label]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -59,10 +59,15 @@ for B, R, f16 in [(32, 4, True), (32, 4, False), (20, 4, True), (64, 8, True), (
         per = []
         for name, lib in libs:
             per.append(run(lib, B, R, f16, T, 1234 + T + B, True))
-        same = [bool(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b))
-                for a, b in zip(per[0][0], per[1][0])]
+        def cmp(a, b):
+            if torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b):
+                return True
+            if a.dtype == torch.int16:      # bf16 images: compare as values
+                a, b = (a.view(torch.bfloat16).float(), b.view(torch.bfloat16).float())
+            return "%.1e of %.1e" % (float((a - b).abs().max()), float(b.abs().max()))      # max |difference| of max |value|
+        same = [cmp(a, b) for a, b in zip(per[0][0], per[1][0])]
         res[T] = (per, same)
     sl = [((res[200][0][i][1] - res[40][0][i][1]) / 160.0, (res[200][0][i][2] - res[40][0][i][2]) / 160.0) for i in range(2)]
     print("B=%3d R=%2d %s | bit-identical outputs (T=40 / T=200): %s / %s | us per timestep fwd / BPTT: %s %.3f / %.3f | %s %.3f / %.3f"
-          % (B, R, "f16 forward" if f16 else "bf16 forward", dict(zip(names, res[40][1])) if not all(res[40][1]) else "all six",
-             dict(zip(names, res[200][1])) if not all(res[200][1]) else "all six", libs[0][0], sl[0][0], sl[0][1], libs[1][0], sl[1][0], sl[1][1]), flush=True)
+          % (B, R, "f16 forward" if f16 else "bf16 forward", dict(zip(names, res[40][1])) if not all(x is True for x in res[40][1]) else "all six",
+             dict(zip(names, res[200][1])) if not all(x is True for x in res[200][1]) else "all six", libs[0][0], sl[0][0], sl[0][1], libs[1][0], sl[1][0], sl[1][1]), flush=True)

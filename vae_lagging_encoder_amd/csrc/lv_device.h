@@ -130,6 +130,37 @@ static inline uint32_t lv_lane_xor1_u32(uint32_t v) { return (uint32_t)__shfl_xo
 // x + (the value of lane l ^ 16) / (l ^ 32): one step of a butterfly sum across a wave's 16-lane rows / its two halves
 static inline float lv_add_xor16(float x) { return x + __shfl_xor(x, 16, 64); }
 static inline float lv_add_xor32(float x) { return x + __shfl_xor(x, 32, 64); }
+// x + (the value of lane l ^ 8)
+static inline float lv_add_xor8(float x) { return x + __shfl_xor(x, 8, 64); }
+// TRANSPOSING butterfly steps: two registers in, one out.  lv_fold16: a lane of an even 16-lane row gets x(l) + x(l + 16), a lane of an
+// odd row y(l - 16) + y(l); lv_fold32: a lane of the lower half gets x(l) + x(l + 32), a lane of the upper half y(l - 32) + y(l) --
+// each step halves the number of live registers instead of leaving every lane with every sum.
+static inline float lv_fold16(float x, float y) {
+    const float xs = __shfl_xor(x, 16, 64), ys = __shfl_xor(y, 16, 64);
+    return (lv_emu::lane() & 16) ? ys + y : x + xs;
+}
+static inline float lv_fold32(float x, float y) {
+    const float xs = __shfl_xor(x, 32, 64), ys = __shfl_xor(y, 32, 64);
+    return (lv_emu::lane() & 32) ? ys + y : x + xs;
+}
+// 16-byte hand-off granules: four dwords that each carry their own tag bits -- 16-byte atomicity is assumed NOWHERE, and here the
+// stores are torn on purpose (another fiber runs between the two halves).  Four granules are polled by one call (one wait for all).
+static inline void lv_agent_load_q4x4(const void* p0, const void* p1, const void* p2, const void* p3, uint4 (&v)[4]) {
+    lv_emu::yield_all();
+    const void* ps[4] = {p0, p1, p2, p3};
+    for (int i = 0; i < 4; ++i) {
+        const unsigned* q = static_cast<const unsigned*>(ps[i]);
+        v[i] = make_uint4(__atomic_load_n(q, __ATOMIC_RELAXED), __atomic_load_n(q + 1, __ATOMIC_RELAXED),
+                          __atomic_load_n(q + 2, __ATOMIC_RELAXED), __atomic_load_n(q + 3, __ATOMIC_RELAXED));
+    }
+}
+static inline void lv_agent_store_q4(void* p, uint4 v) {
+    unsigned* q = static_cast<unsigned*>(p);
+    __atomic_store_n(q + 2, v.z, __ATOMIC_RELAXED); __atomic_store_n(q + 3, v.w, __ATOMIC_RELAXED);
+    lv_emu::yield_all();
+    __atomic_store_n(q, v.x, __ATOMIC_RELAXED); __atomic_store_n(q + 1, v.y, __ATOMIC_RELAXED);
+}
+static inline void lv_xcd_store_q4(void* p, uint4 v) { lv_agent_store_q4(p, v); }
 // two f32 -> packed binary16 (RNE), lo in bits 0..15
 static inline uint32_t lv_pack_f16x2(float lo, float hi) { return (uint32_t)lv_f32_to_f16_bits(lo) | ((uint32_t)lv_f32_to_f16_bits(hi) << 16); }
 // binary16 forms of the two 16-bit-operand MFMAs (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16): the lane maps of the bf16
@@ -380,6 +411,45 @@ __device__ __forceinline__ float lv_add_xor16(float x) {
 __device__ __forceinline__ float lv_add_xor32(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// x + (the value of lane l ^ 8): DPP row_ror:8 (inside a 16-lane row a rotation by 8 IS the xor), folded into the add by the compiler
+__device__ __forceinline__ float lv_add_xor8(float x) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(float, r);
+}
+// TRANSPOSING butterfly steps on the lane-swap instructions: two registers in, one out.  v_permlane16_swap exchanges the ODD rows of
+// its first operand with the EVEN rows of its second: afterwards the first holds (x.row0, y.row0, x.row2, y.row2) and the second
+// (x.row1, y.row1, x.row3, y.row3), so their sum is x(l) + x(l + 16) in the even rows and y(l - 16) + y(l) in the odd rows
+// (lv_fold16); v_permlane32_swap does the same with the two halves of the wave (lv_fold32).  One swap + one add reduces TWO
+// registers by one butterfly level and leaves every lane with a sum nobody else holds.
+__device__ __forceinline__ float lv_fold16(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float lv_fold32(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// 16-byte hand-off granules (four dwords that each carry their own tag bits: 16-byte atomicity is assumed nowhere).  The loads are
+// L2-served (sc1, like lv_agent_load_u64); four granules are polled by ONE statement that also holds the wait -- the compiler does not
+// know when an inline-assembly load lands and would otherwise reuse its destination registers.  Stores: the agent-scope form writes
+// through (sc1), the XCD form stays in the XCD's L2 (see lv_xcd_store_u64).  s_nop: a store of more than 8 bytes must not be followed
+// directly by a write of its data registers (the compiler's hazard recogniser does not see into the statement).
+__device__ __forceinline__ void lv_agent_load_q4x4(const void* p0, const void* p1, const void* p2, const void* p3, uint4 (&v)[4]) {
+    lv_u32x4v r0, r1, r2, r3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+    v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
+}
+__device__ __forceinline__ void lv_agent_store_q4(void* p, uint4 v) {
+    const lv_u32x4v d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ void lv_xcd_store_q4(void* p, uint4 v) {
+    const lv_u32x4v d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
 // DPP row_shr with a bank mask (v_mov_b32_dpp row_shr:SHIFT bank_mask:1 << BANK): lanes of bank BANK (lanes 4 BANK .. 4 BANK + 3 of
 // every 16-lane row) take src from the lane SHIFT positions lower in their row, every other lane keeps old.  Merges the valid

@@ -47,6 +47,9 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_GJ16
 #define LV_GJ16 16
 #endif
+#ifndef LV_RS4_Q
+#define LV_RS4_Q 1                      // 4-row BPTT: the reduce-scatter's partial sums travel as 16-byte granules (rs4_*: four 30-bit
+#endif                                  // floats, 2 tag bits each); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
 #ifndef LV_P16_ABL
 #define LV_P16_ABL 0                    // measurement knob (profiles/microbench/lstm_anatomy_probe.py): WHAT-IF builds of the final
 #endif                                  // kernels with one phase of a timestep removed -- results are garbage, the time is the point.
@@ -460,8 +463,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     }
 
     // owner pairs of this lane: batch beta = 2q + (l >> 5) -> batch row 4 beta + (p >> 2); unit from (w, p, granule half)
+    // (Q4, the 16-byte granules of the 4-row instantiation: the lanes with bit 3 clear own -- wave w receives granules 8w + (l & 7)
+    //  = (unit block w >> 1, row 2 (w & 1) + ((l & 7) >> 2), unit quad l & 3), and the transposing butterfly leaves the lane with
+    //  the quad's unit 2 ((l >> 4) & 1) + (l >> 5))
+    constexpr bool Q4 = RP == 4 && LV_RS4_Q != 0;
     const int pp = l & 15;
-    const int uw = 16 * (w >> 1) + 4 * (pp & 3) + 2 * (w & 1) + ((l >> 4) & 1);
+    const int uw = Q4 ? 16 * (w >> 1) + 4 * (l & 3) + 2 * ((l >> 4) & 1) + (l >> 5)
+                      : 16 * (w >> 1) + 4 * (pp & 3) + 2 * (w & 1) + ((l >> 4) & 1);
     const int punit = 32 * member + uw;
     const long BH = (long)B * PH;
     const long rec = (long)R * SAVED_PER_ROW;
@@ -470,8 +478,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int beta = 2 * q + (l >> 5);
-        prow[q] = 4 * beta + (pp >> 2);
-        own[q] = beta < NB && prow[q] < rows;
+        prow[q] = Q4 ? 2 * (w & 1) + ((l & 7) >> 2) : 4 * beta + (pp >> 2);
+        own[q] = (Q4 ? !(l & 8) : beta < NB) && prow[q] < rows;
         pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
         sg[q] = ((own[q] ? prow[q] : 0) * 32 + uw) * 4;
         sc[q] = R * 128 + (own[q] ? prow[q] : 0) * 32 + uw;
@@ -488,6 +496,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     gran_t* const tx4 = px_g + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS + 2 * (((l & 15) >> 2) & 1) * 4 * RP +
                         4 * (l & 3) + (l >> 4);
 
+    // Q4: a pair's 512 bytes are 32 granules of 16 bytes, granule (unit block b, row c, unit quad rq) at 16 b + 4 c + rq.  Receive:
+    // senders 4 (l >> 3) + j, granule 8w + (l & 7); send: lane position (l & 15) = c + 4 j of a merged chunk n4 carries the quad
+    // (row c, rq = l >> 4) of column block 4 n4 + j -> receiver 8w + 2 n4 + (j >> 1), unit block j & 1.
+    const char* const rx_q = reinterpret_cast<const char*>(px_g) + ((long)member * PMEMBERS + 4 * (l >> 3)) * SLOTS * 8 + (8 * w + (l & 7)) * 16;
+    char* const tx_q = reinterpret_cast<char*>(px_g) + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS * 8 +
+                       ((((l & 15) >> 2) & 1) * 16 + 4 * (l & 3) + (l >> 4)) * 16;
     float dc_rec[NP], gsum[NP][4];
     float dhb[NP][SBK], ctb[NP][SBK + 1];
     float4 recb[NP][SBK];
@@ -586,7 +600,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         }
         return true;
     };
+    // Q4: ONE polling round of four 16-byte granules per lane (senders 4 (l >> 3) + 0..3); the four components are summed over the
+    // senders in a fixed order -- in the lane, across the two lane groups of a row (DPP), then by two transposing lane-swap steps
+    // that leave every lane with the total of ONE unit: 10 cross-lane instructions, none of them an LDS round trip.
+    auto receive_q4 = [&](int k, float (&dh_rec)[NP]) -> bool {
+        const char* src = rx_q + (long)(k & 1) * px_par * 8;
+        const uint32_t want = rs4_tag(k);
+        uint4 u[4];
+        int spins = 0;
+        bool ok;
+        do {
+            lv_agent_load_q4x4(src, src + (long)SLOTS * 8, src + (long)2 * SLOTS * 8, src + (long)3 * SLOTS * 8, u);
+            ok = (LV_P16_ABL & 2) ? true : rs4_all_tagged(u, want);
+            ok = __all(ok);
+            if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+        } while (!ok);
+        LV_TRACE_ONLY(tr_spins[0] = spins;)
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a += rs4_val(u[j].x); b += rs4_val(u[j].y); c += rs4_val(u[j].z); d += rs4_val(u[j].w); }
+        a = lv_add_xor8(a); b = lv_add_xor8(b); c = lv_add_xor8(c); d = lv_add_xor8(d);
+        dh_rec[0] = lv_fold32(lv_fold16(a, c), lv_fold16(b, d));      // lane (half h, row parity rp): component 2 rp + h
+        return true;
+    };
     auto receive = [&](int k, float (&dh_rec)[NP]) -> bool {
+        if constexpr (Q4) return receive_q4(k, dh_rec);
         const gran_t* src = rx + (long)(k & 1) * px_par;
         const uint32_t want = rs_tag(k);
 #pragma unroll
@@ -669,9 +707,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                     m[r] = lv_row_shr_into<8, 2>(m[r], acc[2][r]);
                     m[r] = lv_row_shr_into<12, 3>(m[r], acc[3][r]);
                 }
+                if constexpr (Q4) {      // ... and as ONE 16-byte store: the lane's four consecutive units of its row are a granule
+                    char* d = tx_q + (long)(k & 1) * px_par * 8 + (long)(2 * n4) * PMEMBERS * SLOTS * 8;
+                    const uint32_t t4 = rs4_tag(k);
+                    const uint4 g = make_uint4(rs4_pack(m[0], t4), rs4_pack(m[1], t4), rs4_pack(m[2], t4), rs4_pack(m[3], t4));
+                    if (LOCAL) lv_xcd_store_q4(d, g); else lv_agent_store_q4(d, g);
+                } else {
                 gran_t* d = dst4 + (long)(2 * n4) * PMEMBERS * SLOTS;
                 put(d, rs_pack(m[0], m[1], tag));
                 put(d + 4 * RP, rs_pack(m[2], m[3], tag));
+                }
             } else if ((l & 15) < RP) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -37,4 +37,30 @@ __device__ __forceinline__ float rs_hi(gran_t g) {
     return f;
 }
 
+
+// reduce-scatter granule of the 4-row BPTT: FOUR partial sums in 16 bytes, each dword a 30-bit float (sign, exponent, 21 mantissa
+// bits) under a 2-bit phase tag of its own -- a granule is valid when all four dwords carry the wanted tag, so a torn 16-byte access
+// is detected like a late one.  Phases cycle 1, 2, 3: a slot of the parity-double-buffered exchange last held phase k - 2, whose tag
+// differs from phase k's, and a zeroed buffer matches no phase.
+__device__ __forceinline__ uint32_t rs4_tag(int k) { return 1u + (uint32_t)(k - 1) % 3u; }
+__device__ __forceinline__ uint32_t rs4_pack(float a, uint32_t tag) {
+    uint32_t u;
+    memcpy(&u, &a, 4);
+    return ((u + 2u) >> 2) | (tag << 30);
+}
+__device__ __forceinline__ float rs4_val(uint32_t g) {
+    const uint32_t u = g << 2;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// all sixteen dwords of four granules carry tag `want`
+__device__ __forceinline__ bool rs4_all_tagged(const uint4 (&v)[4], uint32_t want) {
+    const uint32_t w = want << 30;
+    uint32_t x = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x |= (v[j].x ^ w) | (v[j].y ^ w) | (v[j].z ^ w) | (v[j].w ^ w);
+    return (x >> 30) == 0u;
+}
+
 }  // namespace lvp
