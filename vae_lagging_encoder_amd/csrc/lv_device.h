@@ -127,6 +127,8 @@ static inline float lv_f16_bits_to_f32(uint16_t h) {
 // the value held by lane (l ^ 1)
 static inline float lv_lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
 static inline uint32_t lv_lane_xor1_u32(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }
+// the value held by lane I of this lane's quad (lanes 4q .. 4q + 3)
+template <int I> static inline uint32_t lv_quad_bcast_u32(uint32_t v) { return (uint32_t)lv_emu_xchg((int)v, (lv_emu::lane() & ~3) + I); }
 // x + (the value of lane l ^ 16) / (l ^ 32): one step of a butterfly sum across a wave's 16-lane rows / its two halves
 static inline float lv_add_xor16(float x) { return x + __shfl_xor(x, 16, 64); }
 static inline float lv_add_xor32(float x) { return x + __shfl_xor(x, 32, 64); }
@@ -398,6 +400,10 @@ __device__ __forceinline__ float lv_lane_xor1(float v) {
 }
 __device__ __forceinline__ uint32_t lv_lane_xor1_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+// the value held by lane I of this lane's quad (DPP quad_perm:[I, I, I, I])
+template <int I> __device__ __forceinline__ uint32_t lv_quad_bcast_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, I * 0x55, 0xF, 0xF, true);
 }
 // x + (the value of lane l ^ 16) / (l ^ 32): one step of a butterfly sum across a wave's 16-lane rows / its two halves, on gfx950's
 // lane-swap instructions (v_permlane16_swap / v_permlane32_swap: VALU, a few cycles) instead of __shfl_xor's ds_bpermute (an LDS

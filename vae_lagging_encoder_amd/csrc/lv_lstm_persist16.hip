@@ -47,6 +47,9 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_GJ16
 #define LV_GJ16 16
 #endif
+#ifndef LV_FWD4_Q
+#define LV_FWD4_Q 1                     // 4-row forward: h travels as 16-byte granules (four units, each dword = binary16 / bf16 bits under a
+#endif                                  // 16-bit tag of its own); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
 #ifndef LV_RS4_Q
 #define LV_RS4_Q 1                      // 4-row BPTT: the reduce-scatter's partial sums travel as 16-byte granules (rs4_*: four 30-bit
 #endif                                  // floats, 2 tag bits each); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
@@ -234,8 +237,22 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     const long hx_par = (long)PGROUPS * 16 * (PH / 2);
     const bool even = !(uw & 1);
 
+    // QF (4 rows): a granule is 16 bytes = the four units 4i .. 4i + 3 of a row, every dword its unit's 16 bits under the low 16 bits of
+    // the state's tag -- a granule is valid when all four dwords carry it, so 16-byte atomicity is assumed nowhere.  Half as many load
+    // instructions per poll for the same bytes; the publishing lane of a quad collects its neighbours' dwords by DPP.
+    constexpr bool QF = RP == 4 && LV_FWD4_Q != 0;
+    auto tagq = [](int state) -> uint32_t { return 1u + (uint32_t)state % 0xFFFFu; };
+    auto publish_q = [&](int state, int q, float hval) {
+        const uint32_t dw = h16(hval) | (tagq(state) << 16);
+        const uint32_t d1 = lv_quad_bcast_u32<1>(dw), d2 = lv_quad_bcast_u32<2>(dw), d3 = lv_quad_bcast_u32<3>(dw);
+        if (own[q] && !(uw & 3)) {
+            char* d = reinterpret_cast<char*>(hx_g + (long)(state & 1) * hx_par + (long)prow[q] * (PH / 2)) + (punit >> 2) * 16;
+            if (LOCAL) lv_xcd_store_q4(d, make_uint4(dw, d1, d2, d3)); else lv_agent_store_q4(d, make_uint4(dw, d1, d2, d3));
+        }
+    };
 #pragma unroll
     for (int q = 0; q < NP; ++q) {      // publish the initial state hs[0] as state 0 (tag 1)
+        if constexpr (QF) { publish_q(0, q, own[q] ? p.hs[pidx[q]] : 0.f); continue; }
         const uint32_t mine = h16(own[q] ? p.hs[pidx[q]] : 0.f);
         const uint32_t next = lv_lane_xor1_u32(mine);      // (even lanes: their right-hand neighbour; DPP, no LDS round trip)
         if (own[q] && even) put(hx_g + (long)prow[q] * (PH / 2) + (punit >> 1), ((gran_t)1u << 32) | (gran_t)(mine | (next << 16)));
@@ -289,6 +306,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             // ---- gather K-quarter w of state t (tag t + 1) into this wave's part of the LDS image ---------------------------
             const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
             const uint32_t want = (uint32_t)(t + 1);
+            if constexpr (QF) {
+                // one polling round: lane l takes granule 64w + l (k = 256w + 4l .. + 3) of each of the slice's rows -- every load
+                // instruction reads 1 KB of one row; rows the slice does not have re-read row 0 and are neither tested nor staged
+                const char* sq = reinterpret_cast<const char*>(hx_g + (long)(t & 1) * hx_par) + (64 * w + l) * 16;
+                const long rowb = (long)(PH / 2) * 8;
+                const uint32_t wq = tagq(t) << 16;
+                uint4 v[4];
+                int spins = 0;
+                bool ok;
+                do {
+                    lv_agent_load_q4x4(sq, sq + (rows > 1 ? rowb : 0), sq + (rows > 2 ? 2 * rowb : 0), sq + (rows > 3 ? 3 * rowb : 0), v);
+                    uint32_t x = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < rows) x |= (v[j].x ^ wq) | (v[j].y ^ wq) | (v[j].z ^ wq) | (v[j].w ^ wq);
+                    ok = (LV_P16_ABL & 2) ? true : (x >> 16) == 0u;
+                    ok = __all(ok);
+                    if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                } while (!ok);
+                LV_TRACE_VAL(t, 6, spins);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < rows)
+                        *reinterpret_cast<uint2*>(&sm.hl[j * HP16 + 128 * w + 2 * l]) =
+                            make_uint2((v[j].x & 0xFFFFu) | (v[j].y << 16), (v[j].z & 0xFFFFu) | (v[j].w << 16));
+            } else
             for (int base = 0; base < nq; base += 64 * GJ) {
                 // every poll round issues ALL its loads before it looks at a tag (first build: a load and its tag test per granule
                 // inside one predicated block compiled to load -> wait -> compare, GJ dependent round trips: 6.8 us per step at 8 rows)
@@ -393,6 +436,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                     recb[q][s2] = f32x4{ig, fg, gg, og};
                     cb[q][s2] = c; hb[q][s2] = h;
                 }
+                if constexpr (QF) { publish_q(t + 1, q, h); continue; }
                 const uint32_t mine = h16(h);
                 const uint32_t next = lv_lane_xor1_u32(mine);      // (even lanes: their right-hand neighbour; DPP, no LDS round trip)
                 if (own[q] && even)
