@@ -156,6 +156,14 @@ static inline void lv_agent_load_q4x4(const void* p0, const void* p1, const void
                           __atomic_load_n(q + 2, __ATOMIC_RELAXED), __atomic_load_n(q + 3, __ATOMIC_RELAXED));
     }
 }
+static inline void lv_agent_load_q4x8(const void* const (&ps)[8], uint4 (&v)[8]) {
+    lv_emu::yield_all();
+    for (int i = 0; i < 8; ++i) {
+        const unsigned* q = static_cast<const unsigned*>(ps[i]);
+        v[i] = make_uint4(__atomic_load_n(q, __ATOMIC_RELAXED), __atomic_load_n(q + 1, __ATOMIC_RELAXED),
+                          __atomic_load_n(q + 2, __ATOMIC_RELAXED), __atomic_load_n(q + 3, __ATOMIC_RELAXED));
+    }
+}
 static inline void lv_agent_store_q4(void* p, uint4 v) {
     unsigned* q = static_cast<unsigned*>(p);
     __atomic_store_n(q + 2, v.z, __ATOMIC_RELAXED); __atomic_store_n(q + 3, v.w, __ATOMIC_RELAXED);
@@ -448,6 +456,18 @@ __device__ __forceinline__ void lv_agent_load_q4x4(const void* p0, const void* p
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
     v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
     v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
+}
+__device__ __forceinline__ void lv_agent_load_q4x8(const void* const (&ps)[8], uint4 (&v)[8]) {
+    lv_u32x4v r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(ps[0]), "v"(ps[1]), "v"(ps[2]), "v"(ps[3]), "v"(ps[4]), "v"(ps[5]), "v"(ps[6]), "v"(ps[7]) : "memory");
+    v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+    v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
+    v[4] = make_uint4(r4.x, r4.y, r4.z, r4.w); v[5] = make_uint4(r5.x, r5.y, r5.z, r5.w);
+    v[6] = make_uint4(r6.x, r6.y, r6.z, r6.w); v[7] = make_uint4(r7.x, r7.y, r7.z, r7.w);
 }
 __device__ __forceinline__ void lv_agent_store_q4(void* p, uint4 v) {
     const lv_u32x4v d = {v.x, v.y, v.z, v.w};

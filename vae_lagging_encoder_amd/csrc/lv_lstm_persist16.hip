@@ -47,9 +47,9 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_GJ16
 #define LV_GJ16 16
 #endif
-#ifndef LV_FWD4_Q
-#define LV_FWD4_Q 1                     // 4-row forward: h travels as 16-byte granules (four units, each dword = binary16 / bf16 bits under a
-#endif                                  // 16-bit tag of its own); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
+#ifndef LV_FWD_Q
+#define LV_FWD_Q 2                      // forward: h travels as 16-byte granules (four units, each dword = binary16 / bf16 bits under a 16-bit
+#endif                                  // tag of its own): 2 = every instantiation, 1 = the 4-row one only, 0: 8-byte granules (A/B builds)
 #ifndef LV_RS4_Q
 #define LV_RS4_Q 1                      // 4-row BPTT: the reduce-scatter's partial sums travel as 16-byte granules (rs4_*: four 30-bit
 #endif                                  // floats, 2 tag bits each); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
     const long hx_par = (long)PGROUPS * 16 * (PH / 2);
     const bool even = !(uw & 1);
 
-    // QF (4 rows): a granule is 16 bytes = the four units 4i .. 4i + 3 of a row, every dword its unit's 16 bits under the low 16 bits of
+    // QF: a granule is 16 bytes = the four units 4i .. 4i + 3 of a row, every dword its unit's 16 bits under the low 16 bits of
     // the state's tag -- a granule is valid when all four dwords carry it, so 16-byte atomicity is assumed nowhere.  Half as many load
     // instructions per poll for the same bytes; the publishing lane of a quad collects its neighbours' dwords by DPP.
-    constexpr bool QF = RP == 4 && LV_FWD4_Q != 0;
+    constexpr bool QF = LV_FWD_Q == 2 || (RP == 4 && LV_FWD_Q == 1);
     auto tagq = [](int state) -> uint32_t { return 1u + (uint32_t)state % 0xFFFFu; };
     auto publish_q = [&](int state, int q, float hval) {
         const uint32_t dw = h16(hval) | (tagq(state) << 16);
@@ -307,30 +307,43 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             const gran_t* src = hx_g + (long)(t & 1) * hx_par + 128 * w;
             const uint32_t want = (uint32_t)(t + 1);
             if constexpr (QF) {
-                // one polling round: lane l takes granule 64w + l (k = 256w + 4l .. + 3) of each of the slice's rows -- every load
-                // instruction reads 1 KB of one row; rows the slice does not have re-read row 0 and are neither tested nor staged
+                // lane l takes granule 64w + l (k = 256w + 4l .. + 3) of each of the slice's rows -- every load instruction reads 1 KB
+                // of one row -- in polling rounds of 4 (4-row instantiation) or 8 rows; rows the slice does not have re-read row 0 and
+                // are neither tested nor staged
+                constexpr int QR = RP == 4 ? 4 : 8;
                 const char* sq = reinterpret_cast<const char*>(hx_g + (long)(t & 1) * hx_par) + (64 * w + l) * 16;
                 const long rowb = (long)(PH / 2) * 8;
                 const uint32_t wq = tagq(t) << 16;
-                uint4 v[4];
-                int spins = 0;
-                bool ok;
-                do {
-                    lv_agent_load_q4x4(sq, sq + (rows > 1 ? rowb : 0), sq + (rows > 2 ? 2 * rowb : 0), sq + (rows > 3 ? 3 * rowb : 0), v);
-                    uint32_t x = 0u;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < rows) x |= (v[j].x ^ wq) | (v[j].y ^ wq) | (v[j].z ^ wq) | (v[j].w ^ wq);
-                    ok = (LV_P16_ABL & 2) ? true : (x >> 16) == 0u;
-                    ok = __all(ok);
-                    if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
-                } while (!ok);
-                LV_TRACE_VAL(t, 6, spins);
+                for (int r0 = 0; r0 < RP; r0 += QR) {
+                    if (r0 >= rows) break;
+                    uint4 v[QR];
+                    int spins = 0;
+                    bool ok;
+                    do {
+                        if constexpr (QR == 4)
+                            lv_agent_load_q4x4(sq, sq + (rows > 1 ? rowb : 0), sq + (rows > 2 ? 2 * rowb : 0), sq + (rows > 3 ? 3 * rowb : 0), v);
+                        else {
+                            const void* ps[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < rows)
-                        *reinterpret_cast<uint2*>(&sm.hl[j * HP16 + 128 * w + 2 * l]) =
-                            make_uint2((v[j].x & 0xFFFFu) | (v[j].y << 16), (v[j].z & 0xFFFFu) | (v[j].w << 16));
+                            for (int j = 0; j < 8; ++j) ps[j] = sq + (r0 + j < rows ? (r0 + j) * rowb : 0);
+                            lv_agent_load_q4x8(ps, reinterpret_cast<uint4 (&)[8]>(v));
+                        }
+                        uint32_t x = 0u;
+#pragma unroll
+                        for (int j = 0; j < QR; ++j)
+                            if (r0 + j < rows) x |= (v[j].x ^ wq) | (v[j].y ^ wq) | (v[j].z ^ wq) | (v[j].w ^ wq);
+                        ok = (LV_P16_ABL & 2) ? true : (x >> 16) == 0u;
+                        ok = __all(ok);
+                        if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                    } while (!ok);
+                    LV_TRACE_VAL(t, 6, spins);
+#pragma unroll
+                    for (int j = 0; j < QR; ++j)
+                        if (r0 + j < rows)
+                            *reinterpret_cast<uint2*>(&sm.hl[(r0 + j) * HP16 + 128 * w + 2 * l]) =
+                                make_uint2((v[j].x & 0xFFFFu) | (v[j].y << 16), (v[j].z & 0xFFFFu) | (v[j].w << 16));
+                }
             } else
             for (int base = 0; base < nq; base += 64 * GJ) {
                 // every poll round issues ALL its loads before it looks at a tag (first build: a load and its tag test per granule
