@@ -134,9 +134,14 @@ static inline float lv_add_xor16(float x) { return x + __shfl_xor(x, 16, 64); }
 static inline float lv_add_xor32(float x) { return x + __shfl_xor(x, 32, 64); }
 // x + (the value of lane l ^ 8)
 static inline float lv_add_xor8(float x) { return x + __shfl_xor(x, 8, 64); }
-// TRANSPOSING butterfly steps: two registers in, one out.  lv_fold16: a lane of an even 16-lane row gets x(l) + x(l + 16), a lane of an
+// TRANSPOSING butterfly steps: two registers in, one out.  lv_fold8: a lane with bit 3 clear gets x(l) + x(l + 8), one with bit 3 set
+// y(l - 8) + y(l); lv_fold16: a lane of an even 16-lane row gets x(l) + x(l + 16), a lane of an
 // odd row y(l - 16) + y(l); lv_fold32: a lane of the lower half gets x(l) + x(l + 32), a lane of the upper half y(l - 32) + y(l) --
 // each step halves the number of live registers instead of leaving every lane with every sum.
+static inline float lv_fold8(float x, float y) {
+    const float xs = __shfl_xor(x, 8, 64), ys = __shfl_xor(y, 8, 64);
+    return (lv_emu::lane() & 8) ? ys + y : x + xs;
+}
 static inline float lv_fold16(float x, float y) {
     const float xs = __shfl_xor(x, 16, 64), ys = __shfl_xor(y, 16, 64);
     return (lv_emu::lane() & 16) ? ys + y : x + xs;
@@ -163,6 +168,12 @@ static inline void lv_agent_load_q4x8(const void* const (&ps)[8], uint4 (&v)[8])
         v[i] = make_uint4(__atomic_load_n(q, __ATOMIC_RELAXED), __atomic_load_n(q + 1, __ATOMIC_RELAXED),
                           __atomic_load_n(q + 2, __ATOMIC_RELAXED), __atomic_load_n(q + 3, __ATOMIC_RELAXED));
     }
+}
+// eight granules at p + (i & 3) S + (i >> 2) 128 (two polling rounds of the BPTT's reduce-scatter: four senders S bytes apart, rounds 128 apart)
+template <int S> static inline void lv_agent_load_q4x8_rs(const char* p, uint4 (&v)[8]) {
+    const void* ps[8];
+    for (int i = 0; i < 8; ++i) ps[i] = p + (i & 3) * S + (i >> 2) * 128;
+    lv_agent_load_q4x8(ps, v);
 }
 static inline void lv_agent_store_q4(void* p, uint4 v) {
     unsigned* q = static_cast<unsigned*>(p);
@@ -436,6 +447,11 @@ __device__ __forceinline__ float lv_add_xor8(float x) {
 // (x.row1, y.row1, x.row3, y.row3), so their sum is x(l) + x(l + 16) in the even rows and y(l - 16) + y(l) in the odd rows
 // (lv_fold16); v_permlane32_swap does the same with the two halves of the wave (lv_fold32).  One swap + one add reduces TWO
 // registers by one butterfly level and leaves every lane with a sum nobody else holds.
+// the same step between the two halves of a 16-lane row: DPP row_ror:8 of both registers, the lane keeps the sum it is to own
+__device__ __forceinline__ float lv_fold8(float x, float y) {
+    const float xs = lv_add_xor8(x), ys = lv_add_xor8(y);
+    return (threadIdx.x & 8) ? ys : xs;
+}
 __device__ __forceinline__ float lv_fold16(float x, float y) {
     const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
@@ -464,6 +480,30 @@ __device__ __forceinline__ void lv_agent_load_q4x8(const void* const (&ps)[8], u
                  "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
                  : "v"(ps[0]), "v"(ps[1]), "v"(ps[2]), "v"(ps[3]), "v"(ps[4]), "v"(ps[5]), "v"(ps[6]), "v"(ps[7]) : "memory");
+    v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+    v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
+    v[4] = make_uint4(r4.x, r4.y, r4.z, r4.w); v[5] = make_uint4(r5.x, r5.y, r5.z, r5.w);
+    v[6] = make_uint4(r6.x, r6.y, r6.z, r6.w); v[7] = make_uint4(r7.x, r7.y, r7.z, r7.w);
+}
+// eight granules at p + (i & 3) S + (i >> 2) 128 (two polling rounds of the BPTT's reduce-scatter: four senders S bytes apart, rounds
+// 128 apart): ONE or TWO address registers pairs and immediate offsets (12 bits) instead of eight pointers
+template <int S> __device__ __forceinline__ void lv_agent_load_q4x8_rs(const char* p, uint4 (&v)[8]) {
+    static_assert(3 * S + 128 < 8192, "two address registers reach 8 KB");
+    const char* const ph = p + 4096;
+#define LV_RS_O(i) (((i) & 3) * S + ((i) >> 2) * 128)
+#define LV_RS_P(i) (LV_RS_O(i) < 4096 ? p : ph)
+    lv_u32x4v r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("global_load_dwordx4 %0, %8, off offset:%16 sc1\n\tglobal_load_dwordx4 %1, %9, off offset:%17 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off offset:%18 sc1\n\tglobal_load_dwordx4 %3, %11, off offset:%19 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off offset:%20 sc1\n\tglobal_load_dwordx4 %5, %13, off offset:%21 sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off offset:%22 sc1\n\tglobal_load_dwordx4 %7, %15, off offset:%23 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(LV_RS_P(0)), "v"(LV_RS_P(1)), "v"(LV_RS_P(2)), "v"(LV_RS_P(3)), "v"(LV_RS_P(4)), "v"(LV_RS_P(5)), "v"(LV_RS_P(6)), "v"(LV_RS_P(7)),
+                   "n"(LV_RS_O(0) & 4095), "n"(LV_RS_O(1) & 4095), "n"(LV_RS_O(2) & 4095), "n"(LV_RS_O(3) & 4095),
+                   "n"(LV_RS_O(4) & 4095), "n"(LV_RS_O(5) & 4095), "n"(LV_RS_O(6) & 4095), "n"(LV_RS_O(7) & 4095)
+                 : "memory");
+#undef LV_RS_O
+#undef LV_RS_P
     v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
     v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
     v[4] = make_uint4(r4.x, r4.y, r4.z, r4.w); v[5] = make_uint4(r5.x, r5.y, r5.z, r5.w);

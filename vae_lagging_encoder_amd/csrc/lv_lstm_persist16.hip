@@ -50,9 +50,9 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
 #ifndef LV_FWD_Q
 #define LV_FWD_Q 2                      // forward: h travels as 16-byte granules (four units, each dword = binary16 / bf16 bits under a 16-bit
 #endif                                  // tag of its own): 2 = every instantiation, 1 = the 4-row one only, 0: 8-byte granules (A/B builds)
-#ifndef LV_RS4_Q
-#define LV_RS4_Q 1                      // 4-row BPTT: the reduce-scatter's partial sums travel as 16-byte granules (rs4_*: four 30-bit
-#endif                                  // floats, 2 tag bits each); 0: the 8-byte granules of the 8- / 16-row instantiations (A/B builds)
+#ifndef LV_RS_Q
+#define LV_RS_Q 2                       // BPTT: the reduce-scatter's partial sums travel as 16-byte granules (rs4_*: four 30-bit floats, 2 tag
+#endif                                  // bits each): 2 = every instantiation, 1 = the 4-row one only, 0: 8-byte granules (A/B builds)
 #ifndef LV_P16_ABL
 #define LV_P16_ABL 0                    // measurement knob (profiles/microbench/lstm_anatomy_probe.py): WHAT-IF builds of the final
 #endif                                  // kernels with one phase of a timestep removed -- results are garbage, the time is the point.
@@ -314,9 +314,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                 const char* sq = reinterpret_cast<const char*>(hx_g + (long)(t & 1) * hx_par) + (64 * w + l) * 16;
                 const long rowb = (long)(PH / 2) * 8;
                 const uint32_t wq = tagq(t) << 16;
-#pragma unroll
-                for (int r0 = 0; r0 < RP; r0 += QR) {
-                    if (r0 >= rows) break;
+                auto round = [&](auto R0) {      // (a lambda per round: a loop over rounds around the polling loop is not unrolled)
+                    constexpr int r0 = decltype(R0)::value;
+                    if (r0 >= rows) return;
                     uint4 v[QR];
                     int spins = 0;
                     bool ok;
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                         if (r0 + j < rows)
                             *reinterpret_cast<uint2*>(&sm.hl[(r0 + j) * HP16 + 128 * w + 2 * l]) =
                                 make_uint2((v[j].x & 0xFFFFu) | (v[j].y << 16), (v[j].z & 0xFFFFu) | (v[j].w << 16));
-                }
+                };
+                round(lv_const<0>());
+                if constexpr (RP > QR) round(lv_const<QR>());
             } else
             for (int base = 0; base < nq; base += 64 * GJ) {
                 // every poll round issues ALL its loads before it looks at a tag (first build: a load and its tag test per granule
@@ -520,12 +522,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     }
 
     // owner pairs of this lane: batch beta = 2q + (l >> 5) -> batch row 4 beta + (p >> 2); unit from (w, p, granule half)
-    // (Q4, the 16-byte granules of the 4-row instantiation: the lanes with bit 3 clear own -- wave w receives granules 8w + (l & 7)
-    //  = (unit block w >> 1, row 2 (w & 1) + ((l & 7) >> 2), unit quad l & 3), and the transposing butterfly leaves the lane with
-    //  the quad's unit 2 ((l >> 4) & 1) + (l >> 5))
-    constexpr bool Q4 = RP == 4 && LV_RS4_Q != 0;
+    // (QB, 16-byte granules: a pair's 128 RP bytes are 8 RP granules, granule (unit block b, row c, unit quad rq) at (b RP + c) 4 + rq;
+    //  wave w receives the 2 RP granules from 2 RP w on in ROUNDS of eight (lane l: granule l & 7 of the round, senders
+    //  4 (l >> 3) + 0..3), and the transposing butterfly leaves the lane with unit 2 ((l >> 4) & 1) + (l >> 5) of its quad l & 3.
+    //  4 rows: one round, the lanes with bit 3 clear own (row 2 (w & 1) + ((l >> 2) & 1)); 8 / 16 rows: pair q of a lane comes from
+    //  round 2q + ((l >> 3) & 1), row (RP / 2)(w & 1) + 4q + 2 ((l >> 3) & 1) + ((l >> 2) & 1), and every lane owns.)
+    constexpr bool QB = LV_RS_Q == 2 || (RP == 4 && LV_RS_Q == 1);
+    constexpr bool Q4 = RP == 4 && QB;
     const int pp = l & 15;
-    const int uw = Q4 ? 16 * (w >> 1) + 4 * (l & 3) + 2 * ((l >> 4) & 1) + (l >> 5)
+    const int uw = QB ? 16 * (w >> 1) + 4 * (l & 3) + 2 * ((l >> 4) & 1) + (l >> 5)
                       : 16 * (w >> 1) + 4 * (pp & 3) + 2 * (w & 1) + ((l >> 4) & 1);
     const int punit = 32 * member + uw;
     const long BH = (long)B * PH;
@@ -535,8 +540,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int beta = 2 * q + (l >> 5);
-        prow[q] = Q4 ? 2 * (w & 1) + ((l & 7) >> 2) : 4 * beta + (pp >> 2);
-        own[q] = (Q4 ? !(l & 8) : beta < NB) && prow[q] < rows;
+        prow[q] = Q4 ? 2 * (w & 1) + ((l & 7) >> 2) : QB ? (RP / 2) * (w & 1) + 4 * q + 2 * ((l >> 3) & 1) + ((l >> 2) & 1) : 4 * beta + (pp >> 2);
+        own[q] = (Q4 ? !(l & 8) : QB ? true : beta < NB) && prow[q] < rows;
         pidx[q] = (long)(b0 + (own[q] ? prow[q] : 0)) * PH + punit;
         sg[q] = ((own[q] ? prow[q] : 0) * 32 + uw) * 4;
         sc[q] = R * 128 + (own[q] ? prow[q] : 0) * 32 + uw;
@@ -553,12 +558,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     gran_t* const tx4 = px_g + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS + 2 * (((l & 15) >> 2) & 1) * 4 * RP +
                         4 * (l & 3) + (l >> 4);
 
-    // Q4: a pair's 512 bytes are 32 granules of 16 bytes, granule (unit block b, row c, unit quad rq) at 16 b + 4 c + rq.  Receive:
-    // senders 4 (l >> 3) + j, granule 8w + (l & 7); send: lane position (l & 15) = c + 4 j of a merged chunk n4 carries the quad
-    // (row c, rq = l >> 4) of column block 4 n4 + j -> receiver 8w + 2 n4 + (j >> 1), unit block j & 1.
-    const char* const rx_q = reinterpret_cast<const char*>(px_g) + ((long)member * PMEMBERS + 4 * (l >> 3)) * SLOTS * 8 + (8 * w + (l & 7)) * 16;
-    char* const tx_q = reinterpret_cast<char*>(px_g) + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS * 8 +
-                       ((((l & 15) >> 2) & 1) * 16 + 4 * (l & 3) + (l >> 4)) * 16;
+    // QB receive: senders 4 (l >> 3) + j, granule 2 RP w + 8 round + (l & 7).  Send, 4 rows: lane position (l & 15) = c + 4 j of a
+    // merged chunk n4 carries the quad (row c, rq = l >> 4) of column block 4 n4 + j -> receiver 8w + 2 n4 + (j >> 1), unit block
+    // j & 1; 8 / 16 rows: lane (c = l & 15, rq = l >> 4) sends the quad of column block nb to receiver 8w + (nb >> 1), unit block nb & 1.
+    const char* const rx_q = reinterpret_cast<const char*>(px_g) + ((long)member * PMEMBERS + 4 * (l >> 3)) * SLOTS * 8 + (2 * RP * w + (l & 7)) * 16;
+    char* const tx_q = RP == 4 ? reinterpret_cast<char*>(px_g) + ((long)(8 * w + (((l & 15) >> 2) >> 1)) * PMEMBERS + member) * SLOTS * 8 +
+                                     ((((l & 15) >> 2) & 1) * 16 + 4 * (l & 3) + (l >> 4)) * 16
+                               : reinterpret_cast<char*>(px_g) + ((long)(8 * w) * PMEMBERS + member) * SLOTS * 8 + (4 * (l & 15) + (l >> 4)) * 16;
     float dc_rec[NP], gsum[NP][4];
     float dhb[NP][SBK], ctb[NP][SBK + 1];
     float4 recb[NP][SBK];
@@ -680,8 +686,44 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
         dh_rec[0] = lv_fold32(lv_fold16(a, c), lv_fold16(b, d));      // lane (half h, row parity rp): component 2 rp + h
         return true;
     };
+    // 8 / 16 rows: polls of TWO rounds (8 granules per lane in flight, one statement); the first butterfly step transposes too
+    // (lv_fold8: the lanes with bit 3 clear keep the first round's sums, the others the second's), so every lane ends with a total
+    // of its own -- pair q of the lane from the poll q.
+    auto receive_q8 = [&](int k, float (&dh_rec)[NP]) -> bool {
+        const char* src = rx_q + (long)(k & 1) * px_par * 8;
+        const uint32_t want = rs4_tag(k);
+        auto one = [&](auto Q) -> bool {
+            constexpr int q = decltype(Q)::value;
+            uint4 u[8];
+            int spins = 0;
+            bool ok;
+            do {
+                lv_agent_load_q4x8_rs<SLOTS * 8>(src + 256 * q, u);      // rounds 2q, 2q + 1: granules 16q + 8 (i >> 2) on, senders i & 3
+                ok = (LV_P16_ABL & 2) ? true : rs4_all_tagged(u, want);
+                ok = __all(ok);
+                if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+            } while (!ok);
+            LV_TRACE_ONLY(tr_spins[q ? 1 : 0] = spins;)
+            float a[2], b[2], c[2], d[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                a[r] = b[r] = c[r] = d[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[r] += rs4_val(u[4 * r + j].x); b[r] += rs4_val(u[4 * r + j].y);
+                    c[r] += rs4_val(u[4 * r + j].z); d[r] += rs4_val(u[4 * r + j].w);
+                }
+            }
+            dh_rec[q] = lv_fold32(lv_fold16(lv_fold8(a[0], a[1]), lv_fold8(c[0], c[1])), lv_fold16(lv_fold8(b[0], b[1]), lv_fold8(d[0], d[1])));
+            return true;
+        };
+        if (!one(lv_const<0>())) return false;
+        if constexpr (NP > 1) { if (!one(lv_const<1>())) return false; }
+        return true;
+    };
     auto receive = [&](int k, float (&dh_rec)[NP]) -> bool {
         if constexpr (Q4) return receive_q4(k, dh_rec);
+        else if constexpr (QB) return receive_q8(k, dh_rec);
         const gran_t* src = rx + (long)(k & 1) * px_par;
         const uint32_t want = rs_tag(k);
 #pragma unroll
@@ -773,6 +815,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                 gran_t* d = dst4 + (long)(2 * n4) * PMEMBERS * SLOTS;
                 put(d, rs_pack(m[0], m[1], tag));
                 put(d + 4 * RP, rs_pack(m[2], m[3], tag));
+                }
+            } else if constexpr (QB) {
+                if ((l & 15) < RP) {
+                    const uint32_t t4 = rs4_tag(k);
+                    char* d0 = tx_q + (long)(k & 1) * px_par * 8;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int nb = 4 * n4 + j;
+                        char* d = d0 + (long)(nb >> 1) * PMEMBERS * SLOTS * 8 + (nb & 1) * RP * 4 * 16;
+                        const uint4 g = make_uint4(rs4_pack(acc[j][0], t4), rs4_pack(acc[j][1], t4), rs4_pack(acc[j][2], t4), rs4_pack(acc[j][3], t4));
+                        if (LOCAL) lv_xcd_store_q4(d, g); else lv_agent_store_q4(d, g);
+                    }
                 }
             } else if ((l & 15) < RP) {
 #pragma unroll

@@ -54,12 +54,12 @@ __device__ __forceinline__ float rs4_val(uint32_t g) {
     memcpy(&f, &u, 4);
     return f;
 }
-// all sixteen dwords of four granules carry tag `want`
-__device__ __forceinline__ bool rs4_all_tagged(const uint4 (&v)[4], uint32_t want) {
+// all dwords of N granules carry tag `want`
+template <int N> __device__ __forceinline__ bool rs4_all_tagged(const uint4 (&v)[N], uint32_t want) {
     const uint32_t w = want << 30;
     uint32_t x = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x |= (v[j].x ^ w) | (v[j].y ^ w) | (v[j].z ^ w) | (v[j].w ^ w);
+    for (int j = 0; j < N; ++j) x |= (v[j].x ^ w) | (v[j].y ^ w) | (v[j].z ^ w) | (v[j].w ^ w);
     return (x >> 30) == 0u;
 }
 
