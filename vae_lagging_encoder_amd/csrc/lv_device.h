@@ -169,6 +169,12 @@ static inline void lv_agent_load_q4x8(const void* const (&ps)[8], uint4 (&v)[8])
                           __atomic_load_n(q + 2, __ATOMIC_RELAXED), __atomic_load_n(q + 3, __ATOMIC_RELAXED));
     }
 }
+// eight granules 4 KB apart (one per row of the forward's h exchange)
+static inline void lv_agent_load_q4x8_rows(const char* p, uint4 (&v)[8]) {
+    const void* ps[8];
+    for (int i = 0; i < 8; ++i) ps[i] = p + i * 4096;
+    lv_agent_load_q4x8(ps, v);
+}
 // eight granules at p + (i & 3) S + (i >> 2) 128 (two polling rounds of the BPTT's reduce-scatter: four senders S bytes apart, rounds 128 apart)
 template <int S> static inline void lv_agent_load_q4x8_rs(const char* p, uint4 (&v)[8]) {
     const void* ps[8];
@@ -480,6 +486,22 @@ __device__ __forceinline__ void lv_agent_load_q4x8(const void* const (&ps)[8], u
                  "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
                  : "v"(ps[0]), "v"(ps[1]), "v"(ps[2]), "v"(ps[3]), "v"(ps[4]), "v"(ps[5]), "v"(ps[6]), "v"(ps[7]) : "memory");
+    v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
+    v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
+    v[4] = make_uint4(r4.x, r4.y, r4.z, r4.w); v[5] = make_uint4(r5.x, r5.y, r5.z, r5.w);
+    v[6] = make_uint4(r6.x, r6.y, r6.z, r6.w); v[7] = make_uint4(r7.x, r7.y, r7.z, r7.w);
+}
+// eight granules 4 KB apart (one per row of the forward's h exchange): four address register pairs, each reaching its row and the
+// one below it through the signed 13-bit immediate
+__device__ __forceinline__ void lv_agent_load_q4x8_rows(const char* p, uint4 (&v)[8]) {
+    const char *p1 = p + 4096, *p3 = p + 3 * 4096, *p5 = p + 5 * 4096, *p7 = p + 7 * 4096;
+    lv_u32x4v r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("global_load_dwordx4 %0, %8, off offset:-4096 sc1\n\tglobal_load_dwordx4 %1, %8, off sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off offset:-4096 sc1\n\tglobal_load_dwordx4 %3, %9, off sc1\n\t"
+                 "global_load_dwordx4 %4, %10, off offset:-4096 sc1\n\tglobal_load_dwordx4 %5, %10, off sc1\n\t"
+                 "global_load_dwordx4 %6, %11, off offset:-4096 sc1\n\tglobal_load_dwordx4 %7, %11, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(p1), "v"(p3), "v"(p5), "v"(p7) : "memory");
     v[0] = make_uint4(r0.x, r0.y, r0.z, r0.w); v[1] = make_uint4(r1.x, r1.y, r1.z, r1.w);
     v[2] = make_uint4(r2.x, r2.y, r2.z, r2.w); v[3] = make_uint4(r3.x, r3.y, r3.z, r3.w);
     v[4] = make_uint4(r4.x, r4.y, r4.z, r4.w); v[5] = make_uint4(r5.x, r5.y, r5.z, r5.w);

@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
             const uint32_t want = (uint32_t)(t + 1);
             if constexpr (QF) {
                 // lane l takes granule 64w + l (k = 256w + 4l .. + 3) of each of the slice's rows -- every load instruction reads 1 KB
-                // of one row -- in polling rounds of 4 (4-row instantiation) or 8 rows; rows the slice does not have re-read row 0 and
-                // are neither tested nor staged
+                // of one row -- in polling rounds of 4 (4-row instantiation) or 8 rows; rows the slice does not have are neither tested
+                // nor staged
                 constexpr int QR = RP == 4 ? 4 : 8;
                 const char* sq = reinterpret_cast<const char*>(hx_g + (long)(t & 1) * hx_par) + (64 * w + l) * 16;
                 const long rowb = (long)(PH / 2) * 8;
@@ -324,10 +324,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                         if constexpr (QR == 4)
                             lv_agent_load_q4x4(sq, sq + (rows > 1 ? rowb : 0), sq + (rows > 2 ? 2 * rowb : 0), sq + (rows > 3 ? 3 * rowb : 0), v);
                         else {
-                            const void* ps[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) ps[j] = sq + (r0 + j < rows ? (r0 + j) * rowb : 0);
-                            lv_agent_load_q4x8(ps, reinterpret_cast<uint4 (&)[8]>(v));
+                            // (rows the slice does not have are loaded from their own -- allocated, unused -- rows of the exchange)
+                            static_assert((PH / 2) * 8 == 4096, "lv_agent_load_q4x8_rows: rows 4 KB apart");
+                            lv_agent_load_q4x8_rows(sq + r0 * rowb, reinterpret_cast<uint4 (&)[8]>(v));
                         }
                         uint32_t x = 0u;
 #pragma unroll
