@@ -535,9 +535,12 @@ __device__ __forceinline__ void lv_agent_store_q4(void* p, uint4 v) {
     const lv_u32x4v d = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
+#ifndef LV_XCD_ST_MODS
+#define LV_XCD_ST_MODS ""                   // measurement knob: cache-policy bits of the XCD-local granule store (" nt", " sc0", ...)
+#endif
 __device__ __forceinline__ void lv_xcd_store_q4(void* p, uint4 v) {
     const lv_u32x4v d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" LV_XCD_ST_MODS "\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
 // DPP row_shr with a bank mask (v_mov_b32_dpp row_shr:SHIFT bank_mask:1 << BANK): lanes of bank BANK (lanes 4 BANK .. 4 BANK + 3 of
 // every 16-lane row) take src from the lane SHIFT positions lower in their row, every other lane keeps old.  Merges the valid
