@@ -60,35 +60,13 @@ extern "C" int lv_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(
                                         // local pipeline alone); bit 2: no transcendental cell / gate-gradient math; bit 3: no
                                         // LDS quarter-sum exchange + barrier (forward) / dG image barrier (BPTT); bit 4 (forward): the
                                         // gathered granules are not staged through LDS (fragments straight from the poll registers);
-                                        // bit 5 (forward): the granules are not loaded at all; bit 6 (BPTT): the partial-sum
-                                        // exchange moved as 16-byte accesses (half as many load / store instructions, same bytes)
+                                        // bit 5 (forward): the granules are not loaded at all (bits 4, 5: builds with LV_FWD_Q = 0 only)
 
 namespace {
 
 using namespace lvp;
 
 __device__ __forceinline__ float abl_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }      // (what-if builds only)
-#if !defined(LV_EMU) && (LV_P16_ABL & 64)
-typedef uint32_t abl_u32x4 __attribute__((ext_vector_type(4)));
-// (what-if builds only: N 16-byte L2-served loads and the wait for them in ONE statement -- the compiler does not know that an
-// inline-assembly load lands later, and would reuse its destination registers before it has)
-__device__ __forceinline__ void abl_load16x4(const char* q0, const char* q1, const char* q2, const char* q3, abl_u32x4 (&v)[4]) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(q0), "v"(q1), "v"(q2), "v"(q3) : "memory");
-}
-__device__ __forceinline__ void abl_load16x8(const char* q0, const char* q1, const char* q2, const char* q3, long d, abl_u32x4 (&v)[8]) {
-    const char *r0 = q0 + d, *r1 = q1 + d, *r2 = q2 + d, *r3 = q3 + d;
-    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
-                 "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-                 "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
-}
-__device__ __forceinline__ void abl_store16(void* q, abl_u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(q), "v"(v) : "memory");
-}
-#endif
 
 constexpr int HP16 = PH / 2 + 8;        // dwords per row of the gathered h image (130 slots: = 2 mod 16)
 constexpr int DP16 = 64 + 8;            // dwords per row of the dG image (18 slots)
@@ -613,27 +591,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
     LV_TRACE_ONLY(int tr_spins[2] = {0, 0};)
     auto receive_round = [&](auto H0, const gran_t* src, uint32_t want, float (&dh_rec)[NP]) -> bool {
         constexpr int h0 = decltype(H0)::value;
-#if !defined(LV_EMU) && (LV_P16_ABL & 64)
-        {   // what-if: the round's granules as 16-byte loads -- 8 lanes x 16 B per batch and sender, sender 4 (l >> 3) + j
-            abl_u32x4 u[HB * 4];
-            const char* base16 = reinterpret_cast<const char*>(src - (8 * (l >> 4)) * (long)SLOTS - pp) + (long)(4 * (l >> 3)) * SLOTS * 8 + 16 * (l & 7) +
-                                 (long)16 * h0 * 8;
-            if constexpr (HB == 1) abl_load16x4(base16, base16 + (long)SLOTS * 8, base16 + (long)2 * SLOTS * 8, base16 + (long)3 * SLOTS * 8, u);
-            else abl_load16x8(base16, base16 + (long)SLOTS * 8, base16 + (long)2 * SLOTS * 8, base16 + (long)3 * SLOTS * 8, 16 * 8, u);
-#pragma unroll
-            for (int bt = 0; bt < HB; ++bt) {
-                float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { a += abl_u2f(u[4 * bt + j].x << 2); b += abl_u2f(u[4 * bt + j].y << 2); c += abl_u2f(u[4 * bt + j].z << 2); d += abl_u2f(u[4 * bt + j].w << 2); }
-                a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64); c += __shfl_xor(c, 8, 64); d += __shfl_xor(d, 8, 64);
-                a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64); d += __shfl_xor(d, 16, 64);
-                a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64); c += __shfl_xor(c, 32, 64); d += __shfl_xor(d, 32, 64);
-                if ((l >> 5) == ((h0 + bt) & 1)) dh_rec[(h0 + bt) >> 1] = (l & 16) ? ((l & 8) ? d : c) : ((l & 8) ? b : a);
-            }
-            (void)want;
-            return true;
-        }
-#endif
         gran_t v[HB][8];
         int spins = 0;
         bool ok;
@@ -766,33 +723,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                                      : lv_mfma_16x16x32_bf16_areg(wreg[ks][4 * n4 + j], bfr[ks], acc[j]);
         };
         auto chunk_send = [&](int n4, const f32x4 (&acc)[4]) {
-#if !defined(LV_EMU) && (LV_P16_ABL & 64)
-            {   // what-if: a lane's four consecutive units of one row leave as ONE 16-byte store (30-bit floats + 2 tag bits each)
-                char* pair0 = reinterpret_cast<char*>(px_g + (long)(k & 1) * px_par);
-                auto q30 = [&](float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 2) | (tag << 30); };
-                if constexpr (RP == 4) {
-                    float m[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        m[r] = acc[0][r];
-                        m[r] = lv_row_shr_into<4, 1>(m[r], acc[1][r]);
-                        m[r] = lv_row_shr_into<8, 2>(m[r], acc[2][r]);
-                        m[r] = lv_row_shr_into<12, 3>(m[r], acc[3][r]);
-                    }
-                    const int jj = (l & 15) >> 2;
-                    char* d = pair0 + ((long)(8 * w + 2 * n4 + (jj >> 1)) * PMEMBERS + member) * SLOTS * 8 + ((jj & 1) * 16 + 4 * (l & 3) + (l >> 4)) * 16;
-                    abl_store16(d, abl_u32x4{q30(m[0]), q30(m[1]), q30(m[2]), q30(m[3])});
-                } else if ((l & 15) < RP) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int nb = 4 * n4 + j;
-                        char* d = pair0 + ((long)(8 * w + (nb >> 1)) * PMEMBERS + member) * SLOTS * 8 + ((nb & 1) * 4 * RP + 4 * (l & 15) + (l >> 4)) * 16;
-                        abl_store16(d, abl_u32x4{q30(acc[j][0]), q30(acc[j][1]), q30(acc[j][2]), q30(acc[j][3])});
-                    }
-                }
-                return;
-            }
-#endif
             if constexpr (RP == 4) {
                 // Only lanes 0..3 of every 16-lane row hold batch rows at RP = 4: the four column blocks' quarter-rows are merged
                 // into ONE fully populated register set (DPP row_shr into banks 1..3), so that this chunk goes out as 2 full-wave
