@@ -38,6 +38,11 @@ def test_cvt_bf16(emu_backend, R, C):
     K.test_cvt_bf16(emu_backend, CPU, R, C)
 
 
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 52), ("gates", 4 * 24, 40), ("lo_gates", 4 * 20, 36), ("h16", 203, 64)])
+def test_cvt_16_byte_form(emu_backend, mode, R, C):
+    K.test_cvt_16_byte_form(emu_backend, CPU, mode, R, C)
+
+
 @pytest.mark.parametrize("cfg", [(8, 16, 3), (50, 33, 1)])
 def test_gate_interleave_and_gate_weight_image(emu_backend, cfg):
     K.test_gate_interleave_and_gate_weight_image(emu_backend, CPU, *cfg)

@@ -102,6 +102,44 @@ def test_cvt_bf16(lib, hip_device, R, C):
     assert torch.equal(only_t.cpu()[:, :R], want.t())
 
 
+@pytest.mark.parametrize("mode,R,C", [("plain", 70, 52), ("plain", 131, 128), ("gates", 4 * 24, 40), ("lo", 66, 68), ("lo_gates", 4 * 20, 36),
+                                      ("h16", 203, 64), ("h16_gates", 4 * 17, 132)])
+def test_cvt_16_byte_form(lib, hip_device, mode, R, C):
+    """The conversions on operands that allow the 16-byte form of the kernel (C % 4 == 0, strides % 4 == 0: cvt_b16_v4_kernel -- one
+    float4 load and one 8-byte store per four elements, transposed image as 8-byte stores of four rows): every variant bit for bit
+    against torch, ragged R (tail of the transposed rows), padding untouched.  (Odd strides -- the tests above -- take cvt_b16_kernel.)"""
+    dev = hip_device
+    g = torch.Generator().manual_seed(R * 7 + C)
+    lds, ldd, ldt = C + 4, C + 8, (R + 3) // 4 * 4 + 4
+    src = torch.randn(R, lds, generator=g) * 3.0
+    src[0, 0] = 1.00390625
+    rows = src[:, :C]
+    bf = rows.to(torch.bfloat16)
+    gates = mode.endswith("gates")
+    H = R // 4
+    perm = torch.arange(4 * H).view(4, H).t().reshape(-1) if gates else None
+    d = torch.full((R, ldd), 0x1234, dtype=torch.int16, device=dev)
+    dT = torch.full((C, ldt), 0x1234, dtype=torch.int16, device=dev)
+    sd = src.to(dev)
+    if mode in ("plain",):
+        lib.lv_cvt_bf16_f32(P(sd), lds, R, C, P(d), ldd, P(dT), ldt, _s(dev))
+        want_d = want_t = bf.view(torch.int16)
+    elif mode == "gates":
+        lib.lv_cvt_bf16_gates_f32(P(sd), lds, H, C, P(d), ldd, P(dT), ldt, _s(dev))
+        want_t = bf.view(torch.int16); want_d = want_t[perm]
+    elif mode.startswith("lo"):
+        lib.lv_cvt_bf16_lo_f32(P(sd), lds, R, C, H if gates else 0, None, 0, 1, 0, P(d), ldd, P(dT), ldt, _s(dev))
+        want_t = (rows - bf.float()).to(torch.bfloat16).view(torch.int16); want_d = want_t[perm] if gates else want_t
+    else:
+        lib.lv_cvt_h16_f32(P(sd), lds, R, C, H if gates else 0, None, 0, 1, 0, P(d), ldd, P(dT), ldt, _s(dev))
+        want_t = bf.view(torch.int16)
+        want_d = rows.clamp(-65504.0, 65504.0).to(torch.float16).view(torch.int16)
+        if gates: want_d = want_d[perm]
+    assert torch.equal(d.cpu()[:, :C], want_d)
+    assert torch.equal(dT.cpu()[:, :R], want_t.t())
+    assert bool((d.cpu()[:, C:] == 0x1234).all()) and bool((dT.cpu()[:, R:] == 0x1234).all())
+
+
 @pytest.mark.parametrize("mode,R,C", [("plain", 70, 50), ("plain", 64, 128), ("gates", 4 * 24, 40), ("gather", 5 * 7, 33)])
 def test_cvt_bf16_lo(lib, hip_device, mode, R, C):
     """lv_cvt_bf16_lo_f32: the low half of a split-bf16 operand, bit for bit bf16(x - bf16(x)), in the plain, gate-interleaved and

@@ -1902,6 +1902,110 @@ __global__ __launch_bounds__(256) void cvt_b16_kernel(const float* __restrict__ 
     }
 }
 
+
+// The same conversion with 16-byte loads and 8-byte stores: lane (row-in-pass t >> 4, column quad t & 15) takes four CONSECUTIVE
+// columns of its rows (one float4 load, one 4-byte mask load, one 8-byte store of the row image), and the transposed image leaves as
+// 8-byte stores of four consecutive rows of a column.  A vector-memory instruction costs the address unit a quad of lanes per cycle
+// whatever its width (the lesson of the persistent recurrences' hand-off): the 4-byte loads / 2-byte stores
+// of cvt_b16_kernel kept a CU at 8-16 bytes per cycle -- 48 instructions per thread and tile here become 12.  Same arguments, same
+// arithmetic, bit-identical images.  Needs C % 4 == 0 and 16- / 8-byte aligned rows (cvt_launch falls back to cvt_b16_kernel).
+__global__ __launch_bounds__(256) void cvt_b16_v4_kernel(const float* __restrict__ src, long lds_, int R, int C,
+                                                         uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long ldt,
+                                                         int gate_H, const uint8_t* __restrict__ keep, float kscale, int Bsz,
+                                                         const int64_t* __restrict__ gids, long gstride, int gV, int lo) {
+    __shared__ __attribute__((aligned(8))) uint16_t tile[64][68];      // pitch 136 bytes: 8-byte aligned rows
+    const int t = (int)threadIdx.x;
+    const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64;
+    const int q = t >> 4, cl = t & 15;
+    const bool tb = keep || gids;
+    const int Tt = tb ? R / Bsz : 1;
+    int bb = tb ? (r0 + q) % Bsz : 0, tt = tb ? (r0 + q) / Bsz : 0;
+    const int gc = c0 + 4 * cl;
+    const int gcc = gc < C ? gc : C - 4;                  // clamped column quad (C % 4 == 0, C >= 4)
+    int grs[4], bbs[4], tts[4];
+    long sr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        grs[u] = r0 + q + 16 * u;
+        bbs[u] = bb; tts[u] = tt;
+        if (tb) {
+            bb += 16;
+            while (bb >= Bsz) { bb -= Bsz; ++tt; }
+        }
+        sr[u] = grs[u] < R ? grs[u] : R - 1;
+    }
+    if (gids) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sr[u] = gids[(long)bbs[u] * gstride + (grs[u] < R ? tts[u] : 0)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sr[u] = sr[u] < 0 ? 0 : (sr[u] >= gV ? gV - 1 : sr[u]);
+    }
+    float4 v[4];
+    uint32_t kp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + sr[u] * lds_ + gcc);
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            kp[u] = *reinterpret_cast<const uint32_t*>(keep + ((long)bbs[u] * Tt + (grs[u] < R ? tts[u] : 0)) * C + gcc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int gr = grs[u];
+        uint16_t b[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+        const bool in = gr < R && gc < C;
+        if (in) {
+            const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = xs[e];
+                if (keep) {
+                    const bool k = (kp[u] >> (8 * e)) & 0xFFu;
+                    if (gids) x = k ? x * kscale : 0.f;
+                    else x *= k ? kscale : 0.f;
+                }
+                b[e] = (uint16_t)lv_f32_to_bf16_bits(x);
+                if (lo == 1) b[e] = (uint16_t)lv_f32_to_bf16_bits(x - lv_bf16_bits_to_f32(b[e]));
+                d[e] = lo == 2 ? lv_f32_to_f16_bits(lv_sat_f16(x)) : b[e];
+            }
+            if (dst) {
+                const long dr = gate_H > 0 ? (long)(gr % gate_H) * 4 + gr / gate_H : gr;
+                *reinterpret_cast<uint2*>(dst + dr * ldd + gc) = make_uint2((uint32_t)d[0] | ((uint32_t)d[1] << 16), (uint32_t)d[2] | ((uint32_t)d[3] << 16));
+            }
+        }
+        *reinterpret_cast<uint2*>(&tile[q + 16 * u][4 * cl]) = make_uint2((uint32_t)b[0] | ((uint32_t)b[1] << 16), (uint32_t)b[2] | ((uint32_t)b[3] << 16));
+    }
+    if (!dstT) return;
+    __syncthreads();
+    // transposed image: lane (column-in-pass t >> 4, row quad t & 15) stores rows 4 rl .. 4 rl + 3 of column c
+    const int rl = t & 15, gr = r0 + 4 * rl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = q + 16 * i, gct = c0 + c;
+        const uint16_t e0 = tile[4 * rl][c], e1 = tile[4 * rl + 1][c], e2 = tile[4 * rl + 2][c], e3 = tile[4 * rl + 3][c];
+        if (gct < C) {
+            uint16_t* o = dstT + (long)gct * ldt + gr;
+            if (gr + 3 < R) *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)e0 | ((uint32_t)e1 << 16), (uint32_t)e2 | ((uint32_t)e3 << 16));
+            else {
+                if (gr < R) o[0] = e0;
+                if (gr + 1 < R) o[1] = e1;
+                if (gr + 2 < R) o[2] = e2;
+            }
+        }
+    }
+}
+
+// picks the 16-byte form where the operands allow it
+static void cvt_launch(void* stream, const float* src, long lds, int R, int C, uint16_t* dst, long ldd, uint16_t* dstT, long ldt, int gate_H,
+                       const uint8_t* keep, float kscale, int Bsz, const int64_t* gids, long gstride, int gV, int lo) {
+    const dim3 grid((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), block(256);
+    const bool v4 = C >= 4 && C % 4 == 0 && lds % 4 == 0 && (((uintptr_t)src) & 15) == 0 &&
+                    (!dst || (ldd % 4 == 0 && (((uintptr_t)dst) & 7) == 0)) && (!dstT || (ldt % 4 == 0 && (((uintptr_t)dstT) & 7) == 0)) &&
+                    (!keep || (((uintptr_t)keep) & 3) == 0);
+    if (v4) LV_LAUNCH(cvt_b16_v4_kernel, grid, block, 0, stream, src, lds, R, C, dst, ldd, dstT, ldt, gate_H, keep, kscale, Bsz, gids, gstride, gV, lo);
+    else LV_LAUNCH(cvt_b16_kernel, grid, block, 0, stream, src, lds, R, C, dst, ldd, dstT, ldt, gate_H, keep, kscale, Bsz, gids, gstride, gV, lo);
+}
+
 }  // namespace
 
 // ---- tile selection ------------------------------------------------------------------------------------------------------
@@ -2239,7 +2343,7 @@ extern "C" int lv_cvt_bf16_f32(const float* src, long lds, int R, int C, uint16_
     if (!src || (!dst && !dstT)) return LV_ERR_ARG;
     if (R < 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+    cvt_launch(stream, src, lds, R, C,
               dst, ldd, dstT, ldt, 0, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -2253,7 +2357,7 @@ extern "C" int lv_cvt_bf16_keep_f32(const float* src, long lds, int T, int Bsz, 
     const long R = (long)T * Bsz;
     if (T < 0 || Bsz <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, (int)R, C,
+    cvt_launch(stream, src, lds, (int)R, C,
               dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -2269,7 +2373,7 @@ extern "C" int lv_embed_gather_b16(const float* emb, const int64_t* ids, long id
     const long R = (long)T * Bsz;
     if (T < 0 || Bsz <= 0 || C < 0 || V <= 0 || (dst && ldd < C) || (dstT && ldt < R)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, emb, (long)C, (int)R, C,
+    cvt_launch(stream, emb, (long)C, (int)R, C,
               dst, ldd, dstT, ldt, 0, keep, kscale, Bsz, ids, ids_stride, V, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -2282,7 +2386,7 @@ extern "C" int lv_cvt_bf16_gates_f32(const float* src, long lds, int H, int C, u
     if (!src || (!dst && !dstT)) return LV_ERR_ARG;
     if (H <= 0 || C < 0 || lds < C || (dst && ldd < C) || (dstT && ldt < 4 * H)) return LV_ERR_SHAPE;
     if (C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(4 * H, 64)), dim3(256), 0, stream, src, lds, 4 * H, C,
+    cvt_launch(stream, src, lds, 4 * H, C,
               dst, ldd, dstT, ldt, H, (const uint8_t*)nullptr, 1.f, 1, (const int64_t*)nullptr, 0L, 0, 0);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -2303,7 +2407,7 @@ extern "C" int lv_cvt_bf16_lo_f32(const float* src, long lds, int R, int C, int 
     if (gate_H > 0 && (R != 4 * gate_H || ids)) return LV_ERR_ARG;
     if (ids && (Bsz <= 0 || V <= 0 || R % Bsz != 0)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+    cvt_launch(stream, src, lds, R, C,
               dst, ldd, dstT, ldt, gate_H > 0 ? gate_H : 0, (const uint8_t*)nullptr, 1.f, ids ? Bsz : 1, ids, ids_stride, ids ? V : 0, 1);
     LV_CHECK_LAUNCH();
     return LV_OK;
@@ -2321,7 +2425,7 @@ extern "C" int lv_cvt_h16_f32(const float* src, long lds, int R, int C, int gate
     if (gate_H > 0 && (R != 4 * gate_H || ids)) return LV_ERR_ARG;
     if (ids && (Bsz <= 0 || V <= 0 || R % Bsz != 0)) return LV_ERR_SHAPE;
     if (R == 0 || C == 0) return LV_OK;
-    LV_LAUNCH(cvt_b16_kernel, dim3((unsigned)lv_cdiv(C, 64), (unsigned)lv_cdiv(R, 64)), dim3(256), 0, stream, src, lds, R, C,
+    cvt_launch(stream, src, lds, R, C,
               dst, ldd, dstT, ldt, gate_H > 0 ? gate_H : 0, (const uint8_t*)nullptr, 1.f, ids ? Bsz : 1, ids, ids_stride, ids ? V : 0, 2);
     LV_CHECK_LAUNCH();
     return LV_OK;
