@@ -182,9 +182,15 @@ __global__ __launch_bounds__(256) void softmax_nll_merge_kernel(const float2* __
     const int l = (int)threadIdx.x & 63;
     if (r >= R) return;
     float m = -INFINITY, s = 0.f;
-    for (int i = l; i < nparts; i += 64) {
-        const float2 q = part[(long)r * nparts + i];
-        ms_merge(m, s, q.x, q.y);
+    // eight pieces per lane in flight (512 per round: one round at any vocabulary below 32 768), from clamped addresses, merged in
+    // the same order as one by one -- load -> merge per piece was a chain of nparts / 64 memory round trips (9.6 us at V = 20001)
+    for (int i0 = l; i0 < nparts; i0 += 512) {
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = part[(long)r * nparts + (i0 + 64 * u < nparts ? i0 + 64 * u : nparts - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 64 * u < nparts) ms_merge(m, s, q[u].x, q[u].y);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
