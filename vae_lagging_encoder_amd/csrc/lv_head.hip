@@ -12,6 +12,38 @@
 
 namespace {
 
+// Staging loop with its loads IN FLIGHT TOGETHER: element i of n comes from src(i) -- a valid address for every i < n -- and goes to
+// put(i, value).  Eight elements per thread and round trip, the loads from clamped indices and unconditional; written as a plain
+// `for (i = tid; i < n; i += 256) put(i, *src(i))` hipcc keeps one load -> wait -> LDS store per iteration whenever the trip count is
+// a runtime value (dec_tail_bwd_kernel: 8 + 2 + 1 dependent memory round trips in its three staging loops, half of its 21 us).
+// sum_i a(i) b(i) as TWO fma chains (even i, odd i) added at the end -- the order every dot product of this file has used -- with the
+// factors of eight terms read (from LDS) before their fmas: a runtime-length loop of `read, read, fma` waits for the LDS after every
+// pair (dec_tail_bwd_kernel: 2 x 6 us of LDS latency in its two contraction loops).
+template <class FA, class FB> __device__ __forceinline__ float dot2_batched(int n, FA a, FB b) {
+    float s0 = 0.f, s1 = 0.f;
+    int i = 0;
+    for (; i + 7 < n; i += 8) {
+        float x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = a(i + u); y[u] = b(i + u); }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { s0 = fmaf(x[u], y[u], s0); s1 = fmaf(x[u + 1], y[u + 1], s1); }
+    }
+    for (; i + 1 < n; i += 2) { s0 = fmaf(a(i), b(i), s0); s1 = fmaf(a(i + 1), b(i + 1), s1); }
+    if (i < n) s0 = fmaf(a(i), b(i), s0);
+    return s0 + s1;
+}
+
+template <class Src, class Put> __device__ __forceinline__ void stage_batched(int n, int tid, Src src, Put put) {
+    for (int i0 = tid; i0 < n; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = *src(i < n ? i : n - 1); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; if (i < n) put(i, v[u]); }
+    }
+}
+
 // ---- encoder head forward: mulv = h_T . W_lin^T ; z = mu + eps*exp(lv/2) ; KL = 0.5*sum(mu^2 + exp(lv) - lv - 1) -------
 // one workgroup per batch row; a wave owns outputs o = w, w+4, ... and keeps 16 of them in flight (independent loads)
 __global__ __launch_bounds__(256) void enc_head_fwd_kernel(const float* __restrict__ hT, const float* __restrict__ wlin,
@@ -85,21 +117,35 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
     const long pstride = (long)B * ns * nz;
     // staging loads are UNCONDITIONAL (clamped column, the value dropped by a select afterwards): a load behind a condition is
     // waited for right behind its issue, which turns a staging loop into a chain of memory round trips
-    for (int i = tid; i < nz2 * HB_COLS; i += 256) {
-        const int j = i / HB_COLS, c = i % HB_COLS;
-        const float v = wlin[(long)j * H + (h0 + c < H ? h0 + c : H - 1)];
-        sw[i] = h0 + c < H ? v : 0.f;
-    }
-    for (int i = tid; i < B * HB_COLS; i += 256) {
-        const int bb = i / HB_COLS, c = i % HB_COLS;
-        const float v = hT[(long)bb * H + (h0 + c < H ? h0 + c : H - 1)];
-        shh[i] = h0 + c < H ? v : 0.f;
-    }
+    stage_batched(nz2 * HB_COLS, tid,
+                  [&](int i) { const int j = i / HB_COLS, c = i % HB_COLS; return wlin + (long)j * H + (h0 + c < H ? h0 + c : H - 1); },
+                  [&](int i, float v) { sw[i] = h0 + i % HB_COLS < H ? v : 0.f; });
+    stage_batched(B * HB_COLS, tid,
+                  [&](int i) { const int bb = i / HB_COLS, c = i % HB_COLS; return hT + (long)bb * H + (h0 + c < H ? h0 + c : H - 1); },
+                  [&](int i, float v) { shh[i] = h0 + i % HB_COLS < H ? v : 0.f; });
     // dz = sum of the partial sums (in order), staged in LDS first
     float* sg = shh + B * HB_COLS;                         // [B*ns*nz] summed dz
     const int ne = B * ns * nz;
     // (two elements x 32 parts = 64 independent loads per thread and round trip: with 8 in flight the 80 parts of the decoder tail
     //  were 40 dependent round trips per thread, 20 of this kernel's 30 us)
+    // 16-byte form (four consecutive elements per thread and part, 16 parts in flight): a quarter of the load instructions -- the
+    // address unit takes a quad of lanes per cycle whatever the width, and the compiler kept only 16-18 of the 64 scalar loads of a
+    // batch in flight.  Same order of addition per element.
+    const bool v4 = (ne & 3) == 0 && (pstride & 3) == 0 && (((uintptr_t)dz) & 15) == 0;
+    if (v4) {
+        for (int e = 4 * tid; e < ne; e += 1024) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q0 = 0; q0 < parts; q0 += 16) {
+                float4 pv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pv[u] = *reinterpret_cast<const float4*>(dz + (long)(q0 + u < parts ? q0 + u : 0) * pstride + e);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (q0 + u < parts) { g.x += pv[u].x; g.y += pv[u].y; g.z += pv[u].z; g.w += pv[u].w; }
+            }
+            sg[e] = g.x; sg[e + 1] = g.y; sg[e + 2] = g.z; sg[e + 3] = g.w;
+        }
+    } else
     for (int e = tid; e < ne; e += 512) {
         const int e1 = e + 256 < ne ? e + 256 : e;
         float g0 = 0.f, g1 = 0.f;
@@ -142,24 +188,11 @@ __global__ __launch_bounds__(256) void enc_head_bwd_kernel(const float* __restri
     const int c = tid % HB_COLS, g4 = tid / HB_COLS;
     if (h0 + c >= H) return;
     for (int r = g4; r < B + nz2; r += 256 / HB_COLS) {
-        float s0 = 0.f, s1 = 0.f;
         if (r < B) {                                      // dh_T[r][h] = sum_j dmulv[r][j] W_lin[j][h]
-            int j = 0;
-            for (; j + 1 < nz2; j += 2) {
-                s0 = fmaf(sd[r * nz2 + j], sw[j * HB_COLS + c], s0);
-                s1 = fmaf(sd[r * nz2 + j + 1], sw[(j + 1) * HB_COLS + c], s1);
-            }
-            if (j < nz2) s0 = fmaf(sd[r * nz2 + j], sw[j * HB_COLS + c], s0);
-            dhT[(long)r * H + h0 + c] = s0 + s1;
+            dhT[(long)r * H + h0 + c] = dot2_batched(nz2, [&](int j) { return sd[r * nz2 + j]; }, [&](int j) { return sw[j * HB_COLS + c]; });
         } else {                                          // dW_lin[j][h] = sum_b dmulv[b][j] h_T[b][h]
             const int j = r - B;
-            int bb = 0;
-            for (; bb + 1 < B; bb += 2) {
-                s0 = fmaf(sd[bb * nz2 + j], shh[bb * HB_COLS + c], s0);
-                s1 = fmaf(sd[(bb + 1) * nz2 + j], shh[(bb + 1) * HB_COLS + c], s1);
-            }
-            if (bb < B) s0 = fmaf(sd[bb * nz2 + j], shh[bb * HB_COLS + c], s0);
-            gwlin[(long)j * H + h0 + c] = s0 + s1;
+            gwlin[(long)j * H + h0 + c] = dot2_batched(B, [&](int bb) { return sd[bb * nz2 + j]; }, [&](int bb) { return shh[bb * HB_COLS + c]; });
         }
     }
 }
@@ -181,14 +214,14 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
     float* swt = sz + B * nz;                             // [DI_ROWS][nz + 1]
     const int tid = (int)threadIdx.x;
     const int n0 = (int)blockIdx.x * DI_ROWS;
-    for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
-    for (int i = tid; i < DI_ROWS * nz; i += 256) {
-        const int rr = i / nz, k = i % nz, n = n0 + rr;
-        const int nc = n < 5 * H ? n : 5 * H - 1;          // unconditional load from a clamped row (see enc_head_bwd_kernel)
-        const float* src = nc < H ? wtr + (long)nc * nz + k : wih + (long)(nc - H) * ld_wih + col0 + k;
-        const float v = *src;
-        swt[rr * pw + k] = n < 5 * H ? v : 0.f;
-    }
+    stage_batched(B * nz, tid, [&](int i) { return z + i; }, [&](int i, float v) { sz[i] = v; });
+    stage_batched(DI_ROWS * nz, tid,
+                  [&](int i) {
+                      const int rr = i / nz, k = i % nz, n = n0 + rr;
+                      const int nc = n < 5 * H ? n : 5 * H - 1;          // rows beyond the stack read its last row (dropped below)
+                      return nc < H ? wtr + (long)nc * nz + k : wih + (long)(nc - H) * ld_wih + col0 + k;
+                  },
+                  [&](int i, float v) { const int rr = i / nz, k = i % nz; swt[rr * pw + k] = n0 + rr < 5 * H ? v : 0.f; });
     __syncthreads();
     const int rr = tid & 63, bq = tid >> 6;
     const int n = n0 + rr;
@@ -201,11 +234,7 @@ __global__ __launch_bounds__(256) void dec_init_kernel(const float* __restrict__
     const float* wr = swt + rr * pw;
     for (int b = bq; b < B; b += 4) {
         const float* zb = sz + b * nz;
-        float s0 = 0.f, s1 = 0.f;
-        int k = 0;
-        for (; k + 1 < nz; k += 2) { s0 = fmaf(zb[k], wr[k], s0); s1 = fmaf(zb[k + 1], wr[k + 1], s1); }
-        if (k < nz) s0 = fmaf(zb[k], wr[k], s0);
-        const float sv = s0 + s1;
+        const float sv = dot2_batched(nz, [&](int k) { return zb[k]; }, [&](int k) { return wr[k]; });
         if (init) { c0[(long)b * H + r] = sv; h0[(long)b * H + r] = tanhf(sv); }
         else zp[(long)b * 4 * H + ocol] = sv + bias;
     }
@@ -234,34 +263,28 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
     const int part = (int)blockIdx.x;
     const int row0 = part * DZ_ROWS;
     const int nrows = 5 * H - row0 < DZ_ROWS ? 5 * H - row0 : DZ_ROWS;
-    for (int i = tid; i < B * nz; i += 256) sz[i] = z[i];
-    for (int i = tid; i < B * DZ_ROWS; i += 256) {
-        const int b = i / DZ_ROWS, rr = i % DZ_ROWS;
-        const int row = rr < nrows ? row0 + rr : row0;     // unconditional loads from clamped rows (see enc_head_bwd_kernel)
-        const float* src = row < 4 * H ? dGsum + (long)b * 4 * H + row : dc0 + (long)b * H + (row - 4 * H);
-        const float v = *src;
-        sdv[b * pd + rr] = rr < nrows ? v : 0.f;
-    }
-    for (int i = tid; i < DZ_ROWS * nz; i += 256) {
-        const int rr = i / nz, k = i % nz;
-        const int row = rr < nrows ? row0 + rr : row0;
-        const float* src = row < 4 * H ? wih + (long)row * ld_wih + col0 + k : wtr + (long)(row - 4 * H) * nz + k;
-        const float v = *src;
-        swt[i] = rr < nrows ? v : 0.f;
-    }
+    stage_batched(B * nz, tid, [&](int i) { return z + i; }, [&](int i, float v) { sz[i] = v; });
+    stage_batched(B * DZ_ROWS, tid,
+                  [&](int i) {
+                      const int b = i / DZ_ROWS, rr = i % DZ_ROWS;
+                      const int row = rr < nrows ? row0 + rr : row0;     // rows beyond the slice read its first row (dropped below)
+                      return row < 4 * H ? dGsum + (long)b * 4 * H + row : dc0 + (long)b * H + (row - 4 * H);
+                  },
+                  [&](int i, float v) { const int b = i / DZ_ROWS, rr = i % DZ_ROWS; sdv[b * pd + rr] = rr < nrows ? v : 0.f; });
+    stage_batched(DZ_ROWS * nz, tid,
+                  [&](int i) {
+                      const int rr = i / nz, k = i % nz;
+                      const int row = rr < nrows ? row0 + rr : row0;
+                      return row < 4 * H ? wih + (long)row * ld_wih + col0 + k : wtr + (long)(row - 4 * H) * nz + k;
+                  },
+                  [&](int i, float v) { swt[i] = (i / nz) < nrows ? v : 0.f; });
     __syncthreads();
     // weight gradients: (row, k) pairs dealt to the threads with k fastest
     for (int i = tid; i < nrows * nz; i += 256) {
         const int rr = i / nz, k = i % nz, row = row0 + rr;
-        float s0 = 0.f, s1 = 0.f;
-        int b = 0;
-        for (; b + 1 < B; b += 2) {
-            s0 = fmaf(sdv[b * pd + rr], sz[b * nz + k], s0);
-            s1 = fmaf(sdv[(b + 1) * pd + rr], sz[(b + 1) * nz + k], s1);
-        }
-        if (b < B) s0 = fmaf(sdv[b * pd + rr], sz[b * nz + k], s0);
-        if (row < 4 * H) gwih[(long)row * ld_gwih + col0 + k] = s0 + s1;
-        else gwtr[(long)(row - 4 * H) * nz + k] = s0 + s1;
+        const float sv = dot2_batched(B, [&](int b) { return sdv[b * pd + rr]; }, [&](int b) { return sz[b * nz + k]; });
+        if (row < 4 * H) gwih[(long)row * ld_gwih + col0 + k] = sv;
+        else gwtr[(long)(row - 4 * H) * nz + k] = sv;
     }
     for (int rr = tid; rr < nrows; rr += 256) {           // bias gradients (gate rows only)
         const int row = row0 + rr;
@@ -274,14 +297,7 @@ __global__ __launch_bounds__(256) void dec_tail_bwd_kernel(const float* __restri
     // partial dz: (b, k) pairs dealt to the threads with k fastest
     for (int i = tid; i < B * nz; i += 256) {
         const int b = i / nz, k = i % nz;
-        float s0 = 0.f, s1 = 0.f;
-        int rr = 0;
-        for (; rr + 1 < nrows; rr += 2) {
-            s0 = fmaf(sdv[b * pd + rr], swt[rr * nz + k], s0);
-            s1 = fmaf(sdv[b * pd + rr + 1], swt[(rr + 1) * nz + k], s1);
-        }
-        if (rr < nrows) s0 = fmaf(sdv[b * pd + rr], swt[rr * nz + k], s0);
-        dzp[((long)part * B + b) * nz + k] = s0 + s1;
+        dzp[((long)part * B + b) * nz + k] = dot2_batched(nrows, [&](int rr) { return sdv[b * pd + rr]; }, [&](int rr) { return swt[rr * nz + k]; });
     }
 }
 
