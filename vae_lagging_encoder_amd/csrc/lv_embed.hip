@@ -302,13 +302,60 @@ __global__ __launch_bounds__(128) void embed_scatter_kernel(const float* __restr
         // 3 rows per workgroup at the Yahoo shape, and most of the launch's 26-32 us.  Replaces a separate fill of the whole
         // table (41 MB at V = 20001).
         __shared__ int absent_row[64];
+        __shared__ int s_cnt, s_win[128], s_pred[129];
         const int v0 = (int)((long)p * V / N), v1 = (int)((long)(p + 1) * V / N);
+        // Round 6: the first 64 rows of the slice (all of it whenever V <= 64 N) are looked up through a WINDOW of the sorted list
+        // that the whole workgroup fetches together -- the lower bound L of v0 by two counting steps (128 samples of the list, then
+        // the <= N / 128 + 1 positions between two samples: one round trip each), then positions [L, L + 128) into LDS (a third);
+        // a lane then searches its row in LDS.  A row the window does not reach (more than 128 occurrences inside the slice in front
+        // of it) falls back to the search of the whole list.  3 dependent round trips instead of 13.
+        int L = 0;
+        if (v0 < v1) {
+            // number of threads whose predicate holds, for a predicate that holds on a PREFIX of the threads
+            auto prefix_count = [&](bool pred) -> int {
+                s_pred[tid] = pred ? 1 : 0;
+                if (tid == 0) s_pred[128] = 0;
+                __syncthreads();
+                if (pred && !s_pred[tid + 1]) s_cnt = tid + 1;
+                if (tid == 0 && !pred) s_cnt = 0;
+                __syncthreads();
+                const int c = s_cnt;
+                __syncthreads();
+                return c;
+            };
+            // samples: s_i = the token at position ((i + 1) N) / 128 - 1 (no position for the leading i when N < 128: counted as below)
+            const int sp = (int)(((long)(tid + 1) * N) / 128) - 1;
+            const int sk = toks[sp >= 0 ? sp : 0];
+            const int last_below = prefix_count(sp < 0 || sk < v0) - 1;      // the last sample below v0 (-1: none)
+            // L lies behind that sample and not behind the next one (which is >= v0); the list is sorted: count what is below v0 there
+            const int lo2 = (int)(((long)(last_below + 1) * N) / 128);
+            const int hi2 = last_below + 1 < 128 ? (int)(((long)(last_below + 2) * N) / 128) : N;
+            L = lo2;
+            for (int c0 = lo2; c0 < hi2; c0 += 128) {
+                const int q = c0 + tid;
+                const int tk = toks[q < hi2 ? q : hi2 - 1];
+                const int c = prefix_count(q < hi2 && tk < v0);
+                L += c;
+                if (c < 128) break;
+            }
+            const int wq = L + tid;
+            s_win[tid] = wq < N ? toks[wq] : 0x7FFFFFFF;
+            __syncthreads();
+        }
         for (int vb = v0; vb < v1; vb += 64) {
             if (tid < 64) {
                 const int v = vb + tid;
-                int lo = 0, hi = N;                  // first position with toks[pos] >= v
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < v) lo = mid + 1; else hi = mid; }
-                absent_row[tid] = (v < v1 && !(lo < N && toks[lo] == v && v != pad_idx)) ? 1 : 0;
+                bool present;
+                if (vb == v0 && (s_win[127] >= v || L + 128 >= N)) {
+                    int lo = 0, hi = 128;            // first window slot with a token >= v
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_win[mid] < v) lo = mid + 1; else hi = mid; }
+                    present = lo < 128 && s_win[lo] == v;
+                } else {
+                    int lo = 0, hi = N;              // first position with toks[pos] >= v
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (toks[mid] < v) lo = mid + 1; else hi = mid; }
+                    present = lo < N && toks[lo] == v;
+                }
+                absent_row[tid] = (v < v1 && !(present && v != pad_idx)) ? 1 : 0;
             }
             __syncthreads();
             const int nrow = v1 - vb < 64 ? v1 - vb : 64;
