@@ -169,7 +169,7 @@ int lv_lstm_fwd_f32_ug(const float* gx, const float* whh, float* hs, float* cs, 
 /* The same recurrences as ONE persistent launch each (lv_lstm_persist16.hip; nn.LSTM of enc_lstm.py:55 / dec_lstm.py:104, forward
  * and BPTT): 256 workgroups in 8 XCD-sized groups (blockIdx % 8), each group carries a slice of the batch through all T steps with
  * its slice of W_hh held in registers and hands h_t (forward: all-gather) or partial dh sums (BPTT: reduce-scatter) around inside
- * the group through tagged 8-byte granules.  R rows per group (1 <= R <= 16, 8 R >= B), groups [0, ceil(B / R)) carry the batch and
+ * the group through tagged 16-byte granules (every dword under a tag of its own: no 16-byte atomicity assumed).  R rows per group (1 <= R <= 16, 8 R >= B), groups [0, ceil(B / R)) carry the batch and
  * the workgroups of the remaining groups return at once -- B = 32 runs 4 rows on each of the 8 groups, B = 128 sixteen (BASELINE.json
  * configs[4]), and R = 8 at B = 32 runs a recurrence on FOUR XCDs.  Contraction on the 16 x 16 x 32 MFMA with the weights as the A
  * operand.  gx unit-major as for lv_lstm_fwd_bf16_ug.  Weight images: lv_lstm_persist16_pack(whh, wpk, backward, H)

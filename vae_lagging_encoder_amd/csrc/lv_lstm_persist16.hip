@@ -6,7 +6,10 @@
 // rows).  Decomposition and hand-off: a group = the 32 workgroups with the same blockIdx % 8; a group owns a slice of the batch
 // and carries it through all T steps, groups never talk; W_hh stays register-resident for the whole call (a wave's 64 KB slice
 // in 256 AGPRs); per timestep the only exchange is h_t (forward, all-gather) or partial dh sums (BPTT, reduce-scatter) inside
-// the group, as tagged 8-byte granules gathered by polling; bulk I/O in blocks of timesteps; all spins bounded.  The contraction:
+// the group, as tagged granules gathered by polling; bulk I/O in blocks of timesteps; all spins bounded.  Since the end of round 6 a
+// granule is 16 bytes and every dword of it carries its own tag (LV_FWD_Q / LV_RS_Q below; the 8-byte granules with one tag per
+// granule remain as the A/B builds): the hand-off is bound by the NUMBER of load / store instructions, not by their bytes, and
+// 16-byte atomicity is assumed nowhere (the CI emulator tears the stores).  The contraction:
 //
 //   * v_mfma_f32_16x16x32_bf16 with the operands SWAPPED: the weights are the A operand (16 gate columns / output units as the
 //     tile's rows), the batch rows are the B operand's 16 columns.  The matrix-pipe time is the one the 4-row kernels already pay
@@ -14,10 +17,10 @@
 //     lane holds FOUR CONSECUTIVE gate columns of ONE batch row -- in the forward's unit-major column order exactly the
 //     (i, f, g, o) of one unit, so the K-split partial products cross the workgroup as float4 records, and in the BPTT four
 //     consecutive hidden units of one row, i.e. two ready-made partial-sum granules.
-//   * forward (K-split): wave w gathers K-quarter w of h_{t-1} (rows x 128 granules), 8 fragment
+//   * forward (K-split): wave w gathers K-quarter w of h_{t-1} (rows x 64 granules of four units), 8 fragment
 //     reads + 64 MFMAs, 8 float4 LDS writes, ONE barrier, every (row, unit) thread adds the four quarters and runs the cell.
-//   * BPTT (reduce-scatter): a workgroup receives 32 senders x rows x 16 granules of partial dh
-//     for its 32 units, sums them in registers + two shuffles, runs the gate-gradient math, publishes its dG image through LDS
+//   * BPTT (reduce-scatter): a workgroup receives 32 senders x rows x 8 granules (four partial sums each) of partial dh
+//     for its 32 units, sums them in registers + a transposing DPP / lane-swap butterfly, runs the gate-gradient math, publishes its dG image through LDS
 //     (ONE barrier), multiplies it with its 128 gate rows of W_hh (4 fragment reads + 64 MFMAs) and sends the partial sums.
 //   rows per group R <= 16; instantiated for RP = 4 / 8 / 16 (polls per lane, pairs per thread and the I/O block length follow).
 //   * the activations the forward saves for the BPTT (gates i, f, g, o and the cell state) live in a WORKGROUP-MAJOR buffer:
