@@ -26,6 +26,7 @@ static inline unsigned long long lv_agent_load_u64(const unsigned long long* p) 
 }
 static inline void lv_agent_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 static inline void lv_xcd_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+static inline void lv_poll_backoff() { }
 #define LV_WAIT_LDS() lv_emu::wave_sync()      // lanes are fibers here: 'the wave's own LDS writes are visible' needs a rendezvous
 template <class T> static inline void lv_store_nt(T v, T* p) { *p = v; }
 static inline int lv_device_cus() { return 1 << 20; }
@@ -535,6 +536,10 @@ __device__ __forceinline__ void lv_agent_store_q4(void* p, uint4 v) {
     const lv_u32x4v d = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
+#ifndef LV_POLL_SLEEP
+#define LV_POLL_SLEEP 0                     // measurement knob: s_sleep units (64 cycles) after a FAILED poll of a hand-off, before the next one
+#endif
+__device__ __forceinline__ void lv_poll_backoff() { if (LV_POLL_SLEEP > 0) __builtin_amdgcn_s_sleep(LV_POLL_SLEEP); }
 #ifndef LV_XCD_ST_MODS
 #define LV_XCD_ST_MODS ""                   // measurement knob: cache-policy bits of the XCD-local granule store (" nt", " sc0", ...)
 #endif

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
                         ok = (LV_P16_ABL & 2) ? true : (x >> 16) == 0u;
                         ok = __all(ok);
                         if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; break; }
+                        if (!ok) lv_poll_backoff();
                     } while (!ok);
                     LV_TRACE_VAL(t, 6, spins);
 #pragma unroll
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
             ok = (LV_P16_ABL & 2) ? true : rs4_all_tagged(u, want);
             ok = __all(ok);
             if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+            if (!ok) lv_poll_backoff();
         } while (!ok);
         LV_TRACE_ONLY(tr_spins[0] = spins;)
         float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
@@ -661,6 +663,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_rs16_kernel(Bwd16P p) {
                 ok = (LV_P16_ABL & 2) ? true : rs4_all_tagged(u, want);
                 ok = __all(ok);
                 if (!ok && ++spins > SPIN_LIMIT) { s_abort = 1; return false; }
+                if (!ok) lv_poll_backoff();
             } while (!ok);
             LV_TRACE_ONLY(tr_spins[q ? 1 : 0] = spins;)
             float a[2], b[2], c[2], d[2];
