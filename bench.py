@@ -273,8 +273,8 @@ def text_rooflines(prof, steps, workload, dtype, B, T, H, peak_mfma):
         "us_per_timestep": round(1e3 * lstm_ms / max(1, steps_total), 3),
         "algorithmic_bytes_per_launch": round(lstm_bytes / max(1, lstm_launches)),
         "per_recurrence": per_kind,
-        "note": "latency-bound chain of dependent timesteps: a persistent launch costs 12 us (forward) / 16 us (BPTT) fixed + 1.70 / "
-                "1.60 us per timestep at 4 rows per XCD group (profiles/microbench/lstm_fixed_cost_probe.py; per timestep one L2 round "
+        "note": "latency-bound chain of dependent timesteps: a persistent launch costs 12 us (forward) / 16 us (BPTT) fixed + 1.64 / "
+                "1.61 us per timestep at 4 rows per XCD group (profiles/microbench/lstm_fixed_cost_probe.py; per timestep one L2 round "
                 "trip for the hand-off -- 16-byte granules, every dword under its own tag --, 64 MFMAs with their fragments, the cell "
                 "update and the publishing stores): us_per_timestep is the "
                 "actionable number, the HBM fraction is what a perfectly overlapped version would be bound by"}
