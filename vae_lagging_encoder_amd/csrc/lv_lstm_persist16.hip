@@ -455,6 +455,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_k16_kernel(Fwd16P p) {
 // h2 = w & 1) in batches of 16 (batch beta: rows 4 beta + (p >> 2), rq = p & 3 for lane position p = l & 15): lane group l >> 4 =
 // eight of the 32 senders, two shuffles add the four groups.  Owners: lanes 0..31 take batch 2q, lanes 32..63 batch 2q + 1
 // (q = pair index), low / high half of the granule by (l >> 4) & 1.
+// (That is the 8-BYTE granule form, LV_RS_Q = 0, kept for A/B builds.  The shipped form moves the same bytes of the same dense
+//  per-pair extent as 16-byte granules of four units each -- layout, lane maps and the transposing sum: the QB comments in the kernel.)
 struct Bwd16P {
     const float* dh_ext; const float* dh_last;
     const uint4* wpk;
